@@ -1,0 +1,399 @@
+#!/usr/bin/env python3
+"""
+Generate tests/golden/*.npz by running the REFERENCE python hot path on CPU.
+
+Run in the build container only (needs /root/reference; the GPU box never runs this):
+    python tests/golden/make_golden.py
+
+How the reference is driven (nothing from it is copied into the repo):
+  * /root/reference/src is put on sys.path and its own modules are imported:
+    variations.render_helpers (bundle_adjust_frames, track_frame, render_rays, get_features),
+    variations.voxel_helpers (ray_intersect, ray_sample and the two autograd Functions),
+    variations.lidar.Decoder, criterion.Criterion, se3pose.OptimizablePose, lidarFrame.LidarFrame.
+  * its sources hard-code `.cuda()`: torch.Tensor.cuda / nn.Module.cuda are patched to identity and
+    torch.cuda.empty_cache / synchronize to no-ops for the duration of this script.
+  * its `grid` CUDA extension has no CPU path; a module named `grid` is injected whose
+    svo_intersect / inverse_cdf_sampling run oracle/nl_oracle.c (the C restatement of the two
+    kernels) with the exact tensor layouts the reference wrappers pass.
+  * its `svo` octree is the reference C++ itself (oracle/_ref/svo_ref.so, oracle/build_ref.sh).
+  * mapping.py cannot be imported (open3d + a hard-coded load_library path), so the few tensors it
+    derives (centres, structure, id table, bf16 embedding table; mapping.py:293-339) are rebuilt
+    here from the reference octree's outputs.
+  * randomness is injected: LidarFrame.sample_rays is replaced by a recorded boolean mask, and the
+    sampler noise (`Tensor.uniform_` inside InverseCDFRaySampling.forward) is replaced by the
+    counter-based noise of oracle.hash_noise keyed by the ORIGINAL ray index, so the oracle and the
+    HIP path can regenerate it.
+"""
+import os
+import sys
+import types
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("NL_REFERENCE_ROOT", "/root/reference")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(REF, "src"))
+
+from oracle import oracle as O                      # noqa: E402
+from nerf_loam_amd import synthetic as S           # noqa: E402
+
+torch.manual_seed(777)
+np.random.seed(777)
+
+# ------------------------------------------------------------------ patches
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.nn.Module.cuda = lambda self, *a, **k: self
+torch.cuda.empty_cache = lambda: None
+torch.cuda.synchronize = lambda *a, **k: None
+
+# ------------------------------------------------------------------ injected `grid`
+grid = types.ModuleType("grid")
+
+
+def _np(t, dt):
+    return np.ascontiguousarray(t.detach().numpy(), dtype=dt)
+
+
+def svo_intersect(ray_start, ray_dir, points, children, voxelsize, n_max):
+    B, m = ray_start.shape[:2]
+    idx = torch.zeros(B, m, n_max, dtype=torch.int32)
+    t0 = torch.zeros(B, m, n_max)
+    t1 = torch.zeros(B, m, n_max)
+    for b in range(B):
+        i, a, c = O.svo_intersect(_np(ray_start[b], np.float32), _np(ray_dir[b], np.float32),
+                                  _np(points[b], np.float32), _np(children[b], np.int32), voxelsize, n_max)
+        idx[b], t0[b], t1[b] = torch.from_numpy(i), torch.from_numpy(a), torch.from_numpy(c)
+    return idx, t0, t1
+
+
+def inverse_cdf_sampling(pts_idx, min_depth, max_depth, noise, probs, steps, fixed_step_size):
+    G, m, P = pts_idx.shape
+    T = noise.shape[-1]
+    o_idx = -np.ones((G, m, T), np.int32)
+    o_dep = np.zeros((G, m, T), np.float32)
+    o_dst = np.zeros((G, m, T), np.float32)
+    a = [_np(pts_idx, np.int32), _np(min_depth, np.float32), _np(max_depth, np.float32),
+         _np(noise, np.float32), _np(probs, np.float32), _np(steps, np.float32)]
+    O.lib().orc_inverse_cdf_sampling(G, m, P, T, float(fixed_step_size), *[O._p(x) for x in a],
+                                     O._p(o_idx), O._p(o_dep), O._p(o_dst))
+    return torch.from_numpy(o_idx), torch.from_numpy(o_dep), torch.from_numpy(o_dst)
+
+
+grid.svo_intersect = svo_intersect
+grid.inverse_cdf_sampling = inverse_cdf_sampling
+sys.modules["grid"] = grid
+
+import variations.render_helpers as RH              # noqa: E402
+import variations.voxel_helpers as VH               # noqa: E402
+from variations.lidar import Decoder                # noqa: E402
+from criterion import Criterion                     # noqa: E402
+from se3pose import OptimizablePose                 # noqa: E402
+from lidarFrame import LidarFrame                   # noqa: E402
+
+torch.classes.load_library(os.path.join(ROOT, "oracle", "_ref", "svo_ref.so"))
+
+ARGS = Namespace(criteria=dict(sdf_weight=10000.0, fs_weight=1, eiko_weight=0.1, sdf_truncation=0.30),
+                 data_specs=dict(max_depth=50.0, min_depth=1.5))
+VOXEL = 0.2
+
+# ------------------------------------------------------------------ noise injection
+_NOISE = dict(seed=777, ray_ids=None)
+_orig_uniform = torch.Tensor.uniform_
+
+
+def _uniform_patch(self, *a, **k):
+    """Fill the sampler's [200, L, max_steps] noise tensor from hash_noise(seed, ORIGINAL ray id,
+    step); padded rows (copies of ray 0, voxel_helpers.py:278-284) get ray 0's id."""
+    if _NOISE["ray_ids"] is None or self.dim() != 3:
+        return _orig_uniform(self, *a, **k)
+    G, L, T = self.shape
+    ids = _NOISE["ray_ids"]
+    pad = np.concatenate([ids, np.full(G * L - len(ids), ids[0], ids.dtype)])
+    self.copy_(torch.from_numpy(O.hash_noise(_NOISE["seed"], pad, T)).reshape(G, L, T))
+    return self
+
+
+torch.Tensor.uniform_ = _uniform_patch
+
+_orig_ray_sample = VH.ray_sample
+
+
+def _ray_sample_hook(intersection_outputs, step_size=0.01, fixed=False):
+    return _orig_ray_sample(intersection_outputs, step_size=step_size, fixed=fixed)
+
+
+# the reference's render_rays keeps only hit rays before calling ray_sample; record which
+_orig_ray_intersect = VH.ray_intersect
+_CAP = {}
+
+
+def _ray_intersect_hook(*a, **k):
+    inter, hits = _orig_ray_intersect(*a, **k)
+    _NOISE["ray_ids"] = np.nonzero(hits.view(-1).numpy())[0].astype(np.uint32)
+    _CAP.setdefault("intersections", []).append(
+        {kk: vv.clone().numpy() for kk, vv in inter.items()} | {"hits": hits.clone().numpy()})
+    return inter, hits
+
+
+RH.ray_intersect = _ray_intersect_hook
+
+_orig_render = RH.render_rays
+
+
+def _render_hook(*a, **k):
+    out = _orig_render(*a, **k)
+    if isinstance(out, dict):
+        _CAP.setdefault("render", []).append({kk: vv.detach().clone().numpy() for kk, vv in out.items()})
+    return out
+
+
+RH.render_rays = _render_hook
+
+
+class CapCriterion(Criterion):
+    def forward(self, *a, **k):
+        loss, d = super().forward(*a, **k)
+        _CAP.setdefault("loss", []).append(dict(d))
+        return loss, d
+
+
+# ------------------------------------------------------------------ scene construction
+def scene_points(n_beams, n_azimuth, seed):
+    """dense narrow sector of the synthetic scan (same angular density as the 64x2048 scan)"""
+    return S.synthetic_scan(n_beams, n_azimuth, seed, range_noise=0.01, sector=(0.1, 0.1 + n_azimuth / 2048.0))
+
+
+def build_scene(n_beams, n_azimuth, seed):
+    pts, cos = scene_points(n_beams, n_azimuth, seed)
+    pose6 = S.scan_pose()
+    R = O.rodrigues(pose6[3:])
+    vox = S.voxel_coords(pts, R, pose6[:3], VOXEL)
+    svo = torch.classes.svo.Octree()
+    svo.init(256 * 256 * 4, 16, VOXEL)
+    svo.insert(torch.from_numpy(vox))
+    voxels, children, features = svo.get_centres_and_children()
+    centres = ((voxels[:, :3] + voxels[:, -1:] / 2) * VOXEL).float()
+    structure = torch.cat([children, voxels[:, -1:]], -1).int()
+    n = voxels.shape[0]
+    id_table = -torch.ones((n, 1), dtype=torch.int)
+    flat = features.reshape(-1).long()
+    flat = flat[flat.ne(-1)]
+    add = flat[id_table[flat, 0].eq(-1)]
+    id_table[add] = torch.arange(0, add.shape[0], dtype=torch.int).view(-1, 1)
+    E = add.shape[0]
+    emb = torch.from_numpy(init_embeddings(E, seed)).to(torch.bfloat16)
+    return dict(points=pts, cos=cos, vox=vox, centres=centres, structure=structure, features=features,
+                id_table=id_table, emb=emb, voxels=voxels.numpy(), children=children.numpy())
+
+
+def init_embeddings(E, seed):
+    """N(0, 0.01^2) init (the reference's commented-out init, mapping.py:307) from a numpy stream so
+    the fixtures need not store it."""
+    return np.random.default_rng(seed + 1000).normal(0, 0.01, (E, 16)).astype(np.float32)
+
+
+def make_decoder(seed):
+    """Reference Decoder module (variations/lidar.py:80-131) loaded with numpy-seeded nn.Linear-style
+    init (oracle.decoder_init), so fixtures need not store the initial weights."""
+    dec = Decoder(depth=2, width=256, in_dim=16, skips=[], embedder="none", multires=0)
+    d0 = O.decoder_init(seed)
+    sd = {"pts_linears.0.weight": d0.W1, "pts_linears.0.bias": d0.b1, "pts_linears.1.weight": d0.W2,
+          "pts_linears.1.bias": d0.b2, "sdf_out.weight": d0.W3, "sdf_out.bias": d0.b3}
+    dec.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    return dec
+
+
+def sparse_rows(bits, ref_bits=None):
+    """rows that differ from ref_bits (or are non-zero) and their values"""
+    diff = (bits != (ref_bits if ref_bits is not None else 0)).any(1)
+    rows = np.nonzero(diff)[0].astype(np.int32)
+    return rows, bits[rows]
+
+
+def make_frame(index, pts, cos, pose4):
+    fr = LidarFrame(index, torch.from_numpy(pts), torch.from_numpy(cos), pose4.copy())
+    return fr
+
+
+def pose4(tx=0.0, ty=0.0, tz=0.0, rot=(0.0, 0.0, 0.0)):
+    M = np.eye(4)
+    M[:3, :3] = O.rodrigues(np.array(rot, np.float32)).astype(np.float64)
+    M[:3, 3] = [tx, ty, tz]
+    return M
+
+
+def decoder_arrays(dec):
+    sd = dec.state_dict()
+    return dict(W1=sd["pts_linears.0.weight"].numpy().copy(), b1=sd["pts_linears.0.bias"].numpy().copy(),
+                W2=sd["pts_linears.1.weight"].numpy().copy(), b2=sd["pts_linears.1.bias"].numpy().copy(),
+                W3=sd["sdf_out.weight"].numpy().copy(), b3=sd["sdf_out.bias"].numpy().copy())
+
+
+def run_mapping_case(name, n_frames, n_rays, n_iter, seed, update_pose=True, update_decoder=True,
+                     n_beams=64, n_azimuth=48):
+    _CAP.clear()
+    sc = build_scene(n_beams, n_azimuth, seed)
+    rng = np.random.default_rng(seed)
+    frames, masks, poses0 = [], [], []
+    for i in range(n_frames):
+        P4 = pose4(0.4 * i, 0.1 * i, 0.0, rot=(0.004 * (i + 1), -0.003, 0.01 * (i + 1)))
+        fr = make_frame(i + 1, sc["points"], sc["cos"], P4)       # index != 0 -> pose is optimised
+        frames.append(fr)
+        poses0.append(fr.pose.data.detach().numpy().copy())
+        masks.append([])
+    it_counter = {"k": 0}
+
+    def sample_rays(self, N_rays, track=False):
+        fi = frames.index(self)
+        sel = rng.choice(self.num_point, N_rays, replace=False)
+        m = np.zeros((self.num_point, 1), bool)
+        m[sel] = True
+        masks[fi].append(m[:, 0].copy())
+        self.sample_mask = torch.from_numpy(m)
+
+    LidarFrame.sample_rays = sample_rays
+    dec = make_decoder(seed)
+    emb = sc["emb"].clone().requires_grad_()
+    map_states = {"voxel_vertex_idx": sc["features"], "voxel_center_xyz": sc["centres"].requires_grad_(),
+                  "voxel_structure": sc["structure"], "voxel_vertex_emb": emb,
+                  "voxel_id2embedding_id": sc["id_table"]}
+    crit = CapCriterion(ARGS)
+    RH.bundle_adjust_frames(frames, emb, map_states, dec, crit, VOXEL, 0.5 * VOXEL, n_rays, n_iter, 0.30, 20, 50.0,
+                            learning_rate=[0.03, 0.005, 0.001], update_pose=update_pose,
+                            update_decoder=update_decoder)
+    emb0_bits = O.bf16_bits(sc["emb"].float().numpy())
+    ef_rows, ef_vals = sparse_rows(O.bf16_bits(emb.detach().float().numpy()), emb0_bits)
+    eg_rows, eg_vals = sparse_rows(O.bf16_bits(emb.grad.float().numpy()))
+    out = dict(
+        seed=seed, n_beams=n_beams, n_azimuth=n_azimuth,
+        id_table=sc["id_table"].numpy()[:, 0], n_emb_rows=emb0_bits.shape[0],
+        poses0=np.stack(poses0), masks=np.packbits(np.stack([np.stack(m) for m in masks]), axis=-1),
+        emb_final_rows=ef_rows, emb_final_vals=ef_vals, emb_grad_rows=eg_rows, emb_grad_vals=eg_vals,
+        poses_final=np.stack([f.pose.data.detach().numpy() for f in frames]),
+        pose_grad_last=np.stack([f.pose.data.grad.numpy() if f.pose.data.grad is not None else np.zeros(6, np.float32)
+                                 for f in frames]),
+        n_iter=n_iter, n_rays=n_rays, update_pose=update_pose, update_decoder=update_decoder,
+        step_size=0.5 * VOXEL, lrs=np.array([0.03, 0.005, 0.001]),
+    )
+    if update_decoder:
+        for k, v in decoder_arrays(dec).items():
+            out["decF_" + k] = v
+    gd = {n: p.grad for n, p in dec.named_parameters()}
+    if update_decoder:
+        out["decG_W1"], out["decG_b1"] = gd["pts_linears.0.weight"].numpy(), gd["pts_linears.0.bias"].numpy()
+        out["decG_W2"], out["decG_b2"] = gd["pts_linears.1.weight"].numpy(), gd["pts_linears.1.bias"].numpy()
+        out["decG_W3"], out["decG_b3"] = gd["sdf_out.weight"].numpy(), gd["sdf_out.bias"].numpy()
+    for it, r in enumerate(_CAP["render"]):
+        out[f"it{it}_sdf"] = r["sdf"]
+        out[f"it{it}_z_vals"] = r["z_vals"]
+        out[f"it{it}_valid"] = r["valid_mask"]
+        out[f"it{it}_ray_mask"] = r["ray_mask"]
+        out[f"it{it}_loss"] = np.float32(_CAP["loss"][it]["loss"])
+        out[f"it{it}_fs_loss"] = np.float32(_CAP["loss"][it]["fs_loss"])
+        out[f"it{it}_sdf_loss"] = np.float32(_CAP["loss"][it]["sdf_loss"])
+    i0 = _CAP["intersections"][0]
+    out["it0_hit_idx"], out["it0_hit_t0"], out["it0_hit_t1"] = i0["intersected_voxel_idx"], i0["min_depth"], i0["max_depth"]
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: iters={len(_CAP['render'])} loss0={out['it0_loss']:.6f} "
+          f"R={out['it0_sdf'].shape} -> {os.path.getsize(path)/1e3:.0f} kB")
+
+
+def run_tracking_case(name, n_rays, n_iter, seed, frame_index=5, n_beams=64, n_azimuth=48):
+    _CAP.clear()
+    sc = build_scene(n_beams, n_azimuth, seed)
+    rng = np.random.default_rng(seed)
+    P4 = pose4(0.05, -0.03, 0.01, rot=(0.002, -0.004, 0.006))
+    fr = make_frame(frame_index, sc["points"], sc["cos"], P4)
+    masks = []
+
+    def sample_rays(self, N_rays, track=False):
+        sel = rng.choice(self.num_point, N_rays, replace=False)
+        m = np.zeros((self.num_point, 1), bool)
+        m[sel] = True
+        masks.append(m[:, 0].copy())
+        self.sample_mask = torch.from_numpy(m)
+
+    LidarFrame.sample_rays = sample_rays
+    dec = make_decoder(seed)
+    map_states = {"voxel_vertex_idx": sc["features"], "voxel_center_xyz": sc["centres"].requires_grad_(),
+                  "voxel_structure": sc["structure"], "voxel_vertex_emb": sc["emb"].clone(),
+                  "voxel_id2embedding_id": sc["id_table"]}
+    pose0 = fr.pose.data.detach().numpy().copy()
+    crit = CapCriterion(ARGS)
+    new_pose, hit_mask = RH.track_frame(fr.pose, fr, map_states, dec, crit, VOXEL, n_rays, 0.2 * VOXEL, n_iter, 0.30,
+                                        0.005, 20, 50.0, profiler=None, depth_variance=True)
+    out = dict(seed=seed, n_beams=n_beams, n_azimuth=n_azimuth, id_table=sc["id_table"].numpy()[:, 0],
+               n_emb_rows=sc["emb"].shape[0], pose0=pose0, masks=np.packbits(np.stack(masks), axis=-1),
+               pose_final=new_pose.data.detach().numpy(), pose_grad_last=new_pose.data.grad.numpy(),
+               hit_mask=hit_mask.numpy(), n_iter=n_iter, n_rays=n_rays, step_size=0.2 * VOXEL,
+               lr=0.005 * 2 if frame_index < 2 else 0.005 / 3, frame_index=frame_index)
+    for it, r in enumerate(_CAP["render"]):
+        out[f"it{it}_sdf"] = r["sdf"]
+        out[f"it{it}_z_vals"] = r["z_vals"]
+        out[f"it{it}_valid"] = r["valid_mask"]
+        out[f"it{it}_loss"] = np.float32(_CAP["loss"][it]["loss"])
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: iters={len(_CAP['render'])} loss0={out['it0_loss']:.6f} -> {os.path.getsize(path)/1e3:.0f} kB")
+
+
+def run_se3_case():
+    """OptimizablePose rotation + autograd gradient for a handful of w (incl. w = 0)."""
+    ws = np.array([[0, 0, 0], [0.01, -0.02, 0.03], [0.3, 0.1, -0.2], [1e-4, 0, 0], [-1.2, 0.7, 0.4]], np.float32)
+    rng = np.random.default_rng(5)
+    Gs = rng.normal(size=(len(ws), 3, 3)).astype(np.float32)
+    Rs, gws = [], []
+    for w, G in zip(ws, Gs):
+        p = OptimizablePose(torch.cat([torch.zeros(3), torch.from_numpy(w)]))
+        R = p.rotation()
+        (R * torch.from_numpy(G)).sum().backward()
+        Rs.append(R.detach().numpy())
+        gws.append(p.data.grad.numpy()[3:].copy())
+    np.savez_compressed(os.path.join(HERE, "se3.npz"), w=ws, G=Gs, R=np.stack(Rs), gw=np.stack(gws))
+    print("se3: ok")
+
+
+def run_adam_case():
+    """torch.optim.Adam on a bf16 and an fp32 parameter, 5 steps, sparse-ish gradients."""
+    rng = np.random.default_rng(11)
+    p0 = (rng.normal(0, 0.01, (64, 16))).astype(np.float32)
+    gs = (rng.normal(0, 1e-3, (5, 64, 16)) * (rng.random((5, 64, 16)) < 0.6)).astype(np.float32)
+    out = dict(p0=p0, gs=gs)
+    for tag, dt in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+        p = torch.from_numpy(p0.copy()).to(dt).requires_grad_()
+        opt = torch.optim.Adam([p], lr=0.03)
+        hist = []
+        for g in gs:
+            opt.zero_grad()
+            p.grad = torch.from_numpy(g).to(dt)
+            opt.step()
+            hist.append(p.detach().float().numpy().copy())
+        out["p_" + tag] = np.stack(hist)
+    np.savez_compressed(os.path.join(HERE, "adam.npz"), **out)
+    print("adam: ok")
+
+
+CASES = {
+    "se3": lambda: run_se3_case(),
+    "adam": lambda: run_adam_case(),
+    "map_1f_1it": lambda: run_mapping_case("map_1f_1it", n_frames=1, n_rays=512, n_iter=1, seed=777),
+    "map_1f_3it": lambda: run_mapping_case("map_1f_3it", n_frames=1, n_rays=512, n_iter=3, seed=778),
+    "map_2f_2it_frozen": lambda: run_mapping_case("map_2f_2it_frozen", n_frames=2, n_rays=384, n_iter=2, seed=779,
+                                                  update_pose=False, update_decoder=False),
+    "track_2it": lambda: run_tracking_case("track_2it", n_rays=512, n_iter=2, seed=780),
+}
+
+if __name__ == "__main__":
+    # one process per case: the reference octree keeps a process-global node counter
+    # (third_party/sparse_octree/include/octree.h:19), so a second Octree in one process is corrupt.
+    if len(sys.argv) > 1:
+        CASES[sys.argv[1]]()
+    else:
+        import subprocess
+        for c in CASES:
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), c])
