@@ -1,0 +1,146 @@
+/*
+ * nerfloam_hip.h -- C ABI of libnerfloam_hip.so: the MI355X (gfx950) implementation of NeRF-LOAM's
+ * per-iteration neural-SDF path.  Plain pointers and sizes only (no torch types); every device
+ * pointer is a HIP device pointer, `stream` is a hipStream_t passed as void*.  All entry points
+ * return 0 (NL_OK) or an NL_ERR_* code; nothing calls exit() (the reference's CUDA_CHECK_ERRORS
+ * does, third_party/sparse_voxels/include/cuda_utils.h:37-48).  The library allocates nothing on
+ * the hot path: workspaces are caller-owned, sizes are data-independent (worst case), data-dependent
+ * counts live in a device counter block, so a whole iteration is launchable without host syncs.
+ *
+ * Each declaration cites the reference interface it replaces (paths under the reference repo).
+ * Reference-side bindings: see INTEGRATION.md.
+ */
+#ifndef NERFLOAM_HIP_H
+#define NERFLOAM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NL_OK 0
+#define NL_ERR_INVALID_ARG 1
+#define NL_ERR_LAUNCH 2
+#define NL_ERR_NO_DEVICE 3
+#define NL_ERR_CAPACITY 4
+
+/* layout constants shared with the host side */
+#define NL_MAX_HITS 20          /* src/variations/voxel_helpers.py:533 */
+#define NL_CNT_INTS 16          /* int32 counters ... */
+#define NL_CNT_DOUBLES 4        /* ... followed by double sums: counter block = 16*4 + 4*8 bytes */
+#define NL_LOSS_SCALARS_BYTES 48
+#define NL_DEC_PARAMS 70401     /* W1[256x16] b1[256] W2[256x256] b2[256] W3[256] b3[1] */
+#define NL_EMB_CHANNELS 16
+
+int nl_version(void);
+int nl_device_count(void);              /* number of HIP devices visible (0 => product cannot run) */
+int nl_decoder_grid_hint(void);         /* persistent-kernel grid = compute units of the current device */
+
+/* ---- (b1) drop-in operators of the reference's `grid` pybind module ----------------------------
+ * third_party/sparse_voxels/src/binding.cpp:10-21, include/intersect.h:14-15, include/sample.h:12-14 */
+
+/* grid.svo_intersect(ray_start[B,m,3], ray_dir[B,m,3], points[B,n,3], children[B,n,9], voxelsize, n_max)
+ *   -> idx i32[B,m,n_max] (-1 padded), min_depth/max_depth f32[B,m,n_max] (0 where unused)
+ * third_party/sparse_voxels/src/intersect.cpp:83-112, intersect_gpu.cu:193-272.  n_max <= 20. */
+int nl_svo_intersect(const float* ray_start, const float* ray_dir, const float* points, const int* children,
+                     int b, int m, int n, float voxelsize, int n_max,
+                     int* idx, float* min_depth, float* max_depth, void* stream);
+
+/* grid.inverse_cdf_sampling(pts_idx[G,m,P], min_depth, max_depth, uniform_noise[G,m,T], probs, steps[G,m], fixed_step)
+ *   -> sampled_idx i32[G,m,T], sampled_depth, sampled_dists f32[G,m,T]; outputs must be pre-filled (-1, 0, 0)
+ * third_party/sparse_voxels/src/sample.cpp:56-95, sample_gpu.cu:133-239 (tail loop kept bug-for-bug). */
+int nl_inverse_cdf_sampling(const int* pts_idx, const float* min_depth, const float* max_depth, const float* noise,
+                            const float* probs, const float* steps, int b, int num_rays, int max_hits, int max_steps,
+                            float fixed_step_size, int* sampled_idx, float* sampled_depth, float* sampled_dists, void* stream);
+
+/* ---- fused iteration stages (replace src/variations/render_helpers.py:190-318 render_rays and the
+ *      autograd/optimiser part of :356-423 / :452-512) ------------------------------------------- */
+
+/* ray set-up + ray_intersect: render_helpers.py:366-388 (d_world = d_sensor R^T, o = t),
+ * voxel_helpers.py:531-567 (DFS intersect, -1 -> max_distance, sort by t_min, cull).
+ * poses[F,12] = rotation row-major | translation.  frame_id may be NULL (single frame).
+ * Outputs: rays_d_world[N,3], gt_dist[N] = ||p||*cos, hit_idx/t0/t1[N,20], hit_count[N];
+ * counters[NLC_HMAX] is raised (atomic max).  counters must be zeroed per iteration. */
+int nl_ray_intersect(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
+                     const float* poses, const float* centres, const int* structure, float voxel_size, float max_distance,
+                     float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
+                     int* counters, void* stream);
+
+/* exclusive scan of in[0..n) (flag_mode: of (in[i] > 0)); total -> *total_out (device).
+ * workspace >= ceil(n/1024) ints.  Replaces the boolean-mask compactions of render_helpers.py:219-257. */
+int nl_exclusive_scan_i32(const int* in, int* out, int n, int flag_mode, int* total_out, int* workspace, void* stream);
+int nl_compact_hit_rays(int N, const int* hit_count, const int* hit_rank, int* ray_of_rank, void* stream);
+
+/* ray_sample: voxel_helpers.py:571-598 + :262-347 + sample_gpu.cu:133-239.
+ * emit = 0: per-ray sample count, S_max and the geometry-only loss normalisers (criterion.py:67-88);
+ * emit = 1: compacted (voxel, depth, dist, ray) records at samp_off[ray] (capacity-checked).
+ * noise: counter-based hash(seed, ray_id_base + ray, step) clamped to [.001,.999], or 0.5 if !use_hash_noise
+ * (the reference draws torch uniform_ noise, voxel_helpers.py:297-301). */
+int nl_sample_rays(int emit, int N, const int* hit_idx, const float* hit_t0, const float* hit_t1, const int* hit_count,
+                   const int* hit_rank, const int* ray_of_rank, const float* cos_gt, const float* gt_dist,
+                   float step_size, float tau, float max_depth, unsigned seed, int use_hash_noise, int tail_always, int ray_id_base,
+                   int* counters, int* samp_count, const int* samp_off, int capacity,
+                   int* s_vox, float* s_depth, float* s_dist, int* s_ray, void* stream);
+
+/* global loss normalisers from the counter block (criterion.py:84-88 weights, :65 mean divisor R*S) */
+int nl_loss_finalize(int* counters, void* loss_scalars, float fs_weight, float sdf_weight, float tau, float max_depth,
+                     int capacity, void* stream);
+
+/* get_features: render_helpers.py:74-93 + :39-70 (gather + trilinear interpolation) -> X[P,16] */
+int nl_gather_trilinear(const void* loss_scalars, const int* s_vox, const float* s_depth, const int* s_ray,
+                        const float* rays_d_world, const int* frame_id, const float* poses, int n_frames,
+                        const float* centres, const int* vertex_rows, const void* emb_bf16, float voxel_size,
+                        float* X, int nblocks, void* stream);
+
+/* Decoder forward (src/variations/lidar.py:109-131) + Criterion gradient (src/criterion.py:59-100) +
+ * decoder backward (autograd of render_helpers.py:422).  params = decoder block, W2T = transposed W2.
+ * Outputs sdf[P], dsdf[P], dX[P,16]; with train_decoder: per-workgroup weight-gradient slabs
+ * partials[nslabs][NL_DEC_PARAMS] (sum them with nl_reduce_partials) and relu2_mask[P][8] scratch. */
+int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* params, const float* W2T,
+                       const int* s_ray, const float* s_depth, const float* cos_gt, const float* gt_dist,
+                       float* sdf, float* dsdf, float* dX, float* partials, unsigned* relu2_mask, int nslabs, int train_decoder,
+                       int* counters, void* stream);
+/* forward only: Decoder.get_values on a dense batch (mesh-time get_scores, render_helpers.py:96-153) */
+int nl_decoder_forward(const float* X, const float* params, const float* W2T, int P, float* sdf, int nblocks, void* stream);
+int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, void* stream);
+int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream);
+
+/* backward of get_features: embedding gradient (fp32 accumulation of bf16-rounded contributions, the
+ * CUDA embedding_dense_backward semantics) and pose-gradient partials g_pose[F,12] = (dL/dt, dL/dR).
+ * g_emb / g_pose may be NULL to skip either. */
+int nl_trilinear_bwd(const void* loss_scalars, const int* s_vox, const float* s_depth, const int* s_ray,
+                     const float* rays_d_world, const float* rays_d_sensor, const int* frame_id, const float* poses, int n_frames,
+                     const float* centres, const int* vertex_rows, const void* emb_bf16, float voxel_size,
+                     const float* dX, float* g_emb, float* g_pose, int nblocks, void* stream);
+
+/* masked_scatter_ones (render_helpers.py:30-36,301): packed samples -> padded [R,S] tensors */
+int nl_unpack_samples(const void* loss_scalars, const int* s_ray, const int* samp_off, const int* hit_rank,
+                      const float* sdf, const float* depth, int S_stride, float* out_sdf, float* out_z, unsigned char* out_valid,
+                      void* stream);
+
+/* ---- optimiser: torch.optim.Adam as used in render_helpers.py:341-353,421-423,448-450,508-510 ---- */
+int nl_adam_embeddings(void* emb_bf16, float* g_acc, void* m_bf16, void* v_bf16, long long n_elems, double lr, int step, void* stream);
+int nl_embedding_grad_bf16(const float* g_acc, void* g_bf16, long long n_elems, void* stream);
+int nl_adam_f32(float* p, const float* g, float* m, float* v, int n, double lr, int step, void* stream);
+/* se3pose.py:18-35: pose6[F,6] = (t, w) -> poses12[F,12] */
+int nl_pose_matrices(const float* pose6, float* poses12, int F, void* stream);
+/* Rodrigues tail of the pose gradient + Adam on the 6-vectors (enable[f] != 0) + refreshed matrices */
+int nl_pose_step(float* pose6, float* g_pose, float* m, float* v, const int* enable, float* grad6_out, float* poses12,
+                 int F, double lr, int step, int apply, void* stream);
+
+/* ---- (b2) host octree behind torch.classes.svo.Octree (third_party/sparse_octree/src/bindings.cpp:4-31) */
+void* nl_octree_create(long long grid_dim);                              /* Octree::init   octree.cpp:36-50   */
+void nl_octree_destroy(void* h);
+int nl_octree_insert(void* h, const int* voxels_xyz, long long n);       /* Octree::insert octree.cpp:51-111  */
+long long nl_octree_count_nodes(void* h);                                /* octree.cpp:344-365 */
+long long nl_octree_count_leaf_nodes(void* h);                           /* octree.cpp:367-387 */
+int nl_octree_has_voxel(void* h, int x, int y, int z);                   /* octree.cpp:173-206 */
+int nl_octree_export(void* h, float* voxels, float* children, int* features);   /* get_centres_and_children :293-342 */
+int nl_octree_export_device_layout(void* h, float voxel_size, float* centres, int* structure, int* vertex_idx); /* + mapping.py:319-327 */
+
+/* MFMA lane-map self test (debug) */
+int nl_mfma_selftest(const float* A32, const float* B32, float* D32, const float* A16, const float* B16, float* D16, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

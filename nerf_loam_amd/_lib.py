@@ -1,0 +1,112 @@
+"""ctypes binding of libnerfloam_hip.so (include/nerfloam_hip.h).  Fails loudly: there is no CPU or
+PyTorch fallback for the hot path - if the HIP library is missing or no GPU is visible, the product
+raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnerfloam_hip.so")
+
+NL_MAX_HITS = 20
+NL_CNT_INTS = 16
+NL_CNT_DOUBLES = 4
+NL_CNT_BYTES = NL_CNT_INTS * 4 + NL_CNT_DOUBLES * 8
+NL_LOSS_SCALARS_BYTES = 48
+NL_DEC_PARAMS = 70401
+NL_C = 16
+NL_W = 256
+OFF_W1, OFF_B1 = 0, 256 * 16
+OFF_W2 = OFF_B1 + 256
+OFF_B2 = OFF_W2 + 256 * 256
+OFF_W3 = OFF_B2 + 256
+OFF_B3 = OFF_W3 + 256
+
+# counter indices (nl_common.h)
+(NLC_R, NLC_HMAX, NLC_SMAX, NLC_P, NLC_NFS, NLC_NSDF, NLC_INV_FS_RAYS, NLC_INV_FS_CNT, NLC_INV_SDF_RAYS,
+ NLC_INV_SDF_CNT, NLC_OVERFLOW, NLC_GUARD, NLC_R_OFFSET, NLC_R_GLOBAL) = range(14)
+NLD_FS_SQ, NLD_SDF_SQ, NLD_INV_D2, NLD_INV_D2CNT = range(4)
+
+_ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "no HIP device", 4: "capacity exceeded"}
+
+
+class NerfLoamHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_P, _I, _F, _D, _LL, _U = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_longlong, ctypes.c_uint
+
+_SIGS = {
+    "nl_version": ([], _I),
+    "nl_device_count": ([], _I),
+    "nl_decoder_grid_hint": ([], _I),
+    "nl_svo_intersect": ([_P] * 4 + [_I, _I, _I, _F, _I] + [_P] * 4, _I),
+    "nl_inverse_cdf_sampling": ([_P] * 6 + [_I] * 4 + [_F] + [_P] * 4, _I),
+    "nl_ray_intersect": ([_I] + [_P] * 7 + [_F, _F] + [_P] * 8, _I),
+    "nl_exclusive_scan_i32": ([_P, _P, _I, _I, _P, _P, _P], _I),
+    "nl_compact_hit_rays": ([_I, _P, _P, _P, _P], _I),
+    "nl_sample_rays": ([_I, _I] + [_P] * 8 + [_F, _F, _F, _U, _I, _I, _I] + [_P, _P, _P, _I] + [_P] * 5, _I),
+    "nl_loss_finalize": ([_P, _P, _F, _F, _F, _F, _I, _P], _I),
+    "nl_gather_trilinear": ([_P] * 7 + [_I] + [_P] * 3 + [_F, _P, _I, _P], _I),
+    "nl_decoder_fwd_bwd": ([_P] * 13 + [_I, _I, _P, _P], _I),
+    "nl_decoder_forward": ([_P, _P, _P, _I, _P, _I, _P], _I),
+    "nl_reduce_partials": ([_P, _I, _I, _P, _P], _I),
+    "nl_decoder_transpose_w2": ([_P, _P, _P], _I),
+    "nl_trilinear_bwd": ([_P] * 8 + [_I] + [_P] * 3 + [_F] + [_P] * 3 + [_I, _P], _I),
+    "nl_unpack_samples": ([_P] * 6 + [_I] + [_P] * 4, _I),
+    "nl_adam_embeddings": ([_P, _P, _P, _P, _LL, _D, _I, _P], _I),
+    "nl_embedding_grad_bf16": ([_P, _P, _LL, _P], _I),
+    "nl_adam_f32": ([_P, _P, _P, _P, _I, _D, _I, _P], _I),
+    "nl_pose_matrices": ([_P, _P, _I, _P], _I),
+    "nl_pose_step": ([_P] * 7 + [_I, _D, _I, _I, _P], _I),
+    "nl_octree_create": ([_LL], _P),
+    "nl_octree_destroy": ([_P], None),
+    "nl_octree_insert": ([_P, _P, _LL], _I),
+    "nl_octree_count_nodes": ([_P], _LL),
+    "nl_octree_count_leaf_nodes": ([_P], _LL),
+    "nl_octree_has_voxel": ([_P, _I, _I, _I], _I),
+    "nl_octree_export": ([_P, _P, _P, _P], _I),
+    "nl_octree_export_device_layout": ([_P, _F, _P, _P, _P], _I),
+    "nl_mfma_selftest": ([_P] * 7, _I),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+def lib():
+    """Load libnerfloam_hip.so (built by nerf_loam_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NerfLoamHipError(f"{LIB_PATH} not found - run `python -m nerf_loam_amd.build` (needs hipcc); "
+                                   "the SDF hot path has no CPU/PyTorch fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = res
+        _lib = L
+    return _lib
+
+
+def require_gpu():
+    if lib().nl_device_count() <= 0:
+        raise NerfLoamHipError("no HIP device visible: the NeRF-LOAM SDF hot path runs only on the GPU (no CPU fallback)")
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise NerfLoamHipError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def ptr(t):
+    """device/host pointer of a torch tensor (must be contiguous) or None"""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "nerfloam_hip needs contiguous tensors"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

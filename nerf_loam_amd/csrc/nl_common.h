@@ -1,0 +1,59 @@
+// nl_common.h -- shared declarations of the HIP implementation (not part of the public C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nl_device_math.h"
+
+// status codes returned by every nl_* entry point (include/nerfloam_hip.h)
+#define NL_OK 0
+#define NL_ERR_INVALID_ARG 1
+#define NL_ERR_LAUNCH 2
+#define NL_ERR_NO_DEVICE 3
+#define NL_ERR_CAPACITY 4
+
+// device counter block: int32[NL_CNT_INTS] followed (8-byte aligned) by double[NL_CNT_DOUBLES]
+enum {
+    NLC_R = 0,          // number of rays with >=1 hit
+    NLC_HMAX,           // max valid hits per ray over the batch ("P" of the sampler)
+    NLC_SMAX,           // max samples per ray
+    NLC_P,              // total valid samples
+    NLC_NFS,            // front-mask count over VALID samples
+    NLC_NSDF,           // sdf-mask count over VALID samples
+    NLC_INV_FS_RAYS,    // sum over hit rays of front_inv(r)            (invalid slots: z = 80*cos)
+    NLC_INV_FS_CNT,     // sum over hit rays of front_inv(r) * cnt_r
+    NLC_INV_SDF_RAYS,   // sum over hit rays of sdfm_inv(r)
+    NLC_INV_SDF_CNT,    // sum over hit rays of sdfm_inv(r) * cnt_r
+    NLC_OVERFLOW,       // set when P exceeded the sample capacity
+    NLC_GUARD,          // set when a ray's summed interval length exceeds 10*MAX_DEPTH (reference returns None)
+    NLC_R_OFFSET,       // multi-GPU: number of hit rays on lower ranks (global rank of local hit-ray 0)
+    NLC_R_GLOBAL,       // multi-GPU: global number of hit rays (== NLC_R on one GPU)
+    NL_CNT_INTS = 16
+};
+enum {
+    NLD_FS_SQ = 0,      // sum of fs residual^2 over valid samples
+    NLD_SDF_SQ,         // sum of sdf residual^2 over valid samples
+    NLD_INV_D2,         // sum over hit rays of sdfm_inv(r) * d_r^2
+    NLD_INV_D2CNT,      // sum over hit rays of sdfm_inv(r) * cnt_r * d_r^2
+    NL_CNT_DOUBLES = 4
+};
+#define NL_CNT_BYTES (NL_CNT_INTS * 4 + NL_CNT_DOUBLES * 8)
+
+// decoder parameter block (floats), nn.Linear layouts W[out][in]
+#define NL_C 16                 // embedding channels = decoder input width
+#define NL_W 256                // hidden width
+#define NL_OFF_W1 0
+#define NL_OFF_B1 (NL_OFF_W1 + NL_W * NL_C)
+#define NL_OFF_W2 (NL_OFF_B1 + NL_W)
+#define NL_OFF_B2 (NL_OFF_W2 + NL_W * NL_W)
+#define NL_OFF_W3 (NL_OFF_B2 + NL_W)
+#define NL_OFF_B3 (NL_OFF_W3 + NL_W)
+#define NL_DEC_PARAMS (NL_OFF_B3 + 1)      // 70401
+
+#define NL_LAUNCH_CHECK()                                   \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return NL_ERR_LAUNCH;        \
+    } while (0)
+
+static inline int nl_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }

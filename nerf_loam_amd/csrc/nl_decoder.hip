@@ -1,0 +1,500 @@
+// nl_decoder.hip -- the SDF decoder (16 -> 256 -> 256 -> 1 ReLU MLP) forward + loss gradient +
+// backward as ONE persistent kernel on the fp32 matrix cores of gfx950.
+//
+// Reference behaviour: src/variations/lidar.py:109-131 (forward), src/criterion.py:59-100 (loss),
+// torch autograd for the backward.  fp32 in / fp32 accumulate MFMA
+// (v_mfma_f32_32x32x2_f32, v_mfma_f32_16x16x4_f32) is bit-for-bit an fmaf chain, so the 1e-4 SDF
+// parity bar holds without any reduced-precision path.
+//
+// Structure (MI355X-first, not how the reference does it - it runs 3 GEMMs + autograd):
+//   * one 512-thread workgroup (8 waves, 2 per SIMD) per CU, persistent over 64-sample tiles;
+//   * per tile everything stays on chip: X tile, H1 = relu(X W1^T + b1) and dH2/dH1 live in LDS
+//     (row stride 257 floats: conflict-free both as MFMA A operand [row-per-lane] and as
+//     B operand / epilogue target [column-per-lane]); H2 never leaves registers;
+//   * the loss gradient dL/dsdf needs only per-sample geometry + iteration-global scalars that are
+//     known before the decoder runs (nl_geometry.hip), so forward, loss and backward fuse;
+//   * W2 (256 KB fp32 > LDS) is streamed from L2 straight into MFMA B operands: wave w owns output
+//     columns [32w, 32w+32), reads W2T rows (forward) / W2 rows (dgrad) coalesced, each operand
+//     register feeds both 32-row sub-tiles;
+//   * weight gradients accumulate in registers across ALL tiles of the workgroup and are flushed
+//     once as a per-workgroup partial slab - no atomics; nl_reduce_partials sums the slabs.  The
+//     big one, dW2 = dH2^T H1 (8 tiles of 32x32 per wave = 128 accumulator registers), runs in its
+//     own persistent kernel (k_decoder_wgrad2) so that neither kernel spills: it rebuilds H1 from
+//     X (K = 16, 2 % extra MFMA work) and dH2 from dsdf + the 256-bit ReLU mask the first kernel
+//     saves per sample (32 B instead of a 1 KB activation row).
+// FLOPs per sample: 3 * 2 * (16*256 + 256*256 + 256) = 419,328 (279,552 with a frozen decoder).
+#include "nl_common.h"
+
+#define DEC_M 64
+#define DEC_THREADS 512
+#define LDH 257
+#define LDX 17
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// LDS carve (floats)
+#define S_H1 0
+#define S_D (S_H1 + DEC_M * LDH)
+#define S_X (S_D + DEC_M * LDH)
+#define S_DX (S_X + DEC_M * LDX)
+#define S_S (S_DX + DEC_M * LDX)
+#define S_DS (S_S + DEC_M)
+#define S_TOTAL (S_DS + DEC_M)
+
+struct DecArgs {
+    const NlLossScalars* ls;
+    const float* X;             // [P,16] interpolated embeddings
+    const float* params;        // decoder parameter block (NL_OFF_*)
+    const float* W2T;           // [256][256], W2T[k][j] = W2[j][k]
+    const int* s_ray;           // [P]
+    const float* s_depth;       // [P]
+    const float* cos_gt;        // [N]
+    const float* gt_dist;       // [N]
+    float* sdf;                 // [P]
+    float* dsdf;                // [P]
+    float* dX;                  // [P,16]
+    float* partials;            // [gridDim.x][NL_DEC_PARAMS] (train only)
+    unsigned* relu2_mask;       // [P][8] bit j%32 of word j/32 = (H2[j] > 0)   (train only)
+    double* dcounters;          // loss sums
+};
+
+// row of accumulator register r in a 32x32 MFMA result for this lane
+__device__ __forceinline__ int d32_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
+template <bool TRAIN>
+__global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[S_TOTAL];
+    float* sH1 = lds + S_H1; float* sD = lds + S_D; float* sX = lds + S_X; float* sdX = lds + S_DX;
+    float* sS = lds + S_S; float* sdS = lds + S_DS;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5, l15 = lane & 15, lq = lane >> 4;
+    const int col = 32 * w + l31;                 // this lane's output column in 32x32 tiles
+    const NlLossScalars ls = *a.ls;
+    const int P = ls.P;
+    const int ntiles = (P + DEC_M - 1) / DEC_M;
+
+    const float* W1 = a.params + NL_OFF_W1; const float* W2 = a.params + NL_OFF_W2;
+    const float b1c = a.params[NL_OFF_B1 + col], b2c = a.params[NL_OFF_B2 + col], w3c = a.params[NL_OFF_W3 + col];
+    const float b3 = a.params[NL_OFF_B3];
+
+    // persistent weight-gradient accumulators (dW2 lives in k_decoder_wgrad2)
+    f32x4 accW1[2];
+    float aW3 = 0.f, aB2 = 0.f, aB1 = 0.f, aB3 = 0.f;
+    double lossFs = 0.0, lossSdf = 0.0;
+    if (TRAIN) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) for (int r = 0; r < 4; ++r) accW1[t][r] = 0.f;
+    }
+    for (int i = tid; i < DEC_M * LDX; i += DEC_THREADS) sdX[i] = 0.f;
+    if (tid < DEC_M) sS[tid] = 0.f;
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * DEC_M;
+        // ---------------- A: X tile -> LDS ----------------
+        {
+            const int e = tid * 2, i = e >> 4, c = e & 15;
+            float2 v = make_float2(0.f, 0.f);
+            if (row0 + i < P) v = *reinterpret_cast<const float2*>(a.X + (size_t)(row0 + i) * NL_C + c);
+            sX[i * LDX + c] = v.x; sX[i * LDX + c + 1] = v.y;
+        }
+        __syncthreads();
+        // ---------------- B: H1 = relu(X W1^T + b1) ----------------
+        {
+            f32x16 c0, c1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < NL_C / 2; ++kk) {
+                const float bw = W1[col * NL_C + 2 * kk + lh];
+                const float a0 = sX[l31 * LDX + 2 * kk + lh], a1 = sX[(32 + l31) * LDX + 2 * kk + lh];
+                c0 = MFMA32(a0, bw, c0); c1 = MFMA32(a1, bw, c1);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = d32_row(r, lh);
+                sH1[row * LDH + col] = fmaxf(c0[r] + b1c, 0.f);
+                sH1[(32 + row) * LDH + col] = fmaxf(c1[r] + b1c, 0.f);
+            }
+        }
+        __syncthreads();
+        // ---------------- C: H2 = relu(H1 W2^T + b2), s = H2 w3 + b3 ----------------
+        f32x16 h0, h1;
+        {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
+            const float* bp = a.W2T + lh * NL_W + col;
+            const float* ap0 = sH1 + l31 * LDH + lh; const float* ap1 = sH1 + (32 + l31) * LDH + lh;
+#pragma unroll 8
+            for (int kk = 0; kk < NL_W / 2; ++kk) {
+                const float bw = bp[(size_t)kk * 2 * NL_W];
+                const float a0 = ap0[2 * kk], a1 = ap1[2 * kk];
+                h0 = MFMA32(a0, bw, h0); h1 = MFMA32(a1, bw, h1);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                h0[r] = fmaxf(h0[r] + b2c, 0.f); h1[r] = fmaxf(h1[r] + b2c, 0.f);
+                float p0 = h0[r] * w3c, p1 = h1[r] * w3c;
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) { p0 += __shfl_xor(p0, off); p1 += __shfl_xor(p1, off); }
+                if (l31 == 0) {
+                    const int row = d32_row(r, lh);
+                    atomicAdd(&sS[row], p0); atomicAdd(&sS[32 + row], p1);
+                }
+            }
+        }
+        __syncthreads();
+        // ---------------- D: sdf, loss gradient (criterion.py) ----------------
+        if (tid < DEC_M) {
+            const int g = row0 + tid;
+            float ds = 0.f;
+            if (g < P) {
+                const float s = sS[tid] + b3;
+                const int ray = a.s_ray[g];
+                const float c = a.cos_gt[ray], d = a.gt_dist[ray];
+                const float z = a.s_depth[g] * c;
+                bool f, m;
+                nl_loss_masks(z, d, ls.tau, ls.max_depth, &f, &m);
+                float q1, q2;
+                ds = nl_loss_grad(s, z, d, f, m, ls, &q1, &q2);
+                a.sdf[g] = s; a.dsdf[g] = ds;
+                lossFs += (double)q1; lossSdf += (double)q2;
+            }
+            sdS[tid] = ds; sS[tid] = 0.f;
+            if (TRAIN) aB3 += ds;
+        }
+        __syncthreads();
+        // ---------------- E: dH2 = ds * w3 * [H2 > 0] -> LDS ----------------
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = d32_row(r, lh);
+            const float ds0 = sdS[row], ds1 = sdS[32 + row];
+            const float g0 = h0[r] > 0.f ? ds0 * w3c : 0.f, g1 = h1[r] > 0.f ? ds1 * w3c : 0.f;
+            sD[row * LDH + col] = g0; sD[(32 + row) * LDH + col] = g1;
+            if (TRAIN) {
+                aW3 += ds0 * h0[r] + ds1 * h1[r]; aB2 += g0 + g1;
+                // ReLU mask of H2: one ballot = 32 columns of two rows (lanes 0-31 / 32-63)
+                const unsigned long long bm0 = __ballot(h0[r] > 0.f), bm1 = __ballot(h1[r] > 0.f);
+                if (lane == 0) {
+                    const int ra = d32_row(r, 0), rb = d32_row(r, 1);
+                    if (row0 + ra < P) a.relu2_mask[(size_t)(row0 + ra) * 8 + w] = (unsigned)bm0;
+                    if (row0 + rb < P) a.relu2_mask[(size_t)(row0 + rb) * 8 + w] = (unsigned)(bm0 >> 32);
+                    if (row0 + 32 + ra < P) a.relu2_mask[(size_t)(row0 + 32 + ra) * 8 + w] = (unsigned)bm1;
+                    if (row0 + 32 + rb < P) a.relu2_mask[(size_t)(row0 + 32 + rb) * 8 + w] = (unsigned)(bm1 >> 32);
+                }
+            }
+        }
+        __syncthreads();
+        // ---------------- F: dH1 = (dH2 W2) * [H1 > 0]  (kept in registers) ----------------
+        f32x16 g0v, g1v;
+        {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { g0v[r] = 0.f; g1v[r] = 0.f; }
+            const float* bp = W2 + lh * NL_W + col;
+            const float* ap0 = sD + l31 * LDH + lh; const float* ap1 = sD + (32 + l31) * LDH + lh;
+#pragma unroll 8
+            for (int jj = 0; jj < NL_W / 2; ++jj) {
+                const float bw = bp[(size_t)jj * 2 * NL_W];
+                const float a0 = ap0[2 * jj], a1 = ap1[2 * jj];
+                g0v = MFMA32(a0, bw, g0v); g1v = MFMA32(a1, bw, g1v);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = d32_row(r, lh);
+                g0v[r] = sH1[row * LDH + col] > 0.f ? g0v[r] : 0.f;
+                g1v[r] = sH1[(32 + row) * LDH + col] > 0.f ? g1v[r] : 0.f;
+                if (TRAIN) aB1 += g0v[r] + g1v[r];
+            }
+        }
+        __syncthreads();
+        // ---------------- H: dH1 -> LDS (over dH2) ----------------
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = d32_row(r, lh);
+            sD[row * LDH + col] = g0v[r]; sD[(32 + row) * LDH + col] = g1v[r];
+        }
+        __syncthreads();
+        // ---------------- I: dX = dH1 W1 (k-split over waves), dW1 += dH1^T X ----------------
+        {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                f32x4 cx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int k = 32 * w + 4 * q + lq;
+                    cx = MFMA16(sD[(16 * rt + l15) * LDH + k], W1[k * NL_C + l15], cx);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(&sdX[(16 * rt + 4 * lq + r) * LDX + l15], cx[r]);
+            }
+            if (TRAIN) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll 4
+                    for (int ii = 0; ii < DEC_M / 4; ++ii)
+                        accW1[t] = MFMA16(sD[(4 * ii + lq) * LDH + 32 * w + 16 * t + l15], sX[(4 * ii + lq) * LDX + l15], accW1[t]);
+            }
+        }
+        __syncthreads();
+        // ---------------- J: dX tile -> global ----------------
+        {
+            const int e = tid * 2, i = e >> 4, c = e & 15;
+            if (row0 + i < P)
+                *reinterpret_cast<float2*>(a.dX + (size_t)(row0 + i) * NL_C + c) = make_float2(sdX[i * LDX + c], sdX[i * LDX + c + 1]);
+            sdX[i * LDX + c] = 0.f; sdX[i * LDX + c + 1] = 0.f;
+        }
+        __syncthreads();
+    }
+
+    // ---------------- loss sums ----------------
+    if (tid < 64) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { lossFs += __shfl_xor(lossFs, off); lossSdf += __shfl_xor(lossSdf, off); }
+        if (tid == 0 && (lossFs != 0.0 || lossSdf != 0.0)) {
+            atomicAdd(&a.dcounters[NLD_FS_SQ], lossFs); atomicAdd(&a.dcounters[NLD_SDF_SQ], lossSdf);
+        }
+    }
+    // ---------------- flush weight-gradient partials ----------------
+    if (TRAIN) {
+        float* base = a.partials + (size_t)blockIdx.x * NL_DEC_PARAMS;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                base[NL_OFF_W1 + (32 * w + 16 * t + 4 * lq + r) * NL_C + l15] = accW1[t][r];
+        aW3 += __shfl_xor(aW3, 32); aB2 += __shfl_xor(aB2, 32); aB1 += __shfl_xor(aB1, 32);
+        if (lh == 0) { base[NL_OFF_W3 + col] = aW3; base[NL_OFF_B2 + col] = aB2; base[NL_OFF_B1 + col] = aB1; }
+        if (tid < 64) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) aB3 += __shfl_xor(aB3, off);
+            if (tid == 0) base[NL_OFF_B3] = aB3;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dW2 = dH2^T H1 over all samples (K = samples).  Persistent; per 64-sample tile: H1 = relu(X W1^T+b1)
+// -> LDS, dH2[i][j] = mask(i,j) ? dsdf_i * w3_j : 0 -> LDS, then 256 MFMAs per wave into the 8
+// persistent 32x32 accumulators of the wave's 32-row slab of dW2.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2(const NlLossScalars* __restrict__ lsp, const float* __restrict__ X,
+                                                                    const float* __restrict__ params, const float* __restrict__ dsdf,
+                                                                    const unsigned* __restrict__ relu2_mask, float* __restrict__ partials)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2 * DEC_M * LDH + DEC_M * LDX + DEC_M];
+    float* sH1 = lds; float* sD = lds + DEC_M * LDH; float* sX = sD + DEC_M * LDH; float* sdS = sX + DEC_M * LDX;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int col = 32 * w + l31;
+    const int P = lsp->P;
+    const int ntiles = (P + DEC_M - 1) / DEC_M;
+    const float* W1 = params + NL_OFF_W1;
+    const float b1c = params[NL_OFF_B1 + col], w3c = params[NL_OFF_W3 + col];
+    f32x16 accW2[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) for (int r = 0; r < 16; ++r) accW2[t][r] = 0.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * DEC_M;
+        {
+            const int e = tid * 2, i = e >> 4, c = e & 15;
+            float2 v = make_float2(0.f, 0.f);
+            if (row0 + i < P) v = *reinterpret_cast<const float2*>(X + (size_t)(row0 + i) * NL_C + c);
+            sX[i * LDX + c] = v.x; sX[i * LDX + c + 1] = v.y;
+            if (tid < DEC_M) sdS[tid] = (row0 + tid < P) ? dsdf[row0 + tid] : 0.f;
+        }
+        __syncthreads();
+        {   // H1 -> LDS
+            f32x16 c0, c1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < NL_C / 2; ++kk) {
+                const float bw = W1[col * NL_C + 2 * kk + lh];
+                c0 = MFMA32(sX[l31 * LDX + 2 * kk + lh], bw, c0); c1 = MFMA32(sX[(32 + l31) * LDX + 2 * kk + lh], bw, c1);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = d32_row(r, lh);
+                sH1[row * LDH + col] = fmaxf(c0[r] + b1c, 0.f); sH1[(32 + row) * LDH + col] = fmaxf(c1[r] + b1c, 0.f);
+            }
+        }
+        {   // dH2 -> LDS: this lane's column, rows lh, lh+2, ...
+#pragma unroll 4
+            for (int i = lh; i < DEC_M; i += 2) {
+                const unsigned word = (row0 + i < P) ? relu2_mask[(size_t)(row0 + i) * 8 + w] : 0u;
+                sD[i * LDH + col] = ((word >> l31) & 1u) ? sdS[i] * w3c : 0.f;
+            }
+        }
+        __syncthreads();
+        {
+            const float* ap = sD + lh * LDH + col;
+            const float* bp = sH1 + lh * LDH + l31;
+#pragma unroll 2
+            for (int ii = 0; ii < DEC_M / 2; ++ii) {
+                const float av = ap[2 * ii * LDH];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) accW2[t] = MFMA32(av, bp[2 * ii * LDH + 32 * t], accW2[t]);
+            }
+        }
+        __syncthreads();
+    }
+    float* base = partials + (size_t)blockIdx.x * NL_DEC_PARAMS;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            base[NL_OFF_W2 + (32 * w + d32_row(r, lh)) * NL_W + 32 * t + l31] = accW2[t][r];
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward-only variant for dense SDF queries (mesh-time get_scores, render_helpers.py:96-153) and
+// tests: sdf = decoder(X).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __restrict__ X, const float* __restrict__ params,
+                                                                 const float* __restrict__ W2T, int P, float* __restrict__ sdf)
+{
+    __shared__ __attribute__((aligned(16))) float lds[DEC_M * LDH + DEC_M * LDX + DEC_M];
+    float* sH1 = lds; float* sX = lds + DEC_M * LDH; float* sS = sX + DEC_M * LDX;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int col = 32 * w + l31;
+    const float* W1 = params + NL_OFF_W1;
+    const float b1c = params[NL_OFF_B1 + col], b2c = params[NL_OFF_B2 + col], w3c = params[NL_OFF_W3 + col], b3 = params[NL_OFF_B3];
+    const int ntiles = (P + DEC_M - 1) / DEC_M;
+    if (tid < DEC_M) sS[tid] = 0.f;
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * DEC_M;
+        {
+            const int e = tid * 2, i = e >> 4, c = e & 15;
+            float2 v = make_float2(0.f, 0.f);
+            if (row0 + i < P) v = *reinterpret_cast<const float2*>(X + (size_t)(row0 + i) * NL_C + c);
+            sX[i * LDX + c] = v.x; sX[i * LDX + c + 1] = v.y;
+        }
+        __syncthreads();
+        {
+            f32x16 c0, c1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < NL_C / 2; ++kk) {
+                const float bw = W1[col * NL_C + 2 * kk + lh];
+                c0 = MFMA32(sX[l31 * LDX + 2 * kk + lh], bw, c0); c1 = MFMA32(sX[(32 + l31) * LDX + 2 * kk + lh], bw, c1);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = d32_row(r, lh);
+                sH1[row * LDH + col] = fmaxf(c0[r] + b1c, 0.f); sH1[(32 + row) * LDH + col] = fmaxf(c1[r] + b1c, 0.f);
+            }
+        }
+        __syncthreads();
+        {
+            f32x16 h0, h1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
+            const float* bp = W2T + lh * NL_W + col;
+            const float* ap0 = sH1 + l31 * LDH + lh; const float* ap1 = sH1 + (32 + l31) * LDH + lh;
+#pragma unroll 8
+            for (int kk = 0; kk < NL_W / 2; ++kk) {
+                const float bw = bp[(size_t)kk * 2 * NL_W];
+                h0 = MFMA32(ap0[2 * kk], bw, h0); h1 = MFMA32(ap1[2 * kk], bw, h1);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p0 = fmaxf(h0[r] + b2c, 0.f) * w3c, p1 = fmaxf(h1[r] + b2c, 0.f) * w3c;
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) { p0 += __shfl_xor(p0, off); p1 += __shfl_xor(p1, off); }
+                if (l31 == 0) { const int row = d32_row(r, lh); atomicAdd(&sS[row], p0); atomicAdd(&sS[32 + row], p1); }
+            }
+        }
+        __syncthreads();
+        if (tid < DEC_M) { if (row0 + tid < P) sdf[row0 + tid] = sS[tid] + b3; sS[tid] = 0.f; }
+        __syncthreads();
+    }
+}
+
+// sum per-workgroup partial slabs: out[i] = sum_b partials[b][i]
+__global__ void k_reduce_partials(const float* __restrict__ partials, int nslabs, int n, float* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < nslabs; ++b) s += partials[(size_t)b * n + i];
+    out[i] = s;
+}
+
+// MFMA layout self-test: D = A(32x2) B(2x32) and D = A(16x4) B(4x16) written row-major using the lane
+// maps this file assumes (cdna_hip_programming.md section 3).
+__global__ void k_mfma_selftest(const float* A32, const float* B32, float* D32, const float* A16, const float* B16, float* D16)
+{
+    const int lane = threadIdx.x & 63;
+    f32x16 c; for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    c = MFMA32(A32[(lane & 31) * 2 + (lane >> 5)], B32[(lane >> 5) * 32 + (lane & 31)], c);
+    for (int r = 0; r < 16; ++r) D32[d32_row(r, lane >> 5) * 32 + (lane & 31)] = c[r];
+    f32x4 e = {0.f, 0.f, 0.f, 0.f};
+    e = MFMA16(A16[(lane & 15) * 4 + (lane >> 4)], B16[(lane >> 4) * 16 + (lane & 15)], e);
+    for (int r = 0; r < 4; ++r) D16[((lane >> 4) * 4 + r) * 16 + (lane & 15)] = e[r];
+}
+
+extern "C" {
+
+int nl_decoder_grid_hint(void)
+{
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+}
+
+int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* params, const float* W2T,
+                       const int* s_ray, const float* s_depth, const float* cos_gt, const float* gt_dist,
+                       float* sdf, float* dsdf, float* dX, float* partials, unsigned* relu2_mask, int nslabs, int train_decoder,
+                       int* counters, void* stream)
+{
+    if (!loss_scalars || !X || !params || !W2T || !s_ray || !s_depth || !cos_gt || !gt_dist || !sdf || !dsdf || !dX || !counters)
+        return NL_ERR_INVALID_ARG;
+    if (nslabs <= 0 || (train_decoder && (!partials || !relu2_mask))) return NL_ERR_INVALID_ARG;
+    DecArgs a;
+    a.ls = (const NlLossScalars*)loss_scalars; a.X = X; a.params = params; a.W2T = W2T; a.s_ray = s_ray; a.s_depth = s_depth;
+    a.cos_gt = cos_gt; a.gt_dist = gt_dist; a.sdf = sdf; a.dsdf = dsdf; a.dX = dX; a.partials = partials;
+    a.relu2_mask = relu2_mask;
+    a.dcounters = (double*)(counters + NL_CNT_INTS);
+    if (train_decoder) {
+        hipLaunchKernelGGL(k_decoder<true>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(k_decoder_wgrad2, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, a.ls, X, params, dsdf, relu2_mask, partials);
+    } else {
+        hipLaunchKernelGGL(k_decoder<false>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, a);
+    }
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+int nl_decoder_forward(const float* X, const float* params, const float* W2T, int P, float* sdf, int nblocks, void* stream)
+{
+    if (!X || !params || !W2T || !sdf || P < 0 || nblocks <= 0) return NL_ERR_INVALID_ARG;
+    if (P == 0) return NL_OK;
+    hipLaunchKernelGGL(k_decoder_fwd, dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, void* stream)
+{
+    if (!partials || !out || nslabs <= 0 || n <= 0) return NL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nl_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, partials, nslabs, n, out);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+int nl_mfma_selftest(const float* A32, const float* B32, float* D32, const float* A16, const float* B16, float* D16, void* stream)
+{
+    hipLaunchKernelGGL(k_mfma_selftest, dim3(1), dim3(64), 0, (hipStream_t)stream, A32, B32, D32, A16, B16, D16);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+}  // extern "C"

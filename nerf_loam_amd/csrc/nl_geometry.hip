@@ -1,0 +1,491 @@
+// nl_geometry.hip -- ray/octree intersection, hit compaction (scan) and inverse-CDF ray sampling
+// for gfx950.  HBM/L2-bound integer+fp32 kernels: one ray per lane, octree read in place (the
+// reference replicates it G<=256 times, voxel_helpers.py:106-108), DFS cursors in LDS, samples
+// written compacted through an exclusive scan instead of a padded [R, max_steps] tensor.
+//
+// Reference behaviour: third_party/sparse_voxels/src/intersect_gpu.cu:193-272,
+// src/variations/voxel_helpers.py:531-598, third_party/sparse_voxels/src/sample_gpu.cu:133-239.
+#include "nl_common.h"
+
+#define NL_GEO_THREADS 256
+
+// ---------------------------------------------------------------------------------------------
+// DFS cursor stack in LDS: entry = (node << 4) | (cursor + 1), laid out [level][thread] so that a
+// wave's accesses to one level hit 64 consecutive banks.
+// ---------------------------------------------------------------------------------------------
+struct LdsStack {
+    unsigned* base;     // &lds[threadIdx.x]
+    __device__ __forceinline__ void set(int l, int node, int cur) { base[l * NL_GEO_THREADS] = ((unsigned)node << 4) | (unsigned)(cur + 1); }
+    __device__ __forceinline__ int node(int l) const { return (int)(base[l * NL_GEO_THREADS] >> 4); }
+    __device__ __forceinline__ int cursor(int l) const { return (int)(base[l * NL_GEO_THREADS] & 15u) - 1; }
+    __device__ __forceinline__ void set_cursor(int l, int cur) {
+        unsigned v = base[l * NL_GEO_THREADS];
+        base[l * NL_GEO_THREADS] = (v & ~15u) | (unsigned)(cur + 1);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// (b1) drop-in kernel behind grid.svo_intersect: raw DFS-order hits, reference tensor layouts
+// [B,m,3] rays, [B,n,3]/[B,n,9] octree per batch row, [B,m,n_max] outputs (idx -1 padded, depths
+// zero where unused like intersect.cpp:98-106).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NL_GEO_THREADS) void k_svo_intersect_raw(
+    int b, int n, int m, float voxelsize, int n_max,
+    const float* __restrict__ ray_start, const float* __restrict__ ray_dir,
+    const float* __restrict__ points, const int* __restrict__ children,
+    int* __restrict__ idx, float* __restrict__ min_depth, float* __restrict__ max_depth)
+{
+    __shared__ unsigned s_stack[NL_MAX_LEVELS * NL_GEO_THREADS];
+    const long long gid = (long long)blockIdx.x * NL_GEO_THREADS + threadIdx.x;
+    if (gid >= (long long)b * m) return;
+    const int bi = (int)(gid / m);
+    const float* pts = points + (size_t)bi * n * 3;
+    const int* ch = children + (size_t)bi * n * 9;
+    const float* o = ray_start + gid * 3;
+    const float* d = ray_dir + gid * 3;
+    int hi[NL_MAX_HITS]; float h0[NL_MAX_HITS], h1[NL_MAX_HITS];
+    LdsStack stk{&s_stack[threadIdx.x]};
+    const int nm = n_max < NL_MAX_HITS ? n_max : NL_MAX_HITS;
+    const int cnt = nl_octree_walk(pts, ch, o[0], o[1], o[2], d[0], d[1], d[2], voxelsize * 0.5f, nm, stk, hi, h0, h1);
+    int* oi = idx + gid * n_max; float* o0 = min_depth + gid * n_max; float* o1 = max_depth + gid * n_max;
+    for (int l = 0; l < n_max; ++l) {
+        const bool v = l < cnt;
+        oi[l] = v ? hi[l] : -1;
+        o0[l] = v ? h0[l] : 0.0f;
+        o1[l] = v ? h1[l] : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused ray set-up + intersect + sort/cull (render_helpers.py:366-388, voxel_helpers.py:531-567).
+//   inputs per ray: unit direction in the sensor frame, gt return (sensor frame), cos, frame id
+//   poses[F][12]: rotation row-major (9) then translation (3)
+//   outputs: world direction, gt distance*cos, sorted hits [N,20] (idx -1 / depth max_distance
+//   padded), hit count; counters NLC_HMAX (atomic max)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect(
+    int N, const float* __restrict__ rays_d_sensor, const float* __restrict__ points_gt,
+    const float* __restrict__ cos_gt, const int* __restrict__ frame_id, const float* __restrict__ poses,
+    const float* __restrict__ centres, const int* __restrict__ structure,
+    float voxel_size, float max_distance,
+    float* __restrict__ rays_d_world, float* __restrict__ gt_dist,
+    int* __restrict__ hit_idx, float* __restrict__ hit_t0, float* __restrict__ hit_t1,
+    int* __restrict__ hit_count, int* __restrict__ counters)
+{
+    __shared__ unsigned s_stack[NL_MAX_LEVELS * NL_GEO_THREADS];
+    __shared__ int s_hmax;
+    if (threadIdx.x == 0) s_hmax = 0;
+    __syncthreads();
+    const int r = blockIdx.x * NL_GEO_THREADS + threadIdx.x;
+    int valid = 0;
+    if (r < N) {
+        const float* P = poses + 12 * (frame_id ? frame_id[r] : 0);
+        const float s0 = rays_d_sensor[3 * r], s1 = rays_d_sensor[3 * r + 1], s2 = rays_d_sensor[3 * r + 2];
+        float d[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) d[i] = (s0 * P[3 * i] + s1 * P[3 * i + 1]) + s2 * P[3 * i + 2];
+        rays_d_world[3 * r] = d[0]; rays_d_world[3 * r + 1] = d[1]; rays_d_world[3 * r + 2] = d[2];
+        const float gx = points_gt[3 * r], gy = points_gt[3 * r + 1], gz = points_gt[3 * r + 2];
+        gt_dist[r] = sqrtf((gx * gx + gy * gy) + gz * gz) * cos_gt[r];
+
+        int hi[NL_MAX_HITS]; float h0[NL_MAX_HITS], h1[NL_MAX_HITS];
+        LdsStack stk{&s_stack[threadIdx.x]};
+        const int cnt = nl_octree_walk(centres, structure, P[9], P[10], P[11], d[0], d[1], d[2],
+                                       voxel_size * 0.5f, NL_MAX_HITS, stk, hi, h0, h1);
+        valid = nl_sort_cull_hits(cnt, hi, h0, h1, max_distance);
+        int* oi = hit_idx + (size_t)r * NL_MAX_HITS; float* o0 = hit_t0 + (size_t)r * NL_MAX_HITS; float* o1 = hit_t1 + (size_t)r * NL_MAX_HITS;
+        for (int l = 0; l < NL_MAX_HITS; ++l) {
+            const bool v = l < cnt;
+            oi[l] = v ? hi[l] : -1;
+            o0[l] = v ? h0[l] : max_distance;
+            o1[l] = v ? h1[l] : max_distance;
+        }
+        hit_count[r] = valid;
+    }
+    // block max of valid hits -> one atomic per block
+    int wmax = valid;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(&s_hmax, wmax);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_hmax > 0) atomicMax(&counters[NLC_HMAX], s_hmax);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exclusive scan (int32), n <= 1024*1024: per-block (1024 items) scan + block sums, one block
+// scans the sums, third pass adds.  `flag_mode` scans (in[i] > 0) instead of in[i].
+// ---------------------------------------------------------------------------------------------
+#define NL_SCAN_ITEMS 4
+#define NL_SCAN_BLOCK (NL_GEO_THREADS * NL_SCAN_ITEMS)
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* s_wave, int* total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+    if (lane == 63) s_wave[wid] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < NL_GEO_THREADS / 64; ++w) { int t = s_wave[w]; if (w < wid) base += t; tot += t; }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_blocks(const int* __restrict__ in, int* __restrict__ out,
+                                                                 int* __restrict__ block_sums, int n, int flag_mode)
+{
+    __shared__ int s_wave[NL_GEO_THREADS / 64];
+    const int base = blockIdx.x * NL_SCAN_BLOCK + threadIdx.x * NL_SCAN_ITEMS;
+    int v[NL_SCAN_ITEMS], sum = 0;
+#pragma unroll
+    for (int i = 0; i < NL_SCAN_ITEMS; ++i) {
+        int x = (base + i < n) ? in[base + i] : 0;
+        if (flag_mode) x = x > 0 ? 1 : 0;
+        v[i] = x; sum += x;
+    }
+    int tot;
+    int ex = block_exclusive_scan(sum, s_wave, &tot);
+#pragma unroll
+    for (int i = 0; i < NL_SCAN_ITEMS; ++i) { if (base + i < n) out[base + i] = ex; ex += v[i]; }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_sums(int* __restrict__ block_sums, int nblocks, int* __restrict__ total_out)
+{
+    __shared__ int s_wave[NL_GEO_THREADS / 64];
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < nblocks; c0 += NL_SCAN_BLOCK) {
+        const int base = c0 + threadIdx.x * NL_SCAN_ITEMS;
+        int v[NL_SCAN_ITEMS], sum = 0;
+#pragma unroll
+        for (int i = 0; i < NL_SCAN_ITEMS; ++i) { v[i] = (base + i < nblocks) ? block_sums[base + i] : 0; sum += v[i]; }
+        int tot;
+        int ex = block_exclusive_scan(sum, s_wave, &tot) + s_carry;
+#pragma unroll
+        for (int i = 0; i < NL_SCAN_ITEMS; ++i) { if (base + i < nblocks) block_sums[base + i] = ex; ex += v[i]; }
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = s_carry;
+}
+
+__global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_add(int* __restrict__ out, const int* __restrict__ block_sums, int n)
+{
+    const int base = blockIdx.x * NL_SCAN_BLOCK + threadIdx.x * NL_SCAN_ITEMS;
+    const int add = block_sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < NL_SCAN_ITEMS; ++i) if (base + i < n) out[base + i] += add;
+}
+
+// ray_of_rank[rank] = ray  for rays with hit_count > 0   (the reference's boolean-mask compaction
+// of hit rays, render_helpers.py:219-227)
+__global__ void k_compact_hit_rays(int N, const int* __restrict__ hit_count, const int* __restrict__ hit_rank,
+                                   int* __restrict__ ray_of_rank)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < N && hit_count[r] > 0) ray_of_rank[hit_rank[r]] = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sampler, pass 1 (count) and pass 2 (emit).  One hit ray per lane.  EMIT=false: per-ray sample
+// count, S_max, and the loss normalisers that depend only on geometry (criterion.py:67-88):
+// front/sdf mask counts over valid samples plus the per-ray constants of the padded slots
+// (depth 80 fill, voxel_helpers.py:590).  EMIT=true: compacted (voxel, depth, dist, ray) records
+// at samp_off[ray].
+// ---------------------------------------------------------------------------------------------
+struct SampleArgs {
+    int N;
+    const int* hit_idx; const float* hit_t0; const float* hit_t1;
+    const int* hit_count; const int* hit_rank; const int* ray_of_rank;
+    const float* cos_gt; const float* gt_dist;
+    float step_size; float tau; float max_depth;
+    unsigned seed; int use_hash_noise; int tail_always; int ray_id_base;
+    int* counters; double* dcounters;
+    int* samp_count;            // [N]  (0 for rays without hits)
+    const int* samp_off;        // [N]  exclusive scan of samp_count (emit pass)
+    int capacity;
+    int* s_vox; float* s_depth; float* s_dist; int* s_ray;
+};
+
+template <bool EMIT>
+__global__ __launch_bounds__(NL_GEO_THREADS) void k_sample(SampleArgs a)
+{
+    __shared__ int s_red[8];
+    __shared__ double s_dred[2];
+    if (threadIdx.x < 8) s_red[threadIdx.x] = 0;
+    if (threadIdx.x < 2) s_dred[threadIdx.x] = 0.0;
+    __syncthreads();
+    const int r = blockIdx.x * NL_GEO_THREADS + threadIdx.x;
+    int cnt = 0, nfs = 0, nsdf = 0, inv_fs = 0, inv_sdf = 0, guard = 0;
+    double inv_d2 = 0.0;
+    if (r < a.N && a.hit_count[r] > 0) {
+        const int P = a.counters[NLC_HMAX];
+        const int Rg = a.counters[NLC_R_GLOBAL];
+        const int rank = a.hit_rank[r] + a.counters[NLC_R_OFFSET];
+        int hi[NL_MAX_HITS]; float h0[NL_MAX_HITS], h1[NL_MAX_HITS];
+        float tot = 0.0f;
+#pragma unroll
+        for (int l = 0; l < NL_MAX_HITS; ++l) {
+            hi[l] = a.hit_idx[(size_t)r * NL_MAX_HITS + l];
+            h0[l] = a.hit_t0[(size_t)r * NL_MAX_HITS + l];
+            h1[l] = a.hit_t1[(size_t)r * NL_MAX_HITS + l];
+        }
+        for (int l = 0; l < P; ++l) tot = tot + ((hi[l] == -1) ? 0.0f : (h1[l] - h0[l]));
+        if (tot > 10.0f * NL_FILL_DEPTH) guard = 1;
+        NlTailCtx tc;
+        int first_rank;
+        nl_sampler_layout(rank, Rg, &tc.j_in_row, &tc.rays_in_row, &first_rank);
+        // single-GPU: the row's first ray is local.  (multi-GPU: ranks exchange these lists; see dist.py)
+        const int first_local = first_rank - a.counters[NLC_R_OFFSET];
+        const int first_ray = (first_local >= 0 && first_local < a.counters[NLC_R]) ? a.ray_of_rank[first_local] : r;
+        tc.row_first_idx = a.hit_idx + (size_t)first_ray * NL_MAX_HITS;
+        tc.tail_always = a.tail_always != 0;
+        const float c = a.cos_gt[r], d = a.gt_dist[r];
+        const unsigned rid = (unsigned)(r + a.ray_id_base);
+        const unsigned seed = a.seed;
+        const bool hash = a.use_hash_noise != 0;
+        auto noise = [&](int step) -> float { return hash ? nl_noise(seed, rid, (unsigned)step) : 0.5f; };
+        if (!guard) {
+            if (EMIT) {
+                const int off = a.samp_off[r];
+                const int cap = a.capacity;
+                auto emit = [&](int s, int vox, float depth, float dist) {
+                    const int p = off + s;
+                    if (p < cap) { a.s_vox[p] = vox; a.s_depth[p] = depth; a.s_dist[p] = dist < 0.0f ? 0.0f : dist; a.s_ray[p] = r; }
+                };
+                cnt = nl_sample_walk(hi, h0, h1, P, a.step_size, tc, noise, emit);
+            } else {
+                auto emit = [&](int s, int vox, float depth, float dist) {
+                    (void)s; (void)vox; (void)dist;
+                    bool f, m;
+                    nl_loss_masks(depth * c, d, a.tau, a.max_depth, &f, &m);
+                    nfs += f ? 1 : 0; nsdf += m ? 1 : 0;
+                };
+                cnt = nl_sample_walk(hi, h0, h1, P, a.step_size, tc, noise, emit);
+                bool f, m;
+                nl_loss_masks(NL_FILL_DEPTH * c, d, a.tau, a.max_depth, &f, &m);
+                inv_fs = f ? 1 : 0; inv_sdf = m ? 1 : 0;
+                inv_d2 = m ? (double)d * (double)d : 0.0;
+            }
+        }
+    }
+    if (EMIT) return;
+    if (r < a.N) a.samp_count[r] = cnt;
+    // block reductions -> a handful of atomics per block
+    int vmax = cnt;
+    int v1 = nfs, v2 = nsdf, v3 = inv_fs, v4 = inv_fs * cnt, v5 = inv_sdf, v6 = inv_sdf * cnt, v7 = guard;
+    double d1 = inv_d2, d2 = inv_d2 * (double)cnt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        vmax = max(vmax, __shfl_xor(vmax, off));
+        v1 += __shfl_xor(v1, off); v2 += __shfl_xor(v2, off); v3 += __shfl_xor(v3, off); v4 += __shfl_xor(v4, off);
+        v5 += __shfl_xor(v5, off); v6 += __shfl_xor(v6, off); v7 += __shfl_xor(v7, off);
+        d1 += __shfl_xor(d1, off); d2 += __shfl_xor(d2, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&s_red[0], vmax);
+        atomicAdd(&s_red[1], v1); atomicAdd(&s_red[2], v2); atomicAdd(&s_red[3], v3); atomicAdd(&s_red[4], v4);
+        atomicAdd(&s_red[5], v5); atomicAdd(&s_red[6], v6); atomicAdd(&s_red[7], v7);
+        atomicAdd(&s_dred[0], d1); atomicAdd(&s_dred[1], d2);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_red[0] > 0) atomicMax(&a.counters[NLC_SMAX], s_red[0]);
+        if (s_red[1]) atomicAdd(&a.counters[NLC_NFS], s_red[1]);
+        if (s_red[2]) atomicAdd(&a.counters[NLC_NSDF], s_red[2]);
+        if (s_red[3]) atomicAdd(&a.counters[NLC_INV_FS_RAYS], s_red[3]);
+        if (s_red[4]) atomicAdd(&a.counters[NLC_INV_FS_CNT], s_red[4]);
+        if (s_red[5]) atomicAdd(&a.counters[NLC_INV_SDF_RAYS], s_red[5]);
+        if (s_red[6]) atomicAdd(&a.counters[NLC_INV_SDF_CNT], s_red[6]);
+        if (s_red[7]) atomicMax(&a.counters[NLC_GUARD], 1);
+        if (s_dred[0] != 0.0) atomicAdd(&a.dcounters[NLD_INV_D2], s_dred[0]);
+        if (s_dred[1] != 0.0) atomicAdd(&a.dcounters[NLD_INV_D2CNT], s_dred[1]);
+    }
+}
+
+// one thread: global loss normalisers (criterion.py:84-88, :65 mean divisor) from the counters
+__global__ void k_loss_finalize(int* __restrict__ counters, NlLossScalars* __restrict__ ls,
+                                float fs_weight, float sdf_weight, float tau, float max_depth, int capacity)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int R = counters[NLC_R_GLOBAL], S = counters[NLC_SMAX];
+    const int n_fs = counters[NLC_NFS] + (S * counters[NLC_INV_FS_RAYS] - counters[NLC_INV_FS_CNT]);
+    const int n_sdf = counters[NLC_NSDF] + (S * counters[NLC_INV_SDF_RAYS] - counters[NLC_INV_SDF_CNT]);
+    const float nf = (float)n_fs, ns = (float)n_sdf;
+    const float tot = ns + nf;
+    NlLossScalars o;
+    o.w_fs = 1.0f - nf / tot;
+    o.w_sdf = 1.0f - ns / tot;
+    const float n = (float)((long long)R * (long long)S);
+    o.two_over_n = 2.0f / n;
+    o.inv_n = 1.0f / n;
+    o.fs_weight = fs_weight; o.sdf_weight = sdf_weight; o.tau = tau; o.max_depth = max_depth;
+    o.R = R; o.S_max = S; o.P = counters[NLC_P]; o.pad = 0;
+    if (counters[NLC_P] > capacity) { counters[NLC_OVERFLOW] = 1; o.P = capacity; }
+    *ls = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// (b1) drop-in kernel behind grid.inverse_cdf_sampling: the reference kernel's semantics on the
+// reference tensor layouts ([b, num_rays, *]); one ray per lane instead of one block per row.
+// Outputs must be pre-filled (-1 / 0 / 0) by the caller like sample.cpp:78-87 does.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NL_GEO_THREADS) void k_inverse_cdf_raw(
+    int b, int num_rays, int max_hits, int max_steps, float fixed_step_size,
+    const int* __restrict__ pts_idx, const float* __restrict__ min_depth, const float* __restrict__ max_depth,
+    const float* __restrict__ noise, const float* __restrict__ probs, const float* __restrict__ steps,
+    int* __restrict__ sampled_idx, float* __restrict__ sampled_depth, float* __restrict__ sampled_dists)
+{
+    const long long gid = (long long)blockIdx.x * NL_GEO_THREADS + threadIdx.x;
+    if (gid >= (long long)b * num_rays) return;
+    const int bi = (int)(gid / num_rays), j = (int)(gid - (long long)bi * num_rays);
+    const size_t rowH = (size_t)bi * num_rays * max_hits, rowK = (size_t)bi * num_rays * max_steps;
+    const int* idx_row = pts_idx + rowH;
+    const int H = j * max_hits;
+    const size_t K = rowK + (size_t)j * max_steps;
+    const int* idx = idx_row + H; const float* t0 = min_depth + rowH + H; const float* t1 = max_depth + rowH + H;
+    const float* pr = probs + rowH + H; const float* nz = noise + K;
+    int curr_bin = 0, s = 0;
+    float curr_min_depth = t0[0], curr_max_depth = t1[0], curr_min_cdf = 0.0f, curr_max_cdf = pr[0];
+    const float st = steps[(size_t)bi * num_rays + j];
+    float step_size = (float)(1.0 / (double)st);
+    float z_low = curr_min_depth;
+    const int total_steps = (int)ceilf(st);
+    bool done = false;
+    if (fixed_step_size > 0.0f) step_size = fixed_step_size;
+    for (int cs = 0; cs < total_steps; ++cs) {
+        const float curr_cdf = ((float)cs + nz[cs]) * step_size;
+        while (curr_cdf > curr_max_cdf) {
+            sampled_idx[K + s] = idx[curr_bin];
+            sampled_dists[K + s] = curr_max_depth - z_low;
+            sampled_depth[K + s] = (curr_max_depth + z_low) * 0.5f;
+            ++curr_bin; ++s;
+            if (curr_bin >= max_hits || idx[curr_bin] == -1) { done = true; break; }
+            curr_min_depth = t0[curr_bin]; curr_max_depth = t1[curr_bin];
+            curr_min_cdf = curr_max_cdf; curr_max_cdf = curr_max_cdf + pr[curr_bin];
+            z_low = curr_min_depth;
+        }
+        if (done) break;
+        const float u = (curr_cdf - curr_min_cdf) / (curr_max_cdf - curr_min_cdf);
+        const float z = curr_min_depth + u * (curr_max_depth - curr_min_depth);
+        sampled_idx[K + s] = idx[curr_bin];
+        sampled_dists[K + s] = z - z_low;
+        sampled_depth[K + s] = (z + z_low) * 0.5f;
+        z_low = z; ++s;
+    }
+    while (z_low < curr_max_depth && !done && num_rays > H + curr_bin) {
+        sampled_idx[K + s] = idx[curr_bin];
+        sampled_dists[K + s] = curr_max_depth - z_low;
+        sampled_depth[K + s] = (curr_max_depth + z_low) * 0.5f;
+        ++curr_bin; ++s;
+        if (curr_bin >= max_hits || idx_row[curr_bin] == -1) break;      // the row's first ray
+        curr_min_depth = t0[curr_bin]; curr_max_depth = t1[curr_bin];
+        z_low = curr_min_depth;
+    }
+}
+
+// =============================================================================================
+// C ABI launchers (declared in include/nerfloam_hip.h)
+// =============================================================================================
+extern "C" {
+
+int nl_svo_intersect(const float* ray_start, const float* ray_dir, const float* points, const int* children,
+                     int b, int m, int n, float voxelsize, int n_max,
+                     int* idx, float* min_depth, float* max_depth, void* stream)
+{
+    if (!ray_start || !ray_dir || !points || !children || !idx || !min_depth || !max_depth) return NL_ERR_INVALID_ARG;
+    if (b <= 0 || m <= 0 || n <= 0 || n_max <= 0 || n_max > NL_MAX_HITS) return NL_ERR_INVALID_ARG;
+    const long long total = (long long)b * m;
+    hipLaunchKernelGGL(k_svo_intersect_raw, dim3(nl_div_up(total, NL_GEO_THREADS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream,
+                       b, n, m, voxelsize, n_max, ray_start, ray_dir, points, children, idx, min_depth, max_depth);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+int nl_inverse_cdf_sampling(const int* pts_idx, const float* min_depth, const float* max_depth, const float* noise,
+                            const float* probs, const float* steps, int b, int num_rays, int max_hits, int max_steps,
+                            float fixed_step_size, int* sampled_idx, float* sampled_depth, float* sampled_dists, void* stream)
+{
+    if (!pts_idx || !min_depth || !max_depth || !noise || !probs || !steps || !sampled_idx || !sampled_depth || !sampled_dists)
+        return NL_ERR_INVALID_ARG;
+    if (b <= 0 || num_rays <= 0 || max_hits <= 0 || max_steps <= 0) return NL_ERR_INVALID_ARG;
+    const long long total = (long long)b * num_rays;
+    hipLaunchKernelGGL(k_inverse_cdf_raw, dim3(nl_div_up(total, NL_GEO_THREADS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream,
+                       b, num_rays, max_hits, max_steps, fixed_step_size, pts_idx, min_depth, max_depth, noise, probs, steps,
+                       sampled_idx, sampled_depth, sampled_dists);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+int nl_ray_intersect(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
+                     const float* poses, const float* centres, const int* structure, float voxel_size, float max_distance,
+                     float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
+                     int* counters, void* stream)
+{
+    if (N <= 0 || !rays_d_sensor || !points_gt || !cos_gt || !poses || !centres || !structure || !rays_d_world || !gt_dist ||
+        !hit_idx || !hit_t0 || !hit_t1 || !hit_count || !counters) return NL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_ray_intersect, dim3(nl_div_up(N, NL_GEO_THREADS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream,
+                       N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, centres, structure, voxel_size, max_distance,
+                       rays_d_world, gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+// exclusive scan of in[0..n) into out, total -> *total_out (device).  workspace: >= ceil(n/1024) ints.
+int nl_exclusive_scan_i32(const int* in, int* out, int n, int flag_mode, int* total_out, int* workspace, void* stream)
+{
+    if (n <= 0 || !in || !out || !total_out || !workspace) return NL_ERR_INVALID_ARG;
+    const int nb = nl_div_up(n, NL_SCAN_BLOCK);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(NL_GEO_THREADS), 0, s, in, out, workspace, n, flag_mode);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(NL_GEO_THREADS), 0, s, workspace, nb, total_out);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(NL_GEO_THREADS), 0, s, out, workspace, n);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+int nl_compact_hit_rays(int N, const int* hit_count, const int* hit_rank, int* ray_of_rank, void* stream)
+{
+    if (N <= 0 || !hit_count || !hit_rank || !ray_of_rank) return NL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_compact_hit_rays, dim3(nl_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, hit_count, hit_rank, ray_of_rank);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+int nl_sample_rays(int emit, int N, const int* hit_idx, const float* hit_t0, const float* hit_t1, const int* hit_count,
+                   const int* hit_rank, const int* ray_of_rank, const float* cos_gt, const float* gt_dist,
+                   float step_size, float tau, float max_depth, unsigned seed, int use_hash_noise, int tail_always, int ray_id_base,
+                   int* counters, int* samp_count, const int* samp_off, int capacity,
+                   int* s_vox, float* s_depth, float* s_dist, int* s_ray, void* stream)
+{
+    if (N <= 0 || !hit_idx || !hit_t0 || !hit_t1 || !hit_count || !hit_rank || !ray_of_rank || !cos_gt || !gt_dist || !counters || !samp_count)
+        return NL_ERR_INVALID_ARG;
+    if (emit && (!samp_off || !s_vox || !s_depth || !s_dist || !s_ray)) return NL_ERR_INVALID_ARG;
+    SampleArgs a;
+    a.N = N; a.hit_idx = hit_idx; a.hit_t0 = hit_t0; a.hit_t1 = hit_t1; a.hit_count = hit_count; a.hit_rank = hit_rank;
+    a.ray_of_rank = ray_of_rank; a.cos_gt = cos_gt; a.gt_dist = gt_dist; a.step_size = step_size; a.tau = tau; a.max_depth = max_depth;
+    a.seed = seed; a.use_hash_noise = use_hash_noise; a.tail_always = tail_always; a.ray_id_base = ray_id_base;
+    a.counters = counters; a.dcounters = (double*)(counters + NL_CNT_INTS);
+    a.samp_count = samp_count; a.samp_off = samp_off; a.capacity = capacity;
+    a.s_vox = s_vox; a.s_depth = s_depth; a.s_dist = s_dist; a.s_ray = s_ray;
+    if (emit) hipLaunchKernelGGL(k_sample<true>, dim3(nl_div_up(N, NL_GEO_THREADS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);
+    else      hipLaunchKernelGGL(k_sample<false>, dim3(nl_div_up(N, NL_GEO_THREADS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+int nl_loss_finalize(int* counters, void* loss_scalars, float fs_weight, float sdf_weight, float tau, float max_depth,
+                     int capacity, void* stream)
+{
+    if (!counters || !loss_scalars) return NL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, counters, (NlLossScalars*)loss_scalars,
+                       fs_weight, sdf_weight, tau, max_depth, capacity);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,201 @@
+// nl_octree.cpp -- host-side sparse voxel octree behind the `svo.Octree` operator surface.
+//
+// Reference behaviour: third_party/sparse_octree/src/octree.cpp:36-111 (init, insert),
+// :151-171 (find_octant), :263-283 (count), :293-342 (get_centres_and_children),
+// include/utils.h:64-109 (Morton codes).  Same results (node id = creation order, SURFACE/FEATURE
+// leaf types, BFS export that hides FEATURE children), different structure: nodes live in flat
+// index-linked arrays (no per-node heap allocation, no pointer chasing across the heap), the node
+// counter is per instance (the reference's is process-global), and the export writes
+// straight into caller-provided buffers in the layouts the kernels consume.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <queue>
+#include <vector>
+
+namespace {
+
+enum : int8_t { T_NONLEAF = -1, T_SURFACE = 0, T_FEATURE = 1 };
+
+struct Node {
+    uint64_t code;
+    int32_t child[8];
+    uint32_t side;
+    int8_t type;
+    bool leaf;
+};
+
+struct Octree {
+    int size = 0, max_level = 0;
+    std::vector<Node> nodes;
+
+    int new_node() {
+        Node n;
+        n.code = 0; n.side = 0; n.type = T_NONLEAF; n.leaf = false;
+        for (int i = 0; i < 8; ++i) n.child[i] = -1;
+        nodes.push_back(n);
+        return (int)nodes.size() - 1;
+    }
+};
+
+inline uint64_t spread3(uint64_t v) {
+    uint64_t x = v & 0x1fffff;
+    x = (x | x << 32) & 0x1f00000000ffffULL;
+    x = (x | x << 16) & 0x1f0000ff0000ffULL;
+    x = (x | x << 8) & 0x100f00f00f00f00fULL;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ULL;
+    x = (x | x << 2) & 0x1249249249249249ULL;
+    return x;
+}
+inline uint64_t gather3(uint64_t v) {
+    uint64_t x = v & 0x1249249249249249ULL;
+    x = (x | x >> 2) & 0x10c30c30c30c30c3ULL;
+    x = (x | x >> 4) & 0x100f00f00f00f00fULL;
+    x = (x | x >> 8) & 0x1f0000ff0000ffULL;
+    x = (x | x >> 16) & 0x1f00000000ffffULL;
+    x = (x | x >> 32) & 0x1fffff;
+    return x;
+}
+// prefix mask of a level-(i) node: top 3*(i+1) bits of the 63-bit key (utils.h:41-62 MASK[i])
+inline uint64_t prefix_mask(int i) { return i >= 20 ? 0x7fffffffffffffffULL : (0x7fffffffffffffffULL & ~((1ULL << (60 - 3 * i)) - 1ULL)); }
+inline uint64_t morton(int x, int y, int z) {
+    return (spread3((uint64_t)(int64_t)x) | (spread3((uint64_t)(int64_t)y) << 1) | (spread3((uint64_t)(int64_t)z) << 2)) & prefix_mask(20);
+}
+
+const int DX[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+const int DY[8] = {0, 0, 1, 1, 0, 0, 1, 1};
+const int DZ[8] = {0, 1, 0, 1, 0, 1, 0, 1};
+
+inline int octant_of(int x, int y, int z, unsigned edge) {
+    return ((x & edge) > 0) + 2 * ((y & edge) > 0) + 4 * ((z & edge) > 0);
+}
+
+int find_leaf(const Octree& t, int x, int y, int z) {
+    int n = 0;
+    unsigned edge = (unsigned)t.size / 2;
+    for (int d = 1; d <= t.max_level; edge /= 2, ++d) {
+        n = t.nodes[n].child[octant_of(x, y, z, edge)];
+        if (n < 0) return -1;
+    }
+    return n;
+}
+
+}  // namespace
+
+extern "C" {
+
+void* nl_octree_create(long long grid_dim)
+{
+    if (grid_dim <= 1) return nullptr;
+    Octree* t = new Octree();
+    t->size = (int)grid_dim;
+    t->max_level = (int)std::log2((double)t->size);
+    int r = t->new_node();
+    t->nodes[r].side = (uint32_t)t->size;
+    return t;
+}
+
+void nl_octree_destroy(void* h) { delete (Octree*)h; }
+
+// insert voxel coordinates [M,3] int32 (each voxel + its 7 (+x,+y,+z) neighbours as vertices)
+int nl_octree_insert(void* h, const int* pts, long long npts)
+{
+    if (!h || (!pts && npts > 0)) return 1;
+    Octree& t = *(Octree*)h;
+    const int shift = 21 - t.max_level - 1;
+    for (long long i = 0; i < npts; ++i) {
+        for (int j = 0; j < 8; ++j) {
+            const int x = pts[3 * i] + DX[j], y = pts[3 * i + 1] + DY[j], z = pts[3 * i + 2] + DZ[j];
+            const uint64_t key = morton(x, y, z);
+            int n = 0;
+            unsigned edge = (unsigned)t.size / 2;
+            for (int d = 1; d <= t.max_level; edge /= 2, ++d) {
+                const int cid = octant_of(x, y, z, edge);
+                int c = t.nodes[n].child[cid];
+                if (c < 0) {
+                    c = t.new_node();
+                    Node& nd = t.nodes[c];
+                    nd.code = key & prefix_mask(d + shift);
+                    nd.side = edge;
+                    nd.leaf = (d == t.max_level);
+                    nd.type = nd.leaf ? (j == 0 ? T_SURFACE : T_FEATURE) : T_NONLEAF;
+                    t.nodes[n].child[cid] = c;
+                } else if (t.nodes[c].type == T_FEATURE && j == 0) {
+                    t.nodes[c].type = T_SURFACE;
+                }
+                n = c;
+            }
+        }
+    }
+    return 0;
+}
+
+long long nl_octree_count_nodes(void* h) { return h ? (long long)((Octree*)h)->nodes.size() : 0; }
+
+long long nl_octree_count_leaf_nodes(void* h)
+{
+    if (!h) return 0;
+    long long c = 0;
+    for (const Node& n : ((Octree*)h)->nodes) c += (n.type == T_SURFACE);
+    return c;
+}
+
+int nl_octree_has_voxel(void* h, int x, int y, int z) { return h && find_leaf(*(Octree*)h, x, y, z) >= 0; }
+
+// get_centres_and_children: voxels[n,4] f32 (x,y,z,side; zero rows for FEATURE leaves),
+// children[n,8] f32 (-1 = absent or FEATURE leaf), features[n,8] i32 (corner-vertex node ids of
+// SURFACE leaves, -1 elsewhere).  Buffers are fully written.
+int nl_octree_export(void* h, float* voxels, float* children, int* features)
+{
+    if (!h || !voxels || !children || !features) return 1;
+    const Octree& t = *(Octree*)h;
+    const size_t n = t.nodes.size();
+    std::memset(voxels, 0, n * 4 * sizeof(float));
+    for (size_t i = 0; i < n * 8; ++i) { children[i] = -1.0f; features[i] = -1; }
+    std::vector<int> queue;
+    queue.reserve(n);
+    queue.push_back(0);
+    for (size_t head = 0; head < queue.size(); ++head) {
+        const int k = queue[head];
+        const Node& nd = t.nodes[k];
+        const int x = (int)gather3(nd.code), y = (int)gather3(nd.code >> 1), z = (int)gather3(nd.code >> 2);
+        float* v = voxels + 4 * (size_t)k;
+        v[0] = (float)x; v[1] = (float)y; v[2] = (float)z; v[3] = (float)nd.side;
+        if (nd.type == T_SURFACE) {
+            for (int i = 0; i < 8; ++i) {
+                // the reference looks the corner up through float coordinates (octree.cpp:319-325)
+                const int q = find_leaf(t, (int)(v[0] + (float)DX[i]), (int)(v[1] + (float)DY[i]), (int)(v[2] + (float)DZ[i]));
+                if (q >= 0) features[8 * (size_t)k + i] = q;
+            }
+        }
+        for (int i = 0; i < 8; ++i) {
+            const int c = nd.child[i];
+            if (c >= 0 && t.nodes[c].type != T_FEATURE) {
+                queue.push_back(c);
+                children[8 * (size_t)k + i] = (float)c;
+            }
+        }
+    }
+    return 0;
+}
+
+// Fused export for the kernels (mapping.py:319-327 folded in): centres[n,3] = (xyz + side/2)*voxel_size,
+// structure[n,9] = [children(int), side], vertex_idx[n,8].
+int nl_octree_export_device_layout(void* h, float voxel_size, float* centres, int* structure, int* vertex_idx)
+{
+    if (!h || !centres || !structure || !vertex_idx) return 1;
+    const Octree& t = *(Octree*)h;
+    const size_t n = t.nodes.size();
+    std::vector<float> vox(n * 4), ch(n * 8);
+    int rc = nl_octree_export(h, vox.data(), ch.data(), vertex_idx);
+    if (rc) return rc;
+    for (size_t k = 0; k < n; ++k) {
+        const float side = vox[4 * k + 3];
+        for (int a = 0; a < 3; ++a) centres[3 * k + a] = (vox[4 * k + a] + side / 2.0f) * voxel_size;
+        for (int i = 0; i < 8; ++i) structure[9 * k + i] = (int)ch[8 * k + i];
+        structure[9 * k + 8] = (int)side;
+    }
+    return 0;
+}
+
+}  // extern "C"

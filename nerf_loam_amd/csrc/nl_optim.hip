@@ -1,0 +1,151 @@
+// nl_optim.hip -- fused optimiser step: Adam on the bf16 voxel embeddings (bf16 state, the seven
+// rounding points of torch's bf16 tensors), on the fp32 decoder block, and on the SE3 pose 6-vectors
+// (with the Rodrigues tail of the pose gradient).  HBM-bound element-wise kernels.
+//
+// Reference behaviour: torch.optim.Adam as constructed in src/variations/render_helpers.py:341-353
+// and :448-450 (default betas/eps, fresh state per call), src/se3pose.py:18-35 for the pose tail.
+#include "nl_common.h"
+
+// embeddings: g = bf16(fp32 accumulator) ; accumulator is reset for the next iteration
+__global__ void k_adam_emb(uint16_t* __restrict__ p, float* __restrict__ g_acc, uint16_t* __restrict__ m, uint16_t* __restrict__ v,
+                           long long n, NlAdamHyper h)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float ga = g_acc[i];
+        const uint16_t pm = m[i], pv = v[i];
+        if (ga == 0.0f && pm == 0 && pv == 0) continue;      // 0/(0+eps) = 0: untouched rows never move
+        g_acc[i] = 0.0f;
+        uint16_t pp = p[i], mm = pm, vv = pv;
+        nl_adam_bf16(&pp, nl_f32_to_bf16(ga), &mm, &vv, h);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+// convert fp32 accumulators to the bf16 gradient the reference optimiser sees (for tests / RCCL path)
+__global__ void k_emb_grad_bf16(const float* __restrict__ g_acc, uint16_t* __restrict__ g, long long n)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        g[i] = nl_f32_to_bf16(g_acc[i]);
+}
+
+__global__ void k_adam_f32(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                           int n, NlAdamHyper h)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float pp = p[i], mm = m[i], vv = v[i];
+    nl_adam_f32(&pp, g[i], &mm, &vv, h);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+}
+
+// W2T[k][j] = W2[j][k]  (the forward GEMM streams W2^T rows as coalesced MFMA B operands)
+__global__ void k_transpose_w2(const float* __restrict__ params, float* __restrict__ W2T)
+{
+    __shared__ float t[32][33];
+    const float* W2 = params + NL_OFF_W2;
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) t[r][threadIdx.x] = W2[(by + r) * NL_W + bx + threadIdx.x];
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) W2T[(bx + r) * NL_W + by + threadIdx.x] = t[threadIdx.x][r];
+}
+
+// poses12[f] = [R(w) row-major | t]   from pose6[f] = [t, w]     (se3pose.py:18-35)
+__global__ void k_pose_matrix(const float* __restrict__ pose6, float* __restrict__ poses12, int F)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    float R[9];
+    nl_rodrigues(pose6 + 6 * f + 3, R);
+    for (int i = 0; i < 9; ++i) poses12[12 * f + i] = R[i];
+    for (int i = 0; i < 3; ++i) poses12[12 * f + 9 + i] = pose6[6 * f + i];
+}
+
+// pose gradient tail + Adam: g_pose[f] = (dL/dt[3], dL/dR[9]) -> dL/d(t,w) -> Adam (if enabled) ->
+// refreshed pose matrices.  grad6_out (optional) receives the 6-vector gradient; g_pose is cleared.
+__global__ void k_pose_step(float* __restrict__ pose6, float* __restrict__ g_pose, float* __restrict__ m, float* __restrict__ v,
+                            const int* __restrict__ enable, float* __restrict__ grad6_out, float* __restrict__ poses12,
+                            int F, NlAdamHyper h, int apply)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    float g6[6], gw[3];
+    nl_rodrigues_bwd(pose6 + 6 * f + 3, g_pose + 12 * f + 3, gw);
+    for (int i = 0; i < 3; ++i) { g6[i] = g_pose[12 * f + i]; g6[3 + i] = gw[i]; }
+    for (int i = 0; i < 12; ++i) g_pose[12 * f + i] = 0.f;
+    if (grad6_out) for (int i = 0; i < 6; ++i) grad6_out[6 * f + i] = g6[i];
+    if (apply && (!enable || enable[f])) {
+        for (int i = 0; i < 6; ++i) nl_adam_f32(&pose6[6 * f + i], g6[i], &m[6 * f + i], &v[6 * f + i], h);
+    }
+    float R[9];
+    nl_rodrigues(pose6 + 6 * f + 3, R);
+    for (int i = 0; i < 9; ++i) poses12[12 * f + i] = R[i];
+    for (int i = 0; i < 3; ++i) poses12[12 * f + 9 + i] = pose6[6 * f + i];
+}
+
+extern "C" {
+
+static NlAdamHyper hyper(double lr, int step) { return nl_adam_hyper(lr, step, 0.9, 0.999, 1e-8); }
+
+int nl_adam_embeddings(void* emb, float* g_acc, void* m, void* v, long long n_elems, double lr, int step, void* stream)
+{
+    if (!emb || !g_acc || !m || !v || n_elems <= 0 || step <= 0) return NL_ERR_INVALID_ARG;
+    const int blocks = (int)((n_elems + 255) / 256 < 4096 ? (n_elems + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_adam_emb, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (uint16_t*)emb, g_acc, (uint16_t*)m, (uint16_t*)v,
+                       n_elems, hyper(lr, step));
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+int nl_embedding_grad_bf16(const float* g_acc, void* g_bf16, long long n_elems, void* stream)
+{
+    if (!g_acc || !g_bf16 || n_elems <= 0) return NL_ERR_INVALID_ARG;
+    const int blocks = (int)((n_elems + 255) / 256 < 4096 ? (n_elems + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_emb_grad_bf16, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g_acc, (uint16_t*)g_bf16, n_elems);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+int nl_adam_f32(float* p, const float* g, float* m, float* v, int n, double lr, int step, void* stream)
+{
+    if (!p || !g || !m || !v || n <= 0 || step <= 0) return NL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_adam_f32, dim3(nl_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, hyper(lr, step));
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream)
+{
+    if (!params || !W2T) return NL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_transpose_w2, dim3(NL_W / 32, NL_W / 32), dim3(32, 8), 0, (hipStream_t)stream, params, W2T);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+int nl_pose_matrices(const float* pose6, float* poses12, int F, void* stream)
+{
+    if (!pose6 || !poses12 || F <= 0) return NL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_pose_matrix, dim3(nl_div_up(F, 64)), dim3(64), 0, (hipStream_t)stream, pose6, poses12, F);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+int nl_pose_step(float* pose6, float* g_pose, float* m, float* v, const int* enable, float* grad6_out, float* poses12,
+                 int F, double lr, int step, int apply, void* stream)
+{
+    if (!pose6 || !g_pose || !m || !v || !poses12 || F <= 0 || step <= 0) return NL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_pose_step, dim3(nl_div_up(F, 64)), dim3(64), 0, (hipStream_t)stream, pose6, g_pose, m, v, enable, grad6_out,
+                       poses12, F, hyper(lr, step), apply);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+int nl_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int nl_version(void) { return 100; }
+
+}  // extern "C"

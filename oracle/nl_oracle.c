@@ -102,6 +102,11 @@ void orc_svo_intersect(int m, int n, float voxelsize, int n_max,
  * The tail loop (:224-237) compares num_rays with the ELEMENT offset H + curr_bin and reads
  * pts_idx[curr_bin] of the row's first ray - kept bug-for-bug.
  * ------------------------------------------------------------------------------------------ */
+static int g_tail_always = 0;
+/* EXTENSION (not reference behaviour): tail_always != 0 makes the closing loop run for every ray and
+ * test the ray's OWN next hit - the "fixed" sampler SURVEY B5 asks to provide behind a flag. */
+void orc_set_tail_always(int v) { g_tail_always = v; }
+
 void orc_inverse_cdf_sampling(int b, int num_rays, int max_hits, int max_steps,
                               float fixed_step_size,
                               const int *pts_idx_, const float *min_depth_, const float *max_depth_,
@@ -156,12 +161,13 @@ void orc_inverse_cdf_sampling(int b, int num_rays, int max_hits, int max_steps,
                 ++s;
             }
             /* tail: "if there are bins still remained" - position dependent, see header */
-            while (z_low < curr_max_depth && !done && num_rays > H + curr_bin) {
+            while (z_low < curr_max_depth && !done && (g_tail_always || num_rays > H + curr_bin)) {
                 sampled_idx[K + s] = pts_idx[H + curr_bin];
                 sampled_dists[K + s] = curr_max_depth - z_low;
                 sampled_depth[K + s] = (curr_max_depth + z_low) * 0.5f;
                 ++curr_bin; ++s;
-                if (curr_bin >= max_hits || pts_idx[curr_bin] == -1) break;   /* row's ray 0 */
+                if (curr_bin >= max_hits) break;
+                if ((g_tail_always ? pts_idx[H + curr_bin] : pts_idx[curr_bin]) == -1) break;   /* reference: row's ray 0 */
                 curr_min_depth = min_depth[H + curr_bin];
                 curr_max_depth = max_depth[H + curr_bin];
                 z_low = curr_min_depth;

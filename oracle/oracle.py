@@ -62,6 +62,7 @@ def lib():
     L.orc_svo_intersect.restype = None
     L.orc_inverse_cdf_sampling.argtypes = [ctypes.c_int] * 4 + [ctypes.c_float] + [P] * 9
     L.orc_inverse_cdf_sampling.restype = None
+    L.orc_set_tail_always.argtypes = [ctypes.c_int]
     L.orc_octree_create.argtypes = [ctypes.c_int64]
     L.orc_octree_create.restype = P
     L.orc_octree_destroy.argtypes = [P]
@@ -302,7 +303,7 @@ def ray_sample(idx, t0, t1, step_size, noise=None, tail_mode=0):
     idx/t0/t1: [R,P] for the HIT rays only.  noise: None -> 0.5 (the wrapper's deterministic
     mode) or an [R, >=max_steps] array indexed by (hit-ray rank, step).
     tail_mode 0 = reference behaviour (position-dependent tail loop, SURVEY B5);
-    tail_mode 1 = "fixed": every ray is alone in its row, so the tail loop always runs.
+    tail_mode 1 = "fixed" extension: the tail loop always runs and tests the ray's own next hit.
     Returns (sampled_idx, sampled_depth, sampled_dists) [R,S] or None (the reference's guard)."""
     R, P = idx.shape
     inv = idx == -1
@@ -317,13 +318,10 @@ def ray_sample(idx, t0, t1, step_size, noise=None, tail_mode=0):
     if tot.max() > 10 * MAX_DEPTH_FILL:
         return None
 
-    if tail_mode == 1:
-        G, L = R, 1
-        Htot = R
-    else:
-        G = SAMPLER_G
-        L = int(np.ceil(R / G))
-        Htot = L * G
+    G = SAMPLER_G
+    L = int(np.ceil(R / G))
+    Htot = L * G
+    lib().orc_set_tail_always(1 if tail_mode == 1 else 0)
 
     def pad(a):
         if Htot > R:
@@ -359,6 +357,7 @@ def ray_sample(idx, t0, t1, step_size, noise=None, tail_mode=0):
         v3(s_dep)[:, c0:c1] = o_dep
         v3(s_dst)[:, c0:c1] = o_dst
 
+    lib().orc_set_tail_always(0)
     s_idx, s_dep, s_dst = s_idx[:R], s_dep[:R], s_dst[:R]
     S = int((s_idx != -1).sum(-1).max())
     s_idx, s_dep, s_dst = s_idx[:, :S].copy(), s_dep[:, :S].copy(), s_dst[:, :S].copy()

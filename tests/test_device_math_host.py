@@ -1,0 +1,180 @@
+"""CPU: the per-lane device functions of the HIP kernels (nerf_loam_amd/csrc/nl_device_math.h),
+compiled for the host by tests/host_harness.cpp, against the oracle.  Integer/index outputs and
+IEEE fp32 geometry must be bit-identical."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def hh():
+    out_dir = os.path.join(HERE, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "host_harness.so")
+    src = os.path.join(HERE, "host_harness.cpp")
+    hdr = os.path.join(HERE, "..", "nerf_loam_amd", "csrc", "nl_device_math.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", src, "-o", so])
+    return ctypes.CDLL(so)
+
+
+def p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def scene():
+    sc = H.build_oracle_scene(64, 48, 777)
+    rng = np.random.default_rng(3)
+    pts, cos = sc["points"], sc["cos"]
+    pose = np.array([2000.02, 1999.97, 2000.01, 0.004, -0.003, 0.01], np.float32)
+    o, d = O.ray_setup(__import__("nerf_loam_amd.synthetic", fromlist=["x"]).unit_dirs(pts), O.rodrigues(pose[3:]), pose[:3])
+    return dict(sc=sc, o=o, d=d, cos=cos, pts=pts)
+
+
+def test_intersect_sort_cull_bit_exact(hh, scene):
+    ms = scene["sc"]["ms"]
+    o, d = scene["o"], scene["d"]
+    N = len(o)
+    idx = np.zeros((N, 20), np.int32); t0 = np.zeros((N, 20), np.float32); t1 = np.zeros((N, 20), np.float32)
+    cnt = np.zeros(N, np.int32)
+    hh.hh_ray_intersect(N, p(o), p(d), p(ms.centres), p(ms.structure), ctypes.c_float(0.2), ctypes.c_float(50.0),
+                        p(idx), p(t0), p(t1), p(cnt))
+    oi, o0, o1, hits = O.ray_intersect(o, d, ms.centres, ms.structure, 0.2, 50.0)
+    Hm = oi.shape[1]
+    assert cnt.max() == Hm
+    assert np.array_equal(idx[:, :Hm], oi)
+    assert np.array_equal(t0[:, :Hm], o0) and np.array_equal(t1[:, :Hm], o1)
+    assert (idx[:, Hm:] == -1).all()
+    assert np.array_equal(cnt > 0, hits)
+
+
+def test_raw_intersect_matches_reference_kernel_restatement(hh, scene):
+    ms = scene["sc"]["ms"]
+    o, d = scene["o"][:500], scene["d"][:500]
+    for n_max in (20, 3):
+        idx = np.zeros((500, n_max), np.int32); t0 = np.zeros((500, n_max), np.float32); t1 = np.zeros((500, n_max), np.float32)
+        hh.hh_svo_intersect_raw(500, p(o), p(d), p(ms.centres), p(ms.structure), ctypes.c_float(0.2), n_max, p(idx), p(t0), p(t1))
+        oi, o0, o1 = O.svo_intersect(o, d, ms.centres, ms.structure, 0.2, n_max)
+        assert np.array_equal(idx, oi) and np.array_equal(t0, o0) and np.array_equal(t1, o1)
+
+
+@pytest.mark.parametrize("tail_mode,use_hash,step", [(0, 1, 0.1), (0, 0, 0.04), (1, 1, 0.1)])
+def test_sampler_bit_exact(hh, scene, tail_mode, use_hash, step):
+    ms = scene["sc"]["ms"]
+    o, d = scene["o"], scene["d"]
+    oi, o0, o1, hits = O.ray_intersect(o, d, ms.centres, ms.structure, 0.2, 50.0)
+    hr = np.nonzero(hits)[0]
+    R, P = len(hr), oi.shape[1]
+    noise = O.hash_noise(777, hr, 4096) if use_hash else None
+    s_idx, s_dep, s_dst = O.ray_sample(oi[hr], o0[hr], o1[hr], step, noise=noise, tail_mode=tail_mode)
+    S = s_idx.shape[1]
+    pad = lambda a, fill: np.ascontiguousarray(np.concatenate([a[hr], np.full((R, 20 - P), fill, a.dtype)], 1))
+    hi, h0, h1 = pad(oi, -1), pad(o0, np.float32(50)), pad(o1, np.float32(50))
+    cap = S + 8
+    g_idx = -np.ones((R, cap), np.int32); g_dep = np.full((R, cap), 80, np.float32); g_dst = np.zeros((R, cap), np.float32)
+    cnt = np.zeros(R, np.int32)
+    ids = hr.astype(np.uint32)
+    hh.hh_sample(R, p(hi), p(h0), p(h1), P, ctypes.c_float(step), 777, use_hash, tail_mode, p(ids), cap,
+                 p(g_idx), p(g_dep), p(g_dst), p(cnt))
+    assert cnt.max() == S
+    assert np.array_equal(g_idx[:, :S], s_idx)
+    assert np.array_equal(g_dep[:, :S], s_dep)
+    assert np.array_equal(g_dst[:, :S], s_dst)
+
+
+def test_noise_hash(hh):
+    rays = np.array([0, 1, 77, 131071, 2 ** 31 + 5], np.uint32)
+    out = np.zeros((len(rays), 64), np.float32)
+    hh.hh_noise(777, len(rays), p(rays), 64, p(out))
+    assert np.array_equal(out, O.hash_noise(777, rays, 64))
+    assert out.min() >= 0.001 and out.max() <= 0.999
+
+
+def test_adam_bf16_bit_exact_vs_torch_golden(hh, golden_dir):
+    g = np.load(os.path.join(golden_dir, "adam.npz"))
+    pbits = O.bf16_bits(g["p0"]).reshape(-1).copy()
+    m = np.zeros_like(pbits); v = np.zeros_like(pbits)
+    for t, grad in enumerate(g["gs"]):
+        gb = O.bf16_bits(grad).reshape(-1)
+        hh.hh_adam_bf16(pbits.size, p(pbits), p(gb), p(m), p(v), ctypes.c_double(0.03), t + 1)
+        assert np.array_equal(pbits, O.bf16_bits(g["p_bf16"][t]).reshape(-1)), f"step {t}"
+
+
+def test_adam_f32_vs_torch_golden(hh, golden_dir):
+    g = np.load(os.path.join(golden_dir, "adam.npz"))
+    pv = g["p0"].reshape(-1).copy(); m = np.zeros_like(pv); v = np.zeros_like(pv)
+    for t, grad in enumerate(g["gs"]):
+        gg = np.ascontiguousarray(grad.reshape(-1))
+        hh.hh_adam_f32(pv.size, p(pv), p(gg), p(m), p(v), ctypes.c_double(0.03), t + 1)
+        np.testing.assert_allclose(pv, g["p_f32"][t].reshape(-1), rtol=1e-5, atol=1e-8)
+
+
+def test_se3_vs_reference_golden(hh, golden_dir):
+    g = np.load(os.path.join(golden_dir, "se3.npz"))
+    for w, G, R, gw in zip(g["w"], g["G"], g["R"], g["gw"]):
+        Ro = np.zeros(9, np.float32); go = np.zeros(3, np.float32)
+        hh.hh_rodrigues(p(np.ascontiguousarray(w)), p(Ro))
+        hh.hh_rodrigues_bwd(p(np.ascontiguousarray(w)), p(np.ascontiguousarray(G.reshape(-1))), p(go))
+        np.testing.assert_allclose(Ro.reshape(3, 3), R, rtol=0, atol=3e-7)
+        np.testing.assert_allclose(go, gw, rtol=3e-6, atol=3e-7)
+
+
+def test_trilinear_weights_and_dp(hh):
+    rng = np.random.default_rng(0)
+    P = 1000
+    c = (rng.integers(9990, 10100, (P, 3)).astype(np.float32) + 0.5) * np.float32(0.2)
+    x = (c + rng.uniform(-0.1, 0.1, (P, 3)).astype(np.float32)).astype(np.float32)
+    pp = np.zeros((P, 3), np.float32); w = np.zeros((P, 8), np.float32)
+    hh.hh_trilinear(P, p(x), p(c), ctypes.c_float(0.2), p(pp), p(w))
+    emb = O.bf16_bits(rng.normal(0, 0.01, (8, 16)).astype(np.float32))
+    feats, cache = O.trilinear_forward(x, np.arange(P) % 1, c[:1].repeat(1, 0) * 0 + c[:1], np.arange(8, dtype=np.int32)[None], emb, 0.2) if False else (None, None)
+    po = ((x - c) / np.float32(0.2) + np.float32(0.5)).astype(np.float32)
+    assert np.array_equal(pp, po)
+    q = 1 - po
+    for k in range(8):
+        tx = po[:, 0] if k & 4 else q[:, 0]; ty = po[:, 1] if k & 2 else q[:, 1]; tz = po[:, 2] if k & 1 else q[:, 2]
+        assert np.array_equal(w[:, k], (tx * ty) * tz)
+    np.testing.assert_allclose(w.sum(1), 1.0, atol=1e-5)
+    dot = rng.normal(size=(P, 8)).astype(np.float32)
+    dp = np.zeros((P, 3), np.float32)
+    hh.hh_trilinear_dp(P, p(pp), p(dot), p(dp))
+    eps = 1e-3
+    for a in range(3):                       # finite differences of sum_k w_k dot_k
+        pa, pb = pp.copy(), pp.copy(); pa[:, a] += eps; pb[:, a] -= eps
+        wa = np.zeros((P, 8), np.float32); wb = np.zeros((P, 8), np.float32)
+        for pv, wv in ((pa, wa), (pb, wb)):
+            qq = 1 - pv
+            for k in range(8):
+                wv[:, k] = (pv[:, 0] if k & 4 else qq[:, 0]) * (pv[:, 1] if k & 2 else qq[:, 1]) * (pv[:, 2] if k & 1 else qq[:, 2])
+        fd = ((wa - wb) * dot).sum(1) / (2 * eps)
+        np.testing.assert_allclose(dp[:, a], fd, rtol=2e-2, atol=2e-3)
+
+
+def test_loss_gradient_matches_oracle(hh):
+    rng = np.random.default_rng(1)
+    R, S = 40, 12
+    gt = rng.uniform(5, 30, (R, 3)).astype(np.float32); cos = rng.uniform(0.05, 1, R).astype(np.float32)
+    d = (np.sqrt((gt * gt).sum(1, dtype=np.float32)) * cos).astype(np.float32)
+    zv = (np.linalg.norm(gt, axis=1)[:, None] + rng.normal(0, 0.4, (R, S))).astype(np.float32)
+    valid = rng.random((R, S)) < 0.8
+    zv[~valid] = 80.0
+    sdf = rng.normal(0, 0.5, (R, S)).astype(np.float32); sdf[~valid] = 1.0
+    loss, dsdf, st = O.sdf_loss(zv, sdf, valid, gt, cos, O.LossCfg())
+    rr, ss = np.nonzero(valid)
+    z = (zv * cos[:, None]).astype(np.float32)[rr, ss]
+    dd = np.ascontiguousarray(d[rr]); sp = np.ascontiguousarray(sdf[rr, ss]); z = np.ascontiguousarray(z)
+    n = len(rr)
+    ds = np.zeros(n, np.float32); fr = np.zeros(n, np.int32); sm = np.zeros(n, np.int32)
+    two_n = np.float32(2) / np.float32(R * S)
+    hh.hh_loss(n, p(sp), p(z), p(dd), ctypes.c_float(st["w_fs"]), ctypes.c_float(st["w_sdf"]), ctypes.c_float(two_n),
+               ctypes.c_float(1.0), ctypes.c_float(10000.0), ctypes.c_float(0.3), ctypes.c_float(50.0), p(ds), p(fr), p(sm))
+    np.testing.assert_allclose(ds, dsdf[rr, ss], rtol=1e-6, atol=1e-12)
