@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- LiDAR rays/s per SDF iteration on the synthetic 64x2048 scan (BASELINE.json metric M1).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one full mapping iteration of the reference's hot loop
+(/root/reference/src/variations/render_helpers.py:356-423) over ALL 131 072 rays of one synthetic
+scan: ray set-up, octree intersect, inverse-CDF sampling, embedding gather, decoder forward, SDF
+loss, backward (decoder + embeddings + SE3 pose), Adam step - inputs resident in HBM.  With N GPUs
+the scan's rays are sharded (strong scaling, total work fixed) with the three RCCL exchanges of
+nerf_loam_amd/dist.py.  Rank 0 prints ONE JSON line.
+
+Extra objects: "roofline" for the dominant kernel (fused decoder fwd+bwd, fp32 MFMA), timed live
+with HIP events on the launch stream; "cpu_baseline": the oracle port timed on a bounded ray sample
+on this box's host cores (a reported baseline, not the target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+FLOPS_PER_SAMPLE_DECODER = 2 * 2 * (16 * 256 + 256 * 256 + 256) + 2 * (16 * 256 + 256)   # fwd + dgrad + (dW1, dW3): 288 256
+FLOPS_PER_SAMPLE_WGRAD2 = 2 * 256 * 256                                                    # dW2: 131 072
+
+
+def build_workload(device, seed=777):
+    from nerf_loam_amd import pipeline as P, synthetic as S
+    from nerf_loam_amd.svo import Octree
+    pts, cos = S.synthetic_scan(64, 2048, seed)
+    pose = S.scan_pose()
+    oc = Octree()
+    oc.init(256 * 256 * 4, 16, 0.2)
+    oc.insert(S.voxel_coords(pts, np.eye(3, dtype=np.float32), pose[:3], 0.2))
+    centres, structure, vertex_idx = oc.export_device_layout()
+    # embedding rows: one per vertex occurrence like mapping.py:293-317 (160k rows for this scan)
+    flat = vertex_idx.reshape(-1)
+    flat = flat[flat >= 0]
+    id2row = -np.ones(len(centres), np.int32)
+    id2row[flat] = np.arange(len(flat), dtype=np.int32)
+    E = len(flat)
+    rng = np.random.default_rng(seed)
+    emb = rng.normal(0, 0.01, (E, 16)).astype(np.float32)
+    emb_bits = (emb.view(np.uint32) >> 16).astype(np.uint16)             # truncation is fine for a random init
+    k1, k2 = 1 / np.sqrt(16), 1 / np.sqrt(256)
+    W1 = rng.uniform(-k1, k1, (256, 16)); b1 = rng.uniform(-k1, k1, 256)
+    W2 = rng.uniform(-k2, k2, (256, 256)); b2 = rng.uniform(-k2, k2, 256)
+    W3 = rng.uniform(-k2, k2, (1, 256)); b3 = rng.uniform(-k2, k2, 1)
+    m = P.MapDevice(centres, structure, vertex_idx, id2row, emb_bits, 0.2, device=device)
+    dec = P.DecoderDevice(W1, b1, W2, b2, W3, b3, device=device)
+    return dict(points=pts, cos=cos, dirs=S.unit_dirs(pts), pose=pose, map=m, dec=dec, n_nodes=len(centres), n_rows=E,
+                host=dict(centres=centres, structure=structure, vertex_idx=vertex_idx, id2row=id2row, emb_bits=emb_bits,
+                          dec=(W1, b1, W2, b2, W3, b3)))
+
+
+def cpu_baseline(w, n_rays=8192, seed=1):
+    """Oracle port (oracle/oracle.py + nl_oracle.c) of the same iteration on a bounded ray sample."""
+    from oracle import oracle as O
+    h = w["host"]
+    ms = O.MapState(h["centres"], h["structure"], h["vertex_idx"], h["id2row"], h["emb_bits"].copy(), 0.2)
+    dec = O.DecoderParams(*[np.asarray(a, np.float32) for a in h["dec"]])
+    rng = np.random.default_rng(seed)
+    sel = np.sort(rng.choice(len(w["points"]), n_rays, replace=False))
+    fr = O.Frame(w["dirs"][sel], w["points"][sel], w["cos"][sel], w["pose"].copy())
+    st = O.AdamState()
+    cfg = O.IterCfg()
+    out = O.render_and_grad(ms, dec, [fr], cfg)                      # warm-up (library load, BLAS threads)
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        out = O.render_and_grad(ms, dec, [fr], cfg)
+        O.optimiser_step(ms, dec, [fr], out, st, [0.03, 0.005, 0.001])
+    dt = (time.perf_counter() - t0) / reps
+    return dict(value=n_rays / dt, unit="rays/s", cores=int(torch.get_num_threads()), kind="port",
+                sample=f"{n_rays} rays of the same 64x2048 scan, 1 mapping iteration incl. Adam, mean of {reps} "
+                       f"({dt * 1e3:.0f} ms/iter; numpy/C oracle, GEMMs on torch-CPU threads)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frozen-decoder", action="store_true", help="mapping with update_decoder=False (after freeze_frame)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    from nerf_loam_amd import _lib, pipeline as P, dist as D
+    _lib.require_gpu()
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import torch.distributed as tdist
+        tdist.init_process_group("nccl", device_id=device)
+
+    w = build_workload(device)
+    N = len(w["points"])
+    lo, hi = D.shard_bounds(N, rank, world)
+    eng = P.SdfEngine(max_rays=hi - lo, samples_per_ray_cap=48, device=device)
+    if world > 1:
+        D.RayShardedExchange(eng)
+    eng.set_rays(w["dirs"][lo:hi], w["points"][lo:hi], w["cos"][lo:hi])
+    eng.set_poses(w["pose"][None], [1])
+    cfg = P.IterConfig()
+    train_dec = not args.frozen_decoder
+    eng.begin_call(w["map"], w["dec"])
+
+    def step():
+        eng.forward_backward(w["map"], w["dec"], cfg, train_decoder=train_dec, ray_id_base=lo)
+        eng.optimiser_step(w["map"], w["dec"], cfg, update_decoder=train_dec)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as tdist
+            tdist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # per-kernel events for the roofline object (same stream as the launches)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        eng.timers = {"decoder": (ev[k][0], ev[k][1]), "wgrad2": (ev[k][1], ev[k][2])}
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.timers = None
+    if world > 1:
+        import torch.distributed as tdist
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = eng.stats()
+    dec_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev]))
+    wg_ms = float(np.mean([b.elapsed_time(c) for _, b, c in ev])) if train_dec else 0.0
+    P_local = st["P"]
+    if rank == 0:
+        flops_dec = P_local * (FLOPS_PER_SAMPLE_DECODER if train_dec else 2 * 2 * (16 * 256 + 256 * 256 + 256))
+        ach = flops_dec / (dec_ms * 1e-3) / 1e12
+        out = {
+            "metric": "LiDAR rays/sec per SDF iter (64x2048 scan)",
+            "value": N * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic 64x2048 scan (131072 rays), 1 mapping iteration/step: intersect+sample+gather+"
+                                   "decoder fwd/bwd+SDF loss+emb/decoder/pose grads+Adam; voxel 0.2 m, step 0.1 m, "
+                                   + ("decoder trainable" if train_dec else "decoder frozen"),
+                       "rays": N, "octree_nodes": w["n_nodes"], "embedding_rows": w["n_rows"], "hit_rays": st["R"],
+                       "valid_samples_rank0": P_local, "max_samples_per_ray": st["S"], "parallelism": f"ray-shard x{world}"},
+            "roofline": {"bound": "mfma", "kernel": "k_decoder<train>" if train_dec else "k_decoder<frozen>", "achieved": ach,
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "avg_launch_ms": dec_ms, "flops_per_launch": flops_dec,
+                         "second_kernel": ({"kernel": "k_decoder_wgrad2", "avg_launch_ms": wg_ms,
+                                            "achieved": P_local * FLOPS_PER_SAMPLE_WGRAD2 / (wg_ms * 1e-3) / 1e12,
+                                            "frac": P_local * FLOPS_PER_SAMPLE_WGRAD2 / (wg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+                                           if train_dec else None)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as tdist
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -94,11 +94,15 @@ int nl_gather_trilinear(const void* loss_scalars, const int* s_vox, const float*
 /* Decoder forward (src/variations/lidar.py:109-131) + Criterion gradient (src/criterion.py:59-100) +
  * decoder backward (autograd of render_helpers.py:422).  params = decoder block, W2T = transposed W2.
  * Outputs sdf[P], dsdf[P], dX[P,16]; with train_decoder: per-workgroup weight-gradient slabs
- * partials[nslabs][NL_DEC_PARAMS] (sum them with nl_reduce_partials) and relu2_mask[P][8] scratch. */
+ * partials[nslabs][NL_DEC_PARAMS] (all but the W2 block; nl_decoder_wgrad2 adds that; sum the slabs with
+ * nl_reduce_partials) and relu2_mask[P][8] scratch. */
 int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* params, const float* W2T,
                        const int* s_ray, const float* s_depth, const float* cos_gt, const float* gt_dist,
                        float* sdf, float* dsdf, float* dX, float* partials, unsigned* relu2_mask, int nslabs, int train_decoder,
                        int* counters, void* stream);
+/* second half of the decoder weight gradient: dW2 = dH2^T H1 into partials[slab][W2 block] (train only) */
+int nl_decoder_wgrad2(const void* loss_scalars, const float* X, const float* params, const float* dsdf, const unsigned* relu2_mask,
+                      float* partials, int nslabs, void* stream);
 /* forward only: Decoder.get_values on a dense batch (mesh-time get_scores, render_helpers.py:96-153) */
 int nl_decoder_forward(const float* X, const float* params, const float* W2T, int P, float* sdf, int nblocks, void* stream);
 int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, void* stream);

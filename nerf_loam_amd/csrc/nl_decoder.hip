@@ -463,12 +463,19 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
     a.cos_gt = cos_gt; a.gt_dist = gt_dist; a.sdf = sdf; a.dsdf = dsdf; a.dX = dX; a.partials = partials;
     a.relu2_mask = relu2_mask;
     a.dcounters = (double*)(counters + NL_CNT_INTS);
-    if (train_decoder) {
-        hipLaunchKernelGGL(k_decoder<true>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, a);
-        hipLaunchKernelGGL(k_decoder_wgrad2, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, a.ls, X, params, dsdf, relu2_mask, partials);
-    } else {
-        hipLaunchKernelGGL(k_decoder<false>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, a);
-    }
+    if (train_decoder) hipLaunchKernelGGL(k_decoder<true>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, a);
+    else               hipLaunchKernelGGL(k_decoder<false>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, a);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+// dW2 slab of the decoder weight gradient (second persistent kernel; needs nl_decoder_fwd_bwd's dsdf + relu2_mask)
+int nl_decoder_wgrad2(const void* loss_scalars, const float* X, const float* params, const float* dsdf, const unsigned* relu2_mask,
+                      float* partials, int nslabs, void* stream)
+{
+    if (!loss_scalars || !X || !params || !dsdf || !relu2_mask || !partials || nslabs <= 0) return NL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_decoder_wgrad2, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,
+                       params, dsdf, relu2_mask, partials);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

@@ -1,0 +1,143 @@
+"""Typed thin wrappers: torch device tensors -> C ABI of libnerfloam_hip.so (include/nerfloam_hip.h).
+
+torch is plumbing here (device memory + streams); every function launches hand-written HIP kernels
+on the current torch stream and returns nothing (outputs are caller-allocated).  No function in
+this module has a CPU or PyTorch fallback."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from ._lib import check, ptr, stream_ptr
+
+I32, F32 = torch.int32, torch.float32
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise L.NerfLoamHipError(f"{name} must be a CUDA (HIP) tensor - the SDF hot path has no CPU fallback")
+    if t.dtype != dtype:
+        raise L.NerfLoamHipError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise L.NerfLoamHipError(f"{name} must be a contiguous tensor")
+
+
+def svo_intersect(ray_start, ray_dir, points, children, voxelsize, n_max, idx, min_depth, max_depth):
+    for t, d, n in ((ray_start, F32, "ray_start"), (ray_dir, F32, "ray_dir"), (points, F32, "points"), (children, I32, "children"),
+                    (idx, I32, "idx"), (min_depth, F32, "min_depth"), (max_depth, F32, "max_depth")):
+        _chk(t, d, n)
+    b, m = ray_start.shape[0], ray_start.shape[1]
+    check(L.lib().nl_svo_intersect(ptr(ray_start), ptr(ray_dir), ptr(points), ptr(children), b, m, points.shape[1],
+                                   float(voxelsize), int(n_max), ptr(idx), ptr(min_depth), ptr(max_depth), stream_ptr()), "nl_svo_intersect")
+
+
+def inverse_cdf_sampling(pts_idx, min_depth, max_depth, noise, probs, steps, fixed_step_size, s_idx, s_depth, s_dists):
+    for t, d, n in ((pts_idx, I32, "pts_idx"), (min_depth, F32, "min_depth"), (max_depth, F32, "max_depth"), (noise, F32, "uniform_noise"),
+                    (probs, F32, "probs"), (steps, F32, "steps"), (s_idx, I32, "sampled_idx"), (s_depth, F32, "sampled_depth"),
+                    (s_dists, F32, "sampled_dists")):
+        _chk(t, d, n)
+    G, m, P = pts_idx.shape
+    check(L.lib().nl_inverse_cdf_sampling(ptr(pts_idx), ptr(min_depth), ptr(max_depth), ptr(noise), ptr(probs), ptr(steps),
+                                          G, m, P, noise.shape[-1], float(fixed_step_size), ptr(s_idx), ptr(s_depth), ptr(s_dists),
+                                          stream_ptr()), "nl_inverse_cdf_sampling")
+
+
+def ray_intersect(N, rays_d_sensor, points_gt, cos_gt, frame_id, poses12, centres, structure, voxel_size, max_distance,
+                  rays_d_world, gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters):
+    check(L.lib().nl_ray_intersect(int(N), ptr(rays_d_sensor), ptr(points_gt), ptr(cos_gt), ptr(frame_id), ptr(poses12), ptr(centres),
+                                   ptr(structure), float(voxel_size), float(max_distance), ptr(rays_d_world), ptr(gt_dist),
+                                   ptr(hit_idx), ptr(hit_t0), ptr(hit_t1), ptr(hit_count), ptr(counters), stream_ptr()), "nl_ray_intersect")
+
+
+def exclusive_scan(inp, out, n, flag_mode, total_out, workspace):
+    check(L.lib().nl_exclusive_scan_i32(ptr(inp), ptr(out), int(n), int(flag_mode), ptr(total_out), ptr(workspace), stream_ptr()),
+          "nl_exclusive_scan_i32")
+
+
+def compact_hit_rays(N, hit_count, hit_rank, ray_of_rank):
+    check(L.lib().nl_compact_hit_rays(int(N), ptr(hit_count), ptr(hit_rank), ptr(ray_of_rank), stream_ptr()), "nl_compact_hit_rays")
+
+
+def sample_rays(emit, N, hit_idx, hit_t0, hit_t1, hit_count, hit_rank, ray_of_rank, cos_gt, gt_dist, step_size, tau, max_depth,
+                seed, use_hash_noise, tail_always, ray_id_base, counters, samp_count, samp_off, capacity, s_vox, s_depth, s_dist, s_ray):
+    check(L.lib().nl_sample_rays(int(emit), int(N), ptr(hit_idx), ptr(hit_t0), ptr(hit_t1), ptr(hit_count), ptr(hit_rank), ptr(ray_of_rank),
+                                 ptr(cos_gt), ptr(gt_dist), float(step_size), float(tau), float(max_depth),
+                                 ctypes.c_uint(int(seed) & 0xFFFFFFFF), int(use_hash_noise), int(tail_always), int(ray_id_base),
+                                 ptr(counters), ptr(samp_count), ptr(samp_off), int(capacity), ptr(s_vox), ptr(s_depth), ptr(s_dist),
+                                 ptr(s_ray), stream_ptr()), "nl_sample_rays")
+
+
+def loss_finalize(counters, loss_scalars, fs_weight, sdf_weight, tau, max_depth, capacity):
+    check(L.lib().nl_loss_finalize(ptr(counters), ptr(loss_scalars), float(fs_weight), float(sdf_weight), float(tau), float(max_depth),
+                                   int(capacity), stream_ptr()), "nl_loss_finalize")
+
+
+def gather_trilinear(loss_scalars, s_vox, s_depth, s_ray, rays_d_world, frame_id, poses12, n_frames, centres, vertex_rows, emb,
+                     voxel_size, X, nblocks):
+    check(L.lib().nl_gather_trilinear(ptr(loss_scalars), ptr(s_vox), ptr(s_depth), ptr(s_ray), ptr(rays_d_world), ptr(frame_id),
+                                      ptr(poses12), int(n_frames), ptr(centres), ptr(vertex_rows), ptr(emb), float(voxel_size), ptr(X),
+                                      int(nblocks), stream_ptr()), "nl_gather_trilinear")
+
+
+def decoder_fwd_bwd(loss_scalars, X, params, W2T, s_ray, s_depth, cos_gt, gt_dist, sdf, dsdf, dX, partials, relu2_mask, nslabs,
+                    train_decoder, counters):
+    check(L.lib().nl_decoder_fwd_bwd(ptr(loss_scalars), ptr(X), ptr(params), ptr(W2T), ptr(s_ray), ptr(s_depth), ptr(cos_gt), ptr(gt_dist),
+                                     ptr(sdf), ptr(dsdf), ptr(dX), ptr(partials), ptr(relu2_mask), int(nslabs), int(train_decoder),
+                                     ptr(counters), stream_ptr()), "nl_decoder_fwd_bwd")
+
+
+def decoder_wgrad2(loss_scalars, X, params, dsdf, relu2_mask, partials, nslabs):
+    check(L.lib().nl_decoder_wgrad2(ptr(loss_scalars), ptr(X), ptr(params), ptr(dsdf), ptr(relu2_mask), ptr(partials), int(nslabs),
+                                    stream_ptr()), "nl_decoder_wgrad2")
+
+
+def decoder_forward(X, params, W2T, P, sdf, nblocks):
+    check(L.lib().nl_decoder_forward(ptr(X), ptr(params), ptr(W2T), int(P), ptr(sdf), int(nblocks), stream_ptr()), "nl_decoder_forward")
+
+
+def reduce_partials(partials, nslabs, n, out):
+    check(L.lib().nl_reduce_partials(ptr(partials), int(nslabs), int(n), ptr(out), stream_ptr()), "nl_reduce_partials")
+
+
+def decoder_transpose_w2(params, W2T):
+    check(L.lib().nl_decoder_transpose_w2(ptr(params), ptr(W2T), stream_ptr()), "nl_decoder_transpose_w2")
+
+
+def trilinear_bwd(loss_scalars, s_vox, s_depth, s_ray, rays_d_world, rays_d_sensor, frame_id, poses12, n_frames, centres, vertex_rows,
+                  emb, voxel_size, dX, g_emb, g_pose, nblocks):
+    check(L.lib().nl_trilinear_bwd(ptr(loss_scalars), ptr(s_vox), ptr(s_depth), ptr(s_ray), ptr(rays_d_world), ptr(rays_d_sensor),
+                                   ptr(frame_id), ptr(poses12), int(n_frames), ptr(centres), ptr(vertex_rows), ptr(emb), float(voxel_size),
+                                   ptr(dX), ptr(g_emb), ptr(g_pose), int(nblocks), stream_ptr()), "nl_trilinear_bwd")
+
+
+def unpack_samples(loss_scalars, s_ray, samp_off, hit_rank, sdf, depth, S_stride, out_sdf, out_z, out_valid):
+    check(L.lib().nl_unpack_samples(ptr(loss_scalars), ptr(s_ray), ptr(samp_off), ptr(hit_rank), ptr(sdf), ptr(depth), int(S_stride),
+                                    ptr(out_sdf), ptr(out_z), ptr(out_valid), stream_ptr()), "nl_unpack_samples")
+
+
+def adam_embeddings(emb, g_acc, m, v, lr, step):
+    check(L.lib().nl_adam_embeddings(ptr(emb), ptr(g_acc), ptr(m), ptr(v), emb.numel(), float(lr), int(step), stream_ptr()),
+          "nl_adam_embeddings")
+
+
+def embedding_grad_bf16(g_acc, g_bf16):
+    check(L.lib().nl_embedding_grad_bf16(ptr(g_acc), ptr(g_bf16), g_acc.numel(), stream_ptr()), "nl_embedding_grad_bf16")
+
+
+def adam_f32(p, g, m, v, lr, step):
+    check(L.lib().nl_adam_f32(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), int(step), stream_ptr()), "nl_adam_f32")
+
+
+def pose_matrices(pose6, poses12):
+    check(L.lib().nl_pose_matrices(ptr(pose6), ptr(poses12), pose6.shape[0], stream_ptr()), "nl_pose_matrices")
+
+
+def pose_step(pose6, g_pose, m, v, enable, grad6_out, poses12, lr, step, apply):
+    check(L.lib().nl_pose_step(ptr(pose6), ptr(g_pose), ptr(m), ptr(v), ptr(enable), ptr(grad6_out), ptr(poses12), pose6.shape[0],
+                               float(lr), int(step), int(apply), stream_ptr()), "nl_pose_step")
+
+
+def mfma_selftest(A32, B32, D32, A16, B16, D16):
+    check(L.lib().nl_mfma_selftest(ptr(A32), ptr(B32), ptr(D32), ptr(A16), ptr(B16), ptr(D16), stream_ptr()), "nl_mfma_selftest")

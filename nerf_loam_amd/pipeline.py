@@ -1,0 +1,295 @@
+"""SdfEngine: the device-resident NeRF-LOAM SDF iteration on MI355X.
+
+One `iteration()` = what the reference does per pass of its hot loops
+(/root/reference/src/variations/render_helpers.py:356-425 bundle_adjust_frames and :452-512
+track_frame): ray set-up -> octree intersect -> inverse-CDF sampling -> embedding gather ->
+decoder forward -> SDF loss -> backward (decoder, embeddings, SE3 pose) -> Adam.
+
+MI355X-first structure: every stage is a hand-written HIP kernel launched through the C ABI
+(ops.py); all tensors live in HBM for the whole call; data-dependent sizes (hit rays R, max hits,
+max samples S, valid samples P, loss normalisers) stay in a device counter block, so an iteration
+runs WITHOUT a host synchronisation and with a fixed launch sequence (hipGraph-capturable).
+The only torch ops on the path are a memset and two 4-byte device copies.
+
+Multi-GPU (dist.py): rays are sharded; the three exchange points are marked `hook_*`.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+
+I32, F32 = torch.int32, torch.float32
+
+
+@dataclass
+class IterConfig:
+    """Hyper-parameters of one optimisation call (reference config keys in brackets)."""
+    voxel_size: float = 0.2            # mapper_specs.voxel_size
+    step_size: float = 0.1             # metres: mapper 0.5*voxel (mapping.py:61), tracker 0.2*voxel (tracking.py:36)
+    max_distance: float = 50.0         # data_specs.max_depth
+    truncation: float = 0.30           # criteria.sdf_truncation
+    sdf_weight: float = 10000.0        # criteria.sdf_weight
+    fs_weight: float = 1.0             # criteria.fs_weight
+    lr_emb: float = 0.03               # mapper_specs.learning_rate_emb
+    lr_dec: float = 0.005              # mapper_specs.learning_rate_decorder
+    lr_pose: float = 0.001             # mapper_specs.learning_rate_pose
+    noise_seed: int = 777              # None -> deterministic 0.5 noise (voxel_helpers.py:298-299)
+    tail_always: bool = False          # False = reference sampler tail behaviour
+
+
+class MapDevice:
+    """Device copy of the reference's `map_states` (mapping.py:319-339).  The 2e9-row CPU id table
+    (mapping.py:76) is folded, once per map update, into vertex_rows[n,8] = row of each corner."""
+
+    def __init__(self, centres, structure, vertex_idx, id2row, emb_bf16_bits, voxel_size, device="cuda"):
+        self.voxel_size = float(voxel_size)
+        self.centres = torch.as_tensor(np.ascontiguousarray(centres, np.float32)).to(device)
+        self.structure = torch.as_tensor(np.ascontiguousarray(structure, np.int32)).to(device)
+        vi = np.asarray(vertex_idx)
+        rows = np.where(vi >= 0, np.asarray(id2row)[np.maximum(vi, 0)], -1).astype(np.int32)
+        # voxels that are never sampled (non-SURFACE nodes) keep row 0 so a stray read stays in bounds
+        self.vertex_rows = torch.as_tensor(np.maximum(rows, 0)).to(device)
+        self.emb = torch.as_tensor(np.ascontiguousarray(emb_bf16_bits).view(np.int16)).to(device)   # bf16 bit patterns
+        self.n_nodes = self.centres.shape[0]
+        self.n_rows = self.emb.shape[0]
+
+    def emb_bits(self):
+        return self.emb.cpu().numpy().view(np.uint16)
+
+
+class DecoderDevice:
+    """Decoder parameter block (lidar.py:105-107 layers) + transposed W2 + Adam state."""
+
+    def __init__(self, W1, b1, W2, b2, W3, b3, device="cuda"):
+        flat = np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in (W1, b1, W2, b2, W3, b3)])
+        assert flat.size == L.NL_DEC_PARAMS
+        self.params = torch.as_tensor(flat).to(device)
+        self.W2T = torch.empty(L.NL_W * L.NL_W, dtype=F32, device=device)
+        self.m = torch.zeros_like(self.params)
+        self.v = torch.zeros_like(self.params)
+        self.grad = torch.zeros_like(self.params)
+        self.refresh()
+
+    def refresh(self):
+        ops.decoder_transpose_w2(self.params, self.W2T)
+
+    def reset_state(self):
+        self.m.zero_()
+        self.v.zero_()
+
+    def numpy(self):
+        f = self.params.cpu().numpy()
+        return dict(W1=f[L.OFF_W1:L.OFF_B1].reshape(256, 16), b1=f[L.OFF_B1:L.OFF_W2], W2=f[L.OFF_W2:L.OFF_B2].reshape(256, 256),
+                    b2=f[L.OFF_B2:L.OFF_W3], W3=f[L.OFF_W3:L.OFF_B3].reshape(1, 256), b3=f[L.OFF_B3:])
+
+    @staticmethod
+    def split(flat):
+        f = flat
+        return dict(W1=f[L.OFF_W1:L.OFF_B1].reshape(256, 16), b1=f[L.OFF_B1:L.OFF_W2], W2=f[L.OFF_W2:L.OFF_B2].reshape(256, 256),
+                    b2=f[L.OFF_B2:L.OFF_W3], W3=f[L.OFF_W3:L.OFF_B3].reshape(1, 256), b3=f[L.OFF_B3:])
+
+
+class SdfEngine:
+    def __init__(self, max_rays, samples_per_ray_cap=48, max_frames=8, device="cuda"):
+        L.require_gpu()
+        self.dev = torch.device(device)
+        self.N_cap = int(max_rays)
+        self.P_cap = int(max_rays) * int(samples_per_ray_cap)
+        self.F_cap = int(max_frames)
+        d = self.dev
+        N, P = self.N_cap, self.P_cap
+        # per-ray inputs
+        self.rays_d_sensor = torch.zeros(N, 3, dtype=F32, device=d)
+        self.points_gt = torch.zeros(N, 3, dtype=F32, device=d)
+        self.cos_gt = torch.zeros(N, dtype=F32, device=d)
+        self.frame_id = torch.zeros(N, dtype=I32, device=d)
+        # poses
+        self.pose6 = torch.zeros(self.F_cap, 6, dtype=F32, device=d)
+        self.poses12 = torch.zeros(self.F_cap, 12, dtype=F32, device=d)
+        self.pose_m = torch.zeros(self.F_cap, 6, dtype=F32, device=d)
+        self.pose_v = torch.zeros(self.F_cap, 6, dtype=F32, device=d)
+        self.pose_enable = torch.zeros(self.F_cap, dtype=I32, device=d)
+        self.g_pose = torch.zeros(self.F_cap, 12, dtype=F32, device=d)
+        self.pose_grad6 = torch.zeros(self.F_cap, 6, dtype=F32, device=d)
+        # per-ray workspace
+        self.rays_d_world = torch.empty(N, 3, dtype=F32, device=d)
+        self.gt_dist = torch.empty(N, dtype=F32, device=d)
+        self.hit_idx = torch.empty(N, L.NL_MAX_HITS, dtype=I32, device=d)
+        self.hit_t0 = torch.empty(N, L.NL_MAX_HITS, dtype=F32, device=d)
+        self.hit_t1 = torch.empty(N, L.NL_MAX_HITS, dtype=F32, device=d)
+        self.hit_count = torch.zeros(N, dtype=I32, device=d)
+        self.hit_rank = torch.zeros(N, dtype=I32, device=d)
+        self.ray_of_rank = torch.zeros(N, dtype=I32, device=d)
+        self.samp_count = torch.zeros(N, dtype=I32, device=d)
+        self.samp_off = torch.zeros(N, dtype=I32, device=d)
+        self.scan_ws = torch.zeros(max(1, (N + 1023) // 1024) + 8, dtype=I32, device=d)
+        # per-sample workspace
+        self.s_vox = torch.empty(P, dtype=I32, device=d)
+        self.s_depth = torch.empty(P, dtype=F32, device=d)
+        self.s_dist = torch.empty(P, dtype=F32, device=d)
+        self.s_ray = torch.empty(P, dtype=I32, device=d)
+        self.X = torch.empty(P, L.NL_C, dtype=F32, device=d)
+        self.dX = torch.empty(P, L.NL_C, dtype=F32, device=d)
+        self.sdf = torch.empty(P, dtype=F32, device=d)
+        self.dsdf = torch.empty(P, dtype=F32, device=d)
+        self.relu2_mask = torch.empty(P, 8, dtype=I32, device=d)
+        # counters + loss scalars
+        self.counters = torch.zeros(L.NL_CNT_BYTES // 4, dtype=I32, device=d)
+        self.loss_scalars = torch.zeros(L.NL_LOSS_SCALARS_BYTES // 4, dtype=I32, device=d)
+        # decoder partial slabs (one per persistent workgroup)
+        self.n_slabs = int(L.lib().nl_decoder_grid_hint())
+        self.partials = torch.zeros(self.n_slabs, L.NL_DEC_PARAMS, dtype=F32, device=d)
+        self.field_blocks = 4 * self.n_slabs
+        self.N = 0
+        self.F = 1
+        self.g_emb = None
+        self.emb_m = None
+        self.emb_v = None
+        self.step = 0
+        # multi-GPU hooks (dist.py installs them); identity on one GPU
+        self.hook_after_intersect = None
+        self.hook_after_count = None
+        self.hook_after_backward = None
+        self.timers = None       # bench: {"decoder": (start, end), "wgrad2": (start==decoder end, end)} torch.cuda.Event pairs
+
+    # ------------------------------------------------------------------ inputs
+    def set_rays(self, rays_d_sensor, points_gt, cos_gt, frame_id=None):
+        """Upload (or copy on device) the iteration's ray list: the reference's per-iteration
+        `frame.rays_d[mask]`, `frame.points[mask]`, `frame.pointsCos[mask]` (render_helpers.py:366-388)."""
+        n = rays_d_sensor.shape[0]
+        if n > self.N_cap:
+            raise L.NerfLoamHipError(f"{n} rays exceed engine capacity {self.N_cap}")
+        self.N = n
+        self.rays_d_sensor[:n].copy_(torch.as_tensor(rays_d_sensor, dtype=F32), non_blocking=True)
+        self.points_gt[:n].copy_(torch.as_tensor(points_gt, dtype=F32), non_blocking=True)
+        self.cos_gt[:n].copy_(torch.as_tensor(cos_gt, dtype=F32), non_blocking=True)
+        if frame_id is None:
+            self.frame_id[:n].zero_()
+        else:
+            self.frame_id[:n].copy_(torch.as_tensor(frame_id, dtype=I32), non_blocking=True)
+
+    def set_poses(self, pose6, optimise=None):
+        """pose6 [F,6] = (t, w) like se3pose.OptimizablePose.data; optimise[f] = pose is in the optimiser."""
+        p = torch.as_tensor(np.asarray(pose6, np.float32)).reshape(-1, 6)
+        self.F = p.shape[0]
+        if self.F > self.F_cap:
+            raise L.NerfLoamHipError("too many frames")
+        self.pose6[:self.F].copy_(p)
+        en = np.ones(self.F, np.int32) if optimise is None else np.asarray(optimise, np.int32)
+        self.pose_enable[:self.F].copy_(torch.as_tensor(en))
+        ops.pose_matrices(self.pose6[:self.F], self.poses12)
+
+    def begin_call(self, m: MapDevice, dec: DecoderDevice = None):
+        """A fresh torch.optim.Adam is created per bundle_adjust_frames / track_frame call
+        (render_helpers.py:353,448): reset optimiser state."""
+        self.step = 0
+        self.pose_m.zero_()
+        self.pose_v.zero_()
+        E = m.n_rows
+        if self.g_emb is None or self.g_emb.shape[0] != E:
+            self.g_emb = torch.zeros(E, L.NL_C, dtype=F32, device=self.dev)
+            self.emb_m = torch.zeros(E, L.NL_C, dtype=torch.int16, device=self.dev)
+            self.emb_v = torch.zeros(E, L.NL_C, dtype=torch.int16, device=self.dev)
+        else:
+            self.g_emb.zero_()
+            self.emb_m.zero_()
+            self.emb_v.zero_()
+        if dec is not None:
+            dec.reset_state()
+
+    # ------------------------------------------------------------------ one iteration
+    def forward_backward(self, m: MapDevice, dec: DecoderDevice, cfg: IterConfig, train_decoder=True, want_emb_grad=True,
+                         want_pose_grad=True, ray_id_base=0):
+        N = self.N
+        c = self.counters
+        c.zero_()
+        ops.ray_intersect(N, self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self.poses12, m.centres, m.structure,
+                          m.voxel_size, cfg.max_distance, self.rays_d_world, self.gt_dist, self.hit_idx, self.hit_t0, self.hit_t1,
+                          self.hit_count, c)
+        ops.exclusive_scan(self.hit_count, self.hit_rank, N, 1, c[L.NLC_R:L.NLC_R + 1], self.scan_ws)
+        if self.hook_after_intersect is not None:
+            self.hook_after_intersect(self)                      # fills NLC_R_GLOBAL / NLC_R_OFFSET / global NLC_HMAX
+        else:
+            c[L.NLC_R_GLOBAL:L.NLC_R_GLOBAL + 1].copy_(c[L.NLC_R:L.NLC_R + 1])
+        ops.compact_hit_rays(N, self.hit_count, self.hit_rank, self.ray_of_rank)
+        seed = 0 if cfg.noise_seed is None else cfg.noise_seed
+        use_hash = 0 if cfg.noise_seed is None else 1
+        args = (N, self.hit_idx, self.hit_t0, self.hit_t1, self.hit_count, self.hit_rank, self.ray_of_rank, self.cos_gt, self.gt_dist,
+                cfg.step_size, cfg.truncation, cfg.max_distance, seed, use_hash, int(cfg.tail_always), ray_id_base, c, self.samp_count)
+        ops.sample_rays(0, *args, None, self.P_cap, None, None, None, None)
+        ops.exclusive_scan(self.samp_count, self.samp_off, N, 0, c[L.NLC_P:L.NLC_P + 1], self.scan_ws)
+        if self.hook_after_count is not None:
+            self.hook_after_count(self)                          # all-reduce of the loss normalisers
+        ops.loss_finalize(c, self.loss_scalars, cfg.fs_weight, cfg.sdf_weight, cfg.truncation, cfg.max_distance, self.P_cap)
+        ops.sample_rays(1, *args, self.samp_off, self.P_cap, self.s_vox, self.s_depth, self.s_dist, self.s_ray)
+        ops.gather_trilinear(self.loss_scalars, self.s_vox, self.s_depth, self.s_ray, self.rays_d_world, self.frame_id, self.poses12,
+                             self.F, m.centres, m.vertex_rows, m.emb, m.voxel_size, self.X, self.field_blocks)
+        if self.timers is not None:
+            self.timers["decoder"][0].record()
+        ops.decoder_fwd_bwd(self.loss_scalars, self.X, dec.params, dec.W2T, self.s_ray, self.s_depth, self.cos_gt, self.gt_dist,
+                            self.sdf, self.dsdf, self.dX, self.partials, self.relu2_mask, self.n_slabs, int(train_decoder), c)
+        if self.timers is not None:
+            self.timers["decoder"][1].record()
+        if train_decoder:
+            ops.decoder_wgrad2(self.loss_scalars, self.X, dec.params, self.dsdf, self.relu2_mask, self.partials, self.n_slabs)
+            if self.timers is not None:
+                self.timers["wgrad2"][1].record()
+            ops.reduce_partials(self.partials, self.n_slabs, L.NL_DEC_PARAMS, dec.grad)
+        ops.trilinear_bwd(self.loss_scalars, self.s_vox, self.s_depth, self.s_ray, self.rays_d_world, self.rays_d_sensor, self.frame_id,
+                          self.poses12, self.F, m.centres, m.vertex_rows, m.emb, m.voxel_size, self.dX,
+                          self.g_emb if want_emb_grad else None, self.g_pose if want_pose_grad else None, self.field_blocks)
+        if self.hook_after_backward is not None:
+            self.hook_after_backward(self, dec, train_decoder, want_emb_grad, want_pose_grad)
+
+    def optimiser_step(self, m: MapDevice, dec: DecoderDevice, cfg: IterConfig, update_emb=True, update_decoder=True, update_pose=True,
+                       lr_pose=None):
+        """optim.step() of render_helpers.py:421-423 / :508-510 on the device-resident parameters."""
+        self.step += 1
+        if update_emb:
+            ops.adam_embeddings(m.emb, self.g_emb, self.emb_m, self.emb_v, cfg.lr_emb, self.step)
+        if update_decoder:
+            ops.adam_f32(dec.params, dec.grad, dec.m, dec.v, cfg.lr_dec, self.step)
+            dec.refresh()
+        ops.pose_step(self.pose6[:self.F], self.g_pose, self.pose_m, self.pose_v, self.pose_enable, self.pose_grad6, self.poses12,
+                      cfg.lr_pose if lr_pose is None else lr_pose, self.step, int(update_pose))
+
+    # ------------------------------------------------------------------ read-back (tests, API parity)
+    def stats(self):
+        """Host copy of the counter block (synchronises)."""
+        c = self.counters.cpu().numpy()
+        ints = c[:L.NL_CNT_INTS]
+        dbl = c[L.NL_CNT_INTS:].view(np.float64)
+        ls = self.loss_scalars.cpu().numpy()
+        lf = ls.view(np.float32)
+        return dict(R=int(ints[L.NLC_R]), H=int(ints[L.NLC_HMAX]), S=int(ints[L.NLC_SMAX]), P=int(ints[L.NLC_P]),
+                    overflow=int(ints[L.NLC_OVERFLOW]), guard=int(ints[L.NLC_GUARD]),
+                    w_fs=float(lf[0]), w_sdf=float(lf[1]), ints=ints.copy(), dbl=dbl.copy())
+
+    def loss_value(self, cfg: IterConfig):
+        """Scalar loss of criterion.py:43-56 from the device sums (value only; gradients never need it)."""
+        st = self.stats()
+        ints, dbl = st["ints"], st["dbl"]
+        n = float(st["R"]) * float(st["S"])
+        if n == 0:
+            return None
+        inv_fs = st["S"] * int(ints[L.NLC_INV_FS_RAYS]) - int(ints[L.NLC_INV_FS_CNT])
+        fs = (dbl[L.NLD_FS_SQ] + inv_fs) / n * st["w_fs"]
+        sd = (dbl[L.NLD_SDF_SQ] + st["S"] * dbl[L.NLD_INV_D2] - dbl[L.NLD_INV_D2CNT]) / n * st["w_sdf"]
+        return dict(loss=cfg.fs_weight * fs + cfg.sdf_weight * sd, fs_loss=fs, sdf_loss=sd, **{k: st[k] for k in ("R", "S", "P", "H")})
+
+    def export_render(self):
+        """The dict the reference's render_rays returns (render_helpers.py:311-318), rebuilt from the
+        packed device buffers: z_vals[R,S], sdf[R,S] (ones where invalid), valid_mask[R,S], ray_mask[N]."""
+        st = self.stats()
+        R, S, N = st["R"], st["S"], self.N
+        if R == 0 or S == 0:
+            return None
+        out_sdf = torch.ones(R, S, dtype=F32, device=self.dev)
+        out_z = torch.full((R, S), 80.0, dtype=F32, device=self.dev)
+        out_valid = torch.zeros(R, S, dtype=torch.uint8, device=self.dev)
+        ops.unpack_samples(self.loss_scalars, self.s_ray, self.samp_off, self.hit_rank, self.sdf, self.s_depth, S, out_sdf, out_z, out_valid)
+        return dict(z_vals=out_z.cpu().numpy(), sdf=out_sdf.cpu().numpy(), valid_mask=out_valid.cpu().numpy().astype(bool),
+                    ray_mask=(self.hit_count[:N] > 0).cpu().numpy(), stats=st)

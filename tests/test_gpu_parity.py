@@ -1,0 +1,342 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (nerf_loam_amd.ops / pipeline), against the
+oracle on identical seeded inputs and against the reference-generated goldens.
+
+Bars: integer / index / IEEE-fp32 geometry outputs (hits, sample layout, depths) bit-exact;
+SDF within 1e-4 (north_star), measured ~1e-6; gradients to fp32 re-association round-off."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nl():
+    from nerf_loam_amd import _lib, ops, pipeline, grid
+    _lib.require_gpu()
+    return dict(L=_lib, ops=ops, P=pipeline, grid=grid)
+
+
+def dev(a, dt=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dt is not None:
+        t = t.to(dt)
+    return t.cuda()
+
+
+def test_native_library_loaded(nl):
+    import ctypes
+    assert nl["L"].lib().nl_device_count() >= 1
+    with open("/proc/self/maps") as f:
+        assert "libnerfloam_hip.so" in f.read()
+
+
+def test_mfma_lane_maps(nl):
+    rng = np.random.default_rng(0)
+    A32 = rng.normal(size=(32, 2)).astype(np.float32); B32 = rng.normal(size=(2, 32)).astype(np.float32)
+    A16 = rng.normal(size=(16, 4)).astype(np.float32); B16 = rng.normal(size=(4, 16)).astype(np.float32)
+    D32 = torch.zeros(32, 32, device="cuda"); D16 = torch.zeros(16, 16, device="cuda")
+    nl["ops"].mfma_selftest(dev(A32), dev(B32), D32, dev(A16), dev(B16), D16)
+    np.testing.assert_allclose(D32.cpu().numpy(), A32 @ B32, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(D16.cpu().numpy(), A16 @ B16, rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# drop-in `grid` operators
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def scene():
+    from nerf_loam_amd import synthetic as S
+    sc = H.build_oracle_scene(64, 48, 777)
+    pose = np.array([2000.02, 1999.97, 2000.01, 0.004, -0.003, 0.01], np.float32)
+    o, d = O.ray_setup(S.unit_dirs(sc["points"]), O.rodrigues(pose[3:]), pose[:3])
+    sc.update(o=o, d=d, pose=pose)
+    return sc
+
+
+@pytest.mark.parametrize("n_max,batch", [(20, 1), (20, 4), (5, 2)])
+def test_grid_svo_intersect_bit_exact(nl, scene, n_max, batch):
+    ms = scene["ms"]
+    N = (len(scene["o"]) // batch) * batch
+    o, d = scene["o"][:N], scene["d"][:N]
+    rs = dev(o.reshape(batch, -1, 3)); rd = dev(d.reshape(batch, -1, 3))
+    pts = dev(np.broadcast_to(ms.centres, (batch,) + ms.centres.shape)); ch = dev(np.broadcast_to(ms.structure, (batch,) + ms.structure.shape))
+    idx, t0, t1 = nl["grid"].svo_intersect(rs, rd, pts, ch, 0.2, n_max)
+    oi, o0, o1 = O.svo_intersect(o, d, ms.centres, ms.structure, 0.2, n_max)
+    assert np.array_equal(idx.cpu().numpy().reshape(N, n_max), oi)
+    assert np.array_equal(t0.cpu().numpy().reshape(N, n_max), o0)
+    assert np.array_equal(t1.cpu().numpy().reshape(N, n_max), o1)
+
+
+def test_grid_rejects_cpu_and_wrong_dtype(nl, scene):
+    ms = scene["ms"]
+    rs = torch.zeros(1, 4, 3); rd = torch.zeros(1, 4, 3)
+    with pytest.raises(RuntimeError):
+        nl["grid"].svo_intersect(rs, rd, torch.as_tensor(ms.centres)[None], torch.as_tensor(ms.structure)[None], 0.2, 20)
+    with pytest.raises(RuntimeError):
+        nl["grid"].svo_intersect(rs.cuda().double(), rd.cuda(), dev(ms.centres)[None], dev(ms.structure)[None], 0.2, 20)
+
+
+def test_grid_inverse_cdf_sampling_bit_exact(nl, scene):
+    """Same tensors the reference wrapper would pass (voxel_helpers.py:274-316): [200, L, P] layout."""
+    ms = scene["ms"]
+    oi, o0, o1, hits = O.ray_intersect(scene["o"], scene["d"], ms.centres, ms.structure, 0.2, 50.0)
+    hr = np.nonzero(hits)[0]
+    idx, t0, t1 = oi[hr], o0[hr], o1[hr]
+    R, P = idx.shape
+    G = 200; Lr = int(np.ceil(R / G)); Ht = G * Lr
+    pad = lambda a: np.concatenate([a, np.repeat(a[:1], Ht - R, 0)], 0)
+    dists = np.where(idx == -1, 0, t1 - t0).astype(np.float32)
+    tot = dists.sum(-1, dtype=np.float32)
+    probs = (dists / tot[:, None]).astype(np.float32); steps = (tot / np.float32(0.1)).astype(np.float32)
+    T = int(np.ceil(steps).max()) + P
+    noise = O.hash_noise(5, np.arange(Ht), T)
+    a = [pad(x).reshape(G, Lr, -1) for x in (idx, t0, t1, probs)]
+    st = pad(steps).reshape(G, Lr)
+    nz = noise.reshape(G, Lr, T)
+    e_idx = -np.ones((G, Lr, T), np.int32); e_dep = np.zeros((G, Lr, T), np.float32); e_dst = np.zeros((G, Lr, T), np.float32)
+    args = [np.ascontiguousarray(x) for x in (a[0], a[1], a[2], nz, a[3], st)]
+    O.lib().orc_inverse_cdf_sampling(G, Lr, P, T, -1.0, *[O._p(x) for x in args], O._p(e_idx), O._p(e_dep), O._p(e_dst))
+    g_idx, g_dep, g_dst = nl["grid"].inverse_cdf_sampling(dev(args[0]), dev(args[1]), dev(args[2]), dev(args[3]), dev(args[4]), dev(args[5]), -1.0)
+    assert np.array_equal(g_idx.cpu().numpy(), e_idx)
+    assert np.array_equal(g_dep.cpu().numpy(), e_dep)
+    assert np.array_equal(g_dst.cpu().numpy(), e_dst)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused iteration vs oracle and goldens
+# ------------------------------------------------------------------------------------------------
+def make_engine(nl, sc, dec_np, n_rays, n_frames=1):
+    P = nl["P"]
+    ms = sc["ms"]
+    m = P.MapDevice(ms.centres, ms.structure, ms.vertex_idx, ms.id2row, ms.emb, ms.voxel_size)
+    dec = P.DecoderDevice(dec_np.W1, dec_np.b1, dec_np.W2, dec_np.b2, dec_np.W3, dec_np.b3)
+    eng = P.SdfEngine(max_rays=n_rays, samples_per_ray_cap=64, max_frames=max(2, n_frames))
+    return m, dec, eng
+
+
+def load_frames(eng, frames):
+    rays = np.concatenate([f.rays_d for f in frames]); pts = np.concatenate([f.points for f in frames])
+    cos = np.concatenate([f.cos for f in frames])
+    fid = np.concatenate([np.full(len(f.rays_d), i, np.int32) for i, f in enumerate(frames)])
+    eng.set_rays(rays, pts, cos, fid)
+    eng.set_poses(np.stack([f.pose for f in frames]), [int(f.optimize_pose) for f in frames])
+
+
+def compare_iteration(eng, m, dec, out, cfgP, train_decoder, sdf_tol=1e-4):
+    r = eng.export_render()
+    st = r["stats"]
+    assert st["overflow"] == 0 and st["guard"] == 0
+    assert np.array_equal(r["ray_mask"], out["hits"])
+    assert st["R"] == int(out["hits"].sum()) and st["H"] == out["hit_idx"].shape[1]
+    assert st["S"] == out["z_vals"].shape[1] and st["P"] == out["n_samples"]
+    N = len(out["hits"])
+    H_ = st["H"]
+    assert np.array_equal(eng.hit_idx[:N, :H_].cpu().numpy(), out["hit_idx"])
+    assert np.array_equal(eng.hit_t0[:N, :H_].cpu().numpy(), out["hit_t0"])
+    assert np.array_equal(eng.hit_t1[:N, :H_].cpu().numpy(), out["hit_t1"])
+    assert np.array_equal(r["valid_mask"], out["valid"])
+    assert np.array_equal(r["z_vals"], out["z_vals"])                      # IEEE fp32 geometry: bit-exact
+    assert np.array_equal(eng.s_vox[:st["P"]].cpu().numpy(), out["vox"].astype(np.int32))
+    d = np.abs(r["sdf"] - out["sdf"])
+    assert d.max() < sdf_tol, d.max()
+    assert d.mean() < 2e-6
+    assert st["ints"][4] + st["S"] * st["ints"][6] - st["ints"][7] == out["stats"]["n_fs"]
+    assert st["ints"][5] + st["S"] * st["ints"][8] - st["ints"][9] == out["stats"]["n_sdf"]
+    lv = eng.loss_value(cfgP)
+    np.testing.assert_allclose(lv["loss"], out["loss"], rtol=2e-5)
+    Pn = st["P"]
+    np.testing.assert_allclose(eng.X[:Pn].cpu().numpy(), out["feats"], rtol=0, atol=2e-7)
+    ds = eng.dsdf[:Pn].cpu().numpy()
+    ref_ds = out["dsdf"][out["valid"]]
+    np.testing.assert_allclose(ds, ref_ds, rtol=1e-3, atol=1e-9 + 1e-5 * np.abs(ref_ds).max())
+    dX = eng.dX[:Pn].cpu().numpy()
+    np.testing.assert_allclose(dX, out["dfeat"], rtol=0, atol=2e-5 * np.abs(out["dfeat"]).max())
+    if train_decoder:
+        g = nl_split(dec.grad.cpu().numpy())
+        for n_, ref in out["grad_dec"].items():
+            got = g[n_].reshape(ref.shape)
+            assert np.abs(got - ref).max() <= 5e-5 * np.abs(ref).max() + 1e-9, n_
+    return r
+
+
+def nl_split(flat):
+    from nerf_loam_amd.pipeline import DecoderDevice
+    return DecoderDevice.split(flat)
+
+
+@pytest.mark.parametrize("case", ["map_1f_1it", "map_2f_2it_frozen"])
+def test_iteration_matches_oracle_and_golden(nl, golden_dir, case):
+    g = np.load(os.path.join(golden_dir, case + ".npz"))
+    sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]))
+    sc["ms"].id2row = g["id_table"].copy()
+    masks = H.unpack_masks(g["masks"], len(sc["points"]))
+    dec_np = O.decoder_init(int(g["seed"]))
+    nf = masks.shape[0]
+    train = bool(g["update_decoder"])
+    frames = [O.select_rays(sc["points"], sc["cos"], g["poses0"][f].copy(), masks[f][0], optimize_pose=bool(g["update_pose"]))
+              for f in range(nf)]
+    cfgO = O.IterCfg(step_size=float(g["step_size"]))
+    out = O.render_and_grad(sc["ms"], dec_np, frames, cfgO, want_dec_grad=train)
+    m, dec, eng = make_engine(nl, sc, dec_np, sum(len(f.rays_d) for f in frames), nf)
+    cfgP = nl["P"].IterConfig(step_size=float(g["step_size"]))
+    load_frames(eng, frames)
+    eng.begin_call(m, dec)
+    eng.forward_backward(m, dec, cfgP, train_decoder=train)
+    r = compare_iteration(eng, m, dec, out, cfgP, train)
+    # against the REFERENCE outputs (goldens); rays whose hit list has exact t_min ties are unspecified there
+    ok = ~_tie_rays(out)
+    assert np.array_equal(r["valid_mask"][ok], g["it0_valid"][ok])
+    assert np.abs(r["sdf"] - g["it0_sdf"])[ok].max() < 1e-4
+    # embedding gradient (bf16 of the fp32 accumulators) and pose gradient
+    gbf = torch.empty(m.n_rows, 16, dtype=torch.int16, device="cuda")
+    nl["ops"].embedding_grad_bf16(eng.g_emb, gbf)
+    got = O.bf16_to_f32(gbf.cpu().numpy().view(np.uint16)); ref = O.bf16_to_f32(out["grad_emb"])
+    assert np.array_equal(got != 0, ref != 0)
+    assert np.linalg.norm(got - ref) <= 3e-3 * np.linalg.norm(ref)
+    assert (np.abs(got - ref) <= np.abs(ref) * 2 ** -7 + 1e-12).mean() > 0.999          # at most one bf16 ulp
+    eng.optimiser_step(m, dec, cfgP, update_decoder=train, update_pose=False)           # computes grad6, no pose update
+    g6 = eng.pose_grad6[:nf].cpu().numpy()
+    for f in range(nf):
+        np.testing.assert_allclose(g6[f], out["grad_pose"][f], rtol=2e-3, atol=1e-6 + 1e-4 * np.abs(out["grad_pose"][f]).max())
+
+
+def _tie_rays(out):
+    hr = np.nonzero(out["hits"])[0]
+    t0, idx = out["hit_t0"][hr], out["hit_idx"][hr]
+    return ((t0[:, 1:] == t0[:, :-1]) & (idx[:, 1:] != -1)).any(1)
+
+
+def test_mapping_three_steps_track_oracle(nl, golden_dir):
+    """3 Adam iterations (embeddings bf16 + decoder + pose), same ray masks: parameters after each
+    step stay within round-off of the oracle's; final state close to the reference golden."""
+    g = np.load(os.path.join(golden_dir, "map_1f_3it.npz"))
+    sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]))
+    sc["ms"].id2row = g["id_table"].copy()
+    masks = H.unpack_masks(g["masks"], len(sc["points"]))
+    dec_np = O.decoder_init(int(g["seed"]))
+    m, dec, eng = make_engine(nl, sc, dec_np, int(masks[0][0].sum()))
+    cfgP = nl["P"].IterConfig(step_size=float(g["step_size"]))
+    cfgO = O.IterCfg(step_size=float(g["step_size"]))
+    # oracle run (fp32-accumulate embedding-gradient semantics, like the HIP path)
+    ms_o = sc["ms"]; scans = [dict(points=sc["points"], cos=sc["cos"], pose=g["poses0"][0].copy(), index=1)]
+    emb0 = ms_o.emb.copy()
+    outs = O.bundle_adjust(ms_o, dec_np, scans, masks, cfgO, 3, list(g["lrs"]))
+    pose = g["poses0"][0].copy()
+    eng.begin_call(m, dec)
+    m.emb.copy_(torch.as_tensor(emb0.view(np.int16)).cuda())
+    for it in range(3):
+        fr = O.select_rays(sc["points"], sc["cos"], pose, masks[0][it])
+        eng.set_rays(fr.rays_d, fr.points, fr.cos)
+        if it == 0:
+            eng.set_poses(pose[None], [1])
+        eng.forward_backward(m, dec, cfgP, train_decoder=True)
+        if it == 0:
+            r = eng.export_render()
+            assert np.abs(r["sdf"] - outs[0]["sdf"]).max() < 1e-4
+        eng.optimiser_step(m, dec, cfgP)
+        pose = eng.pose6[0].cpu().numpy()
+    emb = m.emb_bits()
+    mism = (emb != ms_o.emb).mean()
+    assert mism < 5e-3, mism
+    d = np.abs(O.bf16_to_f32(emb) - O.bf16_to_f32(ms_o.emb))
+    assert d.max() <= 3 * 0.03 + 1e-6
+    dn = dec.numpy()
+    for n_ in dec_np.names():
+        dd = np.abs(dn[n_].reshape(-1) - getattr(dec_np, n_).reshape(-1))
+        assert (dd > 5e-5).mean() < 5e-3, n_
+    np.testing.assert_allclose(pose, scans[0]["pose"], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(pose[:3], g["poses_final"][0][:3], rtol=0, atol=5e-3)     # reference golden
+
+
+def test_tracking_matches_oracle_and_golden(nl, golden_dir):
+    g = np.load(os.path.join(golden_dir, "track_2it.npz"))
+    sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]))
+    sc["ms"].id2row = g["id_table"].copy()
+    masks = H.unpack_masks(g["masks"], len(sc["points"]))
+    dec_np = O.decoder_init(int(g["seed"]))
+    m, dec, eng = make_engine(nl, sc, dec_np, int(masks[0].sum()))
+    cfgP = nl["P"].IterConfig(step_size=float(g["step_size"]))
+    cfgO = O.IterCfg(step_size=float(g["step_size"]))
+    scan = dict(points=sc["points"], cos=sc["cos"], pose=g["pose0"].copy(), index=int(g["frame_index"]))
+    pose_o, outs = O.track(sc["ms"], dec_np, scan, masks, cfgO, 2, float(g["lr"]))
+    pose = g["pose0"].copy()
+    eng.begin_call(m, None)
+    eng.set_poses(pose[None], [1])
+    for it in range(2):
+        fr = O.select_rays(sc["points"], sc["cos"], pose, masks[it])
+        eng.set_rays(fr.rays_d, fr.points, fr.cos)
+        eng.forward_backward(m, dec, cfgP, train_decoder=False, want_emb_grad=False)
+        r = eng.export_render()
+        if it == 0:
+            assert np.array_equal(r["z_vals"], outs[0]["z_vals"])
+            ok = ~_tie_rays(outs[0])
+            assert np.abs(r["sdf"] - g["it0_sdf"])[ok].max() < 1e-4
+        eng.optimiser_step(m, dec, cfgP, update_emb=False, update_decoder=False, update_pose=True, lr_pose=float(g["lr"]))
+        np.testing.assert_allclose(eng.pose_grad6[0].cpu().numpy(), outs[it]["grad_pose"][0], rtol=5e-3,
+                                   atol=1e-6 + 2e-4 * np.abs(outs[it]["grad_pose"][0]).max())
+        pose = eng.pose6[0].cpu().numpy()
+    np.testing.assert_allclose(pose, pose_o, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(pose, g["pose_final"], rtol=0, atol=3e-4)                  # reference golden
+
+
+# ------------------------------------------------------------------------------------------------
+# full-size properties (131072 rays): size-independent invariants, no oracle at this scale
+# ------------------------------------------------------------------------------------------------
+def test_full_scan_invariants(nl):
+    from nerf_loam_amd import synthetic as S
+    from nerf_loam_amd.svo import Octree
+    pts, cos = S.synthetic_scan()
+    pose = S.scan_pose()
+    oc = Octree(); oc.init(256 * 256 * 4, 16, 0.2)
+    oc.insert(S.voxel_coords(pts, np.eye(3, dtype=np.float32), pose[:3], 0.2))
+    c, s, f = oc.export_device_layout()
+    id2row = -np.ones(len(c), np.int32)
+    E = O.assign_embedding_rows(f, id2row, 0)
+    emb = O.bf16_bits(H.init_embeddings(E, 1))
+    P = nl["P"]
+    m = P.MapDevice(c, s, f, id2row, emb, 0.2)
+    d0 = O.decoder_init(1)
+    dec = P.DecoderDevice(d0.W1, d0.b1, d0.W2, d0.b2, d0.W3, d0.b3)
+    eng = P.SdfEngine(max_rays=len(pts), samples_per_ray_cap=48)
+    eng.set_rays(S.unit_dirs(pts), pts, cos)
+    eng.set_poses(pose[None], [1])
+    cfg = P.IterConfig()
+    eng.begin_call(m, dec)
+    eng.forward_backward(m, dec, cfg)
+    st = eng.stats()
+    N = len(pts)
+    assert st["overflow"] == 0 and st["guard"] == 0
+    hc = eng.hit_count[:N].cpu().numpy(); sc_ = eng.samp_count[:N].cpu().numpy()
+    assert st["R"] == (hc > 0).sum() and st["R"] > 0.99 * N            # every return lies in an occupied voxel
+    assert st["H"] == hc.max() and st["S"] == sc_.max() and st["P"] == sc_.sum()
+    assert np.array_equal(eng.samp_off[:N].cpu().numpy(), np.cumsum(sc_) - sc_)            # exclusive scan
+    rk = eng.hit_rank[:N].cpu().numpy()
+    assert np.array_equal(rk, np.cumsum(hc > 0) - (hc > 0))
+    t0 = eng.hit_t0[:N].cpu().numpy(); t1 = eng.hit_t1[:N].cpu().numpy(); hi = eng.hit_idx[:N].cpu().numpy()
+    assert (np.diff(t0, axis=1) >= 0).all()                              # sortedness
+    assert ((hi >= 0).sum(1) == hc).all() and (t1 >= t0).all()
+    Pn = st["P"]
+    ray = eng.s_ray[:Pn].cpu().numpy(); dep = eng.s_depth[:Pn].cpu().numpy(); dst = eng.s_dist[:Pn].cpu().numpy()
+    assert (np.diff(ray) >= 0).all()                                     # packed in ray order
+    same = np.diff(ray) == 0
+    assert (np.diff(dep)[same] >= -1e-6).all()                           # depths monotone along a ray
+    assert (dst >= 0).all()
+    tot = np.bincount(ray, weights=dst, minlength=N)
+    span = ((t1 - t0) * (hi >= 0)).sum(1)
+    assert (tot <= span + 1e-3).all()                                    # sum of dists <= sum of interval lengths
+    sdf = eng.sdf[:Pn].cpu().numpy()
+    assert np.isfinite(sdf).all() and np.isfinite(eng.dX[:Pn].cpu().numpy()).all()
+    # linearity of the backward in dL/dsdf: doubling both loss weights doubles every gradient
+    g1 = dec.grad.clone(); ge1 = eng.g_emb.clone()
+    eng.g_emb.zero_(); eng.g_pose.zero_()
+    cfg2 = P.IterConfig(sdf_weight=2 * cfg.sdf_weight, fs_weight=2 * cfg.fs_weight)
+    eng.forward_backward(m, dec, cfg2)
+    torch.testing.assert_close(dec.grad, 2 * g1, rtol=1e-4, atol=1e-7 * float(g1.abs().max()))
+    rel = (eng.g_emb - 2 * ge1).norm() / (2 * ge1).norm()
+    assert float(rel) < 2e-3                                             # bf16-rounded contributions
