@@ -78,6 +78,9 @@ def lib():
     """Load libnerfloam_hip.so (built by nerf_loam_amd.build / __graft_entry__.build)."""
     global _lib
     if _lib is None:
+        # torch first: its wheel bundles its own libamdhip64; loading it before our library makes both
+        # use ONE HIP runtime in the process (the other order leaves torch without devices)
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise NerfLoamHipError(f"{LIB_PATH} not found - run `python -m nerf_loam_amd.build` (needs hipcc); "
                                    "the SDF hot path has no CPU/PyTorch fallback")
