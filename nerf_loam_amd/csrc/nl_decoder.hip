@@ -60,7 +60,11 @@ struct DecArgs {
     float* partials;            // [gridDim.x][NL_DEC_PARAMS] (train only)
     unsigned* relu2_mask;       // [P][8] bit j%32 of word j/32 = (H2[j] > 0)   (train only)
     double* dcounters;          // loss sums
+    long long* dbg;             // optional [16 tiles][16] s_memtime stamps of workgroup 0 / thread 0 (profiling aid)
 };
+
+#define DBG_STAMP(slot)                                                                          \
+    do { if (a.dbg && blockIdx.x == 0 && tid == 0 && tile_no < 16) a.dbg[tile_no * 16 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 // row of accumulator register r in a 32x32 MFMA result for this lane
 __device__ __forceinline__ int d32_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
@@ -95,8 +99,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
     if (tid < DEC_M) sS[tid] = 0.f;
     __syncthreads();
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int tile_no = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++tile_no) {
         const int row0 = tile * DEC_M;
+        DBG_STAMP(0);
         // ---------------- A: X tile -> LDS ----------------
         {
             const int e = tid * 2, i = e >> 4, c = e & 15;
@@ -105,6 +111,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             sX[i * LDX + c] = v.x; sX[i * LDX + c + 1] = v.y;
         }
         __syncthreads();
+        DBG_STAMP(1);
         // ---------------- B: H1 = relu(X W1^T + b1) ----------------
         {
             f32x16 c0, c1;
@@ -124,6 +131,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             }
         }
         __syncthreads();
+        DBG_STAMP(2);
         // ---------------- C: H2 = relu(H1 W2^T + b2), s = H2 w3 + b3 ----------------
         f32x16 h0, h1;
         {
@@ -137,6 +145,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
                 const float a0 = ap0[2 * kk], a1 = ap1[2 * kk];
                 h0 = MFMA32(a0, bw, h0); h1 = MFMA32(a1, bw, h1);
             }
+            DBG_STAMP(3);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 h0[r] = fmaxf(h0[r] + b2c, 0.f); h1[r] = fmaxf(h1[r] + b2c, 0.f);
@@ -150,6 +159,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             }
         }
         __syncthreads();
+        DBG_STAMP(4);
         // ---------------- D: sdf, loss gradient (criterion.py) ----------------
         if (tid < DEC_M) {
             const int g = row0 + tid;
@@ -170,6 +180,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             if (TRAIN) aB3 += ds;
         }
         __syncthreads();
+        DBG_STAMP(5);
         // ---------------- E: dH2 = ds * w3 * [H2 > 0] -> LDS ----------------
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -191,6 +202,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             }
         }
         __syncthreads();
+        DBG_STAMP(6);
         // ---------------- F: dH1 = (dH2 W2) * [H1 > 0]  (kept in registers) ----------------
         f32x16 g0v, g1v;
         {
@@ -204,6 +216,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
                 const float a0 = ap0[2 * jj], a1 = ap1[2 * jj];
                 g0v = MFMA32(a0, bw, g0v); g1v = MFMA32(a1, bw, g1v);
             }
+            DBG_STAMP(7);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = d32_row(r, lh);
@@ -213,6 +226,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             }
         }
         __syncthreads();
+        DBG_STAMP(8);
         // ---------------- H: dH1 -> LDS (over dH2) ----------------
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -220,6 +234,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             sD[row * LDH + col] = g0v[r]; sD[(32 + row) * LDH + col] = g1v[r];
         }
         __syncthreads();
+        DBG_STAMP(9);
         // ---------------- I: dX = dH1 W1 (k-split over waves), dW1 += dH1^T X ----------------
         {
 #pragma unroll
@@ -242,6 +257,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             }
         }
         __syncthreads();
+        DBG_STAMP(10);
         // ---------------- J: dX tile -> global ----------------
         {
             const int e = tid * 2, i = e >> 4, c = e & 15;
@@ -250,6 +266,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             sdX[i * LDX + c] = 0.f; sdX[i * LDX + c + 1] = 0.f;
         }
         __syncthreads();
+        DBG_STAMP(11);
     }
 
     // ---------------- loss sums ----------------
@@ -441,7 +458,12 @@ __global__ void k_mfma_selftest(const float* A32, const float* B32, float* D32, 
     for (int r = 0; r < 4; ++r) D16[((lane >> 4) * 4 + r) * 16 + (lane & 15)] = e[r];
 }
 
+static long long* g_dec_dbg = nullptr;
+
 extern "C" {
+
+/* profiling aid: device buffer of 256 int64 receiving per-phase s_memtime stamps (NULL disables) */
+int nl_decoder_set_debug_buffer(void* dbg) { g_dec_dbg = (long long*)dbg; return NL_OK; }
 
 int nl_decoder_grid_hint(void)
 {
@@ -463,6 +485,7 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
     a.cos_gt = cos_gt; a.gt_dist = gt_dist; a.sdf = sdf; a.dsdf = dsdf; a.dX = dX; a.partials = partials;
     a.relu2_mask = relu2_mask;
     a.dcounters = (double*)(counters + NL_CNT_INTS);
+    a.dbg = g_dec_dbg;
     if (train_decoder) hipLaunchKernelGGL(k_decoder<true>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, a);
     else               hipLaunchKernelGGL(k_decoder<false>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, a);
     NL_LAUNCH_CHECK();

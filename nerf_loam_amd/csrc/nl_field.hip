@@ -88,59 +88,110 @@ __global__ __launch_bounds__(NL_FIELD_THREADS) void k_gather_trilinear(FieldArgs
 // backward: dE[row_k] += bf16(w_k * dX)   (fp32 accumulation of bf16-rounded contributions, then one
 // bf16 rounding in the optimiser = torch's CUDA embedding_dense_backward semantics), and
 // dL/dx = (1/vs) * d/dp sum_k w_k <e_k, dX>  ->  dt += dx, dR += depth * dx (x) d_sensor.
+//
+// The scatter is the HBM-atomic hot spot (8 rows x 16 channels per sample = 140 M fp32 atomics for one
+// 64x2048 scan).  Samples are packed in ray order, so a chunk of consecutive samples touches few
+// distinct vertex rows: each workgroup aggregates a 1024-sample chunk in an LDS hash table
+// (open addressing on the row id, ds_add_f32 accumulation) and flushes every touched row once with
+// global atomics - ~40x fewer HBM atomics.  Table overflow falls back to direct global atomics.
+#define TB_CHUNK 1024
+#define TB_SLOTS 1024
+#define TB_PROBES 16
+
+__device__ __forceinline__ int tb_insert(int* s_key, int key)
+{
+    unsigned h = ((unsigned)key * 2654435761u) >> 22;          // top 10 bits -> [0, 1024)
+#pragma unroll 1
+    for (int i = 0; i < TB_PROBES; ++i) {
+        const int prev = atomicCAS(&s_key[h], -1, key);
+        if (prev == -1 || prev == key) return (int)h;
+        h = (h + 1) & (TB_SLOTS - 1);
+    }
+    return -1;
+}
+
 __global__ __launch_bounds__(NL_FIELD_THREADS) void k_trilinear_bwd(FieldArgs a)
 {
+    __shared__ __attribute__((aligned(16))) float s_val[TB_SLOTS * NL_C];
+    __shared__ int s_key[TB_SLOTS];
     __shared__ float s_pose[NL_MAX_FRAMES * 12];
     for (int i = threadIdx.x; i < a.n_frames * 12; i += NL_FIELD_THREADS) s_pose[i] = 0.f;
+    for (int i = threadIdx.x; i < TB_SLOTS; i += NL_FIELD_THREADS) s_key[i] = -1;
+    for (int i = threadIdx.x; i < TB_SLOTS * NL_C; i += NL_FIELD_THREADS) s_val[i] = 0.f;
     __syncthreads();
     const int P = a.ls->P;
     const int half = threadIdx.x & 1;
-    const int stride = (gridDim.x * NL_FIELD_THREADS) >> 1;
-    const int s_first = (blockIdx.x * NL_FIELD_THREADS + threadIdx.x) >> 1;
+    const int pair = threadIdx.x >> 1;
+    const int nchunks = (P + TB_CHUNK - 1) / TB_CHUNK;
     float pa[12]; int pf = -1;                                  // running pose partials of this lane's current frame
 #pragma unroll
     for (int i = 0; i < 12; ++i) pa[i] = 0.f;
-    for (int s = s_first; s < P; s += stride) {                // both lanes of a pair share s: shuffles stay convergent
-        const SampleGeom g = sample_geom(a, s);
-        float w[8]; nl_trilinear_w(g.p, w);
-        int rows[8]; load_rows(a, g.vox, rows);
-        float d[8];
-        const float4* di = reinterpret_cast<const float4*>(a.dX + (size_t)s * NL_C + 8 * half);
-        const float4 d0 = di[0], d1 = di[1];
-        d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
-        float dot[8];
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int s_end = min(P, (chunk + 1) * TB_CHUNK);
+        for (int s = chunk * TB_CHUNK + pair; s < s_end; s += NL_FIELD_THREADS / 2) {   // both lanes of a pair share s
+            const SampleGeom g = sample_geom(a, s);
+            float w[8]; nl_trilinear_w(g.p, w);
+            int rows[8]; load_rows(a, g.vox, rows);
+            float d[8];
+            const float4* di = reinterpret_cast<const float4*>(a.dX + (size_t)s * NL_C + 8 * half);
+            const float4 d0 = di[0], d1 = di[1];
+            d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
+            float dot[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float e[8]; load_emb8(a.emb, rows[k], half, e);
-            float acc = 0.f;
+            for (int k = 0; k < 8; ++k) {
+                float e[8]; load_emb8(a.emb, rows[k], half, e);
+                float acc = 0.f;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) acc += e[c] * d[c];
-            dot[k] = acc;
-            if (a.want_emb_grad) {
-                float* ge = a.g_emb + (size_t)rows[k] * NL_C + 8 * half;
+                for (int c = 0; c < 8; ++c) acc += e[c] * d[c];
+                dot[k] = acc;
+                if (a.want_emb_grad) {
+                    const int slot = tb_insert(s_key, rows[k]);
+                    if (slot >= 0) {
+                        float* dst = s_val + slot * NL_C + 8 * half;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) atomicAdd(ge + c, nl_round_bf16(w[k] * d[c]));
+                        for (int c = 0; c < 8; ++c) atomicAdd(dst + c, nl_round_bf16(w[k] * d[c]));          // ds_add_f32
+                    } else {
+                        float* dst = a.g_emb + (size_t)rows[k] * NL_C + 8 * half;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) atomicAdd(dst + c, nl_round_bf16(w[k] * d[c]));          // global_atomic_add_f32
+                    }
+                }
+            }
+            if (!a.want_pose_grad) continue;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dot[k] += __shfl_xor(dot[k], 1);
+            if (half != 0) continue;
+            float dp[3]; nl_trilinear_dp(g.p, dot, dp);
+            const int f = a.frame_id ? a.frame_id[g.ray] : 0;
+            if (f != pf) {
+                if (pf >= 0) { for (int i = 0; i < 12; ++i) atomicAdd(s_pose + 12 * pf + i, pa[i]); }
+#pragma unroll
+                for (int i = 0; i < 12; ++i) pa[i] = 0.f;
+                pf = f;
+            }
+            const float ds0 = a.rays_d_sensor[3 * g.ray], ds1 = a.rays_d_sensor[3 * g.ray + 1], ds2 = a.rays_d_sensor[3 * g.ray + 2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float dx = dp[i] / a.voxel_size;
+                pa[i] += dx;
+                const float t = g.depth * dx;
+                pa[3 + 3 * i] += t * ds0; pa[4 + 3 * i] += t * ds1; pa[5 + 3 * i] += t * ds2;
             }
         }
-        if (!a.want_pose_grad) continue;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dot[k] += __shfl_xor(dot[k], 1);
-        if (half != 0) continue;
-        float dp[3]; nl_trilinear_dp(g.p, dot, dp);
-        const int f = a.frame_id ? a.frame_id[g.ray] : 0;
-        if (f != pf) {
-            if (pf >= 0) { for (int i = 0; i < 12; ++i) atomicAdd(s_pose + 12 * pf + i, pa[i]); }
-#pragma unroll
-            for (int i = 0; i < 12; ++i) pa[i] = 0.f;
-            pf = f;
-        }
-        const float ds0 = a.rays_d_sensor[3 * g.ray], ds1 = a.rays_d_sensor[3 * g.ray + 1], ds2 = a.rays_d_sensor[3 * g.ray + 2];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float dx = dp[i] / a.voxel_size;
-            pa[i] += dx;
-            const float t = g.depth * dx;
-            pa[3 + 3 * i] += t * ds0; pa[4 + 3 * i] += t * ds1; pa[5 + 3 * i] += t * ds2;
+        if (a.want_emb_grad) {
+            __syncthreads();
+            // flush: 16 lanes per slot (one channel each), touched rows only; slot is reset for the next chunk
+            for (int base = 0; base < TB_SLOTS; base += NL_FIELD_THREADS / NL_C) {
+                const int slot = base + (threadIdx.x >> 4), c = threadIdx.x & 15;
+                const int key = s_key[slot];
+                if (key >= 0) {
+                    const float v = s_val[slot * NL_C + c];
+                    if (v != 0.f) atomicAdd(a.g_emb + (size_t)key * NL_C + c, v);
+                    s_val[slot * NL_C + c] = 0.f;
+                    if (c == 0) s_key[slot] = -1;
+                }
+            }
+            __syncthreads();
         }
     }
     if (a.want_pose_grad) {
