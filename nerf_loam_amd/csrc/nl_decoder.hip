@@ -40,8 +40,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define S_H1 0
 #define S_D (S_H1 + DEC_M * LDH)
 #define S_X (S_D + DEC_M * LDH)
-#define S_DX (S_X + DEC_M * LDX)
-#define S_S (S_DX + DEC_M * LDX)
+#define S_W1 (S_X + DEC_M * LDX)
+#define S_S (S_W1 + NL_W * NL_C)
 #define S_DS (S_S + DEC_M)
 #define S_TOTAL (S_DS + DEC_M)
 
@@ -69,11 +69,71 @@ struct DecArgs {
 // row of accumulator register r in a 32x32 MFMA result for this lane
 __device__ __forceinline__ int d32_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
+// 256-deep GEMM main loop shared by forward (B = W2T) and dgrad (B = W2): per k-pair one coalesced
+// B-operand load straight from L2 feeds both 32-row sub-tiles; B operands are register
+// double-buffered one group of 8 ahead so the L2 latency hides under 16 MFMAs of the previous group.
+__device__ __forceinline__ void gemm256(const float* __restrict__ wbase, int voff, const float* ap0, const float* ap1,
+                                        f32x16& c0, f32x16& c1)
+{
+    // wbase is wave-uniform (kernel argument), voff the lane's 32-bit element offset: lets the compiler use
+    // SGPR-base + VGPR-offset global loads instead of one 64-bit address pair per unrolled load
+    float bA[8], bB[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bA[i] = wbase[voff + i * 2 * NL_W];
+#pragma unroll 1
+    for (int g = 0; g < NL_W / 2; g += 16) {
+        const int o = voff + g * 2 * NL_W;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bB[i] = wbase[o + (8 + i) * 2 * NL_W];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { c0 = MFMA32(ap0[2 * (g + i)], bA[i], c0); c1 = MFMA32(ap1[2 * (g + i)], bA[i], c1); }
+        if (g + 16 < NL_W / 2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bA[i] = wbase[o + (16 + i) * 2 * NL_W];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { c0 = MFMA32(ap0[2 * (g + 8 + i)], bB[i], c0); c1 = MFMA32(ap1[2 * (g + 8 + i)], bB[i], c1); }
+    }
+}
+
+// For each of the 32 rows a half-wave holds (16 of h0 ++ 16 of h1), the sum over its 32 lanes of
+// h[row] * w3c, by recursive halving: 31 shuffles instead of 160; lane l31 ends up with the total of
+// list entry e = l31.  Register-lean: level 1 consumes h0/h1 directly (16 live values), then 8, 4, 2, 1.
+__device__ __forceinline__ float halfwave_rowsum(const f32x16& h0, const f32x16& h1, float w3c, int l31)
+{
+    float v16[16], v8[8], v4[4], v2[2];
+    {
+        const bool up = (l31 & 16) != 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float a0 = h0[i] * w3c, a1 = h1[i] * w3c;
+            v16[i] = (up ? a1 : a0) + __shfl_xor(up ? a0 : a1, 16);
+        }
+    }
+    {
+        const bool up = (l31 & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v8[i] = (up ? v16[i + 8] : v16[i]) + __shfl_xor(up ? v16[i] : v16[i + 8], 8);
+    }
+    {
+        const bool up = (l31 & 4) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v4[i] = (up ? v8[i + 4] : v8[i]) + __shfl_xor(up ? v8[i] : v8[i + 4], 4);
+    }
+    {
+        const bool up = (l31 & 2) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) v2[i] = (up ? v4[i + 2] : v4[i]) + __shfl_xor(up ? v4[i] : v4[i + 2], 2);
+    }
+    const bool up = (l31 & 1) != 0;
+    return (up ? v2[1] : v2[0]) + __shfl_xor(up ? v2[0] : v2[1], 1);
+}
+
 template <bool TRAIN>
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[S_TOTAL];
-    float* sH1 = lds + S_H1; float* sD = lds + S_D; float* sX = lds + S_X; float* sdX = lds + S_DX;
+    float* sH1 = lds + S_H1; float* sD = lds + S_D; float* sX = lds + S_X; float* sW1 = lds + S_W1;
     float* sS = lds + S_S; float* sdS = lds + S_DS;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -83,32 +143,50 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
     const int P = ls.P;
     const int ntiles = (P + DEC_M - 1) / DEC_M;
 
-    const float* W1 = a.params + NL_OFF_W1; const float* W2 = a.params + NL_OFF_W2;
+    const float* W2 = a.params + NL_OFF_W2;
     const float b1c = a.params[NL_OFF_B1 + col], b2c = a.params[NL_OFF_B2 + col], w3c = a.params[NL_OFF_W3 + col];
     const float b3 = a.params[NL_OFF_B3];
 
     // persistent weight-gradient accumulators (dW2 lives in k_decoder_wgrad2)
-    f32x4 accW1[2];
+    f32x4 accW1[4];
     float aW3 = 0.f, aB2 = 0.f, aB1 = 0.f, aB3 = 0.f;
     double lossFs = 0.0, lossSdf = 0.0;
     if (TRAIN) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) for (int r = 0; r < 4; ++r) accW1[t][r] = 0.f;
+        for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) accW1[t][r] = 0.f;
     }
-    for (int i = tid; i < DEC_M * LDX; i += DEC_THREADS) sdX[i] = 0.f;
+    for (int i = tid; i < NL_W * NL_C; i += DEC_THREADS) sW1[i] = a.params[NL_OFF_W1 + i];
     if (tid < DEC_M) sS[tid] = 0.f;
+
+    // software prefetch of the next tile's inputs (X slice; loss inputs for the 64 sample-owner threads)
+    const int xe = tid * 2, xi = xe >> 4, xc = xe & 15;
+    float2 xv = make_float2(0.f, 0.f);
+    float pz = 0.f, pd = 0.f;
+    {
+        const int row0 = blockIdx.x * DEC_M;
+        if (blockIdx.x < ntiles && row0 + xi < P) xv = *reinterpret_cast<const float2*>(a.X + (size_t)(row0 + xi) * NL_C + xc);
+        if (tid < DEC_M && blockIdx.x < ntiles && row0 + tid < P) {
+            const int ray = a.s_ray[row0 + tid];
+            pz = a.s_depth[row0 + tid] * a.cos_gt[ray]; pd = a.gt_dist[ray];
+        }
+    }
     __syncthreads();
 
     int tile_no = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++tile_no) {
         const int row0 = tile * DEC_M;
         DBG_STAMP(0);
-        // ---------------- A: X tile -> LDS ----------------
+        // ---------------- A: X tile -> LDS ; issue the next tile's loads ----------------
+        sX[xi * LDX + xc] = xv.x; sX[xi * LDX + xc + 1] = xv.y;
+        const float cz = pz, cd = pd;
         {
-            const int e = tid * 2, i = e >> 4, c = e & 15;
-            float2 v = make_float2(0.f, 0.f);
-            if (row0 + i < P) v = *reinterpret_cast<const float2*>(a.X + (size_t)(row0 + i) * NL_C + c);
-            sX[i * LDX + c] = v.x; sX[i * LDX + c + 1] = v.y;
+            const int nrow0 = (tile + gridDim.x) * DEC_M;
+            xv = make_float2(0.f, 0.f);
+            if (nrow0 + xi < P) xv = *reinterpret_cast<const float2*>(a.X + (size_t)(nrow0 + xi) * NL_C + xc);
+            if (tid < DEC_M && nrow0 + tid < P) {
+                const int ray = a.s_ray[nrow0 + tid];
+                pz = a.s_depth[nrow0 + tid] * a.cos_gt[ray]; pd = a.gt_dist[ray];
+            }
         }
         __syncthreads();
         DBG_STAMP(1);
@@ -119,9 +197,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
 #pragma unroll
             for (int kk = 0; kk < NL_C / 2; ++kk) {
-                const float bw = W1[col * NL_C + 2 * kk + lh];
-                const float a0 = sX[l31 * LDX + 2 * kk + lh], a1 = sX[(32 + l31) * LDX + 2 * kk + lh];
-                c0 = MFMA32(a0, bw, c0); c1 = MFMA32(a1, bw, c1);
+                const float bw = sW1[col * NL_C + 2 * kk + lh];
+                c0 = MFMA32(sX[l31 * LDX + 2 * kk + lh], bw, c0); c1 = MFMA32(sX[(32 + l31) * LDX + 2 * kk + lh], bw, c1);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -137,26 +214,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
-            const float* bp = a.W2T + lh * NL_W + col;
-            const float* ap0 = sH1 + l31 * LDH + lh; const float* ap1 = sH1 + (32 + l31) * LDH + lh;
-#pragma unroll 8
-            for (int kk = 0; kk < NL_W / 2; ++kk) {
-                const float bw = bp[(size_t)kk * 2 * NL_W];
-                const float a0 = ap0[2 * kk], a1 = ap1[2 * kk];
-                h0 = MFMA32(a0, bw, h0); h1 = MFMA32(a1, bw, h1);
-            }
+            gemm256(a.W2T, lh * NL_W + col, sH1 + l31 * LDH + lh, sH1 + (32 + l31) * LDH + lh, h0, h1);
             DBG_STAMP(3);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                h0[r] = fmaxf(h0[r] + b2c, 0.f); h1[r] = fmaxf(h1[r] + b2c, 0.f);
-                float p0 = h0[r] * w3c, p1 = h1[r] * w3c;
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) { p0 += __shfl_xor(p0, off); p1 += __shfl_xor(p1, off); }
-                if (l31 == 0) {
-                    const int row = d32_row(r, lh);
-                    atomicAdd(&sS[row], p0); atomicAdd(&sS[32 + row], p1);
-                }
-            }
+            for (int r = 0; r < 16; ++r) { h0[r] = fmaxf(h0[r] + b2c, 0.f); h1[r] = fmaxf(h1[r] + b2c, 0.f); }
+            const float tot = halfwave_rowsum(h0, h1, w3c, l31);               // entry e = l31 of [h0 rows | h1 rows]
+            atomicAdd(&sS[(l31 >> 4) * 32 + d32_row(l31 & 15, lh)], tot);
         }
         __syncthreads();
         DBG_STAMP(4);
@@ -166,13 +229,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             float ds = 0.f;
             if (g < P) {
                 const float s = sS[tid] + b3;
-                const int ray = a.s_ray[g];
-                const float c = a.cos_gt[ray], d = a.gt_dist[ray];
-                const float z = a.s_depth[g] * c;
                 bool f, m;
-                nl_loss_masks(z, d, ls.tau, ls.max_depth, &f, &m);
+                nl_loss_masks(cz, cd, ls.tau, ls.max_depth, &f, &m);
                 float q1, q2;
-                ds = nl_loss_grad(s, z, d, f, m, ls, &q1, &q2);
+                ds = nl_loss_grad(s, cz, cd, f, m, ls, &q1, &q2);
                 a.sdf[g] = s; a.dsdf[g] = ds;
                 lossFs += (double)q1; lossSdf += (double)q2;
             }
@@ -182,23 +242,29 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         __syncthreads();
         DBG_STAMP(5);
         // ---------------- E: dH2 = ds * w3 * [H2 > 0] -> LDS ----------------
+        {
+            unsigned myword = 0u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = d32_row(r, lh);
-            const float ds0 = sdS[row], ds1 = sdS[32 + row];
-            const float g0 = h0[r] > 0.f ? ds0 * w3c : 0.f, g1 = h1[r] > 0.f ? ds1 * w3c : 0.f;
-            sD[row * LDH + col] = g0; sD[(32 + row) * LDH + col] = g1;
-            if (TRAIN) {
-                aW3 += ds0 * h0[r] + ds1 * h1[r]; aB2 += g0 + g1;
-                // ReLU mask of H2: one ballot = 32 columns of two rows (lanes 0-31 / 32-63)
-                const unsigned long long bm0 = __ballot(h0[r] > 0.f), bm1 = __ballot(h1[r] > 0.f);
-                if (lane == 0) {
-                    const int ra = d32_row(r, 0), rb = d32_row(r, 1);
-                    if (row0 + ra < P) a.relu2_mask[(size_t)(row0 + ra) * 8 + w] = (unsigned)bm0;
-                    if (row0 + rb < P) a.relu2_mask[(size_t)(row0 + rb) * 8 + w] = (unsigned)(bm0 >> 32);
-                    if (row0 + 32 + ra < P) a.relu2_mask[(size_t)(row0 + 32 + ra) * 8 + w] = (unsigned)bm1;
-                    if (row0 + 32 + rb < P) a.relu2_mask[(size_t)(row0 + 32 + rb) * 8 + w] = (unsigned)(bm1 >> 32);
+            for (int r = 0; r < 16; ++r) {
+                const int row = d32_row(r, lh);
+                const float ds0 = sdS[row], ds1 = sdS[32 + row];
+                const float g0 = h0[r] > 0.f ? ds0 * w3c : 0.f, g1 = h1[r] > 0.f ? ds1 * w3c : 0.f;
+                sD[row * LDH + col] = g0; sD[(32 + row) * LDH + col] = g1;
+                if (TRAIN) {
+                    aW3 += ds0 * h0[r] + ds1 * h1[r]; aB2 += g0 + g1;
+                    // ReLU mask of H2: one ballot = 32 columns of two rows (lanes 0-31 / 32-63);
+                    // lane 4r+s keeps word s of this r, so the 64 words leave in ONE store instruction
+                    const unsigned long long bm0 = __ballot(h0[r] > 0.f), bm1 = __ballot(h1[r] > 0.f);
+                    if (lane == 4 * r + 0) myword = (unsigned)bm0;
+                    if (lane == 4 * r + 1) myword = (unsigned)(bm0 >> 32);
+                    if (lane == 4 * r + 2) myword = (unsigned)bm1;
+                    if (lane == 4 * r + 3) myword = (unsigned)(bm1 >> 32);
                 }
+            }
+            if (TRAIN) {
+                const int r = lane >> 2, sel = lane & 3;
+                const int mrow = row0 + d32_row(r, sel & 1) + ((sel & 2) ? 32 : 0);
+                if (mrow < P) a.relu2_mask[(size_t)mrow * 8 + w] = myword;
             }
         }
         __syncthreads();
@@ -208,14 +274,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { g0v[r] = 0.f; g1v[r] = 0.f; }
-            const float* bp = W2 + lh * NL_W + col;
-            const float* ap0 = sD + l31 * LDH + lh; const float* ap1 = sD + (32 + l31) * LDH + lh;
-#pragma unroll 8
-            for (int jj = 0; jj < NL_W / 2; ++jj) {
-                const float bw = bp[(size_t)jj * 2 * NL_W];
-                const float a0 = ap0[2 * jj], a1 = ap1[2 * jj];
-                g0v = MFMA32(a0, bw, g0v); g1v = MFMA32(a1, bw, g1v);
-            }
+            gemm256(W2, lh * NL_W + col, sD + l31 * LDH + lh, sD + (32 + l31) * LDH + lh, g0v, g1v);
             DBG_STAMP(7);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -235,38 +294,31 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         }
         __syncthreads();
         DBG_STAMP(9);
-        // ---------------- I: dX = dH1 W1 (k-split over waves), dW1 += dH1^T X ----------------
-        {
-#pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
-                f32x4 cx = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int k = 32 * w + 4 * q + lq;
-                    cx = MFMA16(sD[(16 * rt + l15) * LDH + k], W1[k * NL_C + l15], cx);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(&sdX[(16 * rt + 4 * lq + r) * LDX + l15], cx[r]);
+        // ---------------- I: waves 0-3: dX[16 rows each] = dH1 W1 -> global ; waves 4-7: dW1 += dH1^T X ----------------
+        if (w < 4) {
+            f32x4 cxa = {0.f, 0.f, 0.f, 0.f}, cxb = {0.f, 0.f, 0.f, 0.f};
+            const float* ap = sD + (16 * w + l15) * LDH + lq;
+            const float* bq = sW1 + lq * NL_C + l15;
+#pragma unroll 8
+            for (int q = 0; q < NL_W / 4; q += 2) {
+                cxa = MFMA16(ap[4 * q], bq[4 * q * NL_C], cxa);
+                cxb = MFMA16(ap[4 * q + 4], bq[(4 * q + 4) * NL_C], cxb);
             }
-            if (TRAIN) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+            for (int r = 0; r < 4; ++r) {
+                const int g = row0 + 16 * w + 4 * lq + r;
+                if (g < P) a.dX[(size_t)g * NL_C + l15] = cxa[r] + cxb[r];
+            }
+        } else if (TRAIN) {
+            const int hb = 64 * (w - 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
 #pragma unroll 4
-                    for (int ii = 0; ii < DEC_M / 4; ++ii)
-                        accW1[t] = MFMA16(sD[(4 * ii + lq) * LDH + 32 * w + 16 * t + l15], sX[(4 * ii + lq) * LDX + l15], accW1[t]);
-            }
+                for (int ii = 0; ii < DEC_M / 4; ++ii)
+                    accW1[t] = MFMA16(sD[(4 * ii + lq) * LDH + hb + 16 * t + l15], sX[(4 * ii + lq) * LDX + l15], accW1[t]);
         }
         __syncthreads();
         DBG_STAMP(10);
-        // ---------------- J: dX tile -> global ----------------
-        {
-            const int e = tid * 2, i = e >> 4, c = e & 15;
-            if (row0 + i < P)
-                *reinterpret_cast<float2*>(a.dX + (size_t)(row0 + i) * NL_C + c) = make_float2(sdX[i * LDX + c], sdX[i * LDX + c + 1]);
-            sdX[i * LDX + c] = 0.f; sdX[i * LDX + c + 1] = 0.f;
-        }
-        __syncthreads();
-        DBG_STAMP(11);
     }
 
     // ---------------- loss sums ----------------
@@ -280,11 +332,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
     // ---------------- flush weight-gradient partials ----------------
     if (TRAIN) {
         float* base = a.partials + (size_t)blockIdx.x * NL_DEC_PARAMS;
+        if (w >= 4) {
+            const int hb = 64 * (w - 4);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                base[NL_OFF_W1 + (32 * w + 16 * t + 4 * lq + r) * NL_C + l15] = accW1[t][r];
+                for (int r = 0; r < 4; ++r)
+                    base[NL_OFF_W1 + (hb + 16 * t + 4 * lq + r) * NL_C + l15] = accW1[t][r];
+        }
         aW3 += __shfl_xor(aW3, 32); aB2 += __shfl_xor(aB2, 32); aB1 += __shfl_xor(aB1, 32);
         if (lh == 0) { base[NL_OFF_W3 + col] = aW3; base[NL_OFF_B2 + col] = aB2; base[NL_OFF_B1 + col] = aB1; }
         if (tid < 64) {
@@ -298,41 +353,52 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 // ---------------------------------------------------------------------------------------------
 // dW2 = dH2^T H1 over all samples (K = samples).  Persistent; per 64-sample tile: H1 = relu(X W1^T+b1)
 // -> LDS, dH2[i][j] = mask(i,j) ? dsdf_i * w3_j : 0 -> LDS, then 256 MFMAs per wave into the 8
-// persistent 32x32 accumulators of the wave's 32-row slab of dW2.
+// persistent 32x32 accumulators of the wave's 32-row slab of dW2.  The next tile's inputs (X slice,
+// dsdf, mask words: one word per thread) are prefetched into registers under the MFMA phase.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2(const NlLossScalars* __restrict__ lsp, const float* __restrict__ X,
                                                                     const float* __restrict__ params, const float* __restrict__ dsdf,
                                                                     const unsigned* __restrict__ relu2_mask, float* __restrict__ partials)
 {
-    __shared__ __attribute__((aligned(16))) float lds[2 * DEC_M * LDH + DEC_M * LDX + DEC_M];
-    float* sH1 = lds; float* sD = lds + DEC_M * LDH; float* sX = sD + DEC_M * LDH; float* sdS = sX + DEC_M * LDX;
+    __shared__ __attribute__((aligned(16))) float lds[2 * DEC_M * LDH + DEC_M * LDX + NL_W * NL_C + DEC_M + DEC_M * 8];
+    float* sH1 = lds; float* sD = lds + DEC_M * LDH; float* sX = sD + DEC_M * LDH; float* sW1 = sX + DEC_M * LDX;
+    float* sdS = sW1 + NL_W * NL_C; unsigned* sMask = reinterpret_cast<unsigned*>(sdS + DEC_M);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int col = 32 * w + l31;
     const int P = lsp->P;
     const int ntiles = (P + DEC_M - 1) / DEC_M;
-    const float* W1 = params + NL_OFF_W1;
     const float b1c = params[NL_OFF_B1 + col], w3c = params[NL_OFF_W3 + col];
     f32x16 accW2[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) for (int r = 0; r < 16; ++r) accW2[t][r] = 0.f;
+    for (int i = tid; i < NL_W * NL_C; i += DEC_THREADS) sW1[i] = params[NL_OFF_W1 + i];
+
+    const int xe = tid * 2, xi = xe >> 4, xc = xe & 15;
+    float2 xv = make_float2(0.f, 0.f); float pds = 0.f; unsigned pmk = 0u;
+    auto prefetch = [&](int tile) {
+        const int row0 = tile * DEC_M;
+        xv = make_float2(0.f, 0.f); pds = 0.f; pmk = 0u;
+        if (tile < ntiles) {
+            if (row0 + xi < P) xv = *reinterpret_cast<const float2*>(X + (size_t)(row0 + xi) * NL_C + xc);
+            if (tid < DEC_M && row0 + tid < P) pds = dsdf[row0 + tid];
+            if (row0 + (tid >> 3) < P) pmk = relu2_mask[(size_t)row0 * 8 + tid];
+        }
+    };
+    prefetch(blockIdx.x);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int row0 = tile * DEC_M;
-        {
-            const int e = tid * 2, i = e >> 4, c = e & 15;
-            float2 v = make_float2(0.f, 0.f);
-            if (row0 + i < P) v = *reinterpret_cast<const float2*>(X + (size_t)(row0 + i) * NL_C + c);
-            sX[i * LDX + c] = v.x; sX[i * LDX + c + 1] = v.y;
-            if (tid < DEC_M) sdS[tid] = (row0 + tid < P) ? dsdf[row0 + tid] : 0.f;
-        }
+        sX[xi * LDX + xc] = xv.x; sX[xi * LDX + xc + 1] = xv.y;
+        if (tid < DEC_M) sdS[tid] = pds;
+        sMask[tid] = pmk;
         __syncthreads();
+        prefetch(tile + gridDim.x);
         {   // H1 -> LDS
             f32x16 c0, c1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
 #pragma unroll
             for (int kk = 0; kk < NL_C / 2; ++kk) {
-                const float bw = W1[col * NL_C + 2 * kk + lh];
+                const float bw = sW1[col * NL_C + 2 * kk + lh];
                 c0 = MFMA32(sX[l31 * LDX + 2 * kk + lh], bw, c0); c1 = MFMA32(sX[(32 + l31) * LDX + 2 * kk + lh], bw, c1);
             }
 #pragma unroll
@@ -342,11 +408,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2(const NlLossS
             }
         }
         {   // dH2 -> LDS: this lane's column, rows lh, lh+2, ...
-#pragma unroll 4
-            for (int i = lh; i < DEC_M; i += 2) {
-                const unsigned word = (row0 + i < P) ? relu2_mask[(size_t)(row0 + i) * 8 + w] : 0u;
-                sD[i * LDH + col] = ((word >> l31) & 1u) ? sdS[i] * w3c : 0.f;
-            }
+#pragma unroll 8
+            for (int i = lh; i < DEC_M; i += 2)
+                sD[i * LDH + col] = ((sMask[i * 8 + w] >> l31) & 1u) ? sdS[i] * w3c : 0.f;
         }
         __syncthreads();
         {

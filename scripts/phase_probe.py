@@ -17,8 +17,8 @@ for train in (True, False):
     eng.forward_backward(w["map"], w["dec"], cfg, train_decoder=train)
     torch.cuda.synchronize()
     L.lib().nl_decoder_set_debug_buffer(None)
-    d = dbg.cpu().numpy().reshape(16, 16)[:, :12]
-    names = ["A:loadX", "B:H1", "C:loop", "C:epi", "D:loss", "E:dH2", "F:loop", "F:epi", "H:dH1", "I:L1bwd", "J:store"]
+    d = dbg.cpu().numpy().reshape(16, 16)[:, :11]
+    names = ["A:loadX", "B:H1", "C:loop", "C:epi", "D:loss", "E:dH2", "F:loop", "F:epi", "H:dH1", "I:L1bwd"]
     ph = np.diff(d[2:10], axis=1)
     print("train" if train else "frozen", "cycles/phase (mean over tiles 2..9):")
     for n, v in zip(names, ph.mean(0)):
