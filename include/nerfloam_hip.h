@@ -95,7 +95,7 @@ int nl_gather_trilinear(const void* loss_scalars, const int* s_vox, const float*
  * decoder backward (autograd of render_helpers.py:422).  params = decoder block, W2T = transposed W2.
  * Outputs sdf[P], dsdf[P], dX[P,16]; with train_decoder: per-workgroup weight-gradient slabs
  * partials[nslabs][NL_DEC_PARAMS] (all but the W2 block; nl_decoder_wgrad2 adds that; sum the slabs with
- * nl_reduce_partials) and relu2_mask[P][8] scratch. */
+ * nl_reduce_partials) and relu2_mask[ceil(P/64)][512] scratch (one 32-bit ReLU word per tile and thread). */
 int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* params, const float* W2T,
                        const int* s_ray, const float* s_depth, const float* cos_gt, const float* gt_dist,
                        float* sdf, float* dsdf, float* dX, float* partials, unsigned* relu2_mask, int nslabs, int train_decoder,

@@ -58,7 +58,7 @@ struct DecArgs {
     float* dsdf;                // [P]
     float* dX;                  // [P,16]
     float* partials;            // [gridDim.x][NL_DEC_PARAMS] (train only)
-    unsigned* relu2_mask;       // [P][8] bit j%32 of word j/32 = (H2[j] > 0)   (train only)
+    unsigned* relu2_mask;       // [tiles][512] one word per (tile, thread): that lane's 32 ReLU bits of H2 (train only)
     double* dcounters;          // loss sums
     long long* dbg;             // optional [16 tiles][16] s_memtime stamps of workgroup 0 / thread 0 (profiling aid)
 };
@@ -72,24 +72,35 @@ __device__ __forceinline__ int d32_row(int r, int lh) { return (r & 3) + 8 * (r 
 // 256-deep GEMM main loop shared by forward (B = W2T) and dgrad (B = W2): per k-pair one coalesced
 // B-operand load straight from L2 feeds both 32-row sub-tiles; B operands are register
 // double-buffered one group of 8 ahead so the L2 latency hides under 16 MFMAs of the previous group.
-__device__ __forceinline__ void gemm256(const float* __restrict__ wbase, int voff, const float* ap0, const float* ap1,
-                                        f32x16& c0, f32x16& c1)
+typedef __amdgpu_buffer_rsrc_t i32x4;   // 128-bit buffer resource descriptor
+
+// 128-bit buffer resource over a [256][256] fp32 matrix (wave-uniform): loads then need ONE per-lane
+// 32-bit byte offset + a scalar offset, instead of a 64-bit address pair per unrolled load.
+__device__ __forceinline__ i32x4 make_w_rsrc(const float* base)
 {
-    // wbase is wave-uniform (kernel argument), voff the lane's 32-bit element offset: lets the compiler use
-    // SGPR-base + VGPR-offset global loads instead of one 64-bit address pair per unrolled load
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, NL_W * NL_W * 4, 0x00020000);
+}
+__device__ __forceinline__ float bload(i32x4 rsrc, int voff_bytes, int soff_bytes)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_bytes, soff_bytes, 0));
+}
+
+__device__ __forceinline__ void gemm256(i32x4 rsrc, int voff_bytes, const float* ap0, const float* ap1, f32x16& c0, f32x16& c1)
+{
+    constexpr int RB = 2 * NL_W * 4;                   // bytes between consecutive k-pairs of the B matrix
     float bA[8], bB[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bA[i] = wbase[voff + i * 2 * NL_W];
+    for (int i = 0; i < 8; ++i) bA[i] = bload(rsrc, voff_bytes, i * RB);
 #pragma unroll 1
     for (int g = 0; g < NL_W / 2; g += 16) {
-        const int o = voff + g * 2 * NL_W;
+        const int so = g * RB;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) bB[i] = wbase[o + (8 + i) * 2 * NL_W];
+        for (int i = 0; i < 8; ++i) bB[i] = bload(rsrc, voff_bytes, so + (8 + i) * RB);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { c0 = MFMA32(ap0[2 * (g + i)], bA[i], c0); c1 = MFMA32(ap1[2 * (g + i)], bA[i], c1); }
         if (g + 16 < NL_W / 2) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) bA[i] = wbase[o + (16 + i) * 2 * NL_W];
+            for (int i = 0; i < 8; ++i) bA[i] = bload(rsrc, voff_bytes, so + (16 + i) * RB);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) { c0 = MFMA32(ap0[2 * (g + 8 + i)], bB[i], c0); c1 = MFMA32(ap1[2 * (g + 8 + i)], bB[i], c1); }
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
     const int P = ls.P;
     const int ntiles = (P + DEC_M - 1) / DEC_M;
 
-    const float* W2 = a.params + NL_OFF_W2;
+    const i32x4 rsW2 = make_w_rsrc(a.params + NL_OFF_W2), rsW2T = make_w_rsrc(a.W2T);
     const float b1c = a.params[NL_OFF_B1 + col], b2c = a.params[NL_OFF_B2 + col], w3c = a.params[NL_OFF_W3 + col];
     const float b3 = a.params[NL_OFF_B3];
 
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
-            gemm256(a.W2T, lh * NL_W + col, sH1 + l31 * LDH + lh, sH1 + (32 + l31) * LDH + lh, h0, h1);
+            gemm256(rsW2T, (lh * NL_W + col) * 4, sH1 + l31 * LDH + lh, sH1 + (32 + l31) * LDH + lh, h0, h1);
             DBG_STAMP(3);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { h0[r] = fmaxf(h0[r] + b2c, 0.f); h1[r] = fmaxf(h1[r] + b2c, 0.f); }
@@ -243,29 +254,21 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         DBG_STAMP(5);
         // ---------------- E: dH2 = ds * w3 * [H2 > 0] -> LDS ----------------
         {
-            unsigned myword = 0u;
+            unsigned mw = 0u;                       // this lane's 32 ReLU bits: bit r = h0[r] > 0, bit 16+r = h1[r] > 0
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = d32_row(r, lh);
                 const float ds0 = sdS[row], ds1 = sdS[32 + row];
-                const float g0 = h0[r] > 0.f ? ds0 * w3c : 0.f, g1 = h1[r] > 0.f ? ds1 * w3c : 0.f;
+                const bool on0 = h0[r] > 0.f, on1 = h1[r] > 0.f;
+                const float g0 = on0 ? ds0 * w3c : 0.f, g1 = on1 ? ds1 * w3c : 0.f;
                 sD[row * LDH + col] = g0; sD[(32 + row) * LDH + col] = g1;
                 if (TRAIN) {
-                    aW3 += ds0 * h0[r] + ds1 * h1[r]; aB2 += g0 + g1;
-                    // ReLU mask of H2: one ballot = 32 columns of two rows (lanes 0-31 / 32-63);
-                    // lane 4r+s keeps word s of this r, so the 64 words leave in ONE store instruction
-                    const unsigned long long bm0 = __ballot(h0[r] > 0.f), bm1 = __ballot(h1[r] > 0.f);
-                    if (lane == 4 * r + 0) myword = (unsigned)bm0;
-                    if (lane == 4 * r + 1) myword = (unsigned)(bm0 >> 32);
-                    if (lane == 4 * r + 2) myword = (unsigned)bm1;
-                    if (lane == 4 * r + 3) myword = (unsigned)(bm1 >> 32);
+                    aW3 = fmaf(ds0, h0[r], aW3); aW3 = fmaf(ds1, h1[r], aW3); aB2 += g0; aB2 += g1;
+                    mw |= (on0 ? (1u << r) : 0u) | (on1 ? (1u << (16 + r)) : 0u);
                 }
             }
-            if (TRAIN) {
-                const int r = lane >> 2, sel = lane & 3;
-                const int mrow = row0 + d32_row(r, sel & 1) + ((sel & 2) ? 32 : 0);
-                if (mrow < P) a.relu2_mask[(size_t)mrow * 8 + w] = myword;
-            }
+            // one word per thread, thread-major per tile: k_decoder_wgrad2's thread (same wave/lane) reads it back
+            if (TRAIN) a.relu2_mask[(size_t)tile * DEC_THREADS + tid] = mw;
         }
         __syncthreads();
         DBG_STAMP(6);
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { g0v[r] = 0.f; g1v[r] = 0.f; }
-            gemm256(W2, lh * NL_W + col, sD + l31 * LDH + lh, sD + (32 + l31) * LDH + lh, g0v, g1v);
+            gemm256(rsW2, (lh * NL_W + col) * 4, sD + l31 * LDH + lh, sD + (32 + l31) * LDH + lh, g0v, g1v);
             DBG_STAMP(7);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -311,11 +314,13 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             }
         } else if (TRAIN) {
             const int hb = 64 * (w - 4);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
 #pragma unroll 4
-                for (int ii = 0; ii < DEC_M / 4; ++ii)
-                    accW1[t] = MFMA16(sD[(4 * ii + lq) * LDH + hb + 16 * t + l15], sX[(4 * ii + lq) * LDX + l15], accW1[t]);
+            for (int ii = 0; ii < DEC_M / 4; ++ii) {
+                const float xb = sX[(4 * ii + lq) * LDX + l15];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    accW1[t] = MFMA16(sD[(4 * ii + lq) * LDH + hb + 16 * t + l15], xb, accW1[t]);
+            }
         }
         __syncthreads();
         DBG_STAMP(10);
@@ -354,15 +359,15 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 // dW2 = dH2^T H1 over all samples (K = samples).  Persistent; per 64-sample tile: H1 = relu(X W1^T+b1)
 // -> LDS, dH2[i][j] = mask(i,j) ? dsdf_i * w3_j : 0 -> LDS, then 256 MFMAs per wave into the 8
 // persistent 32x32 accumulators of the wave's 32-row slab of dW2.  The next tile's inputs (X slice,
-// dsdf, mask words: one word per thread) are prefetched into registers under the MFMA phase.
+// dsdf, ReLU-mask word: one per thread) are prefetched into registers under the MFMA phase.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2(const NlLossScalars* __restrict__ lsp, const float* __restrict__ X,
                                                                     const float* __restrict__ params, const float* __restrict__ dsdf,
                                                                     const unsigned* __restrict__ relu2_mask, float* __restrict__ partials)
 {
-    __shared__ __attribute__((aligned(16))) float lds[2 * DEC_M * LDH + DEC_M * LDX + NL_W * NL_C + DEC_M + DEC_M * 8];
+    __shared__ __attribute__((aligned(16))) float lds[2 * DEC_M * LDH + DEC_M * LDX + NL_W * NL_C + DEC_M];
     float* sH1 = lds; float* sD = lds + DEC_M * LDH; float* sX = sD + DEC_M * LDH; float* sW1 = sX + DEC_M * LDX;
-    float* sdS = sW1 + NL_W * NL_C; unsigned* sMask = reinterpret_cast<unsigned*>(sdS + DEC_M);
+    float* sdS = sW1 + NL_W * NL_C;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int col = 32 * w + l31;
     const int P = lsp->P;
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2(const NlLossS
         if (tile < ntiles) {
             if (row0 + xi < P) xv = *reinterpret_cast<const float2*>(X + (size_t)(row0 + xi) * NL_C + xc);
             if (tid < DEC_M && row0 + tid < P) pds = dsdf[row0 + tid];
-            if (row0 + (tid >> 3) < P) pmk = relu2_mask[(size_t)row0 * 8 + tid];
+            pmk = relu2_mask[(size_t)tile * DEC_THREADS + tid];
         }
     };
     prefetch(blockIdx.x);
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2(const NlLossS
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         sX[xi * LDX + xc] = xv.x; sX[xi * LDX + xc + 1] = xv.y;
         if (tid < DEC_M) sdS[tid] = pds;
-        sMask[tid] = pmk;
+        const unsigned mw = pmk;
         __syncthreads();
         prefetch(tile + gridDim.x);
         {   // H1 -> LDS
@@ -407,10 +412,13 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2(const NlLossS
                 sH1[row * LDH + col] = fmaxf(c0[r] + b1c, 0.f); sH1[(32 + row) * LDH + col] = fmaxf(c1[r] + b1c, 0.f);
             }
         }
-        {   // dH2 -> LDS: this lane's column, rows lh, lh+2, ...
-#pragma unroll 8
-            for (int i = lh; i < DEC_M; i += 2)
-                sD[i * LDH + col] = ((sMask[i * 8 + w] >> l31) & 1u) ? sdS[i] * w3c : 0.f;
+        {   // dH2 -> LDS: this lane's column, the same 32 rows its mask word describes
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = d32_row(r, lh);
+                sD[row * LDH + col] = ((mw >> r) & 1u) ? sdS[row] * w3c : 0.f;
+                sD[(32 + row) * LDH + col] = ((mw >> (16 + r)) & 1u) ? sdS[32 + row] * w3c : 0.f;
+            }
         }
         __syncthreads();
         {

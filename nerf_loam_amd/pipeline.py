@@ -135,7 +135,7 @@ class SdfEngine:
         self.dX = torch.empty(P, L.NL_C, dtype=F32, device=d)
         self.sdf = torch.empty(P, dtype=F32, device=d)
         self.dsdf = torch.empty(P, dtype=F32, device=d)
-        self.relu2_mask = torch.empty(P, 8, dtype=I32, device=d)
+        self.relu2_mask = torch.empty(P * 8 + 1024, dtype=I32, device=d)     # [tiles][512] ReLU bit words
         # counters + loss scalars
         self.counters = torch.zeros(L.NL_CNT_BYTES // 4, dtype=I32, device=d)
         self.loss_scalars = torch.zeros(L.NL_LOSS_SCALARS_BYTES // 4, dtype=I32, device=d)
