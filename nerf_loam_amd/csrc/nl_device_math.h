@@ -175,6 +175,7 @@ struct NlTailCtx {
     int rays_in_row;            // m   = rays per row in the launched chunk
     int j_in_row;               // j   = this ray's index inside its row chunk
     const int* row_first_idx;   // hit list (stride 1) of the row's first ray in the chunk
+    int row_first_count;        // number of valid entries in that list (entries beyond it read as -1)
     bool tail_always;
 };
 
@@ -216,7 +217,7 @@ NL_HD int nl_sample_walk(const int* idx, const float* t0, const float* t1, int P
         emit(s, idx[curr_bin], (curr_max_depth + z_low) * 0.5f, curr_max_depth - z_low);
         ++curr_bin; ++s;
         if (curr_bin >= P) break;
-        if ((tc.tail_always ? idx[curr_bin] : tc.row_first_idx[curr_bin]) == -1) break;
+        if ((tc.tail_always ? idx[curr_bin] : (curr_bin < tc.row_first_count ? tc.row_first_idx[curr_bin] : -1)) == -1) break;
         curr_min_depth = t0[curr_bin]; curr_max_depth = t1[curr_bin];
         z_low = curr_min_depth;
     }

@@ -92,8 +92,8 @@ __global__ __launch_bounds__(NL_FIELD_THREADS) void k_gather_trilinear(FieldArgs
 // The scatter is the HBM-atomic hot spot (8 rows x 16 channels per sample = 140 M fp32 atomics for one
 // 64x2048 scan).  Samples are packed in ray order, so a chunk of consecutive samples touches few
 // distinct vertex rows: each workgroup aggregates a 1024-sample chunk in an LDS hash table
-// (open addressing on the row id, ds_add_f32 accumulation) and flushes every touched row once with
-// global atomics - ~40x fewer HBM atomics.  Table overflow falls back to direct global atomics.
+// (open addressing on the row id, ds_add_f32 accumulation; a lane pair pre-accumulates each voxel run of its 8
+// consecutive samples in registers) and flushes every touched row once with global atomics - ~40x fewer HBM atomics.  Table overflow falls back to direct global atomics.
 #define TB_CHUNK 1024
 #define TB_SLOTS 1024
 #define TB_PROBES 16
@@ -128,10 +128,41 @@ __global__ __launch_bounds__(NL_FIELD_THREADS) void k_trilinear_bwd(FieldArgs a)
     for (int i = 0; i < 12; ++i) pa[i] = 0.f;
     for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const int s_end = min(P, (chunk + 1) * TB_CHUNK);
-        for (int s = chunk * TB_CHUNK + pair; s < s_end; s += NL_FIELD_THREADS / 2) {   // both lanes of a pair share s
+        // a lane pair walks 8 CONSECUTIVE samples: consecutive samples of a ray mostly stay in one voxel, so the
+        // 8 corner rows' contributions accumulate in registers and reach the LDS table once per voxel run
+        int cur_vox = -1; int rows[8];
+        float acc[8][8];
+        auto flush_run = [&]() {
+            if (cur_vox < 0 || !a.want_emb_grad) return;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int slot = tb_insert(s_key, rows[k]);
+                if (slot >= 0) {
+                    float* dst = s_val + slot * NL_C + 8 * half;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) atomicAdd(dst + c, acc[k][c]);                  // ds_add_f32
+                } else {
+                    float* dst = a.g_emb + (size_t)rows[k] * NL_C + 8 * half;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) atomicAdd(dst + c, acc[k][c]);                  // global_atomic_add_f32
+                }
+            }
+        };
+        const int s_base = chunk * TB_CHUNK + pair * (TB_CHUNK / (NL_FIELD_THREADS / 2));
+#pragma unroll 1
+        for (int j = 0; j < TB_CHUNK / (NL_FIELD_THREADS / 2); ++j) {
+            const int s = s_base + j;
+            if (s >= s_end) break;                                  // both lanes of a pair share s: shuffles stay convergent
             const SampleGeom g = sample_geom(a, s);
             float w[8]; nl_trilinear_w(g.p, w);
-            int rows[8]; load_rows(a, g.vox, rows);
+            if (g.vox != cur_vox) {
+                flush_run();
+                cur_vox = g.vox; load_rows(a, g.vox, rows);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[k][c] = 0.f;
+            }
             float d[8];
             const float4* di = reinterpret_cast<const float4*>(a.dX + (size_t)s * NL_C + 8 * half);
             const float4 d0 = di[0], d1 = di[1];
@@ -139,22 +170,16 @@ __global__ __launch_bounds__(NL_FIELD_THREADS) void k_trilinear_bwd(FieldArgs a)
             float dot[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                float e[8]; load_emb8(a.emb, rows[k], half, e);
-                float acc = 0.f;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) acc += e[c] * d[c];
-                dot[k] = acc;
                 if (a.want_emb_grad) {
-                    const int slot = tb_insert(s_key, rows[k]);
-                    if (slot >= 0) {
-                        float* dst = s_val + slot * NL_C + 8 * half;
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) atomicAdd(dst + c, nl_round_bf16(w[k] * d[c]));          // ds_add_f32
-                    } else {
-                        float* dst = a.g_emb + (size_t)rows[k] * NL_C + 8 * half;
+                    for (int c = 0; c < 8; ++c) acc[k][c] += nl_round_bf16(w[k] * d[c]);
+                }
+                if (a.want_pose_grad) {
+                    float e[8]; load_emb8(a.emb, rows[k], half, e);
+                    float t = 0.f;
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) atomicAdd(dst + c, nl_round_bf16(w[k] * d[c]));          // global_atomic_add_f32
-                    }
+                    for (int c = 0; c < 8; ++c) t += e[c] * d[c];
+                    dot[k] = t;
                 }
             }
             if (!a.want_pose_grad) continue;
@@ -178,6 +203,7 @@ __global__ __launch_bounds__(NL_FIELD_THREADS) void k_trilinear_bwd(FieldArgs a)
                 pa[3 + 3 * i] += t * ds0; pa[4 + 3 * i] += t * ds1; pa[5 + 3 * i] += t * ds2;
             }
         }
+        flush_run();
         if (a.want_emb_grad) {
             __syncthreads();
             // flush: 16 lanes per slot (one channel each), touched rows only; slot is reset for the next chunk

@@ -60,19 +60,27 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_svo_intersect_raw(
 // Fused ray set-up + intersect + sort/cull (render_helpers.py:366-388, voxel_helpers.py:531-567).
 //   inputs per ray: unit direction in the sensor frame, gt return (sensor frame), cos, frame id
 //   poses[F][12]: rotation row-major (9) then translation (3)
-//   outputs: world direction, gt distance*cos, sorted hits [N,20] (idx -1 / depth max_distance
-//   padded), hit count; counters NLC_HMAX (atomic max)
+//   octree in the PACKED device layout built once per map update (pipeline.MapDevice):
+//     node_rec[n]   float4 (cx, cy, cz, bits(side))        16-byte aligned, one load per node visit
+//     node_child[n] 8 x int32 child ids (-1 = none)         32-byte aligned, two 16-byte loads
+//   same results as the reference layouts (centres [n,3] + children [n,9]); a node visit costs ONE
+//   round of three independent vector loads instead of up to eight dependent scalar child probes.
+//   The per-level DFS state (node, remaining-children bitmask) lives in LDS; hits are written to
+//   the ray's own output row in DFS order and then sorted in place (L2-resident).
+//   outputs: world direction, gt distance*cos, hit_idx/t0/t1[N,20] (first hit_count[r] entries are
+//   the sorted, culled hits; the rest of a row is NOT written), hit count; counters[NLC_HMAX].
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect(
     int N, const float* __restrict__ rays_d_sensor, const float* __restrict__ points_gt,
     const float* __restrict__ cos_gt, const int* __restrict__ frame_id, const float* __restrict__ poses,
-    const float* __restrict__ centres, const int* __restrict__ structure,
+    const float4* __restrict__ node_rec, const int4* __restrict__ node_child,
     float voxel_size, float max_distance,
     float* __restrict__ rays_d_world, float* __restrict__ gt_dist,
     int* __restrict__ hit_idx, float* __restrict__ hit_t0, float* __restrict__ hit_t1,
     int* __restrict__ hit_count, int* __restrict__ counters)
 {
-    __shared__ unsigned s_stack[NL_MAX_LEVELS * NL_GEO_THREADS];
+    __shared__ int s_node[NL_MAX_LEVELS * NL_GEO_THREADS];
+    __shared__ unsigned char s_mask[NL_MAX_LEVELS * NL_GEO_THREADS];
     __shared__ int s_hmax;
     if (threadIdx.x == 0) s_hmax = 0;
     __syncthreads();
@@ -87,18 +95,58 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect(
         rays_d_world[3 * r] = d[0]; rays_d_world[3 * r + 1] = d[1]; rays_d_world[3 * r + 2] = d[2];
         const float gx = points_gt[3 * r], gy = points_gt[3 * r + 1], gz = points_gt[3 * r + 2];
         gt_dist[r] = sqrtf((gx * gx + gy * gy) + gz * gz) * cos_gt[r];
-
-        int hi[NL_MAX_HITS]; float h0[NL_MAX_HITS], h1[NL_MAX_HITS];
-        LdsStack stk{&s_stack[threadIdx.x]};
-        const int cnt = nl_octree_walk(centres, structure, P[9], P[10], P[11], d[0], d[1], d[2],
-                                       voxel_size * 0.5f, NL_MAX_HITS, stk, hi, h0, h1);
-        valid = nl_sort_cull_hits(cnt, hi, h0, h1, max_distance);
+        const float ox = P[9], oy = P[10], oz = P[11];
+        const float half_voxel = voxel_size * 0.5f;
         int* oi = hit_idx + (size_t)r * NL_MAX_HITS; float* o0 = hit_t0 + (size_t)r * NL_MAX_HITS; float* o1 = hit_t1 + (size_t)r * NL_MAX_HITS;
-        for (int l = 0; l < NL_MAX_HITS; ++l) {
-            const bool v = l < cnt;
-            oi[l] = v ? hi[l] : -1;
-            o0[l] = v ? h0[l] : max_distance;
-            o1[l] = v ? h1[l] : max_distance;
+        int* st_node = s_node + threadIdx.x; unsigned char* st_mask = s_mask + threadIdx.x;
+
+        auto child_mask = [&](int node) -> unsigned {
+            const int4 a = node_child[2 * (size_t)node], b = node_child[2 * (size_t)node + 1];
+            return (a.x > -1 ? 1u : 0u) | (a.y > -1 ? 2u : 0u) | (a.z > -1 ? 4u : 0u) | (a.w > -1 ? 8u : 0u) |
+                   (b.x > -1 ? 16u : 0u) | (b.y > -1 ? 32u : 0u) | (b.z > -1 ? 64u : 0u) | (b.w > -1 ? 128u : 0u);
+        };
+        int cnt = 0, lvl = -1;
+        {   // root
+            const float4 rc = node_rec[0];
+            const int side = __float_as_int(rc.w);
+            float tn, tf;
+            if (nl_slab(ox, oy, oz, d[0], d[1], d[2], rc.x, rc.y, rc.z, half_voxel * (float)side, &tn, &tf)) {
+                if (side == 1) { oi[0] = 0; o0[0] = tn; o1[0] = tf; cnt = 1; }
+                else { lvl = 0; st_node[0] = 0; st_mask[0] = (unsigned char)child_mask(0); }
+            }
+        }
+        const int* child_flat = reinterpret_cast<const int*>(node_child);
+        while (lvl >= 0 && cnt < NL_MAX_HITS) {
+            unsigned m = st_mask[lvl * NL_GEO_THREADS];
+            if (m == 0) { --lvl; continue; }
+            const int u = 31 - __clz((int)m);                      // highest existing octant first (reference pop order)
+            st_mask[lvl * NL_GEO_THREADS] = (unsigned char)(m & ~(1u << u));
+            const int child = child_flat[8 * (size_t)st_node[lvl * NL_GEO_THREADS] + u];
+            const float4 rc = node_rec[child];
+            const int side = __float_as_int(rc.w);
+            unsigned cm = 0;
+            if (side != 1) cm = child_mask(child);                   // issued together with rc: one latency round
+            float tn, tf;
+            if (!nl_slab(ox, oy, oz, d[0], d[1], d[2], rc.x, rc.y, rc.z, half_voxel * (float)side, &tn, &tf)) continue;
+            if (side == 1) { oi[cnt] = child; o0[cnt] = tn; o1[cnt] = tf; ++cnt; continue; }
+            ++lvl;
+            st_node[lvl * NL_GEO_THREADS] = child; st_mask[lvl * NL_GEO_THREADS] = (unsigned char)cm;
+        }
+        // in-place stable insertion sort by t_min on the ray's own row, then cull (voxel_helpers.py:543-552)
+        for (int i = 1; i < cnt; ++i) {
+            const int ki = oi[i]; const float a = o0[i], b = o1[i];
+            int j = i - 1;
+            while (j >= 0) {
+                const float tj = o0[j];
+                if (!(tj > a)) break;
+                oi[j + 1] = oi[j]; o0[j + 1] = tj; o1[j + 1] = o1[j];
+                --j;
+            }
+            if (j + 1 != i) { oi[j + 1] = ki; o0[j + 1] = a; o1[j + 1] = b; }
+        }
+        for (int i = 0; i < cnt; ++i) {
+            const bool keep = !(o1[i] > 2.0f * max_distance) && !(o0[i] > max_distance);
+            if (keep) ++valid; else { oi[i] = -1; o0[i] = max_distance; o1[i] = max_distance; }
         }
         hit_count[r] = valid;
     }
@@ -228,11 +276,13 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample(SampleArgs a)
         const int rank = a.hit_rank[r] + a.counters[NLC_R_OFFSET];
         int hi[NL_MAX_HITS]; float h0[NL_MAX_HITS], h1[NL_MAX_HITS];
         float tot = 0.0f;
+        const int nh = a.hit_count[r];
 #pragma unroll
-        for (int l = 0; l < NL_MAX_HITS; ++l) {
-            hi[l] = a.hit_idx[(size_t)r * NL_MAX_HITS + l];
-            h0[l] = a.hit_t0[(size_t)r * NL_MAX_HITS + l];
-            h1[l] = a.hit_t1[(size_t)r * NL_MAX_HITS + l];
+        for (int l = 0; l < NL_MAX_HITS; ++l) {               // row tails beyond the ray's own hits are padding
+            const bool v = l < nh;
+            hi[l] = v ? a.hit_idx[(size_t)r * NL_MAX_HITS + l] : -1;
+            h0[l] = v ? a.hit_t0[(size_t)r * NL_MAX_HITS + l] : a.max_depth;
+            h1[l] = v ? a.hit_t1[(size_t)r * NL_MAX_HITS + l] : a.max_depth;
         }
         for (int l = 0; l < P; ++l) tot = tot + ((hi[l] == -1) ? 0.0f : (h1[l] - h0[l]));
         if (tot > 10.0f * NL_FILL_DEPTH) guard = 1;
@@ -243,6 +293,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample(SampleArgs a)
         const int first_local = first_rank - a.counters[NLC_R_OFFSET];
         const int first_ray = (first_local >= 0 && first_local < a.counters[NLC_R]) ? a.ray_of_rank[first_local] : r;
         tc.row_first_idx = a.hit_idx + (size_t)first_ray * NL_MAX_HITS;
+        tc.row_first_count = a.hit_count[first_ray];
         tc.tail_always = a.tail_always != 0;
         const float c = a.cos_gt[r], d = a.gt_dist[r];
         const unsigned rid = (unsigned)(r + a.ray_id_base);
@@ -422,14 +473,14 @@ int nl_inverse_cdf_sampling(const int* pts_idx, const float* min_depth, const fl
 }
 
 int nl_ray_intersect(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
-                     const float* poses, const float* centres, const int* structure, float voxel_size, float max_distance,
+                     const float* poses, const void* node_rec, const void* node_child, float voxel_size, float max_distance,
                      float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
                      int* counters, void* stream)
 {
-    if (N <= 0 || !rays_d_sensor || !points_gt || !cos_gt || !poses || !centres || !structure || !rays_d_world || !gt_dist ||
+    if (N <= 0 || !rays_d_sensor || !points_gt || !cos_gt || !poses || !node_rec || !node_child || !rays_d_world || !gt_dist ||
         !hit_idx || !hit_t0 || !hit_t1 || !hit_count || !counters) return NL_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_ray_intersect, dim3(nl_div_up(N, NL_GEO_THREADS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream,
-                       N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, centres, structure, voxel_size, max_distance,
+                       N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, (const float4*)node_rec, (const int4*)node_child, voxel_size, max_distance,
                        rays_d_world, gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters);
     NL_LAUNCH_CHECK();
     return NL_OK;

@@ -53,6 +53,13 @@ class MapDevice:
         # voxels that are never sampled (non-SURFACE nodes) keep row 0 so a stray read stays in bounds
         self.vertex_rows = torch.as_tensor(np.maximum(rows, 0)).to(device)
         self.emb = torch.as_tensor(np.ascontiguousarray(emb_bf16_bits).view(np.int16)).to(device)   # bf16 bit patterns
+        # packed traversal layout: float4 (cx, cy, cz, bits(side)) + 8 x int32 children, for aligned vector loads
+        st = np.ascontiguousarray(structure, np.int32)
+        rec = np.empty((st.shape[0], 4), np.float32)
+        rec[:, :3] = np.asarray(centres, np.float32)
+        rec[:, 3] = st[:, 8].view(np.float32)
+        self.node_rec = torch.as_tensor(rec).to(device)
+        self.node_child = torch.as_tensor(np.ascontiguousarray(st[:, :8])).to(device)
         self.n_nodes = self.centres.shape[0]
         self.n_rows = self.emb.shape[0]
 
@@ -206,7 +213,7 @@ class SdfEngine:
         N = self.N
         c = self.counters
         c.zero_()
-        ops.ray_intersect(N, self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self.poses12, m.centres, m.structure,
+        ops.ray_intersect(N, self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self.poses12, m.node_rec, m.node_child,
                           m.voxel_size, cfg.max_distance, self.rays_d_world, self.gt_dist, self.hit_idx, self.hit_t0, self.hit_t1,
                           self.hit_count, c)
         ops.exclusive_scan(self.hit_count, self.hit_rank, N, 1, c[L.NLC_R:L.NLC_R + 1], self.scan_ws)

@@ -137,9 +137,12 @@ def compare_iteration(eng, m, dec, out, cfgP, train_decoder, sdf_tol=1e-4):
     assert st["S"] == out["z_vals"].shape[1] and st["P"] == out["n_samples"]
     N = len(out["hits"])
     H_ = st["H"]
-    assert np.array_equal(eng.hit_idx[:N, :H_].cpu().numpy(), out["hit_idx"])
-    assert np.array_equal(eng.hit_t0[:N, :H_].cpu().numpy(), out["hit_t0"])
-    assert np.array_equal(eng.hit_t1[:N, :H_].cpu().numpy(), out["hit_t1"])
+    hc = eng.hit_count[:N].cpu().numpy()
+    live = np.arange(H_)[None, :] < hc[:, None]                      # row tails beyond a ray's own hits are not written
+    assert np.array_equal(hc, (out["hit_idx"] != -1).sum(1))
+    assert np.array_equal(np.where(live, eng.hit_idx[:N, :H_].cpu().numpy(), -1), out["hit_idx"])
+    assert np.array_equal(np.where(live, eng.hit_t0[:N, :H_].cpu().numpy(), np.float32(cfgP.max_distance)), out["hit_t0"])
+    assert np.array_equal(np.where(live, eng.hit_t1[:N, :H_].cpu().numpy(), np.float32(cfgP.max_distance)), out["hit_t1"])
     assert np.array_equal(r["valid_mask"], out["valid"])
     assert np.array_equal(r["z_vals"], out["z_vals"])                      # IEEE fp32 geometry: bit-exact
     assert np.array_equal(eng.s_vox[:st["P"]].cpu().numpy(), out["vox"].astype(np.int32))
@@ -318,7 +321,9 @@ def test_full_scan_invariants(nl):
     assert np.array_equal(eng.samp_off[:N].cpu().numpy(), np.cumsum(sc_) - sc_)            # exclusive scan
     rk = eng.hit_rank[:N].cpu().numpy()
     assert np.array_equal(rk, np.cumsum(hc > 0) - (hc > 0))
-    t0 = eng.hit_t0[:N].cpu().numpy(); t1 = eng.hit_t1[:N].cpu().numpy(); hi = eng.hit_idx[:N].cpu().numpy()
+    live = np.arange(20)[None, :] < hc[:, None]
+    t0 = np.where(live, eng.hit_t0[:N].cpu().numpy(), np.float32(50)); t1 = np.where(live, eng.hit_t1[:N].cpu().numpy(), np.float32(50))
+    hi = np.where(live, eng.hit_idx[:N].cpu().numpy(), -1)
     assert (np.diff(t0, axis=1) >= 0).all()                              # sortedness
     assert ((hi >= 0).sum(1) == hc).all() and (t1 >= t0).all()
     Pn = st["P"]
