@@ -1,0 +1,149 @@
+"""Mapping: the hot-path call sites of the reference's mapper process.
+
+Mirror of /root/reference/src/mapping.py for what SURVEY.md 8 puts in scope: `create_voxels`
+(:283-291), `get_embeddings` (:293-317), `update_grid_features` (:319-339), `do_mapping` ->
+`bundle_adjust_frames` (:172-202), `select_optimize_targets` (:205-225), `insert_keyframe` (:262-281).
+The process loop (spin), meshing, logging and the share-data plumbing stay with the reference.
+
+MI355X-first differences (same results per vertex id):
+  * the sparse octree is the native host octree (svo.Octree, flat arrays, per-instance counter);
+  * the node-id -> embedding-row table is an [n_nodes] int32 tensor instead of a 2e9-row (8 GB)
+    host tensor (mapping.py:76) and rows are allocated once per NEW VERTEX, not once per occurrence
+    (the reference over-allocates ~3x and never reads the duplicates);
+  * the bf16 embedding table grows ON THE DEVICE (the reference copies it D->H, cats, copies H->D
+    every frame, mapping.py:312-314); map_states holds device tensors, so nothing is re-uploaded per
+    iteration (render_helpers.py:76-77,205-206 re-upload the whole octree each iteration)."""
+import random
+
+import numpy as np
+import torch
+
+from .criterion import Criterion
+from .decoder import Decoder
+from .lidar_frame import LidarFrame
+from .render_helpers import bundle_adjust_frames
+from .svo import Octree
+
+
+def _get(d, name, default):
+    return d.get(name, default) if isinstance(d, dict) else getattr(d, name, default)
+
+
+class Mapping:
+    def __init__(self, args, logger=None, device="cuda"):
+        self.args, self.logger, self.device = args, logger, torch.device(device)
+        self.decoder = Decoder(**args.decoder_specs).to(self.device)
+        self.loss_criteria = Criterion(args)
+        self.keyframe_graph = []
+        self.initialized = False
+        ms = args.mapper_specs
+        self.voxel_size = ms["voxel_size"]
+        self.window_size = ms["window_size"]
+        self.num_iterations = ms["num_iterations"]
+        self.n_rays = ms["N_rays_each"]
+        self.sdf_truncation = args.criteria["sdf_truncation"]
+        self.max_voxel_hit = ms["max_voxel_hit"]
+        self.step_size = ms["step_size"] * self.voxel_size
+        self.learning_rate_emb = ms["learning_rate_emb"]
+        self.learning_rate_decorder = ms["learning_rate_decorder"]
+        self.learning_rate_pose = ms["learning_rate_pose"]
+        self.max_distance = args.data_specs["max_depth"]
+        self.freeze_frame = ms["freeze_frame"]
+        self.keyframe_gap = ms["keyframe_gap"]
+        self.remove_back = ms["remove_back"]
+        self.key_distance = ms["key_distance"]
+        embed_dim = args.decoder_specs["in_dim"]
+        self.embed_dim = embed_dim - 3 if ms["use_local_coord"] else embed_dim
+        self.voxel_id2embedding_id = torch.full((0,), -1, dtype=torch.int32)        # [n_nodes] host table, grown with the tree
+        self.current_num_embeds = 0
+        self.dynamic_embeddings = None
+        self.svo = Octree()
+        self.svo.init(256 * 256 * 4, embed_dim, self.voxel_size)
+        self.first_frame_id = 0
+        self.current_keyframe = None
+        self.map_states = None
+
+    # ------------------------------------------------------------------ map growth (once per frame)
+    def create_voxels(self, frame):
+        pose = frame.get_pose().detach()
+        pts = frame.get_points().float() @ pose[:3, :3].transpose(-1, -2) + pose[:3, 3]
+        voxels = torch.div(pts, self.voxel_size, rounding_mode="floor")
+        self.svo.insert(voxels.cpu().int())
+        self.update_grid_features()
+
+    @torch.no_grad()
+    def get_embeddings(self, points_idx):
+        """assign an embedding row to every vertex id seen for the first time; new rows are zero"""
+        n = points_idx.shape[0]
+        if self.voxel_id2embedding_id.shape[0] < n:
+            grown = torch.full((n,), -1, dtype=torch.int32)
+            grown[:self.voxel_id2embedding_id.shape[0]] = self.voxel_id2embedding_id
+            self.voxel_id2embedding_id = grown
+        flat = points_idx.reshape(-1).long()
+        flat = flat[flat.ne(-1)]
+        new_ids = torch.unique(flat[self.voxel_id2embedding_id[flat].eq(-1)])
+        if new_ids.numel() == 0:
+            return
+        start, end = self.current_num_embeds, self.current_num_embeds + new_ids.numel()
+        self.voxel_id2embedding_id[new_ids] = torch.arange(start, end, dtype=torch.int32)
+        add = torch.zeros((end - start, self.embed_dim), dtype=torch.bfloat16, device=self.device)
+        self.dynamic_embeddings = add if self.dynamic_embeddings is None else torch.cat([self.dynamic_embeddings.detach(), add], 0)
+        self.current_num_embeds = end
+
+    @torch.no_grad()
+    def update_grid_features(self):
+        centres, structure, vertex_idx = self.svo.export_device_layout()
+        vertex_idx = torch.from_numpy(vertex_idx)
+        self.get_embeddings(vertex_idx)
+        self.map_states = {
+            "voxel_vertex_idx": vertex_idx.to(self.device),
+            "voxel_center_xyz": torch.from_numpy(centres).to(self.device),
+            "voxel_structure": torch.from_numpy(structure).to(self.device),
+            "voxel_vertex_emb": self.dynamic_embeddings,
+            "voxel_id2embedding_id": self.voxel_id2embedding_id.to(self.device),
+        }
+
+    # ------------------------------------------------------------------ optimisation call site
+    def do_mapping(self, share_data=None, tracked_frame=None, update_pose=True, update_decoder=True, selection_method="current"):
+        self.decoder.train()
+        targets = self.select_optimize_targets(tracked_frame, selection_method=selection_method)
+        bundle_adjust_frames(
+            targets, self.dynamic_embeddings, self.map_states, self.decoder, self.loss_criteria, self.voxel_size, self.step_size,
+            self.n_rays * 2 if selection_method == "random" else self.n_rays, self.num_iterations, self.sdf_truncation,
+            self.max_voxel_hit, self.max_distance,
+            learning_rate=[self.learning_rate_emb, self.learning_rate_decorder, self.learning_rate_pose],
+            update_pose=update_pose,
+            update_decoder=update_decoder if tracked_frame is None or (tracked_frame.index - self.first_frame_id) < self.freeze_frame else False)
+        if share_data is not None:
+            self.update_share_data(share_data)
+
+    def select_optimize_targets(self, tracked_frame=None, selection_method="previous"):
+        if selection_method == "current":
+            if tracked_frame is None:
+                raise ValueError("select one track frame")
+            return [tracked_frame]
+        if len(self.keyframe_graph) <= self.window_size:
+            targets = self.keyframe_graph[:]
+        elif selection_method == "random":
+            targets = random.sample(self.keyframe_graph, self.window_size)
+        elif selection_method == "previous":
+            targets = self.keyframe_graph[-self.window_size:]
+        else:
+            raise NotImplementedError(f"seletion method {selection_method} unknown")
+        if tracked_frame is not None and tracked_frame is not self.current_keyframe:
+            targets = targets + [tracked_frame]
+        return targets
+
+    def insert_keyframe(self, frame):
+        lim = self.key_distance + 0.01
+        mask = (frame.points.abs() < lim).all(-1)
+        if int(mask.sum()) < 2 * self.n_rays:
+            raise ValueError("valid_distance too small")
+        kf = LidarFrame(frame.index, frame.points[mask], frame.get_pointsCos()[mask], frame.pose, new_keyframe=True)
+        self.current_keyframe = kf
+        self.keyframe_graph += [kf]
+
+    def update_share_data(self, share_data):
+        """decoder + map tensors for the tracker (mapping.py:227-232); tensors stay on the device"""
+        share_data.decoder = self.decoder
+        share_data.states = dict(self.map_states)

@@ -66,6 +66,35 @@ class MapDevice:
     def emb_bits(self):
         return self.emb.cpu().numpy().view(np.uint16)
 
+    @classmethod
+    def from_tensors(cls, centres, structure, vertex_idx, id2row, emb_bf16, voxel_size, device="cuda"):
+        """Build from the reference's `map_states` tensors.  `emb_bf16` is the caller's bfloat16 CUDA parameter:
+        it is ALIASED (viewed as int16 bit patterns), so the kernels update it in place like the reference's
+        optimiser does.  `id2row` is the node-id -> embedding-row table (any [>=n] or [>=n,1] int tensor)."""
+        self = cls.__new__(cls)
+        self.voxel_size = float(voxel_size)
+        dev = torch.device(device)
+        self.centres = centres.detach().to(dev, torch.float32).contiguous()
+        self.structure = structure.detach().to(dev, torch.int32).contiguous()
+        n = self.centres.shape[0]
+        vi = vertex_idx.detach().to(dev).long()
+        table = id2row.detach().reshape(-1)[:max(n, 1)].to(dev).long() if id2row.numel() < (1 << 28) else None
+        if table is None:                                   # the reference's 2e9-row host table: gather on its device
+            rows = id2row.reshape(-1)[vi.clamp(min=0).cpu()].to(dev).long()
+        else:
+            rows = table[vi.clamp(min=0)]
+        self.vertex_rows = torch.where(vi >= 0, rows, torch.zeros_like(rows)).clamp(min=0).to(torch.int32).contiguous()
+        if emb_bf16.dtype != torch.bfloat16 or not emb_bf16.is_cuda:
+            raise L.NerfLoamHipError("voxel_vertex_emb must be a CUDA bfloat16 tensor")
+        self.emb = emb_bf16.detach().view(torch.int16)
+        rec = torch.empty(n, 4, dtype=torch.float32, device=dev)
+        rec[:, :3] = self.centres
+        rec[:, 3] = self.structure[:, 8].contiguous().view(torch.float32)
+        self.node_rec = rec
+        self.node_child = self.structure[:, :8].contiguous()
+        self.n_nodes, self.n_rows = n, self.emb.shape[0]
+        return self
+
 
 class DecoderDevice:
     """Decoder parameter block (lidar.py:105-107 layers) + transposed W2 + Adam state."""
@@ -250,6 +279,31 @@ class SdfEngine:
                           self.g_emb if want_emb_grad else None, self.g_pose if want_pose_grad else None, self.field_blocks)
         if self.hook_after_backward is not None:
             self.hook_after_backward(self, dec, train_decoder, want_emb_grad, want_pose_grad)
+
+    def forward_only(self, m: MapDevice, dec: DecoderDevice, cfg: IterConfig, ray_id_base=0):
+        """render_rays without gradients (render_helpers.py:190-318): intersect, sample, gather, decoder forward."""
+        N = self.N
+        c = self.counters
+        c.zero_()
+        ops.ray_intersect(N, self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self.poses12, m.node_rec, m.node_child,
+                          m.voxel_size, cfg.max_distance, self.rays_d_world, self.gt_dist, self.hit_idx, self.hit_t0, self.hit_t1,
+                          self.hit_count, c)
+        ops.exclusive_scan(self.hit_count, self.hit_rank, N, 1, c[L.NLC_R:L.NLC_R + 1], self.scan_ws)
+        c[L.NLC_R_GLOBAL:L.NLC_R_GLOBAL + 1].copy_(c[L.NLC_R:L.NLC_R + 1])
+        ops.compact_hit_rays(N, self.hit_count, self.hit_rank, self.ray_of_rank)
+        seed = 0 if cfg.noise_seed is None else cfg.noise_seed
+        args = (N, self.hit_idx, self.hit_t0, self.hit_t1, self.hit_count, self.hit_rank, self.ray_of_rank, self.cos_gt, self.gt_dist,
+                cfg.step_size, cfg.truncation, cfg.max_distance, seed, 0 if cfg.noise_seed is None else 1, int(cfg.tail_always),
+                ray_id_base, c, self.samp_count)
+        ops.sample_rays(0, *args, None, self.P_cap, None, None, None, None)
+        ops.exclusive_scan(self.samp_count, self.samp_off, N, 0, c[L.NLC_P:L.NLC_P + 1], self.scan_ws)
+        ops.loss_finalize(c, self.loss_scalars, cfg.fs_weight, cfg.sdf_weight, cfg.truncation, cfg.max_distance, self.P_cap)
+        ops.sample_rays(1, *args, self.samp_off, self.P_cap, self.s_vox, self.s_depth, self.s_dist, self.s_ray)
+        ops.gather_trilinear(self.loss_scalars, self.s_vox, self.s_depth, self.s_ray, self.rays_d_world, self.frame_id, self.poses12,
+                             self.F, m.centres, m.vertex_rows, m.emb, m.voxel_size, self.X, self.field_blocks)
+        P = int(c[L.NLC_P].item())                                        # host sync: a forward-only query returns data anyway
+        ops.decoder_forward(self.X, dec.params, dec.W2T, min(P, self.P_cap), self.sdf, self.n_slabs)
+        return P
 
     def optimiser_step(self, m: MapDevice, dec: DecoderDevice, cfg: IterConfig, update_emb=True, update_decoder=True, update_pose=True,
                        lr_pose=None):

@@ -1,0 +1,162 @@
+"""bundle_adjust_frames / track_frame / render_rays on the MI355X SdfEngine.
+
+Host-side mirror of /root/reference/src/variations/render_helpers.py: same function names, argument
+order and meaning, in-place mutation of the embedding parameter, decoder module and frame poses,
+`None` to signal "skip this iteration" (render_helpers.py:216-217,232-233, B9), the tracker's
+learning-rate rule (render_helpers.py:449-450).  What differs is everything underneath: one call
+into SdfEngine per iteration (a fixed sequence of HIP kernels, device-resident state) instead of
+~100 torch ops, autograd and a torch.optim.Adam object.
+
+Kept from the reference on purpose: rays are re-drawn every iteration on the host with the
+reference's Gumbel top-k (LidarFrame.sample_rays), so a seeded run selects the same rays.
+Dropped (no observable effect): torch.cuda.empty_cache() calls, the unused autograd.grad pass of
+render_helpers.py:293-297 (B10), decoder .grad accumulation during tracking (B11)."""
+from copy import deepcopy
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .pipeline import DecoderDevice, IterConfig, MapDevice, SdfEngine
+
+_ENGINES = {}
+
+
+def _engine(n_rays, n_frames, device):
+    key = (str(device), int(n_rays), max(2, int(n_frames)))
+    eng = _ENGINES.get(key)
+    if eng is None:
+        eng = SdfEngine(max_rays=key[1], samples_per_ray_cap=96, max_frames=key[2], device=device)
+        _ENGINES[key] = eng
+    return eng
+
+
+def _map_device(map_states, voxel_size, device):
+    md = map_states.get("_device")
+    emb = map_states["voxel_vertex_emb"]
+    if md is None or md.emb.data_ptr() != emb.data_ptr() or md.n_nodes != map_states["voxel_center_xyz"].shape[0]:
+        md = MapDevice.from_tensors(map_states["voxel_center_xyz"], map_states["voxel_structure"], map_states["voxel_vertex_idx"],
+                                    map_states["voxel_id2embedding_id"], emb, voxel_size, device)
+        map_states["_device"] = md
+    return md
+
+
+def _decoder_device(sdf_network, device):
+    p = sdf_network.flat_params(device).cpu().numpy()
+    return DecoderDevice(p[L.OFF_W1:L.OFF_B1], p[L.OFF_B1:L.OFF_W2], p[L.OFF_W2:L.OFF_B2], p[L.OFF_B2:L.OFF_W3],
+                         p[L.OFF_W3:L.OFF_B3], p[L.OFF_B3:], device=device)
+
+
+def _cfg(loss_criteria, voxel_size, step_size, max_distance, lrs=(0.0, 0.0, 0.0)):
+    return IterConfig(voxel_size=float(voxel_size), step_size=float(step_size), max_distance=float(max_distance),
+                      truncation=float(loss_criteria.truncation), sdf_weight=float(loss_criteria.sdf_weight),
+                      fs_weight=float(loss_criteria.fs_weight), lr_emb=lrs[0], lr_dec=lrs[1], lr_pose=lrs[2],
+                      noise_seed=int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
+
+
+def _gather_rays(frames, N_rays, track=False):
+    d, p, c, f = [], [], [], []
+    for i, fr in enumerate(frames):
+        fr.sample_rays(N_rays, track=track) if track else fr.sample_rays(N_rays)
+        mask = fr.sample_mask.reshape(-1)
+        d.append(fr.rays_d.reshape(-1, 3)[mask]); p.append(fr.points.reshape(-1, 3)[mask]); c.append(fr.pointsCos.reshape(-1)[mask])
+        f.append(torch.full((int(mask.sum()),), i, dtype=torch.int32))
+    return torch.cat(d).float(), torch.cat(p).float(), torch.cat(c).float(), torch.cat(f)
+
+
+def _usable(eng):
+    st = eng.stats()                                      # one small D2H read: the reference syncs far more often
+    return st["R"] > 0 and st["P"] > 0 and not st["guard"] and not st["overflow"], st
+
+
+def bundle_adjust_frames(keyframe_graph, embeddings, map_states, sdf_network, loss_criteria, voxel_size, step_size,
+                         N_rays=512, num_iterations=10, truncation=0.1, max_voxel_hit=10, max_distance=10,
+                         learning_rate=[1e-2, 1e-2, 5e-3], update_pose=True, update_decoder=True, profiler=None):
+    device = embeddings.device
+    if profiler is not None:
+        profiler.tick("mapping_add_optim")
+    assert map_states["voxel_vertex_emb"].data_ptr() == embeddings.data_ptr(), "embeddings must be map_states['voxel_vertex_emb']"
+    m = _map_device(map_states, voxel_size, device)
+    dec = _decoder_device(sdf_network, device)
+    eng = _engine(N_rays * len(keyframe_graph), len(keyframe_graph), device)
+    cfg = _cfg(loss_criteria, voxel_size, step_size, max_distance, learning_rate)
+    optimise = [int(kf.index != 0 and update_pose) for kf in keyframe_graph]
+    eng.set_poses(np.stack([kf.pose.data.detach().cpu().numpy() for kf in keyframe_graph]), optimise)
+    eng.begin_call(m, dec)                                # fresh Adam per call (render_helpers.py:353)
+    if profiler is not None:
+        profiler.tok("mapping_add_optim")
+    for it in range(num_iterations):
+        eng.set_rays(*_gather_rays(keyframe_graph, N_rays))
+        eng.forward_backward(m, dec, cfg, train_decoder=update_decoder, want_emb_grad=True, want_pose_grad=any(optimise))
+        ok, _ = _usable(eng)
+        if not ok:
+            print("Encouter a bug while Mapping, currently not be fixed, Continue!!")
+            eng.g_emb.zero_(); eng.g_pose.zero_()
+            continue
+        eng.optimiser_step(m, dec, cfg, update_emb=True, update_decoder=update_decoder, update_pose=any(optimise))
+    with torch.no_grad():
+        if update_decoder:
+            sdf_network.load_flat(dec.params)
+        p6 = eng.pose6[:len(keyframe_graph)].cpu()
+        for i, kf in enumerate(keyframe_graph):
+            if optimise[i]:
+                kf.pose.data.copy_(p6[i].to(kf.pose.data.device))
+
+
+def track_frame(frame_pose, curr_frame, map_states, sdf_network, loss_criteria, voxel_size, N_rays=512, step_size=0.05,
+                num_iterations=10, truncation=0.1, learning_rate=1e-3, max_voxel_hit=10, max_distance=10, profiler=None,
+                depth_variance=False):
+    emb = map_states["voxel_vertex_emb"]
+    device = emb.device
+    m = _map_device(map_states, voxel_size, device)
+    dec = _decoder_device(sdf_network, device)
+    eng = _engine(N_rays, 1, device)
+    cfg = _cfg(loss_criteria, voxel_size, step_size, max_distance)
+    init_pose = deepcopy(frame_pose)
+    lr = learning_rate * 2 if curr_frame.index < 2 else learning_rate / 3
+    eng.set_poses(init_pose.data.detach().cpu().numpy()[None], [1])
+    eng.begin_call(m, None)
+    hit_mask = None
+    for it in range(num_iterations):
+        eng.set_rays(*_gather_rays([curr_frame], N_rays, track=True))
+        eng.forward_backward(m, dec, cfg, train_decoder=False, want_emb_grad=False, want_pose_grad=True)
+        ok, _ = _usable(eng)
+        if not ok:
+            print("Encouter a bug while Tracking, currently not be fixed, Restarting!!")
+            hit_mask = None
+            eng.g_pose.zero_()
+            break
+        hit_mask = (eng.hit_count[:eng.N] > 0)
+        eng.optimiser_step(m, dec, cfg, update_emb=False, update_decoder=False, update_pose=True, lr_pose=lr)
+    with torch.no_grad():
+        init_pose.data.copy_(eng.pose6[0].to(init_pose.data.device))
+    return init_pose, hit_mask
+
+
+@torch.no_grad()
+def render_rays(rays_o, rays_d, map_states, sdf_network, step_size, voxel_size, truncation, max_voxel_hit, max_distance,
+                chunk_size=10000, profiler=None, return_raw=False):
+    """Forward rendering of world-space rays sharing one origin per call (as every reference caller passes:
+    rays_o is the frame translation expanded over the rays)."""
+    emb = map_states["voxel_vertex_emb"]
+    device = emb.device
+    o = rays_o.reshape(-1, 3)
+    d = rays_d.reshape(-1, 3).float()
+    if not torch.equal(o, o[:1].expand_as(o)):
+        raise L.NerfLoamHipError("render_rays: rays must share one origin (one frame) per call")
+    m = _map_device(map_states, voxel_size, device)
+    dec = _decoder_device(sdf_network, device)
+    eng = _engine(d.shape[0], 1, device)
+    crit = type("C", (), dict(truncation=truncation, sdf_weight=1.0, fs_weight=1.0))
+    cfg = _cfg(crit, voxel_size, step_size, max_distance)
+    eng.set_poses(np.concatenate([o[0].detach().cpu().numpy(), np.zeros(3, np.float32)])[None].astype(np.float32), [0])
+    eng.set_rays(d, torch.zeros_like(d), torch.ones(d.shape[0]))
+    eng.forward_only(m, dec, cfg)
+    r = eng.export_render()
+    if r is None:
+        return None
+    P = r["stats"]["P"]
+    out = {"z_vals": torch.from_numpy(r["z_vals"]).to(device), "sdf": torch.from_numpy(r["sdf"]).to(device),
+           "ray_mask": torch.from_numpy(r["ray_mask"]).to(device).view(1, -1), "valid_mask": torch.from_numpy(r["valid_mask"]).to(device),
+           "sampled_xyz": m.centres[eng.s_vox[:P].long()], "_engine": eng, "_cfg": cfg}
+    return out

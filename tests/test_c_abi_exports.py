@@ -1,0 +1,49 @@
+"""CPU: libnerfloam_hip.so loads without a GPU and exports every symbol include/nerfloam_hip.h declares
+(no compute calls here); the product refuses to run without a device."""
+import os
+import re
+
+import pytest
+
+from nerf_loam_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "nerfloam_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nl_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound():
+    lib = _lib.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/nerfloam_hip.h but not exported"
+    assert set(syms) == set(_lib.EXPORTED_SYMBOLS), set(syms) ^ set(_lib.EXPORTED_SYMBOLS)
+    assert lib.nl_version() >= 100
+
+
+def test_header_constants_match_binding():
+    src = open(os.path.join(ROOT, "include", "nerfloam_hip.h")).read()
+    consts = dict(re.findall(r"#define\s+(NL_[A-Z_]+)\s+(\d+)", src))
+    assert int(consts["NL_MAX_HITS"]) == _lib.NL_MAX_HITS
+    assert int(consts["NL_DEC_PARAMS"]) == _lib.NL_DEC_PARAMS == 16 * 256 + 256 + 256 * 256 + 256 + 256 + 1
+    assert int(consts["NL_CNT_INTS"]) * 4 + int(consts["NL_CNT_DOUBLES"]) * 8 == _lib.NL_CNT_BYTES
+    assert int(consts["NL_LOSS_SCALARS_BYTES"]) == _lib.NL_LOSS_SCALARS_BYTES
+
+
+def test_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.NerfLoamHipError):
+        _lib.require_gpu()
+    from nerf_loam_amd import pipeline
+    with pytest.raises(_lib.NerfLoamHipError):
+        pipeline.SdfEngine(max_rays=16)
+    from nerf_loam_amd import grid
+    with pytest.raises(RuntimeError):
+        grid.svo_intersect(torch.zeros(1, 2, 3), torch.zeros(1, 2, 3), torch.zeros(1, 1, 3), torch.zeros(1, 1, 9, dtype=torch.int32), 0.2, 20)

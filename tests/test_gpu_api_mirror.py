@@ -1,0 +1,77 @@
+"""GPU (-m gpu): the reference's operator surface (Mapping / Tracking / bundle_adjust_frames /
+track_frame / render_rays / Decoder / Criterion / svo.Octree) on the HIP path: a short
+mapping-then-tracking run on a synthetic sector scan behaves like the reference's loop does -
+loss goes down, embeddings/decoder/pose are mutated in place, a perturbed pose is pulled back."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def make_args():
+    return Namespace(
+        criteria=dict(sdf_weight=10000.0, fs_weight=1, eiko_weight=0.1, sdf_truncation=0.30),
+        data_specs=dict(max_depth=50.0, min_depth=1.5),
+        decoder_specs=dict(depth=2, width=256, in_dim=16, skips=[], embedder="none", multires=0),
+        tracker_specs=dict(N_rays=1024, learning_rate=0.005, step_size=0.2, max_voxel_hit=20, num_iterations=10),
+        mapper_specs=dict(N_rays_each=1024, use_local_coord=False, voxel_size=0.2, step_size=0.5, window_size=4, num_iterations=10,
+                          max_voxel_hit=20, final_iter=True, mesh_res=2, learning_rate_emb=0.03, learning_rate_decorder=0.005,
+                          learning_rate_pose=0.001, freeze_frame=5, keyframe_gap=8, remove_back=False, key_distance=12),
+        debug_args=dict(verbose=False, mesh_freq=100))
+
+
+def test_mapping_then_tracking_like_the_reference_loop():
+    from nerf_loam_amd.lidar_frame import LidarFrame
+    from nerf_loam_amd.mapping import Mapping
+    from nerf_loam_amd.tracking import Tracking
+    from nerf_loam_amd.render_helpers import render_rays
+    torch.manual_seed(777)
+    pts, cos = H.scene_points(64, 64, 11)
+    args = make_args()
+    mapper = Mapping(args)
+    f0 = LidarFrame(0, torch.from_numpy(pts), torch.from_numpy(cos), np.eye(4))
+    mapper.create_voxels(f0)
+    assert mapper.svo.count_leaf_nodes() > 500 and mapper.dynamic_embeddings.dtype == torch.bfloat16
+    assert mapper.dynamic_embeddings.is_cuda and mapper.dynamic_embeddings.shape[0] == int((mapper.voxel_id2embedding_id >= 0).sum())
+    emb_before = mapper.dynamic_embeddings.clone()
+    w_before = mapper.decoder.pts_linears[1].weight.detach().clone()
+    share = Namespace(decoder=None, states=None)
+
+    def rendered_loss():
+        pose = f0.get_pose()
+        d = (f0.rays_d.reshape(-1, 3) @ pose[:3, :3].T).cuda()
+        o = pose[:3, 3].reshape(1, 3).expand_as(d).cuda().contiguous()
+        out = render_rays(o[None], d[None], mapper.map_states, mapper.decoder, mapper.step_size, 0.2, 0.3, 20, 50.0)
+        z = out["z_vals"]; sdf = out["sdf"]; m = out["valid_mask"]
+        gt = torch.from_numpy(np.linalg.norm(pts, axis=1) * cos).cuda()[out["ray_mask"].view(-1)]
+        zc = z * torch.from_numpy(cos).cuda()[out["ray_mask"].view(-1)][:, None]
+        near = m & ((zc - gt[:, None]).abs() < 0.3)
+        return float((((zc + sdf * 0.3) - gt[:, None])[near] ** 2).mean())
+
+    l0 = rendered_loss()
+    for _ in range(3):
+        mapper.do_mapping(share, f0, selection_method="current")
+    l1 = rendered_loss()
+    assert l1 < 0.5 * l0, (l0, l1)                                     # the map learns the surface
+    assert not torch.equal(emb_before, mapper.dynamic_embeddings)      # in-place parameter updates
+    assert not torch.equal(w_before, mapper.decoder.pts_linears[1].weight.detach())
+    assert share.decoder is mapper.decoder and share.states["voxel_vertex_emb"] is mapper.dynamic_embeddings
+
+    # tracking: perturb the pose of a second frame looking at the same scene, refine it
+    tracker = Tracking(args)
+    tracker.last_frame = f0
+    P4 = np.eye(4); P4[:3, 3] = [0.06, -0.05, 0.02]
+    f1 = LidarFrame(1, torch.from_numpy(pts), torch.from_numpy(cos), P4)
+    err0 = float((f1.pose.translation() - f0.pose.translation()).norm())
+    tracker.last_frame = f1                                             # start from the perturbed pose (no motion model yet)
+    f2 = LidarFrame(2, torch.from_numpy(pts), torch.from_numpy(cos), np.eye(4))
+    out = tracker.do_tracking(share, f2)
+    err1 = float((out.pose.translation() - f0.pose.translation()).norm())
+    assert out.pose.data.shape == (6,) and torch.isfinite(out.pose.data).all()
+    assert err1 < 0.6 * err0, (err0, err1)                              # pulled back towards the true pose
+    assert 0.9 < float(out.hit_ratio) <= 1.0
