@@ -32,6 +32,20 @@ FLOPS_PER_SAMPLE_DECODER = 2 * 2 * (16 * 256 + 256 * 256 + 256) + 2 * (16 * 256 
 FLOPS_PER_SAMPLE_WGRAD2 = 2 * 256 * 256                                                    # dW2: 131 072
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS command
+    (profiles/r*_pmc_summary.json: (2 x FETCH_SIZE + WRITE_SIZE) KB, the x2 being the gfx950 FETCH_SIZE
+    correction of MI355X_MICROARCH.md).  None when no PMC summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        return float(json.load(open(files[-1]))[kernel]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def build_workload(device, seed=777):
     from nerf_loam_amd import pipeline as P, synthetic as S
     from nerf_loam_amd.svo import Octree
@@ -165,7 +179,8 @@ def main():
                        "rays": N, "octree_nodes": w["n_nodes"], "embedding_rows": w["n_rows"], "hit_rays": st["R"],
                        "valid_samples_rank0": P_local, "max_samples_per_ray": st["S"], "parallelism": f"ray-shard x{world}"},
             "roofline": {"bound": "mfma", "kernel": "k_decoder<train>" if train_dec else "k_decoder<frozen>", "achieved": ach,
-                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": pmc_traffic("k_decoder<true>" if train_dec else "k_decoder<false>"),
                          "avg_launch_ms": dec_ms, "flops_per_launch": flops_dec,
                          "second_kernel": ({"kernel": "k_decoder_wgrad2", "avg_launch_ms": wg_ms,
                                             "achieved": P_local * FLOPS_PER_SAMPLE_WGRAD2 / (wg_ms * 1e-3) / 1e12,
