@@ -55,9 +55,9 @@ def build_workload(device, seed=777):
     oc.init(256 * 256 * 4, 16, 0.2)
     oc.insert(S.voxel_coords(pts, np.eye(3, dtype=np.float32), pose[:3], 0.2))
     centres, structure, vertex_idx = oc.export_device_layout()
-    # embedding rows: one per vertex occurrence like mapping.py:293-317 (160k rows for this scan)
-    flat = vertex_idx.reshape(-1)
-    flat = flat[flat >= 0]
+    # embedding rows: one per vertex, like nerf_loam_amd.mapping.Mapping.get_embeddings (the reference allocates one per
+    # OCCURRENCE, mapping.py:293-317: ~3x the rows, the duplicates are never read - SURVEY B7)
+    flat = np.unique(vertex_idx[vertex_idx >= 0])
     id2row = -np.ones(len(centres), np.int32)
     id2row[flat] = np.arange(len(flat), dtype=np.int32)
     E = len(flat)

@@ -58,14 +58,16 @@ int nl_inverse_cdf_sampling(const int* pts_idx, const float* min_depth, const fl
 /* ray set-up + ray_intersect: render_helpers.py:366-388 (d_world = d_sensor R^T, o = t),
  * voxel_helpers.py:531-567 (DFS intersect, -1 -> max_distance, sort by t_min, cull).
  * poses[F,12] = rotation row-major | translation.  frame_id may be NULL (single frame).
- * Octree in the packed device layout: node_rec[n] = float4 (centre xyz, bit pattern of int side),
- * node_child[n] = 8 x int32 child ids (the reference's voxel_center_xyz [n,3] + voxel_structure [n,9],
- * re-packed once per map update for aligned vector loads).
+ * Octree in the children-block layout (the reference's voxel_center_xyz [n,3] + voxel_structure [n,9] re-packed
+ * once per map update; one block per interior node, numbered breadth-first): blk_hdr[B] = int2 (first child
+ * block, exist mask | own-a-block mask << 8; children blocks are consecutive in octant order), blk_ids[B][8] =
+ * child node ids, root_side = side of node 0 in voxels (voxel_structure[0][8]); block 0 is a pseudo block for the
+ * root.  Node centres are recomputed from the lattice path ((xyz + side/2) * voxel_size, exact), not loaded.
  * Outputs: rays_d_world[N,3], gt_dist[N] = ||p||*cos, hit_idx/t0/t1[N,20] (only the first hit_count[r]
  * entries of a row are written: sorted by t_min, culled), hit_count[N];
  * counters[NLC_HMAX] is raised (atomic max).  counters must be zeroed per iteration. */
 int nl_ray_intersect(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
-                     const float* poses, const void* node_rec, const void* node_child, float voxel_size, float max_distance,
+                     const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
                      float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
                      int* counters, void* stream);
 

@@ -43,7 +43,7 @@ _SIGS = {
     "nl_decoder_grid_hint": ([], _I),
     "nl_svo_intersect": ([_P] * 4 + [_I, _I, _I, _F, _I] + [_P] * 4, _I),
     "nl_inverse_cdf_sampling": ([_P] * 6 + [_I] * 4 + [_F] + [_P] * 4, _I),
-    "nl_ray_intersect": ([_I] + [_P] * 7 + [_F, _F] + [_P] * 8, _I),
+    "nl_ray_intersect": ([_I] + [_P] * 7 + [_I, _F, _F] + [_P] * 8, _I),
     "nl_exclusive_scan_i32": ([_P, _P, _I, _I, _P, _P, _P], _I),
     "nl_compact_hit_rays": ([_I, _P, _P, _P, _P], _I),
     "nl_sample_rays": ([_I, _I] + [_P] * 8 + [_F, _F, _F, _U, _I, _I, _I] + [_P, _P, _P, _I] + [_P] * 5, _I),

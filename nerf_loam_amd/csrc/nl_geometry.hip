@@ -60,27 +60,54 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_svo_intersect_raw(
 // Fused ray set-up + intersect + sort/cull (render_helpers.py:366-388, voxel_helpers.py:531-567).
 //   inputs per ray: unit direction in the sensor frame, gt return (sensor frame), cos, frame id
 //   poses[F][12]: rotation row-major (9) then translation (3)
-//   octree in the PACKED device layout built once per map update (pipeline.MapDevice):
-//     node_rec[n]   float4 (cx, cy, cz, bits(side))        16-byte aligned, one load per node visit
-//     node_child[n] 8 x int32 child ids (-1 = none)         32-byte aligned, two 16-byte loads
-//   same results as the reference layouts (centres [n,3] + children [n,9]); a node visit costs ONE
-//   round of three independent vector loads instead of up to eight dependent scalar child probes.
-//   The per-level DFS state (node, remaining-children bitmask) lives in LDS; hits are written to
-//   the ray's own output row in DFS order and then sorted in place (L2-resident).
+//   octree in the CHILDREN-BLOCK layout built once per map update (pipeline.pack_children_blocks):
+//     blk_hdr [B]    int2    (index of the first child block, exist mask | own-a-block mask << 8); the
+//                            children blocks of a block are numbered consecutively in octant order (BFS)
+//     blk_ids [B][8] int32   child node ids (read on the bottom level only, to name the hit voxels)
+//     block 0 is a pseudo block for the root; block b >= 1 belongs to one interior node
+//   Same hits in the same order as the reference DFS (children visited in descending octant order,
+//   leaves recorded until 20).  Expanding a node costs ONE 8-byte load: child centres are recomputed from
+//   the integer lattice path instead of being fetched (the per-lane divergent 16-byte loads of node records
+//   saturated the CU's address path: ~55 expansions x 11 loads per ray), and the 8 children are slab-tested
+//   together; the reference pays two dependent memory round trips per visited child.
+//   Per-level DFS state (block, surviving-children bitmask) lives in LDS; hits go to the ray's own
+//   output row in DFS order and are then sorted in place (L2-resident).
 //   outputs: world direction, gt distance*cos, hit_idx/t0/t1[N,20] (first hit_count[r] entries are
 //   the sorted, culled hits; the rest of a row is NOT written), hit count; counters[NLC_HMAX].
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool slab_inv(const float o[3], const float inv[3], float cx, float cy, float cz, float half,
+                                         float* tn, float* tf)
+{
+    // nl_slab with the per-ray reciprocals hoisted: identical arithmetic (inv = 1.0f / d is the same value)
+    float lo = 0.0f, hi = 100000.0f;
+    const float c[3] = {cx, cy, cz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float t0 = (c[a] - half - o[a]) * inv[a];
+        float t1 = (c[a] + half - o[a]) * inv[a];
+        if (t1 < t0) { float t = t0; t0 = t1; t1 = t; }
+        if (t1 < lo) return false;
+        if (t0 > hi) return false;
+        lo = (t0 > lo) ? t0 : lo;
+        hi = (t1 < hi) ? t1 : hi;
+        if (lo > hi) return false;
+    }
+    *tn = lo; *tf = hi;
+    return true;
+}
+
 __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect(
     int N, const float* __restrict__ rays_d_sensor, const float* __restrict__ points_gt,
     const float* __restrict__ cos_gt, const int* __restrict__ frame_id, const float* __restrict__ poses,
-    const float4* __restrict__ node_rec, const int4* __restrict__ node_child,
+    const int2* __restrict__ blk_hdr, const int4* __restrict__ blk_ids, int root_side,
     float voxel_size, float max_distance,
     float* __restrict__ rays_d_world, float* __restrict__ gt_dist,
     int* __restrict__ hit_idx, float* __restrict__ hit_t0, float* __restrict__ hit_t1,
     int* __restrict__ hit_count, int* __restrict__ counters)
 {
-    __shared__ int s_node[NL_MAX_LEVELS * NL_GEO_THREADS];
+    __shared__ int s_base[NL_MAX_LEVELS * NL_GEO_THREADS];
     __shared__ unsigned char s_mask[NL_MAX_LEVELS * NL_GEO_THREADS];
+    __shared__ unsigned char s_has[NL_MAX_LEVELS * NL_GEO_THREADS];
     __shared__ int s_hmax;
     if (threadIdx.x == 0) s_hmax = 0;
     __syncthreads();
@@ -95,42 +122,65 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect(
         rays_d_world[3 * r] = d[0]; rays_d_world[3 * r + 1] = d[1]; rays_d_world[3 * r + 2] = d[2];
         const float gx = points_gt[3 * r], gy = points_gt[3 * r + 1], gz = points_gt[3 * r + 2];
         gt_dist[r] = sqrtf((gx * gx + gy * gy) + gz * gz) * cos_gt[r];
-        const float ox = P[9], oy = P[10], oz = P[11];
+        const float o[3] = {P[9], P[10], P[11]};
+        const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
         const float half_voxel = voxel_size * 0.5f;
         int* oi = hit_idx + (size_t)r * NL_MAX_HITS; float* o0 = hit_t0 + (size_t)r * NL_MAX_HITS; float* o1 = hit_t1 + (size_t)r * NL_MAX_HITS;
-        int* st_node = s_node + threadIdx.x; unsigned char* st_mask = s_mask + threadIdx.x;
-
-        auto child_mask = [&](int node) -> unsigned {
-            const int4 a = node_child[2 * (size_t)node], b = node_child[2 * (size_t)node + 1];
-            return (a.x > -1 ? 1u : 0u) | (a.y > -1 ? 2u : 0u) | (a.z > -1 ? 4u : 0u) | (a.w > -1 ? 8u : 0u) |
-                   (b.x > -1 ? 16u : 0u) | (b.y > -1 ? 32u : 0u) | (b.z > -1 ? 64u : 0u) | (b.w > -1 ? 128u : 0u);
-        };
+        int* st_base = s_base + threadIdx.x; unsigned char* st_mask = s_mask + threadIdx.x; unsigned char* st_has = s_has + threadIdx.x;
         int cnt = 0, lvl = -1;
-        {   // root
-            const float4 rc = node_rec[0];
-            const int side = __float_as_int(rc.w);
-            float tn, tf;
-            if (nl_slab(ox, oy, oz, d[0], d[1], d[2], rc.x, rc.y, rc.z, half_voxel * (float)side, &tn, &tf)) {
-                if (side == 1) { oi[0] = 0; o0[0] = tn; o1[0] = tf; cnt = 1; }
-                else { lvl = 0; st_node[0] = 0; st_mask[0] = (unsigned char)child_mask(0); }
+        int px = 0, py = 0, pz = 0;                                 // min-corner voxel coordinates of the node being expanded
+
+        // Expand the block of the node at (px,py,pz) whose children have side `cs` (a power of two).
+        // Node centres are NOT loaded: the reference's centre = (xyz + side/2) * voxel_size (mapping.py:322) is
+        // recomputed from the integer lattice path, bit-for-bit (xyz and side/2 are exact in fp32), so an expansion
+        // costs ONE 8-byte load (+ the 8 leaf ids on the bottom level) instead of 8 x 16-byte records.
+        auto expand = [&](int b, int cs) {
+            const int2 hdr = blk_hdr[b];
+            const unsigned exist = (unsigned)hdr.y & 255u, has = ((unsigned)hdr.y >> 8) & 255u;
+            const float fs = (float)cs, hs = fs * 0.5f, half = half_voxel * fs;
+            unsigned m = 0;
+            if (cs == 1) {                                          // bottom level: children are voxels -> record hits, descending octant
+                const int4 ia = blk_ids[2 * (size_t)b], ib = blk_ids[2 * (size_t)b + 1];
+                const int ids[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+#pragma unroll
+                for (int u = 7; u >= 0; --u) {
+                    if (!((exist >> u) & 1u) || ids[u] < 0) continue;
+                    const float cx = ((float)(px + (u & 1)) + hs) * voxel_size, cy = ((float)(py + ((u >> 1) & 1)) + hs) * voxel_size,
+                                cz = ((float)(pz + ((u >> 2) & 1)) + hs) * voxel_size;
+                    float tn, tf;
+                    if (slab_inv(o, inv, cx, cy, cz, half, &tn, &tf) && cnt < NL_MAX_HITS) { oi[cnt] = ids[u]; o0[cnt] = tn; o1[cnt] = tf; ++cnt; }
+                }
+                return;
             }
-        }
-        const int* child_flat = reinterpret_cast<const int*>(node_child);
-        while (lvl >= 0 && cnt < NL_MAX_HITS) {
-            unsigned m = st_mask[lvl * NL_GEO_THREADS];
-            if (m == 0) { --lvl; continue; }
-            const int u = 31 - __clz((int)m);                      // highest existing octant first (reference pop order)
-            st_mask[lvl * NL_GEO_THREADS] = (unsigned char)(m & ~(1u << u));
-            const int child = child_flat[8 * (size_t)st_node[lvl * NL_GEO_THREADS] + u];
-            const float4 rc = node_rec[child];
-            const int side = __float_as_int(rc.w);
-            unsigned cm = 0;
-            if (side != 1) cm = child_mask(child);                   // issued together with rc: one latency round
+#pragma unroll
+            for (int u = 7; u >= 0; --u) {
+                if (!((has >> u) & 1u)) continue;                   // a hit child without a block has nothing below it
+                const float cx = ((float)(px + ((u & 1) ? cs : 0)) + hs) * voxel_size, cy = ((float)(py + ((u & 2) ? cs : 0)) + hs) * voxel_size,
+                            cz = ((float)(pz + ((u & 4) ? cs : 0)) + hs) * voxel_size;
+                float tn, tf;
+                if (slab_inv(o, inv, cx, cy, cz, half, &tn, &tf)) m |= 1u << u;
+            }
+            if (m) { ++lvl; st_base[lvl * NL_GEO_THREADS] = hdr.x; st_mask[lvl * NL_GEO_THREADS] = (unsigned char)m; st_has[lvl * NL_GEO_THREADS] = (unsigned char)has; }
+        };
+        {   // root (block 0 is the pseudo block holding it): slab test, then its children block
+            const float fs = (float)root_side, hs = fs * 0.5f;
             float tn, tf;
-            if (!nl_slab(ox, oy, oz, d[0], d[1], d[2], rc.x, rc.y, rc.z, half_voxel * (float)side, &tn, &tf)) continue;
-            if (side == 1) { oi[cnt] = child; o0[cnt] = tn; o1[cnt] = tf; ++cnt; continue; }
-            ++lvl;
-            st_node[lvl * NL_GEO_THREADS] = child; st_mask[lvl * NL_GEO_THREADS] = (unsigned char)cm;
+            const int2 h0 = blk_hdr[0];
+            if (slab_inv(o, inv, hs * voxel_size, hs * voxel_size, hs * voxel_size, half_voxel * fs, &tn, &tf) && h0.x >= 0)
+                expand(h0.x, root_side >> 1);
+        }
+        while (lvl >= 0 && cnt < NL_MAX_HITS) {
+            const unsigned m = st_mask[lvl * NL_GEO_THREADS];
+            if (m == 0) { --lvl; continue; }
+            const int u = 31 - __clz((int)m);                       // highest octant first (reference pop order)
+            st_mask[lvl * NL_GEO_THREADS] = (unsigned char)(m & ~(1u << u));
+            // stack level l holds children of side root_side >> (l + 1); the chosen child becomes the expanded node
+            const int cs = root_side >> (lvl + 1);
+            const int keep = ~(2 * cs - 1);
+            px = (px & keep) | ((u & 1) ? cs : 0); py = (py & keep) | ((u & 2) ? cs : 0); pz = (pz & keep) | ((u & 4) ? cs : 0);
+            // children blocks of one block are numbered consecutively in octant order: no load needed to find it
+            const int cb = st_base[lvl * NL_GEO_THREADS] + __popc((unsigned)st_has[lvl * NL_GEO_THREADS] & ((1u << u) - 1u));
+            expand(cb, cs >> 1);
         }
         // in-place stable insertion sort by t_min on the ray's own row, then cull (voxel_helpers.py:543-552)
         for (int i = 1; i < cnt; ++i) {
@@ -473,14 +523,14 @@ int nl_inverse_cdf_sampling(const int* pts_idx, const float* min_depth, const fl
 }
 
 int nl_ray_intersect(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
-                     const float* poses, const void* node_rec, const void* node_child, float voxel_size, float max_distance,
+                     const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
                      float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
                      int* counters, void* stream)
 {
-    if (N <= 0 || !rays_d_sensor || !points_gt || !cos_gt || !poses || !node_rec || !node_child || !rays_d_world || !gt_dist ||
+    if (N <= 0 || !rays_d_sensor || !points_gt || !cos_gt || !poses || !blk_ids || !blk_hdr || root_side < 2 || !rays_d_world || !gt_dist ||
         !hit_idx || !hit_t0 || !hit_t1 || !hit_count || !counters) return NL_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_ray_intersect, dim3(nl_div_up(N, NL_GEO_THREADS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream,
-                       N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, (const float4*)node_rec, (const int4*)node_child, voxel_size, max_distance,
+                       N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, (const int2*)blk_hdr, (const int4*)blk_ids, root_side, voxel_size, max_distance,
                        rays_d_world, gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters);
     NL_LAUNCH_CHECK();
     return NL_OK;

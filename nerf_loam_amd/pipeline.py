@@ -40,6 +40,42 @@ class IterConfig:
     tail_always: bool = False          # False = reference sampler tail behaviour
 
 
+def pack_children_blocks(centres, structure):
+    """Children-block traversal layout of nl_ray_intersect (device tensors in, device tensors out).
+    Block 0 = pseudo block with the root in slot 0; every node with a listed child owns one block; blocks are
+    numbered breadth-first so that the children blocks of a block are consecutive in octant order.
+      blk_ids[B,8]   i32: child node ids (-1 = none)
+      blk_hdr[B,2]   i32: (first child block or -1, exist mask | own-a-block mask << 8)
+    The kernel recomputes node centres from the lattice path, which needs node min-corners to be multiples of their
+    side (true for the octree: Morton prefixes) and centres = (xyz + side/2) * voxel_size (mapping.py:322)."""
+    dev = centres.device
+    n = centres.shape[0]
+    child = structure[:, :8].long()                                   # [n,8]
+    interior = (child > -1).any(1)
+    ids, hdrs = [], []
+    # pseudo block 0
+    i0 = torch.full((1, 8), -1, dtype=torch.int32, device=dev); i0[0, 0] = 0
+    has_root = bool(interior[0])
+    hdrs.append(torch.tensor([[1 if has_root else -1, 0x101 if has_root else 1]], dtype=torch.int32, device=dev))
+    ids.append(i0)
+    frontier = torch.zeros(1, dtype=torch.long, device=dev) if has_root else torch.zeros(0, dtype=torch.long, device=dev)
+    next_index = 1
+    bits = (1 << torch.arange(8, device=dev)).view(1, 8)
+    while frontier.numel() > 0:
+        ch = child[frontier]                                           # [F,8]
+        exist = ch > -1
+        chc = ch.clamp(min=0)
+        owns = exist & interior[chc]                                   # children that own a block themselves
+        cnt = owns.sum(1)
+        first = next_index + frontier.numel() + torch.cumsum(cnt, 0) - cnt      # blocks of this level come first
+        ids.append(torch.where(exist, chc, torch.full_like(chc, -1)).to(torch.int32))
+        hdrs.append(torch.stack([torch.where(cnt > 0, first, torch.full_like(first, -1)),
+                                 (exist * bits).sum(1) + ((owns * bits).sum(1) << 8)], 1).to(torch.int32))
+        next_index += frontier.numel()
+        frontier = chc[owns]                                           # parent-major, octant-minor: consecutive per parent
+    return torch.cat(ids).contiguous(), torch.cat(hdrs).contiguous()
+
+
 class MapDevice:
     """Device copy of the reference's `map_states` (mapping.py:319-339).  The 2e9-row CPU id table
     (mapping.py:76) is folded, once per map update, into vertex_rows[n,8] = row of each corner."""
@@ -53,13 +89,8 @@ class MapDevice:
         # voxels that are never sampled (non-SURFACE nodes) keep row 0 so a stray read stays in bounds
         self.vertex_rows = torch.as_tensor(np.maximum(rows, 0)).to(device)
         self.emb = torch.as_tensor(np.ascontiguousarray(emb_bf16_bits).view(np.int16)).to(device)   # bf16 bit patterns
-        # packed traversal layout: float4 (cx, cy, cz, bits(side)) + 8 x int32 children, for aligned vector loads
-        st = np.ascontiguousarray(structure, np.int32)
-        rec = np.empty((st.shape[0], 4), np.float32)
-        rec[:, :3] = np.asarray(centres, np.float32)
-        rec[:, 3] = st[:, 8].view(np.float32)
-        self.node_rec = torch.as_tensor(rec).to(device)
-        self.node_child = torch.as_tensor(np.ascontiguousarray(st[:, :8])).to(device)
+        self.blk_ids, self.blk_hdr = pack_children_blocks(self.centres, self.structure)
+        self.root_side = int(self.structure[0, 8])
         self.n_nodes = self.centres.shape[0]
         self.n_rows = self.emb.shape[0]
 
@@ -87,11 +118,8 @@ class MapDevice:
         if emb_bf16.dtype != torch.bfloat16 or not emb_bf16.is_cuda:
             raise L.NerfLoamHipError("voxel_vertex_emb must be a CUDA bfloat16 tensor")
         self.emb = emb_bf16.detach().view(torch.int16)
-        rec = torch.empty(n, 4, dtype=torch.float32, device=dev)
-        rec[:, :3] = self.centres
-        rec[:, 3] = self.structure[:, 8].contiguous().view(torch.float32)
-        self.node_rec = rec
-        self.node_child = self.structure[:, :8].contiguous()
+        self.blk_ids, self.blk_hdr = pack_children_blocks(self.centres, self.structure)
+        self.root_side = int(self.structure[0, 8])
         self.n_nodes, self.n_rows = n, self.emb.shape[0]
         return self
 
@@ -242,7 +270,7 @@ class SdfEngine:
         N = self.N
         c = self.counters
         c.zero_()
-        ops.ray_intersect(N, self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self.poses12, m.node_rec, m.node_child,
+        ops.ray_intersect(N, self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self.poses12, m.blk_hdr, m.blk_ids, m.root_side,
                           m.voxel_size, cfg.max_distance, self.rays_d_world, self.gt_dist, self.hit_idx, self.hit_t0, self.hit_t1,
                           self.hit_count, c)
         ops.exclusive_scan(self.hit_count, self.hit_rank, N, 1, c[L.NLC_R:L.NLC_R + 1], self.scan_ws)
@@ -285,7 +313,7 @@ class SdfEngine:
         N = self.N
         c = self.counters
         c.zero_()
-        ops.ray_intersect(N, self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self.poses12, m.node_rec, m.node_child,
+        ops.ray_intersect(N, self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self.poses12, m.blk_hdr, m.blk_ids, m.root_side,
                           m.voxel_size, cfg.max_distance, self.rays_d_world, self.gt_dist, self.hit_idx, self.hit_t0, self.hit_t1,
                           self.hit_count, c)
         ops.exclusive_scan(self.hit_count, self.hit_rank, N, 1, c[L.NLC_R:L.NLC_R + 1], self.scan_ws)
