@@ -69,7 +69,7 @@ int nl_inverse_cdf_sampling(const int* pts_idx, const float* min_depth, const fl
 int nl_ray_intersect(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
                      const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
                      float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
-                     int* counters, void* stream);
+                     int* counters, int* scratch_rays /* >= N ints, free to reuse afterwards */, void* stream);
 
 /* exclusive scan of in[0..n) (flag_mode: of (in[i] > 0)); total -> *total_out (device).
  * workspace >= ceil(n/1024) ints.  Replaces the boolean-mask compactions of render_helpers.py:219-257. */

@@ -23,7 +23,7 @@ OFF_B3 = OFF_W3 + 256
 
 # counter indices (nl_common.h)
 (NLC_R, NLC_HMAX, NLC_SMAX, NLC_P, NLC_NFS, NLC_NSDF, NLC_INV_FS_RAYS, NLC_INV_FS_CNT, NLC_INV_SDF_RAYS,
- NLC_INV_SDF_CNT, NLC_OVERFLOW, NLC_GUARD, NLC_R_OFFSET, NLC_R_GLOBAL) = range(14)
+ NLC_INV_SDF_CNT, NLC_OVERFLOW, NLC_GUARD, NLC_R_OFFSET, NLC_R_GLOBAL, NLC_ISECT_OVF) = range(15)
 NLD_FS_SQ, NLD_SDF_SQ, NLD_INV_D2, NLD_INV_D2CNT = range(4)
 
 _ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "no HIP device", 4: "capacity exceeded"}
@@ -43,7 +43,7 @@ _SIGS = {
     "nl_decoder_grid_hint": ([], _I),
     "nl_svo_intersect": ([_P] * 4 + [_I, _I, _I, _F, _I] + [_P] * 4, _I),
     "nl_inverse_cdf_sampling": ([_P] * 6 + [_I] * 4 + [_F] + [_P] * 4, _I),
-    "nl_ray_intersect": ([_I] + [_P] * 7 + [_I, _F, _F] + [_P] * 8, _I),
+    "nl_ray_intersect": ([_I] + [_P] * 7 + [_I, _F, _F] + [_P] * 9, _I),
     "nl_exclusive_scan_i32": ([_P, _P, _I, _I, _P, _P, _P], _I),
     "nl_compact_hit_rays": ([_I, _P, _P, _P, _P], _I),
     "nl_sample_rays": ([_I, _I] + [_P] * 8 + [_F, _F, _F, _U, _I, _I, _I] + [_P, _P, _P, _I] + [_P] * 5, _I),

@@ -28,6 +28,7 @@ enum {
     NLC_GUARD,          // set when a ray's summed interval length exceeds 10*MAX_DEPTH (reference returns None)
     NLC_R_OFFSET,       // multi-GPU: number of hit rays on lower ranks (global rank of local hit-ray 0)
     NLC_R_GLOBAL,       // multi-GPU: global number of hit rays (== NLC_R on one GPU)
+    NLC_ISECT_OVF,      // rays handed from the queue intersect kernel to the sequential DFS fallback
     NL_CNT_INTS = 16
 };
 enum {

@@ -96,14 +96,14 @@ __device__ __forceinline__ bool slab_inv(const float o[3], const float inv[3], f
     return true;
 }
 
-__global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect(
+__global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_dfs(
     int N, const float* __restrict__ rays_d_sensor, const float* __restrict__ points_gt,
     const float* __restrict__ cos_gt, const int* __restrict__ frame_id, const float* __restrict__ poses,
     const int2* __restrict__ blk_hdr, const int4* __restrict__ blk_ids, int root_side,
     float voxel_size, float max_distance,
     float* __restrict__ rays_d_world, float* __restrict__ gt_dist,
     int* __restrict__ hit_idx, float* __restrict__ hit_t0, float* __restrict__ hit_t1,
-    int* __restrict__ hit_count, int* __restrict__ counters)
+    int* __restrict__ hit_count, int* __restrict__ counters, const int* __restrict__ ray_list)
 {
     __shared__ int s_base[NL_MAX_LEVELS * NL_GEO_THREADS];
     __shared__ unsigned char s_mask[NL_MAX_LEVELS * NL_GEO_THREADS];
@@ -111,7 +111,11 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect(
     __shared__ int s_hmax;
     if (threadIdx.x == 0) s_hmax = 0;
     __syncthreads();
-    const int r = blockIdx.x * NL_GEO_THREADS + threadIdx.x;
+    // ray_list != null: fallback pass over the rays the queue kernel could not finish (count in counters[NLC_ISECT_OVF])
+    const int n_work = ray_list ? counters[NLC_ISECT_OVF] : N;
+    for (int w0 = blockIdx.x * NL_GEO_THREADS; w0 < n_work; w0 += gridDim.x * NL_GEO_THREADS) {
+    const int wi = w0 + threadIdx.x;
+    const int r = wi < n_work ? (ray_list ? ray_list[wi] : wi) : N;
     int valid = 0;
     if (r < N) {
         const float* P = poses + 12 * (frame_id ? frame_id[r] : 0);
@@ -201,6 +205,177 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect(
         hit_count[r] = valid;
     }
     // block max of valid hits -> one atomic per block
+    int wmax = valid;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(&s_hmax, wmax);
+    }   // work loop
+    __syncthreads();
+    if (threadIdx.x == 0 && s_hmax > 0) atomicMax(&counters[NLC_HMAX], s_hmax);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Work-list version of the same traversal: FOUR lanes per ray work through a per-ray LDS stack of pending node
+// expansions, so up to four expansions of one ray are in flight at once.  The sequential DFS is bound by the
+// ray's dependent chain of ~55-110 expansions (one memory round trip each, ~300 us whatever the ray count);
+// with the queue the chain shrinks to about the tree depth.  Expansion order is free because the DFS order of
+// the leaves is recoverable afterwards: the reference visits children in descending octant order, so its hit
+// order is DESCENDING Morton order of the voxel coordinates (z most significant at each level); the 20-hit cap
+// keeps the 20 largest codes.  Hits are then stably sorted by t_min and culled exactly as before.
+// Rays whose queue (32) or hit list (24) overflows are appended to a list and redone by k_ray_intersect_dfs.
+// ---------------------------------------------------------------------------------------------
+#define IQ_LPR 4
+#define IQ_RAYS (NL_GEO_THREADS / IQ_LPR)
+#define IQ_QCAP 32
+#define IQ_HCAP 24
+
+__device__ __forceinline__ bool less_msb(unsigned a, unsigned b) { return a < b && a < (a ^ b); }
+// true if voxel 1 precedes voxel 2 in the reference's DFS order (= larger z-major Morton code)
+__device__ __forceinline__ bool dfs_before(int x1, int y1, int z1, int x2, int y2, int z2)
+{
+    const unsigned dx = (unsigned)(x1 ^ x2), dy = (unsigned)(y1 ^ y2), dz = (unsigned)(z1 ^ z2);
+    unsigned m = dz; int a = z1, b = z2;
+    if (less_msb(m, dy)) { m = dy; a = y1; b = y2; }
+    if (less_msb(m, dx)) { m = dx; a = x1; b = x2; }
+    return a > b;
+}
+
+__global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
+    int N, const float* __restrict__ rays_d_sensor, const float* __restrict__ points_gt,
+    const float* __restrict__ cos_gt, const int* __restrict__ frame_id, const float* __restrict__ poses,
+    const int2* __restrict__ blk_hdr, const int4* __restrict__ blk_ids, int root_side,
+    float voxel_size, float max_distance,
+    float* __restrict__ rays_d_world, float* __restrict__ gt_dist,
+    int* __restrict__ hit_idx, float* __restrict__ hit_t0, float* __restrict__ hit_t1,
+    int* __restrict__ hit_count, int* __restrict__ counters, int* __restrict__ ovf_list)
+{
+    __shared__ int4 s_q[IQ_RAYS * IQ_QCAP];
+    __shared__ int s_hid[IQ_RAYS * IQ_HCAP], s_hx[IQ_RAYS * IQ_HCAP], s_hy[IQ_RAYS * IQ_HCAP], s_hz[IQ_RAYS * IQ_HCAP];
+    __shared__ float s_ht0[IQ_RAYS * IQ_HCAP], s_ht1[IQ_RAYS * IQ_HCAP];
+    __shared__ int s_head[IQ_RAYS], s_tail[IQ_RAYS], s_nh[IQ_RAYS], s_ovf[IQ_RAYS];
+    __shared__ int s_hmax;
+    if (threadIdx.x == 0) s_hmax = 0;
+    const int rl = threadIdx.x / IQ_LPR, j = threadIdx.x % IQ_LPR;
+    const int r = blockIdx.x * IQ_RAYS + rl;
+    const bool live = r < N;
+    float o[3] = {0.f, 0.f, 0.f}, inv[3] = {1.f, 1.f, 1.f};
+    const float half_voxel = voxel_size * 0.5f;
+    if (j == 0) { s_head[rl] = 0; s_tail[rl] = 0; s_nh[rl] = 0; s_ovf[rl] = 0; }
+    if (live) {
+        const float* P = poses + 12 * (frame_id ? frame_id[r] : 0);
+        const float s0 = rays_d_sensor[3 * r], s1 = rays_d_sensor[3 * r + 1], s2 = rays_d_sensor[3 * r + 2];
+        float d[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) d[i] = (s0 * P[3 * i] + s1 * P[3 * i + 1]) + s2 * P[3 * i + 2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { o[i] = P[9 + i]; inv[i] = 1.0f / d[i]; }
+        if (j == 0) {
+            rays_d_world[3 * r] = d[0]; rays_d_world[3 * r + 1] = d[1]; rays_d_world[3 * r + 2] = d[2];
+            const float gx = points_gt[3 * r], gy = points_gt[3 * r + 1], gz = points_gt[3 * r + 2];
+            gt_dist[r] = sqrtf((gx * gx + gy * gy) + gz * gz) * cos_gt[r];
+            const float fs = (float)root_side, hs = fs * 0.5f;
+            float tn, tf;
+            const int2 h0 = blk_hdr[0];
+            if (slab_inv(o, inv, hs * voxel_size, hs * voxel_size, hs * voxel_size, half_voxel * fs, &tn, &tf) && h0.x >= 0) {
+                s_q[rl * IQ_QCAP] = make_int4(h0.x, 0, 0, (31 - __clz(root_side >> 1)) << 20);   // children of the root: side root/2
+                s_tail[rl] = 1;
+            }
+        }
+    }
+    __syncthreads();
+    // The pending expansions form a STACK (s_tail = height): the four lanes always take the deepest pending nodes, which
+    // keeps the pending set as small as a DFS with all siblings pushed (a line meets at most 4 of a node's 8 children,
+    // so <= 3 per level + 4), while still giving four independent memory round trips per ray per round.
+    for (;;) {
+        const int height = (live && !s_ovf[rl]) ? s_tail[rl] : 0;
+        if (!__any(height > 0)) break;                              // wave-uniform: all 16 rays of this wave are done
+        const int k = height < IQ_LPR ? height : IQ_LPR;
+        const bool mine = j < k;
+        int4 e = make_int4(0, 0, 0, 0);
+        if (mine) e = s_q[rl * IQ_QCAP + height - 1 - j];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();                           // every lane of the group has fetched its entry
+        if (j == 0 && height > 0) s_tail[rl] = height - k;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (mine) {
+            const int b = e.x, px = e.y, py = e.z, pz = e.w & 0xFFFFF, csl = e.w >> 20, cs = 1 << csl;
+            const int2 hdr = blk_hdr[b];
+            const unsigned exist = (unsigned)hdr.y & 255u, has = ((unsigned)hdr.y >> 8) & 255u;
+            const float fs = (float)cs, hs = fs * 0.5f, half = half_voxel * fs;
+            if (cs == 1) {
+                const int4 ia = blk_ids[2 * (size_t)b], ib = blk_ids[2 * (size_t)b + 1];
+                const int ids[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+#pragma unroll
+                for (int u = 7; u >= 0; --u) {
+                    if (!((exist >> u) & 1u) || ids[u] < 0) continue;
+                    const int vx = px + (u & 1), vy = py + ((u >> 1) & 1), vz = pz + ((u >> 2) & 1);
+                    float tn, tf;
+                    if (slab_inv(o, inv, ((float)vx + hs) * voxel_size, ((float)vy + hs) * voxel_size, ((float)vz + hs) * voxel_size, half, &tn, &tf)) {
+                        const int slot = atomicAdd(&s_nh[rl], 1);
+                        if (slot < IQ_HCAP) {
+                            const int a = rl * IQ_HCAP + slot;
+                            s_hid[a] = ids[u]; s_ht0[a] = tn; s_ht1[a] = tf; s_hx[a] = vx; s_hy[a] = vy; s_hz[a] = vz;
+                        } else s_ovf[rl] = 1;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 7; u >= 0; --u) {
+                    if (!((has >> u) & 1u)) continue;
+                    const int cx = px + ((u & 1) ? cs : 0), cy = py + ((u & 2) ? cs : 0), cz = pz + ((u & 4) ? cs : 0);
+                    float tn, tf;
+                    if (slab_inv(o, inv, ((float)cx + hs) * voxel_size, ((float)cy + hs) * voxel_size, ((float)cz + hs) * voxel_size, half, &tn, &tf)) {
+                        const int slot = atomicAdd(&s_tail[rl], 1);
+                        if (slot < IQ_QCAP)
+                            s_q[rl * IQ_QCAP + slot] = make_int4(hdr.x + __popc(has & ((1u << u) - 1u)), cx, cy, cz | ((csl - 1) << 20));
+                        else s_ovf[rl] = 1;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // finalise: one lane per ray
+    int valid = 0;
+    if (live && j == 0) {
+        const int nh = s_nh[rl];
+        if (s_ovf[rl] || nh > IQ_HCAP) {
+            ovf_list[atomicAdd(&counters[NLC_ISECT_OVF], 1)] = r;
+            hit_count[r] = 0;                                       // rewritten by the DFS fallback pass
+        } else {
+            const int a0 = rl * IQ_HCAP;
+            // (1) DFS order = descending z-major Morton order of the voxel; keep the first 20 (the reference's cap)
+            for (int i = 1; i < nh; ++i) {
+                const int id = s_hid[a0 + i], x = s_hx[a0 + i], y = s_hy[a0 + i], z = s_hz[a0 + i];
+                const float t0 = s_ht0[a0 + i], t1 = s_ht1[a0 + i];
+                int q = i - 1;
+                while (q >= 0 && dfs_before(x, y, z, s_hx[a0 + q], s_hy[a0 + q], s_hz[a0 + q])) {
+                    s_hid[a0 + q + 1] = s_hid[a0 + q]; s_hx[a0 + q + 1] = s_hx[a0 + q]; s_hy[a0 + q + 1] = s_hy[a0 + q]; s_hz[a0 + q + 1] = s_hz[a0 + q];
+                    s_ht0[a0 + q + 1] = s_ht0[a0 + q]; s_ht1[a0 + q + 1] = s_ht1[a0 + q];
+                    --q;
+                }
+                s_hid[a0 + q + 1] = id; s_hx[a0 + q + 1] = x; s_hy[a0 + q + 1] = y; s_hz[a0 + q + 1] = z; s_ht0[a0 + q + 1] = t0; s_ht1[a0 + q + 1] = t1;
+            }
+            const int cnt = nh < NL_MAX_HITS ? nh : NL_MAX_HITS;
+            // (2) stable sort by t_min (voxel_helpers.py:546), (3) cull, write the ray's row
+            for (int i = 1; i < cnt; ++i) {
+                const int id = s_hid[a0 + i]; const float t0 = s_ht0[a0 + i], t1 = s_ht1[a0 + i];
+                int q = i - 1;
+                while (q >= 0 && s_ht0[a0 + q] > t0) { s_hid[a0 + q + 1] = s_hid[a0 + q]; s_ht0[a0 + q + 1] = s_ht0[a0 + q]; s_ht1[a0 + q + 1] = s_ht1[a0 + q]; --q; }
+                s_hid[a0 + q + 1] = id; s_ht0[a0 + q + 1] = t0; s_ht1[a0 + q + 1] = t1;
+            }
+            int* oi = hit_idx + (size_t)r * NL_MAX_HITS; float* o0 = hit_t0 + (size_t)r * NL_MAX_HITS; float* o1 = hit_t1 + (size_t)r * NL_MAX_HITS;
+            for (int i = 0; i < cnt; ++i) {
+                const float t0 = s_ht0[a0 + i], t1 = s_ht1[a0 + i];
+                const bool keep = !(t1 > 2.0f * max_distance) && !(t0 > max_distance);
+                if (keep) { ++valid; oi[i] = s_hid[a0 + i]; o0[i] = t0; o1[i] = t1; }
+                else { oi[i] = -1; o0[i] = max_distance; o1[i] = max_distance; }
+            }
+            hit_count[r] = valid;
+        }
+    }
     int wmax = valid;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off));
@@ -525,13 +700,18 @@ int nl_inverse_cdf_sampling(const int* pts_idx, const float* min_depth, const fl
 int nl_ray_intersect(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
                      const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
                      float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
-                     int* counters, void* stream)
+                     int* counters, int* scratch_rays, void* stream)
 {
     if (N <= 0 || !rays_d_sensor || !points_gt || !cos_gt || !poses || !blk_ids || !blk_hdr || root_side < 2 || !rays_d_world || !gt_dist ||
-        !hit_idx || !hit_t0 || !hit_t1 || !hit_count || !counters) return NL_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_ray_intersect, dim3(nl_div_up(N, NL_GEO_THREADS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream,
+        !hit_idx || !hit_t0 || !hit_t1 || !hit_count || !counters || !scratch_rays) return NL_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_ray_intersect_q, dim3(nl_div_up(N, IQ_RAYS)), dim3(NL_GEO_THREADS), 0, st,
                        N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, (const int2*)blk_hdr, (const int4*)blk_ids, root_side, voxel_size, max_distance,
-                       rays_d_world, gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters);
+                       rays_d_world, gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, scratch_rays);
+    // rays whose LDS queue / hit list overflowed (none on ordinary scans): sequential DFS, device-side count
+    hipLaunchKernelGGL(k_ray_intersect_dfs, dim3(32), dim3(NL_GEO_THREADS), 0, st,
+                       N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, (const int2*)blk_hdr, (const int4*)blk_ids, root_side, voxel_size, max_distance,
+                       rays_d_world, gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, (const int*)scratch_rays);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

@@ -272,7 +272,7 @@ class SdfEngine:
         c.zero_()
         ops.ray_intersect(N, self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self.poses12, m.blk_hdr, m.blk_ids, m.root_side,
                           m.voxel_size, cfg.max_distance, self.rays_d_world, self.gt_dist, self.hit_idx, self.hit_t0, self.hit_t1,
-                          self.hit_count, c)
+                          self.hit_count, c, self.ray_of_rank)
         ops.exclusive_scan(self.hit_count, self.hit_rank, N, 1, c[L.NLC_R:L.NLC_R + 1], self.scan_ws)
         if self.hook_after_intersect is not None:
             self.hook_after_intersect(self)                      # fills NLC_R_GLOBAL / NLC_R_OFFSET / global NLC_HMAX
@@ -315,7 +315,7 @@ class SdfEngine:
         c.zero_()
         ops.ray_intersect(N, self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self.poses12, m.blk_hdr, m.blk_ids, m.root_side,
                           m.voxel_size, cfg.max_distance, self.rays_d_world, self.gt_dist, self.hit_idx, self.hit_t0, self.hit_t1,
-                          self.hit_count, c)
+                          self.hit_count, c, self.ray_of_rank)
         ops.exclusive_scan(self.hit_count, self.hit_rank, N, 1, c[L.NLC_R:L.NLC_R + 1], self.scan_ws)
         c[L.NLC_R_GLOBAL:L.NLC_R_GLOBAL + 1].copy_(c[L.NLC_R:L.NLC_R + 1])
         ops.compact_hit_rays(N, self.hit_count, self.hit_rank, self.ray_of_rank)

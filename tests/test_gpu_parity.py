@@ -345,3 +345,41 @@ def test_full_scan_invariants(nl):
     torch.testing.assert_close(dec.grad, 2 * g1, rtol=1e-4, atol=1e-7 * float(g1.abs().max()))
     rel = (eng.g_emb - 2 * ge1).norm() / (2 * ge1).norm()
     assert float(rel) < 2e-3                                             # bf16-rounded contributions
+
+
+def test_intersect_cap_and_overflow_paths(nl):
+    """Dense voxel slab + grazing rays: up to ~60 voxels per ray.  Exercises the 20-hit cap (first 20 in the
+    reference's DFS order, before the t_min sort), the queue kernel's hit-list / queue overflow and the DFS
+    fallback pass; results must still be bit-identical to the oracle."""
+    P, ops, L = nl["P"], nl["ops"], nl["L"]
+    xs, ys, zs = np.meshgrid(np.arange(10000, 10048), np.arange(10000, 10040), np.arange(10000, 10003), indexing="ij")
+    vox = np.stack([xs, ys, zs], -1).reshape(-1, 3).astype(np.int32)
+    oc = O.Octree(); oc.init(256 * 256 * 4, 16, 0.2); oc.insert(vox)
+    v, c, f = oc.get_centres_and_children()
+    centres, structure = O.grid_features(v, c, 0.2)
+    rng = np.random.default_rng(5)
+    n = 4096
+    origin = np.array([1999.0, 2003.7, 2000.31], np.float32)
+    tgt = np.stack([rng.uniform(2000.0, 2009.6, n), rng.uniform(2000.0, 2008.0, n), rng.uniform(1998.5, 2002.0, n)], -1).astype(np.float32)
+    d = tgt - origin; d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    oi, o0, o1, hits = O.ray_intersect(np.broadcast_to(origin, d.shape).copy(), d, centres, structure, 0.2, 50.0)
+    raw_cnt = (O.svo_intersect(np.broadcast_to(origin, d.shape).copy(), d, centres, structure, 0.2, 20)[0] != -1).sum(1)
+    assert (raw_cnt == 20).mean() > 0.1 and ((raw_cnt < 20) & (raw_cnt > 0)).mean() > 0.1    # capped and uncapped rays present
+    id2row = np.zeros(len(centres), np.int32)
+    m = P.MapDevice(centres, structure, f, id2row, np.zeros((1, 16), np.uint16), 0.2)
+    eng = P.SdfEngine(max_rays=n, samples_per_ray_cap=8)
+    pose = np.concatenate([origin, np.zeros(3, np.float32)])
+    eng.set_rays(d, np.ones_like(d), np.ones(n, np.float32)); eng.set_poses(pose[None], [0])
+    eng.counters.zero_()
+    ops.ray_intersect(n, eng.rays_d_sensor, eng.points_gt, eng.cos_gt, eng.frame_id, eng.poses12, m.blk_hdr, m.blk_ids, m.root_side, 0.2, 50.0,
+                      eng.rays_d_world, eng.gt_dist, eng.hit_idx, eng.hit_t0, eng.hit_t1, eng.hit_count, eng.counters, eng.ray_of_rank)
+    cnt = eng.counters.cpu().numpy()
+    assert cnt[L.NLC_ISECT_OVF] > 0                                               # the fallback pass really ran
+    hc = eng.hit_count[:n].cpu().numpy()
+    Hm = oi.shape[1]
+    assert cnt[L.NLC_HMAX] == Hm == hc.max()
+    live = np.arange(Hm)[None, :] < hc[:, None]
+    assert np.array_equal(hc, (oi != -1).sum(1))
+    assert np.array_equal(np.where(live, eng.hit_idx[:n, :Hm].cpu().numpy(), -1), oi)
+    assert np.array_equal(np.where(live, eng.hit_t0[:n, :Hm].cpu().numpy(), np.float32(50)), o0)
+    assert np.array_equal(np.where(live, eng.hit_t1[:n, :Hm].cpu().numpy(), np.float32(50)), o1)
