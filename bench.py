@@ -98,6 +98,47 @@ def cpu_baseline(w, n_rays=8192, seed=1):
                        f"({dt * 1e3:.0f} ms/iter; numpy/C oracle, GEMMs on torch-CPU threads)")
 
 
+def pose_refine_bench(w, device, steps=200):
+    """M2: ms per pose-refine step (track_frame iteration, render_helpers.py:452-512): 2048 rays, step 0.2*voxel,
+    decoder + embeddings frozen, 6-dof pose Adam; rays resident, the launch sequence replayed as a hipGraph."""
+    from nerf_loam_amd import pipeline as P
+    rng = np.random.default_rng(3)
+    sel = np.sort(rng.choice(len(w["points"]), 2048, replace=False))
+    eng = P.SdfEngine(max_rays=2048, samples_per_ray_cap=96, device=device)
+    eng.set_rays(w["dirs"][sel], w["points"][sel], w["cos"][sel])
+    pose = w["pose"].copy(); pose[:3] += np.array([0.03, -0.02, 0.01], np.float32)
+    eng.set_poses(pose[None], [1])
+    cfg = P.IterConfig(step_size=0.04)
+    eng.begin_call(w["map"], None)
+    flags = dict(train_decoder=False, want_emb_grad=False, want_pose_grad=True, update_emb=False, update_decoder=False,
+                 update_pose=True, lr_pose=0.005 / 3)
+    out = {}
+    for mode in ("eager", "graph"):
+        if mode == "graph":
+            try:
+                eng.capture_iteration(w["map"], w["dec"], cfg, **flags)
+            except Exception as e:                               # noqa: BLE001 - report, do not fail the bench
+                out["graph_error"] = repr(e)[:200]
+                break
+        def one():
+            if mode == "graph":
+                eng.replay()
+            else:
+                eng.forward_backward(w["map"], w["dec"], cfg, train_decoder=False, want_emb_grad=False, want_pose_grad=True)
+                eng.optimiser_step(w["map"], w["dec"], cfg, update_emb=False, update_decoder=False, update_pose=True, lr_pose=0.005 / 3)
+        for _ in range(10):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        out[f"ms_per_step_{mode}"] = (time.perf_counter() - t0) / steps * 1e3
+    st = eng.stats()
+    out.update(rays=2048, valid_samples=st["P"], step_size_m=0.04)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,6 +228,8 @@ def main():
                                             "frac": P_local * FLOPS_PER_SAMPLE_WGRAD2 / (wg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
                                            if train_dec else None)},
         }
+        if world == 1:
+            out["pose_refine"] = pose_refine_bench(w, device)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))

@@ -127,15 +127,20 @@ int nl_unpack_samples(const void* loss_scalars, const int* s_ray, const int* sam
                       const float* sdf, const float* depth, int S_stride, float* out_sdf, float* out_z, unsigned char* out_valid,
                       void* stream);
 
-/* ---- optimiser: torch.optim.Adam as used in render_helpers.py:341-353,421-423,448-450,508-510 ---- */
-int nl_adam_embeddings(void* emb_bf16, float* g_acc, void* m_bf16, void* v_bf16, long long n_elems, double lr, int step, void* stream);
+/* ---- optimiser: torch.optim.Adam as used in render_helpers.py:341-353,421-423,448-450,508-510 ----
+ * `state` = device block of NL_ADAM_STATE_BYTES: int32 step counter (zero it when a new Adam is "constructed",
+ * render_helpers.py:353,448) + the per-group hyper-parameters.  nl_adam_prepare advances the step and refreshes the
+ * bias corrections on the device (no host scalar => hipGraph-replayable); then the per-group kernels. */
+#define NL_ADAM_STATE_BYTES 112
+int nl_adam_prepare(int* state, double lr_emb, double lr_dec, double lr_pose, void* stream);
+int nl_adam_embeddings(void* emb_bf16, float* g_acc, void* m_bf16, void* v_bf16, long long n_elems, const int* state, void* stream);
 int nl_embedding_grad_bf16(const float* g_acc, void* g_bf16, long long n_elems, void* stream);
-int nl_adam_f32(float* p, const float* g, float* m, float* v, int n, double lr, int step, void* stream);
+int nl_adam_f32(float* p, const float* g, float* m, float* v, int n, const int* state, int group /*1 decoder, 2 pose*/, void* stream);
 /* se3pose.py:18-35: pose6[F,6] = (t, w) -> poses12[F,12] */
 int nl_pose_matrices(const float* pose6, float* poses12, int F, void* stream);
 /* Rodrigues tail of the pose gradient + Adam on the 6-vectors (enable[f] != 0) + refreshed matrices */
 int nl_pose_step(float* pose6, float* g_pose, float* m, float* v, const int* enable, float* grad6_out, float* poses12,
-                 int F, double lr, int step, int apply, void* stream);
+                 int F, const int* state, int apply, void* stream);
 
 /* ---- (b2) host octree behind torch.classes.svo.Octree (third_party/sparse_octree/src/bindings.cpp:4-31) */
 void* nl_octree_create(long long grid_dim);                              /* Octree::init   octree.cpp:36-50   */

@@ -12,6 +12,7 @@ NL_CNT_INTS = 16
 NL_CNT_DOUBLES = 4
 NL_CNT_BYTES = NL_CNT_INTS * 4 + NL_CNT_DOUBLES * 8
 NL_LOSS_SCALARS_BYTES = 48
+NL_ADAM_STATE_BYTES = 112
 NL_DEC_PARAMS = 70401
 NL_C = 16
 NL_W = 256
@@ -56,11 +57,12 @@ _SIGS = {
     "nl_decoder_transpose_w2": ([_P, _P, _P], _I),
     "nl_trilinear_bwd": ([_P] * 8 + [_I] + [_P] * 3 + [_F] + [_P] * 3 + [_I, _P], _I),
     "nl_unpack_samples": ([_P] * 6 + [_I] + [_P] * 4, _I),
-    "nl_adam_embeddings": ([_P, _P, _P, _P, _LL, _D, _I, _P], _I),
+    "nl_adam_prepare": ([_P, _D, _D, _D, _P], _I),
+    "nl_adam_embeddings": ([_P, _P, _P, _P, _LL, _P, _P], _I),
     "nl_embedding_grad_bf16": ([_P, _P, _LL, _P], _I),
-    "nl_adam_f32": ([_P, _P, _P, _P, _I, _D, _I, _P], _I),
+    "nl_adam_f32": ([_P, _P, _P, _P, _I, _P, _I, _P], _I),
     "nl_pose_matrices": ([_P, _P, _I, _P], _I),
-    "nl_pose_step": ([_P] * 7 + [_I, _D, _I, _I, _P], _I),
+    "nl_pose_step": ([_P] * 7 + [_I, _P, _I, _P], _I),
     "nl_octree_create": ([_LL], _P),
     "nl_octree_destroy": ([_P], None),
     "nl_octree_insert": ([_P, _P, _LL], _I),

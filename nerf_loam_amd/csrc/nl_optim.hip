@@ -7,9 +7,24 @@
 #include "nl_common.h"
 
 // embeddings: g = bf16(fp32 accumulator) ; accumulator is reset for the next iteration
-__global__ void k_adam_emb(uint16_t* __restrict__ p, float* __restrict__ g_acc, uint16_t* __restrict__ m, uint16_t* __restrict__ v,
-                           long long n, NlAdamHyper h)
+// optimiser state block on the device: int32 step counter (+3 pad) followed by NlAdamHyper[3] = {embeddings, decoder,
+// pose}.  k_adam_prepare advances the step and recomputes the bias corrections ON THE DEVICE, so the whole optimiser
+// step has no host-side scalar: a captured hipGraph replays correctly for every iteration of a call.
+__global__ void k_adam_prepare(int* __restrict__ state, double lr_emb, double lr_dec, double lr_pose)
 {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int step = state[0] + 1;
+    state[0] = step;
+    NlAdamHyper* h = reinterpret_cast<NlAdamHyper*>(state + 4);
+    h[0] = nl_adam_hyper(lr_emb, step, 0.9, 0.999, 1e-8);
+    h[1] = nl_adam_hyper(lr_dec, step, 0.9, 0.999, 1e-8);
+    h[2] = nl_adam_hyper(lr_pose, step, 0.9, 0.999, 1e-8);
+}
+
+__global__ void k_adam_emb(uint16_t* __restrict__ p, float* __restrict__ g_acc, uint16_t* __restrict__ m, uint16_t* __restrict__ v,
+                           long long n, const NlAdamHyper* __restrict__ hp)
+{
+    const NlAdamHyper h = *hp;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float ga = g_acc[i];
         const uint16_t pm = m[i], pv = v[i];
@@ -29,10 +44,11 @@ __global__ void k_emb_grad_bf16(const float* __restrict__ g_acc, uint16_t* __res
 }
 
 __global__ void k_adam_f32(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                           int n, NlAdamHyper h)
+                           int n, const NlAdamHyper* __restrict__ hp)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const NlAdamHyper h = *hp;
     float pp = p[i], mm = m[i], vv = v[i];
     nl_adam_f32(&pp, g[i], &mm, &vv, h);
     p[i] = pp; m[i] = mm; v[i] = vv;
@@ -64,10 +80,11 @@ __global__ void k_pose_matrix(const float* __restrict__ pose6, float* __restrict
 // refreshed pose matrices.  grad6_out (optional) receives the 6-vector gradient; g_pose is cleared.
 __global__ void k_pose_step(float* __restrict__ pose6, float* __restrict__ g_pose, float* __restrict__ m, float* __restrict__ v,
                             const int* __restrict__ enable, float* __restrict__ grad6_out, float* __restrict__ poses12,
-                            int F, NlAdamHyper h, int apply)
+                            int F, const NlAdamHyper* __restrict__ hp, int apply)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
+    const NlAdamHyper h = *hp;
     float g6[6], gw[3];
     nl_rodrigues_bwd(pose6 + 6 * f + 3, g_pose + 12 * f + 3, gw);
     for (int i = 0; i < 3; ++i) { g6[i] = g_pose[12 * f + i]; g6[3 + i] = gw[i]; }
@@ -84,14 +101,22 @@ __global__ void k_pose_step(float* __restrict__ pose6, float* __restrict__ g_pos
 
 extern "C" {
 
-static NlAdamHyper hyper(double lr, int step) { return nl_adam_hyper(lr, step, 0.9, 0.999, 1e-8); }
-
-int nl_adam_embeddings(void* emb, float* g_acc, void* m, void* v, long long n_elems, double lr, int step, void* stream)
+int nl_adam_prepare(int* state, double lr_emb, double lr_dec, double lr_pose, void* stream)
 {
-    if (!emb || !g_acc || !m || !v || n_elems <= 0 || step <= 0) return NL_ERR_INVALID_ARG;
+    if (!state) return NL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(64), 0, (hipStream_t)stream, state, lr_emb, lr_dec, lr_pose);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+static const NlAdamHyper* hyper_of(const int* state, int which) { return reinterpret_cast<const NlAdamHyper*>(state + 4) + which; }
+
+int nl_adam_embeddings(void* emb, float* g_acc, void* m, void* v, long long n_elems, const int* state, void* stream)
+{
+    if (!emb || !g_acc || !m || !v || n_elems <= 0 || !state) return NL_ERR_INVALID_ARG;
     const int blocks = (int)((n_elems + 255) / 256 < 4096 ? (n_elems + 255) / 256 : 4096);
     hipLaunchKernelGGL(k_adam_emb, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (uint16_t*)emb, g_acc, (uint16_t*)m, (uint16_t*)v,
-                       n_elems, hyper(lr, step));
+                       n_elems, hyper_of(state, 0));
     NL_LAUNCH_CHECK();
     return NL_OK;
 }
@@ -105,10 +130,10 @@ int nl_embedding_grad_bf16(const float* g_acc, void* g_bf16, long long n_elems, 
     return NL_OK;
 }
 
-int nl_adam_f32(float* p, const float* g, float* m, float* v, int n, double lr, int step, void* stream)
+int nl_adam_f32(float* p, const float* g, float* m, float* v, int n, const int* state, int which, void* stream)
 {
-    if (!p || !g || !m || !v || n <= 0 || step <= 0) return NL_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_adam_f32, dim3(nl_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, hyper(lr, step));
+    if (!p || !g || !m || !v || n <= 0 || !state || which < 0 || which > 2) return NL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_adam_f32, dim3(nl_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, hyper_of(state, which));
     NL_LAUNCH_CHECK();
     return NL_OK;
 }
@@ -130,11 +155,11 @@ int nl_pose_matrices(const float* pose6, float* poses12, int F, void* stream)
 }
 
 int nl_pose_step(float* pose6, float* g_pose, float* m, float* v, const int* enable, float* grad6_out, float* poses12,
-                 int F, double lr, int step, int apply, void* stream)
+                 int F, const int* state, int apply, void* stream)
 {
-    if (!pose6 || !g_pose || !m || !v || !poses12 || F <= 0 || step <= 0) return NL_ERR_INVALID_ARG;
+    if (!pose6 || !g_pose || !m || !v || !poses12 || F <= 0 || !state) return NL_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_pose_step, dim3(nl_div_up(F, 64)), dim3(64), 0, (hipStream_t)stream, pose6, g_pose, m, v, enable, grad6_out,
-                       poses12, F, hyper(lr, step), apply);
+                       poses12, F, hyper_of(state, 2), apply);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

@@ -117,26 +117,29 @@ def unpack_samples(loss_scalars, s_ray, samp_off, hit_rank, sdf, depth, S_stride
                                     ptr(out_sdf), ptr(out_z), ptr(out_valid), stream_ptr()), "nl_unpack_samples")
 
 
-def adam_embeddings(emb, g_acc, m, v, lr, step):
-    check(L.lib().nl_adam_embeddings(ptr(emb), ptr(g_acc), ptr(m), ptr(v), emb.numel(), float(lr), int(step), stream_ptr()),
-          "nl_adam_embeddings")
+def adam_prepare(state, lr_emb, lr_dec, lr_pose):
+    check(L.lib().nl_adam_prepare(ptr(state), float(lr_emb), float(lr_dec), float(lr_pose), stream_ptr()), "nl_adam_prepare")
+
+
+def adam_embeddings(emb, g_acc, m, v, state):
+    check(L.lib().nl_adam_embeddings(ptr(emb), ptr(g_acc), ptr(m), ptr(v), emb.numel(), ptr(state), stream_ptr()), "nl_adam_embeddings")
 
 
 def embedding_grad_bf16(g_acc, g_bf16):
     check(L.lib().nl_embedding_grad_bf16(ptr(g_acc), ptr(g_bf16), g_acc.numel(), stream_ptr()), "nl_embedding_grad_bf16")
 
 
-def adam_f32(p, g, m, v, lr, step):
-    check(L.lib().nl_adam_f32(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), int(step), stream_ptr()), "nl_adam_f32")
+def adam_f32(p, g, m, v, state, group):
+    check(L.lib().nl_adam_f32(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(state), int(group), stream_ptr()), "nl_adam_f32")
 
 
 def pose_matrices(pose6, poses12):
     check(L.lib().nl_pose_matrices(ptr(pose6), ptr(poses12), pose6.shape[0], stream_ptr()), "nl_pose_matrices")
 
 
-def pose_step(pose6, g_pose, m, v, enable, grad6_out, poses12, lr, step, apply):
+def pose_step(pose6, g_pose, m, v, enable, grad6_out, poses12, state, apply):
     check(L.lib().nl_pose_step(ptr(pose6), ptr(g_pose), ptr(m), ptr(v), ptr(enable), ptr(grad6_out), ptr(poses12), pose6.shape[0],
-                               float(lr), int(step), int(apply), stream_ptr()), "nl_pose_step")
+                               ptr(state), int(apply), stream_ptr()), "nl_pose_step")
 
 
 def mfma_selftest(A32, B32, D32, A16, B16, D16):

@@ -212,7 +212,8 @@ class SdfEngine:
         self.g_emb = None
         self.emb_m = None
         self.emb_v = None
-        self.step = 0
+        self.adam_state = torch.zeros(L.NL_ADAM_STATE_BYTES // 4, dtype=I32, device=d)   # device step counter + hyper-parameters
+        self.graph = None
         # multi-GPU hooks (dist.py installs them); identity on one GPU
         self.hook_after_intersect = None
         self.hook_after_count = None
@@ -249,7 +250,8 @@ class SdfEngine:
     def begin_call(self, m: MapDevice, dec: DecoderDevice = None):
         """A fresh torch.optim.Adam is created per bundle_adjust_frames / track_frame call
         (render_helpers.py:353,448): reset optimiser state."""
-        self.step = 0
+        self.adam_state.zero_()
+        self.graph = None
         self.pose_m.zero_()
         self.pose_v.zero_()
         E = m.n_rows
@@ -336,14 +338,39 @@ class SdfEngine:
     def optimiser_step(self, m: MapDevice, dec: DecoderDevice, cfg: IterConfig, update_emb=True, update_decoder=True, update_pose=True,
                        lr_pose=None):
         """optim.step() of render_helpers.py:421-423 / :508-510 on the device-resident parameters."""
-        self.step += 1
+        ops.adam_prepare(self.adam_state, cfg.lr_emb, cfg.lr_dec, cfg.lr_pose if lr_pose is None else lr_pose)
         if update_emb:
-            ops.adam_embeddings(m.emb, self.g_emb, self.emb_m, self.emb_v, cfg.lr_emb, self.step)
+            ops.adam_embeddings(m.emb, self.g_emb, self.emb_m, self.emb_v, self.adam_state)
         if update_decoder:
-            ops.adam_f32(dec.params, dec.grad, dec.m, dec.v, cfg.lr_dec, self.step)
+            ops.adam_f32(dec.params, dec.grad, dec.m, dec.v, self.adam_state, 1)
             dec.refresh()
         ops.pose_step(self.pose6[:self.F], self.g_pose, self.pose_m, self.pose_v, self.pose_enable, self.pose_grad6, self.poses12,
-                      cfg.lr_pose if lr_pose is None else lr_pose, self.step, int(update_pose))
+                      self.adam_state, int(update_pose))
+
+    # ------------------------------------------------------------------ hipGraph
+    def capture_iteration(self, m: MapDevice, dec: DecoderDevice, cfg: IterConfig, **flags):
+        """Capture forward_backward + optimiser_step into a hipGraph (torch.cuda.CUDAGraph).  Possible because the launch
+        sequence is fixed, every data-dependent size lives in device memory and the optimiser step counter is on the
+        device.  Ray buffers / poses may be rewritten between replays (set_rays / set_poses write in place)."""
+        fb = {k: flags[k] for k in ("train_decoder", "want_emb_grad", "want_pose_grad", "ray_id_base") if k in flags}
+        op = {k: flags[k] for k in ("update_emb", "update_decoder", "update_pose", "lr_pose") if k in flags}
+        state0 = self.adam_state.clone()
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):                       # warm-up outside capture (allocator, lazy module load)
+            self.forward_backward(m, dec, cfg, **fb)
+            self.g_emb.zero_(); self.g_pose.zero_()
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.forward_backward(m, dec, cfg, **fb)
+            self.optimiser_step(m, dec, cfg, **op)
+        self.adam_state.copy_(state0)                       # capture does not execute, but keep the counter explicit
+        self.graph = g
+        return g
+
+    def replay(self):
+        self.graph.replay()
 
     # ------------------------------------------------------------------ read-back (tests, API parity)
     def stats(self):
