@@ -178,3 +178,89 @@ def test_loss_gradient_matches_oracle(hh):
     hh.hh_loss(n, p(sp), p(z), p(dd), ctypes.c_float(st["w_fs"]), ctypes.c_float(st["w_sdf"]), ctypes.c_float(two_n),
                ctypes.c_float(1.0), ctypes.c_float(10000.0), ctypes.c_float(0.3), ctypes.c_float(50.0), p(ds), p(fr), p(sm))
     np.testing.assert_allclose(ds, dsdf[rr, ss], rtol=1e-6, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------
+# edge cases of the reference kernels (SURVEY 4 list): hand-built octrees, degenerate rays
+# ------------------------------------------------------------------------------------------------
+def _tiny_tree(vox):
+    oc = O.Octree(); oc.init(256 * 256 * 4, 16, 0.2); oc.insert(np.asarray(vox, np.int32))
+    v, c, f = oc.get_centres_and_children()
+    return O.grid_features(v, c, 0.2)
+
+
+def _edge_rays():
+    base = np.array([10000, 10000, 10000], np.float32) * np.float32(0.2)
+    o, d = [], []
+    c0 = base + np.float32(0.1)                                      # centre of voxel (10000,10000,10000)
+    o.append(c0 + [-1.0, 0, 0]); d.append([1, 0, 0])               # axis-parallel through the centre (dy = dz = 0 -> inf/NaN slabs)
+    o.append(c0 + [0, -1.0, 0]); d.append([0, 1, 0])
+    o.append(c0.copy()); d.append([0.6, 0.64, 0.48])               # origin INSIDE the voxel (t_min = 0)
+    o.append(c0 + [-1.0, 0.1, 0]); d.append([1, 0, 0])             # exactly along a voxel face (y = face plane)
+    o.append(c0 + [-1.0, 0.1, 0.1]); d.append([1, 0, 0])           # exactly along a voxel edge
+    o.append(c0 + [-1.0, -1.0, -1.0]); d.append(np.ones(3) / np.sqrt(3))     # through the diagonal / corners
+    o.append(c0 + [-1.0, 0, 0]); d.append([-1, 0, 0])              # pointing away: no hit
+    o.append(c0 + [-1.0, 5.0, 0]); d.append([1, 0, 0])             # parallel miss
+    o.append(c0 + [-1.0, 0.05, 0.02]); d.append([1, 1e-4, -2e-4])  # grazing, nearly parallel
+    o.append(c0 + [30.0, 0.03, 0.01]); d.append([-1, 0, 0])        # far origin, reversed direction
+    o = np.array(o, np.float32); d = np.array(d, np.float32)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    return o, d
+
+
+@pytest.mark.parametrize("vox", [
+    [[10000, 10000, 10000]],                                                         # single voxel
+    [[10000 + i, 10000 + j, 10000 + k] for i in range(2) for j in range(2) for k in range(2)],   # 2x2x2 block
+    [[10000 + i, 10000, 10000] for i in range(30)],                                  # a row of 30: > 20 hits along +x
+])
+def test_intersect_edge_cases_bit_exact(hh, vox):
+    centres, structure = _tiny_tree(vox)
+    o, d = _edge_rays()
+    N = len(o)
+    with np.errstate(all="ignore"):
+        oi, o0, o1, hits = O.ray_intersect(o, d, centres, structure, 0.2, 50.0)
+    idx = np.zeros((N, 20), np.int32); t0 = np.zeros((N, 20), np.float32); t1 = np.zeros((N, 20), np.float32); cnt = np.zeros(N, np.int32)
+    hh.hh_ray_intersect(N, p(o), p(d), p(centres), p(structure), ctypes.c_float(0.2), ctypes.c_float(50.0), p(idx), p(t0), p(t1), p(cnt))
+    Hm = oi.shape[1]
+    assert np.array_equal(cnt > 0, hits)
+    assert np.array_equal(idx[:, :Hm], oi) and np.array_equal(t0[:, :Hm], o0) and np.array_equal(t1[:, :Hm], o1)
+    if len(vox) == 30:
+        assert cnt.max() == 20                                                       # the hard-coded cap (B2)
+    if len(vox) == 1:
+        assert hits[0] and hits[2] and not hits[6] and not hits[7]
+        assert o0[2, 0] == 0.0                                                       # origin inside: t_min clamps to 0
+
+
+def test_sampler_edge_cases_bit_exact(hh):
+    """zero-length intersections, a single hit, many hits, tiny and huge step counts"""
+    md = np.float32(50)
+    rows = [
+        ([5], [1.0], [1.2]),                                         # one interval
+        ([5, 6], [1.0, 1.2], [1.2, 1.2]),                            # zero-length second interval (grazing corner)
+        ([5, 6, 7], [1.0, 1.0, 1.3], [1.0, 1.3, 1.35]),              # zero-length FIRST interval, tie in t_min
+        (list(range(20)), list(np.arange(20) * 0.2 + 2), list(np.arange(20) * 0.2 + 2.2)),   # 20 contiguous intervals
+        ([9], [3.0], [3.0000002]),                                    # one-ulp interval
+        ([3, 4], [0.0, 0.5], [0.4, 7.5]),                             # origin inside + one long interval (many steps)
+    ]
+    R = len(rows)
+    idx = -np.ones((R, 20), np.int32); t0 = np.full((R, 20), md, np.float32); t1 = np.full((R, 20), md, np.float32)
+    for i, (a, b, c) in enumerate(rows):
+        idx[i, :len(a)] = a; t0[i, :len(a)] = b; t1[i, :len(a)] = c
+    P = 20
+    for step, tail in ((0.1, 0), (0.04, 0), (0.1, 1)):
+        noise = O.hash_noise(11, np.arange(R), 4096)
+        with np.errstate(all="ignore"):
+            s_idx, s_dep, s_dst = O.ray_sample(idx, t0, t1, step, noise=noise, tail_mode=tail)
+        S = s_idx.shape[1]
+        cap = S + 4
+        g_idx = -np.ones((R, cap), np.int32); g_dep = np.full((R, cap), 80, np.float32); g_dst = np.zeros((R, cap), np.float32)
+        cnt = np.zeros(R, np.int32)
+        ids = np.arange(R, dtype=np.uint32)
+        hh.hh_sample(R, p(idx), p(t0), p(t1), P, ctypes.c_float(step), 11, 1, tail, p(ids), cap, p(g_idx), p(g_dep), p(g_dst), p(cnt))
+        assert cnt.max() == S
+        assert np.array_equal(g_idx[:, :S], s_idx) and np.array_equal(g_dep[:, :S], s_dep) and np.array_equal(g_dst[:, :S], s_dst)
+        valid = s_idx != -1
+        assert (np.diff(np.where(valid, s_dep, np.inf), axis=1)[valid[:, 1:]] >= 0).all()      # depths monotone along a ray
+        if tail == 1:                                                                   # "fixed" sampler covers every interval fully
+            span = ((t1 - t0) * (idx != -1)).sum(1)
+            np.testing.assert_allclose(s_dst.sum(1), span, rtol=0, atol=2e-5)

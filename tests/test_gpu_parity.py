@@ -383,3 +383,76 @@ def test_intersect_cap_and_overflow_paths(nl):
     assert np.array_equal(np.where(live, eng.hit_idx[:n, :Hm].cpu().numpy(), -1), oi)
     assert np.array_equal(np.where(live, eng.hit_t0[:n, :Hm].cpu().numpy(), np.float32(50)), o0)
     assert np.array_equal(np.where(live, eng.hit_t1[:n, :Hm].cpu().numpy(), np.float32(50)), o1)
+
+
+@pytest.mark.parametrize("vox_kind", ["single", "block", "row30"])
+def test_fused_intersect_and_sampler_edge_cases(nl, vox_kind):
+    """Hand-built octrees and degenerate rays (axis-parallel, origin inside a voxel, along faces/edges/corners,
+    pointing away, > 20 hits): the fused HIP intersect + sampler must equal the oracle bit for bit."""
+    import test_device_math_host as T
+    P, ops, L = nl["P"], nl["ops"], nl["L"]
+    vox = {"single": [[10000, 10000, 10000]],
+           "block": [[10000 + i, 10000 + j, 10000 + k] for i in range(2) for j in range(2) for k in range(2)],
+           "row30": [[10000 + i, 10000, 10000] for i in range(30)]}[vox_kind]
+    oc = O.Octree(); oc.init(256 * 256 * 4, 16, 0.2); oc.insert(np.asarray(vox, np.int32))
+    v, c, f = oc.get_centres_and_children()
+    centres, structure = O.grid_features(v, c, 0.2)
+    o, d = T._edge_rays()
+    n = len(o)
+    with np.errstate(all="ignore"):
+        oi, o0, o1, hits = O.ray_intersect(o, d, centres, structure, 0.2, 50.0)
+    m = P.MapDevice(centres, structure, f, np.zeros(len(centres), np.int32), np.zeros((1, 16), np.uint16), 0.2)
+    eng = P.SdfEngine(max_rays=n, samples_per_ray_cap=256, max_frames=16)
+    poses = np.concatenate([o, np.zeros_like(o)], 1)                 # one frame per ray: its own origin, identity rotation
+    eng.set_rays(d, np.ones_like(d), np.ones(n, np.float32), np.arange(n, dtype=np.int32)); eng.set_poses(poses, [0] * n)
+    cfg = P.IterConfig(step_size=0.04, noise_seed=11)
+    d0 = O.decoder_init(0)
+    dec = P.DecoderDevice(d0.W1, d0.b1, d0.W2, d0.b2, d0.W3, d0.b3)
+    eng.forward_only(m, dec, cfg)
+    st = eng.stats()
+    hc = eng.hit_count[:n].cpu().numpy()
+    Hm = oi.shape[1]
+    assert np.array_equal(hc > 0, hits) and st["R"] == int(hits.sum()) and st["H"] == Hm
+    live = np.arange(Hm)[None, :] < hc[:, None]
+    assert np.array_equal(np.where(live, eng.hit_idx[:n, :Hm].cpu().numpy(), -1), oi)
+    assert np.array_equal(np.where(live, eng.hit_t0[:n, :Hm].cpu().numpy(), np.float32(50)), o0)
+    assert np.array_equal(np.where(live, eng.hit_t1[:n, :Hm].cpu().numpy(), np.float32(50)), o1)
+    hr = np.nonzero(hits)[0]
+    with np.errstate(all="ignore"):
+        s_idx, s_dep, s_dst = O.ray_sample(oi[hr], o0[hr], o1[hr], 0.04, noise=O.hash_noise(11, hr, 4096))
+    r = eng.export_render()
+    assert np.array_equal(r["valid_mask"], s_idx != -1)
+    assert np.array_equal(r["z_vals"], s_dep)
+    assert np.isfinite(r["sdf"]).all()
+
+
+def test_hipgraph_replay_matches_eager(nl, golden_dir):
+    """The captured launch sequence (forward+backward+Adam, device-side step counter) replayed 3x gives the same
+    pose / decoder trajectory as 3 eager iterations (embedding atomics are order-nondeterministic: tolerance)."""
+    g = np.load(os.path.join(golden_dir, "map_1f_3it.npz"))
+    outs = {}
+    for mode in ("eager", "graph"):
+        sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]))
+        sc["ms"].id2row = g["id_table"].copy()
+        masks = H.unpack_masks(g["masks"], len(sc["points"]))
+        dec_np = O.decoder_init(int(g["seed"]))
+        m, dec, eng = make_engine(nl, sc, dec_np, int(masks[0][0].sum()))
+        cfgP = nl["P"].IterConfig(step_size=float(g["step_size"]))
+        fr = O.select_rays(sc["points"], sc["cos"], g["poses0"][0].copy(), masks[0][0])
+        eng.set_rays(fr.rays_d, fr.points, fr.cos); eng.set_poses(fr.pose[None], [1])
+        eng.begin_call(m, dec)
+        if mode == "graph":
+            eng.capture_iteration(m, dec, cfgP, train_decoder=True)
+        for it in range(3):
+            if mode == "graph":
+                eng.replay()
+            else:
+                eng.forward_backward(m, dec, cfgP, train_decoder=True)
+                eng.optimiser_step(m, dec, cfgP)
+        torch.cuda.synchronize()
+        outs[mode] = (eng.pose6[0].cpu().numpy(), dec.params.cpu().numpy(), m.emb_bits().copy(), int(eng.adam_state[0].item()))
+    assert outs["eager"][3] == outs["graph"][3] == 3                      # device step counter advanced once per replay
+    np.testing.assert_allclose(outs["graph"][0], outs["eager"][0], rtol=0, atol=2e-6)
+    d = np.abs(outs["graph"][1] - outs["eager"][1])
+    assert (d > 5e-5).mean() < 2e-3
+    assert (outs["graph"][2] != outs["eager"][2]).mean() < 5e-3
