@@ -97,6 +97,10 @@ int nl_gather_trilinear(const void* loss_scalars, const int* s_vox, const float*
                         const float* centres, const int* vertex_rows, const void* emb_bf16, float voxel_size,
                         float* X, int nblocks, void* stream);
 
+/* get_features on explicit world points with their voxel ids (get_scores / eval_points, render_helpers.py:96-188) */
+int nl_gather_points(int P, const float* xyz, const int* vox, const float* centres, const int* vertex_rows, const void* emb_bf16,
+                     float voxel_size, float* X, void* stream);
+
 /* Decoder forward (src/variations/lidar.py:109-131) + Criterion gradient (src/criterion.py:59-100) +
  * decoder backward (autograd of render_helpers.py:422).  params = decoder block, W2T = transposed W2.
  * Outputs sdf[P], dsdf[P], dX[P,16]; with train_decoder: per-workgroup weight-gradient slabs

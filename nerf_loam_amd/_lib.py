@@ -50,6 +50,7 @@ _SIGS = {
     "nl_sample_rays": ([_I, _I] + [_P] * 8 + [_F, _F, _F, _U, _I, _I, _I] + [_P, _P, _P, _I] + [_P] * 5, _I),
     "nl_loss_finalize": ([_P, _P, _F, _F, _F, _F, _I, _P], _I),
     "nl_gather_trilinear": ([_P] * 7 + [_I] + [_P] * 3 + [_F, _P, _I, _P], _I),
+    "nl_gather_points": ([_I] + [_P] * 5 + [_F, _P, _P], _I),
     "nl_decoder_fwd_bwd": ([_P] * 13 + [_I, _I, _P, _P], _I),
     "nl_decoder_wgrad2": ([_P] * 6 + [_I, _P], _I),
     "nl_decoder_forward": ([_P, _P, _P, _I, _P, _I, _P], _I),

@@ -85,6 +85,35 @@ __global__ __launch_bounds__(NL_FIELD_THREADS) void k_gather_trilinear(FieldArgs
     }
 }
 
+// get_features on explicit points (mesh-time get_scores / eval_points, render_helpers.py:96-188): xyz[P,3] world
+// positions with their voxel ids -> X[P,16].  Same arithmetic as k_gather_trilinear, no ray bookkeeping.
+__global__ __launch_bounds__(NL_FIELD_THREADS) void k_gather_points(int P, const float* __restrict__ xyz, const int* __restrict__ vox,
+                                                                    const float* __restrict__ centres, const int* __restrict__ vertex_rows,
+                                                                    const uint16_t* __restrict__ emb, float voxel_size, float* __restrict__ X)
+{
+    const int half = threadIdx.x & 1;
+    for (int s = (blockIdx.x * NL_FIELD_THREADS + threadIdx.x) >> 1; s < P; s += (gridDim.x * NL_FIELD_THREADS) >> 1) {
+        const int v = vox[s];
+        float x[3], c[3], p[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { x[i] = xyz[3 * (size_t)s + i]; c[i] = centres[3 * (size_t)v + i]; }
+        nl_trilinear_p(x, c, voxel_size, p);
+        float w[8]; nl_trilinear_w(p, w);
+        const int4 r0 = *reinterpret_cast<const int4*>(vertex_rows + 8 * (size_t)v);
+        const int4 r1 = *reinterpret_cast<const int4*>(vertex_rows + 8 * (size_t)v + 4);
+        const int rows[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float e[8]; load_emb8(emb, rows[k], half, e);
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) f[ch] = f[ch] + w[k] * e[ch];
+        }
+        float4* o = reinterpret_cast<float4*>(X + (size_t)s * NL_C + 8 * half);
+        o[0] = make_float4(f[0], f[1], f[2], f[3]); o[1] = make_float4(f[4], f[5], f[6], f[7]);
+    }
+}
+
 // backward: dE[row_k] += bf16(w_k * dX)   (fp32 accumulation of bf16-rounded contributions, then one
 // bf16 rounding in the optimiser = torch's CUDA embedding_dense_backward semantics), and
 // dL/dx = (1/vs) * d/dp sum_k w_k <e_k, dX>  ->  dt += dx, dR += depth * dx (x) d_sensor.
@@ -267,6 +296,18 @@ int nl_gather_trilinear(const void* loss_scalars, const int* s_vox, const float*
     if (rc != NL_OK || !X || nblocks <= 0) return NL_ERR_INVALID_ARG;
     a.X = X;
     hipLaunchKernelGGL(k_gather_trilinear, dim3(nblocks), dim3(NL_FIELD_THREADS), 0, (hipStream_t)stream, a);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+int nl_gather_points(int P, const float* xyz, const int* vox, const float* centres, const int* vertex_rows, const void* emb,
+                     float voxel_size, float* X, void* stream)
+{
+    if (P < 0 || !xyz || !vox || !centres || !vertex_rows || !emb || !X) return NL_ERR_INVALID_ARG;
+    if (P == 0) return NL_OK;
+    const int nb = nl_div_up((long long)P * 2, NL_FIELD_THREADS);
+    hipLaunchKernelGGL(k_gather_points, dim3(nb < 4096 ? nb : 4096), dim3(NL_FIELD_THREADS), 0, (hipStream_t)stream, P, xyz, vox, centres,
+                       vertex_rows, (const uint16_t*)emb, voxel_size, X);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

@@ -81,6 +81,11 @@ def gather_trilinear(loss_scalars, s_vox, s_depth, s_ray, rays_d_world, frame_id
                                       int(nblocks), stream_ptr()), "nl_gather_trilinear")
 
 
+def gather_points(xyz, vox, centres, vertex_rows, emb, voxel_size, X):
+    check(L.lib().nl_gather_points(xyz.shape[0], ptr(xyz), ptr(vox), ptr(centres), ptr(vertex_rows), ptr(emb), float(voxel_size), ptr(X),
+                                   stream_ptr()), "nl_gather_points")
+
+
 def decoder_fwd_bwd(loss_scalars, X, params, W2T, s_ray, s_depth, cos_gt, gt_dist, sdf, dsdf, dX, partials, relu2_mask, nslabs,
                     train_decoder, counters):
     check(L.lib().nl_decoder_fwd_bwd(ptr(loss_scalars), ptr(X), ptr(params), ptr(W2T), ptr(s_ray), ptr(s_depth), ptr(cos_gt), ptr(gt_dist),

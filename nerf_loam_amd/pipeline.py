@@ -98,7 +98,7 @@ class MapDevice:
         return self.emb.cpu().numpy().view(np.uint16)
 
     @classmethod
-    def from_tensors(cls, centres, structure, vertex_idx, id2row, emb_bf16, voxel_size, device="cuda"):
+    def from_tensors(cls, centres, structure, vertex_idx, id2row, emb_bf16, voxel_size, device="cuda", traversal=True):
         """Build from the reference's `map_states` tensors.  `emb_bf16` is the caller's bfloat16 CUDA parameter:
         it is ALIASED (viewed as int16 bit patterns), so the kernels update it in place like the reference's
         optimiser does.  `id2row` is the node-id -> embedding-row table (any [>=n] or [>=n,1] int tensor)."""
@@ -109,7 +109,7 @@ class MapDevice:
         self.structure = structure.detach().to(dev, torch.int32).contiguous()
         n = self.centres.shape[0]
         vi = vertex_idx.detach().to(dev).long()
-        table = id2row.detach().reshape(-1)[:max(n, 1)].to(dev).long() if id2row.numel() < (1 << 28) else None
+        table = id2row.detach().reshape(-1).to(dev).long() if id2row.numel() < (1 << 28) else None
         if table is None:                                   # the reference's 2e9-row host table: gather on its device
             rows = id2row.reshape(-1)[vi.clamp(min=0).cpu()].to(dev).long()
         else:
@@ -118,8 +118,9 @@ class MapDevice:
         if emb_bf16.dtype != torch.bfloat16 or not emb_bf16.is_cuda:
             raise L.NerfLoamHipError("voxel_vertex_emb must be a CUDA bfloat16 tensor")
         self.emb = emb_bf16.detach().view(torch.int16)
-        self.blk_ids, self.blk_hdr = pack_children_blocks(self.centres, self.structure)
-        self.root_side = int(self.structure[0, 8])
+        if traversal:                                      # per-voxel subsets (mesh-time queries) carry no usable tree
+            self.blk_ids, self.blk_hdr = pack_children_blocks(self.centres, self.structure)
+            self.root_side = int(self.structure[0, 8])
         self.n_nodes, self.n_rows = n, self.emb.shape[0]
         return self
 

@@ -160,3 +160,32 @@ def render_rays(rays_o, rays_d, map_states, sdf_network, step_size, voxel_size, 
            "ray_mask": torch.from_numpy(r["ray_mask"]).to(device).view(1, -1), "valid_mask": torch.from_numpy(r["valid_mask"]).to(device),
            "sampled_xyz": m.centres[eng.s_vox[:P].long()], "_engine": eng, "_cfg": cfg}
     return out
+
+
+@torch.no_grad()
+def get_scores(sdf_network, map_states, voxel_size, bits=8):
+    """Dense SDF grid of every voxel passed in map_states (mesh extraction, reference render_helpers.py:96-153):
+    res^3 points on linspace(-0.5, 0.5, res)^3 * voxel_size around each voxel centre -> [n_voxels, res, res, res, 1]
+    on the host, like the reference returns.  One gather + one MFMA forward launch per 10 000-voxel chunk."""
+    from . import ops
+    emb = map_states["voxel_vertex_emb"]
+    device = emb.device
+    m = MapDevice.from_tensors(map_states["voxel_center_xyz"], map_states["voxel_structure"], map_states["voxel_vertex_idx"],
+                               map_states["voxel_id2embedding_id"], emb, voxel_size, device, traversal=False)
+    dec = _decoder_device(sdf_network, device)
+    res = bits
+    lin = torch.linspace(-0.5, 0.5, res)
+    xx, yy, zz = torch.meshgrid(lin, lin, lin, indexing="ij")
+    offs = (torch.stack([xx, yy, zz], dim=-1).float().to(device) * voxel_size).reshape(1, -1, 3)
+    n = m.centres.shape[0]
+    out = []
+    for i in range(0, n, 10000):
+        c = m.centres[i:i + 10000]
+        xyz = (offs + c.unsqueeze(1)).reshape(-1, 3).contiguous()
+        vox = torch.arange(i, i + c.shape[0], device=device, dtype=torch.int32)[:, None].expand(-1, res ** 3).reshape(-1).contiguous()
+        X = torch.empty(xyz.shape[0], L.NL_C, dtype=torch.float32, device=device)
+        ops.gather_points(xyz, vox, m.centres, m.vertex_rows, m.emb, voxel_size, X)
+        sdf = torch.empty(xyz.shape[0], dtype=torch.float32, device=device)
+        ops.decoder_forward(X, dec.params, dec.W2T, xyz.shape[0], sdf, L.lib().nl_decoder_grid_hint())
+        out.append(sdf.reshape(-1, res ** 3, 1).cpu())
+    return torch.cat(out, 0).view(-1, res, res, res, 1)

@@ -75,3 +75,30 @@ def test_mapping_then_tracking_like_the_reference_loop():
     assert out.pose.data.shape == (6,) and torch.isfinite(out.pose.data).all()
     assert err1 < 0.6 * err0, (err0, err1)                              # pulled back towards the true pose
     assert 0.9 < float(out.hit_ratio) <= 1.0
+
+
+def test_get_scores_matches_oracle():
+    """mesh-time dense SDF grid (reference render_helpers.get_scores): HIP gather + decoder forward vs the oracle"""
+    from nerf_loam_amd.decoder import Decoder
+    from nerf_loam_amd.render_helpers import get_scores
+    from oracle import oracle as O
+    sc = H.build_oracle_scene(64, 16, 21)
+    ms = sc["ms"]
+    surf = np.nonzero(ms.vertex_idx[:, 0] >= 0)[0][:300]                       # SURFACE voxels only, like the mesher passes
+    d0 = O.decoder_init(21)
+    dec = Decoder().cuda()
+    dec.load_flat(torch.from_numpy(np.concatenate([a.reshape(-1) for a in (d0.W1, d0.b1, d0.W2, d0.b2, d0.W3, d0.b3)])).cuda())
+    emb = torch.from_numpy(O.bf16_to_f32(ms.emb)).to(torch.bfloat16).cuda()
+    states = {"voxel_vertex_idx": torch.from_numpy(ms.vertex_idx[surf]), "voxel_center_xyz": torch.from_numpy(ms.centres[surf]),
+              "voxel_structure": torch.from_numpy(ms.structure[surf]), "voxel_vertex_emb": emb,
+              "voxel_id2embedding_id": torch.from_numpy(ms.id2row)}
+    res = 4
+    got = get_scores(dec, states, 0.2, bits=res).numpy()
+    assert got.shape == (len(surf), res, res, res, 1)
+    lin = np.linspace(-0.5, 0.5, res, dtype=np.float32)
+    offs = (np.stack(np.meshgrid(lin, lin, lin, indexing="ij"), -1).reshape(-1, 3) * np.float32(0.2)).astype(np.float32)
+    xyz = (ms.centres[surf][:, None, :] + offs[None]).reshape(-1, 3).astype(np.float32)
+    vox = np.repeat(surf, res ** 3)
+    feats, _ = O.trilinear_forward(xyz, vox, ms.centres, ms.vertex_rows(), ms.emb, 0.2)
+    ref, _ = O.decoder_forward(feats, d0)
+    assert np.abs(got.reshape(-1) - ref).max() < 1e-5
