@@ -103,7 +103,6 @@ int nl_gather_points(int P, const float* xyz, const int* vox, const float* centr
 
 /* Decoder forward (src/variations/lidar.py:109-131) + Criterion gradient (src/criterion.py:59-100) +
  * decoder backward (autograd of render_helpers.py:422).  params = decoder block, W2T = transposed W2.
- * nslabs = persistent workgroups (variant 0: #CUs, variant 1: 2 x #CUs).
  * Outputs sdf[P], dsdf[P], dX[P,16]; with train_decoder: per-workgroup weight-gradient slabs
  * partials[nslabs][NL_DEC_PARAMS] (all but the W2 block; nl_decoder_wgrad2 adds that; sum the slabs with
  * nl_reduce_partials) and relu2_mask[ceil(P/64)][512] scratch (one 32-bit ReLU word per tile and thread). */
@@ -116,12 +115,7 @@ int nl_decoder_wgrad2(const void* loss_scalars, const float* X, const float* par
                       float* partials, int nslabs, void* stream);
 /* forward only: Decoder.get_values on a dense batch (mesh-time get_scores, render_helpers.py:96-153) */
 int nl_decoder_forward(const float* X, const float* params, const float* W2T, int P, float* sdf, int nblocks, void* stream);
-int nl_reduce_partials(const float* partials, int nslabs, int nslabs_w2, int n, float* out, void* stream);
-/* decoder tiling variant: 0 = 64-sample tiles / 1 workgroup per CU (default), 1 = 32-sample tiles / 2 workgroups per CU (experimental, not faster) */
-int nl_decoder_set_variant(int v);
-int nl_decoder_get_variant(void);
-/* variant 1: start offset in cycles between the two workgroups sharing a CU (default 29000; 0 = off) */
-int nl_decoder_set_stagger(int cycles);
+int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, void* stream);
 int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream);
 
 /* backward of get_features: embedding gradient (fp32 accumulation of bf16-rounded contributions, the

@@ -54,10 +54,7 @@ _SIGS = {
     "nl_decoder_fwd_bwd": ([_P] * 13 + [_I, _I, _P, _P], _I),
     "nl_decoder_wgrad2": ([_P] * 6 + [_I, _P], _I),
     "nl_decoder_forward": ([_P, _P, _P, _I, _P, _I, _P], _I),
-    "nl_reduce_partials": ([_P, _I, _I, _I, _P, _P], _I),
-    "nl_decoder_set_variant": ([_I], _I),
-    "nl_decoder_get_variant": ([], _I),
-    "nl_decoder_set_stagger": ([_I], _I),
+    "nl_reduce_partials": ([_P, _I, _I, _P, _P], _I),
     "nl_decoder_transpose_w2": ([_P, _P, _P], _I),
     "nl_trilinear_bwd": ([_P] * 8 + [_I] + [_P] * 3 + [_F] + [_P] * 3 + [_I, _P], _I),
     "nl_unpack_samples": ([_P] * 6 + [_I] + [_P] * 4, _I),
@@ -96,11 +93,6 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = res
-        if os.environ.get("NL_DECODER_VARIANT"):          # A/B switch for measurements (default: the library's own default)
-            if L.nl_decoder_set_variant(int(os.environ["NL_DECODER_VARIANT"])) != 0:
-                raise NerfLoamHipError("NL_DECODER_VARIANT must be 0 or 1")
-        if os.environ.get("NL_DECODER_STAGGER"):
-            L.nl_decoder_set_stagger(int(os.environ["NL_DECODER_STAGGER"]))
         _lib = L
     return _lib
 

@@ -61,7 +61,6 @@ struct DecArgs {
     unsigned* relu2_mask;       // [tiles][512] one word per (tile, thread): that lane's 32 ReLU bits of H2 (train only)
     double* dcounters;          // loss sums
     long long* dbg;             // optional [16 tiles][16] s_memtime stamps of workgroup 0 / thread 0 (profiling aid)
-    int stagger;                // k_decoder32: start delay (cycles) of the second workgroup on each CU
 };
 
 #define DBG_STAMP(slot)                                                                          \
@@ -356,336 +355,6 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
     }
 }
 
-// =============================================================================================
-// k_decoder32: the same fused forward + loss + backward on 32-SAMPLE tiles with 256-thread workgroups, TWO workgroups
-// per CU (77 KB LDS each).  One 64-sample workgroup per CU leaves the matrix pipe idle during every epilogue / barrier
-// phase (measured: MFMA busy 77.6 %); two independent workgroups drift apart, so one's serial phases run under the
-// other's MFMA loops.  Each of the 4 waves owns 64 output columns (two 32x32 tiles on the same 32 rows: one A operand
-// from LDS feeds both), W1 lives in registers (32 values per lane), W2 streams from L2 as before.
-// =============================================================================================
-// LICM hoists every "base + constant" LDS address out of the persistent tile loop into its own VGPR (dozens of them);
-// laundering the base through an empty asm inside the loop keeps ONE base register and lets the constants fold into the
-// ds_read/ds_write offset fields.
-__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
-#define D32_RR(r) (((r) & 3) + 8 * ((r) >> 2))          // row of accumulator register r within a half-wave (+ 4*lh)
-
-// Two workgroups that share a CU start in lock-step and - with the matrix pipe arbitrated fairly between their waves -
-// STAY in lock-step: both hit their serial phases (epilogues, loss, LDS round trips) at the same time and the pipe idles.
-// The second arrival on each CU therefore waits half a tile period once, at kernel start; the offset persists, and from
-// then on one workgroup's serial phases run under the other's GEMM loops.
-__device__ unsigned g_cu_arrivals[1024];
-__device__ __forceinline__ unsigned cu_key()
-{
-    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID: cu_id[11:8] sh_id[12] se_id[14:13]
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);      // HW_REG_XCC_ID[3:0]
-    return ((xcc & 7u) << 7) | (((hw >> 13) & 3u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
-}
-__device__ __forceinline__ void stagger_second_workgroup(int cycles)
-{
-    if (threadIdx.x == 0) {
-        const unsigned slot = atomicAdd(&g_cu_arrivals[cu_key()], 1u);
-        if (slot & 1u) {
-            const long long t0 = __builtin_amdgcn_s_memtime();
-            while (__builtin_amdgcn_s_memtime() - t0 < cycles) __builtin_amdgcn_s_sleep(16);
-        }
-    }
-}
-
-#define D32_M 32
-#define D32_THREADS 256
-#define D32_KP 8                                        // B-operand prefetch depth (k-pairs): covers an L2 hit with ONE wave per SIMD in the loop
-#define T_H1 0
-#define T_D (T_H1 + D32_M * LDH)
-#define T_X (T_D + D32_M * LDH)
-#define T_PX (T_X + D32_M * LDX)
-#define T_S (T_PX + 4 * D32_M * LDX)
-#define T_DS (T_S + D32_M)
-#define T_TOTAL (T_DS + D32_M)
-
-template <int KP>                                        // k-pairs per prefetch stage: B operands run 2*KP MFMAs (128*KP cycles) ahead
-__device__ __forceinline__ void gemm256_2col(i32x4 rsrc, int voff_bytes, const float* ap, f32x16& c0, f32x16& c1)
-{
-    // Both operand streams are software-pipelined one stage ahead: B from L2 (buffer loads) AND A from LDS.  With two
-    // workgroups per CU a wave is often alone on its SIMD, so an LDS read issued right before its MFMA would leave the
-    // matrix pipe idle for the whole LDS latency every few instructions.
-    constexpr int RB = 2 * NL_W * 4;
-    float bA[2 * KP], bB[2 * KP], aA[KP], aB[KP];
-#pragma unroll
-    for (int i = 0; i < KP; ++i) { bA[2 * i] = bload(rsrc, voff_bytes, i * RB); bA[2 * i + 1] = bload(rsrc, voff_bytes + 128, i * RB); }
-#pragma unroll
-    for (int i = 0; i < KP; ++i) aA[i] = ap[2 * i];
-#pragma unroll 1
-    for (int g = 0; g < NL_W / 2; g += 2 * KP) {
-        const int so = g * RB;
-#pragma unroll
-        for (int i = 0; i < KP; ++i) { bB[2 * i] = bload(rsrc, voff_bytes, so + (KP + i) * RB); bB[2 * i + 1] = bload(rsrc, voff_bytes + 128, so + (KP + i) * RB); }
-#pragma unroll
-        for (int i = 0; i < KP; ++i) aB[i] = ap[2 * (g + KP + i)];
-#pragma unroll
-        for (int i = 0; i < KP; ++i) { c0 = MFMA32(aA[i], bA[2 * i], c0); c1 = MFMA32(aA[i], bA[2 * i + 1], c1); }
-        if (g + 2 * KP < NL_W / 2) {
-#pragma unroll
-            for (int i = 0; i < KP; ++i) { bA[2 * i] = bload(rsrc, voff_bytes, so + (2 * KP + i) * RB); bA[2 * i + 1] = bload(rsrc, voff_bytes + 128, so + (2 * KP + i) * RB); }
-#pragma unroll
-            for (int i = 0; i < KP; ++i) aA[i] = ap[2 * (g + 2 * KP + i)];
-        }
-#pragma unroll
-        for (int i = 0; i < KP; ++i) { c0 = MFMA32(aB[i], bB[2 * i], c0); c1 = MFMA32(aB[i], bB[2 * i + 1], c1); }
-    }
-}
-
-// sum over the 32 lanes of a half-wave of 16 per-lane row values; lane l31 ends with the total of entry (l31 >> 1) & 15
-__device__ __forceinline__ float halfwave_rowsum16(const float (&v)[16], int l31)
-{
-    float v8[8], v4[4], v2[2];
-    { const bool up = (l31 & 16) != 0;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v8[i] = (up ? v[i + 8] : v[i]) + __shfl_xor(up ? v[i] : v[i + 8], 16); }
-    { const bool up = (l31 & 8) != 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v4[i] = (up ? v8[i + 4] : v8[i]) + __shfl_xor(up ? v8[i] : v8[i + 4], 8); }
-    { const bool up = (l31 & 4) != 0;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) v2[i] = (up ? v4[i + 2] : v4[i]) + __shfl_xor(up ? v4[i] : v4[i + 2], 4); }
-    const bool up = (l31 & 2) != 0;
-    float t = (up ? v2[1] : v2[0]) + __shfl_xor(up ? v2[0] : v2[1], 2);
-    return t + __shfl_xor(t, 1);
-}
-
-#define STAMP32(slot)                                                                            \
-    do { if (a.dbg && tid == 0 && tile_no < 8) a.dbg[((size_t)blockIdx.x * 8 + tile_no) * 16 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
-
-template <bool TRAIN>
-__global__ __launch_bounds__(D32_THREADS, 2) void k_decoder32(DecArgs a)
-{
-    __shared__ __attribute__((aligned(16))) float lds[T_TOTAL];
-    float* sH1 = lds + T_H1; float* sD = lds + T_D; float* sX = lds + T_X; float* sPX = lds + T_PX;
-    float* sS = lds + T_S; float* sdS = lds + T_DS;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5, l15 = lane & 15, lq = lane >> 4;
-    const int colA = 64 * w + l31, colB = colA + 32;
-    const NlLossScalars ls = *a.ls;
-    const int P = ls.P;
-    const int ntiles = (P + D32_M - 1) / D32_M;
-    const i32x4 rsW2 = make_w_rsrc(a.params + NL_OFF_W2), rsW2T = make_w_rsrc(a.W2T);
-    const float b1A = a.params[NL_OFF_B1 + colA], b1B = a.params[NL_OFF_B1 + colB];
-    const float b2A = a.params[NL_OFF_B2 + colA], b2B = a.params[NL_OFF_B2 + colB];
-    const float w3A = a.params[NL_OFF_W3 + colA], w3B = a.params[NL_OFF_W3 + colB];
-    const float b3 = a.params[NL_OFF_B3];
-    float w1b[16];                                       // register-resident W1 (phase B operands)
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-        w1b[2 * kk] = a.params[NL_OFF_W1 + colA * NL_C + 2 * kk + lh];
-        w1b[2 * kk + 1] = a.params[NL_OFF_W1 + colB * NL_C + 2 * kk + lh];
-    }
-    const float* w1i_src = a.params + NL_OFF_W1 + (64 * w + lq) * NL_C + l15;      // phase I operands: L2-resident, re-read per tile
-
-    f32x4 accW1[4];
-    float aW3A = 0.f, aW3B = 0.f, aB2A = 0.f, aB2B = 0.f, aB1A = 0.f, aB1B = 0.f, aB3 = 0.f;
-    double lossFs = 0.0, lossSdf = 0.0;
-    if (TRAIN) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) accW1[t][r] = 0.f;
-    }
-    if (tid < D32_M) sS[tid] = 0.f;
-    if (a.stagger > 0) stagger_second_workgroup(a.stagger);
-    const int xe = tid * 2, xi = xe >> 4, xc = xe & 15;
-    float2 xv = make_float2(0.f, 0.f);
-    float pz = 0.f, pd = 0.f;
-    {
-        const int row0 = blockIdx.x * D32_M;
-        if (blockIdx.x < ntiles && row0 + xi < P) xv = *reinterpret_cast<const float2*>(a.X + (size_t)(row0 + xi) * NL_C + xc);
-        if (tid < D32_M && blockIdx.x < ntiles && row0 + tid < P) {
-            const int ray = a.s_ray[row0 + tid];
-            pz = a.s_depth[row0 + tid] * a.cos_gt[ray]; pd = a.gt_dist[ray];
-        }
-    }
-    __syncthreads();
-
-    int tile_no = 0;
-    if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 128 + 15] = (long long)cu_key();
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++tile_no) {
-        const int row0 = tile * D32_M;
-        STAMP32(0);
-        // ---- A
-        sX[xi * LDX + xc] = xv.x; sX[xi * LDX + xc + 1] = xv.y;
-        const float cz = pz, cd = pd;
-        {
-            const int nrow0 = (tile + gridDim.x) * D32_M;
-            xv = make_float2(0.f, 0.f);
-            if (nrow0 + xi < P) xv = *reinterpret_cast<const float2*>(a.X + (size_t)(nrow0 + xi) * NL_C + xc);
-            if (tid < D32_M && nrow0 + tid < P) {
-                const int ray = a.s_ray[nrow0 + tid];
-                pz = a.s_depth[nrow0 + tid] * a.cos_gt[ray]; pd = a.gt_dist[ray];
-            }
-        }
-        __syncthreads();
-        STAMP32(1);
-        // ---- B: H1 = relu(X W1^T + b1)
-        {
-            f32x16 c0, c1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
-#pragma unroll
-            for (int kk = 0; kk < NL_C / 2; ++kk) {
-                const float av = sX[l31 * LDX + 2 * kk + lh];
-                c0 = MFMA32(av, w1b[2 * kk], c0); c1 = MFMA32(av, w1b[2 * kk + 1], c1);
-            }
-            float* hw = sH1 + opaque(4 * lh * LDH + colA);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                hw[D32_RR(r) * LDH] = fmaxf(c0[r] + b1A, 0.f); hw[D32_RR(r) * LDH + 32] = fmaxf(c1[r] + b1B, 0.f);
-            }
-        }
-        __syncthreads();
-        STAMP32(2);
-        // ---- C: H2, sdf partial sums
-        f32x16 h0, h1;
-        {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
-            gemm256_2col<D32_KP>(rsW2T, (lh * NL_W + colA) * 4, sH1 + l31 * LDH + lh, h0, h1);
-            STAMP32(3);
-            float v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                h0[r] = fmaxf(h0[r] + b2A, 0.f); h1[r] = fmaxf(h1[r] + b2B, 0.f);
-                v[r] = h0[r] * w3A + h1[r] * w3B;
-            }
-            const float tot = halfwave_rowsum16(v, l31);
-            if ((l31 & 1) == 0) atomicAdd(&sS[d32_row((l31 >> 1) & 15, lh)], tot);
-        }
-        __syncthreads();
-        STAMP32(4);
-        // ---- D: sdf + loss gradient
-        if (tid < D32_M) {
-            const int g = row0 + tid;
-            float ds = 0.f;
-            if (g < P) {
-                const float s = sS[tid] + b3;
-                bool f, m;
-                nl_loss_masks(cz, cd, ls.tau, ls.max_depth, &f, &m);
-                float q1, q2;
-                ds = nl_loss_grad(s, cz, cd, f, m, ls, &q1, &q2);
-                a.sdf[g] = s; a.dsdf[g] = ds;
-                lossFs += (double)q1; lossSdf += (double)q2;
-            }
-            sdS[tid] = ds; sS[tid] = 0.f;
-            if (TRAIN) aB3 += ds;
-        }
-        __syncthreads();
-        STAMP32(5);
-        // ---- E: dH2 -> LDS, ReLU mask word
-        {
-            unsigned mw = 0u;
-            float* dw = sD + opaque(4 * lh * LDH + colA);
-            const float* dsr = sdS + opaque(4 * lh);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float ds = dsr[D32_RR(r)];
-                const bool on0 = h0[r] > 0.f, on1 = h1[r] > 0.f;
-                const float g0 = on0 ? ds * w3A : 0.f, g1 = on1 ? ds * w3B : 0.f;
-                dw[D32_RR(r) * LDH] = g0; dw[D32_RR(r) * LDH + 32] = g1;
-                if (TRAIN) {
-                    aW3A = fmaf(ds, h0[r], aW3A); aW3B = fmaf(ds, h1[r], aW3B); aB2A += g0; aB2B += g1;
-                    mw |= (on0 ? (1u << r) : 0u) | (on1 ? (1u << (16 + r)) : 0u);
-                }
-            }
-            if (TRAIN) a.relu2_mask[(size_t)tile * D32_THREADS + tid] = mw;
-        }
-        __syncthreads();
-        STAMP32(6);
-        // ---- F: dH1 = (dH2 W2) * [H1 > 0]
-        f32x16 g0v, g1v;
-        {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { g0v[r] = 0.f; g1v[r] = 0.f; }
-            gemm256_2col<D32_KP>(rsW2, (lh * NL_W + colA) * 4, sD + l31 * LDH + lh, g0v, g1v);
-            STAMP32(7);
-            const float* hr = sH1 + opaque(4 * lh * LDH + colA);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                g0v[r] = hr[D32_RR(r) * LDH] > 0.f ? g0v[r] : 0.f;
-                g1v[r] = hr[D32_RR(r) * LDH + 32] > 0.f ? g1v[r] : 0.f;
-                if (TRAIN) { aB1A += g0v[r]; aB1B += g1v[r]; }
-            }
-        }
-        __syncthreads();
-        STAMP32(8);
-        // ---- H: dH1 -> LDS
-        {
-            float* dw = sD + opaque(4 * lh * LDH + colA);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { dw[D32_RR(r) * LDH] = g0v[r]; dw[D32_RR(r) * LDH + 32] = g1v[r]; }
-        }
-        float w1i[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) w1i[q] = w1i_src[4 * q * NL_C];
-        __syncthreads();
-        STAMP32(9);
-        // ---- I: dX partial over this wave's 64-deep k slab; dW1 += dH1^T X for its 64 hidden rows
-        {
-            f32x4 cx0 = {0.f, 0.f, 0.f, 0.f}, cx1 = {0.f, 0.f, 0.f, 0.f};
-            const float* ap = sD + opaque(l15 * LDH + 64 * w + lq);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) { cx0 = MFMA16(ap[4 * q], w1i[q], cx0); cx1 = MFMA16(ap[16 * LDH + 4 * q], w1i[q], cx1); }
-            float* px = sPX + opaque(w * (D32_M * LDX) + 4 * lq * LDX + l15);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { px[r * LDX] = cx0[r]; px[(16 + r) * LDX] = cx1[r]; }
-            if (TRAIN) {
-                const float* xr = sX + opaque(lq * LDX + l15);
-                const float* dr = sD + opaque(lq * LDH + 64 * w + l15);
-#pragma unroll 2
-                for (int ii = 0; ii < D32_M / 4; ++ii) {
-                    const float xb = xr[4 * ii * LDX];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        accW1[t] = MFMA16(dr[4 * ii * LDH + 16 * t], xb, accW1[t]);
-                }
-            }
-        }
-        __syncthreads();
-        STAMP32(10);
-        // ---- J: dX = sum of the four k-slab partials -> global
-        if (row0 + xi < P) {
-            const float* pr = sPX + opaque(xi * LDX + xc);
-            float2 o;
-            o.x = (pr[0] + pr[D32_M * LDX]) + (pr[2 * D32_M * LDX] + pr[3 * D32_M * LDX]);
-            o.y = (pr[1] + pr[D32_M * LDX + 1]) + (pr[2 * D32_M * LDX + 1] + pr[3 * D32_M * LDX + 1]);
-            *reinterpret_cast<float2*>(a.dX + (size_t)(row0 + xi) * NL_C + xc) = o;
-        }
-        STAMP32(11);
-        // (the next tile's phase A writes sX only; sPX / sD / sH1 are rewritten after its barriers)
-    }
-
-    if (tid < 64) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { lossFs += __shfl_xor(lossFs, off); lossSdf += __shfl_xor(lossSdf, off); }
-        if (tid == 0 && (lossFs != 0.0 || lossSdf != 0.0)) {
-            atomicAdd(&a.dcounters[NLD_FS_SQ], lossFs); atomicAdd(&a.dcounters[NLD_SDF_SQ], lossSdf);
-        }
-    }
-    if (TRAIN) {
-        float* base = a.partials + (size_t)blockIdx.x * NL_DEC_PARAMS;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                base[NL_OFF_W1 + (64 * w + 16 * t + 4 * lq + r) * NL_C + l15] = accW1[t][r];
-        aW3A += __shfl_xor(aW3A, 32); aW3B += __shfl_xor(aW3B, 32); aB2A += __shfl_xor(aB2A, 32); aB2B += __shfl_xor(aB2B, 32);
-        aB1A += __shfl_xor(aB1A, 32); aB1B += __shfl_xor(aB1B, 32);
-        if (lh == 0) {
-            base[NL_OFF_W3 + colA] = aW3A; base[NL_OFF_W3 + colB] = aW3B; base[NL_OFF_B2 + colA] = aB2A; base[NL_OFF_B2 + colB] = aB2B;
-            base[NL_OFF_B1 + colA] = aB1A; base[NL_OFF_B1 + colB] = aB1B;
-        }
-        if (tid < 64) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) aB3 += __shfl_xor(aB3, off);
-            if (tid == 0) base[NL_OFF_B3] = aB3;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // dW2 = dH2^T H1 over all samples (K = samples).  Persistent; per 64-sample tile: H1 = relu(X W1^T+b1)
 // -> LDS, dH2[i][j] = mask(i,j) ? dsdf_i * w3_j : 0 -> LDS, then 256 MFMAs per wave into the 8
@@ -694,8 +363,7 @@ __global__ __launch_bounds__(D32_THREADS, 2) void k_decoder32(DecArgs a)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2(const NlLossScalars* __restrict__ lsp, const float* __restrict__ X,
                                                                     const float* __restrict__ params, const float* __restrict__ dsdf,
-                                                                    const unsigned* __restrict__ relu2_mask, float* __restrict__ partials,
-                                                                    int mask32)
+                                                                    const unsigned* __restrict__ relu2_mask, float* __restrict__ partials)
 {
     __shared__ __attribute__((aligned(16))) float lds[2 * DEC_M * LDH + DEC_M * LDX + NL_W * NL_C + DEC_M];
     float* sH1 = lds; float* sD = lds + DEC_M * LDH; float* sX = sD + DEC_M * LDH; float* sW1 = sX + DEC_M * LDX;
@@ -718,17 +386,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2(const NlLossS
         if (tile < ntiles) {
             if (row0 + xi < P) xv = *reinterpret_cast<const float2*>(X + (size_t)(row0 + xi) * NL_C + xc);
             if (tid < DEC_M && row0 + tid < P) pds = dsdf[row0 + tid];
-            if (!mask32) {
-                pmk = relu2_mask[(size_t)tile * DEC_THREADS + tid];
-            } else {
-                // masks written by k_decoder32: [32-row tile][256 threads], bits 0-15 = column 64w'+l31, bits 16-31 = +32.
-                // this thread's column 32w+l31 lives in producer wave w>>1, low or high half by w&1; rows 0-31 / 32-63
-                // of this 64-row tile are the 32-row tiles 2*tile and 2*tile+1.
-                const int src = (w >> 1) * 64 + lane, sh = (w & 1) * 16;
-                const unsigned lo = relu2_mask[(size_t)(2 * tile) * D32_THREADS + src];
-                const unsigned hi = (2 * tile + 1) * D32_M < P ? relu2_mask[(size_t)(2 * tile + 1) * D32_THREADS + src] : 0u;
-                pmk = ((lo >> sh) & 0xFFFFu) | (((hi >> sh) & 0xFFFFu) << 16);
-            }
+            pmk = relu2_mask[(size_t)tile * DEC_THREADS + tid];
         }
     };
     prefetch(blockIdx.x);
@@ -849,15 +507,13 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
     }
 }
 
-// sum per-workgroup partial slabs: out[i] = sum_b partials[b][i]; the W2 block is written by k_decoder_wgrad2's
-// workgroups (nslabs_w2), every other parameter by the fused decoder kernel's workgroups (nslabs)
-__global__ void k_reduce_partials(const float* __restrict__ partials, int nslabs, int nslabs_w2, int n, float* __restrict__ out)
+// sum per-workgroup partial slabs: out[i] = sum_b partials[b][i]
+__global__ void k_reduce_partials(const float* __restrict__ partials, int nslabs, int n, float* __restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int nb = (i >= NL_OFF_W2 && i < NL_OFF_B2 && n == NL_DEC_PARAMS) ? nslabs_w2 : nslabs;
     float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += partials[(size_t)b * n + i];
+    for (int b = 0; b < nslabs; ++b) s += partials[(size_t)b * n + i];
     out[i] = s;
 }
 
@@ -875,20 +531,11 @@ __global__ void k_mfma_selftest(const float* A32, const float* B32, float* D32, 
 }
 
 static long long* g_dec_dbg = nullptr;
-static int g_dec_stagger = 29000;        // k_decoder32: ~half of a tile's stand-alone period
-static int g_dec_variant = 0;            // 0: 64-sample tiles, 1 workgroup per CU; 1: 32-sample tiles, 2 workgroups per CU
 
 extern "C" {
 
 /* profiling aid: device buffer of 256 int64 receiving per-phase s_memtime stamps (NULL disables) */
 int nl_decoder_set_debug_buffer(void* dbg) { g_dec_dbg = (long long*)dbg; return NL_OK; }
-
-/* decoder kernel variant: 0 = k_decoder (64-sample tiles, 512 threads, 1 workgroup/CU; default), 1 = k_decoder32 (32-sample tiles,
- * 256 threads, 2 workgroups/CU).  Both produce the same results; kept selectable for A/B measurements. */
-int nl_decoder_set_variant(int v) { if (v < 0 || v > 1) return NL_ERR_INVALID_ARG; g_dec_variant = v; return NL_OK; }
-int nl_decoder_get_variant(void) { return g_dec_variant; }
-/* start offset (cycles) between the two workgroups that share a CU in variant 1; 0 disables it (measurement aid) */
-int nl_decoder_set_stagger(int cycles) { if (cycles < 0 || cycles > 10000000) return NL_ERR_INVALID_ARG; g_dec_stagger = cycles; return NL_OK; }
 
 int nl_decoder_grid_hint(void)
 {
@@ -911,14 +558,8 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
     a.relu2_mask = relu2_mask;
     a.dcounters = (double*)(counters + NL_CNT_INTS);
     a.dbg = g_dec_dbg;
-    a.stagger = g_dec_stagger;
-    if (g_dec_variant == 1) {       // nslabs = workgroups = 2 x CUs
-        if (train_decoder) hipLaunchKernelGGL(k_decoder32<true>, dim3(nslabs), dim3(D32_THREADS), 0, (hipStream_t)stream, a);
-        else               hipLaunchKernelGGL(k_decoder32<false>, dim3(nslabs), dim3(D32_THREADS), 0, (hipStream_t)stream, a);
-    } else {
-        if (train_decoder) hipLaunchKernelGGL(k_decoder<true>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, a);
-        else               hipLaunchKernelGGL(k_decoder<false>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, a);
-    }
+    if (train_decoder) hipLaunchKernelGGL(k_decoder<true>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, a);
+    else               hipLaunchKernelGGL(k_decoder<false>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, a);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }
@@ -929,7 +570,7 @@ int nl_decoder_wgrad2(const void* loss_scalars, const float* X, const float* par
 {
     if (!loss_scalars || !X || !params || !dsdf || !relu2_mask || !partials || nslabs <= 0) return NL_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_decoder_wgrad2, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,
-                       params, dsdf, relu2_mask, partials, g_dec_variant == 1 ? 1 : 0);
+                       params, dsdf, relu2_mask, partials);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }
@@ -943,10 +584,10 @@ int nl_decoder_forward(const float* X, const float* params, const float* W2T, in
     return NL_OK;
 }
 
-int nl_reduce_partials(const float* partials, int nslabs, int nslabs_w2, int n, float* out, void* stream)
+int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, void* stream)
 {
-    if (!partials || !out || nslabs <= 0 || nslabs_w2 <= 0 || n <= 0) return NL_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_reduce_partials, dim3(nl_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, partials, nslabs, nslabs_w2, n, out);
+    if (!partials || !out || nslabs <= 0 || n <= 0) return NL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nl_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, partials, nslabs, n, out);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

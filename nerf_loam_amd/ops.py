@@ -102,8 +102,8 @@ def decoder_forward(X, params, W2T, P, sdf, nblocks):
     check(L.lib().nl_decoder_forward(ptr(X), ptr(params), ptr(W2T), int(P), ptr(sdf), int(nblocks), stream_ptr()), "nl_decoder_forward")
 
 
-def reduce_partials(partials, nslabs, nslabs_w2, n, out):
-    check(L.lib().nl_reduce_partials(ptr(partials), int(nslabs), int(nslabs_w2), int(n), ptr(out), stream_ptr()), "nl_reduce_partials")
+def reduce_partials(partials, nslabs, n, out):
+    check(L.lib().nl_reduce_partials(ptr(partials), int(nslabs), int(n), ptr(out), stream_ptr()), "nl_reduce_partials")
 
 
 def decoder_transpose_w2(params, W2T):

@@ -205,8 +205,8 @@ class SdfEngine:
         self.counters = torch.zeros(L.NL_CNT_BYTES // 4, dtype=I32, device=d)
         self.loss_scalars = torch.zeros(L.NL_LOSS_SCALARS_BYTES // 4, dtype=I32, device=d)
         # decoder partial slabs (one per persistent workgroup)
-        self.n_slabs = int(L.lib().nl_decoder_grid_hint())              # compute units: workgroups of k_decoder_wgrad2
-        self.partials = torch.zeros(2 * self.n_slabs, L.NL_DEC_PARAMS, dtype=F32, device=d)
+        self.n_slabs = int(L.lib().nl_decoder_grid_hint())
+        self.partials = torch.zeros(self.n_slabs, L.NL_DEC_PARAMS, dtype=F32, device=d)
         self.field_blocks = 4 * self.n_slabs
         self.N = 0
         self.F = 1
@@ -220,10 +220,6 @@ class SdfEngine:
         self.hook_after_count = None
         self.hook_after_backward = None
         self.timers = None       # bench: {"decoder": (start, end), "wgrad2": (start==decoder end, end)} torch.cuda.Event pairs
-
-    def dec_grid(self):
-        """persistent workgroups of the fused decoder kernel: 2 per CU for the 32-sample-tile variant, else 1"""
-        return self.n_slabs * (2 if L.lib().nl_decoder_get_variant() == 1 else 1)
 
     # ------------------------------------------------------------------ inputs
     def set_rays(self, rays_d_sensor, points_gt, cos_gt, frame_id=None):
@@ -301,14 +297,14 @@ class SdfEngine:
         if self.timers is not None:
             self.timers["decoder"][0].record()
         ops.decoder_fwd_bwd(self.loss_scalars, self.X, dec.params, dec.W2T, self.s_ray, self.s_depth, self.cos_gt, self.gt_dist,
-                            self.sdf, self.dsdf, self.dX, self.partials, self.relu2_mask, self.dec_grid(), int(train_decoder), c)
+                            self.sdf, self.dsdf, self.dX, self.partials, self.relu2_mask, self.n_slabs, int(train_decoder), c)
         if self.timers is not None:
             self.timers["decoder"][1].record()
         if train_decoder:
             ops.decoder_wgrad2(self.loss_scalars, self.X, dec.params, self.dsdf, self.relu2_mask, self.partials, self.n_slabs)
             if self.timers is not None:
                 self.timers["wgrad2"][1].record()
-            ops.reduce_partials(self.partials, self.dec_grid(), self.n_slabs, L.NL_DEC_PARAMS, dec.grad)
+            ops.reduce_partials(self.partials, self.n_slabs, L.NL_DEC_PARAMS, dec.grad)
         ops.trilinear_bwd(self.loss_scalars, self.s_vox, self.s_depth, self.s_ray, self.rays_d_world, self.rays_d_sensor, self.frame_id,
                           self.poses12, self.F, m.centres, m.vertex_rows, m.emb, m.voxel_size, self.dX,
                           self.g_emb if want_emb_grad else None, self.g_pose if want_pose_grad else None, self.field_blocks)

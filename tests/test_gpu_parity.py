@@ -173,19 +173,8 @@ def nl_split(flat):
     return DecoderDevice.split(flat)
 
 
-@pytest.fixture
-def decoder_variant(nl, request):
-    """run a test under one of the two decoder tilings (0: 64-sample tiles, 1: 32-sample tiles, 2 workgroups per CU)"""
-    lib = nl["L"].lib()
-    old = lib.nl_decoder_get_variant()
-    assert lib.nl_decoder_set_variant(request.param) == 0
-    yield request.param
-    lib.nl_decoder_set_variant(old)
-
-
-@pytest.mark.parametrize("decoder_variant", [0, 1], indirect=True)
 @pytest.mark.parametrize("case", ["map_1f_1it", "map_2f_2it_frozen"])
-def test_iteration_matches_oracle_and_golden(nl, golden_dir, case, decoder_variant):
+def test_iteration_matches_oracle_and_golden(nl, golden_dir, case):
     g = np.load(os.path.join(golden_dir, case + ".npz"))
     sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]))
     sc["ms"].id2row = g["id_table"].copy()
