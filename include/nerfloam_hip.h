@@ -113,6 +113,11 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
 /* second half of the decoder weight gradient: dW2 = dH2^T H1 into partials[slab][W2 block] (train only) */
 int nl_decoder_wgrad2(const void* loss_scalars, const float* X, const float* params, const float* dsdf, const unsigned* relu2_mask,
                       float* partials, int nslabs, void* stream);
+/* dW2 kernel selection: 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32), 1 = bf16 matrix cores on the exact
+ * formulation dW2[j][k] = w3_j * sum_i m(i,j) * (dsdf_i * H1[i][k]) with the {0,1} mask m as A operand and the fp32
+ * B operand split into three bf16 terms (exact products, fp32 accumulation; default). */
+int nl_decoder_set_wgrad2_mode(int mode);
+int nl_decoder_get_wgrad2_mode(void);
 /* forward only: Decoder.get_values on a dense batch (mesh-time get_scores, render_helpers.py:96-153) */
 int nl_decoder_forward(const float* X, const float* params, const float* W2T, int P, float* sdf, int nblocks, void* stream);
 int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, void* stream);

@@ -54,6 +54,8 @@ _SIGS = {
     "nl_decoder_fwd_bwd": ([_P] * 13 + [_I, _I, _P, _P], _I),
     "nl_decoder_wgrad2": ([_P] * 6 + [_I, _P], _I),
     "nl_decoder_forward": ([_P, _P, _P, _I, _P, _I, _P], _I),
+    "nl_decoder_set_wgrad2_mode": ([_I], _I),
+    "nl_decoder_get_wgrad2_mode": ([], _I),
     "nl_reduce_partials": ([_P, _I, _I, _P, _P], _I),
     "nl_decoder_transpose_w2": ([_P, _P, _P], _I),
     "nl_trilinear_bwd": ([_P] * 8 + [_I] + [_P] * 3 + [_F] + [_P] * 3 + [_I, _P], _I),
@@ -93,6 +95,9 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = res
+        if os.environ.get("NL_WGRAD2_MODE"):                # A/B switch for measurements (default: the library's own default)
+            if L.nl_decoder_set_wgrad2_mode(int(os.environ["NL_WGRAD2_MODE"])) != 0:
+                raise NerfLoamHipError("NL_WGRAD2_MODE must be 0 or 1")
         _lib = L
     return _lib
 

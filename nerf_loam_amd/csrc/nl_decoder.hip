@@ -442,6 +442,172 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2(const NlLossS
 }
 
 // ---------------------------------------------------------------------------------------------
+// dW2 on the bf16 matrix cores, EXACTLY.  dW2[j][k] = sum_i dH2[i][j] H1[i][k] with dH2[i][j] = m(i,j) * dsdf_i * w3_j
+// and m the 0/1 ReLU mask of H2, so
+//     dW2[j][k] = w3_j * sum_i  m(i,j) * (dsdf_i * H1[i][k]).
+// The A operand m is exactly representable in bf16, and the fp32 B operand v = dsdf_i * H1[i][k] is split into three
+// bf16 terms v = v_hi + v_mid + v_lo (8 + 8 + 8 significand bits: the split is exact), so every product the matrix
+// core forms is exact and the accumulation is fp32 - the same arithmetic class as the fp32 MFMA kernel above (a
+// different summation order, nothing else), at 3/16 of its matrix-pipe time (v_mfma_f32_32x32x16_bf16 retires
+// 16 k-steps in 32 cycles against 2 in 64).
+//
+// Layout per 64-sample tile (K = the 64 samples).  The k-slot order inside the tile is chosen so that both operands
+// come straight out of their producers' register layouts: slot = 32*sub + 16*lh + r for the sample row
+// 32*sub + d32_row(r, lh) (sub = 32-row sub-tile; lh, r = lane half and accumulator register of the 32x32 MFMA that
+// produced it).  k_decoder's saved mask word of (column j, lane half lh) then holds slots [16*lh, 16*lh+16) of sub 0
+// in its low half and of sub 1 in its high half: an A fragment (8 slots of one j) is one BYTE of a mask word,
+// expanded to 8 bf16 by a 256-entry LDS table.  H1 is rebuilt from X (K = 16, fp32 MFMA) in the same register layout,
+// so a lane packs its 16 rows of one column into 32 contiguous bytes per plane: sB[plane][column k][slot], row
+// stride 144 B (conflict-free ds_read_b128 / ds_write_b128).
+// Wave (wj = w>>1, wk = w&1) owns dW2 rows [64 wj, +64) x columns [128 wk, +128): 2 x 4 accumulators; one B
+// fragment (ds_read_b128) feeds two MFMAs.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define WX_STRIDE 144                                   // bytes per column row of a plane: 64 slots x 2 B + 16 pad
+#define WX_PLANE (NL_W * WX_STRIDE)
+#define WX_OFF_LUT (3 * WX_PLANE)
+#define WX_OFF_MASK (WX_OFF_LUT + 256 * 16)
+#define WX_OFF_X (WX_OFF_MASK + 2 * DEC_THREADS * 4)
+#define WX_OFF_DS (WX_OFF_X + DEC_M * LDX * 4)
+#define WX_TOTAL (WX_OFF_DS + DEC_M * 4)
+
+// upper halves of two fp32 registers -> one register of two bf16 (lo = a, hi = b): truncation, used on values whose
+// low 16 bits are already zero or are carried by the next split term
+__device__ __forceinline__ unsigned pack_hi16(float a, float b)
+{
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
+
+__global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLossScalars* __restrict__ lsp, const float* __restrict__ X,
+                                                                      const float* __restrict__ params, const float* __restrict__ dsdf,
+                                                                      const unsigned* __restrict__ relu2_mask, float* __restrict__ partials)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WX_TOTAL];
+    unsigned char* sB = smem;
+    uint4* sLut = reinterpret_cast<uint4*>(smem + WX_OFF_LUT);
+    unsigned* sMask = reinterpret_cast<unsigned*>(smem + WX_OFF_MASK);
+    float* sX = reinterpret_cast<float*>(smem + WX_OFF_X);
+    float* sdS = reinterpret_cast<float*>(smem + WX_OFF_DS);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int col = 32 * w + l31;                        // producer role: H1 column of this lane
+    const int wj = w >> 1, wk = w & 1;                   // consumer role: dW2 block of this wave
+    const int P = lsp->P;
+    const int ntiles = (P + DEC_M - 1) / DEC_M;
+    const float b1c = params[NL_OFF_B1 + col];
+    float w1r[NL_C / 2];
+#pragma unroll
+    for (int kk = 0; kk < NL_C / 2; ++kk) w1r[kk] = params[NL_OFF_W1 + col * NL_C + 2 * kk + lh];
+    if (tid < 256) {                                     // byte -> 8 bf16 (1.0 where the bit is set)
+        uint4 e;
+        e.x = ((tid & 1) ? 0x3F80u : 0u) | ((tid & 2) ? 0x3F800000u : 0u);
+        e.y = ((tid & 4) ? 0x3F80u : 0u) | ((tid & 8) ? 0x3F800000u : 0u);
+        e.z = ((tid & 16) ? 0x3F80u : 0u) | ((tid & 32) ? 0x3F800000u : 0u);
+        e.w = ((tid & 64) ? 0x3F80u : 0u) | ((tid & 128) ? 0x3F800000u : 0u);
+        sLut[tid] = e;
+    }
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a_][t][r] = 0.f;
+
+    const int xe = tid * 2, xi = xe >> 4, xc = xe & 15;
+    float2 xv = make_float2(0.f, 0.f); float pds = 0.f; unsigned pmk = 0u;
+    auto prefetch = [&](int tile) {
+        const int row0 = tile * DEC_M;
+        xv = make_float2(0.f, 0.f); pds = 0.f; pmk = 0u;
+        if (tile < ntiles) {
+            if (row0 + xi < P) xv = *reinterpret_cast<const float2*>(X + (size_t)(row0 + xi) * NL_C + xc);
+            if (tid < DEC_M && row0 + tid < P) pds = dsdf[row0 + tid];
+            pmk = relu2_mask[(size_t)tile * DEC_THREADS + tid];
+        }
+    };
+    prefetch(blockIdx.x);
+
+    int par = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
+        sX[xi * LDX + xc] = xv.x; sX[xi * LDX + xc + 1] = xv.y;
+        if (tid < DEC_M) sdS[tid] = pds;
+        sMask[par * DEC_THREADS + tid] = pmk;            // double-buffered: still read by slow waves of the previous tile
+        __syncthreads();
+        prefetch(tile + gridDim.x);
+        {   // producer: v = dsdf_i * relu(X W1^T + b1)[i][col], split into 3 bf16 planes, k-slot order
+            f32x16 c0, c1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < NL_C / 2; ++kk) {
+                c0 = MFMA32(sX[l31 * LDX + 2 * kk + lh], w1r[kk], c0); c1 = MFMA32(sX[(32 + l31) * LDX + 2 * kk + lh], w1r[kk], c1);
+            }
+            unsigned char* dst = sB + col * WX_STRIDE + 32 * lh;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                unsigned hi[8], mid[8], lo[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float v0, v1;
+                    {
+                        const float h0 = fmaxf((sub ? c1[2 * q] : c0[2 * q]) + b1c, 0.f), h1 = fmaxf((sub ? c1[2 * q + 1] : c0[2 * q + 1]) + b1c, 0.f);
+                        v0 = h0 * sdS[32 * sub + d32_row(2 * q, lh)]; v1 = h1 * sdS[32 * sub + d32_row(2 * q + 1, lh)];
+                    }
+                    hi[q] = pack_hi16(v0, v1);
+                    const float r0 = v0 - trunc_bf16(v0), r1 = v1 - trunc_bf16(v1);
+                    mid[q] = pack_hi16(r0, r1);
+                    const float s0 = r0 - trunc_bf16(r0), s1 = r1 - trunc_bf16(r1);
+                    lo[q] = pack_hi16(s0, s1);
+                }
+                uint4* d0 = reinterpret_cast<uint4*>(dst + 64 * sub);
+                d0[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]); d0[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+                uint4* d1 = reinterpret_cast<uint4*>(dst + 64 * sub + WX_PLANE);
+                d1[0] = make_uint4(mid[0], mid[1], mid[2], mid[3]); d1[1] = make_uint4(mid[4], mid[5], mid[6], mid[7]);
+                uint4* d2 = reinterpret_cast<uint4*>(dst + 64 * sub + 2 * WX_PLANE);
+                d2[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]); d2[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+            }
+        }
+        __syncthreads();
+        {   // consumer: 4 k-steps of 16 slots x 3 planes x 4 column tiles, each B fragment feeding both row tiles
+            const unsigned* mk = sMask + par * DEC_THREADS + l31;
+            unsigned mwd[2][2];                          // [row tile jt][producer lane half]
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) { mwd[jt][0] = mk[(2 * wj + jt) * 64]; mwd[jt][1] = mk[(2 * wj + jt) * 64 + 32]; }
+            const unsigned char* bsrc = sB + (128 * wk + l31) * WX_STRIDE + 16 * lh;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                bf16x8 af[2];
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) {
+                    const unsigned byte = (mwd[jt][s4 & 1] >> (16 * (s4 >> 1) + 8 * lh)) & 0xFFu;
+                    af[jt] = __builtin_bit_cast(bf16x8, sLut[byte]);
+                }
+#pragma unroll
+                for (int p3 = 0; p3 < 3; ++p3)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt) {
+                        const bf16x8 bf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bsrc + p3 * WX_PLANE + 32 * kt * WX_STRIDE + 32 * s4));
+                        acc[0][kt] = MFMA_BF16(af[0], bf, acc[0][kt]); acc[1][kt] = MFMA_BF16(af[1], bf, acc[1][kt]);
+                    }
+            }
+        }
+        // (the next tile's X / dsdf stores touch buffers read only before the barrier above; sMask is double-buffered;
+        //  sB is rewritten after the next barrier)
+    }
+    float* base = partials + (size_t)blockIdx.x * NL_DEC_PARAMS;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = 64 * wj + 32 * jt + d32_row(r, lh);
+            const float w3j = params[NL_OFF_W3 + j];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) base[NL_OFF_W2 + j * NL_W + 128 * wk + 32 * kt + l31] = w3j * acc[jt][kt][r];
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward-only variant for dense SDF queries (mesh-time get_scores, render_helpers.py:96-153) and
 // tests: sdf = decoder(X).
 // ---------------------------------------------------------------------------------------------
@@ -531,11 +697,17 @@ __global__ void k_mfma_selftest(const float* A32, const float* B32, float* D32, 
 }
 
 static long long* g_dec_dbg = nullptr;
+static int g_wgrad2_mode = 1;            // 0: fp32 MFMA (k_decoder_wgrad2), 1: exact 0/1-mask x 3-term bf16 split (k_decoder_wgrad2_x)
 
 extern "C" {
 
 /* profiling aid: device buffer of 256 int64 receiving per-phase s_memtime stamps (NULL disables) */
 int nl_decoder_set_debug_buffer(void* dbg) { g_dec_dbg = (long long*)dbg; return NL_OK; }
+
+/* dW2 kernel: 0 = fp32 matrix cores, 1 = bf16 matrix cores on the exact {0,1}-mask x 3-term-split formulation (default).
+ * Same arithmetic class (exact products, fp32 accumulation); selectable for A/B measurements and cross-checks. */
+int nl_decoder_set_wgrad2_mode(int mode) { if (mode < 0 || mode > 1) return NL_ERR_INVALID_ARG; g_wgrad2_mode = mode; return NL_OK; }
+int nl_decoder_get_wgrad2_mode(void) { return g_wgrad2_mode; }
 
 int nl_decoder_grid_hint(void)
 {
@@ -569,8 +741,12 @@ int nl_decoder_wgrad2(const void* loss_scalars, const float* X, const float* par
                       float* partials, int nslabs, void* stream)
 {
     if (!loss_scalars || !X || !params || !dsdf || !relu2_mask || !partials || nslabs <= 0) return NL_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_decoder_wgrad2, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,
-                       params, dsdf, relu2_mask, partials);
+    if (g_wgrad2_mode == 1)
+        hipLaunchKernelGGL(k_decoder_wgrad2_x, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,
+                           params, dsdf, relu2_mask, partials);
+    else
+        hipLaunchKernelGGL(k_decoder_wgrad2, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,
+                           params, dsdf, relu2_mask, partials);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

@@ -173,8 +173,19 @@ def nl_split(flat):
     return DecoderDevice.split(flat)
 
 
+@pytest.fixture
+def wgrad2_mode(nl, request):
+    """run a test under one of the two dW2 kernels (0: fp32 MFMA, 1: exact {0,1}-mask x 3-term bf16 split)"""
+    lib = nl["L"].lib()
+    old = lib.nl_decoder_get_wgrad2_mode()
+    assert lib.nl_decoder_set_wgrad2_mode(request.param) == 0
+    yield request.param
+    lib.nl_decoder_set_wgrad2_mode(old)
+
+
+@pytest.mark.parametrize("wgrad2_mode", [0, 1], indirect=True)
 @pytest.mark.parametrize("case", ["map_1f_1it", "map_2f_2it_frozen"])
-def test_iteration_matches_oracle_and_golden(nl, golden_dir, case):
+def test_iteration_matches_oracle_and_golden(nl, golden_dir, case, wgrad2_mode):
     g = np.load(os.path.join(golden_dir, case + ".npz"))
     sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]))
     sc["ms"].id2row = g["id_table"].copy()
@@ -345,6 +356,18 @@ def test_full_scan_invariants(nl):
     torch.testing.assert_close(dec.grad, 2 * g1, rtol=1e-4, atol=1e-7 * float(g1.abs().max()))
     rel = (eng.g_emb - 2 * ge1).norm() / (2 * ge1).norm()
     assert float(rel) < 2e-3                                             # bf16-rounded contributions
+    # the two dW2 kernels (fp32 MFMA vs exact {0,1}-mask x 3-term bf16 split) agree to fp32 summation-order noise
+    lib = nl["L"].lib()
+    old = lib.nl_decoder_get_wgrad2_mode()
+    grads = []
+    for mode in (0, 1):
+        assert lib.nl_decoder_set_wgrad2_mode(mode) == 0
+        eng.g_emb.zero_(); eng.g_pose.zero_()
+        eng.forward_backward(m, dec, cfg)
+        grads.append(P.DecoderDevice.split(dec.grad.cpu().numpy())["W2"].astype(np.float64))
+    lib.nl_decoder_set_wgrad2_mode(old)
+    assert np.abs(grads[0]).max() > 0
+    assert np.abs(grads[0] - grads[1]).max() <= 2e-5 * np.abs(grads[0]).max()          # ~1.1 M terms per element
 
 
 def test_intersect_cap_and_overflow_paths(nl):
