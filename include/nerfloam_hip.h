@@ -29,6 +29,7 @@ extern "C" {
 #define NL_CNT_DOUBLES 4        /* ... followed by double sums: counter block = 16*4 + 4*8 bytes */
 #define NL_LOSS_SCALARS_BYTES 48
 #define NL_DEC_PARAMS 70401     /* W1[256x16] b1[256] W2[256x256] b2[256] W3[256] b3[1] */
+#define NL_DEC_WS_FLOATS 163840    /* decoder weight workspace: W2^T fp32 + 3 bf16 planes of w3*W2 */
 #define NL_EMB_CHANNELS 16
 
 int nl_version(void);
@@ -102,7 +103,7 @@ int nl_gather_points(int P, const float* xyz, const int* vox, const float* centr
                      float voxel_size, float* X, void* stream);
 
 /* Decoder forward (src/variations/lidar.py:109-131) + Criterion gradient (src/criterion.py:59-100) +
- * decoder backward (autograd of render_helpers.py:422).  params = decoder block, W2T = transposed W2.
+ * decoder backward (autograd of render_helpers.py:422).  params = decoder block, W2T = decoder weight workspace (nl_decoder_transpose_w2).
  * Outputs sdf[P], dsdf[P], dX[P,16]; with train_decoder: per-workgroup weight-gradient slabs
  * partials[nslabs][NL_DEC_PARAMS] (all but the W2 block; nl_decoder_wgrad2 adds that; sum the slabs with
  * nl_reduce_partials) and relu2_mask[ceil(P/64)][512] scratch (one 32-bit ReLU word per tile and thread). */
@@ -121,7 +122,15 @@ int nl_decoder_get_wgrad2_mode(void);
 /* forward only: Decoder.get_values on a dense batch (mesh-time get_scores, render_helpers.py:96-153) */
 int nl_decoder_forward(const float* X, const float* params, const float* W2T, int P, float* sdf, int nblocks, void* stream);
 int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, void* stream);
+/* Decoder weight workspace W2T[NL_DEC_WS_FLOATS], rebuilt from params after every optimiser step:
+ *   floats [0, 65536):      W2 transposed (fp32; forward GEMM B operand),
+ *   floats [65536, 163840): "W2X" = w3_j * W2[j][k] as three bf16 planes (hi + mid + lo == the fp32 product exactly) in
+ *                           MFMA-fragment order (dgrad GEMM B operand on the bf16 matrix cores). */
 int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream);
+/* dgrad GEMM inside nl_decoder_fwd_bwd: 0 = fp32 matrix cores, 1 = bf16 matrix cores on the exact formulation
+ * dH1[i][k] = dsdf_i * sum_j m(i,j) * (w3_j W2[j][k]), m = {0,1} ReLU mask as A operand (default) */
+int nl_decoder_set_dgrad_mode(int mode);
+int nl_decoder_get_dgrad_mode(void);
 
 /* backward of get_features: embedding gradient (fp32 accumulation of bf16-rounded contributions, the
  * CUDA embedding_dense_backward semantics) and pose-gradient partials g_pose[F,12] = (dL/dt, dL/dR).

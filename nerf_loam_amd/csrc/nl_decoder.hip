@@ -35,6 +35,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 // LDS carve (floats)
 #define S_H1 0
@@ -42,7 +44,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define S_X (S_D + DEC_M * LDH)
 #define S_W1 (S_X + DEC_M * LDX)
 #define S_S (S_W1 + NL_W * NL_C)
-#define S_DS (S_S + DEC_M)
+#define S_DS (S_S + 8 * DEC_M)                          // sS: per-wave partial row sums [8][64] (fixed-order reduce)
 #define S_TOTAL (S_DS + DEC_M)
 
 struct DecArgs {
@@ -107,6 +109,63 @@ __device__ __forceinline__ void gemm256(i32x4 rsrc, int voff_bytes, const float*
     }
 }
 
+// LICM hoists every "base + constant" LDS address out of the persistent tile loop into its own VGPR (dozens of them);
+// laundering the base through an empty asm inside the loop keeps ONE base register and lets the constants fold into the
+// ds_read/ds_write offset fields.
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+#define D32_RR(r) (((r) & 3) + 8 * ((r) >> 2))          // row of accumulator register r within a half-wave (+ 4*lh)
+
+// ---- dgrad on the bf16 matrix cores, exactly -------------------------------------------------------------------------
+// dH1[i][k] = sum_j dH2[i][j] W2[j][k] with dH2[i][j] = m(i,j) dsdf_i w3_j (m = 0/1 ReLU mask of H2), hence
+//     dH1[i][k] = dsdf_i * sum_j m(i,j) * (w3_j W2[j][k]).
+// A = m is exact in bf16; B = w3_j W2[j][k] (one fp32 rounding, done once per optimiser step by k_prepare_w2x) is split
+// into three bf16 terms whose sum is the fp32 value exactly.  Every product in the matrix core is exact, accumulation is
+// fp32: the same arithmetic class as the fp32 MFMA GEMM at 3/16 of its pipe time.
+// W2X layout (fragment-major, so every B fragment is one contiguous 1 KB buffer_load_dwordx4 per wave):
+//     [plane p(3)][column tile kt(8)][k-step s(16)][lane(64)][8 bf16],  lane = 32*h + n holds j = 16 s + 8 h + e (e = 0..7)
+//     of column k = 32 kt + n.
+// The mask tile lives in LDS as bf16 [64 rows][264] (row stride 528 B: conflict-free ds_read_b128 A fragments).
+#define SM_STRIDE 264                                   // bf16 elements per mask row (256 + 8 pad)
+#define W2X_PLANE_BYTES (NL_W * NL_W * 2)
+#define NL_DEC_WS_W2X_OFF (NL_W * NL_W)                 // floats: W2X follows W2T in the decoder weight workspace
+
+__device__ __forceinline__ uint4 bload4(i32x4 rsrc, int voff_bytes, int soff_bytes)
+{
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_bytes, soff_bytes, 0));
+}
+
+__device__ __forceinline__ void gemm_mask_x(i32x4 rsX, int w, int lane, const unsigned char* sM, f32x16& c0, f32x16& c1)
+{
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int voff = lane * 16;
+    const int kt_off = w * 16 * 1024;                    // this wave's column tile
+    const unsigned char* a0 = sM + opaque(l31 * (SM_STRIDE * 2) + 16 * lh);
+    constexpr int RING = 4;                              // B fragments run RING-1 k-steps (6 MFMAs each) ahead: L2 latency
+    uint4 bq[RING][3], aq[2][2];
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[s][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + kt_off + s * 1024);
+    aq[0][0] = *reinterpret_cast<const uint4*>(a0); aq[0][1] = *reinterpret_cast<const uint4*>(a0 + 32 * SM_STRIDE * 2);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        if (s + RING - 1 < 16) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bq[(s + RING - 1) % RING][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + kt_off + (s + RING - 1) * 1024);
+        }
+        if (s + 1 < 16) {
+            aq[(s + 1) & 1][0] = *reinterpret_cast<const uint4*>(a0 + 32 * (s + 1));
+            aq[(s + 1) & 1][1] = *reinterpret_cast<const uint4*>(a0 + 32 * SM_STRIDE * 2 + 32 * (s + 1));
+        }
+        const bf16x8 fa0 = __builtin_bit_cast(bf16x8, aq[s & 1][0]), fa1 = __builtin_bit_cast(bf16x8, aq[s & 1][1]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const bf16x8 fb = __builtin_bit_cast(bf16x8, bq[s % RING][p]);
+            c0 = MFMA_BF16(fa0, fb, c0); c1 = MFMA_BF16(fa1, fb, c1);
+        }
+    }
+}
+
 // For each of the 32 rows a half-wave holds (16 of h0 ++ 16 of h1), the sum over its 32 lanes of
 // h[row] * w3c, by recursive halving: 31 shuffles instead of 160; lane l31 ends up with the total of
 // list entry e = l31.  Register-lean: level 1 consumes h0/h1 directly (16 live values), then 8, 4, 2, 1.
@@ -140,7 +199,7 @@ __device__ __forceinline__ float halfwave_rowsum(const f32x16& h0, const f32x16&
     return (up ? v2[1] : v2[0]) + __shfl_xor(up ? v2[0] : v2[1], 1);
 }
 
-template <bool TRAIN>
+template <bool TRAIN, bool XDG>                         // XDG: dgrad GEMM on the bf16 matrix cores (exact mask formulation)
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[S_TOTAL];
@@ -155,6 +214,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
     const int ntiles = (P + DEC_M - 1) / DEC_M;
 
     const i32x4 rsW2 = make_w_rsrc(a.params + NL_OFF_W2), rsW2T = make_w_rsrc(a.W2T);
+    const i32x4 rsW2X = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W2T + NL_DEC_WS_W2X_OFF), 0, 3 * W2X_PLANE_BYTES, 0x00020000);
     const float b1c = a.params[NL_OFF_B1 + col], b2c = a.params[NL_OFF_B2 + col], w3c = a.params[NL_OFF_W3 + col];
     const float b3 = a.params[NL_OFF_B3];
 
@@ -167,7 +227,6 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) accW1[t][r] = 0.f;
     }
     for (int i = tid; i < NL_W * NL_C; i += DEC_THREADS) sW1[i] = a.params[NL_OFF_W1 + i];
-    if (tid < DEC_M) sS[tid] = 0.f;
 
     // software prefetch of the next tile's inputs (X slice; loss inputs for the 64 sample-owner threads)
     const int xe = tid * 2, xi = xe >> 4, xc = xe & 15;
@@ -206,16 +265,18 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             f32x16 c0, c1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+            const float* xb = sX + opaque(l31 * LDX + lh);
+            const float* wb = sW1 + opaque(col * NL_C + lh);
 #pragma unroll
             for (int kk = 0; kk < NL_C / 2; ++kk) {
-                const float bw = sW1[col * NL_C + 2 * kk + lh];
-                c0 = MFMA32(sX[l31 * LDX + 2 * kk + lh], bw, c0); c1 = MFMA32(sX[(32 + l31) * LDX + 2 * kk + lh], bw, c1);
+                const float bw = wb[2 * kk];
+                c0 = MFMA32(xb[2 * kk], bw, c0); c1 = MFMA32(xb[32 * LDX + 2 * kk], bw, c1);
             }
+            float* hb = sH1 + opaque(4 * lh * LDH + col);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = d32_row(r, lh);
-                sH1[row * LDH + col] = fmaxf(c0[r] + b1c, 0.f);
-                sH1[(32 + row) * LDH + col] = fmaxf(c1[r] + b1c, 0.f);
+                hb[D32_RR(r) * LDH] = fmaxf(c0[r] + b1c, 0.f);
+                hb[(32 + D32_RR(r)) * LDH] = fmaxf(c1[r] + b1c, 0.f);
             }
         }
         __syncthreads();
@@ -230,7 +291,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { h0[r] = fmaxf(h0[r] + b2c, 0.f); h1[r] = fmaxf(h1[r] + b2c, 0.f); }
             const float tot = halfwave_rowsum(h0, h1, w3c, l31);               // entry e = l31 of [h0 rows | h1 rows]
-            atomicAdd(&sS[(l31 >> 4) * 32 + d32_row(l31 & 15, lh)], tot);
+            sS[w * DEC_M + (l31 >> 4) * 32 + d32_row(l31 & 15, lh)] = tot;     // this wave's 32 columns of 64 distinct rows
         }
         __syncthreads();
         DBG_STAMP(4);
@@ -239,7 +300,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             const int g = row0 + tid;
             float ds = 0.f;
             if (g < P) {
-                const float s = sS[tid] + b3;
+                float s = sS[tid];                              // fixed summation order: run-to-run reproducible sdf
+#pragma unroll
+                for (int ww = 1; ww < 8; ++ww) s += sS[ww * DEC_M + tid];
+                s += b3;
                 bool f, m;
                 nl_loss_masks(cz, cd, ls.tau, ls.max_depth, &f, &m);
                 float q1, q2;
@@ -247,7 +311,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
                 a.sdf[g] = s; a.dsdf[g] = ds;
                 lossFs += (double)q1; lossSdf += (double)q2;
             }
-            sdS[tid] = ds; sS[tid] = 0.f;
+            sdS[tid] = ds;
             if (TRAIN) aB3 += ds;
         }
         __syncthreads();
@@ -255,13 +319,19 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         // ---------------- E: dH2 = ds * w3 * [H2 > 0] -> LDS ----------------
         {
             unsigned mw = 0u;                       // this lane's 32 ReLU bits: bit r = h0[r] > 0, bit 16+r = h1[r] > 0
+            const float* dsb = sdS + opaque(4 * lh);
+            unsigned short* mb = reinterpret_cast<unsigned short*>(sD) + opaque(4 * lh * SM_STRIDE + col);
+            float* db = sD + opaque(4 * lh * LDH + col);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = d32_row(r, lh);
-                const float ds0 = sdS[row], ds1 = sdS[32 + row];
+                const float ds0 = dsb[D32_RR(r)], ds1 = dsb[32 + D32_RR(r)];
                 const bool on0 = h0[r] > 0.f, on1 = h1[r] > 0.f;
                 const float g0 = on0 ? ds0 * w3c : 0.f, g1 = on1 ? ds1 * w3c : 0.f;
-                sD[row * LDH + col] = g0; sD[(32 + row) * LDH + col] = g1;
+                if (XDG) {                          // the 0/1 mask itself, as bf16, is the dgrad A operand
+                    mb[D32_RR(r) * SM_STRIDE] = on0 ? 0x3F80 : 0; mb[(32 + D32_RR(r)) * SM_STRIDE] = on1 ? 0x3F80 : 0;
+                } else {
+                    db[D32_RR(r) * LDH] = g0; db[(32 + D32_RR(r)) * LDH] = g1;
+                }
                 if (TRAIN) {
                     aW3 = fmaf(ds0, h0[r], aW3); aW3 = fmaf(ds1, h1[r], aW3); aB2 += g0; aB2 += g1;
                     mw |= (on0 ? (1u << r) : 0u) | (on1 ? (1u << (16 + r)) : 0u);
@@ -277,31 +347,34 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { g0v[r] = 0.f; g1v[r] = 0.f; }
-            gemm256(rsW2, (lh * NL_W + col) * 4, sD + l31 * LDH + lh, sD + (32 + l31) * LDH + lh, g0v, g1v);
+            if (XDG) gemm_mask_x(rsW2X, w, lane, reinterpret_cast<const unsigned char*>(sD), g0v, g1v);
+            else     gemm256(rsW2, (lh * NL_W + col) * 4, sD + l31 * LDH + lh, sD + (32 + l31) * LDH + lh, g0v, g1v);
             DBG_STAMP(7);
+            const float* dsb = sdS + opaque(4 * lh);
+            const float* hb = sH1 + opaque(4 * lh * LDH + col);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = d32_row(r, lh);
-                g0v[r] = sH1[row * LDH + col] > 0.f ? g0v[r] : 0.f;
-                g1v[r] = sH1[(32 + row) * LDH + col] > 0.f ? g1v[r] : 0.f;
+                if (XDG) { g0v[r] *= dsb[D32_RR(r)]; g1v[r] *= dsb[32 + D32_RR(r)]; }
+                g0v[r] = hb[D32_RR(r) * LDH] > 0.f ? g0v[r] : 0.f;
+                g1v[r] = hb[(32 + D32_RR(r)) * LDH] > 0.f ? g1v[r] : 0.f;
                 if (TRAIN) aB1 += g0v[r] + g1v[r];
             }
         }
         __syncthreads();
         DBG_STAMP(8);
         // ---------------- H: dH1 -> LDS (over dH2) ----------------
+        {
+            float* db = sD + opaque(4 * lh * LDH + col);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = d32_row(r, lh);
-            sD[row * LDH + col] = g0v[r]; sD[(32 + row) * LDH + col] = g1v[r];
+            for (int r = 0; r < 16; ++r) { db[D32_RR(r) * LDH] = g0v[r]; db[(32 + D32_RR(r)) * LDH] = g1v[r]; }
         }
         __syncthreads();
         DBG_STAMP(9);
         // ---------------- I: waves 0-3: dX[16 rows each] = dH1 W1 -> global ; waves 4-7: dW1 += dH1^T X ----------------
         if (w < 4) {
             f32x4 cxa = {0.f, 0.f, 0.f, 0.f}, cxb = {0.f, 0.f, 0.f, 0.f};
-            const float* ap = sD + (16 * w + l15) * LDH + lq;
-            const float* bq = sW1 + lq * NL_C + l15;
+            const float* ap = sD + opaque((16 * w + l15) * LDH + lq);
+            const float* bq = sW1 + opaque(lq * NL_C + l15);
 #pragma unroll 8
             for (int q = 0; q < NL_W / 4; q += 2) {
                 cxa = MFMA16(ap[4 * q], bq[4 * q * NL_C], cxa);
@@ -313,13 +386,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
                 if (g < P) a.dX[(size_t)g * NL_C + l15] = cxa[r] + cxb[r];
             }
         } else if (TRAIN) {
-            const int hb = 64 * (w - 4);
+            const float* xr = sX + opaque(lq * LDX + l15);
+            const float* dr = sD + opaque(lq * LDH + 64 * (w - 4) + l15);
 #pragma unroll 4
             for (int ii = 0; ii < DEC_M / 4; ++ii) {
-                const float xb = sX[(4 * ii + lq) * LDX + l15];
+                const float xb = xr[4 * ii * LDX];
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    accW1[t] = MFMA16(sD[(4 * ii + lq) * LDH + hb + 16 * t + l15], xb, accW1[t]);
+                    accW1[t] = MFMA16(dr[4 * ii * LDH + 16 * t], xb, accW1[t]);
             }
         }
         __syncthreads();
@@ -462,8 +536,6 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2(const NlLossS
 // Wave (wj = w>>1, wk = w&1) owns dW2 rows [64 wj, +64) x columns [128 wk, +128): 2 x 4 accumulators; one B
 // fragment (ds_read_b128) feeds two MFMAs.
 // ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #define WX_STRIDE 144                                   // bytes per column row of a plane: 64 slots x 2 B + 16 pad
 #define WX_PLANE (NL_W * WX_STRIDE)
 #define WX_OFF_LUT (3 * WX_PLANE)
@@ -614,15 +686,17 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __restrict__ X, const float* __restrict__ params,
                                                                  const float* __restrict__ W2T, int P, float* __restrict__ sdf)
 {
-    __shared__ __attribute__((aligned(16))) float lds[DEC_M * LDH + DEC_M * LDX + DEC_M];
+    __shared__ __attribute__((aligned(16))) float lds[DEC_M * LDH + DEC_M * LDX + 8 * DEC_M];
     float* sH1 = lds; float* sX = lds + DEC_M * LDH; float* sS = sX + DEC_M * LDX;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int col = 32 * w + l31;
     const float* W1 = params + NL_OFF_W1;
+    const i32x4 rsW2T = make_w_rsrc(W2T);
     const float b1c = params[NL_OFF_B1 + col], b2c = params[NL_OFF_B2 + col], w3c = params[NL_OFF_W3 + col], b3 = params[NL_OFF_B3];
+    float w1r[NL_C / 2];
+#pragma unroll
+    for (int kk = 0; kk < NL_C / 2; ++kk) w1r[kk] = W1[col * NL_C + 2 * kk + lh];
     const int ntiles = (P + DEC_M - 1) / DEC_M;
-    if (tid < DEC_M) sS[tid] = 0.f;
-    __syncthreads();
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * DEC_M;
         {
@@ -636,40 +710,34 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
             f32x16 c0, c1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+            const float* xb = sX + opaque(l31 * LDX + lh);
 #pragma unroll
-            for (int kk = 0; kk < NL_C / 2; ++kk) {
-                const float bw = W1[col * NL_C + 2 * kk + lh];
-                c0 = MFMA32(sX[l31 * LDX + 2 * kk + lh], bw, c0); c1 = MFMA32(sX[(32 + l31) * LDX + 2 * kk + lh], bw, c1);
-            }
+            for (int kk = 0; kk < NL_C / 2; ++kk) { c0 = MFMA32(xb[2 * kk], w1r[kk], c0); c1 = MFMA32(xb[32 * LDX + 2 * kk], w1r[kk], c1); }
+            float* hb = sH1 + opaque(4 * lh * LDH + col);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = d32_row(r, lh);
-                sH1[row * LDH + col] = fmaxf(c0[r] + b1c, 0.f); sH1[(32 + row) * LDH + col] = fmaxf(c1[r] + b1c, 0.f);
+                hb[D32_RR(r) * LDH] = fmaxf(c0[r] + b1c, 0.f); hb[(32 + D32_RR(r)) * LDH] = fmaxf(c1[r] + b1c, 0.f);
             }
         }
         __syncthreads();
-        {
+        {   // identical arithmetic (and summation order) to k_decoder's phase C/D: forward-only sdf == fused-kernel sdf
             f32x16 h0, h1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
-            const float* bp = W2T + lh * NL_W + col;
-            const float* ap0 = sH1 + l31 * LDH + lh; const float* ap1 = sH1 + (32 + l31) * LDH + lh;
-#pragma unroll 8
-            for (int kk = 0; kk < NL_W / 2; ++kk) {
-                const float bw = bp[(size_t)kk * 2 * NL_W];
-                h0 = MFMA32(ap0[2 * kk], bw, h0); h1 = MFMA32(ap1[2 * kk], bw, h1);
-            }
+            gemm256(rsW2T, (lh * NL_W + col) * 4, sH1 + l31 * LDH + lh, sH1 + (32 + l31) * LDH + lh, h0, h1);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p0 = fmaxf(h0[r] + b2c, 0.f) * w3c, p1 = fmaxf(h1[r] + b2c, 0.f) * w3c;
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) { p0 += __shfl_xor(p0, off); p1 += __shfl_xor(p1, off); }
-                if (l31 == 0) { const int row = d32_row(r, lh); atomicAdd(&sS[row], p0); atomicAdd(&sS[32 + row], p1); }
-            }
+            for (int r = 0; r < 16; ++r) { h0[r] = fmaxf(h0[r] + b2c, 0.f); h1[r] = fmaxf(h1[r] + b2c, 0.f); }
+            const float tot = halfwave_rowsum(h0, h1, w3c, l31);
+            sS[w * DEC_M + (l31 >> 4) * 32 + d32_row(l31 & 15, lh)] = tot;
         }
         __syncthreads();
-        if (tid < DEC_M) { if (row0 + tid < P) sdf[row0 + tid] = sS[tid] + b3; sS[tid] = 0.f; }
-        __syncthreads();
+        if (tid < DEC_M && row0 + tid < P) {
+            float sv = sS[tid];
+#pragma unroll
+            for (int ww = 1; ww < 8; ++ww) sv += sS[ww * DEC_M + tid];
+            sdf[row0 + tid] = sv + b3;
+        }
+        // (sS is rewritten only after two more barriers; sX / sH1 after one)
     }
 }
 
@@ -697,6 +765,7 @@ __global__ void k_mfma_selftest(const float* A32, const float* B32, float* D32, 
 }
 
 static long long* g_dec_dbg = nullptr;
+static int g_dgrad_mode = 1;             // 0: fp32 MFMA dgrad GEMM, 1: exact 0/1-mask x 3-term bf16 split (gemm_mask_x)
 static int g_wgrad2_mode = 1;            // 0: fp32 MFMA (k_decoder_wgrad2), 1: exact 0/1-mask x 3-term bf16 split (k_decoder_wgrad2_x)
 
 extern "C" {
@@ -708,6 +777,10 @@ int nl_decoder_set_debug_buffer(void* dbg) { g_dec_dbg = (long long*)dbg; return
  * Same arithmetic class (exact products, fp32 accumulation); selectable for A/B measurements and cross-checks. */
 int nl_decoder_set_wgrad2_mode(int mode) { if (mode < 0 || mode > 1) return NL_ERR_INVALID_ARG; g_wgrad2_mode = mode; return NL_OK; }
 int nl_decoder_get_wgrad2_mode(void) { return g_wgrad2_mode; }
+/* dgrad GEMM (dH1 = dH2 W2) inside the fused decoder kernel: 0 = fp32 matrix cores, 1 = bf16 matrix cores on the exact
+ * formulation dH1[i][k] = dsdf_i * sum_j m(i,j) * (w3_j W2[j][k]) (default) */
+int nl_decoder_set_dgrad_mode(int mode) { if (mode < 0 || mode > 1) return NL_ERR_INVALID_ARG; g_dgrad_mode = mode; return NL_OK; }
+int nl_decoder_get_dgrad_mode(void) { return g_dgrad_mode; }
 
 int nl_decoder_grid_hint(void)
 {
@@ -730,8 +803,14 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
     a.relu2_mask = relu2_mask;
     a.dcounters = (double*)(counters + NL_CNT_INTS);
     a.dbg = g_dec_dbg;
-    if (train_decoder) hipLaunchKernelGGL(k_decoder<true>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, a);
-    else               hipLaunchKernelGGL(k_decoder<false>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, a);
+    const dim3 g(nslabs), b(DEC_THREADS);
+    if (g_dgrad_mode == 1) {
+        if (train_decoder) hipLaunchKernelGGL((k_decoder<true, true>), g, b, 0, (hipStream_t)stream, a);
+        else               hipLaunchKernelGGL((k_decoder<false, true>), g, b, 0, (hipStream_t)stream, a);
+    } else {
+        if (train_decoder) hipLaunchKernelGGL((k_decoder<true, false>), g, b, 0, (hipStream_t)stream, a);
+        else               hipLaunchKernelGGL((k_decoder<false, false>), g, b, 0, (hipStream_t)stream, a);
+    }
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

@@ -65,6 +65,29 @@ __global__ void k_transpose_w2(const float* __restrict__ params, float* __restri
     for (int r = threadIdx.y; r < 32; r += blockDim.y) W2T[(bx + r) * NL_W + by + threadIdx.x] = t[threadIdx.x][r];
 }
 
+// W2X: the dgrad B operand w3_j * W2[j][k] split into three bf16 terms (hi + mid + lo == the fp32 product exactly:
+// truncation splits of 8 + 8 + 8 significand bits), in the fragment-major layout gemm_mask_x (nl_decoder.hip) streams:
+// [plane(3)][column tile kt(8)][k-step s(16)][lane(64)][8 bf16], lane = 32 h + n <-> j = 16 s + 8 h + e, k = 32 kt + n.
+__global__ void k_prepare_w2x(const float* __restrict__ params, uint16_t* __restrict__ W2X)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;         // one thread per (kt, s, lane)
+    if (t >= 8 * 16 * 64) return;
+    const int lane = t & 63, s = (t >> 6) & 15, kt = t >> 10;
+    const int k = 32 * kt + (lane & 31), j0 = 16 * s + 8 * (lane >> 5);
+    uint16_t* dst = W2X + (size_t)t * 8;
+    for (int e = 0; e < 8; ++e) {
+        const int j = j0 + e;
+        const float v = params[NL_OFF_W3 + j] * params[NL_OFF_W2 + j * NL_W + k];
+        union { float f; uint32_t u; } a, b, c;
+        a.f = v; a.u &= 0xFFFF0000u;
+        b.f = v - a.f; b.u &= 0xFFFF0000u;
+        c.f = (v - a.f) - b.f;                                   // <= 8 significant bits left: exact in bf16
+        dst[e] = (uint16_t)(a.u >> 16);
+        dst[e + NL_W * NL_W] = (uint16_t)(b.u >> 16);
+        dst[e + 2 * NL_W * NL_W] = (uint16_t)(c.u >> 16);
+    }
+}
+
 // poses12[f] = [R(w) row-major | t]   from pose6[f] = [t, w]     (se3pose.py:18-35)
 __global__ void k_pose_matrix(const float* __restrict__ pose6, float* __restrict__ poses12, int F)
 {
@@ -142,6 +165,8 @@ int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream)
 {
     if (!params || !W2T) return NL_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_transpose_w2, dim3(NL_W / 32, NL_W / 32), dim3(32, 8), 0, (hipStream_t)stream, params, W2T);
+    hipLaunchKernelGGL(k_prepare_w2x, dim3(8 * 16 * 64 / 256), dim3(256), 0, (hipStream_t)stream, params,
+                       reinterpret_cast<uint16_t*>(W2T + NL_W * NL_W));
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

@@ -45,7 +45,7 @@ class Decoder(nn.Module):
             raise L.NerfLoamHipError("Decoder.get_values needs a CUDA (HIP) tensor - no CPU path")
         x = x.detach().float().contiguous()
         params = self.flat_params(x.device)
-        W2T = torch.empty(L.NL_W * L.NL_W, dtype=torch.float32, device=x.device)
+        W2T = torch.empty(L.NL_DEC_WS_FLOATS, dtype=torch.float32, device=x.device)
         ops.decoder_transpose_w2(params, W2T)
         out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
         ops.decoder_forward(x, params, W2T, x.shape[0], out, L.lib().nl_decoder_grid_hint())

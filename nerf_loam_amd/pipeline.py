@@ -132,7 +132,7 @@ class DecoderDevice:
         flat = np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in (W1, b1, W2, b2, W3, b3)])
         assert flat.size == L.NL_DEC_PARAMS
         self.params = torch.as_tensor(flat).to(device)
-        self.W2T = torch.empty(L.NL_W * L.NL_W, dtype=F32, device=device)
+        self.W2T = torch.empty(L.NL_DEC_WS_FLOATS, dtype=F32, device=device)
         self.m = torch.zeros_like(self.params)
         self.v = torch.zeros_like(self.params)
         self.grad = torch.zeros_like(self.params)

@@ -174,18 +174,19 @@ def nl_split(flat):
 
 
 @pytest.fixture
-def wgrad2_mode(nl, request):
-    """run a test under one of the two dW2 kernels (0: fp32 MFMA, 1: exact {0,1}-mask x 3-term bf16 split)"""
+def backward_mode(nl, request):
+    """run a test with the backward GEMMs (dgrad inside the fused kernel, dW2) on the fp32 matrix cores (0) or on the
+    bf16 matrix cores via the exact {0,1}-mask x 3-term-split formulation (1, the default)"""
     lib = nl["L"].lib()
-    old = lib.nl_decoder_get_wgrad2_mode()
-    assert lib.nl_decoder_set_wgrad2_mode(request.param) == 0
+    old = lib.nl_decoder_get_wgrad2_mode(), lib.nl_decoder_get_dgrad_mode()
+    assert lib.nl_decoder_set_wgrad2_mode(request.param) == 0 and lib.nl_decoder_set_dgrad_mode(request.param) == 0
     yield request.param
-    lib.nl_decoder_set_wgrad2_mode(old)
+    lib.nl_decoder_set_wgrad2_mode(old[0]); lib.nl_decoder_set_dgrad_mode(old[1])
 
 
-@pytest.mark.parametrize("wgrad2_mode", [0, 1], indirect=True)
+@pytest.mark.parametrize("backward_mode", [0, 1], indirect=True)
 @pytest.mark.parametrize("case", ["map_1f_1it", "map_2f_2it_frozen"])
-def test_iteration_matches_oracle_and_golden(nl, golden_dir, case, wgrad2_mode):
+def test_iteration_matches_oracle_and_golden(nl, golden_dir, case, backward_mode):
     g = np.load(os.path.join(golden_dir, case + ".npz"))
     sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]))
     sc["ms"].id2row = g["id_table"].copy()
@@ -356,18 +357,25 @@ def test_full_scan_invariants(nl):
     torch.testing.assert_close(dec.grad, 2 * g1, rtol=1e-4, atol=1e-7 * float(g1.abs().max()))
     rel = (eng.g_emb - 2 * ge1).norm() / (2 * ge1).norm()
     assert float(rel) < 2e-3                                             # bf16-rounded contributions
-    # the two dW2 kernels (fp32 MFMA vs exact {0,1}-mask x 3-term bf16 split) agree to fp32 summation-order noise
+    # backward GEMMs on the fp32 matrix cores vs on the bf16 matrix cores (exact {0,1}-mask x 3-term split): the same
+    # sums in a different order
     lib = nl["L"].lib()
-    old = lib.nl_decoder_get_wgrad2_mode()
-    grads = []
+    old = lib.nl_decoder_get_wgrad2_mode(), lib.nl_decoder_get_dgrad_mode()
+    res = []
     for mode in (0, 1):
-        assert lib.nl_decoder_set_wgrad2_mode(mode) == 0
+        assert lib.nl_decoder_set_wgrad2_mode(mode) == 0 and lib.nl_decoder_set_dgrad_mode(mode) == 0
         eng.g_emb.zero_(); eng.g_pose.zero_()
         eng.forward_backward(m, dec, cfg)
-        grads.append(P.DecoderDevice.split(dec.grad.cpu().numpy())["W2"].astype(np.float64))
-    lib.nl_decoder_set_wgrad2_mode(old)
-    assert np.abs(grads[0]).max() > 0
-    assert np.abs(grads[0] - grads[1]).max() <= 2e-5 * np.abs(grads[0]).max()          # ~1.1 M terms per element
+        res.append((P.DecoderDevice.split(dec.grad.cpu().numpy()), eng.dX[:Pn].cpu().numpy().astype(np.float64), eng.sdf[:Pn].cpu().numpy()))
+    lib.nl_decoder_set_wgrad2_mode(old[0]); lib.nl_decoder_set_dgrad_mode(old[1])
+    assert np.array_equal(res[0][2], res[1][2])                                            # forward untouched, and reproducible
+    assert eng.forward_only(m, dec, cfg) == Pn
+    assert np.array_equal(eng.sdf[:Pn].cpu().numpy(), res[0][2])                           # forward-only kernel: same arithmetic
+    assert np.abs(res[0][1]).max() > 0
+    assert np.abs(res[0][1] - res[1][1]).max() <= 2e-6 * np.abs(res[0][1]).max()          # dX: 256-term sums
+    for name in ("W1", "b1", "W2"):                                                        # ~1.1 M terms per element
+        g0, g1 = res[0][0][name].astype(np.float64), res[1][0][name].astype(np.float64)
+        assert np.abs(g0).max() > 0 and np.abs(g0 - g1).max() <= 2e-5 * np.abs(g0).max(), name
 
 
 def test_intersect_cap_and_overflow_paths(nl):
