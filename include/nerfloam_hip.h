@@ -29,7 +29,7 @@ extern "C" {
 #define NL_CNT_DOUBLES 4        /* ... followed by double sums: counter block = 16*4 + 4*8 bytes */
 #define NL_LOSS_SCALARS_BYTES 48
 #define NL_DEC_PARAMS 70401     /* W1[256x16] b1[256] W2[256x256] b2[256] W3[256] b3[1] */
-#define NL_DEC_WS_FLOATS 163840    /* decoder weight workspace: W2^T fp32 + 3 bf16 planes of w3*W2 */
+#define NL_DEC_WS_FLOATS 262144    /* decoder weight workspace: W2^T fp32 + 2 x 3 bf16 operand planes */
 #define NL_EMB_CHANNELS 16
 
 int nl_version(void);
@@ -123,14 +123,18 @@ int nl_decoder_get_wgrad2_mode(void);
 int nl_decoder_forward(const float* X, const float* params, const float* W2T, int P, float* sdf, int nblocks, void* stream);
 int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, void* stream);
 /* Decoder weight workspace W2T[NL_DEC_WS_FLOATS], rebuilt from params after every optimiser step:
- *   floats [0, 65536):      W2 transposed (fp32; forward GEMM B operand),
- *   floats [65536, 163840): "W2X" = w3_j * W2[j][k] as three bf16 planes (hi + mid + lo == the fp32 product exactly) in
- *                           MFMA-fragment order (dgrad GEMM B operand on the bf16 matrix cores). */
+ *   floats [0, 65536):        W2 transposed (fp32; forward GEMM B operand of gemm mode 0),
+ *   floats [65536, 163840):   "W2X"  = w3_j * W2[j][k] as three bf16 planes (hi + mid + lo == the fp32 value exactly) in
+ *                             MFMA-fragment order: dgrad GEMM B operand on the bf16 matrix cores,
+ *   floats [163840, 262144):  "W2TX" = W2[n][k], same split and order: forward GEMM B operand on the bf16 matrix cores. */
 int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream);
-/* dgrad GEMM inside nl_decoder_fwd_bwd: 0 = fp32 matrix cores, 1 = bf16 matrix cores on the exact formulation
- * dH1[i][k] = dsdf_i * sum_j m(i,j) * (w3_j W2[j][k]), m = {0,1} ReLU mask as A operand (default) */
-int nl_decoder_set_dgrad_mode(int mode);
-int nl_decoder_get_dgrad_mode(void);
+/* The two 256-deep GEMMs of nl_decoder_fwd_bwd / nl_decoder_forward: 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32),
+ * 1 = bf16 matrix cores (v_mfma_f32_32x32x16_bf16) on exact-product formulations (default):
+ *   forward  H2 = H1 W2^T:  both operands split into three bf16 terms, all nine partial products (each exact in fp32);
+ *   dgrad    dH1[i][k] = dsdf_i * sum_j m(i,j) * (w3_j W2[j][k]),  m = the {0,1} ReLU mask as A operand, B split in three.
+ * Accumulation is fp32 in both modes; results differ by summation order only. */
+int nl_decoder_set_gemm_mode(int mode);
+int nl_decoder_get_gemm_mode(void);
 
 /* backward of get_features: embedding gradient (fp32 accumulation of bf16-rounded contributions, the
  * CUDA embedding_dense_backward semantics) and pose-gradient partials g_pose[F,12] = (dL/dt, dL/dR).

@@ -14,7 +14,7 @@ NL_CNT_BYTES = NL_CNT_INTS * 4 + NL_CNT_DOUBLES * 8
 NL_LOSS_SCALARS_BYTES = 48
 NL_ADAM_STATE_BYTES = 112
 NL_DEC_PARAMS = 70401
-NL_DEC_WS_FLOATS = 163840        # decoder weight workspace: W2^T fp32 + 3 bf16 planes of w3*W2 (include/nerfloam_hip.h)
+NL_DEC_WS_FLOATS = 262144        # decoder weight workspace: W2^T fp32 + 2 x 3 bf16 operand planes (include/nerfloam_hip.h)
 NL_C = 16
 NL_W = 256
 OFF_W1, OFF_B1 = 0, 256 * 16
@@ -55,8 +55,8 @@ _SIGS = {
     "nl_decoder_fwd_bwd": ([_P] * 13 + [_I, _I, _P, _P], _I),
     "nl_decoder_wgrad2": ([_P] * 6 + [_I, _P], _I),
     "nl_decoder_forward": ([_P, _P, _P, _I, _P, _I, _P], _I),
-    "nl_decoder_set_dgrad_mode": ([_I], _I),
-    "nl_decoder_get_dgrad_mode": ([], _I),
+    "nl_decoder_set_gemm_mode": ([_I], _I),
+    "nl_decoder_get_gemm_mode": ([], _I),
     "nl_decoder_set_wgrad2_mode": ([_I], _I),
     "nl_decoder_get_wgrad2_mode": ([], _I),
     "nl_reduce_partials": ([_P, _I, _I, _P, _P], _I),
@@ -98,9 +98,9 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = res
-        if os.environ.get("NL_DGRAD_MODE"):
-            if L.nl_decoder_set_dgrad_mode(int(os.environ["NL_DGRAD_MODE"])) != 0:
-                raise NerfLoamHipError("NL_DGRAD_MODE must be 0 or 1")
+        if os.environ.get("NL_GEMM_MODE"):
+            if L.nl_decoder_set_gemm_mode(int(os.environ["NL_GEMM_MODE"])) != 0:
+                raise NerfLoamHipError("NL_GEMM_MODE must be 0 or 1")
         if os.environ.get("NL_WGRAD2_MODE"):                # A/B switch for measurements (default: the library's own default)
             if L.nl_decoder_set_wgrad2_mode(int(os.environ["NL_WGRAD2_MODE"])) != 0:
                 raise NerfLoamHipError("NL_WGRAD2_MODE must be 0 or 1")

@@ -109,6 +109,14 @@ __device__ __forceinline__ void gemm256(i32x4 rsrc, int voff_bytes, const float*
     }
 }
 
+// upper halves of two fp32 registers -> one register of two bf16 (lo = a, hi = b): truncation, used on values whose
+// low 16 bits are already zero or are carried by the next split term
+__device__ __forceinline__ unsigned pack_hi16(float a, float b)
+{
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
+
 // LICM hoists every "base + constant" LDS address out of the persistent tile loop into its own VGPR (dozens of them);
 // laundering the base through an empty asm inside the loop keeps ONE base register and lets the constants fold into the
 // ds_read/ds_write offset fields.
@@ -166,6 +174,80 @@ __device__ __forceinline__ void gemm_mask_x(i32x4 rsX, int w, int lane, const un
     }
 }
 
+// ---- forward GEMM on the bf16 matrix cores with exact products ---------------------------------------------------------
+// H2pre[i][n] = sum_k H1[i][k] W2[n][k]: both operands are general fp32, so BOTH are split into three bf16 terms
+// (x = x_hi + x_mid + x_lo exactly) and all nine partial products are formed: each bf16 x bf16 product is exact in fp32,
+// their sum is the exact fp32 x fp32 product, accumulation is fp32 - again the arithmetic class of the fp32 MFMA GEMM,
+// at 9/16 of its pipe time.  A planes: LDS, bf16 [3][64 rows][264]; B planes "W2TX": fragment-major like W2X with
+// k = 16 s + 8 h + e (input index) and n = 32 nt + (lane & 31) (output column).
+#define X_PLANE_ELEMS (DEC_M * SM_STRIDE)
+#define X_PLANE_BYTES (X_PLANE_ELEMS * 2)
+#define NL_DEC_WS_W2TX_OFF (NL_DEC_WS_W2X_OFF + 3 * NL_W * NL_W / 2)       // floats
+
+__device__ __forceinline__ void gemm_x9(i32x4 rsX, int w, int lane, const unsigned char* sP, f32x16& c0, f32x16& c1)
+{
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int voff = lane * 16;
+    const int nt_off = w * 16 * 1024;
+    const unsigned char* a0 = sP + opaque(l31 * (SM_STRIDE * 2) + 16 * lh);
+    constexpr int RING = 3;                              // B fragments 2 k-steps (36 MFMAs) ahead
+    uint4 bq[RING][3], aq[2][2][3];
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[s][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + nt_off + s * 1024);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        aq[0][0][p] = *reinterpret_cast<const uint4*>(a0 + p * X_PLANE_BYTES);
+        aq[0][1][p] = *reinterpret_cast<const uint4*>(a0 + p * X_PLANE_BYTES + 32 * SM_STRIDE * 2);
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        if (s + RING - 1 < 16) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bq[(s + RING - 1) % RING][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + nt_off + (s + RING - 1) * 1024);
+        }
+        if (s + 1 < 16) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                aq[(s + 1) & 1][0][p] = *reinterpret_cast<const uint4*>(a0 + p * X_PLANE_BYTES + 32 * (s + 1));
+                aq[(s + 1) & 1][1][p] = *reinterpret_cast<const uint4*>(a0 + p * X_PLANE_BYTES + 32 * SM_STRIDE * 2 + 32 * (s + 1));
+            }
+        }
+#pragma unroll
+        for (int pb = 2; pb >= 0; --pb) {
+            const bf16x8 fb = __builtin_bit_cast(bf16x8, bq[s % RING][pb]);
+#pragma unroll
+            for (int pa = 2; pa >= 0; --pa) {
+                c0 = MFMA_BF16(__builtin_bit_cast(bf16x8, aq[s & 1][0][pa]), fb, c0);
+                c1 = MFMA_BF16(__builtin_bit_cast(bf16x8, aq[s & 1][1][pa]), fb, c1);
+            }
+        }
+    }
+}
+
+// H1 = relu(pre + b1) for this lane's column / 32 rows -> three bf16 planes in LDS (A operand of gemm_x9); returns the
+// lane's 32 ReLU bits (bit r: row d32_row(r, lh), bit 16 + r: row 32 + d32_row(r, lh)) for the dgrad epilogue
+__device__ __forceinline__ unsigned store_h1_planes(unsigned short* sP, int col, int lh, const f32x16& c0, const f32x16& c1, float b1c)
+{
+    unsigned short* pb = sP + opaque(4 * lh * SM_STRIDE + col);
+    unsigned m1 = 0u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const float h = fmaxf((sub ? c1[r] : c0[r]) + b1c, 0.f);
+            m1 |= (h > 0.f) ? (1u << (16 * sub + r)) : 0u;
+            const float hi = trunc_bf16(h), r1 = h - hi, mid = trunc_bf16(r1), lo = r1 - mid;      // lo: <= 8 significant bits
+            unsigned short* d = pb + (32 * sub + D32_RR(r)) * SM_STRIDE;
+            d[0] = (unsigned short)(__float_as_uint(hi) >> 16);
+            d[X_PLANE_ELEMS] = (unsigned short)(__float_as_uint(mid) >> 16);
+            d[2 * X_PLANE_ELEMS] = (unsigned short)(__float_as_uint(lo) >> 16);
+        }
+    }
+    return m1;
+}
+
 // For each of the 32 rows a half-wave holds (16 of h0 ++ 16 of h1), the sum over its 32 lanes of
 // h[row] * w3c, by recursive halving: 31 shuffles instead of 160; lane l31 ends up with the total of
 // list entry e = l31.  Register-lean: level 1 consumes h0/h1 directly (16 live values), then 8, 4, 2, 1.
@@ -199,11 +281,13 @@ __device__ __forceinline__ float halfwave_rowsum(const f32x16& h0, const f32x16&
     return (up ? v2[1] : v2[0]) + __shfl_xor(up ? v2[0] : v2[1], 1);
 }
 
-template <bool TRAIN, bool XDG>                         // XDG: dgrad GEMM on the bf16 matrix cores (exact mask formulation)
+template <bool TRAIN, bool XG>                          // XG: both 256-deep GEMMs on the bf16 matrix cores (exact-product formulations)
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[S_TOTAL];
-    float* sH1 = lds + S_H1; float* sD = lds + S_D; float* sX = lds + S_X; float* sW1 = lds + S_W1;
+    // XG: the three bf16 planes of H1 occupy the first 101 KB; the bf16 mask tile (phases E/F) and then the fp32 dH1 tile
+    // (phases H/I) alias them once the forward GEMM has consumed them
+    float* sH1 = lds + S_H1; float* sD = XG ? lds : lds + S_D; float* sX = lds + S_X; float* sW1 = lds + S_W1;
     float* sS = lds + S_S; float* sdS = lds + S_DS;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -215,6 +299,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 
     const i32x4 rsW2 = make_w_rsrc(a.params + NL_OFF_W2), rsW2T = make_w_rsrc(a.W2T);
     const i32x4 rsW2X = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W2T + NL_DEC_WS_W2X_OFF), 0, 3 * W2X_PLANE_BYTES, 0x00020000);
+    const i32x4 rsW2TX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W2T + NL_DEC_WS_W2TX_OFF), 0, 3 * W2X_PLANE_BYTES, 0x00020000);
     const float b1c = a.params[NL_OFF_B1 + col], b2c = a.params[NL_OFF_B2 + col], w3c = a.params[NL_OFF_W3 + col];
     const float b3 = a.params[NL_OFF_B3];
 
@@ -261,6 +346,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         __syncthreads();
         DBG_STAMP(1);
         // ---------------- B: H1 = relu(X W1^T + b1) ----------------
+        unsigned m1 = 0u;                               // XG: this lane's 32 ReLU bits of H1
         {
             f32x16 c0, c1;
 #pragma unroll
@@ -272,11 +358,15 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
                 const float bw = wb[2 * kk];
                 c0 = MFMA32(xb[2 * kk], bw, c0); c1 = MFMA32(xb[32 * LDX + 2 * kk], bw, c1);
             }
-            float* hb = sH1 + opaque(4 * lh * LDH + col);
+            if (XG) {
+                m1 = store_h1_planes(reinterpret_cast<unsigned short*>(lds), col, lh, c0, c1, b1c);
+            } else {
+                float* hb = sH1 + opaque(4 * lh * LDH + col);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                hb[D32_RR(r) * LDH] = fmaxf(c0[r] + b1c, 0.f);
-                hb[(32 + D32_RR(r)) * LDH] = fmaxf(c1[r] + b1c, 0.f);
+                for (int r = 0; r < 16; ++r) {
+                    hb[D32_RR(r) * LDH] = fmaxf(c0[r] + b1c, 0.f);
+                    hb[(32 + D32_RR(r)) * LDH] = fmaxf(c1[r] + b1c, 0.f);
+                }
             }
         }
         __syncthreads();
@@ -286,7 +376,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
-            gemm256(rsW2T, (lh * NL_W + col) * 4, sH1 + l31 * LDH + lh, sH1 + (32 + l31) * LDH + lh, h0, h1);
+            if (XG) gemm_x9(rsW2TX, w, lane, reinterpret_cast<const unsigned char*>(lds), h0, h1);
+            else    gemm256(rsW2T, (lh * NL_W + col) * 4, sH1 + l31 * LDH + lh, sH1 + (32 + l31) * LDH + lh, h0, h1);
             DBG_STAMP(3);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { h0[r] = fmaxf(h0[r] + b2c, 0.f); h1[r] = fmaxf(h1[r] + b2c, 0.f); }
@@ -320,14 +411,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         {
             unsigned mw = 0u;                       // this lane's 32 ReLU bits: bit r = h0[r] > 0, bit 16+r = h1[r] > 0
             const float* dsb = sdS + opaque(4 * lh);
-            unsigned short* mb = reinterpret_cast<unsigned short*>(sD) + opaque(4 * lh * SM_STRIDE + col);
+            unsigned short* mb = reinterpret_cast<unsigned short*>(lds) + opaque(4 * lh * SM_STRIDE + col);
             float* db = sD + opaque(4 * lh * LDH + col);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float ds0 = dsb[D32_RR(r)], ds1 = dsb[32 + D32_RR(r)];
                 const bool on0 = h0[r] > 0.f, on1 = h1[r] > 0.f;
                 const float g0 = on0 ? ds0 * w3c : 0.f, g1 = on1 ? ds1 * w3c : 0.f;
-                if (XDG) {                          // the 0/1 mask itself, as bf16, is the dgrad A operand
+                if (XG) {                          // the 0/1 mask itself, as bf16, is the dgrad A operand
                     mb[D32_RR(r) * SM_STRIDE] = on0 ? 0x3F80 : 0; mb[(32 + D32_RR(r)) * SM_STRIDE] = on1 ? 0x3F80 : 0;
                 } else {
                     db[D32_RR(r) * LDH] = g0; db[(32 + D32_RR(r)) * LDH] = g1;
@@ -347,16 +438,20 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { g0v[r] = 0.f; g1v[r] = 0.f; }
-            if (XDG) gemm_mask_x(rsW2X, w, lane, reinterpret_cast<const unsigned char*>(sD), g0v, g1v);
+            if (XG) gemm_mask_x(rsW2X, w, lane, reinterpret_cast<const unsigned char*>(lds), g0v, g1v);
             else     gemm256(rsW2, (lh * NL_W + col) * 4, sD + l31 * LDH + lh, sD + (32 + l31) * LDH + lh, g0v, g1v);
             DBG_STAMP(7);
             const float* dsb = sdS + opaque(4 * lh);
             const float* hb = sH1 + opaque(4 * lh * LDH + col);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (XDG) { g0v[r] *= dsb[D32_RR(r)]; g1v[r] *= dsb[32 + D32_RR(r)]; }
-                g0v[r] = hb[D32_RR(r) * LDH] > 0.f ? g0v[r] : 0.f;
-                g1v[r] = hb[(32 + D32_RR(r)) * LDH] > 0.f ? g1v[r] : 0.f;
+                if (XG) {
+                    g0v[r] = ((m1 >> r) & 1u) ? g0v[r] * dsb[D32_RR(r)] : 0.f;
+                    g1v[r] = ((m1 >> (16 + r)) & 1u) ? g1v[r] * dsb[32 + D32_RR(r)] : 0.f;
+                } else {
+                    g0v[r] = hb[D32_RR(r) * LDH] > 0.f ? g0v[r] : 0.f;
+                    g1v[r] = hb[(32 + D32_RR(r)) * LDH] > 0.f ? g1v[r] : 0.f;
+                }
                 if (TRAIN) aB1 += g0v[r] + g1v[r];
             }
         }
@@ -544,13 +639,6 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2(const NlLossS
 #define WX_OFF_DS (WX_OFF_X + DEC_M * LDX * 4)
 #define WX_TOTAL (WX_OFF_DS + DEC_M * 4)
 
-// upper halves of two fp32 registers -> one register of two bf16 (lo = a, hi = b): truncation, used on values whose
-// low 16 bits are already zero or are carried by the next split term
-__device__ __forceinline__ unsigned pack_hi16(float a, float b)
-{
-    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
-}
-__device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
 
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLossScalars* __restrict__ lsp, const float* __restrict__ X,
                                                                       const float* __restrict__ params, const float* __restrict__ dsdf,
@@ -683,15 +771,18 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
 // forward-only variant for dense SDF queries (mesh-time get_scores, render_helpers.py:96-153) and
 // tests: sdf = decoder(X).
 // ---------------------------------------------------------------------------------------------
+template <bool XG>
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __restrict__ X, const float* __restrict__ params,
                                                                  const float* __restrict__ W2T, int P, float* __restrict__ sdf)
 {
-    __shared__ __attribute__((aligned(16))) float lds[DEC_M * LDH + DEC_M * LDX + 8 * DEC_M];
-    float* sH1 = lds; float* sX = lds + DEC_M * LDH; float* sS = sX + DEC_M * LDX;
+    constexpr int H1_FLOATS = XG ? 3 * X_PLANE_BYTES / 4 : DEC_M * LDH;
+    __shared__ __attribute__((aligned(16))) float lds[H1_FLOATS + DEC_M * LDX + 8 * DEC_M];
+    float* sH1 = lds; float* sX = lds + H1_FLOATS; float* sS = sX + DEC_M * LDX;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int col = 32 * w + l31;
     const float* W1 = params + NL_OFF_W1;
     const i32x4 rsW2T = make_w_rsrc(W2T);
+    const i32x4 rsW2TX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W2T + NL_DEC_WS_W2TX_OFF), 0, 3 * W2X_PLANE_BYTES, 0x00020000);
     const float b1c = params[NL_OFF_B1 + col], b2c = params[NL_OFF_B2 + col], w3c = params[NL_OFF_W3 + col], b3 = params[NL_OFF_B3];
     float w1r[NL_C / 2];
 #pragma unroll
@@ -713,10 +804,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
             const float* xb = sX + opaque(l31 * LDX + lh);
 #pragma unroll
             for (int kk = 0; kk < NL_C / 2; ++kk) { c0 = MFMA32(xb[2 * kk], w1r[kk], c0); c1 = MFMA32(xb[32 * LDX + 2 * kk], w1r[kk], c1); }
-            float* hb = sH1 + opaque(4 * lh * LDH + col);
+            if (XG) {
+                store_h1_planes(reinterpret_cast<unsigned short*>(lds), col, lh, c0, c1, b1c);
+            } else {
+                float* hb = sH1 + opaque(4 * lh * LDH + col);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                hb[D32_RR(r) * LDH] = fmaxf(c0[r] + b1c, 0.f); hb[(32 + D32_RR(r)) * LDH] = fmaxf(c1[r] + b1c, 0.f);
+                for (int r = 0; r < 16; ++r) {
+                    hb[D32_RR(r) * LDH] = fmaxf(c0[r] + b1c, 0.f); hb[(32 + D32_RR(r)) * LDH] = fmaxf(c1[r] + b1c, 0.f);
+                }
             }
         }
         __syncthreads();
@@ -724,7 +819,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
             f32x16 h0, h1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
-            gemm256(rsW2T, (lh * NL_W + col) * 4, sH1 + l31 * LDH + lh, sH1 + (32 + l31) * LDH + lh, h0, h1);
+            if (XG) gemm_x9(rsW2TX, w, lane, reinterpret_cast<const unsigned char*>(lds), h0, h1);
+            else    gemm256(rsW2T, (lh * NL_W + col) * 4, sH1 + l31 * LDH + lh, sH1 + (32 + l31) * LDH + lh, h0, h1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { h0[r] = fmaxf(h0[r] + b2c, 0.f); h1[r] = fmaxf(h1[r] + b2c, 0.f); }
             const float tot = halfwave_rowsum(h0, h1, w3c, l31);
@@ -765,7 +861,7 @@ __global__ void k_mfma_selftest(const float* A32, const float* B32, float* D32, 
 }
 
 static long long* g_dec_dbg = nullptr;
-static int g_dgrad_mode = 1;             // 0: fp32 MFMA dgrad GEMM, 1: exact 0/1-mask x 3-term bf16 split (gemm_mask_x)
+static int g_gemm_mode = 1;              // 0: fp32 MFMA GEMMs, 1: bf16 MFMA on the exact-product formulations (gemm_x9 / gemm_mask_x)
 static int g_wgrad2_mode = 1;            // 0: fp32 MFMA (k_decoder_wgrad2), 1: exact 0/1-mask x 3-term bf16 split (k_decoder_wgrad2_x)
 
 extern "C" {
@@ -777,10 +873,11 @@ int nl_decoder_set_debug_buffer(void* dbg) { g_dec_dbg = (long long*)dbg; return
  * Same arithmetic class (exact products, fp32 accumulation); selectable for A/B measurements and cross-checks. */
 int nl_decoder_set_wgrad2_mode(int mode) { if (mode < 0 || mode > 1) return NL_ERR_INVALID_ARG; g_wgrad2_mode = mode; return NL_OK; }
 int nl_decoder_get_wgrad2_mode(void) { return g_wgrad2_mode; }
-/* dgrad GEMM (dH1 = dH2 W2) inside the fused decoder kernel: 0 = fp32 matrix cores, 1 = bf16 matrix cores on the exact
- * formulation dH1[i][k] = dsdf_i * sum_j m(i,j) * (w3_j W2[j][k]) (default) */
-int nl_decoder_set_dgrad_mode(int mode) { if (mode < 0 || mode > 1) return NL_ERR_INVALID_ARG; g_dgrad_mode = mode; return NL_OK; }
-int nl_decoder_get_dgrad_mode(void) { return g_dgrad_mode; }
+/* the two 256-deep GEMMs of the fused decoder kernels (forward H1 W2^T, dgrad dH2 W2): 0 = fp32 matrix cores,
+ * 1 = bf16 matrix cores on exact-product formulations (default): forward = both operands split into three bf16 terms, all
+ * nine partial products; dgrad = {0,1} ReLU mask x three-term split of w3_j W2[j][k].  fp32 accumulation in both. */
+int nl_decoder_set_gemm_mode(int mode) { if (mode < 0 || mode > 1) return NL_ERR_INVALID_ARG; g_gemm_mode = mode; return NL_OK; }
+int nl_decoder_get_gemm_mode(void) { return g_gemm_mode; }
 
 int nl_decoder_grid_hint(void)
 {
@@ -804,7 +901,7 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
     a.dcounters = (double*)(counters + NL_CNT_INTS);
     a.dbg = g_dec_dbg;
     const dim3 g(nslabs), b(DEC_THREADS);
-    if (g_dgrad_mode == 1) {
+    if (g_gemm_mode == 1) {
         if (train_decoder) hipLaunchKernelGGL((k_decoder<true, true>), g, b, 0, (hipStream_t)stream, a);
         else               hipLaunchKernelGGL((k_decoder<false, true>), g, b, 0, (hipStream_t)stream, a);
     } else {
@@ -834,7 +931,8 @@ int nl_decoder_forward(const float* X, const float* params, const float* W2T, in
 {
     if (!X || !params || !W2T || !sdf || P < 0 || nblocks <= 0) return NL_ERR_INVALID_ARG;
     if (P == 0) return NL_OK;
-    hipLaunchKernelGGL(k_decoder_fwd, dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
+    if (g_gemm_mode == 1) hipLaunchKernelGGL(k_decoder_fwd<true>, dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
+    else                  hipLaunchKernelGGL(k_decoder_fwd<false>, dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

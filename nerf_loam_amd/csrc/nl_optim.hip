@@ -65,26 +65,31 @@ __global__ void k_transpose_w2(const float* __restrict__ params, float* __restri
     for (int r = threadIdx.y; r < 32; r += blockDim.y) W2T[(bx + r) * NL_W + by + threadIdx.x] = t[threadIdx.x][r];
 }
 
-// W2X: the dgrad B operand w3_j * W2[j][k] split into three bf16 terms (hi + mid + lo == the fp32 product exactly:
-// truncation splits of 8 + 8 + 8 significand bits), in the fragment-major layout gemm_mask_x (nl_decoder.hip) streams:
-// [plane(3)][column tile kt(8)][k-step s(16)][lane(64)][8 bf16], lane = 32 h + n <-> j = 16 s + 8 h + e, k = 32 kt + n.
-__global__ void k_prepare_w2x(const float* __restrict__ params, uint16_t* __restrict__ W2X)
+// bf16 operand planes of the decoder's 256-deep GEMMs (nl_decoder.hip: gemm_x9 / gemm_mask_x), rebuilt with W2T after every
+// optimiser step.  A value v is split by truncation into hi + mid + lo (8 + 8 + 8 significand bits: v == hi + mid + lo
+// exactly, each term a bf16).  Both matrices are stored in MFMA-fragment order so a wave fetches one B fragment with one
+// contiguous 1 KB load:  [plane(3)][column tile t(8)][k-step s(16)][lane(64)][8 bf16],  lane = 32 h + c:
+//     W2X  (dgrad,   dH1 = dH2 W2):    element e <-> j = 16 s + 8 h + e, k = 32 t + c, value w3_j * W2[j][k]
+//     W2TX (forward, H2 = H1 W2^T):    element e <-> k = 16 s + 8 h + e, n = 32 t + c, value W2[n][k]
+__global__ void k_prepare_w2x(const float* __restrict__ params, uint16_t* __restrict__ W2X, uint16_t* __restrict__ W2TX)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;         // one thread per (kt, s, lane)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;         // one thread per (tile, s, lane)
     if (t >= 8 * 16 * 64) return;
-    const int lane = t & 63, s = (t >> 6) & 15, kt = t >> 10;
-    const int k = 32 * kt + (lane & 31), j0 = 16 * s + 8 * (lane >> 5);
-    uint16_t* dst = W2X + (size_t)t * 8;
-    for (int e = 0; e < 8; ++e) {
-        const int j = j0 + e;
-        const float v = params[NL_OFF_W3 + j] * params[NL_OFF_W2 + j * NL_W + k];
-        union { float f; uint32_t u; } a, b, c;
-        a.f = v; a.u &= 0xFFFF0000u;
-        b.f = v - a.f; b.u &= 0xFFFF0000u;
-        c.f = (v - a.f) - b.f;                                   // <= 8 significant bits left: exact in bf16
-        dst[e] = (uint16_t)(a.u >> 16);
-        dst[e + NL_W * NL_W] = (uint16_t)(b.u >> 16);
-        dst[e + 2 * NL_W * NL_W] = (uint16_t)(c.u >> 16);
+    const int lane = t & 63, s = (t >> 6) & 15, tl = t >> 10;
+    const int c = 32 * tl + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
+    for (int which = 0; which < 2; ++which) {
+        uint16_t* dst = (which ? W2TX : W2X) + (size_t)t * 8;
+        for (int e = 0; e < 8; ++e) {
+            const int kk = k0 + e;
+            const float v = which ? params[NL_OFF_W2 + c * NL_W + kk] : params[NL_OFF_W3 + kk] * params[NL_OFF_W2 + kk * NL_W + c];
+            union { float f; uint32_t u; } a, b, r;
+            a.f = v; a.u &= 0xFFFF0000u;
+            b.f = v - a.f; b.u &= 0xFFFF0000u;
+            r.f = (v - a.f) - b.f;                               // <= 8 significant bits left: exact in bf16
+            dst[e] = (uint16_t)(a.u >> 16);
+            dst[e + NL_W * NL_W] = (uint16_t)(b.u >> 16);
+            dst[e + 2 * NL_W * NL_W] = (uint16_t)(r.u >> 16);
+        }
     }
 }
 
@@ -166,7 +171,7 @@ int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream)
     if (!params || !W2T) return NL_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_transpose_w2, dim3(NL_W / 32, NL_W / 32), dim3(32, 8), 0, (hipStream_t)stream, params, W2T);
     hipLaunchKernelGGL(k_prepare_w2x, dim3(8 * 16 * 64 / 256), dim3(256), 0, (hipStream_t)stream, params,
-                       reinterpret_cast<uint16_t*>(W2T + NL_W * NL_W));
+                       reinterpret_cast<uint16_t*>(W2T + NL_W * NL_W), reinterpret_cast<uint16_t*>(W2T + NL_W * NL_W + 3 * NL_W * NL_W / 2));
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

@@ -178,10 +178,10 @@ def backward_mode(nl, request):
     """run a test with the backward GEMMs (dgrad inside the fused kernel, dW2) on the fp32 matrix cores (0) or on the
     bf16 matrix cores via the exact {0,1}-mask x 3-term-split formulation (1, the default)"""
     lib = nl["L"].lib()
-    old = lib.nl_decoder_get_wgrad2_mode(), lib.nl_decoder_get_dgrad_mode()
-    assert lib.nl_decoder_set_wgrad2_mode(request.param) == 0 and lib.nl_decoder_set_dgrad_mode(request.param) == 0
+    old = lib.nl_decoder_get_wgrad2_mode(), lib.nl_decoder_get_gemm_mode()
+    assert lib.nl_decoder_set_wgrad2_mode(request.param) == 0 and lib.nl_decoder_set_gemm_mode(request.param) == 0
     yield request.param
-    lib.nl_decoder_set_wgrad2_mode(old[0]); lib.nl_decoder_set_dgrad_mode(old[1])
+    lib.nl_decoder_set_wgrad2_mode(old[0]); lib.nl_decoder_set_gemm_mode(old[1])
 
 
 @pytest.mark.parametrize("backward_mode", [0, 1], indirect=True)
@@ -357,25 +357,33 @@ def test_full_scan_invariants(nl):
     torch.testing.assert_close(dec.grad, 2 * g1, rtol=1e-4, atol=1e-7 * float(g1.abs().max()))
     rel = (eng.g_emb - 2 * ge1).norm() / (2 * ge1).norm()
     assert float(rel) < 2e-3                                             # bf16-rounded contributions
-    # backward GEMMs on the fp32 matrix cores vs on the bf16 matrix cores (exact {0,1}-mask x 3-term split): the same
-    # sums in a different order
+    # the 256-deep GEMMs on the fp32 matrix cores (mode 0) vs on the bf16 matrix cores via the exact-product formulations
+    # (mode 1): the same sums in a different order.  Within a mode the forward is reproducible bit for bit, and the
+    # forward-only kernel performs the same arithmetic as the fused one.
     lib = nl["L"].lib()
-    old = lib.nl_decoder_get_wgrad2_mode(), lib.nl_decoder_get_dgrad_mode()
+    old = lib.nl_decoder_get_wgrad2_mode(), lib.nl_decoder_get_gemm_mode()
     res = []
     for mode in (0, 1):
-        assert lib.nl_decoder_set_wgrad2_mode(mode) == 0 and lib.nl_decoder_set_dgrad_mode(mode) == 0
+        assert lib.nl_decoder_set_wgrad2_mode(mode) == 0 and lib.nl_decoder_set_gemm_mode(mode) == 0
         eng.g_emb.zero_(); eng.g_pose.zero_()
         eng.forward_backward(m, dec, cfg)
         res.append((P.DecoderDevice.split(dec.grad.cpu().numpy()), eng.dX[:Pn].cpu().numpy().astype(np.float64), eng.sdf[:Pn].cpu().numpy()))
-    lib.nl_decoder_set_wgrad2_mode(old[0]); lib.nl_decoder_set_dgrad_mode(old[1])
-    assert np.array_equal(res[0][2], res[1][2])                                            # forward untouched, and reproducible
-    assert eng.forward_only(m, dec, cfg) == Pn
-    assert np.array_equal(eng.sdf[:Pn].cpu().numpy(), res[0][2])                           # forward-only kernel: same arithmetic
-    assert np.abs(res[0][1]).max() > 0
-    assert np.abs(res[0][1] - res[1][1]).max() <= 2e-6 * np.abs(res[0][1]).max()          # dX: 256-term sums
-    for name in ("W1", "b1", "W2"):                                                        # ~1.1 M terms per element
+        eng.g_emb.zero_(); eng.g_pose.zero_()
+        eng.forward_backward(m, dec, cfg)
+        assert np.array_equal(eng.sdf[:Pn].cpu().numpy(), res[-1][2])                      # reproducible
+        assert eng.forward_only(m, dec, cfg) == Pn
+        assert np.array_equal(eng.sdf[:Pn].cpu().numpy(), res[-1][2])                      # forward-only kernel: same arithmetic
+    lib.nl_decoder_set_wgrad2_mode(old[0]); lib.nl_decoder_set_gemm_mode(old[1])
+    assert np.abs(res[0][2] - res[1][2]).max() <= 2e-6                                     # sdf: |values| ~ 0.1, 256-term sums
+    # dX: a hidden unit whose pre-activation is ~0 can fall on either side of the ReLU under a different summation order
+    # (a handful of the 1.1 M x 256 units), so compare in norm and element-wise on all but a vanishing fraction
+    dx0, dx1 = res[0][1], res[1][1]
+    assert np.abs(dx0).max() > 0
+    assert np.linalg.norm(dx0 - dx1) <= 1e-3 * np.linalg.norm(dx0)                        # ~1e2 flipped units of 2.8e8
+    assert (np.abs(dx0 - dx1) > 2e-5 * np.abs(dx0).max()).mean() < 1e-4
+    for name in ("W1", "b1", "W2", "b2", "W3"):                                            # ~1.1 M terms per element
         g0, g1 = res[0][0][name].astype(np.float64), res[1][0][name].astype(np.float64)
-        assert np.abs(g0).max() > 0 and np.abs(g0 - g1).max() <= 2e-5 * np.abs(g0).max(), name
+        assert np.abs(g0).max() > 0 and np.abs(g0 - g1).max() <= 5e-5 * np.abs(g0).max(), name
 
 
 def test_intersect_cap_and_overflow_paths(nl):
