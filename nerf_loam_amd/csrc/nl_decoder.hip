@@ -146,7 +146,8 @@ __device__ __forceinline__ void gemm_mask_x(i32x4 rsX, int w, int lane, const un
 {
     const int l31 = lane & 31, lh = lane >> 5;
     const int voff = lane * 16;
-    const int kt_off = w * 16 * 1024;                    // this wave's column tile
+    const int kt_off = __builtin_amdgcn_readfirstlane(w) * 16 * 1024;     // this wave's column tile; provably wave-uniform, or every
+                                                                          // load below becomes a waterfall loop over soffset
     const unsigned char* a0 = sM + opaque(l31 * (SM_STRIDE * 2) + 16 * lh);
     constexpr int RING = 4;                              // B fragments run RING-1 k-steps (6 MFMAs each) ahead: L2 latency
     uint4 bq[RING][3], aq[2][2];
@@ -188,7 +189,7 @@ __device__ __forceinline__ void gemm_x9(i32x4 rsX, int w, int lane, const unsign
 {
     const int l31 = lane & 31, lh = lane >> 5;
     const int voff = lane * 16;
-    const int nt_off = w * 16 * 1024;
+    const int nt_off = __builtin_amdgcn_readfirstlane(w) * 16 * 1024;     // wave-uniform scalar offset (no waterfall loops)
     const unsigned char* a0 = sP + opaque(l31 * (SM_STRIDE * 2) + 16 * lh);
     constexpr int RING = 3;                              // B fragments 2 k-steps (36 MFMAs) ahead
     uint4 bq[RING][3], aq[2][2][3];
@@ -446,8 +447,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (XG) {
-                    g0v[r] = ((m1 >> r) & 1u) ? g0v[r] * dsb[D32_RR(r)] : 0.f;
-                    g1v[r] = ((m1 >> (16 + r)) & 1u) ? g1v[r] * dsb[32 + D32_RR(r)] : 0.f;
+                    const float d0 = dsb[D32_RR(r)], d1 = dsb[32 + D32_RR(r)];           // unconditional loads: no exec-mask branches
+                    g0v[r] *= ((m1 >> r) & 1u) ? d0 : 0.f;                              // select on the factor: v_cndmask, no branch
+                    g1v[r] *= ((m1 >> (16 + r)) & 1u) ? d1 : 0.f;
                 } else {
                     g0v[r] = hb[D32_RR(r) * LDH] > 0.f ? g0v[r] : 0.f;
                     g1v[r] = hb[(32 + D32_RR(r)) * LDH] > 0.f ? g1v[r] : 0.f;
