@@ -41,11 +41,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // LDS carve (floats)
 #define S_H1 0
 #define S_D (S_H1 + DEC_M * LDH)
-#define S_X (S_D + DEC_M * LDH)
-#define S_W1 (S_X + DEC_M * LDX)
+#define S_X (S_D + DEC_M * LDH)                         // two X tiles (double-buffered across tiles)
+#define S_W1 (S_X + 2 * DEC_M * LDX)
 #define S_S (S_W1 + NL_W * NL_C)
 #define S_DS (S_S + 8 * DEC_M)                          // sS: per-wave partial row sums [8][64] (fixed-order reduce)
-#define S_TOTAL (S_DS + DEC_M)
+#define S_TOTAL (S_DS + 8 * DEC_M)                      // sdS: one copy of the tile's dL/dsdf per wave
 
 struct DecArgs {
     const NlLossScalars* ls;
@@ -142,17 +142,34 @@ __device__ __forceinline__ uint4 bload4(i32x4 rsrc, int voff_bytes, int soff_byt
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_bytes, soff_bytes, 0));
 }
 
-__device__ __forceinline__ void gemm_mask_x(i32x4 rsX, int w, int lane, const unsigned char* sM, f32x16& c0, f32x16& c1)
+#define MX_RING 6                                       // B fragments run MX_RING-1 k-steps (6 MFMAs = 192 pipe cycles each) ahead
+#define MX_PRE 2                                        // of which this many are issued before the barrier (register budget)
+// first MX_PRE stages of the B stream: independent of the tile, so issued BEFORE the barrier that publishes the mask
+__device__ __forceinline__ void gemm_mask_x_prefetch(i32x4 rsX, int w, int lane, uint4 (&bq)[MX_RING][3])
+{
+    const int voff = lane * 16;
+    const int kt_off = __builtin_amdgcn_readfirstlane(w) * 16 * 1024;
+#pragma unroll
+    for (int s = 0; s < MX_PRE; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[s][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + kt_off + s * 1024);
+}
+
+template <bool PIN>                                     // PIN: hold the software pipeline in place with scheduling barriers.  Without them
+                                                        // the scheduler sinks every prefetch to just before its use (vmcnt(0) after each
+                                                        // load); with them the trainable-decoder kernel, which is at the 256-VGPR limit,
+                                                        // spills ~40 registers - so it is enabled where registers allow (frozen / forward)
+__device__ __forceinline__ void gemm_mask_x(i32x4 rsX, int w, int lane, const unsigned char* sM, uint4 (&bq)[MX_RING][3], f32x16& c0, f32x16& c1)
 {
     const int l31 = lane & 31, lh = lane >> 5;
     const int voff = lane * 16;
     const int kt_off = __builtin_amdgcn_readfirstlane(w) * 16 * 1024;     // this wave's column tile; provably wave-uniform, or every
                                                                           // load below becomes a waterfall loop over soffset
     const unsigned char* a0 = sM + opaque(l31 * (SM_STRIDE * 2) + 16 * lh);
-    constexpr int RING = 4;                              // B fragments run RING-1 k-steps (6 MFMAs each) ahead: L2 latency
-    uint4 bq[RING][3], aq[2][2];
+    constexpr int RING = MX_RING;
+    uint4 aq[2][2];
 #pragma unroll
-    for (int s = 0; s < RING - 1; ++s)
+    for (int s = MX_PRE; s < RING - 1; ++s)
 #pragma unroll
         for (int p = 0; p < 3; ++p) bq[s][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + kt_off + s * 1024);
     aq[0][0] = *reinterpret_cast<const uint4*>(a0); aq[0][1] = *reinterpret_cast<const uint4*>(a0 + 32 * SM_STRIDE * 2);
@@ -166,12 +183,58 @@ __device__ __forceinline__ void gemm_mask_x(i32x4 rsX, int w, int lane, const un
             aq[(s + 1) & 1][0] = *reinterpret_cast<const uint4*>(a0 + 32 * (s + 1));
             aq[(s + 1) & 1][1] = *reinterpret_cast<const uint4*>(a0 + 32 * SM_STRIDE * 2 + 32 * (s + 1));
         }
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
         const bf16x8 fa0 = __builtin_bit_cast(bf16x8, aq[s & 1][0]), fa1 = __builtin_bit_cast(bf16x8, aq[s & 1][1]);
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const bf16x8 fb = __builtin_bit_cast(bf16x8, bq[s % RING][p]);
             c0 = MFMA_BF16(fa0, fb, c0); c1 = MFMA_BF16(fa1, fb, c1);
         }
+    }
+}
+
+// Rolled variant for the trainable-decoder kernel (no scheduling barriers, so no spills at its 256-VGPR limit): the k-steps go
+// through a rolled loop in pairs with two register buffers, like gemm256 - a load issued in one half of the body cannot be
+// sunk below the MFMAs of that half because its consumers sit in the other half.  bq[0], bq[1] arrive preloaded.
+__device__ __forceinline__ void gemm_mask_x_rolled(i32x4 rsX, int w, int lane, const unsigned char* sM, uint4 (&bq)[MX_RING][3], f32x16& c0, f32x16& c1)
+{
+    static_assert(MX_PRE == 2, "the rolled loop consumes the two pre-barrier stages as its first buffer");
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int voff = lane * 16;
+    const int kt_off = __builtin_amdgcn_readfirstlane(w) * 16 * 1024;
+    const unsigned char* a0 = sM + opaque(l31 * (SM_STRIDE * 2) + 16 * lh);
+    uint4 bA[2][3], bB[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bA[t][p] = bq[t][p];
+    auto steps2 = [&](const uint4 (&b)[2][3], const unsigned char* ap) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const bf16x8 fa0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + 32 * t));
+            const bf16x8 fa1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + 32 * SM_STRIDE * 2 + 32 * t));
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const bf16x8 fb = __builtin_bit_cast(bf16x8, b[t][p]);
+                c0 = MFMA_BF16(fa0, fb, c0); c1 = MFMA_BF16(fa1, fb, c1);
+            }
+        }
+    };
+#pragma unroll 1
+    for (int s = 0; s < 16; s += 4) {
+        const int so = kt_off + s * 1024;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bB[t][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + so + (2 + t) * 1024);
+        steps2(bA, a0 + 32 * s);
+        if (s + 4 < 16) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bA[t][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + so + (4 + t) * 1024);
+        }
+        steps2(bB, a0 + 32 * (s + 2));
     }
 }
 
@@ -185,44 +248,49 @@ __device__ __forceinline__ void gemm_mask_x(i32x4 rsX, int w, int lane, const un
 #define X_PLANE_BYTES (X_PLANE_ELEMS * 2)
 #define NL_DEC_WS_W2TX_OFF (NL_DEC_WS_W2X_OFF + 3 * NL_W * NL_W / 2)       // floats
 
-__device__ __forceinline__ void gemm_x9(i32x4 rsX, int w, int lane, const unsigned char* sP, f32x16& c0, f32x16& c1)
+#define X9_RING 3                                       // B fragments 2 k-steps (18 MFMAs = 576 pipe cycles each) ahead
+__device__ __forceinline__ void gemm_x9_prefetch(i32x4 rsX, int w, int lane, uint4 (&bq)[X9_RING][3])
+{
+    const int voff = lane * 16;
+    const int nt_off = __builtin_amdgcn_readfirstlane(w) * 16 * 1024;
+#pragma unroll
+    for (int s = 0; s < X9_RING - 1; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[s][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + nt_off + s * 1024);
+}
+
+template <bool PIN>
+__device__ __forceinline__ void gemm_x9(i32x4 rsX, int w, int lane, const unsigned char* sP, uint4 (&bq)[X9_RING][3], f32x16& c0, f32x16& c1)
 {
     const int l31 = lane & 31, lh = lane >> 5;
     const int voff = lane * 16;
     const int nt_off = __builtin_amdgcn_readfirstlane(w) * 16 * 1024;     // wave-uniform scalar offset (no waterfall loops)
     const unsigned char* a0 = sP + opaque(l31 * (SM_STRIDE * 2) + 16 * lh);
-    constexpr int RING = 3;                              // B fragments 2 k-steps (36 MFMAs) ahead
-    uint4 bq[RING][3], aq[2][2][3];
+    constexpr int RING = X9_RING;
+    // 48 groups of 6 MFMAs: group g = (k-step s = g / 3, A plane pa = 2 - g % 3) x (3 B planes x 2 row tiles).  The A fragments
+    // of the NEXT group are read from LDS while this group's MFMAs run (192 pipe cycles > LDS latency): 16 registers of A
+    // instead of 48 for a whole k-step ahead.
+    uint4 aq[2][2];
+    aq[0][0] = *reinterpret_cast<const uint4*>(a0 + 2 * X_PLANE_BYTES);
+    aq[0][1] = *reinterpret_cast<const uint4*>(a0 + 2 * X_PLANE_BYTES + 32 * SM_STRIDE * 2);
 #pragma unroll
-    for (int s = 0; s < RING - 1; ++s)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) bq[s][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + nt_off + s * 1024);
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        aq[0][0][p] = *reinterpret_cast<const uint4*>(a0 + p * X_PLANE_BYTES);
-        aq[0][1][p] = *reinterpret_cast<const uint4*>(a0 + p * X_PLANE_BYTES + 32 * SM_STRIDE * 2);
-    }
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        if (s + RING - 1 < 16) {
+    for (int g = 0; g < 48; ++g) {
+        const int s = g / 3;
+        if (g % 3 == 0 && s + RING - 1 < 16) {
 #pragma unroll
             for (int p = 0; p < 3; ++p) bq[(s + RING - 1) % RING][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + nt_off + (s + RING - 1) * 1024);
         }
-        if (s + 1 < 16) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                aq[(s + 1) & 1][0][p] = *reinterpret_cast<const uint4*>(a0 + p * X_PLANE_BYTES + 32 * (s + 1));
-                aq[(s + 1) & 1][1][p] = *reinterpret_cast<const uint4*>(a0 + p * X_PLANE_BYTES + 32 * SM_STRIDE * 2 + 32 * (s + 1));
-            }
+        if (g + 1 < 48) {
+            const int sn = (g + 1) / 3, pn = 2 - (g + 1) % 3;
+            aq[(g + 1) & 1][0] = *reinterpret_cast<const uint4*>(a0 + pn * X_PLANE_BYTES + 32 * sn);
+            aq[(g + 1) & 1][1] = *reinterpret_cast<const uint4*>(a0 + pn * X_PLANE_BYTES + 32 * SM_STRIDE * 2 + 32 * sn);
         }
+        if (PIN) __builtin_amdgcn_sched_barrier(0);      // pin the prefetches above this group's MFMAs (see gemm_mask_x)
+        const bf16x8 fa0 = __builtin_bit_cast(bf16x8, aq[g & 1][0]), fa1 = __builtin_bit_cast(bf16x8, aq[g & 1][1]);
 #pragma unroll
         for (int pb = 2; pb >= 0; --pb) {
             const bf16x8 fb = __builtin_bit_cast(bf16x8, bq[s % RING][pb]);
-#pragma unroll
-            for (int pa = 2; pa >= 0; --pa) {
-                c0 = MFMA_BF16(__builtin_bit_cast(bf16x8, aq[s & 1][0][pa]), fb, c0);
-                c1 = MFMA_BF16(__builtin_bit_cast(bf16x8, aq[s & 1][1][pa]), fb, c1);
-            }
+            c0 = MFMA_BF16(fa0, fb, c0); c1 = MFMA_BF16(fa1, fb, c1);
         }
     }
 }
@@ -286,14 +354,16 @@ template <bool TRAIN, bool XG>                          // XG: both 256-deep GEM
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[S_TOTAL];
-    // XG: the three bf16 planes of H1 occupy the first 101 KB; the bf16 mask tile (phases E/F) and then the fp32 dH1 tile
-    // (phases H/I) alias them once the forward GEMM has consumed them
-    float* sH1 = lds + S_H1; float* sD = XG ? lds : lds + S_D; float* sX = lds + S_X; float* sW1 = lds + S_W1;
-    float* sS = lds + S_S; float* sdS = lds + S_DS;
+    // XG: the three bf16 planes of H1 occupy the first 101 KB.  Once the forward GEMM has consumed them, the bf16 mask
+    // tile (phases E/F) aliases plane 0 and the fp32 dH1 tile (phases H/I) aliases planes 1-2: F reads and H writes
+    // never overlap, so no barrier separates them.
+    float* sH1 = lds + S_H1; float* sD = XG ? lds + X_PLANE_BYTES / 4 : lds + S_D; float* sW1 = lds + S_W1;
+    float* sS = lds + S_S;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5, l15 = lane & 15, lq = lane >> 4;
     const int col = 32 * w + l31;                 // this lane's output column in 32x32 tiles
+    float* sdS = lds + S_DS + DEC_M * w;          // this WAVE's copy of the tile's dL/dsdf (written and read by the same wave)
     const NlLossScalars ls = *a.ls;
     const int P = ls.P;
     const int ntiles = (P + DEC_M - 1) / DEC_M;
@@ -314,40 +384,40 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
     }
     for (int i = tid; i < NL_W * NL_C; i += DEC_THREADS) sW1[i] = a.params[NL_OFF_W1 + i];
 
-    // software prefetch of the next tile's inputs (X slice; loss inputs for the 64 sample-owner threads)
+    // software prefetch of the next tile's inputs: the X slice (2 floats per thread) and the loss inputs of row `lane`
+    // (every wave keeps its own copy: the loss gradient is recomputed per wave, which removes a workgroup barrier)
     const int xe = tid * 2, xi = xe >> 4, xc = xe & 15;
     float2 xv = make_float2(0.f, 0.f);
     float pz = 0.f, pd = 0.f;
-    {
-        const int row0 = blockIdx.x * DEC_M;
-        if (blockIdx.x < ntiles && row0 + xi < P) xv = *reinterpret_cast<const float2*>(a.X + (size_t)(row0 + xi) * NL_C + xc);
-        if (tid < DEC_M && blockIdx.x < ntiles && row0 + tid < P) {
-            const int ray = a.s_ray[row0 + tid];
-            pz = a.s_depth[row0 + tid] * a.cos_gt[ray]; pd = a.gt_dist[ray];
+    auto prefetch = [&](int tile) {
+        const int row0 = tile * DEC_M;
+        xv = make_float2(0.f, 0.f); pz = 0.f; pd = 0.f;
+        if (tile < ntiles) {
+            if (row0 + xi < P) xv = *reinterpret_cast<const float2*>(a.X + (size_t)(row0 + xi) * NL_C + xc);
+            if (row0 + lane < P) {
+                const int ray = a.s_ray[row0 + lane];
+                pz = a.s_depth[row0 + lane] * a.cos_gt[ray]; pd = a.gt_dist[ray];
+            }
         }
+    };
+    prefetch(blockIdx.x);
+    {   // phase A of the first tile: X -> LDS buffer 0
+        float* sX = lds + S_X;
+        sX[xi * LDX + xc] = xv.x; sX[xi * LDX + xc + 1] = xv.y;
     }
+    float cz = pz, cd = pd;
+    prefetch(blockIdx.x + gridDim.x);
     __syncthreads();
 
     int tile_no = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++tile_no) {
         const int row0 = tile * DEC_M;
+        float* sX = lds + S_X + (tile_no & 1) * (DEC_M * LDX);
         DBG_STAMP(0);
-        // ---------------- A: X tile -> LDS ; issue the next tile's loads ----------------
-        sX[xi * LDX + xc] = xv.x; sX[xi * LDX + xc + 1] = xv.y;
-        const float cz = pz, cd = pd;
-        {
-            const int nrow0 = (tile + gridDim.x) * DEC_M;
-            xv = make_float2(0.f, 0.f);
-            if (nrow0 + xi < P) xv = *reinterpret_cast<const float2*>(a.X + (size_t)(nrow0 + xi) * NL_C + xc);
-            if (tid < DEC_M && nrow0 + tid < P) {
-                const int ray = a.s_ray[nrow0 + tid];
-                pz = a.s_depth[nrow0 + tid] * a.cos_gt[ray]; pd = a.gt_dist[ray];
-            }
-        }
-        __syncthreads();
         DBG_STAMP(1);
         // ---------------- B: H1 = relu(X W1^T + b1) ----------------
         unsigned m1 = 0u;                               // XG: this lane's 32 ReLU bits of H1
+        uint4 bq9[X9_RING][3];
         {
             f32x16 c0, c1;
 #pragma unroll
@@ -360,6 +430,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
                 c0 = MFMA32(xb[2 * kk], bw, c0); c1 = MFMA32(xb[32 * LDX + 2 * kk], bw, c1);
             }
             if (XG) {
+                gemm_x9_prefetch(rsW2TX, w, lane, bq9);          // W2 planes of the first k-steps: in flight across the barrier
                 m1 = store_h1_planes(reinterpret_cast<unsigned short*>(lds), col, lh, c0, c1, b1c);
             } else {
                 float* hb = sH1 + opaque(4 * lh * LDH + col);
@@ -377,7 +448,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
-            if (XG) gemm_x9(rsW2TX, w, lane, reinterpret_cast<const unsigned char*>(lds), h0, h1);
+            if (XG) gemm_x9<true>(rsW2TX, w, lane, reinterpret_cast<const unsigned char*>(lds), bq9, h0, h1);
             else    gemm256(rsW2T, (lh * NL_W + col) * 4, sH1 + l31 * LDH + lh, sH1 + (32 + l31) * LDH + lh, h0, h1);
             DBG_STAMP(3);
 #pragma unroll
@@ -387,28 +458,33 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         }
         __syncthreads();
         DBG_STAMP(4);
-        // ---------------- D: sdf, loss gradient (criterion.py) ----------------
-        if (tid < DEC_M) {
-            const int g = row0 + tid;
+        // ---------------- D: sdf, loss gradient (criterion.py): every wave computes all 64 rows (lane = row) for itself;
+        //                  wave 0 owns the global outputs and the loss sums ----------------
+        {
+            const int g = row0 + lane;
             float ds = 0.f;
             if (g < P) {
-                float s = sS[tid];                              // fixed summation order: run-to-run reproducible sdf
+                float s = sS[lane];                             // fixed summation order: run-to-run reproducible sdf
 #pragma unroll
-                for (int ww = 1; ww < 8; ++ww) s += sS[ww * DEC_M + tid];
+                for (int ww = 1; ww < 8; ++ww) s += sS[ww * DEC_M + lane];
                 s += b3;
                 bool f, m;
                 nl_loss_masks(cz, cd, ls.tau, ls.max_depth, &f, &m);
                 float q1, q2;
                 ds = nl_loss_grad(s, cz, cd, f, m, ls, &q1, &q2);
-                a.sdf[g] = s; a.dsdf[g] = ds;
-                lossFs += (double)q1; lossSdf += (double)q2;
+                if (w == 0) {
+                    a.sdf[g] = s; a.dsdf[g] = ds;
+                    lossFs += (double)q1; lossSdf += (double)q2;
+                }
             }
-            sdS[tid] = ds;
-            if (TRAIN) aB3 += ds;
+            sdS[lane] = ds;
+            if (TRAIN && w == 0) aB3 += ds;
+            __builtin_amdgcn_wave_barrier();                    // same-wave LDS write -> read: in order, keep the compiler from reordering
         }
-        __syncthreads();
         DBG_STAMP(5);
         // ---------------- E: dH2 = ds * w3 * [H2 > 0] -> LDS ----------------
+        uint4 bqm[MX_RING][3];
+        if (XG) gemm_mask_x_prefetch(rsW2X, w, lane, bqm);
         {
             unsigned mw = 0u;                       // this lane's 32 ReLU bits: bit r = h0[r] > 0, bit 16+r = h1[r] > 0
             const float* dsb = sdS + opaque(4 * lh);
@@ -439,8 +515,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { g0v[r] = 0.f; g1v[r] = 0.f; }
-            if (XG) gemm_mask_x(rsW2X, w, lane, reinterpret_cast<const unsigned char*>(lds), g0v, g1v);
-            else     gemm256(rsW2, (lh * NL_W + col) * 4, sD + l31 * LDH + lh, sD + (32 + l31) * LDH + lh, g0v, g1v);
+            if (XG && TRAIN) gemm_mask_x_rolled(rsW2X, w, lane, reinterpret_cast<const unsigned char*>(lds), bqm, g0v, g1v);
+            else if (XG)     gemm_mask_x<true>(rsW2X, w, lane, reinterpret_cast<const unsigned char*>(lds), bqm, g0v, g1v);
+            else    gemm256(rsW2, (lh * NL_W + col) * 4, sD + l31 * LDH + lh, sD + (32 + l31) * LDH + lh, g0v, g1v);
             DBG_STAMP(7);
             const float* dsb = sdS + opaque(4 * lh);
             const float* hb = sH1 + opaque(4 * lh * LDH + col);
@@ -457,9 +534,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
                 if (TRAIN) aB1 += g0v[r] + g1v[r];
             }
         }
-        __syncthreads();
+        if (!XG) __syncthreads();                       // fp32 path: dH1 overwrites the dH2 tile other waves may still be reading
         DBG_STAMP(8);
-        // ---------------- H: dH1 -> LDS (over dH2) ----------------
+        // ---------------- H: dH1 -> LDS ----------------
         {
             float* db = sD + opaque(4 * lh * LDH + col);
 #pragma unroll
@@ -492,6 +569,13 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
                 for (int t = 0; t < 4; ++t)
                     accW1[t] = MFMA16(dr[4 * ii * LDH + 16 * t], xb, accW1[t]);
             }
+        }
+        // ---------------- A (next tile): X -> the other LDS buffer; issue the loads of the tile after it ----------------
+        {
+            float* sXn = lds + S_X + ((tile_no + 1) & 1) * (DEC_M * LDX);
+            sXn[xi * LDX + xc] = xv.x; sXn[xi * LDX + xc + 1] = xv.y;
+            cz = pz; cd = pd;
+            prefetch(tile + 2 * gridDim.x);
         }
         __syncthreads();
         DBG_STAMP(10);
@@ -799,6 +883,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
             sX[i * LDX + c] = v.x; sX[i * LDX + c + 1] = v.y;
         }
         __syncthreads();
+        uint4 bq9[X9_RING][3];
         {
             f32x16 c0, c1;
 #pragma unroll
@@ -807,6 +892,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
 #pragma unroll
             for (int kk = 0; kk < NL_C / 2; ++kk) { c0 = MFMA32(xb[2 * kk], w1r[kk], c0); c1 = MFMA32(xb[32 * LDX + 2 * kk], w1r[kk], c1); }
             if (XG) {
+                gemm_x9_prefetch(rsW2TX, w, lane, bq9);
                 store_h1_planes(reinterpret_cast<unsigned short*>(lds), col, lh, c0, c1, b1c);
             } else {
                 float* hb = sH1 + opaque(4 * lh * LDH + col);
@@ -821,7 +907,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
             f32x16 h0, h1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
-            if (XG) gemm_x9(rsW2TX, w, lane, reinterpret_cast<const unsigned char*>(lds), h0, h1);
+            if (XG) gemm_x9<true>(rsW2TX, w, lane, reinterpret_cast<const unsigned char*>(lds), bq9, h0, h1);
             else    gemm256(rsW2T, (lh * NL_W + col) * 4, sH1 + l31 * LDH + lh, sH1 + (32 + l31) * LDH + lh, h0, h1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { h0[r] = fmaxf(h0[r] + b2c, 0.f); h1[r] = fmaxf(h1[r] + b2c, 0.f); }
