@@ -175,6 +175,7 @@ int nl_octree_export(void* h, float* voxels, float* children, int* features);   
 int nl_octree_export_device_layout(void* h, float voxel_size, float* centres, int* structure, int* vertex_idx); /* + mapping.py:319-327 */
 
 /* profiling aid: 256 x int64 device buffer receiving per-phase shader-clock stamps of workgroup 0 (NULL = off) */
+int nl_field_set_debug_buffer(void* dbg);      /* [blocks][8] int64 stamps of nl_trilinear_bwd's workgroups */
 int nl_decoder_set_debug_buffer(void* dbg);
 /* MFMA lane-map self test (debug) */
 int nl_mfma_selftest(const float* A32, const float* B32, float* D32, const float* A16, const float* B16, float* D16, void* stream);

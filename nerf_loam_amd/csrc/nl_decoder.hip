@@ -925,14 +925,25 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
     }
 }
 
-// sum per-workgroup partial slabs: out[i] = sum_b partials[b][i]
-__global__ void k_reduce_partials(const float* __restrict__ partials, int nslabs, int n, float* __restrict__ out)
+// sum per-workgroup partial slabs: out[i] = sum_b partials[b][i].  HBM-bound (nslabs x n floats in): 64 columns per block,
+// 4 slab groups per column, 4 independent accumulators per thread (16 loads in flight), fixed combination order.
+__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partials, int nslabs, int n, float* __restrict__ out)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int b = 0; b < nslabs; ++b) s += partials[(size_t)b * n + i];
-    out[i] = s;
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        const float* p = partials + i;
+        int b = g;
+        for (; b + 12 < nslabs; b += 16) {
+            s0 += p[(size_t)b * n]; s1 += p[(size_t)(b + 4) * n]; s2 += p[(size_t)(b + 8) * n]; s3 += p[(size_t)(b + 12) * n];
+        }
+        for (; b < nslabs; b += 4) s0 += p[(size_t)b * n];
+    }
+    red[g][c] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && i < n) out[i] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 // MFMA layout self-test: D = A(32x2) B(2x32) and D = A(16x4) B(4x16) written row-major using the lane
@@ -1028,7 +1039,7 @@ int nl_decoder_forward(const float* X, const float* params, const float* W2T, in
 int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, void* stream)
 {
     if (!partials || !out || nslabs <= 0 || n <= 0) return NL_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_reduce_partials, dim3(nl_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, partials, nslabs, n, out);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nl_div_up(n, 64)), dim3(256), 0, (hipStream_t)stream, partials, nslabs, n, out);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

@@ -31,7 +31,9 @@ struct FieldArgs {
     int n_frames;
     int want_emb_grad;
     int want_pose_grad;
+    long long* dbg;                 // optional [blocks][8] s_memtime stamps of thread 0 (profiling aid, k_trilinear_bwd)
 };
+#define FSTAMP(k) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 struct SampleGeom { float p[3]; float depth; int ray; int vox; };
 
@@ -118,18 +120,25 @@ __global__ __launch_bounds__(NL_FIELD_THREADS) void k_gather_points(int P, const
 // bf16 rounding in the optimiser = torch's CUDA embedding_dense_backward semantics), and
 // dL/dx = (1/vs) * d/dp sum_k w_k <e_k, dX>  ->  dt += dx, dR += depth * dx (x) d_sensor.
 //
-// The scatter is the HBM-atomic hot spot (8 rows x 16 channels per sample = 140 M fp32 atomics for one
-// 64x2048 scan).  Samples are packed in ray order, so a chunk of consecutive samples touches few
-// distinct vertex rows: each workgroup aggregates a 1024-sample chunk in an LDS hash table
-// (open addressing on the row id, ds_add_f32 accumulation; a lane pair pre-accumulates each voxel run of its 8
-// consecutive samples in registers) and flushes every touched row once with global atomics - ~40x fewer HBM atomics.  Table overflow falls back to direct global atomics.
-#define TB_CHUNK 1024
-#define TB_SLOTS 1024
+// The scatter is the atomic hot spot (8 rows x 16 channels per sample = 140 M fp32 adds for one 64x2048 scan).
+// Samples are packed in ray order, so consecutive samples mostly stay in one voxel and a chunk of consecutive samples
+// touches few distinct vertex rows (~200 per 1024 samples).  Layout: EIGHT lanes per sample, one per voxel corner - every
+// lane owns one embedding row at a time: its 16-channel contribution accumulates in registers over the voxel run, the
+// row id and the bf16 row (pose gradient) are loaded once per run, and the lanes of a wave do uniform work (the previous
+// 2-lanes-per-sample layout looped over the 8 corners per lane: 174 VGPRs, 2 waves/SIMD, 41 k cycles per sample).  A
+// group of 8 lanes walks 32 consecutive samples; runs are flushed into a per-workgroup LDS hash table (open addressing on
+// the row id, ds_add_f32) and every touched row leaves once per chunk with global atomics.  Table overflow falls back
+// to direct global atomics.
+#define TB_SLOTS 512
+#define TB_STRIDE (NL_C + 1)                             // floats per table slot: with 16, channel c of EVERY slot sits in one of 4 banks
+                                                        // and a wave's ds_add_f32 on channel c serialises 16-fold
 #define TB_PROBES 16
+#define TB_GROUPS (NL_FIELD_THREADS / 8)                 // 8-lane groups per workgroup
+#define TB_MIN_SPAN 256                                 // samples per workgroup: at least this many (aggregation), else P / grid
 
 __device__ __forceinline__ int tb_insert(int* s_key, int key)
 {
-    unsigned h = ((unsigned)key * 2654435761u) >> 22;          // top 10 bits -> [0, 1024)
+    unsigned h = ((unsigned)key * 2654435761u) >> 23;          // top 9 bits -> [0, 512)
 #pragma unroll 1
     for (int i = 0; i < TB_PROBES; ++i) {
         const int prev = atomicCAS(&s_key[h], -1, key);
@@ -139,82 +148,97 @@ __device__ __forceinline__ int tb_insert(int* s_key, int key)
     return -1;
 }
 
-__global__ __launch_bounds__(NL_FIELD_THREADS) void k_trilinear_bwd(FieldArgs a)
+__global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float s_val[TB_SLOTS * NL_C];
+    __shared__ __attribute__((aligned(16))) float s_val[TB_SLOTS * TB_STRIDE];
     __shared__ int s_key[TB_SLOTS];
     __shared__ float s_pose[NL_MAX_FRAMES * 12];
     for (int i = threadIdx.x; i < a.n_frames * 12; i += NL_FIELD_THREADS) s_pose[i] = 0.f;
     for (int i = threadIdx.x; i < TB_SLOTS; i += NL_FIELD_THREADS) s_key[i] = -1;
-    for (int i = threadIdx.x; i < TB_SLOTS * NL_C; i += NL_FIELD_THREADS) s_val[i] = 0.f;
+    for (int i = threadIdx.x; i < TB_SLOTS * TB_STRIDE; i += NL_FIELD_THREADS) s_val[i] = 0.f;
+    FSTAMP(0);
     __syncthreads();
+    FSTAMP(1);
     const int P = a.ls->P;
-    const int half = threadIdx.x & 1;
-    const int pair = threadIdx.x >> 1;
-    const int nchunks = (P + TB_CHUNK - 1) / TB_CHUNK;
-    float pa[12]; int pf = -1;                                  // running pose partials of this lane's current frame
+    const int k = threadIdx.x & 7;                              // this lane's voxel corner
+    const int grp = threadIdx.x >> 3;
+    const int lane0 = (threadIdx.x & 63) & ~7;                  // first lane of the group inside its wave
+    // the P samples are split EVENLY over the workgroups (one span each, one table flush each): with fixed-size chunks
+    // P = 1.05 x grid x chunk would send 5 % of the workgroups through a second chunk and double the kernel's time
+    int per_group = (P + (int)gridDim.x * TB_GROUPS - 1) / ((int)gridDim.x * TB_GROUPS);
+    if (per_group * TB_GROUPS < TB_MIN_SPAN) per_group = TB_MIN_SPAN / TB_GROUPS;
+    const int span = per_group * TB_GROUPS;
+    const int nchunks = (P + span - 1) / span;
+    float pa[12]; int pf = -1;                                  // running pose partials (corner-0 lane) of the current frame
 #pragma unroll
     for (int i = 0; i < 12; ++i) pa[i] = 0.f;
     for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        const int s_end = min(P, (chunk + 1) * TB_CHUNK);
-        // a lane pair walks 8 CONSECUTIVE samples: consecutive samples of a ray mostly stay in one voxel, so the
-        // 8 corner rows' contributions accumulate in registers and reach the LDS table once per voxel run
-        int cur_vox = -1; int rows[8];
-        float acc[8][8];
+        const int s_end = min(P, (chunk + 1) * span);
+        int cur_vox = -1, row = -1;
+        float acc[NL_C];
+        unsigned eb[NL_C / 2];                                      // this lane's embedding row, packed bf16 pairs (pose gradient)
+#pragma unroll
+        for (int c = 0; c < NL_C; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NL_C / 2; ++c) eb[c] = 0u;
         auto flush_run = [&]() {
-            if (cur_vox < 0 || !a.want_emb_grad) return;
+            if (row < 0 || !a.want_emb_grad) return;
+            const int slot = tb_insert(s_key, row);
+            if (slot >= 0) {                    // (two separately typed pointers: one merged generic pointer would make these flat atomics)
+                float* dst = s_val + slot * TB_STRIDE;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int slot = tb_insert(s_key, rows[k]);
-                if (slot >= 0) {
-                    float* dst = s_val + slot * NL_C + 8 * half;
+                for (int c = 0; c < NL_C; ++c) atomicAdd(dst + c, acc[c]);                      // ds_add_f32
+            } else {
+                float* dst = a.g_emb + (size_t)row * NL_C;
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) atomicAdd(dst + c, acc[k][c]);                  // ds_add_f32
-                } else {
-                    float* dst = a.g_emb + (size_t)rows[k] * NL_C + 8 * half;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) atomicAdd(dst + c, acc[k][c]);                  // global_atomic_add_f32
-                }
+                for (int c = 0; c < NL_C; ++c) atomicAdd(dst + c, acc[c]);                      // global_atomic_add_f32
             }
         };
-        const int s_base = chunk * TB_CHUNK + pair * (TB_CHUNK / (NL_FIELD_THREADS / 2));
+        const int s_base = chunk * span + grp * per_group;
 #pragma unroll 1
-        for (int j = 0; j < TB_CHUNK / (NL_FIELD_THREADS / 2); ++j) {
+        for (int j = 0; j < per_group; ++j) {
             const int s = s_base + j;
-            if (s >= s_end) break;                                  // both lanes of a pair share s: shuffles stay convergent
+            if (s >= s_end) break;                                  // the 8 lanes of a group share s: shuffles stay convergent
             const SampleGeom g = sample_geom(a, s);
-            float w[8]; nl_trilinear_w(g.p, w);
             if (g.vox != cur_vox) {
                 flush_run();
-                cur_vox = g.vox; load_rows(a, g.vox, rows);
+                cur_vox = g.vox;
+                row = a.vertex_rows[8 * (size_t)g.vox + k];
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) acc[k][c] = 0.f;
-            }
-            float d[8];
-            const float4* di = reinterpret_cast<const float4*>(a.dX + (size_t)s * NL_C + 8 * half);
-            const float4 d0 = di[0], d1 = di[1];
-            d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
-            float dot[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (a.want_emb_grad) {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) acc[k][c] += nl_round_bf16(w[k] * d[c]);
-                }
+                for (int c = 0; c < NL_C; ++c) acc[c] = 0.f;
                 if (a.want_pose_grad) {
-                    float e[8]; load_emb8(a.emb, rows[k], half, e);
-                    float t = 0.f;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) t += e[c] * d[c];
-                    dot[k] = t;
+                    const uint4* er = reinterpret_cast<const uint4*>(a.emb + (size_t)row * NL_C);
+                    const uint4 v0 = er[0], v1 = er[1];
+                    eb[0] = v0.x; eb[1] = v0.y; eb[2] = v0.z; eb[3] = v0.w; eb[4] = v1.x; eb[5] = v1.y; eb[6] = v1.z; eb[7] = v1.w;
                 }
+            }
+            float w[8]; nl_trilinear_w(g.p, w);
+            float wk = w[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) wk = (k == i) ? w[i] : wk;
+            float d[NL_C];
+            {
+                const float4* di = reinterpret_cast<const float4*>(a.dX + (size_t)s * NL_C);
+                const float4 d0 = di[0], d1 = di[1], d2 = di[2], d3 = di[3];
+                d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
+                d[8] = d2.x; d[9] = d2.y; d[10] = d2.z; d[11] = d2.w; d[12] = d3.x; d[13] = d3.y; d[14] = d3.z; d[15] = d3.w;
+            }
+            if (a.want_emb_grad) {
+#pragma unroll
+                for (int c = 0; c < NL_C; ++c) acc[c] += nl_round_bf16(wk * d[c]);
             }
             if (!a.want_pose_grad) continue;
+            float t0 = 0.f, t1 = 0.f;                               // <e_k, dX>: same association as the 2-halves version (8 + 8, then add)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) dot[k] += __shfl_xor(dot[k], 1);
-            if (half != 0) continue;
+            for (int c = 0; c < 4; ++c) {
+                t0 += __uint_as_float(eb[c] << 16) * d[2 * c];                 t0 += __uint_as_float(eb[c] & 0xFFFF0000u) * d[2 * c + 1];
+                t1 += __uint_as_float(eb[4 + c] << 16) * d[8 + 2 * c];         t1 += __uint_as_float(eb[4 + c] & 0xFFFF0000u) * d[8 + 2 * c + 1];
+            }
+            const float dotk = t0 + t1;
+            float dot[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dot[i] = __shfl(dotk, lane0 + i);
+            if (k != 0) continue;
             float dp[3]; nl_trilinear_dp(g.p, dot, dp);
             const int f = a.frame_id ? a.frame_id[g.ray] : 0;
             if (f != pf) {
@@ -232,21 +256,26 @@ __global__ __launch_bounds__(NL_FIELD_THREADS) void k_trilinear_bwd(FieldArgs a)
                 pa[3 + 3 * i] += t * ds0; pa[4 + 3 * i] += t * ds1; pa[5 + 3 * i] += t * ds2;
             }
         }
+        FSTAMP(2);
         flush_run();
+        FSTAMP(3);
         if (a.want_emb_grad) {
             __syncthreads();
+            FSTAMP(4);
             // flush: 16 lanes per slot (one channel each), touched rows only; slot is reset for the next chunk
             for (int base = 0; base < TB_SLOTS; base += NL_FIELD_THREADS / NL_C) {
                 const int slot = base + (threadIdx.x >> 4), c = threadIdx.x & 15;
                 const int key = s_key[slot];
                 if (key >= 0) {
-                    const float v = s_val[slot * NL_C + c];
+                    const float v = s_val[slot * TB_STRIDE + c];
                     if (v != 0.f) atomicAdd(a.g_emb + (size_t)key * NL_C + c, v);
-                    s_val[slot * NL_C + c] = 0.f;
+                    s_val[slot * TB_STRIDE + c] = 0.f;
                     if (c == 0) s_key[slot] = -1;
                 }
             }
+            FSTAMP(5);
             __syncthreads();
+            FSTAMP(6);
         }
     }
     if (a.want_pose_grad) {
@@ -271,12 +300,15 @@ __global__ void k_unpack_samples(const NlLossScalars* ls, const int* s_ray, cons
     }
 }
 
+static long long* g_field_dbg = nullptr;
+
 extern "C" {
 
 static int fill_args(FieldArgs& a, const void* ls, const int* s_vox, const float* s_depth, const int* s_ray,
                      const float* rays_d_world, const float* rays_d_sensor, const int* frame_id, const float* poses, int n_frames,
                      const float* centres, const int* vertex_rows, const void* emb, float voxel_size)
 {
+    a.dbg = nullptr;
     if (!ls || !s_vox || !s_depth || !s_ray || !rays_d_world || !poses || !centres || !vertex_rows || !emb) return NL_ERR_INVALID_ARG;
     if (n_frames <= 0 || n_frames > NL_MAX_FRAMES) return NL_ERR_INVALID_ARG;
     a.ls = (const NlLossScalars*)ls; a.s_vox = s_vox; a.s_depth = s_depth; a.s_ray = s_ray; a.rays_d_world = rays_d_world;
@@ -312,6 +344,9 @@ int nl_gather_points(int P, const float* xyz, const int* vox, const float* centr
     return NL_OK;
 }
 
+/* profiling aid: device buffer [nblocks][8] int64 receiving s_memtime stamps of k_trilinear_bwd (NULL disables) */
+int nl_field_set_debug_buffer(void* dbg) { g_field_dbg = (long long*)dbg; return NL_OK; }
+
 int nl_trilinear_bwd(const void* loss_scalars, const int* s_vox, const float* s_depth, const int* s_ray,
                      const float* rays_d_world, const float* rays_d_sensor, const int* frame_id, const float* poses, int n_frames,
                      const float* centres, const int* vertex_rows, const void* emb, float voxel_size,
@@ -321,6 +356,7 @@ int nl_trilinear_bwd(const void* loss_scalars, const int* s_vox, const float* s_
     int rc = fill_args(a, loss_scalars, s_vox, s_depth, s_ray, rays_d_world, rays_d_sensor, frame_id, poses, n_frames, centres, vertex_rows, emb, voxel_size);
     if (rc != NL_OK || !dX || nblocks <= 0 || (g_pose && !rays_d_sensor)) return NL_ERR_INVALID_ARG;
     a.dX = dX; a.g_emb = g_emb; a.g_pose = g_pose; a.want_emb_grad = g_emb != nullptr; a.want_pose_grad = g_pose != nullptr;
+    a.dbg = g_field_dbg;
     hipLaunchKernelGGL(k_trilinear_bwd, dim3(nblocks), dim3(NL_FIELD_THREADS), 0, (hipStream_t)stream, a);
     NL_LAUNCH_CHECK();
     return NL_OK;
