@@ -120,28 +120,29 @@ __global__ __launch_bounds__(NL_FIELD_THREADS) void k_gather_points(int P, const
 // bf16 rounding in the optimiser = torch's CUDA embedding_dense_backward semantics), and
 // dL/dx = (1/vs) * d/dp sum_k w_k <e_k, dX>  ->  dt += dx, dR += depth * dx (x) d_sensor.
 //
-// The scatter is the atomic hot spot (8 rows x 16 channels per sample = 140 M fp32 adds for one 64x2048 scan).
-// Samples are packed in ray order, so consecutive samples mostly stay in one voxel and a chunk of consecutive samples
-// touches few distinct vertex rows (~200 per 1024 samples).  Layout: EIGHT lanes per sample, one per voxel corner - every
-// lane owns one embedding row at a time: its 16-channel contribution accumulates in registers over the voxel run, the
-// row id and the bf16 row (pose gradient) are loaded once per run, and the lanes of a wave do uniform work (the previous
-// 2-lanes-per-sample layout looped over the 8 corners per lane: 174 VGPRs, 2 waves/SIMD, 41 k cycles per sample).  A
-// group of 8 lanes walks 32 consecutive samples; runs are flushed into a per-workgroup LDS hash table (open addressing on
-// the row id, ds_add_f32) and every touched row leaves once per chunk with global atomics.  Table overflow falls back
-// to direct global atomics.
-#define TB_SLOTS 512
-#define TB_STRIDE (NL_C + 1)                             // floats per table slot: with 16, channel c of EVERY slot sits in one of 4 banks
-                                                        // and a wave's ds_add_f32 on channel c serialises 16-fold
+// The scatter is the hot spot (8 rows x 16 channels per sample = 140 M fp32 adds for one 64x2048 scan).  Samples are
+// packed in ray order, so consecutive samples mostly stay in one voxel and a span of consecutive samples touches few
+// distinct vertex rows.  Layout: EIGHT lanes per sample, one per voxel corner - every lane owns one embedding row at a
+// time: its 16-channel contribution accumulates in registers over the voxel run, the row id and the bf16 row (pose
+// gradient) are loaded once per run, and the lanes of a wave do uniform work.  A group of 8 lanes walks ~32 consecutive
+// samples; finished runs go into an LDS hash table (open addressing on the row id) that is PRIVATE TO THE WAVE and
+// updated WITHOUT float atomics: LDS executes a wave's instructions in order, the 8 corner rows of one voxel are
+// distinct, so adding one 8-lane group at a time (read 16 floats, add, write back) is race-free.  ds_add_f32 retires
+// about one lane per cycle per CU: the atomic version of this kernel spent 220 of its 380 us in them (measured by
+// swapping them for plain read-modify-writes).  Every touched row leaves the table once per span with global
+// atomics; table overflow falls back to direct global atomics.
+#define TB_WAVES (NL_FIELD_THREADS / 64)
+#define TB_SLOTS 128                                    // per wave
 #define TB_PROBES 16
 #define TB_GROUPS (NL_FIELD_THREADS / 8)                 // 8-lane groups per workgroup
 #define TB_MIN_SPAN 256                                 // samples per workgroup: at least this many (aggregation), else P / grid
 
 __device__ __forceinline__ int tb_insert(int* s_key, int key)
 {
-    unsigned h = ((unsigned)key * 2654435761u) >> 23;          // top 9 bits -> [0, 512)
+    unsigned h = ((unsigned)key * 2654435761u) >> 25;          // top 7 bits -> [0, 128)
 #pragma unroll 1
     for (int i = 0; i < TB_PROBES; ++i) {
-        const int prev = atomicCAS(&s_key[h], -1, key);
+        const int prev = atomicCAS(&s_key[h], -1, key);         // lanes of this wave racing for a slot (integer CAS: cheap)
         if (prev == -1 || prev == key) return (int)h;
         h = (h + 1) & (TB_SLOTS - 1);
     }
@@ -150,19 +151,23 @@ __device__ __forceinline__ int tb_insert(int* s_key, int key)
 
 __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float s_val[TB_SLOTS * TB_STRIDE];
-    __shared__ int s_key[TB_SLOTS];
+    __shared__ __attribute__((aligned(16))) float s_val_all[TB_WAVES * TB_SLOTS * NL_C];
+    __shared__ int s_key_all[TB_WAVES * TB_SLOTS];
     __shared__ float s_pose[NL_MAX_FRAMES * 12];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* s_val = s_val_all + wv * TB_SLOTS * NL_C;            // this wave's table
+    int* s_key = s_key_all + wv * TB_SLOTS;
     for (int i = threadIdx.x; i < a.n_frames * 12; i += NL_FIELD_THREADS) s_pose[i] = 0.f;
-    for (int i = threadIdx.x; i < TB_SLOTS; i += NL_FIELD_THREADS) s_key[i] = -1;
-    for (int i = threadIdx.x; i < TB_SLOTS * TB_STRIDE; i += NL_FIELD_THREADS) s_val[i] = 0.f;
+    for (int i = lane; i < TB_SLOTS; i += 64) s_key[i] = -1;
+    for (int i = lane; i < TB_SLOTS * NL_C; i += 64) s_val[i] = 0.f;
     FSTAMP(0);
     __syncthreads();
     FSTAMP(1);
     const int P = a.ls->P;
     const int k = threadIdx.x & 7;                              // this lane's voxel corner
     const int grp = threadIdx.x >> 3;
-    const int lane0 = (threadIdx.x & 63) & ~7;                  // first lane of the group inside its wave
+    const int gw = lane >> 3;                                   // group index inside the wave
+    const int lane0 = lane & ~7;                                // first lane of the group inside its wave
     // the P samples are split EVENLY over the workgroups (one span each, one table flush each): with fixed-size chunks
     // P = 1.05 x grid x chunk would send 5 % of the workgroups through a second chunk and double the kernel's time
     int per_group = (P + (int)gridDim.x * TB_GROUPS - 1) / ((int)gridDim.x * TB_GROUPS);
@@ -181,27 +186,47 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
         for (int c = 0; c < NL_C; ++c) acc[c] = 0.f;
 #pragma unroll
         for (int c = 0; c < NL_C / 2; ++c) eb[c] = 0u;
-        auto flush_run = [&]() {
-            if (row < 0 || !a.want_emb_grad) return;
-            const int slot = tb_insert(s_key, row);
-            if (slot >= 0) {                    // (two separately typed pointers: one merged generic pointer would make these flat atomics)
-                float* dst = s_val + slot * TB_STRIDE;
+        // add this lane's finished run (row, acc) into the wave's table; `flush` may differ per 8-lane group but is uniform
+        // inside a group.  All 64 lanes call it together.
+        auto flush_run = [&](bool flush) {
+            flush = flush && row >= 0 && a.want_emb_grad;
+            const unsigned long long fm = __ballot(flush);
+            if (fm == 0ull) return;
+            int slot = -1;
+            if (flush) {
+                slot = tb_insert(s_key, row);
+                if (slot < 0) {                                     // table full: straight to memory
+                    float* dst = a.g_emb + (size_t)row * NL_C;
 #pragma unroll
-                for (int c = 0; c < NL_C; ++c) atomicAdd(dst + c, acc[c]);                      // ds_add_f32
-            } else {
-                float* dst = a.g_emb + (size_t)row * NL_C;
-#pragma unroll
-                for (int c = 0; c < NL_C; ++c) atomicAdd(dst + c, acc[c]);                      // global_atomic_add_f32
+                    for (int c = 0; c < NL_C; ++c) atomicAdd(dst + c, acc[c]);
+                }
+            }
+#pragma unroll 1
+            for (int gi = 0; gi < 8; ++gi) {                         // one group at a time: same-row updates of different groups stay ordered
+                if (((fm >> (8 * gi)) & 0xFFull) == 0ull) continue;
+                if (gw == gi && slot >= 0) {
+                    float4* dst = reinterpret_cast<float4*>(s_val + slot * NL_C);
+                    float4 v0 = dst[0], v1 = dst[1], v2 = dst[2], v3 = dst[3];
+                    v0.x += acc[0]; v0.y += acc[1]; v0.z += acc[2]; v0.w += acc[3];
+                    v1.x += acc[4]; v1.y += acc[5]; v1.z += acc[6]; v1.w += acc[7];
+                    v2.x += acc[8]; v2.y += acc[9]; v2.z += acc[10]; v2.w += acc[11];
+                    v3.x += acc[12]; v3.y += acc[13]; v3.z += acc[14]; v3.w += acc[15];
+                    dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
+                }
+                __builtin_amdgcn_wave_barrier();                    // keep the groups' read-modify-writes in program order
             }
         };
         const int s_base = chunk * span + grp * per_group;
 #pragma unroll 1
         for (int j = 0; j < per_group; ++j) {
             const int s = s_base + j;
-            if (s >= s_end) break;                                  // the 8 lanes of a group share s: shuffles stay convergent
-            const SampleGeom g = sample_geom(a, s);
-            if (g.vox != cur_vox) {
-                flush_run();
+            const bool live = s < s_end;                            // the 8 lanes of a group share s; dead groups keep calling flush_run
+            if (__ballot(live) == 0ull) break;
+            SampleGeom g;
+            if (live) g = sample_geom(a, s); else { g.vox = cur_vox; g.ray = 0; g.depth = 0.f; g.p[0] = g.p[1] = g.p[2] = 0.f; }
+            const bool change = live && g.vox != cur_vox;
+            flush_run(change);
+            if (change) {
                 cur_vox = g.vox;
                 row = a.vertex_rows[8 * (size_t)g.vox + k];
 #pragma unroll
@@ -212,6 +237,7 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
                     eb[0] = v0.x; eb[1] = v0.y; eb[2] = v0.z; eb[3] = v0.w; eb[4] = v1.x; eb[5] = v1.y; eb[6] = v1.z; eb[7] = v1.w;
                 }
             }
+            if (!live) continue;
             float w[8]; nl_trilinear_w(g.p, w);
             float wk = w[0];
 #pragma unroll
@@ -228,7 +254,7 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
                 for (int c = 0; c < NL_C; ++c) acc[c] += nl_round_bf16(wk * d[c]);
             }
             if (!a.want_pose_grad) continue;
-            float t0 = 0.f, t1 = 0.f;                               // <e_k, dX>: same association as the 2-halves version (8 + 8, then add)
+            float t0 = 0.f, t1 = 0.f;                               // <e_k, dX>: 8 + 8 channels, then add
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 t0 += __uint_as_float(eb[c] << 16) * d[2 * c];                 t0 += __uint_as_float(eb[c] & 0xFFFF0000u) * d[2 * c + 1];
@@ -257,25 +283,22 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
             }
         }
         FSTAMP(2);
-        flush_run();
+        flush_run(true);
         FSTAMP(3);
         if (a.want_emb_grad) {
-            __syncthreads();
-            FSTAMP(4);
-            // flush: 16 lanes per slot (one channel each), touched rows only; slot is reset for the next chunk
-            for (int base = 0; base < TB_SLOTS; base += NL_FIELD_THREADS / NL_C) {
-                const int slot = base + (threadIdx.x >> 4), c = threadIdx.x & 15;
+            // flush this wave's table: 16 lanes per slot (one channel each), touched rows only; slots are reset for the next span
+            for (int base = 0; base < TB_SLOTS; base += 4) {
+                const int slot = base + (lane >> 4), c = lane & 15;
                 const int key = s_key[slot];
                 if (key >= 0) {
-                    const float v = s_val[slot * TB_STRIDE + c];
+                    const float v = s_val[slot * NL_C + c];
                     if (v != 0.f) atomicAdd(a.g_emb + (size_t)key * NL_C + c, v);
-                    s_val[slot * TB_STRIDE + c] = 0.f;
-                    if (c == 0) s_key[slot] = -1;
+                    s_val[slot * NL_C + c] = 0.f;
                 }
             }
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < TB_SLOTS; i += 64) s_key[i] = -1;
             FSTAMP(5);
-            __syncthreads();
-            FSTAMP(6);
         }
     }
     if (a.want_pose_grad) {

@@ -307,7 +307,7 @@ class SdfEngine:
             ops.reduce_partials(self.partials, self.n_slabs, L.NL_DEC_PARAMS, dec.grad)
         ops.trilinear_bwd(self.loss_scalars, self.s_vox, self.s_depth, self.s_ray, self.rays_d_world, self.rays_d_sensor, self.frame_id,
                           self.poses12, self.F, m.centres, m.vertex_rows, m.emb, m.voxel_size, self.dX,
-                          self.g_emb if want_emb_grad else None, self.g_pose if want_pose_grad else None, self.field_blocks)
+                          self.g_emb if want_emb_grad else None, self.g_pose if want_pose_grad else None, 2 * self.field_blocks)
         if self.hook_after_backward is not None:
             self.hook_after_backward(self, dec, train_decoder, want_emb_grad, want_pose_grad)
 
