@@ -77,6 +77,15 @@ int nl_ray_intersect(int N, const float* rays_d_sensor, const float* points_gt, 
 int nl_exclusive_scan_i32(const int* in, int* out, int n, int flag_mode, int* total_out, int* workspace, void* stream);
 int nl_compact_hit_rays(int N, const int* hit_count, const int* hit_rank, int* ray_of_rank, void* stream);
 
+/* On-device ray selection (LidarFrame.sample_rays -> sampling_without_replacement, src/lidarFrame.py:55-57,
+ * src/utils/sample_util.py:4-19): a uniformly random subset of n_select of the frame's M returns, kept in dataset order,
+ * gathered into out_*[0..n_select) (out_frame_id, mask_out optional; mask_out[M] = the reference's boolean sample_mask).
+ * Deterministic in (seed, M, n_select).  workspace >= NL_SELECT_WS_INTS(M) ints. */
+#define NL_SELECT_WS_INTS(M) (264 + 2 * (M) + ((M) + 1023) / 1024 + 8)
+int nl_select_rays(int M, int n_select, unsigned seed, const float* rays_d, const float* points, const float* cos_in, int frame,
+                   float* out_rays_d, float* out_points, float* out_cos, int* out_frame_id, unsigned char* mask_out,
+                   int* workspace, void* stream);
+
 /* ray_sample: voxel_helpers.py:571-598 + :262-347 + sample_gpu.cu:133-239.
  * emit = 0: per-ray sample count, S_max and the geometry-only loss normalisers (criterion.py:67-88);
  * emit = 1: compacted (voxel, depth, dist, ray) records at samp_off[ray] (capacity-checked).

@@ -54,6 +54,13 @@ NL_HD float nl_noise(uint32_t seed, uint32_t ray, uint32_t step) {
     return u < 0.001f ? 0.001f : (u > 0.999f ? 0.999f : u);
 }
 
+// ray-selection key (nl_select.hip): lowbias32 is a bijection on 32-bit integers, so keys of distinct rays never tie
+NL_HD uint32_t nl_select_key(uint32_t seed, uint32_t i) {
+    uint32_t x = i ^ (seed * 0x9E3779B9u + 0x7F4A7C15u);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
 // ---------------------------------------------------------------------------------------------
 // ray / cube slab test.  Returns true on hit.
 // ---------------------------------------------------------------------------------------------

@@ -67,5 +67,16 @@ class LidarFrame(nn.Module):
         return (self.points / self.rays_norm).unsqueeze(1).float()
 
     @torch.no_grad()
+    def device_scan(self, device):
+        """the frame's returns resident on `device` (cached): input of SdfEngine.select_rays (on-device ray selection)"""
+        sc = getattr(self, "_device_scan", None)
+        if sc is None or sc["dirs"].device != torch.device(device):
+            sc = dict(dirs=self.rays_d.reshape(-1, 3).float().contiguous().to(device),
+                      points=self.points.reshape(-1, 3).float().contiguous().to(device),
+                      cos=self.pointsCos.reshape(-1).float().contiguous().to(device))
+            self._device_scan = sc
+        return sc
+
+    @torch.no_grad()
     def sample_rays(self, N_rays, track=False):
         self.sample_mask = sample_rays(torch.ones((self.num_point, 1))[None, ...], N_rays)[0, ...]

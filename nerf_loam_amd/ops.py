@@ -149,3 +149,9 @@ def pose_step(pose6, g_pose, m, v, enable, grad6_out, poses12, state, apply):
 
 def mfma_selftest(A32, B32, D32, A16, B16, D16):
     check(L.lib().nl_mfma_selftest(ptr(A32), ptr(B32), ptr(D32), ptr(A16), ptr(B16), ptr(D16), stream_ptr()), "nl_mfma_selftest")
+
+
+def select_rays(M, n_select, seed, rays_d, points, cos_in, frame, out_rays_d, out_points, out_cos, out_frame_id, mask_out, workspace):
+    check(L.lib().nl_select_rays(int(M), int(n_select), int(seed) & 0xFFFFFFFF, ptr(rays_d), ptr(points), ptr(cos_in), int(frame),
+                                 ptr(out_rays_d), ptr(out_points), ptr(out_cos), ptr(out_frame_id), ptr(mask_out), ptr(workspace),
+                                 stream_ptr()), "nl_select_rays")

@@ -237,6 +237,30 @@ class SdfEngine:
         else:
             self.frame_id[:n].copy_(torch.as_tensor(frame_id, dtype=I32), non_blocking=True)
 
+    def select_rays(self, scans, n_rays, seed, want_masks=False):
+        """On-device ray selection (LidarFrame.sample_rays, lidarFrame.py:55-57): for every frame in `scans`
+        (dicts of DEVICE tensors dirs [M,3], points [M,3], cos [M]) a uniformly random subset of n_rays returns, dataset
+        order kept, gathered straight into the engine's ray buffers - no host RNG, no top-k on the CPU, no H2D copy.
+        Deterministic in (seed, M, n_rays).  Returns the boolean masks (device) when want_masks."""
+        total = 0
+        masks = []
+        for f, sc in enumerate(scans):
+            M = int(sc["dirs"].shape[0])
+            n = min(int(n_rays), M)
+            if total + n > self.N_cap:
+                raise L.NerfLoamHipError(f"{total + n} rays exceed engine capacity {self.N_cap}")
+            need = 264 + 2 * M + (M + 1023) // 1024 + 8
+            if getattr(self, "_sel_ws", None) is None or self._sel_ws.numel() < need:
+                self._sel_ws = torch.empty(need, dtype=I32, device=self.dev)
+            mask = torch.empty(M, dtype=torch.uint8, device=self.dev) if want_masks else None
+            ops.select_rays(M, n, (int(seed) * 1000003 + f) & 0xFFFFFFFF, sc["dirs"], sc["points"], sc["cos"], f,
+                            self.rays_d_sensor[total:], self.points_gt[total:], self.cos_gt[total:], self.frame_id[total:],
+                            mask, self._sel_ws)
+            masks.append(mask)
+            total += n
+        self.N = total
+        return masks if want_masks else None
+
     def set_poses(self, pose6, optimise=None):
         """pose6 [F,6] = (t, w) like se3pose.OptimizablePose.data; optimise[f] = pose is in the optimiser."""
         p = torch.as_tensor(np.asarray(pose6, np.float32)).reshape(-1, 6)

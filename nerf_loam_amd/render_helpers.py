@@ -21,6 +21,10 @@ from .pipeline import DecoderDevice, IterConfig, MapDevice, SdfEngine
 
 _ENGINES = {}
 
+# "host": rays are re-drawn every iteration with the reference's Gumbel top-k on the CPU generator (a seeded run picks the
+# rays the reference would pick on its CPU path); "device": nl_select_rays - same distribution, no host work, no H2D copies
+RAY_SELECTION = "host"
+
 
 def _engine(n_rays, n_frames, device):
     key = (str(device), int(n_rays), max(2, int(n_frames)))
@@ -64,6 +68,16 @@ def _gather_rays(frames, N_rays, track=False):
     return torch.cat(d).float(), torch.cat(p).float(), torch.cat(c).float(), torch.cat(f)
 
 
+def _set_rays(eng, frames, N_rays, track=False):
+    if RAY_SELECTION == "device":
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        masks = eng.select_rays([fr.device_scan(eng.dev) for fr in frames], N_rays, seed, want_masks=True)
+        for fr, mk in zip(frames, masks):
+            fr.sample_mask = mk.bool().reshape(-1, 1)
+    else:
+        eng.set_rays(*_gather_rays(frames, N_rays, track=track))
+
+
 def _usable(eng):
     st = eng.stats()                                      # one small D2H read: the reference syncs far more often
     return st["R"] > 0 and st["P"] > 0 and not st["guard"] and not st["overflow"], st
@@ -86,7 +100,7 @@ def bundle_adjust_frames(keyframe_graph, embeddings, map_states, sdf_network, lo
     if profiler is not None:
         profiler.tok("mapping_add_optim")
     for it in range(num_iterations):
-        eng.set_rays(*_gather_rays(keyframe_graph, N_rays))
+        _set_rays(eng, keyframe_graph, N_rays)
         eng.forward_backward(m, dec, cfg, train_decoder=update_decoder, want_emb_grad=True, want_pose_grad=any(optimise))
         ok, _ = _usable(eng)
         if not ok:
@@ -118,7 +132,7 @@ def track_frame(frame_pose, curr_frame, map_states, sdf_network, loss_criteria, 
     eng.begin_call(m, None)
     hit_mask = None
     for it in range(num_iterations):
-        eng.set_rays(*_gather_rays([curr_frame], N_rays, track=True))
+        _set_rays(eng, [curr_frame], N_rays, track=True)
         eng.forward_backward(m, dec, cfg, train_decoder=False, want_emb_grad=False, want_pose_grad=True)
         ok, _ = _usable(eng)
         if not ok:

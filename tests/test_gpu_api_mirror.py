@@ -77,6 +77,82 @@ def test_mapping_then_tracking_like_the_reference_loop():
     assert 0.9 < float(out.hit_ratio) <= 1.0
 
 
+def _select_key_np(seed, n):
+    """numpy restatement of nl_select_key (nl_device_math.h): lowbias32(i ^ (seed * 0x9E3779B9 + 0x7F4A7C15))"""
+    x = np.arange(n, dtype=np.uint64) ^ np.uint64((seed * 0x9E3779B9 + 0x7F4A7C15) & 0xFFFFFFFF)
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7FEB352D)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846CA68B)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    return x
+
+
+@pytest.mark.parametrize("M,n", [(131072, 2048), (4097, 4096), (1000, 1), (300, 300), (50, 80), (70000, 35000)])
+def test_device_ray_selection_is_the_exact_top_n_subset(M, n):
+    """nl_select_rays: exactly n distinct rays, dataset order, == the n largest keys of a bijective hash"""
+    from nerf_loam_amd import pipeline as P
+    rng = np.random.default_rng(M)
+    dirs = rng.normal(size=(M, 3)).astype(np.float32); pts = rng.normal(size=(M, 3)).astype(np.float32); cos = rng.random(M).astype(np.float32)
+    sc = dict(dirs=torch.from_numpy(dirs).cuda(), points=torch.from_numpy(pts).cuda(), cos=torch.from_numpy(cos).cuda())
+    eng = P.SdfEngine(max_rays=2 * min(n, M) + 8, samples_per_ray_cap=4)
+    seed = 12345
+    masks = eng.select_rays([sc, sc], n, seed, want_masks=True)
+    k = min(n, M)
+    assert eng.N == 2 * k
+    for f in range(2):
+        keys = _select_key_np((seed * 1000003 + f) & 0xFFFFFFFF, M)
+        assert len(np.unique(keys)) == M                                    # bijection: no ties
+        want = np.zeros(M, bool); want[np.argsort(keys)[M - k:]] = True
+        got = masks[f].cpu().numpy().astype(bool)
+        assert got.sum() == k and np.array_equal(got, want)
+        sl = slice(f * k, (f + 1) * k)
+        assert np.array_equal(eng.rays_d_sensor[sl].cpu().numpy(), dirs[want])   # dataset order kept
+        assert np.array_equal(eng.points_gt[sl].cpu().numpy(), pts[want])
+        assert np.array_equal(eng.cos_gt[sl].cpu().numpy(), cos[want])
+        assert (eng.frame_id[sl].cpu().numpy() == f).all()
+    # different seeds give different, equally sized subsets; every ray is picked about n/M of the time
+    if M == 131072:
+        hits = np.zeros(M)
+        for sd in range(40):
+            mk = eng.select_rays([sc], n, sd, want_masks=True)[0].cpu().numpy()
+            assert mk.sum() == n
+            hits += mk
+        assert abs(hits.mean() - 40 * n / M) < 1e-9 and hits.max() <= 8     # Binomial(40, 1/64): P(> 8) ~ 1e-8 per ray
+
+
+def test_mapping_and_tracking_with_device_ray_selection():
+    """the reference loop with rays re-drawn ON THE DEVICE every iteration (render_helpers.RAY_SELECTION = "device")"""
+    from nerf_loam_amd import render_helpers as RH
+    from nerf_loam_amd.lidar_frame import LidarFrame
+    from nerf_loam_amd.mapping import Mapping
+    from nerf_loam_amd.tracking import Tracking
+    torch.manual_seed(5)
+    pts, cos = H.scene_points(64, 64, 11)
+    args = make_args()
+    old = RH.RAY_SELECTION
+    RH.RAY_SELECTION = "device"
+    try:
+        mapper = Mapping(args)
+        f0 = LidarFrame(0, torch.from_numpy(pts), torch.from_numpy(cos), np.eye(4))
+        mapper.create_voxels(f0)
+        share = Namespace(decoder=None, states=None)
+        emb_before = mapper.dynamic_embeddings.clone()
+        for _ in range(3):
+            mapper.do_mapping(share, f0, selection_method="current")
+        assert f0.sample_mask is not None and f0.sample_mask.is_cuda and int(f0.sample_mask.sum()) == 1024
+        assert not torch.equal(emb_before, mapper.dynamic_embeddings)
+        tracker = Tracking(args)
+        P4 = np.eye(4); P4[:3, 3] = [0.06, -0.05, 0.02]
+        f1 = LidarFrame(1, torch.from_numpy(pts), torch.from_numpy(cos), P4)
+        err0 = float((f1.pose.translation().detach() - f0.pose.translation().detach()).norm())
+        tracker.last_frame = f1
+        f2 = LidarFrame(2, torch.from_numpy(pts), torch.from_numpy(cos), np.eye(4))
+        out = tracker.do_tracking(share, f2)
+        err1 = float((out.pose.translation().detach() - f0.pose.translation().detach()).norm())
+        assert err1 < 0.8 * err0, (err0, err1)                            # 10 refinement steps on freshly drawn rays pull the pose back
+    finally:
+        RH.RAY_SELECTION = old
+
+
 def test_get_scores_matches_oracle():
     """mesh-time dense SDF grid (reference render_helpers.get_scores): HIP gather + decoder forward vs the oracle"""
     from nerf_loam_amd.decoder import Decoder
