@@ -169,6 +169,22 @@ def pose_refine_bench(w, device, steps=200):
             one()
         torch.cuda.synchronize()
         out[f"ms_per_step_{mode}"] = (time.perf_counter() - t0) / steps * 1e3
+    # the reference's track_frame re-draws its 2048 rays every iteration (LidarFrame.sample_rays on the CPU + H2D copy):
+    # same step with the rays re-drawn on the device from the resident scan (nl_select_rays)
+    scan = dict(dirs=torch.from_numpy(np.ascontiguousarray(w["dirs"])).to(device), points=torch.from_numpy(np.ascontiguousarray(w["points"])).to(device),
+                cos=torch.from_numpy(np.ascontiguousarray(w["cos"])).to(device))
+    def one_sel(k):
+        eng.select_rays([scan], 2048, k)
+        eng.forward_backward(w["map"], w["dec"], cfg, train_decoder=False, want_emb_grad=False, want_pose_grad=True)
+        eng.optimiser_step(w["map"], w["dec"], cfg, update_emb=False, update_decoder=False, update_pose=True, lr_pose=0.005 / 3)
+    for k in range(10):
+        one_sel(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        one_sel(100 + k)
+    torch.cuda.synchronize()
+    out["ms_per_step_eager_with_device_ray_selection"] = (time.perf_counter() - t0) / steps * 1e3
     st = eng.stats()
     out.update(rays=2048, valid_samples=st["P"], step_size_m=0.04)
     return out

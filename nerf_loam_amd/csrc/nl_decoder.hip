@@ -546,13 +546,26 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         DBG_STAMP(9);
         // ---------------- I: waves 0-3: dX[16 rows each] = dH1 W1 -> global ; waves 4-7: dW1 += dH1^T X ----------------
         if (w < 4) {
+            // 64 MFMA16 in two accumulator chains; operands double-buffered 8 k-steps ahead through a rolled loop (an unrolled
+            // loop lets the scheduler sink every ds_read to just before its MFMA and the chain stalls on LDS latency)
             f32x4 cxa = {0.f, 0.f, 0.f, 0.f}, cxb = {0.f, 0.f, 0.f, 0.f};
             const float* ap = sD + opaque((16 * w + l15) * LDH + lq);
             const float* bq = sW1 + opaque(lq * NL_C + l15);
-#pragma unroll 8
-            for (int q = 0; q < NL_W / 4; q += 2) {
-                cxa = MFMA16(ap[4 * q], bq[4 * q * NL_C], cxa);
-                cxb = MFMA16(ap[4 * q + 4], bq[(4 * q + 4) * NL_C], cxb);
+            float aA[8], bA[8], aB[8], bB[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { aA[i] = ap[4 * i]; bA[i] = bq[4 * i * NL_C]; }
+#pragma unroll 1
+            for (int q = 0; q < NL_W / 4; q += 16) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { aB[i] = ap[4 * (q + 8 + i)]; bB[i] = bq[4 * (q + 8 + i) * NL_C]; }
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) { cxa = MFMA16(aA[i], bA[i], cxa); cxb = MFMA16(aA[i + 1], bA[i + 1], cxb); }
+                if (q + 16 < NL_W / 4) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { aA[i] = ap[4 * (q + 16 + i)]; bA[i] = bq[4 * (q + 16 + i) * NL_C]; }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) { cxa = MFMA16(aB[i], bB[i], cxa); cxb = MFMA16(aB[i + 1], bB[i + 1], cxb); }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -562,12 +575,37 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         } else if (TRAIN) {
             const float* xr = sX + opaque(lq * LDX + l15);
             const float* dr = sD + opaque(lq * LDH + 64 * (w - 4) + l15);
-#pragma unroll 4
-            for (int ii = 0; ii < DEC_M / 4; ++ii) {
-                const float xb = xr[4 * ii * LDX];
+            float xA[2], dA[2][4], xB[2], dB[2][4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    accW1[t] = MFMA16(dr[4 * ii * LDH + 16 * t], xb, accW1[t]);
+            for (int u = 0; u < 2; ++u) {
+                xA[u] = xr[4 * u * LDX];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dA[u][t] = dr[4 * u * LDH + 16 * t];
+            }
+#pragma unroll 1
+            for (int ii = 0; ii < DEC_M / 4; ii += 4) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    xB[u] = xr[4 * (ii + 2 + u) * LDX];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dB[u][t] = dr[4 * (ii + 2 + u) * LDH + 16 * t];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) accW1[t] = MFMA16(dA[u][t], xA[u], accW1[t]);
+                if (ii + 4 < DEC_M / 4) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        xA[u] = xr[4 * (ii + 4 + u) * LDX];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) dA[u][t] = dr[4 * (ii + 4 + u) * LDH + 16 * t];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) accW1[t] = MFMA16(dB[u][t], xB[u], accW1[t]);
             }
         }
         // ---------------- A (next tile): X -> the other LDS buffer; issue the loads of the tile after it ----------------
@@ -821,21 +859,34 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) { mwd[jt][0] = mk[(2 * wj + jt) * 64]; mwd[jt][1] = mk[(2 * wj + jt) * 64 + 32]; }
             const unsigned char* bsrc = sB + (128 * wk + l31) * WX_STRIDE + 16 * lh;
+            // 12 groups (k-step s4, plane p3) of 8 MFMAs; the 4 B fragments of the NEXT group are read while this group's MFMAs
+            // run (256 pipe cycles > LDS latency), held in place by a scheduling barrier
+            uint4 bfr[2][4];
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                bf16x8 af[2];
+            for (int kt = 0; kt < 4; ++kt) bfr[0][kt] = *reinterpret_cast<const uint4*>(bsrc + 32 * kt * WX_STRIDE);
+            bf16x8 af[2];
 #pragma unroll
-                for (int jt = 0; jt < 2; ++jt) {
-                    const unsigned byte = (mwd[jt][s4 & 1] >> (16 * (s4 >> 1) + 8 * lh)) & 0xFFu;
-                    af[jt] = __builtin_bit_cast(bf16x8, sLut[byte]);
-                }
+            for (int gq = 0; gq < 12; ++gq) {
+                const int s4 = gq / 3, p3 = gq % 3;
+                if (p3 == 0) {
 #pragma unroll
-                for (int p3 = 0; p3 < 3; ++p3)
-#pragma unroll
-                    for (int kt = 0; kt < 4; ++kt) {
-                        const bf16x8 bf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bsrc + p3 * WX_PLANE + 32 * kt * WX_STRIDE + 32 * s4));
-                        acc[0][kt] = MFMA_BF16(af[0], bf, acc[0][kt]); acc[1][kt] = MFMA_BF16(af[1], bf, acc[1][kt]);
+                    for (int jt = 0; jt < 2; ++jt) {
+                        const unsigned byte = (mwd[jt][s4 & 1] >> (16 * (s4 >> 1) + 8 * lh)) & 0xFFu;
+                        af[jt] = __builtin_bit_cast(bf16x8, sLut[byte]);
                     }
+                }
+                if (gq + 1 < 12) {
+                    const int sn = (gq + 1) / 3, pn = (gq + 1) % 3;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+                        bfr[(gq + 1) & 1][kt] = *reinterpret_cast<const uint4*>(bsrc + pn * WX_PLANE + 32 * kt * WX_STRIDE + 32 * sn);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const bf16x8 bf = __builtin_bit_cast(bf16x8, bfr[gq & 1][kt]);
+                    acc[0][kt] = MFMA_BF16(af[0], bf, acc[0][kt]); acc[1][kt] = MFMA_BF16(af[1], bf, acc[1][kt]);
+                }
             }
         }
         // (the next tile's X / dsdf stores touch buffers read only before the barrier above; sMask is double-buffered;
