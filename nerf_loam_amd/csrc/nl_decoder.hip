@@ -760,8 +760,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2(const NlLossS
 #define WX_OFF_LUT (3 * WX_PLANE)
 #define WX_OFF_MASK (WX_OFF_LUT + 256 * 16)
 #define WX_OFF_X (WX_OFF_MASK + 2 * DEC_THREADS * 4)
-#define WX_OFF_DS (WX_OFF_X + DEC_M * LDX * 4)
-#define WX_TOTAL (WX_OFF_DS + DEC_M * 4)
+#define WX_OFF_DS (WX_OFF_X + 2 * DEC_M * LDX * 4)
+#define WX_TOTAL (WX_OFF_DS + 2 * DEC_M * 4)
 
 
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLossScalars* __restrict__ lsp, const float* __restrict__ X,
@@ -810,87 +810,99 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
             pmk = relu2_mask[(size_t)tile * DEC_THREADS + tid];
         }
     };
-    prefetch(blockIdx.x);
+    // inputs of a tile -> LDS buffers of parity `pb` (X tile, dsdf and mask words are double-buffered by tile parity)
+    auto stage_inputs = [&](int pb) {
+        float* sx = sX + pb * (DEC_M * LDX);
+        sx[xi * LDX + xc] = xv.x; sx[xi * LDX + xc + 1] = xv.y;
+        if (tid < DEC_M) sdS[pb * DEC_M + tid] = pds;
+        sMask[pb * DEC_THREADS + tid] = pmk;
+    };
+    // producer of one 32-sample half tile: v = dsdf_i * relu(X W1^T + b1)[i][col], split into 3 bf16 planes, k-slot order
+    auto produce = [&](int pb, int sub) {
+        const float* sx = sX + pb * (DEC_M * LDX) + opaque((32 * sub + l31) * LDX + lh);
+        const float* ds = sdS + pb * DEC_M + opaque(32 * sub + 4 * lh);
+        f32x16 c0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c0[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < NL_C / 2; ++kk) c0 = MFMA32(sx[2 * kk], w1r[kk], c0);
+        unsigned hi[8], mid[8], lo[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float h0 = fmaxf(c0[2 * q] + b1c, 0.f), h1 = fmaxf(c0[2 * q + 1] + b1c, 0.f);
+            const float v0 = h0 * ds[D32_RR(2 * q)], v1 = h1 * ds[D32_RR(2 * q + 1)];
+            hi[q] = pack_hi16(v0, v1);
+            const float r0 = v0 - trunc_bf16(v0), r1 = v1 - trunc_bf16(v1);
+            mid[q] = pack_hi16(r0, r1);
+            const float s0 = r0 - trunc_bf16(r0), s1 = r1 - trunc_bf16(r1);
+            lo[q] = pack_hi16(s0, s1);
+        }
+        unsigned char* dst = sB + opaque(col * WX_STRIDE + 32 * lh + 64 * sub);
+        uint4* d0 = reinterpret_cast<uint4*>(dst);
+        d0[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]); d0[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+        uint4* d1 = reinterpret_cast<uint4*>(dst + WX_PLANE);
+        d1[0] = make_uint4(mid[0], mid[1], mid[2], mid[3]); d1[1] = make_uint4(mid[4], mid[5], mid[6], mid[7]);
+        uint4* d2 = reinterpret_cast<uint4*>(dst + 2 * WX_PLANE);
+        d2[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]); d2[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+    };
+    // consumer of one half tile: 2 k-steps of 16 slots x 3 planes x 4 column tiles, each B fragment feeding both row tiles.
+    // 6 groups (k-step, plane) of 8 MFMAs; the 4 B fragments of the NEXT group are read while this group's MFMAs run.
+    auto consume = [&](int pb, int sub) {
+        const unsigned* mk = sMask + pb * DEC_THREADS + l31;
+        unsigned mwd[2][2];                              // [row tile jt][producer lane half]
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) { mwd[jt][0] = mk[(2 * wj + jt) * 64]; mwd[jt][1] = mk[(2 * wj + jt) * 64 + 32]; }
+        const unsigned char* bsrc = sB + opaque((128 * wk + l31) * WX_STRIDE + 16 * lh + 64 * sub);
+        uint4 bfr[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) bfr[0][kt] = *reinterpret_cast<const uint4*>(bsrc + 32 * kt * WX_STRIDE);
+        bf16x8 af[2];
+#pragma unroll
+        for (int gq = 0; gq < 6; ++gq) {
+            const int s2 = gq / 3, p3 = gq % 3;          // k-step inside the half tile: producer lane half s2
+            if (p3 == 0) {
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) {
+                    const unsigned byte = (mwd[jt][s2] >> (16 * sub + 8 * lh)) & 0xFFu;
+                    af[jt] = __builtin_bit_cast(bf16x8, sLut[byte]);
+                }
+            }
+            if (gq + 1 < 6) {
+                const int sn = (gq + 1) / 3, pn = (gq + 1) % 3;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+                    bfr[(gq + 1) & 1][kt] = *reinterpret_cast<const uint4*>(bsrc + pn * WX_PLANE + 32 * kt * WX_STRIDE + 32 * sn);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const bf16x8 bf = __builtin_bit_cast(bf16x8, bfr[gq & 1][kt]);
+                acc[0][kt] = MFMA_BF16(af[0], bf, acc[0][kt]); acc[1][kt] = MFMA_BF16(af[1], bf, acc[1][kt]);
+            }
+        }
+    };
 
+    // Pipeline over 32-sample half tiles (the two halves of a tile's k-slots are separate regions of sB): in every barrier
+    // interval the workgroup produces the operand planes of the NEXT half tile and runs the MFMAs of the current one, so the
+    // split/LDS-store work of one wave runs under the other waves' matrix work.
+    prefetch(blockIdx.x);
+    stage_inputs(0);
+    prefetch(blockIdx.x + gridDim.x);
+    __syncthreads();
+    if (blockIdx.x < ntiles) produce(0, 0);
+    __syncthreads();
     int par = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
-        sX[xi * LDX + xc] = xv.x; sX[xi * LDX + xc + 1] = xv.y;
-        if (tid < DEC_M) sdS[tid] = pds;
-        sMask[par * DEC_THREADS + tid] = pmk;            // double-buffered: still read by slow waves of the previous tile
+        // step A: inputs of the next tile -> the other buffers; planes of this tile's second half; MFMAs of its first half
+        stage_inputs(par ^ 1);
+        prefetch(tile + 2 * gridDim.x);
+        produce(par, 1);
+        consume(par, 0);
         __syncthreads();
-        prefetch(tile + gridDim.x);
-        {   // producer: v = dsdf_i * relu(X W1^T + b1)[i][col], split into 3 bf16 planes, k-slot order
-            f32x16 c0, c1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
-#pragma unroll
-            for (int kk = 0; kk < NL_C / 2; ++kk) {
-                c0 = MFMA32(sX[l31 * LDX + 2 * kk + lh], w1r[kk], c0); c1 = MFMA32(sX[(32 + l31) * LDX + 2 * kk + lh], w1r[kk], c1);
-            }
-            unsigned char* dst = sB + col * WX_STRIDE + 32 * lh;
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                unsigned hi[8], mid[8], lo[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    float v0, v1;
-                    {
-                        const float h0 = fmaxf((sub ? c1[2 * q] : c0[2 * q]) + b1c, 0.f), h1 = fmaxf((sub ? c1[2 * q + 1] : c0[2 * q + 1]) + b1c, 0.f);
-                        v0 = h0 * sdS[32 * sub + d32_row(2 * q, lh)]; v1 = h1 * sdS[32 * sub + d32_row(2 * q + 1, lh)];
-                    }
-                    hi[q] = pack_hi16(v0, v1);
-                    const float r0 = v0 - trunc_bf16(v0), r1 = v1 - trunc_bf16(v1);
-                    mid[q] = pack_hi16(r0, r1);
-                    const float s0 = r0 - trunc_bf16(r0), s1 = r1 - trunc_bf16(r1);
-                    lo[q] = pack_hi16(s0, s1);
-                }
-                uint4* d0 = reinterpret_cast<uint4*>(dst + 64 * sub);
-                d0[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]); d0[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
-                uint4* d1 = reinterpret_cast<uint4*>(dst + 64 * sub + WX_PLANE);
-                d1[0] = make_uint4(mid[0], mid[1], mid[2], mid[3]); d1[1] = make_uint4(mid[4], mid[5], mid[6], mid[7]);
-                uint4* d2 = reinterpret_cast<uint4*>(dst + 64 * sub + 2 * WX_PLANE);
-                d2[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]); d2[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
-            }
-        }
+        // step B: planes of the next tile's first half (its inputs were published by the barrier above); MFMAs of this tile's second half
+        if (tile + gridDim.x < ntiles) produce(par ^ 1, 0);
+        consume(par, 1);
         __syncthreads();
-        {   // consumer: 4 k-steps of 16 slots x 3 planes x 4 column tiles, each B fragment feeding both row tiles
-            const unsigned* mk = sMask + par * DEC_THREADS + l31;
-            unsigned mwd[2][2];                          // [row tile jt][producer lane half]
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt) { mwd[jt][0] = mk[(2 * wj + jt) * 64]; mwd[jt][1] = mk[(2 * wj + jt) * 64 + 32]; }
-            const unsigned char* bsrc = sB + (128 * wk + l31) * WX_STRIDE + 16 * lh;
-            // 12 groups (k-step s4, plane p3) of 8 MFMAs; the 4 B fragments of the NEXT group are read while this group's MFMAs
-            // run (256 pipe cycles > LDS latency), held in place by a scheduling barrier
-            uint4 bfr[2][4];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) bfr[0][kt] = *reinterpret_cast<const uint4*>(bsrc + 32 * kt * WX_STRIDE);
-            bf16x8 af[2];
-#pragma unroll
-            for (int gq = 0; gq < 12; ++gq) {
-                const int s4 = gq / 3, p3 = gq % 3;
-                if (p3 == 0) {
-#pragma unroll
-                    for (int jt = 0; jt < 2; ++jt) {
-                        const unsigned byte = (mwd[jt][s4 & 1] >> (16 * (s4 >> 1) + 8 * lh)) & 0xFFu;
-                        af[jt] = __builtin_bit_cast(bf16x8, sLut[byte]);
-                    }
-                }
-                if (gq + 1 < 12) {
-                    const int sn = (gq + 1) / 3, pn = (gq + 1) % 3;
-#pragma unroll
-                    for (int kt = 0; kt < 4; ++kt)
-                        bfr[(gq + 1) & 1][kt] = *reinterpret_cast<const uint4*>(bsrc + pn * WX_PLANE + 32 * kt * WX_STRIDE + 32 * sn);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) {
-                    const bf16x8 bf = __builtin_bit_cast(bf16x8, bfr[gq & 1][kt]);
-                    acc[0][kt] = MFMA_BF16(af[0], bf, acc[0][kt]); acc[1][kt] = MFMA_BF16(af[1], bf, acc[1][kt]);
-                }
-            }
-        }
-        // (the next tile's X / dsdf stores touch buffers read only before the barrier above; sMask is double-buffered;
-        //  sB is rewritten after the next barrier)
     }
     float* base = partials + (size_t)blockIdx.x * NL_DEC_PARAMS;
 #pragma unroll
