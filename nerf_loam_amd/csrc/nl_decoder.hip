@@ -1,28 +1,28 @@
-// nl_decoder.hip -- the SDF decoder (16 -> 256 -> 256 -> 1 ReLU MLP) forward + loss gradient +
-// backward as ONE persistent kernel on the fp32 matrix cores of gfx950.
+// nl_decoder.hip -- the SDF decoder (16 -> 256 -> 256 -> 1 ReLU MLP) forward + loss gradient + backward as ONE persistent
+// kernel on the matrix cores of gfx950, plus the dW2 kernel and the forward-only kernel.
 //
-// Reference behaviour: src/variations/lidar.py:109-131 (forward), src/criterion.py:59-100 (loss),
-// torch autograd for the backward.  fp32 in / fp32 accumulate MFMA
-// (v_mfma_f32_32x32x2_f32, v_mfma_f32_16x16x4_f32) is bit-for-bit an fmaf chain, so the 1e-4 SDF
-// parity bar holds without any reduced-precision path.
+// Reference behaviour: src/variations/lidar.py:109-131 (forward), src/criterion.py:59-100 (loss), torch autograd for the
+// backward.  All values and all accumulations are fp32.  The three 256 x 256 contractions run
+// on the bf16 matrix cores as EXACT-PRODUCT formulations (gemm_x9, gemm_mask_x, k_decoder_wgrad2_x): an fp32
+// operand is the exact sum of three bf16 terms, a {0,1} ReLU mask is a bf16 operand as it stands, every product the matrix
+// core forms is exact, accumulation is fp32.  The plain fp32-MFMA versions (v_mfma_f32_32x32x2_f32: gemm256,
+// k_decoder_wgrad2) stay selectable (nl_decoder_set_gemm_mode / nl_decoder_set_wgrad2_mode) and are cross-checked in
+// tests/test_gpu_parity.py; the K = 16 layers always run on the fp32 matrix cores.
 //
 // Structure (MI355X-first, not how the reference does it - it runs 3 GEMMs + autograd):
-//   * one 512-thread workgroup (8 waves, 2 per SIMD) per CU, persistent over 64-sample tiles;
-//   * per tile everything stays on chip: X tile, H1 = relu(X W1^T + b1) and dH2/dH1 live in LDS
-//     (row stride 257 floats: conflict-free both as MFMA A operand [row-per-lane] and as
-//     B operand / epilogue target [column-per-lane]); H2 never leaves registers;
-//   * the loss gradient dL/dsdf needs only per-sample geometry + iteration-global scalars that are
-//     known before the decoder runs (nl_geometry.hip), so forward, loss and backward fuse;
-//   * W2 (256 KB fp32 > LDS) is streamed from L2 straight into MFMA B operands: wave w owns output
-//     columns [32w, 32w+32), reads W2T rows (forward) / W2 rows (dgrad) coalesced, each operand
-//     register feeds both 32-row sub-tiles;
-//   * weight gradients accumulate in registers across ALL tiles of the workgroup and are flushed
-//     once as a per-workgroup partial slab - no atomics; nl_reduce_partials sums the slabs.  The
-//     big one, dW2 = dH2^T H1 (8 tiles of 32x32 per wave = 128 accumulator registers), runs in its
-//     own persistent kernel (k_decoder_wgrad2) so that neither kernel spills: it rebuilds H1 from
-//     X (K = 16, 2 % extra MFMA work) and dH2 from dsdf + the 256-bit ReLU mask the first kernel
-//     saves per sample (32 B instead of a 1 KB activation row).
-// FLOPs per sample: 3 * 2 * (16*256 + 256*256 + 256) = 419,328 (279,552 with a frozen decoder).
+//   * one 512-thread workgroup (8 waves, 2 per SIMD) per CU, persistent over 64-sample tiles, 5 barriers per tile;
+//   * per tile everything stays on chip: X tile, H1 (three bf16 planes / fp32 tile), the ReLU-mask tile and dH1 live in
+//     LDS; H2 never leaves registers;
+//   * the loss gradient dL/dsdf needs only per-sample geometry + iteration-global scalars that are known before the decoder
+//     runs (nl_geometry.hip), so forward, loss and backward fuse; every wave recomputes the 64 loss gradients of the tile
+//     for itself (no barrier between the loss and the mask phase);
+//   * W2 (256 KB fp32 > LDS) is streamed from L2 straight into MFMA B operands, pre-split into bf16 planes in MFMA-fragment
+//     order by k_prepare_w2x (nl_optim.hip): one contiguous 1 KB buffer_load_dwordx4 per fragment, software-pipelined;
+//   * weight gradients accumulate in registers across ALL tiles of the workgroup and are flushed once as a per-workgroup
+//     partial slab - no atomics; nl_reduce_partials sums the slabs.  The big one, dW2 = dH2^T H1 (8 tiles of 32x32 per wave
+//     = 128 accumulator registers), runs in its own persistent kernel so that neither kernel spills: it rebuilds H1 from X
+//     (K = 16) and dH2 from dsdf + the 256-bit ReLU mask the first kernel saves per sample (32 B instead of a 1 KB row).
+// FLOPs per sample (algorithmic): 3 * 2 * (16*256 + 256*256 + 256) = 419,328 (279,552 with a frozen decoder).
 #include "nl_common.h"
 
 #define DEC_M 64
