@@ -182,6 +182,9 @@ long long nl_octree_count_leaf_nodes(void* h);                           /* octr
 int nl_octree_has_voxel(void* h, int x, int y, int z);                   /* octree.cpp:173-206 */
 int nl_octree_export(void* h, float* voxels, float* children, int* features);   /* get_centres_and_children :293-342 */
 int nl_octree_export_device_layout(void* h, float voxel_size, float* centres, int* structure, int* vertex_idx); /* + mapping.py:319-327 */
+/* incremental export: rows, in the layout above, of the nodes that changed since the previous call */
+long long nl_octree_delta_count(void* h);
+int nl_octree_export_delta(void* h, float voxel_size, int* ids, float* centres, int* structure, int* vertex_idx);
 
 /* profiling aid: 256 x int64 device buffer receiving per-phase shader-clock stamps of workgroup 0 (NULL = off) */
 int nl_field_set_debug_buffer(void* dbg);      /* [blocks][8] int64 stamps of nl_trilinear_bwd's workgroups */

@@ -79,6 +79,8 @@ _SIGS = {
     "nl_octree_has_voxel": ([_P, _I, _I, _I], _I),
     "nl_octree_export": ([_P, _P, _P, _P], _I),
     "nl_octree_export_device_layout": ([_P, _F, _P, _P, _P], _I),
+    "nl_octree_delta_count": ([_P], _LL),
+    "nl_octree_export_delta": ([_P, _F, _P, _P, _P, _P], _I),
     "nl_mfma_selftest": ([_P] * 7, _I),
     "nl_decoder_set_debug_buffer": ([_P], _I),
 }

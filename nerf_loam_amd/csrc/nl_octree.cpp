@@ -28,14 +28,20 @@ struct Node {
 struct Octree {
     int size = 0, max_level = 0;
     std::vector<Node> nodes;
+    // nodes whose exported rows changed since the last nl_octree_export_delta: new nodes, parents that gained a child,
+    // FEATURE leaves upgraded to SURFACE (incremental export instead of a full one per frame)
+    std::vector<int> dirty;
+    std::vector<uint8_t> dirty_flag;
 
     int new_node() {
         Node n;
         n.code = 0; n.side = 0; n.type = T_NONLEAF; n.leaf = false;
         for (int i = 0; i < 8; ++i) n.child[i] = -1;
         nodes.push_back(n);
+        dirty_flag.push_back(0);
         return (int)nodes.size() - 1;
     }
+    void mark(int k) { if (!dirty_flag[k]) { dirty_flag[k] = 1; dirty.push_back(k); } }
 };
 
 inline uint64_t spread3(uint64_t v) {
@@ -92,6 +98,7 @@ void* nl_octree_create(long long grid_dim)
     t->max_level = (int)std::log2((double)t->size);
     int r = t->new_node();
     t->nodes[r].side = (uint32_t)t->size;
+    t->mark(r);
     return t;
 }
 
@@ -120,8 +127,10 @@ int nl_octree_insert(void* h, const int* pts, long long npts)
                     nd.leaf = (d == t.max_level);
                     nd.type = nd.leaf ? (j == 0 ? T_SURFACE : T_FEATURE) : T_NONLEAF;
                     t.nodes[n].child[cid] = c;
+                    t.mark(c); t.mark(n);
                 } else if (t.nodes[c].type == T_FEATURE && j == 0) {
                     t.nodes[c].type = T_SURFACE;
+                    t.mark(c); t.mark(n);                              // becomes visible in its parent's children row
                 }
                 n = c;
             }
@@ -195,6 +204,47 @@ int nl_octree_export_device_layout(void* h, float voxel_size, float* centres, in
         for (int i = 0; i < 8; ++i) structure[9 * k + i] = (int)ch[8 * k + i];
         structure[9 * k + 8] = (int)side;
     }
+    return 0;
+}
+
+// Incremental export (the reference re-exports and re-uploads the whole tree every frame,
+// mapping.py:283-339): the rows - in the nl_octree_export_device_layout format - of exactly the nodes whose rows changed
+// since the previous call (or since creation).  Rows of untouched nodes are unchanged by construction: node ids are
+// creation-ordered, a SURFACE leaf's eight corner leaves exist from the moment it is inserted, and a node's row depends
+// only on itself and on the types of its children.  Applying the deltas in order to arrays grown to count_nodes() rows
+// reproduces the full export bit for bit (tests/test_octree_host.py).
+long long nl_octree_delta_count(void* h) { return h ? (long long)((Octree*)h)->dirty.size() : 0; }
+
+int nl_octree_export_delta(void* h, float voxel_size, int* ids, float* centres, int* structure, int* vertex_idx)
+{
+    if (!h || !ids || !centres || !structure || !vertex_idx) return 1;
+    Octree& t = *(Octree*)h;
+    const size_t nd_ = t.dirty.size();
+    for (size_t q = 0; q < nd_; ++q) {
+        const int k = t.dirty[q];
+        const Node& nd = t.nodes[k];
+        ids[q] = k;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 8; ++i) { structure[9 * q + i] = -1; vertex_idx[8 * q + i] = -1; }
+        if (nd.type != T_FEATURE) {                                     // FEATURE leaves are never reached by the export walk
+            v[0] = (float)(int)gather3(nd.code); v[1] = (float)(int)gather3(nd.code >> 1); v[2] = (float)(int)gather3(nd.code >> 2);
+            v[3] = (float)nd.side;
+            if (nd.type == T_SURFACE) {
+                for (int i = 0; i < 8; ++i) {
+                    const int c = find_leaf(t, (int)(v[0] + (float)DX[i]), (int)(v[1] + (float)DY[i]), (int)(v[2] + (float)DZ[i]));
+                    if (c >= 0) vertex_idx[8 * q + i] = c;
+                }
+            }
+            for (int i = 0; i < 8; ++i) {
+                const int c = nd.child[i];
+                if (c >= 0 && t.nodes[c].type != T_FEATURE) structure[9 * q + i] = (int)(float)c;
+            }
+        }
+        for (int a = 0; a < 3; ++a) centres[3 * q + a] = (v[a] + v[3] / 2.0f) * voxel_size;
+        structure[9 * q + 8] = (int)v[3];
+        t.dirty_flag[k] = 0;
+    }
+    t.dirty.clear();
     return 0;
 }
 

@@ -21,6 +21,7 @@ import torch
 from .criterion import Criterion
 from .decoder import Decoder
 from .lidar_frame import LidarFrame
+from .pipeline import MapDevice
 from .render_helpers import bundle_adjust_frames
 from .svo import Octree
 
@@ -57,6 +58,8 @@ class Mapping:
         self.voxel_id2embedding_id = torch.full((0,), -1, dtype=torch.int32)        # [n_nodes] host table, grown with the tree
         self.current_num_embeds = 0
         self.dynamic_embeddings = None
+        self._emb_buf = None                     # embedding table with spare capacity; dynamic_embeddings is a view of it
+        self._node_buf = None                    # device copies of the octree tensors with spare capacity
         self.svo = Octree()
         self.svo.init(256 * 256 * 4, embed_dim, self.voxel_size)
         self.first_frame_id = 0
@@ -73,35 +76,72 @@ class Mapping:
 
     @torch.no_grad()
     def get_embeddings(self, points_idx):
-        """assign an embedding row to every vertex id seen for the first time; new rows are zero"""
-        n = points_idx.shape[0]
+        """assign an embedding row to every vertex id seen for the first time; new rows are zero.  `points_idx` may be the
+        vertex rows of the CHANGED nodes only (incremental update).  Returns the ids that received a row."""
+        n = self.svo.count_nodes()
         if self.voxel_id2embedding_id.shape[0] < n:
-            grown = torch.full((n,), -1, dtype=torch.int32)
+            grown = torch.full((max(n, 2 * self.voxel_id2embedding_id.shape[0]),), -1, dtype=torch.int32)
             grown[:self.voxel_id2embedding_id.shape[0]] = self.voxel_id2embedding_id
             self.voxel_id2embedding_id = grown
         flat = points_idx.reshape(-1).long()
         flat = flat[flat.ne(-1)]
         new_ids = torch.unique(flat[self.voxel_id2embedding_id[flat].eq(-1)])
         if new_ids.numel() == 0:
-            return
+            return new_ids
         start, end = self.current_num_embeds, self.current_num_embeds + new_ids.numel()
         self.voxel_id2embedding_id[new_ids] = torch.arange(start, end, dtype=torch.int32)
-        add = torch.zeros((end - start, self.embed_dim), dtype=torch.bfloat16, device=self.device)
-        self.dynamic_embeddings = add if self.dynamic_embeddings is None else torch.cat([self.dynamic_embeddings.detach(), add], 0)
+        # embedding table with spare capacity: growth appends zero rows in place (the reference round-trips the whole
+        # table through the host every frame, mapping.py:312-314); a reallocation happens only when capacity doubles
+        if self._emb_buf is None or end > self._emb_buf.shape[0]:
+            cap = max(2 * end, 4096)
+            buf = torch.zeros((cap, self.embed_dim), dtype=torch.bfloat16, device=self.device)
+            if self._emb_buf is not None:
+                buf[:start] = self._emb_buf[:start]
+            self._emb_buf = buf
+        self.dynamic_embeddings = self._emb_buf[:end]
         self.current_num_embeds = end
+        return new_ids
+
+    def _grow_nodes(self, n):
+        cap = 0 if self._node_buf is None else self._node_buf["centres"].shape[0]
+        if n <= cap:
+            return
+        new_cap = max(2 * n, 1 << 14)
+        shapes = dict(centres=((new_cap, 3), torch.float32), structure=((new_cap, 9), torch.int32),
+                      vertex_idx=((new_cap, 8), torch.int32), id2row=((new_cap,), torch.int32))
+        buf = {k: torch.full(sh, -1 if k != "centres" else 0, dtype=dt, device=self.device) for k, (sh, dt) in shapes.items()}
+        if self._node_buf is not None:
+            for k in buf:
+                buf[k][:cap] = self._node_buf[k]
+        self._node_buf = buf
 
     @torch.no_grad()
     def update_grid_features(self):
-        centres, structure, vertex_idx = self.svo.export_device_layout()
-        vertex_idx = torch.from_numpy(vertex_idx)
-        self.get_embeddings(vertex_idx)
+        """Incremental map update: only the rows of nodes that changed since the last frame leave the host
+        octree (svo.export_delta), are uploaded and scattered into capacity-managed device tensors; new vertex ids get
+        zero embedding rows appended in place.  The reference re-exports the whole tree, rebuilds a 2e9-row id table entry
+        by entry and re-uploads everything every frame (mapping.py:283-339)."""
+        ids, centres, structure, vertex_idx = self.svo.export_delta()
+        n = self.svo.count_nodes()
+        self._grow_nodes(n)
+        new_ids = self.get_embeddings(torch.from_numpy(vertex_idx))
+        nb = self._node_buf
+        if len(ids):
+            di = torch.from_numpy(ids).to(self.device).long()
+            nb["centres"].index_copy_(0, di, torch.from_numpy(centres).to(self.device))
+            nb["structure"].index_copy_(0, di, torch.from_numpy(structure).to(self.device))
+            nb["vertex_idx"].index_copy_(0, di, torch.from_numpy(vertex_idx).to(self.device))
+        if new_ids.numel():
+            nb["id2row"].index_copy_(0, new_ids.to(self.device), self.voxel_id2embedding_id[new_ids].to(self.device))
         self.map_states = {
-            "voxel_vertex_idx": vertex_idx.to(self.device),
-            "voxel_center_xyz": torch.from_numpy(centres).to(self.device),
-            "voxel_structure": torch.from_numpy(structure).to(self.device),
+            "voxel_vertex_idx": nb["vertex_idx"][:n],
+            "voxel_center_xyz": nb["centres"][:n],
+            "voxel_structure": nb["structure"][:n],
             "voxel_vertex_emb": self.dynamic_embeddings,
-            "voxel_id2embedding_id": self.voxel_id2embedding_id.to(self.device),
+            "voxel_id2embedding_id": nb["id2row"][:n],
         }
+        self.map_states["_device"] = MapDevice.from_tensors(nb["centres"][:n], nb["structure"][:n], nb["vertex_idx"][:n], nb["id2row"][:n],
+                                                            self.dynamic_embeddings, self.voxel_size, self.device)
 
     # ------------------------------------------------------------------ optimisation call site
     def do_mapping(self, share_data=None, tracked_frame=None, update_pose=True, update_decoder=True, selection_method="current"):

@@ -88,6 +88,21 @@ class Octree:
             raise RuntimeError("nl_octree_export_device_layout failed")
         return c, s, f
 
+    def export_delta(self):
+        """Rows (export_device_layout format) of the nodes that changed since the previous call:
+        ids i32[d], centres f32[d,3], structure i32[d,9], vertex_idx i32[d,8].  Applying the deltas in order to arrays of
+        count_nodes() rows reproduces export_device_layout()."""
+        self._need()
+        d = int(L.lib().nl_octree_delta_count(self._h))
+        ids = np.empty(d, np.int32); c = np.empty((d, 3), np.float32); s = np.empty((d, 9), np.int32); f = np.empty((d, 8), np.int32)
+        P = ctypes.c_void_p
+        if d:
+            rc = L.lib().nl_octree_export_delta(self._h, ctypes.c_float(self.voxel_size_), ids.ctypes.data_as(P), c.ctypes.data_as(P),
+                                                s.ctypes.data_as(P), f.ctypes.data_as(P))
+            if rc:
+                raise RuntimeError("nl_octree_export_delta failed")
+        return ids, c, s, f
+
     # pickle protocol of bindings.cpp:23-31: (size, feat_dim, voxel_size, all_pts), rebuilt by replay
     def __getstate__(self):
         return (self.size_, self.feat_dim_, self.voxel_size_, self.all_pts)

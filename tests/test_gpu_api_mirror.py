@@ -153,6 +153,46 @@ def test_mapping_and_tracking_with_device_ray_selection():
         RH.RAY_SELECTION = old
 
 
+def test_incremental_map_update_equals_a_full_rebuild():
+    """frame-by-frame map growth through svo.export_delta + in-place device scatter keeps map_states equal to
+    a full export, keeps the optimised embedding rows of earlier frames, and the traversal built from it intersects the
+    same voxels as one built from scratch"""
+    from nerf_loam_amd import pipeline as P
+    from nerf_loam_amd.lidar_frame import LidarFrame
+    from nerf_loam_amd.mapping import Mapping
+    torch.manual_seed(3)
+    args = make_args()
+    mapper = Mapping(args)
+    share = Namespace(decoder=None, states=None)
+    frames = []
+    for i, seed in enumerate((11, 12, 13)):
+        pts, cos = H.scene_points(64, 48, seed)
+        pose = np.eye(4); pose[0, 3] = 1.5 * i
+        fr = LidarFrame(i, torch.from_numpy(pts), torch.from_numpy(cos), pose)
+        frames.append(fr)
+        rows_before = 0 if mapper.dynamic_embeddings is None else mapper.dynamic_embeddings.shape[0]
+        emb_before = None if rows_before == 0 else mapper.dynamic_embeddings.clone()
+        mapper.create_voxels(fr)
+        ms = mapper.map_states
+        c, s_, f = mapper.svo.export_device_layout()
+        assert np.array_equal(ms["voxel_center_xyz"].cpu().numpy(), c)
+        assert np.array_equal(ms["voxel_structure"].cpu().numpy(), s_)
+        assert np.array_equal(ms["voxel_vertex_idx"].cpu().numpy(), f)
+        used = np.unique(f[f >= 0])
+        table = ms["voxel_id2embedding_id"].cpu().numpy()
+        assert (table[used] >= 0).all() and len(np.unique(table[used])) == len(used) == mapper.dynamic_embeddings.shape[0]
+        if emb_before is not None:                                           # old rows keep their (optimised) values, new rows are zero
+            assert torch.equal(mapper.dynamic_embeddings[:rows_before], emb_before)
+            assert mapper.dynamic_embeddings.shape[0] > rows_before and not mapper.dynamic_embeddings[rows_before:].any()
+        md = ms["_device"]
+        fresh = P.MapDevice.from_tensors(torch.from_numpy(c), torch.from_numpy(s_), torch.from_numpy(f), torch.from_numpy(table),
+                                         mapper.dynamic_embeddings, mapper.voxel_size)
+        assert torch.equal(md.blk_ids, fresh.blk_ids) and torch.equal(md.blk_hdr, fresh.blk_hdr) and torch.equal(md.vertex_rows, fresh.vertex_rows)
+        mapper.do_mapping(share, fr, selection_method="current")            # optimise on the grown map (rows change in place)
+        assert mapper.map_states["voxel_vertex_emb"].data_ptr() == mapper.dynamic_embeddings.data_ptr()
+    assert mapper.svo.count_nodes() == mapper.map_states["voxel_center_xyz"].shape[0]
+
+
 def test_get_scores_matches_oracle():
     """mesh-time dense SDF grid (reference render_helpers.get_scores): HIP gather + decoder forward vs the oracle"""
     from nerf_loam_amd.decoder import Decoder

@@ -7,6 +7,7 @@ import subprocess
 import sys
 
 import numpy as np
+import torch
 import pytest
 
 import helpers as H
@@ -113,3 +114,33 @@ print('OK', r.count_nodes())
 """
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)   # own process: reference's global node counter
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_incremental_export_reproduces_the_full_export():
+    """deltas (changed rows only) applied in order == full export, after every insert batch, including
+    FEATURE -> SURFACE upgrades and parents gaining children"""
+    from nerf_loam_amd.svo import Octree
+    rng = np.random.default_rng(5)
+    oc = Octree(); oc.init(256 * 256 * 4, 16, 0.2)
+    C = np.zeros((0, 3), np.float32); S = np.zeros((0, 9), np.int32); F = np.zeros((0, 8), np.int32)
+    total_delta = 0
+    base = np.array([10000, 10000, 10000])
+    for batch in range(6):
+        pts = base + rng.integers(-12, 12, size=(300, 3)) + np.array([batch * 5, 0, 0])
+        if batch == 3:                                           # re-insert vertex-only leaves of earlier voxels: upgrades
+            pts = np.concatenate([pts, prev + 1])
+        prev = pts
+        oc.insert(torch.from_numpy(pts.astype(np.int32)))
+        ids, c, s, f = oc.export_delta()
+        n = oc.count_nodes()
+        grow = n - len(C)
+        C = np.concatenate([C, np.zeros((grow, 3), np.float32)]); S = np.concatenate([S, np.zeros((grow, 9), np.int32)])
+        F = np.concatenate([F, np.zeros((grow, 8), np.int32)])
+        assert len(np.unique(ids)) == len(ids) and set(range(n - grow, n)) <= set(ids.tolist())      # every new node is in the delta
+        C[ids] = c; S[ids] = s; F[ids] = f
+        fc, fs, ff = oc.export_device_layout()
+        assert np.array_equal(C, fc) and np.array_equal(S, fs) and np.array_equal(F, ff)
+        total_delta += len(ids)
+        if batch > 0:
+            assert len(ids) < n                                  # later deltas are partial
+    assert len(oc.export_delta()[0]) == 0                        # nothing changed since
