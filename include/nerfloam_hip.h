@@ -32,6 +32,10 @@ extern "C" {
 #define NL_DEC_WS_FLOATS 262144    /* decoder weight workspace: W2^T fp32 + 2 x 3 bf16 operand planes */
 #define NL_EMB_CHANNELS 16
 
+/* Multi-GPU ray sharding: fold the all-gathered counter blocks gathered[world][NL_CNT_INTS + 2*NL_CNT_DOUBLES] (ints) into
+ * this rank's block.  stage 1 (after nl_ray_intersect): NLC_R_GLOBAL, NLC_R_OFFSET, global NLC_HMAX;
+ * stage 2 (after the counting sampler pass): summed loss normalisers, max samples per ray, padded-slot constants. */
+int nl_dist_merge_counters(const int* gathered, int world, int rank, int stage, int* counters, void* stream);
 int nl_version(void);
 int nl_device_count(void);              /* number of HIP devices visible (0 => product cannot run) */
 int nl_decoder_grid_hint(void);         /* persistent-kernel grid = compute units of the current device */

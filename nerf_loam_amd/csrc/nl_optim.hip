@@ -127,7 +127,51 @@ __global__ void k_pose_step(float* __restrict__ pose6, float* __restrict__ g_pos
     for (int i = 0; i < 3; ++i) poses12[12 * f + 9 + i] = pose6[6 * f + i];
 }
 
+// Multi-GPU (nerf_loam_amd/dist.py): every rank all-gathers its whole counter block (one small collective) and this kernel
+// folds the gathered blocks into the local one - instead of one collective per quantity and a dozen tiny torch kernels.
+//   stage 1 (after intersect): global hit-ray count, this rank's hit-rank offset, global max hits per ray
+//   stage 2 (after counting):  summed loss normalisers / flags, max samples per ray, summed padded-slot constants
+__global__ void k_dist_merge(const int* __restrict__ gathered, int world, int rank, int stage, int* __restrict__ counters)
+{
+    constexpr int STRIDE = NL_CNT_INTS + 2 * NL_CNT_DOUBLES;
+    const int t = threadIdx.x;
+    if (stage == 1) {
+        if (t == 0) {
+            int tot = 0, off = 0, hmax = 0;
+            for (int r = 0; r < world; ++r) {
+                const int v = gathered[r * STRIDE + NLC_R];
+                tot += v; if (r < rank) off += v;
+                hmax = max(hmax, gathered[r * STRIDE + NLC_HMAX]);
+            }
+            counters[NLC_R_GLOBAL] = tot; counters[NLC_R_OFFSET] = off; counters[NLC_HMAX] = hmax;
+        }
+        return;
+    }
+    if (t >= NLC_NFS && t <= NLC_GUARD) {                        // NFS, NSDF, INV_* (4), OVERFLOW, GUARD: contiguous
+        int sum = 0;
+        for (int r = 0; r < world; ++r) sum += gathered[r * STRIDE + t];
+        counters[t] = sum;
+    } else if (t == NLC_SMAX) {
+        int m = 0;
+        for (int r = 0; r < world; ++r) m = max(m, gathered[r * STRIDE + NLC_SMAX]);
+        counters[NLC_SMAX] = m;
+    } else if (t == 32 || t == 33) {
+        const int d = t == 32 ? NLD_INV_D2 : NLD_INV_D2CNT;
+        double sum = 0.0;
+        for (int r = 0; r < world; ++r) sum += reinterpret_cast<const double*>(gathered + r * STRIDE + NL_CNT_INTS)[d];
+        reinterpret_cast<double*>(counters + NL_CNT_INTS)[d] = sum;
+    }
+}
+
 extern "C" {
+
+int nl_dist_merge_counters(const int* gathered, int world, int rank, int stage, int* counters, void* stream)
+{
+    if (!gathered || !counters || world <= 0 || rank < 0 || rank >= world || (stage != 1 && stage != 2)) return NL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_dist_merge, dim3(1), dim3(64), 0, (hipStream_t)stream, gathered, world, rank, stage, counters);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
 
 int nl_adam_prepare(int* state, double lr_emb, double lr_dec, double lr_pose, void* stream)
 {

@@ -14,8 +14,12 @@ The reference has no distributed code.  Rays are independent up to 
                        optimiser step to its replica.
 
 One process per GPU, torch.distributed backend "nccl" (= RCCL on ROCm); on CPU test rigs "gloo".
-Exchanges 1 and 2 are a few dozen bytes (latency-bound); exchange 3 is 0.28 MB + 64 B per embedding
-row.  Known deviation under sharding: the sampler's tail loop consults the hit list of the first ray
+Exchanges 1 and 2 are latency-bound, so each is ONE collective: every rank all-gathers its whole 96-byte counter block
+and a one-block kernel (nl_dist_merge_counters) folds the gathered blocks into the local one (sums, max, rank offset) -
+not one collective per quantity plus a dozen tiny torch kernels.  Exchange 3 all-reduces the gradients IN PLACE: the
+decoder gradient, the pose partials and the embedding accumulators are re-homed once into one flat buffer
+[decoder | pose | embeddings], so there is nothing to pack or unpack (0.28 MB + 64 B per embedding row).
+Known deviation under sharding: the sampler's tail loop consults the hit list of the first ray
 of its batch row (sample_gpu.cu:231); when that ray lives on another rank the own list is used.
 """
 import torch
@@ -23,8 +27,7 @@ import torch.distributed as dist
 
 from . import _lib as L
 
-_SUM_INTS = [L.NLC_NFS, L.NLC_NSDF, L.NLC_INV_FS_RAYS, L.NLC_INV_FS_CNT, L.NLC_INV_SDF_RAYS, L.NLC_INV_SDF_CNT,
-             L.NLC_OVERFLOW, L.NLC_GUARD]
+assert (L.NLC_NFS, L.NLC_GUARD) == (4, 11)          # the summed counters are the contiguous slots NFS .. GUARD (nl_common.h)
 
 
 def shard_bounds(n, rank, world):
@@ -41,57 +44,74 @@ class RayShardedExchange:
         self.rank = dist.get_rank(group)
         self.eng = engine
         dev = engine.counters.device
-        self._gather = torch.zeros(self.world, 2, dtype=torch.int32, device=dev)
-        self._local2 = torch.zeros(2, dtype=torch.int32, device=dev)
-        self._sum_idx = torch.tensor(_SUM_INTS, dtype=torch.long, device=dev)
+        self._stride = L.NL_CNT_BYTES // 4
+        self._gather = torch.zeros(self.world * self._stride, dtype=torch.int32, device=dev)
+        self._flat = None
         engine.hook_after_intersect = self.after_intersect
         engine.hook_after_count = self.after_count
         engine.hook_after_backward = self.after_backward
 
+    def _merge(self, c, stage):
+        """fold the gathered counter blocks into the local block `c`"""
+        if c.is_cuda:
+            L.check(L.lib().nl_dist_merge_counters(L.ptr(self._gather), self.world, self.rank, stage, L.ptr(c),
+                                                   torch.cuda.current_stream().cuda_stream), "nl_dist_merge_counters")
+            return
+        # host tensors: the gloo test rig of tests/test_dist_gloo.py (no GPU in the loop) - same arithmetic in torch
+        g = self._gather.view(self.world, self._stride)
+        if stage == 1:
+            c[L.NLC_R_GLOBAL] = g[:, L.NLC_R].sum()
+            c[L.NLC_R_OFFSET] = g[:self.rank, L.NLC_R].sum()
+            c[L.NLC_HMAX] = g[:, L.NLC_HMAX].max()
+        else:
+            c[L.NLC_NFS:L.NLC_GUARD + 1] = g[:, L.NLC_NFS:L.NLC_GUARD + 1].sum(0)
+            c[L.NLC_SMAX] = g[:, L.NLC_SMAX].max()
+            gd = g[:, L.NL_CNT_INTS:].contiguous().view(torch.float64)
+            c[L.NL_CNT_INTS:].view(torch.float64)[L.NLD_INV_D2:L.NLD_INV_D2CNT + 1] = gd[:, L.NLD_INV_D2:L.NLD_INV_D2CNT + 1].sum(0)
+
     # exchange 1
     def after_intersect(self, eng):
-        c = eng.counters
-        self._local2[0:1].copy_(c[L.NLC_R:L.NLC_R + 1])
-        self._local2[1:2].copy_(c[L.NLC_HMAX:L.NLC_HMAX + 1])
-        dist.all_gather_into_tensor(self._gather.view(-1), self._local2, group=self.group)
-        g = self._gather
-        c[L.NLC_R_GLOBAL:L.NLC_R_GLOBAL + 1].copy_(g[:, 0].sum(dtype=torch.int32).view(1))
-        c[L.NLC_R_OFFSET:L.NLC_R_OFFSET + 1].copy_(g[:self.rank, 0].sum(dtype=torch.int32).view(1))
-        c[L.NLC_HMAX:L.NLC_HMAX + 1].copy_(g[:, 1].max().view(1))
+        dist.all_gather_into_tensor(self._gather, eng.counters, group=self.group)
+        self._merge(eng.counters, 1)
 
     # exchange 2
     def after_count(self, eng):
-        c = eng.counters
-        ints = c[self._sum_idx]
-        dist.all_reduce(ints, op=dist.ReduceOp.SUM, group=self.group)
-        c[self._sum_idx] = ints
-        smax = c[L.NLC_SMAX:L.NLC_SMAX + 1]
-        dist.all_reduce(smax, op=dist.ReduceOp.MAX, group=self.group)
-        dbl = c[L.NL_CNT_INTS:].view(torch.float64)[L.NLD_INV_D2:L.NLD_INV_D2CNT + 1]
-        dist.all_reduce(dbl, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_gather_into_tensor(self._gather, eng.counters, group=self.group)
+        self._merge(eng.counters, 2)
+
+    def _adopt(self, eng, dec):
+        """re-home dec.grad, eng.g_pose, eng.g_emb into ONE flat buffer (views keep shape and contents); redone when the
+        engine reallocated one of them (new map size)"""
+        parts = [dec.grad, eng.g_pose, eng.g_emb]
+        f = self._flat
+        if f is not None:
+            off, ok = 0, True
+            for p in parts:
+                ok = ok and p.data_ptr() == f.data_ptr() + 4 * off and p.dtype == torch.float32
+                off += p.numel()
+            if ok and off == f.numel():
+                return
+        f = torch.empty(sum(p.numel() for p in parts), dtype=torch.float32, device=parts[0].device)
+        off, views = 0, []
+        for p in parts:
+            v = f[off:off + p.numel()].view(p.shape)
+            v.copy_(p)
+            views.append(v)
+            off += p.numel()
+        dec.grad, eng.g_pose, eng.g_emb = views
+        self._flat = f
 
     # exchange 3
     def after_backward(self, eng, dec, train_decoder, want_emb_grad, want_pose_grad):
-        """ONE collective for all gradients: pack [decoder | pose partials | embedding accumulators] into a flat fp32
-        buffer (two tiny copy kernels cost far less than two extra RCCL launches), all-reduce, unpack."""
-        parts = []
-        if train_decoder:
-            parts.append(dec.grad.view(-1))
-        if want_pose_grad:
-            parts.append(eng.g_pose.view(-1))
-        if want_emb_grad:
-            parts.append(eng.g_emb.view(-1))
-        if not parts:
+        """ONE in-place collective over the contiguous range of [decoder | pose | embeddings] that covers what was computed
+        (an unused part in between is all zeros: the accumulators are cleared by the optimiser step)"""
+        if not (train_decoder or want_pose_grad or want_emb_grad):
             return
-        if len(parts) == 1:
-            dist.all_reduce(parts[0], op=dist.ReduceOp.SUM, group=self.group)
-            return
-        flat = torch.cat(parts)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        off = 0
-        for p in parts:
-            p.copy_(flat[off:off + p.numel()])
-            off += p.numel()
+        self._adopt(eng, dec)
+        nd, npz = dec.grad.numel(), eng.g_pose.numel()
+        lo = 0 if train_decoder else (nd if want_pose_grad else nd + npz)
+        hi = self._flat.numel() if want_emb_grad else (nd + npz if want_pose_grad else nd)
+        dist.all_reduce(self._flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
 
     def reduce_loss_sums(self):
         c = self.eng.counters

@@ -495,3 +495,27 @@ def test_hipgraph_replay_matches_eager(nl, golden_dir):
     d = np.abs(outs["graph"][1] - outs["eager"][1])
     assert (d > 5e-5).mean() < 2e-3
     assert (outs["graph"][2] != outs["eager"][2]).mean() < 5e-3
+
+
+def test_dist_counter_merge_kernel_matches_the_host_rig(nl):
+    """nl_dist_merge_counters (the one-block kernel behind exchanges 1 and 2 of nerf_loam_amd/dist.py) against the torch
+    arithmetic the gloo test rig uses on host tensors"""
+    from types import SimpleNamespace
+    from nerf_loam_amd import dist as D
+    L = nl["L"]
+    world, stride = 4, L.NL_CNT_BYTES // 4
+    rng = np.random.default_rng(9)
+    blocks = rng.integers(0, 1000, size=(world, stride)).astype(np.int32)
+    dbl = rng.normal(size=(world, L.NL_CNT_DOUBLES))
+    blocks[:, L.NL_CNT_INTS:] = dbl.view(np.int32).reshape(world, -1)
+    for rank in range(world):
+        for stage in (1, 2):
+            res = []
+            for dev in ("cpu", "cuda"):
+                ex = SimpleNamespace(world=world, rank=rank, _stride=stride, _gather=torch.from_numpy(blocks.reshape(-1).copy()).to(dev))
+                c = torch.from_numpy(blocks[rank].copy()).to(dev)
+                D.RayShardedExchange._merge(ex, c, stage)
+                res.append(c.cpu().numpy())
+            assert np.array_equal(res[0], res[1]), (rank, stage)
+            if stage == 1:
+                assert res[1][L.NLC_R_GLOBAL] == blocks[:, L.NLC_R].sum() and res[1][L.NLC_R_OFFSET] == blocks[:rank, L.NLC_R].sum()
