@@ -413,8 +413,8 @@ class SdfEngine:
         """Scalar loss of criterion.py:43-56 from the device sums (value only; gradients never need it)."""
         st = self.stats()
         ints, dbl = st["ints"], st["dbl"]
-        n = float(st["R"]) * float(st["S"])
-        if n == 0:
+        n = float(int(ints[L.NLC_R_GLOBAL])) * float(st["S"])       # global hit-ray count (== R on one GPU; under ray sharding the
+        if n == 0:                                                  # residual sums must have been all-reduced: dist.reduce_loss_sums)
             return None
         inv_fs = st["S"] * int(ints[L.NLC_INV_FS_RAYS]) - int(ints[L.NLC_INV_FS_CNT])
         fs = (dbl[L.NLD_FS_SQ] + inv_fs) / n * st["w_fs"]
