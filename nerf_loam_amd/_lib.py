@@ -48,6 +48,7 @@ _SIGS = {
     "nl_ray_intersect": ([_I] + [_P] * 7 + [_I, _F, _F] + [_P] * 9, _I),
     "nl_exclusive_scan_i32": ([_P, _P, _I, _I, _P, _P, _P], _I),
     "nl_compact_hit_rays": ([_I, _P, _P, _P, _P], _I),
+    "nl_scan_hit_rays": ([_P, _P, _P, _I, _P, _P, _P, _P], _I),
     "nl_sample_rays": ([_I, _I] + [_P] * 8 + [_F, _F, _F, _U, _I, _I, _I] + [_P, _P, _P, _I] + [_P] * 5, _I),
     "nl_loss_finalize": ([_P, _P, _F, _F, _F, _F, _I, _P], _I),
     "nl_gather_trilinear": ([_P] * 7 + [_I] + [_P] * 3 + [_F, _P, _I, _P], _I),

@@ -424,34 +424,70 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_blocks(const int* __res
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_sums(int* __restrict__ block_sums, int nblocks, int* __restrict__ total_out)
+// Second (last) pass of the large scan: block b adds the sum of the block sums before it (at most a few hundred values,
+// reduced by the block itself: no separate "scan of the sums" launch), optionally writes the hit-ray compaction
+// ray_of_rank[rank] = ray (render_helpers.py:219-227) and the grand total to up to two places.
+__global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_finish(const int* __restrict__ in, int* __restrict__ out,
+                                                                 const int* __restrict__ block_sums, int n, int* __restrict__ ray_of_rank,
+                                                                 int* __restrict__ total_out, int* __restrict__ total_out2)
 {
     __shared__ int s_wave[NL_GEO_THREADS / 64];
-    __shared__ int s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
+    int part = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += NL_GEO_THREADS) part += block_sums[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = part;
     __syncthreads();
-    for (int c0 = 0; c0 < nblocks; c0 += NL_SCAN_BLOCK) {
+    int add = 0;
+#pragma unroll
+    for (int w = 0; w < NL_GEO_THREADS / 64; ++w) add += s_wave[w];
+    const int base = blockIdx.x * NL_SCAN_BLOCK + threadIdx.x * NL_SCAN_ITEMS;
+#pragma unroll
+    for (int i = 0; i < NL_SCAN_ITEMS; ++i) {
+        if (base + i < n) {
+            const int r = out[base + i] + add;
+            out[base + i] = r;
+            if (ray_of_rank && in[base + i] > 0) ray_of_rank[r] = base + i;
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const int tot = add + block_sums[blockIdx.x];
+        *total_out = tot;
+        if (total_out2) *total_out2 = tot;
+    }
+}
+
+// Whole scan in ONE launch for small inputs (tracking: 2048 rays; a ray shard of a multi-GPU run): one block walks the
+// input in chunks of 1024 with a carry.  For these sizes the three-launch version was pure launch latency.
+#define NL_SCAN_ONE_BLOCK_MAX 16384
+__global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_one_block(const int* __restrict__ in, int* __restrict__ out, int n, int flag_mode,
+                                                                    int* __restrict__ ray_of_rank, int* __restrict__ total_out,
+                                                                    int* __restrict__ total_out2)
+{
+    __shared__ int s_wave[NL_GEO_THREADS / 64];
+    int carry = 0;
+    for (int c0 = 0; c0 < n; c0 += NL_SCAN_BLOCK) {
         const int base = c0 + threadIdx.x * NL_SCAN_ITEMS;
         int v[NL_SCAN_ITEMS], sum = 0;
 #pragma unroll
-        for (int i = 0; i < NL_SCAN_ITEMS; ++i) { v[i] = (base + i < nblocks) ? block_sums[base + i] : 0; sum += v[i]; }
+        for (int i = 0; i < NL_SCAN_ITEMS; ++i) {
+            int x = (base + i < n) ? in[base + i] : 0;
+            if (flag_mode) x = x > 0 ? 1 : 0;
+            v[i] = x; sum += x;
+        }
         int tot;
-        int ex = block_exclusive_scan(sum, s_wave, &tot) + s_carry;
+        int ex = block_exclusive_scan(sum, s_wave, &tot) + carry;
 #pragma unroll
-        for (int i = 0; i < NL_SCAN_ITEMS; ++i) { if (base + i < nblocks) block_sums[base + i] = ex; ex += v[i]; }
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry += tot;
-        __syncthreads();
+        for (int i = 0; i < NL_SCAN_ITEMS; ++i) {
+            if (base + i < n) {
+                out[base + i] = ex;
+                if (ray_of_rank && v[i] > 0) ray_of_rank[ex] = base + i;
+            }
+            ex += v[i];
+        }
+        carry += tot;
     }
-    if (threadIdx.x == 0) *total_out = s_carry;
-}
-
-__global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_add(int* __restrict__ out, const int* __restrict__ block_sums, int n)
-{
-    const int base = blockIdx.x * NL_SCAN_BLOCK + threadIdx.x * NL_SCAN_ITEMS;
-    const int add = block_sums[blockIdx.x];
-#pragma unroll
-    for (int i = 0; i < NL_SCAN_ITEMS; ++i) if (base + i < n) out[base + i] += add;
+    if (threadIdx.x == 0) { *total_out = carry; if (total_out2) *total_out2 = carry; }
 }
 
 // ray_of_rank[rank] = ray  for rays with hit_count > 0   (the reference's boolean-mask compaction
@@ -716,17 +752,35 @@ int nl_ray_intersect(int N, const float* rays_d_sensor, const float* points_gt, 
     return NL_OK;
 }
 
+static int scan_launch(const int* in, int* out, int n, int flag_mode, int* ray_of_rank, int* total_out, int* total_out2,
+                       int* workspace, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (n <= NL_SCAN_ONE_BLOCK_MAX) {
+        hipLaunchKernelGGL(k_scan_one_block, dim3(1), dim3(NL_GEO_THREADS), 0, s, in, out, n, flag_mode, ray_of_rank, total_out, total_out2);
+    } else {
+        const int nb = nl_div_up(n, NL_SCAN_BLOCK);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(NL_GEO_THREADS), 0, s, in, out, workspace, n, flag_mode);
+        hipLaunchKernelGGL(k_scan_finish, dim3(nb), dim3(NL_GEO_THREADS), 0, s, in, out, workspace, n, ray_of_rank, total_out, total_out2);
+    }
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
 // exclusive scan of in[0..n) into out, total -> *total_out (device).  workspace: >= ceil(n/1024) ints.
 int nl_exclusive_scan_i32(const int* in, int* out, int n, int flag_mode, int* total_out, int* workspace, void* stream)
 {
     if (n <= 0 || !in || !out || !total_out || !workspace) return NL_ERR_INVALID_ARG;
-    const int nb = nl_div_up(n, NL_SCAN_BLOCK);
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(NL_GEO_THREADS), 0, s, in, out, workspace, n, flag_mode);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(NL_GEO_THREADS), 0, s, workspace, nb, total_out);
-    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(NL_GEO_THREADS), 0, s, out, workspace, n);
-    NL_LAUNCH_CHECK();
-    return NL_OK;
+    return scan_launch(in, out, n, flag_mode, nullptr, total_out, nullptr, workspace, stream);
+}
+
+/* hit-ray bookkeeping in one go (render_helpers.py:219-227): hit_rank = exclusive scan of (hit_count > 0),
+ * ray_of_rank[rank] = ray, number of hit rays -> *total_out and (optional) *total_out2 */
+int nl_scan_hit_rays(const int* hit_count, int* hit_rank, int* ray_of_rank, int N, int* total_out, int* total_out2, int* workspace,
+                     void* stream)
+{
+    if (N <= 0 || !hit_count || !hit_rank || !ray_of_rank || !total_out || !workspace) return NL_ERR_INVALID_ARG;
+    return scan_launch(hit_count, hit_rank, N, 1, ray_of_rank, total_out, total_out2, workspace, stream);
 }
 
 int nl_compact_hit_rays(int N, const int* hit_count, const int* hit_rank, int* ray_of_rank, void* stream)

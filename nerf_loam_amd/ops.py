@@ -155,3 +155,8 @@ def select_rays(M, n_select, seed, rays_d, points, cos_in, frame, out_rays_d, ou
     check(L.lib().nl_select_rays(int(M), int(n_select), int(seed) & 0xFFFFFFFF, ptr(rays_d), ptr(points), ptr(cos_in), int(frame),
                                  ptr(out_rays_d), ptr(out_points), ptr(out_cos), ptr(out_frame_id), ptr(mask_out), ptr(workspace),
                                  stream_ptr()), "nl_select_rays")
+
+
+def scan_hit_rays(hit_count, hit_rank, ray_of_rank, N, total_out, total_out2, workspace):
+    check(L.lib().nl_scan_hit_rays(ptr(hit_count), ptr(hit_rank), ptr(ray_of_rank), int(N), ptr(total_out), ptr(total_out2), ptr(workspace),
+                                   stream_ptr()), "nl_scan_hit_rays")

@@ -300,12 +300,11 @@ class SdfEngine:
         ops.ray_intersect(N, self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self.poses12, m.blk_hdr, m.blk_ids, m.root_side,
                           m.voxel_size, cfg.max_distance, self.rays_d_world, self.gt_dist, self.hit_idx, self.hit_t0, self.hit_t1,
                           self.hit_count, c, self.ray_of_rank)
-        ops.exclusive_scan(self.hit_count, self.hit_rank, N, 1, c[L.NLC_R:L.NLC_R + 1], self.scan_ws)
+        # hit-ray ranks + compaction + R (and R_GLOBAL: overwritten by the multi-GPU hook) in one launch (two beyond 16 k rays)
+        ops.scan_hit_rays(self.hit_count, self.hit_rank, self.ray_of_rank, N, c[L.NLC_R:L.NLC_R + 1], c[L.NLC_R_GLOBAL:L.NLC_R_GLOBAL + 1],
+                          self.scan_ws)
         if self.hook_after_intersect is not None:
             self.hook_after_intersect(self)                      # fills NLC_R_GLOBAL / NLC_R_OFFSET / global NLC_HMAX
-        else:
-            c[L.NLC_R_GLOBAL:L.NLC_R_GLOBAL + 1].copy_(c[L.NLC_R:L.NLC_R + 1])
-        ops.compact_hit_rays(N, self.hit_count, self.hit_rank, self.ray_of_rank)
         seed = 0 if cfg.noise_seed is None else cfg.noise_seed
         use_hash = 0 if cfg.noise_seed is None else 1
         args = (N, self.hit_idx, self.hit_t0, self.hit_t1, self.hit_count, self.hit_rank, self.ray_of_rank, self.cos_gt, self.gt_dist,
@@ -343,9 +342,8 @@ class SdfEngine:
         ops.ray_intersect(N, self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self.poses12, m.blk_hdr, m.blk_ids, m.root_side,
                           m.voxel_size, cfg.max_distance, self.rays_d_world, self.gt_dist, self.hit_idx, self.hit_t0, self.hit_t1,
                           self.hit_count, c, self.ray_of_rank)
-        ops.exclusive_scan(self.hit_count, self.hit_rank, N, 1, c[L.NLC_R:L.NLC_R + 1], self.scan_ws)
-        c[L.NLC_R_GLOBAL:L.NLC_R_GLOBAL + 1].copy_(c[L.NLC_R:L.NLC_R + 1])
-        ops.compact_hit_rays(N, self.hit_count, self.hit_rank, self.ray_of_rank)
+        ops.scan_hit_rays(self.hit_count, self.hit_rank, self.ray_of_rank, N, c[L.NLC_R:L.NLC_R + 1], c[L.NLC_R_GLOBAL:L.NLC_R_GLOBAL + 1],
+                          self.scan_ws)
         seed = 0 if cfg.noise_seed is None else cfg.noise_seed
         args = (N, self.hit_idx, self.hit_t0, self.hit_t1, self.hit_count, self.hit_rank, self.ray_of_rank, self.cos_gt, self.gt_dist,
                 cfg.step_size, cfg.truncation, cfg.max_distance, seed, 0 if cfg.noise_seed is None else 1, int(cfg.tail_always),
