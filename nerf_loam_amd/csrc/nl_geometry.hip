@@ -240,6 +240,9 @@ __device__ __forceinline__ bool dfs_before(int x1, int y1, int z1, int x2, int y
     return a > b;
 }
 
+__device__ long long* g_isect_dbg = nullptr;            // optional [blocks][8] stamps of thread 0 (profiling aid, nl_geometry_set_debug_buffer)
+#define ISTAMP(k, v) do { if (g_isect_dbg && threadIdx.x == 0) g_isect_dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)(v); } while (0)
+
 __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
     int N, const float* __restrict__ rays_d_sensor, const float* __restrict__ points_gt,
     const float* __restrict__ cos_gt, const int* __restrict__ frame_id, const float* __restrict__ poses,
@@ -255,6 +258,8 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
     __shared__ int s_head[IQ_RAYS], s_tail[IQ_RAYS], s_nh[IQ_RAYS], s_ovf[IQ_RAYS];
     __shared__ int s_hmax;
     if (threadIdx.x == 0) s_hmax = 0;
+    ISTAMP(0, __builtin_readcyclecounter());
+    int rounds = 0;
     const int rl = threadIdx.x / IQ_LPR, j = threadIdx.x % IQ_LPR;
     const int r = blockIdx.x * IQ_RAYS + rl;
     const bool live = r < N;
@@ -286,9 +291,11 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
     // The pending expansions form a STACK (s_tail = height): the four lanes always take the deepest pending nodes, which
     // keeps the pending set as small as a DFS with all siblings pushed (a line meets at most 4 of a node's 8 children,
     // so <= 3 per level + 4), while still giving four independent memory round trips per ray per round.
+    ISTAMP(1, __builtin_readcyclecounter());
     for (;;) {
         const int height = (live && !s_ovf[rl]) ? s_tail[rl] : 0;
         if (!__any(height > 0)) break;                              // wave-uniform: all 16 rays of this wave are done
+        ++rounds;
         const int k = height < IQ_LPR ? height : IQ_LPR;
         const bool mine = j < k;
         int4 e = make_int4(0, 0, 0, 0);
@@ -337,6 +344,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    ISTAMP(2, __builtin_readcyclecounter()); ISTAMP(4, rounds);
     // finalise: one lane per ray
     int valid = 0;
     if (live && j == 0) {
@@ -376,6 +384,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
             hit_count[r] = valid;
         }
     }
+    ISTAMP(3, __builtin_readcyclecounter());
     int wmax = valid;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off));
@@ -781,6 +790,14 @@ int nl_scan_hit_rays(const int* hit_count, int* hit_rank, int* ray_of_rank, int 
 {
     if (N <= 0 || !hit_count || !hit_rank || !ray_of_rank || !total_out || !workspace) return NL_ERR_INVALID_ARG;
     return scan_launch(hit_count, hit_rank, N, 1, ray_of_rank, total_out, total_out2, workspace, stream);
+}
+
+/* profiling aid: device buffer [blocks][8] int64: cycle stamps (start, after set-up, after traversal, after finalise) and the
+ * round count of wave 0 of every workgroup of k_ray_intersect_q (NULL disables) */
+int nl_geometry_set_debug_buffer(void* dbg)
+{
+    long long* p = (long long*)dbg;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_isect_dbg), &p, sizeof(p)) == hipSuccess ? NL_OK : NL_ERR_LAUNCH;
 }
 
 int nl_compact_hit_rays(int N, const int* hit_count, const int* hit_rank, int* ray_of_rank, void* stream)

@@ -25,4 +25,10 @@ for n, mode in [(N, "all"), (16384, "first"), (16384, "random"), (2048, "random"
     a.record()
     for _ in range(10): run()
     b.record(); torch.cuda.synchronize()
-    print(f"N={n:7d} {mode:9s} {a.elapsed_time(b)/10*1e3:8.1f} us/launch")
+    nb = (n + 63) // 64
+    dbg = torch.zeros(nb * 8, dtype=torch.int64, device="cuda")
+    L.lib().nl_geometry_set_debug_buffer(L.ptr(dbg)); run(); torch.cuda.synchronize(); L.lib().nl_geometry_set_debug_buffer(None)
+    d = dbg.cpu().numpy().reshape(nb, 8)
+    ph = np.diff(d[:, :4], axis=1)
+    print(f"N={n:7d} {mode:9s} {a.elapsed_time(b)/10*1e3:8.1f} us/launch | cycles of wave 0: set-up {ph[:,0].mean():.0f}, traversal {ph[:,1].mean():.0f} "
+          f"(max {ph[:,1].max():.0f}; rounds mean {d[:,4].mean():.1f} max {d[:,4].max()}), finalise {ph[:,2].mean():.0f} (max {ph[:,2].max():.0f})")
