@@ -54,6 +54,17 @@ NL_HD float nl_noise(uint32_t seed, uint32_t ray, uint32_t step) {
     return u < 0.001f ? 0.001f : (u > 0.999f ? 0.999f : u);
 }
 
+// Exact three-term bf16 split of an fp32 value (nl_decoder.hip / nl_optim.hip: operands of the bf16 matrix cores):
+// hi = v truncated to its top 8 significand bits, mid = (v - hi) truncated likewise, lo = the rest (<= 8 significant bits).
+// Each term is exactly representable in bf16 (returned as its 16-bit pattern) and hi + mid + lo == v exactly.
+NL_HD void nl_split3_bf16(float v, uint16_t* hi, uint16_t* mid, uint16_t* lo) {
+    union { float f; uint32_t u; } a, b, r;
+    a.f = v; a.u &= 0xFFFF0000u;
+    b.f = v - a.f; b.u &= 0xFFFF0000u;
+    r.f = (v - a.f) - b.f;
+    *hi = (uint16_t)(a.u >> 16); *mid = (uint16_t)(b.u >> 16); *lo = (uint16_t)(r.u >> 16);
+}
+
 // ray-selection key (nl_select.hip): lowbias32 is a bijection on 32-bit integers, so keys of distinct rays never tie
 NL_HD uint32_t nl_select_key(uint32_t seed, uint32_t i) {
     uint32_t x = i ^ (seed * 0x9E3779B9u + 0x7F4A7C15u);

@@ -82,13 +82,7 @@ __global__ void k_prepare_w2x(const float* __restrict__ params, uint16_t* __rest
         for (int e = 0; e < 8; ++e) {
             const int kk = k0 + e;
             const float v = which ? params[NL_OFF_W2 + c * NL_W + kk] : params[NL_OFF_W3 + kk] * params[NL_OFF_W2 + kk * NL_W + c];
-            union { float f; uint32_t u; } a, b, r;
-            a.f = v; a.u &= 0xFFFF0000u;
-            b.f = v - a.f; b.u &= 0xFFFF0000u;
-            r.f = (v - a.f) - b.f;                               // <= 8 significant bits left: exact in bf16
-            dst[e] = (uint16_t)(a.u >> 16);
-            dst[e + NL_W * NL_W] = (uint16_t)(b.u >> 16);
-            dst[e + 2 * NL_W * NL_W] = (uint16_t)(r.u >> 16);
+            nl_split3_bf16(v, &dst[e], &dst[e + NL_W * NL_W], &dst[e + 2 * NL_W * NL_W]);
         }
     }
 }

@@ -103,4 +103,14 @@ void hh_loss(int P, const float* sdf, const float* z, const float* d, float w_fs
     }
 }
 
+void hh_split3_bf16(int n, const float* v, uint16_t* hi, uint16_t* mid, uint16_t* lo)
+{
+    for (int i = 0; i < n; ++i) nl_split3_bf16(v[i], &hi[i], &mid[i], &lo[i]);
+}
+
+void hh_select_key(int n, uint32_t seed, uint32_t* out)
+{
+    for (int i = 0; i < n; ++i) out[i] = nl_select_key(seed, (uint32_t)i);
+}
+
 }  // extern "C"

@@ -264,3 +264,48 @@ def test_sampler_edge_cases_bit_exact(hh):
         if tail == 1:                                                                   # "fixed" sampler covers every interval fully
             span = ((t1 - t0) * (idx != -1)).sum(1)
             np.testing.assert_allclose(s_dst.sum(1), span, rtol=0, atol=2e-5)
+
+
+def test_three_term_bf16_split_is_exact(hh):
+    """The arithmetic fact behind the decoder GEMMs on the bf16 matrix cores: nl_split3_bf16 writes an fp32
+    value as three bf16 terms whose sum is the value EXACTLY, and any product of two bf16 terms is exact in fp32 - so the
+    matrix core forms exact partial products and only the fp32 accumulation rounds, as in an fp32 GEMM."""
+    rng = np.random.default_rng(0)
+    v = np.concatenate([
+        rng.normal(size=200000).astype(np.float32), (rng.normal(size=50000) * 1e-6).astype(np.float32),
+        (rng.normal(size=50000) * 1e6).astype(np.float32), rng.integers(0, 2 ** 32, 200000, dtype=np.uint64).astype(np.uint32).view(np.float32),
+        np.array([0.0, -0.0, 1.0, -1.0, 1e-30, -1e-30, 3.4e38, 1.1754944e-38, np.float32(1) + np.float32(2 ** -23), 0.1, 1 / 3], np.float32)])
+    v = v[np.isfinite(v) & ((np.abs(v) >= 2.0 ** -100) | (v == 0))]        # results far above the bf16 subnormal range, as in the kernels
+    n = len(v)
+    hi, mid, lo = (np.empty(n, np.uint16) for _ in range(3))
+    hh.hh_split3_bf16(n, p(v), p(hi), p(mid), p(lo))
+    f = lambda b: (b.astype(np.uint32) << 16).view(np.float32)
+    H_, M_, L_ = f(hi).astype(np.float64), f(mid).astype(np.float64), f(lo).astype(np.float64)
+    assert np.array_equal(H_ + M_ + L_, v.astype(np.float64))                 # exact (float64 holds the three-term sum exactly)
+    assert (np.abs(M_) <= np.abs(H_) * 2.0 ** -7 + 0).all() and (np.abs(L_) <= np.abs(H_) * 2.0 ** -15).all()
+    # a bf16 x bf16 product has a 16-bit significand: exact in fp32
+    a, b = f(hi[:100000]), f(mid[100000:200000])
+    assert np.array_equal((a.astype(np.float64) * b.astype(np.float64)).astype(np.float32).astype(np.float64), a.astype(np.float64) * b.astype(np.float64))
+    # hence sum_k a_k b_k == sum_k sum_{p,q} a_k^(p) b_k^(q) exactly (checked in float64 on a 256-term dot product of fp32 values)
+    x, w = rng.normal(size=256).astype(np.float32), rng.normal(size=256).astype(np.float32)
+    parts = []
+    for arr in (x, w):
+        h_, m_, l_ = (np.empty(256, np.uint16) for _ in range(3))
+        hh.hh_split3_bf16(256, p(arr), p(h_), p(m_), p(l_))
+        parts.append([f(h_).astype(np.float64), f(m_).astype(np.float64), f(l_).astype(np.float64)])
+    from fractions import Fraction
+    exact = sum(Fraction(float(a_)) * Fraction(float(b_)) for a_, b_ in zip(x, w))
+    nine = sum(Fraction(float(pa[k])) * Fraction(float(pb[k])) for pa in parts[0] for pb in parts[1] for k in range(256))
+    assert exact == nine
+
+
+def test_select_key_is_a_bijection_and_matches_the_numpy_restatement(hh):
+    n = 1 << 20
+    out = np.empty(n, np.uint32)
+    hh.hh_select_key(n, 12345, p(out))
+    assert len(np.unique(out)) == n
+    x = np.arange(n, dtype=np.uint64) ^ np.uint64((12345 * 0x9E3779B9 + 0x7F4A7C15) & 0xFFFFFFFF)
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7FEB352D)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846CA68B)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    assert np.array_equal(out.astype(np.uint64), x)
