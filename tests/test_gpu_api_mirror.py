@@ -193,6 +193,53 @@ def test_incremental_map_update_equals_a_full_rebuild():
     assert mapper.svo.count_nodes() == mapper.map_states["voxel_center_xyz"].shape[0]
 
 
+def test_device_resident_share_data_hand_off():
+    """nerf_loam_amd.share.ShareData - the reference's ShareData attributes, snapshots kept on the device in two
+    alternating buffers: publication isolates the tracker from later mapper updates, no host round trip"""
+    from nerf_loam_amd.lidar_frame import LidarFrame
+    from nerf_loam_amd.mapping import Mapping
+    from nerf_loam_amd.share import ShareData
+    from nerf_loam_amd.tracking import Tracking
+    torch.manual_seed(777)
+    pts, cos = H.scene_points(64, 64, 11)
+    args = make_args()
+    mapper = Mapping(args)
+    share = ShareData()
+    assert share.states is None and share.decoder is None
+    f0 = LidarFrame(0, torch.from_numpy(pts), torch.from_numpy(cos), np.eye(4))
+    mapper.create_voxels(f0)
+    for _ in range(3):
+        mapper.do_mapping(share, f0, selection_method="current")
+    assert share.version == 3
+    st = share.states
+    assert st["voxel_vertex_emb"].is_cuda and st["voxel_vertex_emb"].data_ptr() != mapper.dynamic_embeddings.data_ptr()
+    for k in ("voxel_center_xyz", "voxel_structure", "voxel_vertex_idx"):
+        assert torch.equal(st[k], mapper.map_states[k])
+    assert torch.equal(st["voxel_vertex_emb"], mapper.dynamic_embeddings)
+    w_pub = share.decoder.pts_linears[1].weight.detach().clone()
+    assert torch.equal(w_pub, mapper.decoder.pts_linears[1].weight.detach()) and share.decoder is not mapper.decoder
+    # the mapper keeps optimising: the published snapshot does not move until the next publication
+    snap = st["voxel_vertex_emb"].clone(); ptr3 = st["voxel_vertex_emb"].data_ptr()
+    mapper.dynamic_embeddings.add_(1.0)
+    assert torch.equal(share.states["voxel_vertex_emb"], snap) and share.states is st
+    mapper.update_share_data(share)
+    st4 = share.states
+    assert share.version == 4 and st4 is not st and st4["voxel_vertex_emb"].data_ptr() != ptr3       # the other buffer
+    assert torch.equal(st4["voxel_vertex_emb"], mapper.dynamic_embeddings)
+    mapper.dynamic_embeddings.sub_(1.0)
+    mapper.update_share_data(share)
+    assert share.version == 5 and share.states["voxel_vertex_emb"].data_ptr() == ptr3              # buffers alternate
+    # the tracker consumes the snapshot exactly like the reference's share_data
+    tracker = Tracking(args)
+    P4 = np.eye(4); P4[:3, 3] = [0.06, -0.05, 0.02]
+    f1 = LidarFrame(1, torch.from_numpy(pts), torch.from_numpy(cos), P4)
+    err0 = float((f1.pose.translation().detach() - f0.pose.translation().detach()).norm())
+    tracker.last_frame = f1
+    out = tracker.do_tracking(share, LidarFrame(2, torch.from_numpy(pts), torch.from_numpy(cos), np.eye(4)))
+    err1 = float((out.pose.translation().detach() - f0.pose.translation().detach()).norm())
+    assert err1 < 0.6 * err0, (err0, err1)
+
+
 def test_get_scores_matches_oracle():
     """mesh-time dense SDF grid (reference render_helpers.get_scores): HIP gather + decoder forward vs the oracle"""
     from nerf_loam_amd.decoder import Decoder
