@@ -197,17 +197,19 @@ struct NlTailCtx {
     bool tail_always;
 };
 
-template <typename NoiseF, typename EmitF>
-NL_HD int nl_sample_walk(const int* idx, const float* t0, const float* t1, int P, float step_size_m,
-                         const NlTailCtx& tc, NoiseF noise, EmitF emit) {
-    // ray_sample(): dists, probs, steps      (voxel_helpers.py:572-577), sequential fp32 sums
-    float tot = 0.0f;
-    for (int h = 0; h < P; ++h) { float d = (idx[h] == -1) ? 0.0f : (t1[h] - t0[h]); tot = tot + d; }
+// Core walk over accessor functors (idx(b), t0(b), t1(b) for 0 <= b < P) with the interval-length total `tot` supplied by
+// the caller (sequential fp32 sum over b = 0..P-1 of (idx == -1 ? 0 : t1 - t0)).  The fused GPU sampler keeps a ray's hit
+// list in LDS and passes accessors for it: a per-lane array indexed with a run-time bin index lives in scratch memory, and
+// its ~700-cycle latency sits on the walk's critical path at every interval change of ANY lane of the wave.
+template <typename GetI, typename GetF0, typename GetF1, typename NoiseF, typename EmitF>
+NL_HD int nl_sample_walk_core(GetI idx, GetF0 t0, GetF1 t1, int P, float tot, float step_size_m,
+                              const NlTailCtx& tc, NoiseF noise, EmitF emit) {
     const float steps = tot / step_size_m;
     int curr_bin = 0, s = 0;
-    float curr_min_depth = t0[0], curr_max_depth = t1[0];
+    int curr_idx = idx(0);
+    float curr_min_depth = t0(0), curr_max_depth = t1(0);
     float curr_min_cdf = 0.0f;
-    float curr_max_cdf = ((idx[0] == -1) ? 0.0f : (t1[0] - t0[0])) / tot;
+    float curr_max_cdf = ((curr_idx == -1) ? 0.0f : (curr_max_depth - curr_min_depth)) / tot;
     const float step = (float)(1.0 / (double)steps);
     float z_low = curr_min_depth;
     const int total_steps = (int)ceilf(steps);
@@ -215,31 +217,44 @@ NL_HD int nl_sample_walk(const int* idx, const float* t0, const float* t1, int P
     for (int cs = 0; cs < total_steps; ++cs) {
         float curr_cdf = ((float)cs + noise(cs)) * step;
         while (curr_cdf > curr_max_cdf) {
-            emit(s, idx[curr_bin], (curr_max_depth + z_low) * 0.5f, curr_max_depth - z_low);
+            emit(s, curr_idx, (curr_max_depth + z_low) * 0.5f, curr_max_depth - z_low);
             ++curr_bin; ++s;
-            if (curr_bin >= P || idx[curr_bin] == -1) { done = true; break; }
-            curr_min_depth = t0[curr_bin]; curr_max_depth = t1[curr_bin];
+            if (curr_bin >= P) { done = true; break; }
+            curr_idx = idx(curr_bin);
+            if (curr_idx == -1) { done = true; break; }
+            curr_min_depth = t0(curr_bin); curr_max_depth = t1(curr_bin);
             curr_min_cdf = curr_max_cdf;
-            curr_max_cdf = curr_max_cdf + (t1[curr_bin] - t0[curr_bin]) / tot;
+            curr_max_cdf = curr_max_cdf + (curr_max_depth - curr_min_depth) / tot;
             z_low = curr_min_depth;
         }
         if (done) break;
         float u = (curr_cdf - curr_min_cdf) / (curr_max_cdf - curr_min_cdf);
         float z = curr_min_depth + u * (curr_max_depth - curr_min_depth);
-        emit(s, idx[curr_bin], (z + z_low) * 0.5f, z - z_low);
+        emit(s, curr_idx, (z + z_low) * 0.5f, z - z_low);
         z_low = z;
         ++s;
     }
     while (z_low < curr_max_depth && !done &&
            (tc.tail_always || tc.rays_in_row > tc.j_in_row * P + curr_bin)) {
-        emit(s, idx[curr_bin], (curr_max_depth + z_low) * 0.5f, curr_max_depth - z_low);
+        emit(s, curr_idx, (curr_max_depth + z_low) * 0.5f, curr_max_depth - z_low);
         ++curr_bin; ++s;
         if (curr_bin >= P) break;
-        if ((tc.tail_always ? idx[curr_bin] : (curr_bin < tc.row_first_count ? tc.row_first_idx[curr_bin] : -1)) == -1) break;
-        curr_min_depth = t0[curr_bin]; curr_max_depth = t1[curr_bin];
+        curr_idx = idx(curr_bin);
+        if ((tc.tail_always ? curr_idx : (curr_bin < tc.row_first_count ? tc.row_first_idx[curr_bin] : -1)) == -1) break;
+        curr_min_depth = t0(curr_bin); curr_max_depth = t1(curr_bin);
         z_low = curr_min_depth;
     }
     return s;
+}
+
+template <typename NoiseF, typename EmitF>
+NL_HD int nl_sample_walk(const int* idx, const float* t0, const float* t1, int P, float step_size_m,
+                         const NlTailCtx& tc, NoiseF noise, EmitF emit) {
+    // ray_sample(): dists, probs, steps      (voxel_helpers.py:572-577), sequential fp32 sums
+    float tot = 0.0f;
+    for (int h = 0; h < P; ++h) { float d = (idx[h] == -1) ? 0.0f : (t1[h] - t0[h]); tot = tot + d; }
+    return nl_sample_walk_core([&](int b) { return idx[b]; }, [&](int b) { return t0[b]; }, [&](int b) { return t1[b]; },
+                               P, tot, step_size_m, tc, noise, emit);
 }
 
 // position of hit-ray r (0-based rank among the R hit rays) in the reference wrapper's padded

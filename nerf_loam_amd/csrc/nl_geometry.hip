@@ -242,6 +242,7 @@ __device__ __forceinline__ bool dfs_before(int x1, int y1, int z1, int x2, int y
 
 __device__ long long* g_isect_dbg = nullptr;            // optional [blocks][8] stamps of thread 0 (profiling aid, nl_geometry_set_debug_buffer)
 #define ISTAMP(k, v) do { if (g_isect_dbg && threadIdx.x == 0) g_isect_dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)(v); } while (0)
+#define SSTAMP(k) do { if (g_isect_dbg && threadIdx.x == 0) g_isect_dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
     int N, const float* __restrict__ rays_d_sensor, const float* __restrict__ points_gt,
@@ -534,27 +535,36 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample(SampleArgs a)
 {
     __shared__ int s_red[8];
     __shared__ double s_dred[2];
+    // the lane's hit list, entry-major ([entry][lane]: a lane's run-time bin index is conflict-free): 60 KB per workgroup
+    __shared__ int s_hi[NL_MAX_HITS * NL_GEO_THREADS];
+    __shared__ float s_h0[NL_MAX_HITS * NL_GEO_THREADS], s_h1[NL_MAX_HITS * NL_GEO_THREADS];
     if (threadIdx.x < 8) s_red[threadIdx.x] = 0;
     if (threadIdx.x < 2) s_dred[threadIdx.x] = 0.0;
     __syncthreads();
     const int r = blockIdx.x * NL_GEO_THREADS + threadIdx.x;
+    SSTAMP(0);
     int cnt = 0, nfs = 0, nsdf = 0, inv_fs = 0, inv_sdf = 0, guard = 0;
     double inv_d2 = 0.0;
     if (r < a.N && a.hit_count[r] > 0) {
         const int P = a.counters[NLC_HMAX];
         const int Rg = a.counters[NLC_R_GLOBAL];
         const int rank = a.hit_rank[r] + a.counters[NLC_R_OFFSET];
-        int hi[NL_MAX_HITS]; float h0[NL_MAX_HITS], h1[NL_MAX_HITS];
         float tot = 0.0f;
         const int nh = a.hit_count[r];
+        int* my_i = s_hi + threadIdx.x; float* my_0 = s_h0 + threadIdx.x; float* my_1 = s_h1 + threadIdx.x;
 #pragma unroll
         for (int l = 0; l < NL_MAX_HITS; ++l) {               // row tails beyond the ray's own hits are padding
             const bool v = l < nh;
-            hi[l] = v ? a.hit_idx[(size_t)r * NL_MAX_HITS + l] : -1;
-            h0[l] = v ? a.hit_t0[(size_t)r * NL_MAX_HITS + l] : a.max_depth;
-            h1[l] = v ? a.hit_t1[(size_t)r * NL_MAX_HITS + l] : a.max_depth;
+            const int i_ = v ? a.hit_idx[(size_t)r * NL_MAX_HITS + l] : -1;
+            const float t0_ = v ? a.hit_t0[(size_t)r * NL_MAX_HITS + l] : a.max_depth;
+            const float t1_ = v ? a.hit_t1[(size_t)r * NL_MAX_HITS + l] : a.max_depth;
+            my_i[l * NL_GEO_THREADS] = i_; my_0[l * NL_GEO_THREADS] = t0_; my_1[l * NL_GEO_THREADS] = t1_;
+            if (l < P) tot = tot + ((i_ == -1) ? 0.0f : (t1_ - t0_));                             // same order as l = 0..P-1
         }
-        for (int l = 0; l < P; ++l) tot = tot + ((hi[l] == -1) ? 0.0f : (h1[l] - h0[l]));
+        auto get_i = [&](int b) { return my_i[b * NL_GEO_THREADS]; };
+        auto get_0 = [&](int b) { return my_0[b * NL_GEO_THREADS]; };
+        auto get_1 = [&](int b) { return my_1[b * NL_GEO_THREADS]; };
+        SSTAMP(1);
         if (tot > 10.0f * NL_FILL_DEPTH) guard = 1;
         NlTailCtx tc;
         int first_rank;
@@ -565,6 +575,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample(SampleArgs a)
         tc.row_first_idx = a.hit_idx + (size_t)first_ray * NL_MAX_HITS;
         tc.row_first_count = a.hit_count[first_ray];
         tc.tail_always = a.tail_always != 0;
+        SSTAMP(2);
         const float c = a.cos_gt[r], d = a.gt_dist[r];
         const unsigned rid = (unsigned)(r + a.ray_id_base);
         const unsigned seed = a.seed;
@@ -578,7 +589,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample(SampleArgs a)
                     const int p = off + s;
                     if (p < cap) { a.s_vox[p] = vox; a.s_depth[p] = depth; a.s_dist[p] = dist < 0.0f ? 0.0f : dist; a.s_ray[p] = r; }
                 };
-                cnt = nl_sample_walk(hi, h0, h1, P, a.step_size, tc, noise, emit);
+                cnt = nl_sample_walk_core(get_i, get_0, get_1, P, tot, a.step_size, tc, noise, emit);
             } else {
                 auto emit = [&](int s, int vox, float depth, float dist) {
                     (void)s; (void)vox; (void)dist;
@@ -586,7 +597,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample(SampleArgs a)
                     nl_loss_masks(depth * c, d, a.tau, a.max_depth, &f, &m);
                     nfs += f ? 1 : 0; nsdf += m ? 1 : 0;
                 };
-                cnt = nl_sample_walk(hi, h0, h1, P, a.step_size, tc, noise, emit);
+                cnt = nl_sample_walk_core(get_i, get_0, get_1, P, tot, a.step_size, tc, noise, emit);
                 bool f, m;
                 nl_loss_masks(NL_FILL_DEPTH * c, d, a.tau, a.max_depth, &f, &m);
                 inv_fs = f ? 1 : 0; inv_sdf = m ? 1 : 0;
@@ -594,6 +605,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample(SampleArgs a)
             }
         }
     }
+    SSTAMP(3);
     if (EMIT) return;
     if (r < a.N) a.samp_count[r] = cnt;
     // block reductions -> a handful of atomics per block

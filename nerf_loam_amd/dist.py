@@ -37,6 +37,19 @@ def shard_bounds(n, rank, world):
     return lo, min(n, lo + per)
 
 
+def interleaved_order(n, world):
+    """Permutation of a ray list such that the contiguous blocks of shard_bounds() are the strided subsets r, r+world, ...:
+    neighbouring LiDAR returns (same beam, adjacent azimuth) cost about the same, whole beams do not (grazing beams cross
+    several times more voxels than upward ones), so contiguous blocks of a beam-major scan are badly balanced
+    (profiles/r01_i_shard_probe.txt).  Identity for world == 1."""
+    import numpy as np
+    if world <= 1:
+        return np.arange(n)
+    per = (n + world - 1) // world
+    idx = np.arange(per * world).reshape(per, world).T.reshape(-1)      # rank-major: r, r+world, r+2*world, ...
+    return idx[idx < n]
+
+
 class RayShardedExchange:
     def __init__(self, engine, group=None):
         self.group = group
