@@ -240,6 +240,43 @@ __device__ __forceinline__ bool dfs_before(int x1, int y1, int z1, int x2, int y
     return a > b;
 }
 
+// The 8 children of a node have only two candidate centre coordinates per axis (offset 0 or `cs`): the six (entry, exit)
+// parameter pairs are computed once per expansion and every child combines three of them with the early-out sequence
+// of slab_inv - the same operations on the same values, so the results are bit-identical to testing each child separately.
+struct ChildSlabs {
+    float t0[3][2], t1[3][2];
+    __device__ __forceinline__ void init(const float o[3], const float inv[3], int px, int py, int pz, int cs, float hs, float voxel_size, float half)
+    {
+        const int p[3] = {px, py, pz};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float c = ((float)(p[a] + (k ? cs : 0)) + hs) * voxel_size;
+                float u0 = (c - half - o[a]) * inv[a];
+                float u1 = (c + half - o[a]) * inv[a];
+                if (u1 < u0) { const float t = u0; u0 = u1; u1 = t; }
+                t0[a][k] = u0; t1[a][k] = u1;
+            }
+    }
+    __device__ __forceinline__ bool hit(int u, float* tn, float* tf) const
+    {
+        float lo = 0.0f, hi = 100000.0f;
+        const int k[3] = {u & 1, (u >> 1) & 1, (u >> 2) & 1};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float a0 = k[a] ? t0[a][1] : t0[a][0], a1 = k[a] ? t1[a][1] : t1[a][0];
+            if (a1 < lo) return false;
+            if (a0 > hi) return false;
+            lo = (a0 > lo) ? a0 : lo;
+            hi = (a1 < hi) ? a1 : hi;
+            if (lo > hi) return false;
+        }
+        *tn = lo; *tf = hi;
+        return true;
+    }
+};
+
 __device__ long long* g_isect_dbg = nullptr;            // optional [blocks][8] stamps of thread 0 (profiling aid, nl_geometry_set_debug_buffer)
 #define ISTAMP(k, v) do { if (g_isect_dbg && threadIdx.x == 0) g_isect_dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)(v); } while (0)
 #define SSTAMP(k) do { if (g_isect_dbg && threadIdx.x == 0) g_isect_dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -308,18 +345,23 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
         __builtin_amdgcn_wave_barrier();
         if (mine) {
             const int b = e.x, px = e.y, py = e.z, pz = e.w & 0xFFFFF, csl = e.w >> 20, cs = 1 << csl;
+            // leaf-parent blocks also need their node ids: both loads depend on b only, so issue them together (inside the
+            // `cs == 1` branch below the ids would wait for the header's round trip first)
+            int4 ia = make_int4(-1, -1, -1, -1), ib = ia;
+            if (cs == 1) { ia = blk_ids[2 * (size_t)b]; ib = blk_ids[2 * (size_t)b + 1]; }
             const int2 hdr = blk_hdr[b];
             const unsigned exist = (unsigned)hdr.y & 255u, has = ((unsigned)hdr.y >> 8) & 255u;
             const float fs = (float)cs, hs = fs * 0.5f, half = half_voxel * fs;
+            ChildSlabs slabs;
+            slabs.init(o, inv, px, py, pz, cs, hs, voxel_size, half);
             if (cs == 1) {
-                const int4 ia = blk_ids[2 * (size_t)b], ib = blk_ids[2 * (size_t)b + 1];
                 const int ids[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
 #pragma unroll
                 for (int u = 7; u >= 0; --u) {
                     if (!((exist >> u) & 1u) || ids[u] < 0) continue;
                     const int vx = px + (u & 1), vy = py + ((u >> 1) & 1), vz = pz + ((u >> 2) & 1);
                     float tn, tf;
-                    if (slab_inv(o, inv, ((float)vx + hs) * voxel_size, ((float)vy + hs) * voxel_size, ((float)vz + hs) * voxel_size, half, &tn, &tf)) {
+                    if (slabs.hit(u, &tn, &tf)) {
                         const int slot = atomicAdd(&s_nh[rl], 1);
                         if (slot < IQ_HCAP) {
                             const int a = rl * IQ_HCAP + slot;
@@ -333,10 +375,11 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
                     if (!((has >> u) & 1u)) continue;
                     const int cx = px + ((u & 1) ? cs : 0), cy = py + ((u & 2) ? cs : 0), cz = pz + ((u & 4) ? cs : 0);
                     float tn, tf;
-                    if (slab_inv(o, inv, ((float)cx + hs) * voxel_size, ((float)cy + hs) * voxel_size, ((float)cz + hs) * voxel_size, half, &tn, &tf)) {
+                    if (slabs.hit(u, &tn, &tf)) {
+                        const int cb = hdr.x + __popc(has & ((1u << u) - 1u));
                         const int slot = atomicAdd(&s_tail[rl], 1);
                         if (slot < IQ_QCAP)
-                            s_q[rl * IQ_QCAP + slot] = make_int4(hdr.x + __popc(has & ((1u << u) - 1u)), cx, cy, cz | ((csl - 1) << 20));
+                            s_q[rl * IQ_QCAP + slot] = make_int4(cb, cx, cy, cz | ((csl - 1) << 20));
                         else s_ovf[rl] = 1;
                     }
                 }
