@@ -219,7 +219,11 @@ def main():
     eng = P.SdfEngine(max_rays=hi - lo, samples_per_ray_cap=48, device=device)
     if world > 1:
         D.RayShardedExchange(eng)
-    eng.set_rays(w["dirs"][lo:hi], w["points"][lo:hi], w["cos"][lo:hi])
+    # balanced shards: the scan is beam-major and beams differ several-fold in voxels/samples per ray, so each rank takes every
+    # world-th return instead of a block of whole beams (identity for one GPU; scripts/shard_probe.py, profiles/r01_i_shard_probe.txt)
+    order = D.interleaved_order(N, world)
+    sel = order[lo:hi]
+    eng.set_rays(w["dirs"][sel], w["points"][sel], w["cos"][sel])
     eng.set_poses(w["pose"][None], [1])
     cfg = P.IterConfig()
     train_dec = not args.frozen_decoder
@@ -280,7 +284,7 @@ def main():
                                    "decoder fwd/bwd+SDF loss+emb/decoder/pose grads+Adam; voxel 0.2 m, step 0.1 m, "
                                    + ("decoder trainable" if train_dec else "decoder frozen"),
                        "rays": N, "octree_nodes": w["n_nodes"], "embedding_rows": w["n_rows"], "hit_rays": st["R"],
-                       "valid_samples_rank0": P_local, "max_samples_per_ray": st["S"], "parallelism": f"ray-shard x{world}"},
+                       "valid_samples_rank0": P_local, "max_samples_per_ray": st["S"], "parallelism": f"ray-shard x{world}" + (" (interleaved returns)" if world > 1 else "")},
             "roofline": rf,
         }
         if world == 1:

@@ -81,3 +81,13 @@ def test_shard_bounds_partition():
             assert segs[0][0] == 0 and segs[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(segs, segs[1:]))
             assert all(lo <= hi for lo, hi in segs)
+
+
+def test_interleaved_order_gives_strided_shards():
+    for n, world in ((131072, 8), (16, 4), (10, 3), (7, 8), (5, 1)):
+        p = D.interleaved_order(n, world)
+        assert sorted(p.tolist()) == list(range(n))
+        if n % world == 0:
+            for r in range(world):
+                lo, hi = D.shard_bounds(n, r, world)
+                assert np.array_equal(p[lo:hi], np.arange(r, n, world))
