@@ -224,8 +224,10 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_dfs(
 // keeps the 20 largest codes.  Hits are then stably sorted by t_min and culled exactly as before.
 // Rays whose queue (32) or hit list (24) overflows are appended to a list and redone by k_ray_intersect_dfs.
 // ---------------------------------------------------------------------------------------------
-#define IQ_LPR 4
-#define IQ_RAYS (NL_GEO_THREADS / IQ_LPR)
+// lanes per ray: template parameter of k_ray_intersect_q.  Measured (profiles/r01_k_intersect_lanes_per_ray.txt): more lanes pop
+// more pending nodes per round - 16 lanes reach the minimum of one round per tree level (18) - and the traversal is a latency
+// chain per round, so small ray counts want 16 lanes (2048 rays: 77 us with 4 lanes, 52 with 8, 39 with 16); at 131 072 rays the
+// extra workgroups cost throughput (198 / 162 / 198 us) and 8 is best.  0 = choose by ray count (default).
 #define IQ_QCAP 32
 #define IQ_HCAP 24
 
@@ -277,10 +279,12 @@ struct ChildSlabs {
     }
 };
 
+static int g_isect_lpr = 0;
 __device__ long long* g_isect_dbg = nullptr;            // optional [blocks][8] stamps of thread 0 (profiling aid, nl_geometry_set_debug_buffer)
 #define ISTAMP(k, v) do { if (g_isect_dbg && threadIdx.x == 0) g_isect_dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)(v); } while (0)
 #define SSTAMP(k) do { if (g_isect_dbg && threadIdx.x == 0) g_isect_dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
 
+template <int IQ_LPR>
 __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
     int N, const float* __restrict__ rays_d_sensor, const float* __restrict__ points_gt,
     const float* __restrict__ cos_gt, const int* __restrict__ frame_id, const float* __restrict__ poses,
@@ -290,6 +294,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
     int* __restrict__ hit_idx, float* __restrict__ hit_t0, float* __restrict__ hit_t1,
     int* __restrict__ hit_count, int* __restrict__ counters, int* __restrict__ ovf_list)
 {
+    constexpr int IQ_RAYS = NL_GEO_THREADS / IQ_LPR;
     __shared__ int4 s_q[IQ_RAYS * IQ_QCAP];
     __shared__ int s_hid[IQ_RAYS * IQ_HCAP], s_hx[IQ_RAYS * IQ_HCAP], s_hy[IQ_RAYS * IQ_HCAP], s_hz[IQ_RAYS * IQ_HCAP];
     __shared__ float s_ht0[IQ_RAYS * IQ_HCAP], s_ht1[IQ_RAYS * IQ_HCAP];
@@ -805,7 +810,10 @@ int nl_ray_intersect(int N, const float* rays_d_sensor, const float* points_gt, 
     if (N <= 0 || !rays_d_sensor || !points_gt || !cos_gt || !poses || !blk_ids || !blk_hdr || root_side < 2 || !rays_d_world || !gt_dist ||
         !hit_idx || !hit_t0 || !hit_t1 || !hit_count || !counters || !scratch_rays) return NL_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_ray_intersect_q, dim3(nl_div_up(N, IQ_RAYS)), dim3(NL_GEO_THREADS), 0, st,
+    const int lpr = g_isect_lpr ? g_isect_lpr : (N <= 32768 ? 16 : 8);
+    auto kq = lpr == 16 ? k_ray_intersect_q<16> : lpr == 8 ? k_ray_intersect_q<8> : lpr == 2 ? k_ray_intersect_q<2> : k_ray_intersect_q<4>;
+    const int IQ_RAYS = NL_GEO_THREADS / lpr;
+    hipLaunchKernelGGL(kq, dim3(nl_div_up(N, IQ_RAYS)), dim3(NL_GEO_THREADS), 0, st,
                        N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, (const int2*)blk_hdr, (const int4*)blk_ids, root_side, voxel_size, max_distance,
                        rays_d_world, gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, scratch_rays);
     // rays whose LDS queue / hit list overflowed (none on ordinary scans): sequential DFS, device-side count
@@ -846,6 +854,9 @@ int nl_scan_hit_rays(const int* hit_count, int* hit_rank, int* ray_of_rank, int 
     if (N <= 0 || !hit_count || !hit_rank || !ray_of_rank || !total_out || !workspace) return NL_ERR_INVALID_ARG;
     return scan_launch(hit_count, hit_rank, N, 1, ray_of_rank, total_out, total_out2, workspace, stream);
 }
+
+/* lanes per ray of the work-list intersect kernel: 0 = by ray count (default: 16 up to 32 768 rays, else 8), or 2 / 4 / 8 / 16 */
+int nl_geometry_set_lanes_per_ray(int lpr) { if (lpr != 0 && lpr != 2 && lpr != 4 && lpr != 8 && lpr != 16) return NL_ERR_INVALID_ARG; g_isect_lpr = lpr; return NL_OK; }
 
 /* profiling aid: device buffer [blocks][8] int64: cycle stamps (start, after set-up, after traversal, after finalise) and the
  * round count of wave 0 of every workgroup of k_ray_intersect_q (NULL disables) */
