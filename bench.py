@@ -220,7 +220,7 @@ def main():
     if world > 1:
         D.RayShardedExchange(eng)
     # balanced shards: the scan is beam-major and beams differ several-fold in voxels/samples per ray, so each rank takes every
-    # world-th return instead of a block of whole beams (identity for one GPU; scripts/shard_probe.py, profiles/r01_j_shard_probe.txt)
+    # world-th return instead of a block of whole beams (identity for one GPU; scripts/shard_probe.py, profiles/r01_k_shard_probe.txt)
     order = D.interleaved_order(N, world)
     sel = order[lo:hi]
     eng.set_rays(w["dirs"][sel], w["points"][sel], w["cos"][sel])

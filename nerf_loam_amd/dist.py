@@ -41,7 +41,7 @@ def interleaved_order(n, world):
     """Permutation of a ray list such that the contiguous blocks of shard_bounds() are the strided subsets r, r+world, ...:
     neighbouring LiDAR returns (same beam, adjacent azimuth) cost about the same, whole beams do not (grazing beams cross
     several times more voxels than upward ones), so contiguous blocks of a beam-major scan are badly balanced
-    (profiles/r01_j_shard_probe.txt).  Identity for world == 1."""
+    (profiles/r01_k_shard_probe.txt).  Identity for world == 1."""
     import numpy as np
     if world <= 1:
         return np.arange(n)
