@@ -59,6 +59,7 @@ _SIGS = {
     "nl_field_set_debug_buffer": ([_P], _I),
     "nl_geometry_set_debug_buffer": ([_P], _I),
     "nl_geometry_set_lanes_per_ray": ([_I], _I),
+    "nl_geometry_set_sampler_mode": ([_I], _I),
     "nl_dist_merge_counters": ([_P, _I, _I, _I, _P, _P], _I),
     "nl_select_rays": ([_I, _I, ctypes.c_uint, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P], _I),
     "nl_decoder_set_gemm_mode": ([_I], _I),
@@ -109,6 +110,8 @@ def lib():
         if os.environ.get("NL_GEMM_MODE"):
             if L.nl_decoder_set_gemm_mode(int(os.environ["NL_GEMM_MODE"])) != 0:
                 raise NerfLoamHipError("NL_GEMM_MODE must be 0 or 1")
+        if os.environ.get("NL_SAMPLER_MODE"):
+            L.nl_geometry_set_sampler_mode(int(os.environ["NL_SAMPLER_MODE"]))
         if os.environ.get("NL_WGRAD2_MODE"):                # A/B switch for measurements (default: the library's own default)
             if L.nl_decoder_set_wgrad2_mode(int(os.environ["NL_WGRAD2_MODE"])) != 0:
                 raise NerfLoamHipError("NL_WGRAD2_MODE must be 0 or 1")

@@ -257,6 +257,120 @@ NL_HD int nl_sample_walk(const int* idx, const float* t0, const float* t1, int P
                                P, tot, step_size_m, tc, noise, emit);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Step-parallel form of the same sampler (same arithmetic, same sample order): the sequential walk advances a bin cursor
+// while it visits the stratified steps cs = 0..T-1; because (cs + noise) * step increases with cs and the interval CDF
+// boundaries cum[b] are non-decreasing, the bin of step cs depends on cs alone - bin(cs) = first b with !(cdf > cum[b]) -
+// so every step can be evaluated independently (one GPU lane per step) and the samples land at known indices:
+//   own sample of step cs            -> index cs + bin(cs)
+//   closing sample of interval q     -> index cs + q, emitted by the first step cs that lies beyond interval q
+// (before it come cs own samples and q closing samples).  cum[] is the sequential fp32 chain of the walk
+// (cum[0] = len_0 / tot, cum[b] = cum[b-1] + len_b / tot); nb = number of leading usable intervals (idx != -1, b < P).
+//   nl_walk_plan    fills cum[0..nb) and returns nb
+//   nl_walk_eval    bin and depth of one step
+//   nl_walk_step    emits everything step cs is responsible for; returns 1 if it produced an own sample
+//   nl_walk_tail    the closing loop after the last step (sequential, a few iterations) ; returns the final sample count
+// ---------------------------------------------------------------------------------------------
+template <typename GetI, typename GetF0, typename GetF1, typename PutC>
+NL_HD int nl_walk_plan(GetI idx, GetF0 t0, GetF1 t1, int P, float tot, PutC put_cum) {
+    int nb = 0;
+    float c = 0.0f;
+    for (int b = 0; b < P; ++b) {
+        const int i = idx(b);
+        if (b > 0 && i == -1) break;                       // the walk stops at the first invalid interval after the first
+        const float len = (i == -1) ? 0.0f : (t1(b) - t0(b));
+        c = (b == 0) ? (len / tot) : (c + len / tot);
+        put_cum(b, c);
+        ++nb;
+        if (i == -1) break;
+    }
+    return nb;
+}
+
+template <typename GetC, typename GetF0, typename GetF1>
+NL_HD void nl_walk_eval(int cs, float noise_cs, float step, int nb, GetC cum, GetF0 t0, GetF1 t1, int* bin, float* z) {
+    const float cdf = ((float)cs + noise_cs) * step;
+    int b = 0;
+    while (b < nb && cdf > cum(b)) ++b;
+    *bin = b;
+    *z = 0.0f;
+    if (b < nb) {
+        const float lo = (b > 0) ? cum(b - 1) : 0.0f, hi = cum(b);
+        const float u = (cdf - lo) / (hi - lo);
+        const float d0 = t0(b), d1 = t1(b);
+        *z = d0 + u * (d1 - d0);
+    }
+}
+
+template <typename GetI, typename GetC, typename GetF0, typename GetF1, typename NoiseF, typename EmitF>
+NL_HD int nl_walk_step(int cs, float step, int nb, GetI idx, GetC cum, GetF0 t0, GetF1 t1, NoiseF noise, EmitF emit) {
+    int bp = 0; float zl = t0(0);
+    if (cs > 0) {
+        float zp;
+        nl_walk_eval(cs - 1, noise(cs - 1), step, nb, cum, t0, t1, &bp, &zp);
+        if (bp >= nb) return 0;                              // the walk ended at an earlier step
+        zl = zp;
+    }
+    int b; float z;
+    nl_walk_eval(cs, noise(cs), step, nb, cum, t0, t1, &b, &z);
+    for (int q = bp; q < b; ++q) {                           // closing samples of the intervals this step leaves behind
+        const float d1 = t1(q);
+        emit(cs + q, idx(q), (d1 + zl) * 0.5f, d1 - zl);
+        if (q + 1 < nb) zl = t0(q + 1);
+    }
+    if (b >= nb) return 0;
+    emit(cs + b, idx(b), (z + zl) * 0.5f, z - zl);
+    return 1;
+}
+
+template <typename GetI, typename GetC, typename GetF0, typename GetF1, typename NoiseF, typename EmitF>
+NL_HD int nl_walk_tail(int T, float step, int nb, int P, GetI idx, GetC cum, GetF0 t0, GetF1 t1, const NlTailCtx& tc, NoiseF noise, EmitF emit) {
+    int bin = 0, s = 0; float zl = t0(0);
+    if (T > 0) {
+        nl_walk_eval(T - 1, noise(T - 1), step, nb, cum, t0, t1, &bin, &zl);
+        if (bin >= nb) {                                     // ran out of intervals during the steps: own samples = steps before the end
+            int lo = 0, hi = T - 1;                          // first step whose bin is nb (bins are monotone in cs)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1; int bm; float zm;
+                nl_walk_eval(mid, noise(mid), step, nb, cum, t0, t1, &bm, &zm);
+                if (bm >= nb) hi = mid; else lo = mid + 1;
+            }
+            return lo + nb;
+        }
+        s = T + bin;
+    }
+    float curr_max_depth = t1(bin);
+    int curr_idx = idx(bin);
+    while (zl < curr_max_depth && (tc.tail_always || tc.rays_in_row > tc.j_in_row * P + bin)) {
+        emit(s, curr_idx, (curr_max_depth + zl) * 0.5f, curr_max_depth - zl);
+        ++bin; ++s;
+        if (bin >= P) break;
+        curr_idx = idx(bin);
+        if ((tc.tail_always ? curr_idx : (bin < tc.row_first_count ? tc.row_first_idx[bin] : -1)) == -1) break;
+        zl = t0(bin); curr_max_depth = t1(bin);
+    }
+    return s;
+}
+
+// host / single-thread driver of the step-parallel form: same results and emit order as nl_sample_walk
+template <typename NoiseF, typename EmitF>
+NL_HD int nl_sample_walk_steps(const int* idx, const float* t0, const float* t1, int P, float step_size_m,
+                               const NlTailCtx& tc, NoiseF noise, EmitF emit) {
+    float tot = 0.0f;
+    for (int h = 0; h < P; ++h) { float d = (idx[h] == -1) ? 0.0f : (t1[h] - t0[h]); tot = tot + d; }
+    float cum[NL_MAX_HITS];
+    auto gi = [&](int b) { return idx[b]; };
+    auto g0 = [&](int b) { return t0[b]; };
+    auto g1 = [&](int b) { return t1[b]; };
+    auto gc = [&](int b) { return cum[b]; };
+    const int nb = nl_walk_plan(gi, g0, g1, P < NL_MAX_HITS ? P : NL_MAX_HITS, tot, [&](int b, float c) { cum[b] = c; });
+    const float steps = tot / step_size_m;
+    const float step = (float)(1.0 / (double)steps);
+    const int T = (int)ceilf(steps);
+    for (int cs = 0; cs < T; ++cs) nl_walk_step(cs, step, nb, gi, gc, g0, g1, noise, emit);
+    return nl_walk_tail(T, step, nb, P, gi, gc, g0, g1, tc, noise, emit);
+}
+
 // position of hit-ray r (0-based rank among the R hit rays) in the reference wrapper's padded
 // [200, L, P] layout, chunked by 800 along dim 1 (voxel_helpers.py:274-316)
 NL_HD void nl_sampler_layout(int r, int R, int* j_in_row, int* rays_in_row, int* row_first_rank) {

@@ -280,6 +280,7 @@ struct ChildSlabs {
 };
 
 static int g_isect_lpr = 0;
+static int g_sampler_mode = 2;          // 0: one lane per ray, sequential walk (k_sample); 1: step-parallel (k_sample_par); 2: by ray count
 __device__ long long* g_isect_dbg = nullptr;            // optional [blocks][8] stamps of thread 0 (profiling aid, nl_geometry_set_debug_buffer)
 #define ISTAMP(k, v) do { if (g_isect_dbg && threadIdx.x == 0) g_isect_dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)(v); } while (0)
 #define SSTAMP(k) do { if (g_isect_dbg && threadIdx.x == 0) g_isect_dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -578,6 +579,146 @@ struct SampleArgs {
     int* s_vox; float* s_depth; float* s_dist; int* s_ray;
 };
 
+// ---------------------------------------------------------------------------------------------
+// Step-parallel sampler: SP_LPR lanes per hit ray, one stratified step per lane per iteration (nl_walk_* in
+// nl_device_math.h: the bin of a step depends on the step alone, samples land at known indices, so the steps are
+// independent).  The sequential walk of k_sample costs ~700 cycles per sample on the critical path of a whole wave; here a
+// ray's ~16-34 steps take 2-5 iterations.  Same arithmetic, same results bit for bit (host: tests/test_device_math_host.py).
+// ---------------------------------------------------------------------------------------------
+#define SP_LPR 8
+#define SP_RAYS (NL_GEO_THREADS / SP_LPR)
+template <bool EMIT>
+__global__ __launch_bounds__(NL_GEO_THREADS) void k_sample_par(SampleArgs a)
+{
+    __shared__ int s_red[8];
+    __shared__ double s_dred[2];
+    __shared__ int s_i[SP_RAYS * NL_MAX_HITS];
+    __shared__ float s_0[SP_RAYS * NL_MAX_HITS], s_1[SP_RAYS * NL_MAX_HITS], s_c[SP_RAYS * NL_MAX_HITS];
+    __shared__ float s_tot[SP_RAYS];
+    __shared__ int s_nb[SP_RAYS];
+    if (threadIdx.x < 8) s_red[threadIdx.x] = 0;
+    if (threadIdx.x < 2) s_dred[threadIdx.x] = 0.0;
+    __syncthreads();
+    const int rl = threadIdx.x / SP_LPR, j = threadIdx.x % SP_LPR;
+    // persistent over batches of SP_RAYS rays: the per-block reduction and its ~10 global atomics happen once per workgroup
+    // (one workgroup per 32 rays would mean 4096 x 10 atomics on the same counters for a full scan)
+    int vmax = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0;
+    double d1 = 0.0, d2 = 0.0;
+    for (int batch = blockIdx.x; batch * SP_RAYS < a.N; batch += gridDim.x) {
+    const int r = batch * SP_RAYS + rl;
+    int cnt = 0, nfs = 0, nsdf = 0, inv_fs = 0, inv_sdf = 0, guard = 0;
+    double inv_d2 = 0.0;
+    const bool live = r < a.N && a.hit_count[r] > 0;
+    int* my_i = s_i + rl * NL_MAX_HITS; float* my_0 = s_0 + rl * NL_MAX_HITS; float* my_1 = s_1 + rl * NL_MAX_HITS; float* my_c = s_c + rl * NL_MAX_HITS;
+    const int P = a.counters[NLC_HMAX];
+    if (live) {
+        const int nh = a.hit_count[r];
+        for (int l = j; l < NL_MAX_HITS; l += SP_LPR) {          // row tails beyond the ray's own hits are padding
+            const bool v = l < nh;
+            my_i[l] = v ? a.hit_idx[(size_t)r * NL_MAX_HITS + l] : -1;
+            my_0[l] = v ? a.hit_t0[(size_t)r * NL_MAX_HITS + l] : a.max_depth;
+            my_1[l] = v ? a.hit_t1[(size_t)r * NL_MAX_HITS + l] : a.max_depth;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();                               // a ray's lanes sit in one wave
+    auto get_i = [&](int b) { return my_i[b]; };
+    auto get_0 = [&](int b) { return my_0[b]; };
+    auto get_1 = [&](int b) { return my_1[b]; };
+    auto get_c = [&](int b) { return my_c[b]; };
+    if (live && j == 0) {
+        float tot = 0.0f;
+        for (int l = 0; l < P; ++l) { const int i_ = my_i[l]; tot = tot + ((i_ == -1) ? 0.0f : (my_1[l] - my_0[l])); }
+        s_tot[rl] = tot;
+        s_nb[rl] = nl_walk_plan(get_i, get_0, get_1, P, tot, [&](int b, float c) { my_c[b] = c; });
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (live) {
+        const float tot = s_tot[rl];
+        const int nb = s_nb[rl];
+        if (tot > 10.0f * NL_FILL_DEPTH) guard = 1;
+        const float c = a.cos_gt[r], d = a.gt_dist[r];
+        const unsigned rid = (unsigned)(r + a.ray_id_base);
+        const unsigned seed = a.seed;
+        const bool hash = a.use_hash_noise != 0;
+        auto noise = [&](int step) -> float { return hash ? nl_noise(seed, rid, (unsigned)step) : 0.5f; };
+        const int off = EMIT ? a.samp_off[r] : 0;
+        const int cap = a.capacity;
+        auto emit = [&](int s, int vox, float depth, float dist) {
+            if (EMIT) {
+                const int p = off + s;
+                if (p < cap) { a.s_vox[p] = vox; a.s_depth[p] = depth; a.s_dist[p] = dist < 0.0f ? 0.0f : dist; a.s_ray[p] = r; }
+            } else {
+                bool f, m;
+                nl_loss_masks(depth * c, d, a.tau, a.max_depth, &f, &m);
+                nfs += f ? 1 : 0; nsdf += m ? 1 : 0;
+            }
+        };
+        if (!guard) {
+            const float steps = tot / a.step_size;
+            const float step = (float)(1.0 / (double)steps);
+            const int T = (int)ceilf(steps);
+            for (int cs = j; cs < T; cs += SP_LPR) nl_walk_step(cs, step, nb, get_i, get_c, get_0, get_1, noise, emit);
+            if (j == 0) {
+                NlTailCtx tc;
+                const int Rg = a.counters[NLC_R_GLOBAL];
+                const int rank = a.hit_rank[r] + a.counters[NLC_R_OFFSET];
+                int first_rank;
+                nl_sampler_layout(rank, Rg, &tc.j_in_row, &tc.rays_in_row, &first_rank);
+                // single-GPU: the row's first ray is local.  (multi-GPU: see dist.py)
+                const int first_local = first_rank - a.counters[NLC_R_OFFSET];
+                const int first_ray = (first_local >= 0 && first_local < a.counters[NLC_R]) ? a.ray_of_rank[first_local] : r;
+                tc.row_first_idx = a.hit_idx + (size_t)first_ray * NL_MAX_HITS;
+                tc.row_first_count = a.hit_count[first_ray];
+                tc.tail_always = a.tail_always != 0;
+                cnt = nl_walk_tail(T, step, nb, P, get_i, get_c, get_0, get_1, tc, noise, emit);
+            }
+        }
+        if (!EMIT && j == 0) {
+            bool f, m;
+            nl_loss_masks(NL_FILL_DEPTH * c, d, a.tau, a.max_depth, &f, &m);
+            if (!guard) { inv_fs = f ? 1 : 0; inv_sdf = m ? 1 : 0; inv_d2 = m ? (double)d * (double)d : 0.0; }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();                               // the ray's LDS rows are reused by the next batch
+    if (EMIT) continue;
+    if (r < a.N && j == 0) a.samp_count[r] = cnt;
+    // per-lane running sums (a ray's mask counts are spread over its lanes; cnt and the per-ray constants sit in lane 0)
+    vmax = max(vmax, cnt);
+    v1 += nfs; v2 += nsdf; v3 += inv_fs; v4 += inv_fs * cnt; v5 += inv_sdf; v6 += inv_sdf * cnt; v7 += guard;
+    d1 += inv_d2; d2 += inv_d2 * (double)cnt;
+    }
+    if (EMIT) return;
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+        vmax = max(vmax, __shfl_xor(vmax, o2));
+        v1 += __shfl_xor(v1, o2); v2 += __shfl_xor(v2, o2); v3 += __shfl_xor(v3, o2); v4 += __shfl_xor(v4, o2);
+        v5 += __shfl_xor(v5, o2); v6 += __shfl_xor(v6, o2); v7 += __shfl_xor(v7, o2);
+        d1 += __shfl_xor(d1, o2); d2 += __shfl_xor(d2, o2);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&s_red[0], vmax);
+        atomicAdd(&s_red[1], v1); atomicAdd(&s_red[2], v2); atomicAdd(&s_red[3], v3); atomicAdd(&s_red[4], v4);
+        atomicAdd(&s_red[5], v5); atomicAdd(&s_red[6], v6); atomicAdd(&s_red[7], v7);
+        atomicAdd(&s_dred[0], d1); atomicAdd(&s_dred[1], d2);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_red[0] > 0) atomicMax(&a.counters[NLC_SMAX], s_red[0]);
+        if (s_red[1]) atomicAdd(&a.counters[NLC_NFS], s_red[1]);
+        if (s_red[2]) atomicAdd(&a.counters[NLC_NSDF], s_red[2]);
+        if (s_red[3]) atomicAdd(&a.counters[NLC_INV_FS_RAYS], s_red[3]);
+        if (s_red[4]) atomicAdd(&a.counters[NLC_INV_FS_CNT], s_red[4]);
+        if (s_red[5]) atomicAdd(&a.counters[NLC_INV_SDF_RAYS], s_red[5]);
+        if (s_red[6]) atomicAdd(&a.counters[NLC_INV_SDF_CNT], s_red[6]);
+        if (s_red[7]) atomicMax(&a.counters[NLC_GUARD], 1);
+        if (s_dred[0] != 0.0) atomicAdd(&a.dcounters[NLD_INV_D2], s_dred[0]);
+        if (s_dred[1] != 0.0) atomicAdd(&a.dcounters[NLD_INV_D2CNT], s_dred[1]);
+    }
+}
+
 template <bool EMIT>
 __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample(SampleArgs a)
 {
@@ -855,6 +996,10 @@ int nl_scan_hit_rays(const int* hit_count, int* hit_rank, int* ray_of_rank, int 
     return scan_launch(hit_count, hit_rank, N, 1, ray_of_rank, total_out, total_out2, workspace, stream);
 }
 
+/* fused sampler kernel: 0 = sequential walk, one lane per ray; 1 = step-parallel, 8 lanes per ray; 2 = step-parallel up to
+ * 32 768 rays, sequential beyond (default); same results */
+int nl_geometry_set_sampler_mode(int mode) { if (mode < 0 || mode > 2) return NL_ERR_INVALID_ARG; g_sampler_mode = mode; return NL_OK; }
+
 /* lanes per ray of the work-list intersect kernel: 0 = by ray count (default: 16 up to 32 768 rays, else 8), or 2 / 4 / 8 / 16 */
 int nl_geometry_set_lanes_per_ray(int lpr) { if (lpr != 0 && lpr != 2 && lpr != 4 && lpr != 8 && lpr != 16) return NL_ERR_INVALID_ARG; g_isect_lpr = lpr; return NL_OK; }
 
@@ -890,8 +1035,16 @@ int nl_sample_rays(int emit, int N, const int* hit_idx, const float* hit_t0, con
     a.counters = counters; a.dcounters = (double*)(counters + NL_CNT_INTS);
     a.samp_count = samp_count; a.samp_off = samp_off; a.capacity = capacity;
     a.s_vox = s_vox; a.s_depth = s_depth; a.s_dist = s_dist; a.s_ray = s_ray;
-    if (emit) hipLaunchKernelGGL(k_sample<true>, dim3(nl_div_up(N, NL_GEO_THREADS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);
-    else      hipLaunchKernelGGL(k_sample<false>, dim3(nl_div_up(N, NL_GEO_THREADS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);
+    // step-parallel (SP_LPR lanes per ray) in the latency-bound regime; at full-scan sizes its extra threads and redundant step
+    // evaluations cost throughput (count pass 96 us against 30 us at 131 072 rays) and the sequential kernel is used
+    if (g_sampler_mode == 1 || (g_sampler_mode == 2 && N <= 32768)) {
+        const int nbk = nl_div_up(N, SP_RAYS) < 1024 ? nl_div_up(N, SP_RAYS) : 1024;
+        if (emit) hipLaunchKernelGGL(k_sample_par<true>, dim3(nbk), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);
+        else      hipLaunchKernelGGL(k_sample_par<false>, dim3(nbk), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);
+    } else {
+        if (emit) hipLaunchKernelGGL(k_sample<true>, dim3(nl_div_up(N, NL_GEO_THREADS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);
+        else      hipLaunchKernelGGL(k_sample<false>, dim3(nl_div_up(N, NL_GEO_THREADS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);
+    }
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

@@ -53,14 +53,16 @@ void hh_sample(int R, const int* idx, const float* t0, const float* t1, int P, f
         nl_sampler_layout(r, R, &tc.j_in_row, &tc.rays_in_row, &first);
         tc.row_first_idx = idx + (size_t)first * NL_MAX_HITS;
         tc.row_first_count = NL_MAX_HITS;
-        tc.tail_always = tail_always != 0;
+        tc.tail_always = (tail_always & 1) != 0;                       // bit 1 selects the step-parallel formulation
         const unsigned rid = ray_ids[r];
         auto noise = [&](int s) -> float { return use_hash ? nl_noise(seed, rid, (unsigned)s) : 0.5f; };
         auto emit = [&](int s, int v, float depth, float dist) {
             if (s < S_cap) { s_idx[(size_t)r * S_cap + s] = v; s_depth[(size_t)r * S_cap + s] = depth; s_dist[(size_t)r * S_cap + s] = dist < 0.f ? 0.f : dist; }
         };
-        count[r] = nl_sample_walk(idx + (size_t)r * NL_MAX_HITS, t0 + (size_t)r * NL_MAX_HITS, t1 + (size_t)r * NL_MAX_HITS, P,
-                                  step_size, tc, noise, emit);
+        count[r] = (tail_always & 2) ? nl_sample_walk_steps(idx + (size_t)r * NL_MAX_HITS, t0 + (size_t)r * NL_MAX_HITS, t1 + (size_t)r * NL_MAX_HITS, P,
+                                                             step_size, tc, noise, emit)
+                                     : nl_sample_walk(idx + (size_t)r * NL_MAX_HITS, t0 + (size_t)r * NL_MAX_HITS, t1 + (size_t)r * NL_MAX_HITS, P,
+                                                      step_size, tc, noise, emit);
     }
 }
 

@@ -67,8 +67,9 @@ def test_raw_intersect_matches_reference_kernel_restatement(hh, scene):
         assert np.array_equal(idx, oi) and np.array_equal(t0, o0) and np.array_equal(t1, o1)
 
 
-@pytest.mark.parametrize("tail_mode,use_hash,step", [(0, 1, 0.1), (0, 0, 0.04), (1, 1, 0.1)])
-def test_sampler_bit_exact(hh, scene, tail_mode, use_hash, step):
+@pytest.mark.parametrize("form", [0, 2])                     # 0: sequential walk, 2: step-parallel formulation (nl_sample_walk_steps)
+@pytest.mark.parametrize("tail_mode,use_hash,step", [(0, 1, 0.1), (0, 0, 0.04), (1, 1, 0.1), (0, 1, 0.04)])
+def test_sampler_bit_exact(hh, scene, tail_mode, use_hash, step, form):
     ms = scene["sc"]["ms"]
     o, d = scene["o"], scene["d"]
     oi, o0, o1, hits = O.ray_intersect(o, d, ms.centres, ms.structure, 0.2, 50.0)
@@ -83,7 +84,7 @@ def test_sampler_bit_exact(hh, scene, tail_mode, use_hash, step):
     g_idx = -np.ones((R, cap), np.int32); g_dep = np.full((R, cap), 80, np.float32); g_dst = np.zeros((R, cap), np.float32)
     cnt = np.zeros(R, np.int32)
     ids = hr.astype(np.uint32)
-    hh.hh_sample(R, p(hi), p(h0), p(h1), P, ctypes.c_float(step), 777, use_hash, tail_mode, p(ids), cap,
+    hh.hh_sample(R, p(hi), p(h0), p(h1), P, ctypes.c_float(step), 777, use_hash, tail_mode | form, p(ids), cap,
                  p(g_idx), p(g_dep), p(g_dst), p(cnt))
     assert cnt.max() == S
     assert np.array_equal(g_idx[:, :S], s_idx)
@@ -256,9 +257,11 @@ def test_sampler_edge_cases_bit_exact(hh):
         g_idx = -np.ones((R, cap), np.int32); g_dep = np.full((R, cap), 80, np.float32); g_dst = np.zeros((R, cap), np.float32)
         cnt = np.zeros(R, np.int32)
         ids = np.arange(R, dtype=np.uint32)
-        hh.hh_sample(R, p(idx), p(t0), p(t1), P, ctypes.c_float(step), 11, 1, tail, p(ids), cap, p(g_idx), p(g_dep), p(g_dst), p(cnt))
-        assert cnt.max() == S
-        assert np.array_equal(g_idx[:, :S], s_idx) and np.array_equal(g_dep[:, :S], s_dep) and np.array_equal(g_dst[:, :S], s_dst)
+        for form in (0, 2):                                           # sequential walk / step-parallel formulation
+            g_idx[:] = -1; g_dep[:] = 80; g_dst[:] = 0; cnt[:] = 0
+            hh.hh_sample(R, p(idx), p(t0), p(t1), P, ctypes.c_float(step), 11, 1, tail | form, p(ids), cap, p(g_idx), p(g_dep), p(g_dst), p(cnt))
+            assert cnt.max() == S, form
+            assert np.array_equal(g_idx[:, :S], s_idx) and np.array_equal(g_dep[:, :S], s_dep) and np.array_equal(g_dst[:, :S], s_dst), form
         valid = s_idx != -1
         assert (np.diff(np.where(valid, s_dep, np.inf), axis=1)[valid[:, 1:]] >= 0).all()      # depths monotone along a ray
         if tail == 1:                                                                   # "fixed" sampler covers every interval fully

@@ -619,3 +619,27 @@ def test_two_virtual_ranks_match_the_single_rank_iteration(nl, golden_dir, monke
     for k in ("params", "emb", "pose6"):
         assert np.array_equal(a[k], b[k]), k                                    # replicas stay in lock-step
     assert np.abs(a["params"] - one["params"]).max() < 1e-4 and np.abs(a["pose6"] - one["pose6"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sampler_kernels_agree_bit_for_bit(nl, golden_dir, mode):
+    """the sequential (one lane per ray) and the step-parallel (8 lanes per ray) sampler kernels against the oracle on the same
+    iteration: identical sample records and loss normalisers"""
+    lib = nl["L"].lib()
+    assert lib.nl_geometry_set_sampler_mode(mode) == 0
+    try:
+        g = np.load(os.path.join(golden_dir, "map_1f_1it.npz"))
+        sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]))
+        sc["ms"].id2row = g["id_table"].copy()
+        masks = H.unpack_masks(g["masks"], len(sc["points"]))
+        dec_np = O.decoder_init(int(g["seed"]))
+        frames = [O.select_rays(sc["points"], sc["cos"], g["poses0"][0].copy(), masks[0][0], optimize_pose=True)]
+        out = O.render_and_grad(sc["ms"], dec_np, frames, O.IterCfg(step_size=float(g["step_size"])), want_dec_grad=True)
+        m, dec, eng = make_engine(nl, sc, dec_np, len(frames[0].rays_d), 1)
+        cfgP = nl["P"].IterConfig(step_size=float(g["step_size"]))
+        load_frames(eng, frames)
+        eng.begin_call(m, dec)
+        eng.forward_backward(m, dec, cfgP, train_decoder=True)
+        compare_iteration(eng, m, dec, out, cfgP, True)
+    finally:
+        lib.nl_geometry_set_sampler_mode(2)
