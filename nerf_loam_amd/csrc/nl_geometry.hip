@@ -227,7 +227,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_dfs(
 // lanes per ray: template parameter of k_ray_intersect_q.  Measured (profiles/r01_k_intersect_lanes_per_ray.txt): more lanes pop
 // more pending nodes per round - 16 lanes reach the minimum of one round per tree level (18) - and the traversal is a latency
 // chain per round, so small ray counts want 16 lanes (2048 rays: 77 us with 4 lanes, 52 with 8, 39 with 16); at 131 072 rays the
-// extra workgroups cost throughput (198 / 162 / 198 us) and 8 is best.  0 = choose by ray count (default).
+// extra workgroups cost throughput (198 / 162 / 198 us) and 8 is best.  0 = choose by ray count (default: 16 lanes up to 16 384 rays).
 #define IQ_QCAP 32
 #define IQ_HCAP 24
 
@@ -951,7 +951,7 @@ int nl_ray_intersect(int N, const float* rays_d_sensor, const float* points_gt, 
     if (N <= 0 || !rays_d_sensor || !points_gt || !cos_gt || !poses || !blk_ids || !blk_hdr || root_side < 2 || !rays_d_world || !gt_dist ||
         !hit_idx || !hit_t0 || !hit_t1 || !hit_count || !counters || !scratch_rays) return NL_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const int lpr = g_isect_lpr ? g_isect_lpr : (N <= 32768 ? 16 : 8);
+    const int lpr = g_isect_lpr ? g_isect_lpr : (N <= 16384 ? 16 : 8);
     auto kq = lpr == 16 ? k_ray_intersect_q<16> : lpr == 8 ? k_ray_intersect_q<8> : lpr == 2 ? k_ray_intersect_q<2> : k_ray_intersect_q<4>;
     const int IQ_RAYS = NL_GEO_THREADS / lpr;
     hipLaunchKernelGGL(kq, dim3(nl_div_up(N, IQ_RAYS)), dim3(NL_GEO_THREADS), 0, st,
@@ -997,10 +997,10 @@ int nl_scan_hit_rays(const int* hit_count, int* hit_rank, int* ray_of_rank, int 
 }
 
 /* fused sampler kernel: 0 = sequential walk, one lane per ray; 1 = step-parallel, 8 lanes per ray; 2 = step-parallel up to
- * 32 768 rays, sequential beyond (default); same results */
+ * 8192 rays, sequential beyond (default); same results */
 int nl_geometry_set_sampler_mode(int mode) { if (mode < 0 || mode > 2) return NL_ERR_INVALID_ARG; g_sampler_mode = mode; return NL_OK; }
 
-/* lanes per ray of the work-list intersect kernel: 0 = by ray count (default: 16 up to 32 768 rays, else 8), or 2 / 4 / 8 / 16 */
+/* lanes per ray of the work-list intersect kernel: 0 = by ray count (default: 16 up to 16 384 rays, else 8), or 2 / 4 / 8 / 16 */
 int nl_geometry_set_lanes_per_ray(int lpr) { if (lpr != 0 && lpr != 2 && lpr != 4 && lpr != 8 && lpr != 16) return NL_ERR_INVALID_ARG; g_isect_lpr = lpr; return NL_OK; }
 
 /* profiling aid: device buffer [blocks][8] int64: cycle stamps (start, after set-up, after traversal, after finalise) and the
@@ -1037,7 +1037,7 @@ int nl_sample_rays(int emit, int N, const int* hit_idx, const float* hit_t0, con
     a.s_vox = s_vox; a.s_depth = s_depth; a.s_dist = s_dist; a.s_ray = s_ray;
     // step-parallel (SP_LPR lanes per ray) in the latency-bound regime; at full-scan sizes its extra threads and redundant step
     // evaluations cost throughput (count pass 96 us against 30 us at 131 072 rays) and the sequential kernel is used
-    if (g_sampler_mode == 1 || (g_sampler_mode == 2 && N <= 32768)) {
+    if (g_sampler_mode == 1 || (g_sampler_mode == 2 && N <= 8192)) {   // (16 384 rays: count pass 16 -> 21 us, no gain)
         const int nbk = nl_div_up(N, SP_RAYS) < 1024 ? nl_div_up(N, SP_RAYS) : 1024;
         if (emit) hipLaunchKernelGGL(k_sample_par<true>, dim3(nbk), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);
         else      hipLaunchKernelGGL(k_sample_par<false>, dim3(nbk), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);

@@ -11,7 +11,7 @@ m = w["map"]
 rng = np.random.default_rng(0)
 LPR = int(os.environ.get("LPR", "0"))                      # 0 = the library's choice by ray count
 L.lib().nl_geometry_set_lanes_per_ray(LPR)
-print("lanes per ray:", LPR or "auto (16 up to 32768 rays, else 8)")
+print("lanes per ray:", LPR or "auto (16 up to 16384 rays, else 8)")
 for n, mode in [(N, "all"), (16384, "first"), (16384, "random"), (2048, "random"), (131072, "shuffled")]:
     if mode == "all": sel = np.arange(N)
     elif mode == "first": sel = np.arange(n)
@@ -28,7 +28,7 @@ for n, mode in [(N, "all"), (16384, "first"), (16384, "random"), (2048, "random"
     a.record()
     for _ in range(10): run()
     b.record(); torch.cuda.synchronize()
-    nb = (n * (LPR or (16 if n <= 32768 else 8)) + 255) // 256
+    nb = (n * (LPR or (16 if n <= 16384 else 8)) + 255) // 256
     dbg = torch.zeros(nb * 8, dtype=torch.int64, device="cuda")
     L.lib().nl_geometry_set_debug_buffer(L.ptr(dbg)); run(); torch.cuda.synchronize(); L.lib().nl_geometry_set_debug_buffer(None)
     d = dbg.cpu().numpy().reshape(nb, 8)
