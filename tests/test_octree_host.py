@@ -144,3 +144,78 @@ def test_incremental_export_reproduces_the_full_export():
         if batch > 0:
             assert len(ids) < n                                  # later deltas are partial
     assert len(oc.export_delta()[0]) == 0                        # nothing changed since
+
+
+def test_children_block_layout_describes_the_tree_and_reproduces_the_oracle_hits():
+    """pack_children_blocks (host logic of the traversal layout; CPU tensors): (1) walking the blocks from the pseudo root
+    recovers voxel_structure exactly, children blocks are consecutive in octant order; (2) a plain DFS over the packed layout
+    with centres recomputed from the lattice path finds the same leaves with the same t_min / t_max as the oracle's
+    traversal of the reference layout (bit for bit)"""
+    from nerf_loam_amd.pipeline import pack_children_blocks
+    sc = H.build_oracle_scene(32, 24, 5)
+    ms = sc["ms"]
+    c, st = ms.centres, ms.structure
+    ids, hdr = pack_children_blocks(torch.from_numpy(c), torch.from_numpy(st))
+    ids, hdr = ids.numpy(), hdr.numpy()
+    interior = (st[:, :8] > -1).any(1)
+    assert ids[0, 0] == 0 and hdr[0, 0] == 1 and (ids[0, 1:] == -1).all()
+    seen_nodes, stack = 0, [(1, 0)]                                   # (block, the node whose children it lists)
+    while stack:
+        b, node = stack.pop()
+        seen_nodes += 1
+        assert np.array_equal(ids[b], st[node, :8])
+        exist, has = hdr[b, 1] & 255, (hdr[b, 1] >> 8) & 255
+        assert exist == sum(1 << u for u in range(8) if st[node, u] > -1)
+        assert has == sum(1 << u for u in range(8) if st[node, u] > -1 and interior[st[node, u]])
+        assert (hdr[b, 0] == -1) == (has == 0)
+        for u in range(8):
+            if (has >> u) & 1:
+                stack.append((hdr[b, 0] + bin(has & ((1 << u) - 1)).count("1"), st[node, u]))
+    assert seen_nodes == int(interior.sum()) == len(ids) - 1
+
+    # (2) DFS over the packed layout, fp32 arithmetic of the kernels (nl_slab), against the oracle
+    f32 = np.float32
+    vs, root_side = f32(0.2), int(st[0, 8])
+    pts, cos = sc["points"], sc["cos"]
+    pose = np.array([2000.0, 2000.0, 2000.0, 0, 0, 0], np.float32)
+    o, d = O.ray_setup(S.unit_dirs(pts), O.rodrigues(pose[3:]), pose[:3])
+    sel = np.arange(0, len(o), 37)
+    oi, o0, o1 = O.svo_intersect(o[sel], d[sel], c, st, 0.2, 20)
+
+    def slab(o_, inv, ctr, half):
+        lo, hi = f32(0), f32(100000)
+        for a in range(3):
+            t0 = f32(f32(f32(ctr[a] - half) - o_[a]) * inv[a]); t1 = f32(f32(f32(ctr[a] + half) - o_[a]) * inv[a])
+            if t1 < t0: t0, t1 = t1, t0
+            if t1 < lo or t0 > hi: return None
+            lo = max(lo, t0); hi = min(hi, t1)
+            if lo > hi: return None
+        return lo, hi
+
+    for q, r in enumerate(sel[:60]):
+        with np.errstate(divide="ignore"):
+            inv = (f32(1) / d[r]).astype(f32)
+        hits = []
+        def centre(x, y, z, side):
+            hs = f32(side) * f32(0.5)
+            return [f32(f32(f32(x) + hs) * vs), f32(f32(f32(y) + hs) * vs), f32(f32(f32(z) + hs) * vs)], f32(f32(vs * f32(0.5)) * f32(side))
+        def walk(b, x, y, z, cs):                                       # children of the node at (x,y,z), child side cs, DESCENDING octants
+            exist, has = hdr[b, 1] & 255, (hdr[b, 1] >> 8) & 255
+            for u in range(7, -1, -1):
+                if not (exist >> u) & 1: continue
+                cx, cy, cz = x + (cs if u & 1 else 0), y + (cs if u & 2 else 0), z + (cs if u & 4 else 0)
+                ctr, half = centre(cx, cy, cz, cs)
+                t = slab(o[r], inv, ctr, half)
+                if t is None: continue
+                if cs == 1:
+                    hits.append((ids[b, u], t[0], t[1]))
+                elif (has >> u) & 1:
+                    walk(hdr[b, 0] + bin(has & ((1 << u) - 1)).count("1"), cx, cy, cz, cs // 2)
+        ctr, half = centre(0, 0, 0, root_side)
+        if slab(o[r], inv, ctr, half) is not None:
+            walk(1, 0, 0, 0, root_side // 2)
+        hits = hits[:20]
+        n = int((oi[q] != -1).sum())
+        assert n == len(hits)
+        assert [h[0] for h in hits] == oi[q, :n].tolist()
+        assert np.array_equal(np.array([h[1] for h in hits], np.float32), o0[q, :n]) and np.array_equal(np.array([h[2] for h in hits], np.float32), o1[q, :n])
