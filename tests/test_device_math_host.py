@@ -312,3 +312,26 @@ def test_select_key_is_a_bijection_and_matches_the_numpy_restatement(hh):
     x ^= x >> np.uint64(15); x = (x * np.uint64(0x846CA68B)) & np.uint64(0xFFFFFFFF)
     x ^= x >> np.uint64(16)
     assert np.array_equal(out.astype(np.uint64), x)
+
+
+def test_relu_mask_identities_behind_the_bf16_backward_gemms():
+    """with dH2[i][j] = m(i,j) * dsdf_i * w3_j (m = 0/1 ReLU mask of H2),
+        dH2 @ W2      == dsdf[:,None] * (m @ (w3[:,None] * W2))            (dgrad, gemm_mask_x)
+        dH2.T @ H1    == w3[:,None] * (m.T @ (dsdf[:,None] * H1))           (dW2, k_decoder_wgrad2_x)
+    exactly (checked in rational arithmetic on a small case, and to float64 round-off on the decoder's sizes)."""
+    from fractions import Fraction as Fr
+    rng = np.random.default_rng(4)
+    n, w = 5, 6
+    F = lambda a: np.vectorize(lambda x: Fr(float(x)))(a.astype(np.float32))
+    m = (rng.random((n, w)) > 0.5).astype(np.float32); ds = rng.normal(size=n); w3 = rng.normal(size=w)
+    W2 = rng.normal(size=(w, w)); H1 = np.maximum(rng.normal(size=(n, w)), 0)
+    mF, dsF, w3F, W2F, H1F = F(m), F(ds), F(w3), F(W2), F(H1)
+    dH2 = mF * dsF[:, None] * w3F[None, :]
+    assert (dH2.dot(W2F) == dsF[:, None] * mF.dot(w3F[:, None] * W2F)).all()
+    assert (dH2.T.dot(H1F) == w3F[:, None] * mF.T.dot(dsF[:, None] * H1F)).all()
+    n, w = 64, 256
+    m = (rng.random((n, w)) > 0.5).astype(np.float64); ds = rng.normal(size=n); w3 = rng.normal(size=w)
+    W2 = rng.normal(size=(w, w)); H1 = np.maximum(rng.normal(size=(n, w)), 0)
+    dH2 = m * ds[:, None] * w3[None, :]
+    np.testing.assert_allclose(dH2 @ W2, ds[:, None] * (m @ (w3[:, None] * W2)), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(dH2.T @ H1, w3[:, None] * (m.T @ (ds[:, None] * H1)), rtol=1e-12, atol=1e-12)
