@@ -181,6 +181,15 @@ int nl_pose_matrices(const float* pose6, float* poses12, int F, void* stream);
 int nl_pose_step(float* pose6, float* g_pose, float* m, float* v, const int* enable, float* grad6_out, float* poses12,
                  int F, const int* state, int apply, void* stream);
 
+/* The whole optim.step() of one iteration as ONE launch: nl_adam_prepare + nl_adam_embeddings + nl_adam_f32(decoder) +
+ * nl_decoder_transpose_w2 + nl_pose_step, same arithmetic bit for bit.  A group is skipped when its first pointer is NULL
+ * (emb_bf16 / dec_params / pose6); dec_ws is the decoder workspace of NL_DEC_WS_FLOATS floats (W2^T + operand planes). */
+int nl_optimiser_step(int* state, double lr_emb, double lr_dec, double lr_pose,
+                      void* emb_bf16, float* g_emb, void* emb_m_bf16, void* emb_v_bf16, long long n_emb,
+                      float* dec_params, const float* dec_grad, float* dec_m, float* dec_v, float* dec_ws,
+                      float* pose6, float* g_pose, float* pose_m, float* pose_v, const int* pose_enable, float* grad6_out,
+                      float* poses12, int F, int apply_pose, void* stream);
+
 /* ---- (b2) host octree behind torch.classes.svo.Octree (third_party/sparse_octree/src/bindings.cpp:4-31) */
 void* nl_octree_create(long long grid_dim);                              /* Octree::init   octree.cpp:36-50   */
 void nl_octree_destroy(void* h);

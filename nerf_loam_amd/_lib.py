@@ -76,6 +76,7 @@ _SIGS = {
     "nl_adam_f32": ([_P, _P, _P, _P, _I, _P, _I, _P], _I),
     "nl_pose_matrices": ([_P, _P, _I, _P], _I),
     "nl_pose_step": ([_P] * 7 + [_I, _P, _I, _P], _I),
+    "nl_optimiser_step": ([_P, _D, _D, _D] + [_P] * 4 + [_LL] + [_P] * 5 + [_P] * 7 + [_I, _I, _P], _I),
     "nl_octree_create": ([_LL], _P),
     "nl_octree_destroy": ([_P], None),
     "nl_octree_insert": ([_P, _P, _LL], _I),

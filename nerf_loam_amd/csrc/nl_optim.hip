@@ -100,13 +100,10 @@ __global__ void k_pose_matrix(const float* __restrict__ pose6, float* __restrict
 
 // pose gradient tail + Adam: g_pose[f] = (dL/dt[3], dL/dR[9]) -> dL/d(t,w) -> Adam (if enabled) ->
 // refreshed pose matrices.  grad6_out (optional) receives the 6-vector gradient; g_pose is cleared.
-__global__ void k_pose_step(float* __restrict__ pose6, float* __restrict__ g_pose, float* __restrict__ m, float* __restrict__ v,
-                            const int* __restrict__ enable, float* __restrict__ grad6_out, float* __restrict__ poses12,
-                            int F, const NlAdamHyper* __restrict__ hp, int apply)
+__device__ __forceinline__ void pose_step_one(int f, float* __restrict__ pose6, float* __restrict__ g_pose, float* __restrict__ m,
+                                              float* __restrict__ v, const int* __restrict__ enable, float* __restrict__ grad6_out,
+                                              float* __restrict__ poses12, const NlAdamHyper& h, int apply)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
-    const NlAdamHyper h = *hp;
     float g6[6], gw[3];
     nl_rodrigues_bwd(pose6 + 6 * f + 3, g_pose + 12 * f + 3, gw);
     for (int i = 0; i < 3; ++i) { g6[i] = g_pose[12 * f + i]; g6[3 + i] = gw[i]; }
@@ -119,6 +116,92 @@ __global__ void k_pose_step(float* __restrict__ pose6, float* __restrict__ g_pos
     nl_rodrigues(pose6 + 6 * f + 3, R);
     for (int i = 0; i < 9; ++i) poses12[12 * f + i] = R[i];
     for (int i = 0; i < 3; ++i) poses12[12 * f + 9 + i] = pose6[6 * f + i];
+}
+
+__global__ void k_pose_step(float* __restrict__ pose6, float* __restrict__ g_pose, float* __restrict__ m, float* __restrict__ v,
+                            const int* __restrict__ enable, float* __restrict__ grad6_out, float* __restrict__ poses12,
+                            int F, const NlAdamHyper* __restrict__ hp, int apply)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    pose_step_one(f, pose6, g_pose, m, v, enable, grad6_out, poses12, *hp, apply);
+}
+
+// ---- the whole optimiser step as ONE launch (the iteration is launch-bound at small ray counts: six ~5 us launches -> one).
+// Workgroup roles by index: [embeddings | decoder rows of W2 | rest of the decoder | poses].  Every workgroup derives its group's
+// bias corrections from the device step counter itself; the counter is advanced by the workgroup that finishes last (ticket in
+// state[1]), so nobody reads the new value.  A W2-row workgroup j also owns w3_j: all its threads evaluate the update of w3_j
+// from the old values (they need the NEW w3_j for the dgrad operand planes, value w3_j * W2[j][k]), one stores it after a barrier.
+// Each thread then writes its updated element into W2T and into the six bf16 operand planes (layouts: k_prepare_w2x above).
+struct OptimArgs {
+    int* state; double lr_emb, lr_dec, lr_pose;
+    uint16_t* emb; float* g_emb; uint16_t* emb_m; uint16_t* emb_v; long long n_emb; int nb_emb;
+    float* params; const float* grad; float* dm; float* dv; float* W2T; uint16_t* W2X; uint16_t* W2TX; int nb_dec;
+    float* pose6; float* g_pose; float* pm; float* pv; const int* enable; float* grad6_out; float* poses12; int F; int apply_pose;
+};
+#define OPT_DEC_REST (NL_DEC_PARAMS - NL_W * NL_W - NL_W)            // W1, b1, b2, b3 (w3 rides with the W2 rows)
+#define OPT_DEC_BLOCKS (NL_W + (OPT_DEC_REST + 255) / 256)
+
+__global__ void __launch_bounds__(256) k_optim_step(OptimArgs a)
+{
+    __shared__ NlAdamHyper s_h;
+    const int step = *reinterpret_cast<volatile const int*>(a.state) + 1;       // read once, before anybody can advance it
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int role = b < a.nb_emb ? 0 : (b < a.nb_emb + a.nb_dec ? 1 : 2);
+    if (tid == 0) s_h = nl_adam_hyper(role == 0 ? a.lr_emb : (role == 1 ? a.lr_dec : a.lr_pose), step, 0.9, 0.999, 1e-8);
+    __syncthreads();
+    const NlAdamHyper h = s_h;
+    if (role == 0) {
+        for (long long i = (long long)b * 256 + tid; i < a.n_emb; i += (long long)a.nb_emb * 256) {
+            const float ga = a.g_emb[i];
+            const uint16_t pm = a.emb_m[i], pv = a.emb_v[i];
+            if (ga == 0.0f && pm == 0 && pv == 0) continue;
+            a.g_emb[i] = 0.0f;
+            uint16_t pp = a.emb[i], mm = pm, vv = pv;
+            nl_adam_bf16(&pp, nl_f32_to_bf16(ga), &mm, &vv, h);
+            a.emb[i] = pp; a.emb_m[i] = mm; a.emb_v[i] = vv;
+        }
+    } else if (role == 1) {
+        const int r = b - a.nb_emb;
+        if (r < NL_W) {
+            const int j = r, k = tid, iw = NL_OFF_W3 + j, i = NL_OFF_W2 + j * NL_W + k;
+            float w3 = a.params[iw], w3m = a.dm[iw], w3v = a.dv[iw];
+            nl_adam_f32(&w3, a.grad[iw], &w3m, &w3v, h);
+            float p = a.params[i], m = a.dm[i], v = a.dv[i];
+            nl_adam_f32(&p, a.grad[i], &m, &v, h);
+            a.params[i] = p; a.dm[i] = m; a.dv[i] = v;
+            __syncthreads();                                         // every thread holds the old w3_j
+            if (k == 0) { a.params[iw] = w3; a.dm[iw] = w3m; a.dv[iw] = w3v; }
+            a.W2T[k * NL_W + j] = p;
+            {   // forward planes: value W2[n = j][kk = k]
+                uint16_t* d = a.W2TX + (size_t)((((j >> 5) * 16 + (k >> 4)) * 64) + 32 * ((k >> 3) & 1) + (j & 31)) * 8 + (k & 7);
+                nl_split3_bf16(p, &d[0], &d[NL_W * NL_W], &d[2 * NL_W * NL_W]);
+            }
+            {   // dgrad planes: value w3_j * W2[j][k] at row index j (the reduction index), column k
+                uint16_t* d = a.W2X + (size_t)((((k >> 5) * 16 + (j >> 4)) * 64) + 32 * ((j >> 3) & 1) + (k & 31)) * 8 + (j & 7);
+                nl_split3_bf16(w3 * p, &d[0], &d[NL_W * NL_W], &d[2 * NL_W * NL_W]);
+            }
+        } else {
+            const int g = (r - NL_W) * 256 + tid;
+            int i = -1;
+            if (g < NL_OFF_W2) i = g;                                 // W1, b1
+            else if (g < NL_OFF_W2 + NL_W) i = NL_OFF_B2 + (g - NL_OFF_W2);
+            else if (g == NL_OFF_W2 + NL_W) i = NL_OFF_B3;
+            if (i >= 0) {
+                float p = a.params[i], m = a.dm[i], v = a.dv[i];
+                nl_adam_f32(&p, a.grad[i], &m, &v, h);
+                a.params[i] = p; a.dm[i] = m; a.dv[i] = v;
+            }
+        }
+    } else {
+        const int f = (b - a.nb_emb - a.nb_dec) * 256 + tid;
+        if (f < a.F) pose_step_one(f, a.pose6, a.g_pose, a.pm, a.pv, a.enable, a.grad6_out, a.poses12, h, a.apply_pose);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(&a.state[1], 1) == (int)gridDim.x - 1) { a.state[1] = 0; a.state[0] = step; }
+    }
 }
 
 // Multi-GPU (nerf_loam_amd/dist.py): every rank all-gathers its whole counter block (one small collective) and this kernel
@@ -228,6 +311,33 @@ int nl_pose_step(float* pose6, float* g_pose, float* m, float* v, const int* ena
     if (!pose6 || !g_pose || !m || !v || !poses12 || F <= 0 || !state) return NL_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_pose_step, dim3(nl_div_up(F, 64)), dim3(64), 0, (hipStream_t)stream, pose6, g_pose, m, v, enable, grad6_out,
                        poses12, F, hyper_of(state, 2), apply);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+int nl_optimiser_step(int* state, double lr_emb, double lr_dec, double lr_pose,
+                      void* emb, float* g_emb, void* emb_m, void* emb_v, long long n_emb,
+                      float* dec_params, const float* dec_grad, float* dec_m, float* dec_v, float* dec_ws,
+                      float* pose6, float* g_pose, float* pose_m, float* pose_v, const int* pose_enable, float* grad6_out,
+                      float* poses12, int F, int apply_pose, void* stream)
+{
+    if (!state) return NL_ERR_INVALID_ARG;
+    if (emb && (!g_emb || !emb_m || !emb_v || n_emb <= 0)) return NL_ERR_INVALID_ARG;
+    if (dec_params && (!dec_grad || !dec_m || !dec_v || !dec_ws)) return NL_ERR_INVALID_ARG;
+    if (pose6 && (!g_pose || !pose_m || !pose_v || !poses12 || F <= 0)) return NL_ERR_INVALID_ARG;
+    if (!emb && !dec_params && !pose6) return NL_ERR_INVALID_ARG;
+    OptimArgs a;
+    a.state = state; a.lr_emb = lr_emb; a.lr_dec = lr_dec; a.lr_pose = lr_pose;
+    a.emb = (uint16_t*)emb; a.g_emb = g_emb; a.emb_m = (uint16_t*)emb_m; a.emb_v = (uint16_t*)emb_v; a.n_emb = emb ? n_emb : 0;
+    a.nb_emb = emb ? (int)((n_emb + 255) / 256 < 4096 ? (n_emb + 255) / 256 : 4096) : 0;
+    a.params = dec_params; a.grad = dec_grad; a.dm = dec_m; a.dv = dec_v; a.W2T = dec_ws;
+    a.W2X = dec_ws ? reinterpret_cast<uint16_t*>(dec_ws + NL_W * NL_W) : nullptr;
+    a.W2TX = dec_ws ? reinterpret_cast<uint16_t*>(dec_ws + NL_W * NL_W + 3 * NL_W * NL_W / 2) : nullptr;
+    a.nb_dec = dec_params ? OPT_DEC_BLOCKS : 0;
+    a.pose6 = pose6; a.g_pose = g_pose; a.pm = pose_m; a.pv = pose_v; a.enable = pose_enable; a.grad6_out = grad6_out;
+    a.poses12 = poses12; a.F = pose6 ? F : 0; a.apply_pose = apply_pose;
+    const int nb_pose = pose6 ? nl_div_up(F, 256) : 0;
+    hipLaunchKernelGGL(k_optim_step, dim3(a.nb_emb + a.nb_dec + nb_pose), dim3(256), 0, (hipStream_t)stream, a);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

@@ -142,6 +142,16 @@ def pose_matrices(pose6, poses12):
     check(L.lib().nl_pose_matrices(ptr(pose6), ptr(poses12), pose6.shape[0], stream_ptr()), "nl_pose_matrices")
 
 
+def optimiser_step(state, lr_emb, lr_dec, lr_pose, emb, dec, pose):
+    """one launch for the whole optimiser step; emb = (emb, g_acc, m, v) or None, dec = (params, grad, m, v, workspace) or None,
+    pose = (pose6, g_pose, m, v, enable, grad6_out, poses12, apply) or None"""
+    e = [ptr(t) for t in emb] + [emb[0].numel()] if emb else [None] * 4 + [0]
+    d = [ptr(t) for t in dec] if dec else [None] * 5
+    q = [ptr(t) for t in pose[:7]] + [pose[0].shape[0], int(pose[7])] if pose else [None] * 7 + [0, 0]
+    check(L.lib().nl_optimiser_step(ptr(state), float(lr_emb), float(lr_dec), float(lr_pose), *e, *d, *q, stream_ptr()),
+          "nl_optimiser_step")
+
+
 def pose_step(pose6, g_pose, m, v, enable, grad6_out, poses12, state, apply):
     check(L.lib().nl_pose_step(ptr(pose6), ptr(g_pose), ptr(m), ptr(v), ptr(enable), ptr(grad6_out), ptr(poses12), pose6.shape[0],
                                ptr(state), int(apply), stream_ptr()), "nl_pose_step")

@@ -361,14 +361,11 @@ class SdfEngine:
     def optimiser_step(self, m: MapDevice, dec: DecoderDevice, cfg: IterConfig, update_emb=True, update_decoder=True, update_pose=True,
                        lr_pose=None):
         """optim.step() of render_helpers.py:421-423 / :508-510 on the device-resident parameters."""
-        ops.adam_prepare(self.adam_state, cfg.lr_emb, cfg.lr_dec, cfg.lr_pose if lr_pose is None else lr_pose)
-        if update_emb:
-            ops.adam_embeddings(m.emb, self.g_emb, self.emb_m, self.emb_v, self.adam_state)
-        if update_decoder:
-            ops.adam_f32(dec.params, dec.grad, dec.m, dec.v, self.adam_state, 1)
-            dec.refresh()
-        ops.pose_step(self.pose6[:self.F], self.g_pose, self.pose_m, self.pose_v, self.pose_enable, self.pose_grad6, self.poses12,
-                      self.adam_state, int(update_pose))
+        ops.optimiser_step(self.adam_state, cfg.lr_emb, cfg.lr_dec, cfg.lr_pose if lr_pose is None else lr_pose,
+                           (m.emb, self.g_emb, self.emb_m, self.emb_v) if update_emb else None,
+                           (dec.params, dec.grad, dec.m, dec.v, dec.W2T) if update_decoder else None,
+                           (self.pose6[:self.F], self.g_pose, self.pose_m, self.pose_v, self.pose_enable, self.pose_grad6, self.poses12,
+                            update_pose))
 
     # ------------------------------------------------------------------ hipGraph
     def capture_iteration(self, m: MapDevice, dec: DecoderDevice, cfg: IterConfig, **flags):

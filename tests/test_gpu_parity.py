@@ -497,6 +497,69 @@ def test_hipgraph_replay_matches_eager(nl, golden_dir):
     assert (outs["graph"][2] != outs["eager"][2]).mean() < 5e-3
 
 
+@pytest.mark.parametrize("groups", ["all", "emb+pose", "pose", "decoder"])
+def test_one_launch_optimiser_step_equals_the_separate_kernels(nl, groups):
+    """nl_optimiser_step (one launch) against nl_adam_prepare + nl_adam_embeddings + nl_adam_f32 + nl_decoder_transpose_w2 +
+    nl_pose_step on the same state, three consecutive steps: every buffer bit for bit, the step counter included"""
+    L, ops = nl["L"], nl["ops"]
+    rng = np.random.default_rng(31)
+    n_rows, F = 5000, 3
+    use_emb, use_dec = groups in ("all", "emb+pose"), groups in ("all", "decoder")
+
+    def fresh():
+        r = np.random.default_rng(5)
+        st = dict(
+            state=torch.zeros(L.NL_ADAM_STATE_BYTES // 4, dtype=torch.int32, device="cuda"),
+            emb=dev(r.normal(scale=0.1, size=(n_rows, 16)).astype(np.float32)).to(torch.bfloat16).view(torch.int16),
+            g_emb=torch.zeros(n_rows, 16, device="cuda"), emb_m=torch.zeros(n_rows, 16, dtype=torch.int16, device="cuda"),
+            emb_v=torch.zeros(n_rows, 16, dtype=torch.int16, device="cuda"),
+            params=dev(r.normal(scale=0.05, size=L.NL_DEC_PARAMS).astype(np.float32)), grad=torch.zeros(L.NL_DEC_PARAMS, device="cuda"),
+            m=torch.zeros(L.NL_DEC_PARAMS, device="cuda"), v=torch.zeros(L.NL_DEC_PARAMS, device="cuda"),
+            ws=torch.zeros(L.NL_DEC_WS_FLOATS, device="cuda"),
+            pose6=dev(r.normal(scale=0.1, size=(F, 6)).astype(np.float32)), g_pose=torch.zeros(F, 12, device="cuda"),
+            pose_m=torch.zeros(F, 6, device="cuda"), pose_v=torch.zeros(F, 6, device="cuda"),
+            enable=dev(np.array([0, 1, 1], np.int32)), grad6=torch.zeros(F, 6, device="cuda"), poses12=torch.zeros(F, 12, device="cuda"))
+        ops.decoder_transpose_w2(st["params"], st["ws"])
+        return st
+
+    a, b = fresh(), fresh()
+    lrs = (1e-2, 3e-3, 1e-3)
+    for step in range(3):
+        ge = rng.normal(scale=1e-2, size=(n_rows, 16)).astype(np.float32)
+        ge[rng.random(n_rows) < 0.5] = 0.0                            # untouched rows never move
+        gd = rng.normal(scale=1e-2, size=L.NL_DEC_PARAMS).astype(np.float32)
+        gp = rng.normal(scale=1e-1, size=(F, 12)).astype(np.float32)
+        for st in (a, b):
+            st["g_emb"].copy_(dev(ge)); st["grad"].copy_(dev(gd)); st["g_pose"].copy_(dev(gp))
+        apply_pose = step != 1
+        # separate kernels
+        ops.adam_prepare(a["state"], *lrs)
+        if use_emb:
+            ops.adam_embeddings(a["emb"], a["g_emb"], a["emb_m"], a["emb_v"], a["state"])
+        if use_dec:
+            ops.adam_f32(a["params"], a["grad"], a["m"], a["v"], a["state"], 1)
+            ops.decoder_transpose_w2(a["params"], a["ws"])
+        ops.pose_step(a["pose6"], a["g_pose"], a["pose_m"], a["pose_v"], a["enable"], a["grad6"], a["poses12"], a["state"], apply_pose)
+        # one launch
+        ops.optimiser_step(b["state"], *lrs,
+                           (b["emb"], b["g_emb"], b["emb_m"], b["emb_v"]) if use_emb else None,
+                           (b["params"], b["grad"], b["m"], b["v"], b["ws"]) if use_dec else None,
+                           (b["pose6"], b["g_pose"], b["pose_m"], b["pose_v"], b["enable"], b["grad6"], b["poses12"], apply_pose))
+        torch.cuda.synchronize()
+        assert int(a["state"][0]) == int(b["state"][0]) == step + 1 and int(b["state"][1]) == 0
+        for k in a:
+            if k in ("state", "grad") or (k == "g_emb" and not use_emb):
+                continue
+            x, y = a[k].cpu().numpy(), b[k].cpu().numpy()
+            assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), (groups, step, k)
+        if use_emb:
+            assert float(b["g_emb"].abs().max()) == 0.0                # accumulators are cleared for the next iteration
+        assert float(b["g_pose"].abs().max()) == 0.0
+    assert not np.array_equal(a["pose6"].cpu().numpy()[1], fresh()["pose6"].cpu().numpy()[1])      # something did move
+    if use_dec:
+        assert float((a["params"] - fresh()["params"]).abs().max()) > 0
+
+
 def test_dist_counter_merge_kernel_matches_the_host_rig(nl):
     """nl_dist_merge_counters (the one-block kernel behind exchanges 1 and 2 of nerf_loam_amd/dist.py) against the torch
     arithmetic the gloo test rig uses on host tensors"""
