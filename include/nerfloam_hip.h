@@ -181,8 +181,8 @@ int nl_pose_matrices(const float* pose6, float* poses12, int F, void* stream);
 int nl_pose_step(float* pose6, float* g_pose, float* m, float* v, const int* enable, float* grad6_out, float* poses12,
                  int F, const int* state, int apply, void* stream);
 
-/* The whole optim.step() of one iteration as ONE launch: nl_adam_prepare + nl_adam_embeddings + nl_adam_f32(decoder) +
- * nl_decoder_transpose_w2 + nl_pose_step, same arithmetic bit for bit.  A group is skipped when its first pointer is NULL
+/* The whole optim.step() of one iteration as one launch (plus a one-thread counter advance unless only poses step):
+ * nl_adam_prepare + nl_adam_embeddings + nl_adam_f32(decoder) + nl_decoder_transpose_w2 + nl_pose_step, bit for bit.  A group is skipped when its first pointer is NULL
  * (emb_bf16 / dec_params / pose6); dec_ws is the decoder workspace of NL_DEC_WS_FLOATS floats (W2^T + operand planes). */
 int nl_optimiser_step(int* state, double lr_emb, double lr_dec, double lr_pose,
                       void* emb_bf16, float* g_emb, void* emb_m_bf16, void* emb_v_bf16, long long n_emb,

@@ -129,8 +129,8 @@ __global__ void k_pose_step(float* __restrict__ pose6, float* __restrict__ g_pos
 
 // ---- the whole optimiser step as ONE launch (the iteration is launch-bound at small ray counts: six ~5 us launches -> one).
 // Workgroup roles by index: [embeddings | decoder rows of W2 | rest of the decoder | poses].  Every workgroup derives its group's
-// bias corrections from the device step counter itself; the counter is advanced by the workgroup that finishes last (ticket in
-// state[1]), so nobody reads the new value.  A W2-row workgroup j also owns w3_j: all its threads evaluate the update of w3_j
+// bias corrections from the device step counter itself (nobody writes it while they run: a single-workgroup launch - the pose
+// step of tracking - advances it at its end, a larger one leaves that to the one-thread kernel launched right behind it).  A W2-row workgroup j also owns w3_j: all its threads evaluate the update of w3_j
 // from the old values (they need the NEW w3_j for the dgrad operand planes, value w3_j * W2[j][k]), one stores it after a barrier.
 // Each thread then writes its updated element into W2T and into the six bf16 operand planes (layouts: k_prepare_w2x above).
 struct OptimArgs {
@@ -197,12 +197,12 @@ __global__ void __launch_bounds__(256) k_optim_step(OptimArgs a)
         const int f = (b - a.nb_emb - a.nb_dec) * 256 + tid;
         if (f < a.F) pose_step_one(f, a.pose6, a.g_pose, a.pm, a.pv, a.enable, a.grad6_out, a.poses12, h, a.apply_pose);
     }
-    __syncthreads();
-    if (tid == 0) {
-        __threadfence();
-        if (atomicAdd(&a.state[1], 1) == (int)gridDim.x - 1) { a.state[1] = 0; a.state[0] = step; }
-    }
+    if (gridDim.x == 1 && tid == 0) a.state[0] = step;               // (tid 0 read the old value before the barrier above)
 }
+
+// advance the step counter after a multi-workgroup k_optim_step (a last-workgroup ticket costs more than this launch: thousands
+// of same-address device-scope atomics, profiles/r01_m_optimiser_step.txt)
+__global__ void k_adam_advance(int* __restrict__ state) { state[0] = state[0] + 1; }
 
 // Multi-GPU (nerf_loam_amd/dist.py): every rank all-gathers its whole counter block (one small collective) and this kernel
 // folds the gathered blocks into the local one - instead of one collective per quantity and a dozen tiny torch kernels.
@@ -337,7 +337,9 @@ int nl_optimiser_step(int* state, double lr_emb, double lr_dec, double lr_pose,
     a.pose6 = pose6; a.g_pose = g_pose; a.pm = pose_m; a.pv = pose_v; a.enable = pose_enable; a.grad6_out = grad6_out;
     a.poses12 = poses12; a.F = pose6 ? F : 0; a.apply_pose = apply_pose;
     const int nb_pose = pose6 ? nl_div_up(F, 256) : 0;
-    hipLaunchKernelGGL(k_optim_step, dim3(a.nb_emb + a.nb_dec + nb_pose), dim3(256), 0, (hipStream_t)stream, a);
+    const int nb = a.nb_emb + a.nb_dec + nb_pose;
+    hipLaunchKernelGGL(k_optim_step, dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
+    if (nb > 1) hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }
