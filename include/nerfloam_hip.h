@@ -80,7 +80,7 @@ int nl_ray_intersect(int N, const float* rays_d_sensor, const float* points_gt, 
  * workspace >= ceil(n/1024) ints.  Replaces the boolean-mask compactions of render_helpers.py:219-257. */
 int nl_exclusive_scan_i32(const int* in, int* out, int n, int flag_mode, int* total_out, int* workspace, void* stream);
 int nl_compact_hit_rays(int N, const int* hit_count, const int* hit_rank, int* ray_of_rank, void* stream);
-/* the two calls above fused (one launch up to 16 384 rays, two beyond): hit_rank = exclusive scan of (hit_count > 0),
+/* the two calls above fused (one launch up to 4096 rays, two beyond): hit_rank = exclusive scan of (hit_count > 0),
  * ray_of_rank[rank] = ray, number of hit rays -> *total_out and, if not NULL, *total_out2 */
 int nl_scan_hit_rays(const int* hit_count, int* hit_rank, int* ray_of_rank, int N, int* total_out, int* total_out2, int* workspace,
                      void* stream);

@@ -516,9 +516,10 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_finish(const int* __res
     }
 }
 
-// Whole scan in ONE launch for small inputs (tracking: 2048 rays; a ray shard of a multi-GPU run): one block walks the
-// input in chunks of 1024 with a carry.  For these sizes the three-launch version was pure launch latency.
-#define NL_SCAN_ONE_BLOCK_MAX 16384
+// Whole scan in ONE launch for small inputs (tracking: 2048 rays): one block walks the input in chunks of 1024 with a carry,
+// ~1 us per chunk behind a ~4.8 us launch; the two-launch version costs 2 x 4.8 us at any of these sizes, so it wins from
+// 5 chunks on (16 384 rays: 20.8 us in one block, profiles/r01_m_timeline_latency_bound_steps.txt).
+#define NL_SCAN_ONE_BLOCK_MAX 4096
 __global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_one_block(const int* __restrict__ in, int* __restrict__ out, int n, int flag_mode,
                                                                     int* __restrict__ ray_of_rank, int* __restrict__ total_out,
                                                                     int* __restrict__ total_out2)
