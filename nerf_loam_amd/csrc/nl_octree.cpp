@@ -32,6 +32,13 @@ struct Octree {
     // FEATURE leaves upgraded to SURFACE (incremental export instead of a full one per frame)
     std::vector<int> dirty;
     std::vector<uint8_t> dirty_flag;
+    // path of the previous descent (node per depth) and its key: consecutive LiDAR returns fall into the same or neighbouring
+    // voxels and the eight corner vertices of a voxel share all but the last levels, so a descent resumes at the deepest node it
+    // shares with the previous one (nodes are never removed, and only the leaf level has side effects on existing nodes).
+    // Needs level d <-> coordinate bit (max_level - d), i.e. a power-of-two grid; otherwise every descent starts at the root.
+    int path[24] = {0};
+    uint64_t last_key = 0, low_mask = 0;
+    bool resume_ok = false, have_last = false;
 
     int new_node() {
         Node n;
@@ -86,6 +93,37 @@ int find_leaf(const Octree& t, int x, int y, int z) {
     return n;
 }
 
+// find_leaf for runs of nearby lookups (the eight corners of a voxel, voxels in creation order): resumes from the deepest node
+// shared with the previous lookup, like the insert does.  `valid` = depth down to which path[] belongs to the last key.
+struct LeafFinder {
+    const Octree& t;
+    int path[24];
+    uint64_t last = 0;
+    int valid = -1;
+    explicit LeafFinder(const Octree& tree) : t(tree) { path[0] = 0; }
+    int find(int x, int y, int z) {
+        if (!t.resume_ok) return find_leaf(t, x, y, z);
+        const int L = t.max_level;
+        const uint64_t lk = morton(x, y, z) & t.low_mask;
+        int p = 0;
+        if (valid >= 0) {
+            const uint64_t diff = lk ^ last;
+            p = diff ? L - 1 - (63 - __builtin_clzll(diff)) / 3 : L;
+            if (p > valid) p = valid;
+        }
+        last = lk;
+        int n = path[p];
+        unsigned edge = ((unsigned)t.size / 2) >> p;
+        for (int d = p + 1; d <= L; edge /= 2, ++d) {
+            n = t.nodes[n].child[octant_of(x, y, z, edge)];
+            if (n < 0) { valid = d - 1; return -1; }
+            path[d] = n;
+        }
+        valid = L;
+        return n;
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -99,6 +137,8 @@ void* nl_octree_create(long long grid_dim)
     int r = t->new_node();
     t->nodes[r].side = (uint32_t)t->size;
     t->mark(r);
+    t->resume_ok = t->max_level >= 1 && t->max_level <= 20 && grid_dim == (1LL << t->max_level);
+    t->low_mask = (1ULL << (3 * (t->max_level < 21 ? t->max_level : 20))) - 1ULL;
     return t;
 }
 
@@ -109,14 +149,21 @@ int nl_octree_insert(void* h, const int* pts, long long npts)
 {
     if (!h || (!pts && npts > 0)) return 1;
     Octree& t = *(Octree*)h;
-    const int shift = 21 - t.max_level - 1;
+    const int shift = 21 - t.max_level - 1, L = t.max_level;
     for (long long i = 0; i < npts; ++i) {
         for (int j = 0; j < 8; ++j) {
             const int x = pts[3 * i] + DX[j], y = pts[3 * i + 1] + DY[j], z = pts[3 * i + 2] + DZ[j];
             const uint64_t key = morton(x, y, z);
-            int n = 0;
-            unsigned edge = (unsigned)t.size / 2;
-            for (int d = 1; d <= t.max_level; edge /= 2, ++d) {
+            const uint64_t lk = key & t.low_mask;
+            int p = 0;                                               // levels shared with the previous descent
+            if (t.resume_ok && t.have_last) {
+                const uint64_t diff = lk ^ t.last_key;
+                p = diff ? L - 1 - (63 - __builtin_clzll(diff)) / 3 : L - 1;      // the leaf level is always redone
+            }
+            int n = t.path[p];
+            unsigned edge = ((unsigned)t.size / 2) >> p;
+            bool was_surface = false;
+            for (int d = p + 1; d <= L; edge /= 2, ++d) {
                 const int cid = octant_of(x, y, z, edge);
                 int c = t.nodes[n].child[cid];
                 if (c < 0) {
@@ -124,16 +171,24 @@ int nl_octree_insert(void* h, const int* pts, long long npts)
                     Node& nd = t.nodes[c];
                     nd.code = key & prefix_mask(d + shift);
                     nd.side = edge;
-                    nd.leaf = (d == t.max_level);
+                    nd.leaf = (d == L);
                     nd.type = nd.leaf ? (j == 0 ? T_SURFACE : T_FEATURE) : T_NONLEAF;
                     t.nodes[n].child[cid] = c;
                     t.mark(c); t.mark(n);
                 } else if (t.nodes[c].type == T_FEATURE && j == 0) {
                     t.nodes[c].type = T_SURFACE;
                     t.mark(c); t.mark(n);                              // becomes visible in its parent's children row
+                } else if (d == L && j == 0) {
+                    was_surface = t.nodes[c].type == T_SURFACE;
                 }
                 n = c;
+                t.path[d] = n;
             }
+            t.last_key = lk; t.have_last = true;
+            // a voxel that already is a SURFACE leaf got there through an earlier insert of the same coordinates (modulo the grid
+            // size), which also created its seven corner neighbours: the rest of this point changes nothing (most returns of a
+            // scan repeat a voxel).  Not so on a non-power-of-two grid, where `x & edge` lets unrelated coordinates share a leaf.
+            if (was_surface && t.resume_ok) break;
         }
     }
     return 0;
@@ -164,6 +219,7 @@ int nl_octree_export(void* h, float* voxels, float* children, int* features)
     std::vector<int> queue;
     queue.reserve(n);
     queue.push_back(0);
+    LeafFinder finder(t);
     for (size_t head = 0; head < queue.size(); ++head) {
         const int k = queue[head];
         const Node& nd = t.nodes[k];
@@ -173,7 +229,7 @@ int nl_octree_export(void* h, float* voxels, float* children, int* features)
         if (nd.type == T_SURFACE) {
             for (int i = 0; i < 8; ++i) {
                 // the reference looks the corner up through float coordinates (octree.cpp:319-325)
-                const int q = find_leaf(t, (int)(v[0] + (float)DX[i]), (int)(v[1] + (float)DY[i]), (int)(v[2] + (float)DZ[i]));
+                const int q = finder.find((int)(v[0] + (float)DX[i]), (int)(v[1] + (float)DY[i]), (int)(v[2] + (float)DZ[i]));
                 if (q >= 0) features[8 * (size_t)k + i] = q;
             }
         }
@@ -220,6 +276,7 @@ int nl_octree_export_delta(void* h, float voxel_size, int* ids, float* centres, 
     if (!h || !ids || !centres || !structure || !vertex_idx) return 1;
     Octree& t = *(Octree*)h;
     const size_t nd_ = t.dirty.size();
+    LeafFinder finder(t);
     for (size_t q = 0; q < nd_; ++q) {
         const int k = t.dirty[q];
         const Node& nd = t.nodes[k];
@@ -231,7 +288,7 @@ int nl_octree_export_delta(void* h, float voxel_size, int* ids, float* centres, 
             v[3] = (float)nd.side;
             if (nd.type == T_SURFACE) {
                 for (int i = 0; i < 8; ++i) {
-                    const int c = find_leaf(t, (int)(v[0] + (float)DX[i]), (int)(v[1] + (float)DY[i]), (int)(v[2] + (float)DZ[i]));
+                    const int c = finder.find((int)(v[0] + (float)DX[i]), (int)(v[1] + (float)DY[i]), (int)(v[2] + (float)DZ[i]));
                     if (c >= 0) vertex_idx[8 * q + i] = c;
                 }
             }

@@ -38,8 +38,9 @@ class Octree:
         t = torch.as_tensor(pts)
         if t.dim() != 2 or t.shape[1] != 3:
             raise ValueError(f"Point dimensions mismatch: inputs are {tuple(t.shape)} expect [M,3]")
-        a = np.ascontiguousarray(t.cpu().numpy(), dtype=np.int32)
-        self.all_pts.append(t.clone())
+        keep = np.array(t.cpu().numpy(), copy=True)          # private copy for the pickle state (numpy: no thread-pool wake-up per frame)
+        self.all_pts.append(torch.from_numpy(keep))
+        a = np.ascontiguousarray(keep, dtype=np.int32)
         rc = L.lib().nl_octree_insert(self._h, a.ctypes.data_as(ctypes.c_void_p), a.shape[0])
         if rc:
             raise RuntimeError("nl_octree_insert failed")

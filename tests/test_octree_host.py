@@ -45,6 +45,42 @@ def test_matches_oracle_single_and_incremental():
         assert np.array_equal(c, c2) and np.array_equal(s, s2) and np.array_equal(f, fb)
 
 
+@pytest.mark.parametrize("pattern", ["shuffled", "far_apart", "duplicates", "vertex_then_voxel", "non_pow2_grid", "wraps_around"])
+def test_insert_patterns_match_oracle(pattern):
+    """the insert resumes a descent from the path of the previous one and skips points whose voxel already is a SURFACE leaf:
+    orders and repeats that stress exactly that (node ids are creation-ordered, so any slip changes the export)"""
+    rng = np.random.default_rng(11)
+    v = _vox()
+    grid = 256 * 256 * 4
+    if pattern == "shuffled":
+        batches = [v[rng.permutation(len(v))], v[rng.permutation(len(v))][:500] + np.array([1, 0, 0], np.int32)]
+    elif pattern == "far_apart":
+        batches = [rng.integers(0, grid, size=(1500, 3)).astype(np.int32), np.array([[0, 0, 0], [grid - 2, grid - 2, grid - 2], [0, 0, 0]], np.int32)]
+    elif pattern == "duplicates":
+        base = v[:40]
+        batches = [np.repeat(base, 5, axis=0), base[::-1].copy(), np.concatenate([base, base + np.array([0, 1, 0], np.int32), base])]
+    elif pattern == "vertex_then_voxel":
+        # a coordinate first created as a corner vertex (FEATURE) of its -x neighbour, then inserted as a voxel right after:
+        # same key twice in a row, the leaf level must still be revisited for the upgrade
+        a = v[:200]
+        batches = [np.stack([a, a + np.array([1, 0, 0], np.int32)], axis=1).reshape(-1, 3), a + np.array([1, 1, 1], np.int32)]
+    elif pattern == "wraps_around":
+        grid = 64                                                  # coordinates beyond the grid alias modulo its size
+        c = rng.integers(0, 200, size=(600, 3)).astype(np.int32)
+        batches = [c, c[:100] + 64, c[::-1].copy()]
+    else:
+        grid = 1000                                                # not a power of two: every descent starts at the root
+        batches = [rng.integers(0, 512, size=(800, 3)).astype(np.int32)]
+    a = Octree(); a.init(grid, 16, 0.2)
+    b = O.Octree(); b.init(grid, 16, 0.2)
+    for bt in batches:
+        a.insert(bt); b.insert(bt)
+        assert a.count_nodes() == b.count_nodes() and a.count_leaf_nodes() == b.count_leaf_nodes()
+    va, ca, fa = [t.numpy() for t in a.get_centres_and_children()]
+    vb, cb, fb = b.get_centres_and_children()
+    assert np.array_equal(va, vb) and np.array_equal(ca, cb) and np.array_equal(fa, fb)
+
+
 def test_invariants_and_edge_cases():
     a = Octree(); a.init(256 * 256 * 4, 16, 0.2)
     assert a.count_nodes() == 1 and a.count_leaf_nodes() == 0
@@ -106,6 +142,8 @@ v = S.voxel_coords(pts, O.rodrigues(pose[3:]), pose[:3], 0.2)
 r = torch.classes.svo.Octree(); r.init(256*256*4, 16, 0.2); r.insert(torch.from_numpy(v[:9000])); r.insert(torch.from_numpy(v[7000:]))
 a = Octree(); a.init(256*256*4, 16, 0.2); a.insert(v[:9000]); a.insert(v[7000:])
 o = O.Octree(); o.init(256*256*4, 16, 0.2); o.insert(v[:9000]); o.insert(v[7000:])
+w = v[np.random.default_rng(3).permutation(len(v))[:6000]] + np.array([2, -1, 0], np.int32)    # incoherent order, partly new
+r.insert(torch.from_numpy(w)); a.insert(w); o.insert(w)
 ref = [t.numpy() for t in r.get_centres_and_children()]
 for got in ([t.numpy() for t in a.get_centres_and_children()], list(o.get_centres_and_children())):
     assert all(np.array_equal(x, y) for x, y in zip(ref, got))
