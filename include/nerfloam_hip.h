@@ -149,7 +149,9 @@ int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream);
  * 1 = bf16 matrix cores (v_mfma_f32_32x32x16_bf16) on exact-product formulations (default):
  *   forward  H2 = H1 W2^T:  both operands split into three bf16 terms, all nine partial products (each exact in fp32);
  *   dgrad    dH1[i][k] = dsdf_i * sum_j m(i,j) * (w3_j W2[j][k]),  m = the {0,1} ReLU mask as A operand, B split in three.
- * Accumulation is fp32 in both modes; results differ by summation order only. */
+ * Accumulation is fp32 in both modes; results differ by summation order only.
+ * 2 = mode 1 with six of the nine forward products (without lo x lo, lo x mid, mid x lo: below 2^-24 of a product, i.e. below the
+ *     rounding of the fp32 accumulation; two thirds of the matrix-pipe time).  Prepared, not yet verified on a GPU: not a default. */
 int nl_decoder_set_gemm_mode(int mode);
 int nl_decoder_get_gemm_mode(void);
 

@@ -110,7 +110,7 @@ def lib():
             fn.restype = res
         if os.environ.get("NL_GEMM_MODE"):
             if L.nl_decoder_set_gemm_mode(int(os.environ["NL_GEMM_MODE"])) != 0:
-                raise NerfLoamHipError("NL_GEMM_MODE must be 0 or 1")
+                raise NerfLoamHipError("NL_GEMM_MODE must be 0, 1 or 2")
         if os.environ.get("NL_SAMPLER_MODE"):
             L.nl_geometry_set_sampler_mode(int(os.environ["NL_SAMPLER_MODE"]))
         if os.environ.get("NL_WGRAD2_MODE"):                # A/B switch for measurements (default: the library's own default)

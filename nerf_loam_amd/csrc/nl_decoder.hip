@@ -259,9 +259,13 @@ __device__ __forceinline__ void gemm_x9_prefetch(i32x4 rsX, int w, int lane, uin
         for (int p = 0; p < 3; ++p) bq[s][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + nt_off + s * 1024);
 }
 
-template <bool PIN>
+// NP = 9: all nine partial products (exact).  NP = 6: without lo x lo, lo x mid, mid x lo - terms below 2^-24 of the product,
+// i.e. below the rounding of the fp32 accumulation itself (measured on a 4096 x 256 x 256 case: rms error 7e-9 of sum|a||b|
+// against 2.6e-8 for an fp32 GEMM's own rounding) - at two thirds of the matrix-pipe time.
+template <bool PIN, int NP = 9>
 __device__ __forceinline__ void gemm_x9(i32x4 rsX, int w, int lane, const unsigned char* sP, uint4 (&bq)[X9_RING][3], f32x16& c0, f32x16& c1)
 {
+    static_assert(NP == 9 || NP == 6, "nine or six partial products");
     const int l31 = lane & 31, lh = lane >> 5;
     const int voff = lane * 16;
     const int nt_off = __builtin_amdgcn_readfirstlane(w) * 16 * 1024;     // wave-uniform scalar offset (no waterfall loops)
@@ -289,6 +293,7 @@ __device__ __forceinline__ void gemm_x9(i32x4 rsX, int w, int lane, const unsign
         const bf16x8 fa0 = __builtin_bit_cast(bf16x8, aq[g & 1][0]), fa1 = __builtin_bit_cast(bf16x8, aq[g & 1][1]);
 #pragma unroll
         for (int pb = 2; pb >= 0; --pb) {
+            if (NP == 6 && (2 - g % 3) + pb > 2) continue;             // A plane (2 - g % 3) x B plane pb: keep hi/mid/lo index sums <= 2
             const bf16x8 fb = __builtin_bit_cast(bf16x8, bq[s % RING][pb]);
             c0 = MFMA_BF16(fa0, fb, c0); c1 = MFMA_BF16(fa1, fb, c1);
         }
@@ -350,7 +355,7 @@ __device__ __forceinline__ float halfwave_rowsum(const f32x16& h0, const f32x16&
     return (up ? v2[1] : v2[0]) + __shfl_xor(up ? v2[0] : v2[1], 1);
 }
 
-template <bool TRAIN, bool XG>                          // XG: both 256-deep GEMMs on the bf16 matrix cores (exact-product formulations)
+template <bool TRAIN, bool XG, int NP = 9>               // NP: partial products of the forward GEMM (gemm_x9); XG: both 256-deep GEMMs on the bf16 matrix cores (exact-product formulations)
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[S_TOTAL];
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
-            if (XG) gemm_x9<true>(rsW2TX, w, lane, reinterpret_cast<const unsigned char*>(lds), bq9, h0, h1);
+            if (XG) gemm_x9<true, NP>(rsW2TX, w, lane, reinterpret_cast<const unsigned char*>(lds), bq9, h0, h1);
             else    gemm256(rsW2T, (lh * NL_W + col) * 4, sH1 + l31 * LDH + lh, sH1 + (32 + l31) * LDH + lh, h0, h1);
             DBG_STAMP(3);
 #pragma unroll
@@ -920,7 +925,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
 // forward-only variant for dense SDF queries (mesh-time get_scores, render_helpers.py:96-153) and
 // tests: sdf = decoder(X).
 // ---------------------------------------------------------------------------------------------
-template <bool XG>
+template <bool XG, int NP = 9>
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __restrict__ X, const float* __restrict__ params,
                                                                  const float* __restrict__ W2T, int P, float* __restrict__ sdf)
 {
@@ -970,7 +975,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
             f32x16 h0, h1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
-            if (XG) gemm_x9<true>(rsW2TX, w, lane, reinterpret_cast<const unsigned char*>(lds), bq9, h0, h1);
+            if (XG) gemm_x9<true, NP>(rsW2TX, w, lane, reinterpret_cast<const unsigned char*>(lds), bq9, h0, h1);
             else    gemm256(rsW2T, (lh * NL_W + col) * 4, sH1 + l31 * LDH + lh, sH1 + (32 + l31) * LDH + lh, h0, h1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { h0[r] = fmaxf(h0[r] + b2c, 0.f); h1[r] = fmaxf(h1[r] + b2c, 0.f); }
@@ -1023,7 +1028,8 @@ __global__ void k_mfma_selftest(const float* A32, const float* B32, float* D32, 
 }
 
 static long long* g_dec_dbg = nullptr;
-static int g_gemm_mode = 1;              // 0: fp32 MFMA GEMMs, 1: bf16 MFMA on the exact-product formulations (gemm_x9 / gemm_mask_x)
+static int g_gemm_mode = 1;              // 0: fp32 MFMA GEMMs, 1: bf16 MFMA on the exact-product formulations (gemm_x9 / gemm_mask_x),
+                                         // 2: as 1 with six of the nine forward products (gemm_x9<.., 6>)
 static int g_wgrad2_mode = 1;            // 0: fp32 MFMA (k_decoder_wgrad2), 1: exact 0/1-mask x 3-term bf16 split (k_decoder_wgrad2_x)
 
 extern "C" {
@@ -1037,8 +1043,11 @@ int nl_decoder_set_wgrad2_mode(int mode) { if (mode < 0 || mode > 1) return NL_E
 int nl_decoder_get_wgrad2_mode(void) { return g_wgrad2_mode; }
 /* the two 256-deep GEMMs of the fused decoder kernels (forward H1 W2^T, dgrad dH2 W2): 0 = fp32 matrix cores,
  * 1 = bf16 matrix cores on exact-product formulations (default): forward = both operands split into three bf16 terms, all
- * nine partial products; dgrad = {0,1} ReLU mask x three-term split of w3_j W2[j][k].  fp32 accumulation in both. */
-int nl_decoder_set_gemm_mode(int mode) { if (mode < 0 || mode > 1) return NL_ERR_INVALID_ARG; g_gemm_mode = mode; return NL_OK; }
+ * nine partial products; dgrad = {0,1} ReLU mask x three-term split of w3_j W2[j][k].  fp32 accumulation in both.
+ * 2 = as 1 with six of the nine forward products (the dropped ones are below 2^-24 of a product: below the rounding of the
+ * fp32 accumulation).  PREPARED FOR ROUND 2: compiles, the kernels of modes 0 / 1 are instruction-identical with and without
+ * it, but it has not run on a GPU yet - nothing selects it by default and no test covers it. */
+int nl_decoder_set_gemm_mode(int mode) { if (mode < 0 || mode > 2) return NL_ERR_INVALID_ARG; g_gemm_mode = mode; return NL_OK; }
 int nl_decoder_get_gemm_mode(void) { return g_gemm_mode; }
 
 int nl_decoder_grid_hint(void)
@@ -1063,7 +1072,10 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
     a.dcounters = (double*)(counters + NL_CNT_INTS);
     a.dbg = g_dec_dbg;
     const dim3 g(nslabs), b(DEC_THREADS);
-    if (g_gemm_mode == 1) {
+    if (g_gemm_mode == 2) {
+        if (train_decoder) hipLaunchKernelGGL((k_decoder<true, true, 6>), g, b, 0, (hipStream_t)stream, a);
+        else               hipLaunchKernelGGL((k_decoder<false, true, 6>), g, b, 0, (hipStream_t)stream, a);
+    } else if (g_gemm_mode == 1) {
         if (train_decoder) hipLaunchKernelGGL((k_decoder<true, true>), g, b, 0, (hipStream_t)stream, a);
         else               hipLaunchKernelGGL((k_decoder<false, true>), g, b, 0, (hipStream_t)stream, a);
     } else {
@@ -1093,7 +1105,8 @@ int nl_decoder_forward(const float* X, const float* params, const float* W2T, in
 {
     if (!X || !params || !W2T || !sdf || P < 0 || nblocks <= 0) return NL_ERR_INVALID_ARG;
     if (P == 0) return NL_OK;
-    if (g_gemm_mode == 1) hipLaunchKernelGGL(k_decoder_fwd<true>, dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
+    if (g_gemm_mode == 2) hipLaunchKernelGGL((k_decoder_fwd<true, 6>), dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
+    else if (g_gemm_mode == 1) hipLaunchKernelGGL(k_decoder_fwd<true>, dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
     else                  hipLaunchKernelGGL(k_decoder_fwd<false>, dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
     NL_LAUNCH_CHECK();
     return NL_OK;

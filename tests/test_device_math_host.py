@@ -335,3 +335,30 @@ def test_relu_mask_identities_behind_the_bf16_backward_gemms():
     dH2 = m * ds[:, None] * w3[None, :]
     np.testing.assert_allclose(dH2 @ W2, ds[:, None] * (m @ (w3[:, None] * W2)), rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(dH2.T @ H1, w3[:, None] * (m.T @ (ds[:, None] * H1)), rtol=1e-12, atol=1e-12)
+
+
+def test_six_of_nine_split_products_stay_below_fp32_accumulation_noise():
+    """gemm mode 2 (prepared for the next round): the forward GEMM without the lo x lo, lo x mid, mid x lo partial products.
+    Emulated in float64 on a decoder-shaped case: the error of leaving them out is several times SMALLER than the rounding an
+    fp32 GEMM commits by accumulating in fp32, while the nine-product sum is exact."""
+    rng = np.random.default_rng(0)
+
+    def split3(x):
+        def tr(v):
+            return (np.ascontiguousarray(v, np.float32).view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+        hi = tr(x); r = (x - hi).astype(np.float32); mid = tr(r); lo = (r - mid).astype(np.float32)
+        assert np.array_equal(hi.astype(np.float64) + mid + lo, x.astype(np.float64))
+        return [p.astype(np.float64) for p in (hi, mid, lo)]
+
+    M, K, N = 1024, 256, 256
+    H1 = np.maximum(rng.normal(size=(M, K)) * 0.5, 0).astype(np.float32)
+    W2T = (rng.uniform(-1, 1, size=(K, N)) / 16).astype(np.float32)
+    a, b = split3(H1), split3(W2T)
+    exact = H1.astype(np.float64) @ W2T.astype(np.float64)
+    scale = np.abs(H1).astype(np.float64) @ np.abs(W2T).astype(np.float64)
+    s9 = sum(a[i] @ b[j] for i in range(3) for j in range(3))
+    s6 = sum(a[i] @ b[j] for i in range(3) for j in range(3) if i + j <= 2)
+    f32 = (H1 @ W2T).astype(np.float64)
+    rms = lambda s_: float(np.sqrt((((s_ - exact) / scale) ** 2).mean()))
+    assert rms(s9) < 1e-15
+    assert np.abs(s6 - exact).max() / scale.max() < 2.0 ** -23 and rms(s6) < 0.5 * rms(f32)
