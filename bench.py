@@ -49,8 +49,8 @@ def matrix_pipe_model(kernel, gemm_mode, wgrad2_mode, train):
     if kernel == "decoder":
         alg = FLOPS_PER_SAMPLE_DECODER if train else FLOPS_PER_SAMPLE_DECODER_FROZEN
         small = L1 * (3 if train else 2)                        # layer-1 forward, dX, (dW1)
-        if gemm_mode == 1:
-            return alg, small, 9 * G + 3 * G                    # forward: 3x3 split, dgrad: {0,1} mask x 3-term split
+        if gemm_mode in (1, 2):                                 # forward: 3x3 split (mode 2: six of the nine products),
+            return alg, small, (9 if gemm_mode == 1 else 6) * G + 3 * G     # dgrad: {0,1} mask x 3-term split
         return alg, small + 2 * G, 0
     if wgrad2_mode == 1:
         return FLOPS_PER_SAMPLE_WGRAD2, L1, 3 * G               # H1 rebuilt on fp32 MFMA; mask x 3-term split
@@ -265,10 +265,10 @@ def main():
         gm, wm = _lib.lib().nl_decoder_get_gemm_mode(), _lib.lib().nl_decoder_get_wgrad2_mode()
         rf = roofline_entry("k_decoder<train>" if train_dec else "k_decoder<frozen>", "decoder", dec_ms, P_local, gm, wm, train_dec)
         rf = {"bound": "mfma", **rf,
-              "traffic": pmc_traffic(("k_decoder<true, %s>" if train_dec else "k_decoder<false, %s>") % ("true" if gm == 1 else "false")),
+              "traffic": pmc_traffic(("k_decoder<true, %s>" if train_dec else "k_decoder<false, %s>") % ("true" if gm >= 1 else "false")) if gm != 2 else None,
               "peak_note": ("matrix-pipe bound of the kernel's instruction mix: "
-                            + ("256-deep GEMMs as exact-product bf16 splits (9 + 3 MFMAs per fp32 product, 2500 TF pipe), "
-                               "K=16 layers on the fp32 pipe (157.3 TF)" if gm == 1 else "all GEMMs on the fp32 pipe (157.3 TF)")),
+                            + (f"256-deep GEMMs as {'exact-product ' if gm == 1 else ''}bf16 splits ({9 if gm == 1 else 6} + 3 MFMAs per fp32 product, 2500 TF pipe), "
+                               "K=16 layers on the fp32 pipe (157.3 TF)" if gm >= 1 else "all GEMMs on the fp32 pipe (157.3 TF)")),
               "second_kernel": (roofline_entry("k_decoder_wgrad2_x" if wm == 1 else "k_decoder_wgrad2", "wgrad2", wg_ms, P_local, gm, wm, True)
                                 if train_dec else None)}
         out = {
@@ -278,7 +278,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "dtype_note": ("fp32 values and fp32 accumulation throughout; the decoder's 256-deep GEMMs are evaluated on the bf16 "
                            "matrix cores as exact-product splits (each fp32 operand = 3 bf16 terms exactly; ReLU masks are {0,1}), "
-                           "NL_GEMM_MODE=0 / NL_WGRAD2_MODE=0 select the plain fp32-MFMA kernels" if (gm == 1 or wm == 1)
+                           "NL_GEMM_MODE=0 / NL_WGRAD2_MODE=0 select the plain fp32-MFMA kernels" if (gm >= 1 or wm == 1)
                            else "fp32 MFMA kernels (NL_GEMM_MODE=0, NL_WGRAD2_MODE=0)"),
             "config": {"workload": "synthetic 64x2048 scan (131072 rays), 1 mapping iteration/step: intersect+sample+gather+"
                                    "decoder fwd/bwd+SDF loss+emb/decoder/pose grads+Adam; voxel 0.2 m, step 0.1 m, "
