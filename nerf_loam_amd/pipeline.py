@@ -300,7 +300,7 @@ class SdfEngine:
         ops.ray_intersect(N, self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self.poses12, m.blk_hdr, m.blk_ids, m.root_side,
                           m.voxel_size, cfg.max_distance, self.rays_d_world, self.gt_dist, self.hit_idx, self.hit_t0, self.hit_t1,
                           self.hit_count, c, self.ray_of_rank)
-        # hit-ray ranks + compaction + R (and R_GLOBAL: overwritten by the multi-GPU hook) in one launch (two beyond 16 k rays)
+        # hit-ray ranks + compaction + R (and R_GLOBAL: overwritten by the multi-GPU hook) in one launch (two beyond 4096 rays)
         ops.scan_hit_rays(self.hit_count, self.hit_rank, self.ray_of_rank, N, c[L.NLC_R:L.NLC_R + 1], c[L.NLC_R_GLOBAL:L.NLC_R_GLOBAL + 1],
                           self.scan_ws)
         if self.hook_after_intersect is not None:
