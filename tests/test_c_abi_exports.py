@@ -26,6 +26,34 @@ def test_header_symbols_exported_and_bound():
     assert lib.nl_version() >= 100
 
 
+def test_header_is_plain_c_and_every_entry_links_from_c(tmp_path):
+    """the boundary is a C ABI: the header compiles as strict C99 (no C++, no torch types), and a C translation unit that takes
+    the address of every declared entry point links against the library (and runs: nl_version, the host octree - no GPU calls)"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    syms = declared_symbols()
+    src = ['#include "nerfloam_hip.h"', "#include <stdio.h>", "typedef void (*fn)(void);", "int main(void) {",
+           "    fn table[] = {"] + [f"        (fn){s}," for s in syms] + ["    };",
+           "    void* t = nl_octree_create(64);", "    int v[6] = {1, 2, 3, 1, 2, 4};",
+           "    if (!t || nl_octree_insert(t, v, 2) != 0) return 2;",
+           "    long long n = nl_octree_count_nodes(t), leaves = nl_octree_count_leaf_nodes(t);", "    nl_octree_destroy(t);",
+           '    printf("%d %d %lld %lld\\n", (int)(sizeof table / sizeof table[0]), nl_version(), n, leaves);', "    return 0;", "}"]
+    c = tmp_path / "abi.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe),
+           "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + libdir]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    n_syms, version, nodes, leaves = out.stdout.split()
+    assert int(n_syms) == len(syms) and int(version) >= 100 and int(leaves) == 2 and int(nodes) > 2
+
+
 def test_header_constants_match_binding():
     src = open(os.path.join(ROOT, "include", "nerfloam_hip.h")).read()
     consts = dict(re.findall(r"#define\s+(NL_[A-Z_]+)\s+(\d+)", src))
