@@ -12,15 +12,16 @@ import torch.nn as nn
 
 
 def _taylor(x, kind, nth=10):
-    """sin(x)/x ("A") and (1-cos x)/x^2 ("B") by their 11-term series (se3pose.py:64-83)."""
+    """sin(x)/x ("A"), (1-cos x)/x^2 ("B") and (x-sin x)/x^3 ("C") by their (nth+1)-term series sum_i (-1)^i x^(2i) / (2i+k)!,
+    k = 1, 2, 3 (se3pose.py:64-93)."""
+    k = {"A": 1, "B": 2, "C": 3}[kind]
     ans = torch.zeros_like(x)
     denom = 1.0
+    for j in range(2, k + 1):
+        denom *= j                                           # k!
     for i in range(nth + 1):
-        if kind == "A":
-            if i > 0:
-                denom *= (2 * i) * (2 * i + 1)
-        else:
-            denom *= (2 * i + 1) * (2 * i + 2)
+        if i > 0:
+            denom *= (2 * i + k - 1) * (2 * i + k)               # (2i+k)! from (2i+k-2)!
         ans = ans + (-1) ** i * x ** (2 * i) / denom
     return ans
 
@@ -55,6 +56,19 @@ class OptimizablePose(nn.Module):
         w0, w1, w2 = w.unbind(dim=-1)
         z = torch.zeros_like(w0)
         return torch.stack([torch.stack([z, -w2, w1], -1), torch.stack([w2, z, -w0], -1), torch.stack([-w1, w0, z], -1)], -2)
+
+    # the series helpers of the reference class (se3pose.py:64-93), kept for callers that use them directly
+    @classmethod
+    def taylor_A(cls, x, nth=10):
+        return _taylor(x, "A", nth)
+
+    @classmethod
+    def taylor_B(cls, x, nth=10):
+        return _taylor(x, "B", nth)
+
+    @classmethod
+    def taylor_C(cls, x, nth=10):
+        return _taylor(x, "C", nth)
 
     @classmethod
     def log(cls, R, eps=1e-7):
