@@ -174,7 +174,8 @@ class Mapping:
             targets = targets + [tracked_frame]
         return targets
 
-    def insert_keyframe(self, frame):
+    def insert_keyframe(self, frame, valid_distance=-1):
+        """mapping.py:266-280 (`valid_distance` is accepted and overridden there too)"""
         lim = self.key_distance + 0.01
         mask = (frame.points.abs() < lim).all(-1)
         if int(mask.sum()) < 2 * self.n_rays:
@@ -183,7 +184,7 @@ class Mapping:
         self.current_keyframe = kf
         self.keyframe_graph += [kf]
 
-    def update_share_data(self, share_data):
+    def update_share_data(self, share_data, frameid=None):
         """decoder + map tensors for the tracker (mapping.py:227-232); tensors stay on the device"""
         share_data.decoder = self.decoder
         share_data.states = dict(self.map_states)

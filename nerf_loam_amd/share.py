@@ -46,6 +46,37 @@ class ShareData:
         self.stop_mapping = False
         self.stop_tracking = False
         self.tracking_trajectory = []
+        self._voxels = self._octree = None
+
+    # ------------------------------------------------------------------ the remaining attributes of src/share.py (off the hot path)
+    @property
+    def voxels(self):
+        from copy import deepcopy
+        with self._lock:
+            return deepcopy(self._voxels)
+
+    @voxels.setter
+    def voxels(self, voxels):
+        from copy import deepcopy
+        with self._lock:
+            self._voxels = deepcopy(voxels)
+
+    @property
+    def octree(self):
+        from copy import deepcopy
+        with self._lock:
+            return deepcopy(self._octree)
+
+    @octree.setter
+    def octree(self, octree):
+        from copy import deepcopy
+        with self._lock:
+            self._octree = deepcopy(octree)
+
+    def push_pose(self, pose):
+        from copy import deepcopy
+        with self._lock:
+            self.tracking_trajectory.append(deepcopy(pose))
 
     # ------------------------------------------------------------------ capacity
     def reserve(self, n_nodes, n_rows, channels=16):

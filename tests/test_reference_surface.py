@@ -83,3 +83,50 @@ def test_pose_frame_and_criterion_containers(ref):
     p = OptimizablePose(torch.tensor([0.3, -0.2, 0.1, 0.02, -0.01, 0.03]))
     assert [n for n, _ in p.named_parameters()] == ref["pose_params"]
     np.testing.assert_allclose(p.matrix().detach().numpy(), np.array(ref["pose_matrix"]), rtol=0, atol=1e-6)
+
+
+def _ast_methods(path, cls):
+    import ast
+    tree = ast.parse(open(path).read())
+    node = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls)
+    out = {}
+    for m in node.body:
+        if isinstance(m, ast.FunctionDef):
+            names = [a.arg for a in m.args.args]
+            defaults = [None] * (len(names) - len(m.args.defaults)) + [ast.unparse(d) for d in m.args.defaults]
+            out[m.name] = list(zip(names, defaults))
+    return out
+
+
+@pytest.mark.parametrize("module,cls,methods", [
+    ("mapping", "Mapping", ["__init__", "create_voxels", "get_embeddings", "update_grid_features", "do_mapping", "select_optimize_targets",
+                            "insert_keyframe", "update_share_data"]),
+    ("tracking", "Tracking", ["__init__", "do_tracking"])])
+def test_mapping_and_tracking_call_sites_keep_their_signatures(module, cls, methods):
+    """mapping.py / tracking.py cannot be imported here (open3d, a hard-coded load_library path): their signatures are read from
+    the source tree with ast.  Every call that is valid for the reference must be valid here: same names and order, same defaults; ours may make a
+    required parameter optional and append defaulted parameters (e.g. `device`)."""
+    import importlib
+    want = _ast_methods(os.path.join(REF, "src", module + ".py"), cls)
+    ours = getattr(importlib.import_module("nerf_loam_amd." + module), cls)
+    for m in methods:
+        got = [(n, None if p.default is inspect._empty else repr(p.default)) for n, p in inspect.signature(getattr(ours, m)).parameters.items()]
+        ref_sig = want[m]
+        assert [g[0] for g in got[:len(ref_sig)]] == [r[0] for r in ref_sig], (cls, m)
+        for (n, d), (_, rd) in zip(got, ref_sig):
+            if rd is not None:                                                    # optional stays optional with the same default;
+                assert d is not None and d.replace('"', "'") == rd.replace('"', "'"), (cls, m, n)     # (required may become optional)
+        assert all(d is not None for _, d in got[len(ref_sig):]), (cls, m)         # anything we append is optional
+
+
+def test_share_data_has_the_attributes_of_the_reference():
+    import ast
+    from nerf_loam_amd.share import ShareData
+    tree = ast.parse(open(os.path.join(REF, "src", "share.py")).read())
+    node = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "ShareData")
+    names = {m.name for m in node.body if isinstance(m, ast.FunctionDef) and not m.name.startswith("__")}
+    assert {"decoder", "states", "stop_mapping", "stop_tracking", "tracking_trajectory", "push_pose"} <= names
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nerf_loam_amd", "share.py")).read()
+    for n in names:                                                              # properties, plain attributes or methods
+        assert hasattr(ShareData, n) or ("self." + n + " =") in src, n
+
