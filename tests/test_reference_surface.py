@@ -130,3 +130,15 @@ def test_share_data_has_the_attributes_of_the_reference():
     for n in names:                                                              # properties, plain attributes or methods
         assert hasattr(ShareData, n) or ("self." + n + " =") in src, n
 
+
+def test_grid_operators_take_the_arguments_of_the_pybind_module():
+    """third_party/sparse_voxels: include/intersect.h, include/sample.h declare what src/binding.cpp exports as `grid`"""
+    import re
+    from nerf_loam_amd import grid
+    inc = os.path.join(REF, "third_party", "sparse_voxels", "include")
+    for header, fn in (("intersect.h", "svo_intersect"), ("sample.h", "inverse_cdf_sampling")):
+        src = re.sub(r"\s+", " ", open(os.path.join(inc, header)).read())
+        args = re.search(fn + r"\s*\(([^)]*)\)", src).group(1)
+        names = [a.strip().split()[-1] for a in args.split(",")]
+        assert list(inspect.signature(getattr(grid, fn)).parameters) == names, fn
+
