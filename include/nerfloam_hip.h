@@ -199,6 +199,9 @@ int nl_octree_insert(void* h, const int* voxels_xyz, long long n);       /* Octr
 long long nl_octree_count_nodes(void* h);                                /* octree.cpp:344-365 */
 long long nl_octree_count_leaf_nodes(void* h);                           /* octree.cpp:367-387 */
 int nl_octree_has_voxel(void* h, int x, int y, int z);                   /* octree.cpp:173-206 */
+int nl_octree_voxels_dfs(void* h, float* out_xyzs);                      /* get_voxels octree.cpp:242-265: [count_nodes,4], pre-order */
+long long nl_octree_leaf_voxels(void* h, float* out_xyz);                /* get_leaf_voxels octree.cpp:212-240; NULL: count */
+double nl_octree_try_insert(void* h, const int* voxels_xyz, long long n);  /* octree.cpp:113-149: overlap ratio of the vertex keys */
 int nl_octree_export(void* h, float* voxels, float* children, int* features);   /* get_centres_and_children :293-342 */
 int nl_octree_export_device_layout(void* h, float voxel_size, float* centres, int* structure, int* vertex_idx); /* + mapping.py:319-327 */
 /* incremental export: rows, in the layout above, of the nodes that changed since the previous call */

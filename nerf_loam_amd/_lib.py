@@ -83,6 +83,9 @@ _SIGS = {
     "nl_octree_count_nodes": ([_P], _LL),
     "nl_octree_count_leaf_nodes": ([_P], _LL),
     "nl_octree_has_voxel": ([_P, _I, _I, _I], _I),
+    "nl_octree_voxels_dfs": ([_P, _P], _I),
+    "nl_octree_leaf_voxels": ([_P, _P], _LL),
+    "nl_octree_try_insert": ([_P, _P, _LL], ctypes.c_double),
     "nl_octree_export": ([_P, _P, _P, _P], _I),
     "nl_octree_export_device_layout": ([_P, _F, _P, _P, _P], _I),
     "nl_octree_delta_count": ([_P], _LL),

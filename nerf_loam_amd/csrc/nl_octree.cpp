@@ -7,6 +7,7 @@
 // index-linked arrays (no per-node heap allocation, no pointer chasing across the heap), the node
 // counter is per instance (the reference's is process-global), and the export writes
 // straight into caller-provided buffers in the layouts the kernels consume.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -205,6 +206,80 @@ long long nl_octree_count_leaf_nodes(void* h)
 }
 
 int nl_octree_has_voxel(void* h, int x, int y, int z) { return h && find_leaf(*(Octree*)h, x, y, z) >= 0; }
+
+// get_leaf_voxels (octree.cpp:212-240): integer coordinates of the SURFACE leaves in depth-first octant order.  out == NULL: count only.
+long long nl_octree_leaf_voxels(void* h, float* out)
+{
+    if (!h) return 0;
+    const Octree& t = *(Octree*)h;
+    long long count = 0;
+    std::vector<int> stack;
+    stack.push_back(0);
+    while (!stack.empty()) {
+        const int k = stack.back();
+        stack.pop_back();
+        const Node& nd = t.nodes[k];
+        if (nd.leaf) {
+            if (nd.type == T_SURFACE) {
+                if (out) {
+                    out[3 * count] = (float)gather3(nd.code); out[3 * count + 1] = (float)gather3(nd.code >> 1);
+                    out[3 * count + 2] = (float)gather3(nd.code >> 2);
+                }
+                ++count;
+            }
+            continue;
+        }
+        for (int i = 7; i >= 0; --i)                                  // pushed in reverse: popped in octant order 0..7
+            if (nd.child[i] >= 0) stack.push_back(nd.child[i]);
+    }
+    return count;
+}
+
+// get_voxels (octree.cpp:242-265): (x, y, z, side) of EVERY node, depth-first pre-order in octant order; out: [count_nodes, 4]
+int nl_octree_voxels_dfs(void* h, float* out)
+{
+    if (!h || !out) return 1;
+    const Octree& t = *(Octree*)h;
+    std::vector<int> stack;
+    stack.push_back(0);
+    size_t q = 0;
+    while (!stack.empty()) {
+        const int k = stack.back();
+        stack.pop_back();
+        const Node& nd = t.nodes[k];
+        out[4 * q] = (float)gather3(nd.code); out[4 * q + 1] = (float)gather3(nd.code >> 1); out[4 * q + 2] = (float)gather3(nd.code >> 2);
+        out[4 * q + 3] = (float)nd.side;
+        ++q;
+        for (int i = 7; i >= 0; --i)
+            if (nd.child[i] >= 0) stack.push_back(nd.child[i]);
+    }
+    return 0;
+}
+
+// try_insert (octree.cpp:113-149): which fraction of the DISTINCT vertex keys of `pts` (each voxel + its 7 corner neighbours) is in
+// the tree already.  The reference intersects with its set of inserted keys into a std::set<int>, i.e. it counts the matches by
+// their low 32 key bits; kept.  Membership is read from the tree (leaf at the coordinates whose stored key equals the query),
+// which equals the reference's key set for coordinates inside the grid.  No points: 0 / 0 = NaN, as there.
+double nl_octree_try_insert(void* h, const int* pts, long long npts)
+{
+    if (!h || (!pts && npts > 0)) return -1.0;
+    const Octree& t = *(Octree*)h;
+    std::vector<uint64_t> keys;
+    keys.reserve((size_t)npts * 8);
+    for (long long i = 0; i < npts; ++i)
+        for (int j = 0; j < 8; ++j) keys.push_back(morton(pts[3 * i] + DX[j], pts[3 * i + 1] + DY[j], pts[3 * i + 2] + DZ[j]));
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    std::vector<uint32_t> hit;
+    LeafFinder finder(t);
+    for (uint64_t key : keys) {
+        const int n = finder.find((int)gather3(key), (int)gather3(key >> 1), (int)gather3(key >> 2));
+        if (n >= 0 && t.nodes[n].code == key) hit.push_back((uint32_t)key);
+    }
+    std::sort(hit.begin(), hit.end());
+    hit.erase(std::unique(hit.begin(), hit.end()), hit.end());
+    return 1.0 * (double)hit.size() / (double)keys.size();
+}
 
 // get_centres_and_children: voxels[n,4] f32 (x,y,z,side; zero rows for FEATURE leaves),
 // children[n,8] f32 (-1 = absent or FEATURE leaf), features[n,8] i32 (corner-vertex node ids of

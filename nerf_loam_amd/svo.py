@@ -1,7 +1,8 @@
 """`svo.Octree` operator surface on the native host octree (csrc/nl_octree.cpp).
 
 Mirrors torch.classes.svo.Octree (/root/reference/third_party/sparse_octree/src/bindings.cpp:4-31):
-same method names, argument meaning and returned tensors (CPU torch tensors, same dtypes/shapes),
+same method names (init, insert, try_insert, get_voxels, get_leaf_voxels, get_features, count_nodes, count_leaf_nodes, has_voxel,
+get_centres_and_children; the free op `encode`), argument meaning and returned tensors (CPU torch tensors, same dtypes/shapes),
 same pickle state (size, feat_dim, voxel_size, list of inserted tensors).  Differences, on purpose:
 the node counter is per instance (the reference's is process-global) and malformed
 input raises instead of printing to stdout."""
@@ -11,6 +12,23 @@ import numpy as np
 import torch
 
 from . import _lib as L
+
+
+def encode(coords):
+    """torch.ops.svo.encode (bindings.cpp:6, include/test.h:75-86): i64[K,3] -> i64[K,1] Morton keys of 21-bit coordinates.  As in
+    the reference, the z slot of the key is filled from the x column (test.h:82 reads coords[3 i] twice)."""
+    c = torch.as_tensor(coords)
+    if c.dim() != 2 or c.shape[1] != 3 or c.dtype != torch.int64:
+        raise ValueError("encode expects an int64 tensor [K,3]")
+    a = c.cpu().numpy().astype(np.uint64)
+
+    def spread(v):
+        x = v & np.uint64(0x1fffff)
+        for sh, mask in ((32, 0x1f00000000ffff), (16, 0x1f0000ff0000ff), (8, 0x100f00f00f00f00f), (4, 0x10c30c30c30c30c3), (2, 0x1249249249249249)):
+            x = (x | (x << np.uint64(sh))) & np.uint64(mask)
+        return x
+    key = (spread(a[:, 0]) | (spread(a[:, 1]) << np.uint64(1)) | (spread(a[:, 0]) << np.uint64(2))) & np.uint64(0x7fffffffffffffff)
+    return torch.from_numpy(key.astype(np.int64)).reshape(-1, 1)
 
 
 class Octree:
@@ -72,8 +90,34 @@ class Octree:
         return torch.from_numpy(vox), torch.from_numpy(ch), torch.from_numpy(ft)
 
     def get_voxels(self):
-        v, _, _ = self.get_centres_and_children()
-        return v
+        """-> f32[n,4]: (x, y, z, side) of every node in depth-first octant order (octree.cpp:242-265) - NOT the node-id order of
+        get_centres_and_children()"""
+        self._need()
+        out = np.empty((self.count_nodes(), 4), np.float32)
+        if L.lib().nl_octree_voxels_dfs(self._h, out.ctypes.data_as(ctypes.c_void_p)):
+            raise RuntimeError("nl_octree_voxels_dfs failed")
+        return torch.from_numpy(out)
+
+    def get_leaf_voxels(self):
+        """-> f32[L,3]: integer coordinates of the SURFACE leaves, depth-first octant order (octree.cpp:212-240)"""
+        self._need()
+        n = int(L.lib().nl_octree_leaf_voxels(self._h, None))
+        out = np.empty((n, 3), np.float32)
+        if n:
+            L.lib().nl_octree_leaf_voxels(self._h, out.ctypes.data_as(ctypes.c_void_p))
+        return torch.from_numpy(out)
+
+    def try_insert(self, pts):
+        """fraction of the vertex keys of `pts` already in the tree, nothing inserted (octree.cpp:113-149)"""
+        self._need()
+        t = torch.as_tensor(pts)
+        if t.dim() != 2 or t.shape[1] != 3:
+            raise ValueError(f"Point dimensions mismatch: inputs are {tuple(t.shape)} expect [M,3]")
+        a = np.ascontiguousarray(t.cpu().numpy(), dtype=np.int32)
+        return float(L.lib().nl_octree_try_insert(self._h, a.ctypes.data_as(ctypes.c_void_p), a.shape[0]))
+
+    def get_features(self, pts):
+        raise NotImplementedError("Octree::get_features has an empty body in the reference (octree.cpp:208-210)")
 
     def export_device_layout(self):
         """centres f32[n,3], structure i32[n,9], vertex_idx i32[n,8] (mapping.py:319-327 folded in)"""

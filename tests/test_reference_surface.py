@@ -142,3 +142,16 @@ def test_grid_operators_take_the_arguments_of_the_pybind_module():
         names = [a.strip().split()[-1] for a in args.split(",")]
         assert list(inspect.signature(getattr(grid, fn)).parameters) == names, fn
 
+
+def test_octree_class_has_every_bound_method():
+    """third_party/sparse_octree/src/bindings.cpp: the methods of torch.classes.svo.Octree and the free op svo.encode"""
+    import re
+    from nerf_loam_amd import svo
+    src = open(os.path.join(REF, "third_party", "sparse_octree", "src", "bindings.cpp")).read()
+    bound = re.findall(r'\.def\("(\w+)"', src)
+    assert {"init", "insert", "try_insert", "get_voxels", "get_leaf_voxels", "get_features", "count_nodes", "count_leaf_nodes", "has_voxel",
+            "get_centres_and_children"} <= set(bound)
+    for m in bound:
+        assert hasattr(svo, m) if m == "encode" else hasattr(svo.Octree, m), m
+    assert "def_pickle" in src and hasattr(svo.Octree, "__getstate__") and hasattr(svo.Octree, "__setstate__")
+
