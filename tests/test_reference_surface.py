@@ -28,7 +28,16 @@ d = Decoder(**cfg['decoder_specs'])
 pub = lambda c: sorted(m for m in c.__dict__ if not m.startswith('_'))
 sig = lambda f: [(n, None if p.default is inspect._empty else repr(p.default)) for n, p in inspect.signature(f).parameters.items()]
 pose = OptimizablePose(torch.tensor([0.3, -0.2, 0.1, 0.02, -0.01, 0.03]))
-print(json.dumps(dict(
+import numpy as np
+pts = torch.from_numpy(np.random.default_rng(2).normal(size=(500, 3)).astype(np.float32) * 10)
+cosv = torch.from_numpy(np.random.default_rng(3).uniform(0.2, 1.0, size=(500,)).astype(np.float32))
+T = np.eye(4); T[:3, :3] = OptimizablePose(torch.tensor([0., 0., 0., 0.1, -0.2, 0.05])).rotation().detach().numpy(); T[:3, 3] = [1.0, -2.0, 0.5]
+fr = LidarFrame(7, pts, cosv, T.copy())
+torch.manual_seed(5)
+fr.sample_rays(128)
+frame_case = dict(rays_d=fr.rays_d.tolist(), rays_norm=fr.rays_norm.tolist(), pose=fr.get_pose().detach().tolist(), data=fr.pose.data.detach().tolist(),
+                  mask=fr.sample_mask.reshape(-1).int().tolist(), mask_shape=list(fr.sample_mask.shape), T=T.tolist())
+print(json.dumps(dict(frame_case=frame_case,
     fns={f: sig(getattr(RH, f)) for f in ('bundle_adjust_frames', 'track_frame', 'render_rays')},
     decoder_specs=cfg['decoder_specs'], decoder_state={k: list(v.shape) for k, v in d.state_dict().items()},
     criterion_init=sig(Criterion.__init__), pose_methods=pub(OptimizablePose), pose_matrix=pose.matrix().detach().tolist(),
@@ -154,4 +163,22 @@ def test_octree_class_has_every_bound_method():
     for m in bound:
         assert hasattr(svo, m) if m == "encode" else hasattr(svo.Octree, m), m
     assert "def_pickle" in src and hasattr(svo.Octree, "__getstate__") and hasattr(svo.Octree, "__setstate__")
+
+
+def test_lidar_frame_reproduces_the_reference_on_the_same_inputs(ref):
+    """same points / pose matrix / torch seed: unit directions, norms, the +2000 m pose and the per-iteration ray subset drawn from
+    the CPU generator (the default RAY_SELECTION = "host" path) are the reference's, bit for bit"""
+    import numpy as np
+    import torch
+    from nerf_loam_amd.lidar_frame import LidarFrame
+    c = ref["frame_case"]
+    pts = torch.from_numpy(np.random.default_rng(2).normal(size=(500, 3)).astype(np.float32) * 10)
+    cosv = torch.from_numpy(np.random.default_rng(3).uniform(0.2, 1.0, size=(500,)).astype(np.float32))
+    fr = LidarFrame(7, pts, cosv, np.array(c["T"]))
+    torch.manual_seed(5)
+    fr.sample_rays(128)
+    assert np.array_equal(fr.rays_d.numpy(), np.array(c["rays_d"], np.float32)) and np.array_equal(fr.rays_norm.numpy(), np.array(c["rays_norm"], np.float32))
+    assert list(fr.sample_mask.shape) == c["mask_shape"] and fr.sample_mask.reshape(-1).int().tolist() == c["mask"] and sum(c["mask"]) == 128
+    np.testing.assert_allclose(fr.pose.data.detach().numpy(), np.array(c["data"], np.float32), rtol=0, atol=2e-4)      # 2000 m offset: 1.2e-4 ulp
+    np.testing.assert_allclose(fr.get_pose().detach().numpy(), np.array(c["pose"], np.float32), rtol=0, atol=2e-4)
 
