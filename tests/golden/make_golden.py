@@ -167,7 +167,7 @@ def scene_points(n_beams, n_azimuth, seed):
     return S.synthetic_scan(n_beams, n_azimuth, seed, range_noise=0.01, sector=(0.1, 0.1 + n_azimuth / 2048.0))
 
 
-def build_scene(n_beams, n_azimuth, seed):
+def build_scene(n_beams, n_azimuth, seed, VOXEL=VOXEL):
     pts, cos = scene_points(n_beams, n_azimuth, seed)
     pose6 = S.scan_pose()
     R = O.rodrigues(pose6[3:])
@@ -234,9 +234,11 @@ def decoder_arrays(dec):
 
 
 def run_mapping_case(name, n_frames, n_rays, n_iter, seed, update_pose=True, update_decoder=True,
-                     n_beams=64, n_azimuth=48):
+                     n_beams=64, n_azimuth=48, VOXEL=VOXEL, step_factor=0.5, lrs=(0.03, 0.005, 0.001)):
+    """VOXEL / step_factor / lrs: mapper_specs voxel_size, step_size and learning rates of the dataset configs
+    (configs/maicity: 0.2, 0.5, .03/.005/.001; configs/kitti: 0.3, 0.5, .01/.005/.001; configs/ncd: 0.2, 0.2, .002/.005/.001)"""
     _CAP.clear()
-    sc = build_scene(n_beams, n_azimuth, seed)
+    sc = build_scene(n_beams, n_azimuth, seed, VOXEL)
     rng = np.random.default_rng(seed)
     frames, masks, poses0 = [], [], []
     for i in range(n_frames):
@@ -262,8 +264,8 @@ def run_mapping_case(name, n_frames, n_rays, n_iter, seed, update_pose=True, upd
                   "voxel_structure": sc["structure"], "voxel_vertex_emb": emb,
                   "voxel_id2embedding_id": sc["id_table"]}
     crit = CapCriterion(ARGS)
-    RH.bundle_adjust_frames(frames, emb, map_states, dec, crit, VOXEL, 0.5 * VOXEL, n_rays, n_iter, 0.30, 20, 50.0,
-                            learning_rate=[0.03, 0.005, 0.001], update_pose=update_pose,
+    RH.bundle_adjust_frames(frames, emb, map_states, dec, crit, VOXEL, step_factor * VOXEL, n_rays, n_iter, 0.30, 20, 50.0,
+                            learning_rate=list(lrs), update_pose=update_pose,
                             update_decoder=update_decoder)
     emb0_bits = O.bf16_bits(sc["emb"].float().numpy())
     ef_rows, ef_vals = sparse_rows(O.bf16_bits(emb.detach().float().numpy()), emb0_bits)
@@ -277,7 +279,7 @@ def run_mapping_case(name, n_frames, n_rays, n_iter, seed, update_pose=True, upd
         pose_grad_last=np.stack([f.pose.data.grad.numpy() if f.pose.data.grad is not None else np.zeros(6, np.float32)
                                  for f in frames]),
         n_iter=n_iter, n_rays=n_rays, update_pose=update_pose, update_decoder=update_decoder,
-        step_size=0.5 * VOXEL, lrs=np.array([0.03, 0.005, 0.001]),
+        step_size=step_factor * VOXEL, lrs=np.array(lrs), voxel_size=VOXEL,
     )
     if update_decoder:
         for k, v in decoder_arrays(dec).items():
@@ -386,6 +388,11 @@ CASES = {
     "map_2f_2it_frozen": lambda: run_mapping_case("map_2f_2it_frozen", n_frames=2, n_rays=384, n_iter=2, seed=779,
                                                   update_pose=False, update_decoder=False),
     "track_2it": lambda: run_tracking_case("track_2it", n_rays=512, n_iter=2, seed=780),
+    # mapper settings of the other dataset configs (BASELINE.json configs[2], [3]): coarser voxels / much denser sampling
+    "map_kitti_1f_1it": lambda: run_mapping_case("map_kitti_1f_1it", n_frames=1, n_rays=512, n_iter=1, seed=781, VOXEL=0.3,
+                                                 step_factor=0.5, lrs=(0.01, 0.005, 0.001)),
+    "map_ncd_1f_1it": lambda: run_mapping_case("map_ncd_1f_1it", n_frames=1, n_rays=384, n_iter=1, seed=782, VOXEL=0.2,
+                                               step_factor=0.2, lrs=(0.002, 0.005, 0.001)),
 }
 
 if __name__ == "__main__":

@@ -44,8 +44,12 @@ def test_adam_matches_torch(golden_dir, tag, bf16):
             np.testing.assert_allclose(p, g["p_" + tag][t], rtol=1e-5, atol=1e-8)
 
 
+def _voxel(g):
+    return float(g["voxel_size"]) if "voxel_size" in g.files else H.VOXEL
+
+
 def _scene(g):
-    sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]))
+    sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]), voxel=_voxel(g))
     # raw row numbering of duplicate vertex ids is assignment-order dependent in the reference
     # (SURVEY B7): take the fixture's table, check ours covers the same vertices
     assert np.array_equal(sc["ms"].id2row >= 0, g["id_table"] >= 0)
@@ -75,8 +79,11 @@ def _check_iter(out, g, it, strict_loss=True):
     np.testing.assert_allclose(out["loss"], g[f"it{it}_loss"], rtol=2e-5 if ok.all() else 2e-3)
 
 
-def test_mapping_one_iteration(golden_dir):
-    g = load(golden_dir, "map_1f_1it")
+@pytest.mark.parametrize("case", ["map_1f_1it", "map_kitti_1f_1it", "map_ncd_1f_1it"])
+def test_mapping_one_iteration(golden_dir, case):
+    """maicity mapper settings, and those of the kitti (voxel 0.3 m, step 0.15 m) and ncd (voxel 0.2 m, step 0.04 m: up to 58
+    samples per ray) configs"""
+    g = load(golden_dir, case)
     sc = _scene(g)
     masks = H.unpack_masks(g["masks"], len(sc["points"]))
     dec = O.decoder_init(int(g["seed"]))
