@@ -305,9 +305,11 @@ def run_mapping_case(name, n_frames, n_rays, n_iter, seed, update_pose=True, upd
           f"R={out['it0_sdf'].shape} -> {os.path.getsize(path)/1e3:.0f} kB")
 
 
-def run_tracking_case(name, n_rays, n_iter, seed, frame_index=5, n_beams=64, n_azimuth=48):
+def run_tracking_case(name, n_rays, n_iter, seed, frame_index=5, n_beams=64, n_azimuth=48, VOXEL=VOXEL, step_factor=0.2, lr=0.005):
+    """VOXEL / step_factor / lr: mapper voxel_size and tracker_specs step_size, learning_rate of the dataset configs
+    (maicity 0.2, 0.2, .005; kitti 0.3, 0.2, .06; ncd 0.2, 0.1, .04)"""
     _CAP.clear()
-    sc = build_scene(n_beams, n_azimuth, seed)
+    sc = build_scene(n_beams, n_azimuth, seed, VOXEL)
     rng = np.random.default_rng(seed)
     P4 = pose4(0.05, -0.03, 0.01, rot=(0.002, -0.004, 0.006))
     fr = make_frame(frame_index, sc["points"], sc["cos"], P4)
@@ -327,13 +329,13 @@ def run_tracking_case(name, n_rays, n_iter, seed, frame_index=5, n_beams=64, n_a
                   "voxel_id2embedding_id": sc["id_table"]}
     pose0 = fr.pose.data.detach().numpy().copy()
     crit = CapCriterion(ARGS)
-    new_pose, hit_mask = RH.track_frame(fr.pose, fr, map_states, dec, crit, VOXEL, n_rays, 0.2 * VOXEL, n_iter, 0.30,
-                                        0.005, 20, 50.0, profiler=None, depth_variance=True)
+    new_pose, hit_mask = RH.track_frame(fr.pose, fr, map_states, dec, crit, VOXEL, n_rays, step_factor * VOXEL, n_iter, 0.30,
+                                        lr, 20, 50.0, profiler=None, depth_variance=True)
     out = dict(seed=seed, n_beams=n_beams, n_azimuth=n_azimuth, id_table=sc["id_table"].numpy()[:, 0],
                n_emb_rows=sc["emb"].shape[0], pose0=pose0, masks=np.packbits(np.stack(masks), axis=-1),
                pose_final=new_pose.data.detach().numpy(), pose_grad_last=new_pose.data.grad.numpy(),
-               hit_mask=hit_mask.numpy(), n_iter=n_iter, n_rays=n_rays, step_size=0.2 * VOXEL,
-               lr=0.005 * 2 if frame_index < 2 else 0.005 / 3, frame_index=frame_index)
+               hit_mask=hit_mask.numpy(), n_iter=n_iter, n_rays=n_rays, step_size=step_factor * VOXEL, voxel_size=VOXEL,
+               lr=lr * 2 if frame_index < 2 else lr / 3, frame_index=frame_index)
     for it, r in enumerate(_CAP["render"]):
         out[f"it{it}_sdf"] = r["sdf"]
         out[f"it{it}_z_vals"] = r["z_vals"]
@@ -391,6 +393,8 @@ CASES = {
     # mapper settings of the other dataset configs (BASELINE.json configs[2], [3]): coarser voxels / much denser sampling
     "map_kitti_1f_1it": lambda: run_mapping_case("map_kitti_1f_1it", n_frames=1, n_rays=512, n_iter=1, seed=781, VOXEL=0.3,
                                                  step_factor=0.5, lrs=(0.01, 0.005, 0.001)),
+    "track_kitti_2it": lambda: run_tracking_case("track_kitti_2it", n_rays=384, n_iter=2, seed=783, VOXEL=0.3, step_factor=0.2, lr=0.06),
+    "track_ncd_2it": lambda: run_tracking_case("track_ncd_2it", n_rays=256, n_iter=2, seed=784, VOXEL=0.2, step_factor=0.1, lr=0.04),
     "map_ncd_1f_1it": lambda: run_mapping_case("map_ncd_1f_1it", n_frames=1, n_rays=384, n_iter=1, seed=782, VOXEL=0.2,
                                                step_factor=0.2, lrs=(0.002, 0.005, 0.001)),
 }

@@ -17,6 +17,7 @@ BACKWARD_MODES = [0, 1] + ([2] if os.environ.get("NL_TEST_GEMM_MODE2") else [])
 # goldens with the mapper settings of the kitti / ncd configs, generated after the round's GPU time was spent (the oracle matches
 # them on CPU, tests/test_oracle_golden.py): their GPU cases run with NL_TEST_EXTRA_GOLDENS=1 until they have been verified once
 EXTRA_GOLDENS = ["map_kitti_1f_1it", "map_ncd_1f_1it"] if os.environ.get("NL_TEST_EXTRA_GOLDENS") else []
+EXTRA_TRACK_GOLDENS = ["track_kitti_2it", "track_ncd_2it"] if os.environ.get("NL_TEST_EXTRA_GOLDENS") else []
 
 
 @pytest.fixture(scope="module")
@@ -275,9 +276,11 @@ def test_mapping_three_steps_track_oracle(nl, golden_dir):
     np.testing.assert_allclose(pose[:3], g["poses_final"][0][:3], rtol=0, atol=5e-3)     # reference golden
 
 
-def test_tracking_matches_oracle_and_golden(nl, golden_dir):
-    g = np.load(os.path.join(golden_dir, "track_2it.npz"))
-    sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]))
+@pytest.mark.parametrize("case", ["track_2it"] + EXTRA_TRACK_GOLDENS)
+def test_tracking_matches_oracle_and_golden(nl, golden_dir, case):
+    g = np.load(os.path.join(golden_dir, case + ".npz"))
+    sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]),
+                              voxel=float(g["voxel_size"]) if "voxel_size" in g.files else H.VOXEL)
     sc["ms"].id2row = g["id_table"].copy()
     masks = H.unpack_masks(g["masks"], len(sc["points"]))
     dec_np = O.decoder_init(int(g["seed"]))

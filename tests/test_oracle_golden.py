@@ -148,8 +148,10 @@ def test_mapping_two_frames_frozen(golden_dir):
     np.testing.assert_allclose(np.stack([s["pose"] for s in scans]), g["poses_final"], rtol=0, atol=0)
 
 
-def test_tracking_two_iterations(golden_dir):
-    g = load(golden_dir, "track_2it")
+@pytest.mark.parametrize("case", ["track_2it", "track_kitti_2it", "track_ncd_2it"])
+def test_tracking_two_iterations(golden_dir, case):
+    """tracker settings of the maicity, kitti (voxel 0.3 m, step 0.06 m, lr 0.06) and ncd (step 0.02 m, lr 0.04) configs"""
+    g = load(golden_dir, case)
     sc = _scene(g)
     masks = H.unpack_masks(g["masks"], len(sc["points"]))
     dec = O.decoder_init(int(g["seed"]))
