@@ -80,7 +80,11 @@ def _set_rays(eng, frames, N_rays, track=False):
 
 def _usable(eng):
     st = eng.stats()                                      # one small D2H read: the reference syncs far more often
-    return st["R"] > 0 and st["P"] > 0 and not st["guard"] and not st["overflow"], st
+    if st["overflow"]:                                    # not the reference's "returns None" case: fail loudly, do not skip silently
+        raise L.NerfLoamHipError(f"sample buffers too small: the iteration produced more than {eng.P_cap} valid samples "
+                                 f"({eng.P_cap // max(eng.N_cap, 1)} per ray on average are provided for); step_size is too fine for "
+                                 "nerf_loam_amd.render_helpers._engine's samples_per_ray_cap")
+    return st["R"] > 0 and st["P"] > 0 and not st["guard"], st
 
 
 def bundle_adjust_frames(keyframe_graph, embeddings, map_states, sdf_network, loss_criteria, voxel_size, step_size,
