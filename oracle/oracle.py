@@ -301,7 +301,8 @@ def ray_sample(idx, t0, t1, step_size, noise=None, tail_mode=0):
     """voxel_helpers.py:571-598 (ray_sample) + :262-347 (InverseCDFRaySampling.forward).
 
     idx/t0/t1: [R,P] for the HIT rays only.  noise: None -> 0.5 (the wrapper's deterministic
-    mode) or an [R, >=max_steps] array indexed by (hit-ray rank, step).
+    mode), an [R, >=max_steps] array indexed by (hit-ray rank, step), or a callable n_steps -> [R, n_steps]
+    (so a full scan does not have to materialise thousands of unused columns).
     tail_mode 0 = reference behaviour (position-dependent tail loop, SURVEY B5);
     tail_mode 1 = "fixed" extension: the tail loop always runs and tests the ray's own next hit.
     Returns (sampled_idx, sampled_depth, sampled_dists) [R,S] or None (the reference's guard)."""
@@ -333,7 +334,7 @@ def ray_sample(idx, t0, t1, step_size, noise=None, tail_mode=0):
     if noise is None:
         nz = np.full((Htot, max_steps), 0.5, f32)
     else:
-        nz = pad(_c(noise, f32)[:, :max_steps])
+        nz = pad(_c(noise(max_steps) if callable(noise) else noise, f32)[:, :max_steps])
         assert nz.shape[1] == max_steps, "noise must cover max_steps columns"
     s_idx = -np.ones((Htot, max_steps), np.int32)
     s_dep = np.zeros((Htot, max_steps), f32)
@@ -478,8 +479,12 @@ def decoder_init(seed, in_dim=16, width=256):
 
 
 def _mm(a, b):
+    """fp32 GEMM on the torch-CPU BLAS threads; transposed VIEWS go in as they are (no 1 GB transpose copies on a full scan)"""
     import torch
-    return (torch.from_numpy(np.ascontiguousarray(a)) @ torch.from_numpy(np.ascontiguousarray(b))).numpy()
+
+    def t(x):
+        return torch.from_numpy(x if all(st > 0 for st in x.strides) else np.ascontiguousarray(x))
+    return (t(a) @ t(b)).numpy()
 
 
 def decoder_forward(x, dp):
@@ -614,10 +619,16 @@ class IterCfg:
 
 
 def render_and_grad(ms: MapState, dec: DecoderParams, frames, cfg: IterCfg,
-                    want_emb_grad=True, want_dec_grad=True, ray_id_base=0, emb_accumulate="fp32"):
+                    want_emb_grad=True, want_dec_grad=True, ray_id_base=0, emb_accumulate="fp32", eval_rays=None):
     """One forward+backward of the reference iteration (render_helpers.py:356-423 minus the
     optimiser): returns a dict with every intermediate the parity tests compare, or None when the
-    reference would skip the iteration."""
+    reference would skip the iteration.
+
+    eval_rays (checker shortcut, not reference behaviour): boolean mask over ALL rays.  Geometry (hits, samples, loss
+    masks and normalisers) is still computed for the whole ray set - the sampler's tail loop depends on a ray's position
+    in the batch, SURVEY B5 - but the field / decoder are evaluated only on the samples of the marked rays.  Per-sample
+    outputs of those rays (sdf, dsdf, feats, dfeat, dxyz) are exactly those of the full run; the loss value and the
+    parameter gradients are sums over the marked rays only and are returned as None / partial."""
     o_l, d_l, Rs = [], [], []
     for fr in frames:
         R = rodrigues(fr.pose[3:])
@@ -638,7 +649,7 @@ def render_and_grad(ms: MapState, dec: DecoderParams, frames, cfg: IterCfg,
     R_hit = len(hr)
     noise = None
     if cfg.noise_seed is not None:
-        noise = hash_noise(cfg.noise_seed, hr + ray_id_base, 4096)
+        noise = lambda n_steps: hash_noise(cfg.noise_seed, hr + ray_id_base, n_steps)    # noqa: E731
     smp = ray_sample(idx[hr], t0[hr], t1[hr], cfg.step_size, noise=noise, tail_mode=cfg.tail_mode)
     if smp is None:
         return None
@@ -648,7 +659,7 @@ def render_and_grad(ms: MapState, dec: DecoderParams, frames, cfg: IterCfg,
         return None
     S = s_idx.shape[1]
     o_h, d_h = rays_o[hr], rays_d[hr]
-    rr, ss = np.nonzero(mask)
+    rr, ss = np.nonzero(mask if eval_rays is None else mask & np.asarray(eval_rays, bool)[hr][:, None])
     depth = s_dep[rr, ss]
     xyz = (o_h[rr] + d_h[rr] * depth[:, None]).astype(f32)
     vox = s_idx[rr, ss].astype(np.int64)
@@ -678,7 +689,7 @@ def render_and_grad(ms: MapState, dec: DecoderParams, frames, cfg: IterCfg,
                 s_idx=s_idx, z_vals=s_dep, s_dists=s_dst, valid=mask, sdf=sdf, loss=loss, dsdf=dsdf,
                 stats=stats, feats=feats, xyz=xyz, vox=vox, dfeat=dfeat, dxyz=dxyz,
                 grad_emb=gE, grad_dec=gdec, grad_pose=pose_grads, n_samples=int(mask.sum()),
-                sample_ray=hr[rr], sample_slot=ss)
+                sample_ray=hr[rr], sample_slot=ss, partial=eval_rays is not None)
 
 
 @dataclass

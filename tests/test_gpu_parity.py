@@ -13,11 +13,10 @@ import helpers as H
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
-BACKWARD_MODES = [0, 1] + ([2] if os.environ.get("NL_TEST_GEMM_MODE2") else [])
-# goldens with the mapper settings of the kitti / ncd configs, generated after the round's GPU time was spent (the oracle matches
-# them on CPU, tests/test_oracle_golden.py): their GPU cases run with NL_TEST_EXTRA_GOLDENS=1 until they have been verified once
-EXTRA_GOLDENS = ["map_kitti_1f_1it", "map_ncd_1f_1it"] if os.environ.get("NL_TEST_EXTRA_GOLDENS") else []
-EXTRA_TRACK_GOLDENS = ["track_kitti_2it", "track_ncd_2it"] if os.environ.get("NL_TEST_EXTRA_GOLDENS") else []
+BACKWARD_MODES = [0, 1, 2]          # 0: fp32 MFMA GEMMs, 1: exact bf16 splits (default), 2: six-product forward (opt-in, not exact)
+# goldens with the mapper / tracker settings of the kitti (voxel 0.3 m) and ncd (step 0.04 m, up to 58 samples per ray) configs
+EXTRA_GOLDENS = ["map_kitti_1f_1it", "map_ncd_1f_1it"]
+EXTRA_TRACK_GOLDENS = ["track_kitti_2it", "track_ncd_2it"]
 
 
 @pytest.fixture(scope="module")
@@ -173,6 +172,9 @@ def compare_iteration(eng, m, dec, out, cfgP, train_decoder, sdf_tol=1e-4):
     return r
 
 
+POSE_GRAD_RTOL = 2e-3
+
+
 def nl_split(flat):
     from nerf_loam_amd.pipeline import DecoderDevice
     return DecoderDevice.split(flat)
@@ -215,7 +217,11 @@ def test_iteration_matches_oracle_and_golden(nl, golden_dir, case, backward_mode
     ok = ~_tie_rays(out)
     assert np.array_equal(r["valid_mask"][ok], g["it0_valid"][ok])
     assert np.abs(r["sdf"] - g["it0_sdf"])[ok].max() < 1e-4
-    # embedding gradient (bf16 of the fp32 accumulators) and pose gradient
+    compare_emb_and_pose_grads(nl, eng, m, dec, out, cfgP, nf, train)
+
+
+def compare_emb_and_pose_grads(nl, eng, m, dec, out, cfgP, nf, train):
+    """embedding gradient (bf16 of the fp32 accumulators) and pose gradient against the oracle"""
     gbf = torch.empty(m.n_rows, 16, dtype=torch.int16, device="cuda")
     nl["ops"].embedding_grad_bf16(eng.g_emb, gbf)
     got = O.bf16_to_f32(gbf.cpu().numpy().view(np.uint16)); ref = O.bf16_to_f32(out["grad_emb"])
@@ -225,7 +231,7 @@ def test_iteration_matches_oracle_and_golden(nl, golden_dir, case, backward_mode
     eng.optimiser_step(m, dec, cfgP, update_decoder=train, update_pose=False)           # computes grad6, no pose update
     g6 = eng.pose_grad6[:nf].cpu().numpy()
     for f in range(nf):
-        np.testing.assert_allclose(g6[f], out["grad_pose"][f], rtol=2e-3, atol=1e-6 + 1e-4 * np.abs(out["grad_pose"][f]).max())
+        np.testing.assert_allclose(g6[f], out["grad_pose"][f], rtol=POSE_GRAD_RTOL, atol=1e-6 + 1e-4 * np.abs(out["grad_pose"][f]).max())
 
 
 def _tie_rays(out):
@@ -310,8 +316,47 @@ def test_tracking_matches_oracle_and_golden(nl, golden_dir, case):
 
 
 # ------------------------------------------------------------------------------------------------
-# full-size properties (131072 rays): size-independent invariants, no oracle at this scale
+# full size (BASELINE's headline workload: the 64 x 2048 = 131 072-ray scan)
 # ------------------------------------------------------------------------------------------------
+def full_scan_scene():
+    from nerf_loam_amd import synthetic as S
+    pts, cos = S.synthetic_scan()
+    pose = S.scan_pose()
+    oc = O.Octree(); oc.init(256 * 256 * 4, 16, 0.2)
+    oc.insert(S.voxel_coords(pts, np.eye(3, dtype=np.float32), pose[:3], 0.2))
+    v, c, f = oc.get_centres_and_children()
+    centres, structure = O.grid_features(v, c, 0.2)
+    id2row = -np.ones(len(centres), np.int32)
+    E = O.assign_embedding_rows(f, id2row, 0)
+    ms = O.MapState(centres, structure, f, id2row, O.bf16_bits(H.init_embeddings(E, 1)), 0.2)
+    return dict(points=pts, cos=cos, pose=pose, ms=ms)
+
+
+def test_full_scan_matches_the_oracle(nl):
+    """one whole mapping iteration on all 131 072 rays of the synthetic scan against the oracle run on the same inputs:
+    hit lists, sample layout and depths bit for bit (C restatement of the two CUDA kernels at full size, incl. the
+    position-dependent sampler tail in the reference's [200, L, P] batch layout), sdf / loss / dsdf / dX / decoder, embedding
+    and pose gradients to the tolerances of the small cases"""
+    from nerf_loam_amd import synthetic as S
+    sc = full_scan_scene()
+    dec_np = O.decoder_init(1)
+    fr = O.Frame(S.unit_dirs(sc["points"]), sc["points"], sc["cos"], sc["pose"].copy())
+    cfgO = O.IterCfg()
+    out = O.render_and_grad(sc["ms"], dec_np, [fr], cfgO)
+    P = nl["P"]
+    ms = sc["ms"]
+    m = P.MapDevice(ms.centres, ms.structure, ms.vertex_idx, ms.id2row, ms.emb, ms.voxel_size)
+    dec = P.DecoderDevice(dec_np.W1, dec_np.b1, dec_np.W2, dec_np.b2, dec_np.W3, dec_np.b3)
+    eng = P.SdfEngine(max_rays=len(fr.rays_d), samples_per_ray_cap=48)
+    load_frames(eng, [fr])
+    cfgP = P.IterConfig()
+    eng.begin_call(m, dec)
+    eng.forward_backward(m, dec, cfgP, train_decoder=True)
+    assert out["n_samples"] > 1_000_000
+    compare_iteration(eng, m, dec, out, cfgP, True)
+    compare_emb_and_pose_grads(nl, eng, m, dec, out, cfgP, 1, True)
+
+
 def test_full_scan_invariants(nl):
     from nerf_loam_amd import synthetic as S
     from nerf_loam_amd.svo import Octree
