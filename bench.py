@@ -110,27 +110,207 @@ def build_workload(device, seed=777):
                           dec=(W1, b1, W2, b2, W3, b3)))
 
 
-def cpu_baseline(w, n_rays=8192, seed=1):
-    """Oracle port (oracle/oracle.py + nl_oracle.c) of the same iteration on a bounded ray sample."""
+def cpu_baseline(w, n_rays=32768, warm=2, reps=5, n_rays_1t=8192, reps_1t=3, seed=1):
+    """The SAME iteration on this box's host cores with the oracle port (oracle/oracle.py + nl_oracle.c: numpy / C, the GEMMs on
+    the torch-CPU BLAS threads) - kind "port": the reference checkout does not exist on the GPU box; the reference's own Python
+    path timed on CPU in the build container is recorded in BASELINE.md.  Bounded sample of the same 64x2048 scan (a strided
+    subset keeps the beam mix), full mapping iteration incl. Adam, `warm` untimed + `reps` timed, median; all cores and one."""
     from oracle import oracle as O
     h = w["host"]
-    ms = O.MapState(h["centres"], h["structure"], h["vertex_idx"], h["id2row"], h["emb_bits"].copy(), 0.2)
-    dec = O.DecoderParams(*[np.asarray(a, np.float32) for a in h["dec"]])
-    rng = np.random.default_rng(seed)
-    sel = np.sort(rng.choice(len(w["points"]), n_rays, replace=False))
-    fr = O.Frame(w["dirs"][sel], w["points"][sel], w["cos"][sel], w["pose"].copy())
-    st = O.AdamState()
-    cfg = O.IterCfg()
-    out = O.render_and_grad(ms, dec, [fr], cfg)                      # warm-up (library load, BLAS threads)
+    N = len(w["points"])
+
+    def run(n, n_warm, n_rep):
+        ms = O.MapState(h["centres"], h["structure"], h["vertex_idx"], h["id2row"], h["emb_bits"].copy(), 0.2)
+        dec = O.DecoderParams(*[np.asarray(a, np.float32) for a in h["dec"]])
+        sel = np.arange(0, N, max(1, N // n))[:n]
+        fr = O.Frame(w["dirs"][sel], w["points"][sel], w["cos"][sel], w["pose"].copy())
+        st = O.AdamState()
+        cfg = O.IterCfg()
+        ts = []
+        for k in range(n_warm + n_rep):
+            t0 = time.perf_counter()
+            out = O.render_and_grad(ms, dec, [fr], cfg)
+            O.optimiser_step(ms, dec, [fr], out, st, [0.03, 0.005, 0.001])
+            if k >= n_warm:
+                ts.append(time.perf_counter() - t0)
+        return len(sel), float(np.median(ts))
+
+    cores = int(torch.get_num_threads())
+    n_all, t_all = run(n_rays, warm, reps)
+    torch.set_num_threads(1)
+    try:
+        n_1, t_1 = run(n_rays_1t, 1, reps_1t)
+    finally:
+        torch.set_num_threads(cores)
+    return dict(value=n_all / t_all, unit="rays/s", cores=cores, kind="port",
+                sample=f"{n_all} rays (every {max(1, N // n_rays)}th return of the same 64x2048 scan), 1 mapping iteration incl. Adam, "
+                       f"{warm} warm-up + {reps} timed, median {t_all * 1e3:.0f} ms/iter; numpy/C oracle port, GEMMs on {cores} torch-CPU threads "
+                       "(the numpy / C stages are single-threaded)",
+                single_thread=dict(value=n_1 / t_1, unit="rays/s", cores=1,
+                                   sample=f"{n_1} rays, 1 warm-up + {reps_1t} timed, median {t_1 * 1e3:.0f} ms/iter, torch.set_num_threads(1)"))
+
+
+def parity_check(eng, w, cfg, train_dec, every=8):
+    """parity on the same inputs in the same run.  One more forward+backward of the timed engine (current, i.e.
+    Adam-updated, embeddings / decoder / pose) against the oracle on ALL 131 072 rays for the geometry (hit lists, sample
+    layout, depths: bit for bit, C restatement of the two CUDA kernels) and on every `every`-th ray's samples for the field /
+    decoder outputs (sdf, dL/dsdf, dL/dX).  Bars: the tests' (tests/test_gpu_parity.py compare_iteration)."""
+    from oracle import oracle as O
+    h = w["host"]
+    m, dec = w["map"], w["dec"]
+    N = eng.N
+    eng.forward_backward(m, dec, cfg, train_decoder=train_dec)
+    torch.cuda.synchronize()
+    st = eng.stats()
+    P_ = st["P"]
+    emb_bits = m.emb.cpu().numpy().view(np.uint16).copy()
+    dn = dec.numpy()
+    pose = eng.pose6[0].cpu().numpy().copy()
+    got = dict(hit_count=eng.hit_count[:N].cpu().numpy(), hit_idx=eng.hit_idx[:N].cpu().numpy(), hit_t0=eng.hit_t0[:N].cpu().numpy(),
+               hit_t1=eng.hit_t1[:N].cpu().numpy(), samp_off=eng.samp_off[:N].cpu().numpy(), samp_count=eng.samp_count[:N].cpu().numpy(),
+               vox=eng.s_vox[:P_].cpu().numpy(), depth=eng.s_depth[:P_].cpu().numpy(), sdf=eng.sdf[:P_].cpu().numpy(),
+               dsdf=eng.dsdf[:P_].cpu().numpy(), X=eng.X[:P_].cpu().numpy(), dX=eng.dX[:P_].cpu().numpy())
+    if eng.g_emb is not None:
+        eng.g_emb.zero_()
+    eng.g_pose.zero_()
     t0 = time.perf_counter()
-    reps = 2
-    for _ in range(reps):
-        out = O.render_and_grad(ms, dec, [fr], cfg)
-        O.optimiser_step(ms, dec, [fr], out, st, [0.03, 0.005, 0.001])
-    dt = (time.perf_counter() - t0) / reps
-    return dict(value=n_rays / dt, unit="rays/s", cores=int(torch.get_num_threads()), kind="port",
-                sample=f"{n_rays} rays of the same 64x2048 scan, 1 mapping iteration incl. Adam, mean of {reps} "
-                       f"({dt * 1e3:.0f} ms/iter; numpy/C oracle, GEMMs on torch-CPU threads)")
+    ms = O.MapState(h["centres"], h["structure"], h["vertex_idx"], h["id2row"], emb_bits, 0.2)
+    dp = O.DecoderParams(dn["W1"], dn["b1"], dn["W2"], dn["b2"], dn["W3"], dn["b3"])
+    fr = O.Frame(w["dirs"], w["points"], w["cos"], pose)
+    sub = np.zeros(N, bool); sub[::every] = True
+    out = O.render_and_grad(ms, dp, [fr], O.IterCfg(step_size=cfg.step_size, noise_seed=cfg.noise_seed), want_emb_grad=False,
+                            want_dec_grad=False, eval_rays=sub)
+    H_ = out["hit_idx"].shape[1]
+    live = np.arange(H_)[None, :] < got["hit_count"][:, None]
+    md = np.float32(cfg.max_distance)
+    hits_equal = bool(np.array_equal(got["hit_count"] > 0, out["hits"]) and st["H"] == H_
+                      and np.array_equal(np.where(live, got["hit_idx"][:, :H_], -1), out["hit_idx"])
+                      and np.array_equal(np.where(live, got["hit_t0"][:, :H_], md), out["hit_t0"])
+                      and np.array_equal(np.where(live, got["hit_t1"][:, :H_], md), out["hit_t1"]))
+    hr = np.nonzero(out["hits"])[0]
+    rr, ss = np.nonzero(out["valid"])
+    samples_equal = bool(P_ == out["n_samples"] and st["S"] == out["valid"].shape[1]
+                         and np.array_equal(got["samp_count"][hr], out["valid"].sum(1))
+                         and np.array_equal(got["depth"], out["z_vals"][rr, ss]) and np.array_equal(got["vox"], out["s_idx"][rr, ss]))
+    res = dict(rays=int(N), hits_equal=hits_equal, samples_equal=samples_equal, valid_samples=int(P_), subset_rays=int(sub.sum()))
+    if samples_equal:
+        idx = got["samp_off"][out["sample_ray"]] + out["sample_slot"]            # engine sample index of the subset's samples
+        ref_sdf = out["sdf"][np.searchsorted(hr, out["sample_ray"]), out["sample_slot"]]
+        ref_ds = out["dsdf"][np.searchsorted(hr, out["sample_ray"]), out["sample_slot"]]
+        dxe, dxr = got["dX"][idx].astype(np.float64), out["dfeat"].astype(np.float64)
+        res.update(subset_samples=int(len(idx)),
+                   sdf_max_abs_err=float(np.abs(got["sdf"][idx] - ref_sdf).max()), sdf_mean_abs_err=float(np.abs(got["sdf"][idx] - ref_sdf).mean()),
+                   X_max_abs_err=float(np.abs(got["X"][idx] - out["feats"]).max()),
+                   dsdf_max_err_rel_to_max=float(np.abs(got["dsdf"][idx] - ref_ds).max() / max(np.abs(ref_ds).max(), 1e-30)),
+                   dX_rel_l2=float(np.linalg.norm(dxe - dxr) / max(np.linalg.norm(dxr), 1e-30)))
+        res["ok"] = bool(hits_equal and res["sdf_max_abs_err"] < 1e-4 and res["dsdf_max_err_rel_to_max"] < 1e-3 and res["dX_rel_l2"] < 1e-3)
+    else:
+        res["ok"] = False
+    res["bars"] = {"hits/samples": "bit-exact", "sdf_max_abs_err": 1e-4, "dsdf_max_err_rel_to_max": 1e-3, "dX_rel_l2": 1e-3}
+    res["oracle_seconds"] = round(time.perf_counter() - t0, 2)
+    return res
+
+
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured float4 copy)
+
+
+def stage_rooflines(eng, w, cfg, train_dec, steps=5):
+    """HIP-event times of every stage of the iteration (a separate short pass after the headline loop, all stage timers on)
+    and the bandwidth-bound kernels' achieved GB/s on their ALGORITHMIC bytes (unavoidable traffic: every input read once,
+    every output written once; DESIGN.md section 7 lists the per-unit figures)."""
+    names = ["intersect", "sample", "gather", "decoder", "wgrad2", "reduce", "scatter", "optim"]
+    ev = [{n: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for n in names} for _ in range(steps)]
+    for k in range(steps):
+        eng.timers = ev[k]
+        eng.forward_backward(w["map"], w["dec"], cfg, train_decoder=train_dec)
+        eng.optimiser_step(w["map"], w["dec"], cfg, update_decoder=train_dec)
+    torch.cuda.synchronize()
+    eng.timers = None
+    ms = {n: float(np.mean([e[n][0].elapsed_time(e[n][1]) for e in ev])) for n in names if train_dec or n not in ("wgrad2", "reduce")}
+    st = eng.stats()
+    N, P_, E = eng.N, st["P"], w["n_rows"]
+    nhits = int(eng.hit_count[:N].sum().item())
+    touched = int((eng.emb_m != 0).any(1).sum().item())                    # embedding rows the call has touched (they carry moments)
+    by = {
+        "intersect": N * (28 + 20) + nhits * 12,                            # dir, gt point, cos in; world dir, gt dist, count + hit list out
+        "sample": 2 * (nhits * 12 + N * 16) + P_ * 16 + N * 8,              # both passes read the hit lists; (voxel, depth, dist, ray) out
+        "gather": P_ * (12 + 32 + 256 + 64),                                # sample record, 8 row ids, 8 bf16 rows, X out
+        "scatter": P_ * (12 + 64 + 32 + 256) + touched * 64 * 2,            # + dX in; every touched accumulator row read-modify-written once
+        "optim": touched * 16 * 20 + (E - touched) * 16 * 8 + (70401 * 28 + 1835008 if train_dec else 0),
+        "reduce": (eng.n_slabs + 1) * 70401 * 4,
+    }
+    out = []
+    for n, b in by.items():
+        if n in ms:
+            gbs = b / (ms[n] * 1e-3) / 1e9
+            out.append({"stage": n, "algorithmic_bytes_per_launch": int(b), "avg_ms": ms[n], "achieved": gbs, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
+    return ms, by, out
+
+
+def api_path_bench(w, device, iters=20):
+    """The path users call: bundle_adjust_frames / track_frame of nerf_loam_amd.render_helpers at the reference's live
+    shapes (configs/maicity/maicity.yaml:18-41, src/mapping.py:172-202): steady-state mapping 2048 rays x 1 frame, post-processing
+    BA 4096 rays x 4 key-scans, tracking 2048 rays; `iters` iterations per call, ms per iteration of the whole call (ray
+    selection, kernels, the call's set-up and its one read-back included), next to the bare engine loop on the same shapes."""
+    from argparse import Namespace
+    from nerf_loam_amd import pipeline as P, render_helpers as RH
+    from nerf_loam_amd.criterion import Criterion
+    from nerf_loam_amd.decoder import Decoder
+    from nerf_loam_amd.lidar_frame import LidarFrame
+    args = Namespace(criteria=dict(sdf_weight=10000.0, fs_weight=1, eiko_weight=0.1, sdf_truncation=0.30), data_specs=dict(max_depth=50.0))
+    crit = Criterion(args)
+    dec_mod = Decoder().to(device)
+    dec_mod.load_flat(w["dec"].params.clone())
+    m = w["map"]
+    emb = m.emb.view(torch.bfloat16)
+    table = torch.from_numpy(w["host"]["id2row"]).to(device)
+    map_states = {"voxel_vertex_idx": torch.from_numpy(w["host"]["vertex_idx"]).to(device), "voxel_center_xyz": m.centres,
+                  "voxel_structure": m.structure, "voxel_vertex_emb": emb, "voxel_id2embedding_id": table}
+    pts, cos = torch.from_numpy(w["points"]), torch.from_numpy(w["cos"])
+    frames = []
+    for i in range(4):
+        P4 = np.eye(4); P4[:3, 3] = [0.25 * i, -0.1 * i, 0.0]
+        frames.append(LidarFrame(i + 1, pts, cos, P4))
+    out = {"iterations_per_call": iters, "ray_selection": RH.RAY_SELECTION}
+
+    def timed(fn, reps=3):
+        fn(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) / iters * 1e3
+
+    kw = dict(truncation=0.3, max_voxel_hit=20, max_distance=50.0)
+    out["bundle_adjust_2048x1_ms_per_iter"] = timed(lambda: RH.bundle_adjust_frames(
+        frames[:1], emb, map_states, dec_mod, crit, 0.2, 0.1, 2048, iters, learning_rate=[0.03, 0.005, 0.001], update_pose=True,
+        update_decoder=True, **kw))
+    out["bundle_adjust_4096x4_frozen_decoder_ms_per_iter"] = timed(lambda: RH.bundle_adjust_frames(
+        frames, emb, map_states, dec_mod, crit, 0.2, 0.1, 4096, iters, learning_rate=[0.03, 0.005, 0.001], update_pose=False,
+        update_decoder=False, **kw))
+    out["track_frame_2048_ms_per_iter"] = timed(lambda: RH.track_frame(
+        frames[1].pose, frames[1], map_states, dec_mod, crit, 0.2, 2048, 0.04, iters, learning_rate=0.005, **kw))
+
+    # the bare engine on the same shapes (resident rays, no selection): what the API path is measured against
+    def engine_loop(n_rays, n_frames, step, train, emb_grad, pose_grad):
+        eng = P.SdfEngine(max_rays=n_rays * n_frames, samples_per_ray_cap=96, max_frames=max(2, n_frames), device=device)
+        rng = np.random.default_rng(5)
+        sel = np.concatenate([np.sort(rng.choice(len(w["points"]), n_rays, replace=False)) for _ in range(n_frames)])
+        fid = np.repeat(np.arange(n_frames, dtype=np.int32), n_rays)
+        eng.set_rays(w["dirs"][sel], w["points"][sel], w["cos"][sel], fid)
+        eng.set_poses(np.stack([fr.pose.data.detach().numpy() for fr in frames[:n_frames]]), [1] * n_frames)
+        cfg = P.IterConfig(step_size=step)
+        eng.begin_call(m, w["dec"])
+
+        def loop():
+            for _ in range(iters):
+                eng.forward_backward(m, w["dec"], cfg, train_decoder=train, want_emb_grad=emb_grad, want_pose_grad=pose_grad)
+                eng.optimiser_step(m, w["dec"], cfg, update_emb=emb_grad, update_decoder=train, update_pose=pose_grad)
+        return timed(loop)
+    out["engine_2048x1_ms_per_iter"] = engine_loop(2048, 1, 0.1, True, True, True)
+    out["engine_4096x4_frozen_decoder_ms_per_iter"] = engine_loop(4096, 4, 0.1, False, True, False)
+    out["engine_track_2048_ms_per_iter"] = engine_loop(2048, 1, 0.04, False, False, True)
+    return out
 
 
 def pose_refine_bench(w, device, steps=200):
@@ -196,6 +376,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle parity check")
+    ap.add_argument("--no-api-path", action="store_true", help="skip the bundle_adjust_frames / track_frame timings")
     ap.add_argument("--frozen-decoder", action="store_true", help="mapping with update_decoder=False (after freeze_frame)")
     args = ap.parse_args()
 
@@ -243,11 +425,11 @@ def main():
         step()
     barrier()
     # per-kernel events for the roofline object (same stream as the launches)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev = [{n: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for n in ("decoder", "wgrad2")}
           for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        eng.timers = {"decoder": (ev[k][0], ev[k][1]), "wgrad2": (ev[k][1], ev[k][2])}
+        eng.timers = ev[k]
         step()
     barrier()
     dt = time.perf_counter() - t0
@@ -258,14 +440,18 @@ def main():
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         dt = float(t.item())
     st = eng.stats()
-    dec_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev]))
-    wg_ms = float(np.mean([b.elapsed_time(c) for _, b, c in ev])) if train_dec else 0.0
+    if st["overflow"] or st["guard"]:                    # a truncated sample set would overstate the throughput
+        raise SystemExit(f"bench invalid: sample overflow={st['overflow']} guard={st['guard']}")
+    dec_ms = float(np.mean([e["decoder"][0].elapsed_time(e["decoder"][1]) for e in ev]))
+    wg_ms = float(np.mean([e["wgrad2"][0].elapsed_time(e["wgrad2"][1]) for e in ev])) if train_dec else 0.0
     P_local = st["P"]
+    stage_ms, stage_bytes, hbm_entries = stage_rooflines(eng, w, cfg, train_dec) if world == 1 else ({}, {}, [])
     if rank == 0:
         gm, wm = _lib.lib().nl_decoder_get_gemm_mode(), _lib.lib().nl_decoder_get_wgrad2_mode()
         rf = roofline_entry("k_decoder<train>" if train_dec else "k_decoder<frozen>", "decoder", dec_ms, P_local, gm, wm, train_dec)
         rf = {"bound": "mfma", **rf,
               "traffic": pmc_traffic(("k_decoder<true, %s>" if train_dec else "k_decoder<false, %s>") % ("true" if gm >= 1 else "false")) if gm != 2 else None,
+              "traffic_source": "committed rocprofv3 PMC passes of this command (newest profiles/r*_pmc_summary.json), not measured in this run",
               "peak_note": ("matrix-pipe bound of the kernel's instruction mix: "
                             + (f"256-deep GEMMs as {'exact-product ' if gm == 1 else ''}bf16 splits ({9 if gm == 1 else 6} + 3 MFMAs per fp32 product, 2500 TF pipe), "
                                "K=16 layers on the fp32 pipe (157.3 TF)" if gm >= 1 else "all GEMMs on the fp32 pipe (157.3 TF)")),
@@ -288,7 +474,19 @@ def main():
             "roofline": rf,
         }
         if world == 1:
+            # bandwidth-bound stages + the whole iteration against the sum of its per-kernel bounds
+            rf["hbm"] = hbm_entries
+            bounds = {"decoder": rf["matrix_pipe_bound_ms"], **{e["stage"]: e["algorithmic_bytes_per_launch"] / (HBM_PEAK_GBS * 1e9) * 1e3 for e in hbm_entries}}
+            if train_dec:
+                bounds["wgrad2"] = rf["second_kernel"]["matrix_pipe_bound_ms"]
+            rf["end_to_end"] = {"sum_of_bounds_ms": float(sum(bounds.values())), "ms_per_step": dt / args.steps * 1e3,
+                                "frac": float(sum(bounds.values())) / (dt / args.steps * 1e3), "bounds_ms": bounds, "stage_ms": stage_ms,
+                                "note": "decoder kernels: matrix-pipe bound of their instruction mix; every other stage: algorithmic bytes / 8 TB/s"}
+            if not args.no_parity:
+                out["parity"] = parity_check(eng, w, cfg, train_dec)
             out["pose_refine"] = pose_refine_bench(w, device)
+            if not args.no_api_path:
+                out["api_path"] = api_path_bench(w, device)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))

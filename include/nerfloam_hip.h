@@ -98,11 +98,13 @@ int nl_select_rays(int M, int n_select, unsigned seed, const float* rays_d, cons
  * emit = 0: per-ray sample count, S_max and the geometry-only loss normalisers (criterion.py:67-88);
  * emit = 1: compacted (voxel, depth, dist, ray) records at samp_off[ray] (capacity-checked).
  * noise: counter-based hash(seed, ray_id_base + ray, step) clamped to [.001,.999], or 0.5 if !use_hash_noise
- * (the reference draws torch uniform_ noise, voxel_helpers.py:297-301). */
+ * (the reference draws torch uniform_ noise EVERY iteration, voxel_helpers.py:297-301).  seed_mix (optional, NULL = off):
+ * device word - e.g. the optimiser's step counter, word 0 of adam_state - folded into the seed as
+ * seed + 0x9E3779B9 * *seed_mix, so a hipGraph-replayed or host-loop iteration draws fresh jitter without host work. */
 int nl_sample_rays(int emit, int N, const int* hit_idx, const float* hit_t0, const float* hit_t1, const int* hit_count,
                    const int* hit_rank, const int* ray_of_rank, const float* cos_gt, const float* gt_dist,
                    float step_size, float tau, float max_depth, unsigned seed, int use_hash_noise, int tail_always, int ray_id_base,
-                   int* counters, int* samp_count, const int* samp_off, int capacity,
+                   const unsigned* seed_mix, int* counters, int* samp_count, const int* samp_off, int capacity,
                    int* s_vox, float* s_depth, float* s_dist, int* s_ray, void* stream);
 
 /* global loss normalisers from the counter block (criterion.py:84-88 weights, :65 mean divisor R*S) */
@@ -156,12 +158,13 @@ int nl_decoder_set_gemm_mode(int mode);
 int nl_decoder_get_gemm_mode(void);
 
 /* backward of get_features: embedding gradient (fp32 accumulation of bf16-rounded contributions, the
- * CUDA embedding_dense_backward semantics) and pose-gradient partials g_pose[F,12] = (dL/dt, dL/dR).
+ * CUDA embedding_dense_backward semantics) and pose-gradient partials g_pose[F,12] = (dL/dt, dL/dR), accumulated in fp64
+ * (the per-sample terms cancel heavily: fp64 makes the sums independent of the summation order).
  * g_emb / g_pose may be NULL to skip either. */
 int nl_trilinear_bwd(const void* loss_scalars, const int* s_vox, const float* s_depth, const int* s_ray,
                      const float* rays_d_world, const float* rays_d_sensor, const int* frame_id, const float* poses, int n_frames,
                      const float* centres, const int* vertex_rows, const void* emb_bf16, float voxel_size,
-                     const float* dX, float* g_emb, float* g_pose, int nblocks, void* stream);
+                     const float* dX, float* g_emb, double* g_pose, int nblocks, void* stream);
 
 /* masked_scatter_ones (render_helpers.py:30-36,301): packed samples -> padded [R,S] tensors */
 int nl_unpack_samples(const void* loss_scalars, const int* s_ray, const int* samp_off, const int* hit_rank,
@@ -180,17 +183,22 @@ int nl_adam_f32(float* p, const float* g, float* m, float* v, int n, const int* 
 /* se3pose.py:18-35: pose6[F,6] = (t, w) -> poses12[F,12] */
 int nl_pose_matrices(const float* pose6, float* poses12, int F, void* stream);
 /* Rodrigues tail of the pose gradient + Adam on the 6-vectors (enable[f] != 0) + refreshed matrices */
-int nl_pose_step(float* pose6, float* g_pose, float* m, float* v, const int* enable, float* grad6_out, float* poses12,
+int nl_pose_step(float* pose6, double* g_pose, float* m, float* v, const int* enable, float* grad6_out, float* poses12,
                  int F, const int* state, int apply, void* stream);
 
 /* The whole optim.step() of one iteration as one launch (plus a one-thread counter advance unless only poses step):
  * nl_adam_prepare + nl_adam_embeddings + nl_adam_f32(decoder) + nl_decoder_transpose_w2 + nl_pose_step, bit for bit.  A group is skipped when its first pointer is NULL
- * (emb_bf16 / dec_params / pose6); dec_ws is the decoder workspace of NL_DEC_WS_FLOATS floats (W2^T + operand planes). */
+ * (emb_bf16 / dec_params / pose6); dec_ws is the decoder workspace of NL_DEC_WS_FLOATS floats (W2^T + operand planes).
+ * skip_mode != 0 (needs the iteration's counter block): the step decides ON THE DEVICE whether the iteration was usable, like the
+ * reference's `if final_outputs == None` (render_helpers.py:407-410 mapping: carry on; :486-489 tracking: stop) - unusable = no
+ * hit ray, the sampler guard, or a sample-buffer overflow.  An unusable iteration's step clears the gradient accumulators and
+ * changes nothing else; state[2] counts such steps, state[3] latches the overflow flag (the host checks both once per call).
+ * 1 = skip that step only, 2 = sticky (every step after a skipped one is skipped too). */
 int nl_optimiser_step(int* state, double lr_emb, double lr_dec, double lr_pose,
                       void* emb_bf16, float* g_emb, void* emb_m_bf16, void* emb_v_bf16, long long n_emb,
                       float* dec_params, const float* dec_grad, float* dec_m, float* dec_v, float* dec_ws,
-                      float* pose6, float* g_pose, float* pose_m, float* pose_v, const int* pose_enable, float* grad6_out,
-                      float* poses12, int F, int apply_pose, void* stream);
+                      float* pose6, double* g_pose, float* pose_m, float* pose_v, const int* pose_enable, float* grad6_out,
+                      float* poses12, int F, int apply_pose, const int* counters, int skip_mode, void* stream);
 
 /* ---- (b2) host octree behind torch.classes.svo.Octree (third_party/sparse_octree/src/bindings.cpp:4-31) */
 void* nl_octree_create(long long grid_dim);                              /* Octree::init   octree.cpp:36-50   */

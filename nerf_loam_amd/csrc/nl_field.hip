@@ -27,7 +27,7 @@ struct FieldArgs {
     float* X;                       // [P,16] out (forward)
     const float* dX;                // [P,16] in (backward)
     float* g_emb;                   // [E,16] fp32 accumulators (backward, atomics)
-    float* g_pose;                  // [F,12] (dt[3], dR[9]) fp32 accumulators (backward)
+    double* g_pose;                 // [F,12] (dt[3], dR[9]) fp64 accumulators (backward)
     int n_frames;
     int want_emb_grad;
     int want_pose_grad;
@@ -153,11 +153,11 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
 {
     __shared__ __attribute__((aligned(16))) float s_val_all[TB_WAVES * TB_SLOTS * NL_C];
     __shared__ int s_key_all[TB_WAVES * TB_SLOTS];
-    __shared__ float s_pose[NL_MAX_FRAMES * 12];
+    __shared__ double s_pose[NL_MAX_FRAMES * 12];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* s_val = s_val_all + wv * TB_SLOTS * NL_C;            // this wave's table
     int* s_key = s_key_all + wv * TB_SLOTS;
-    for (int i = threadIdx.x; i < a.n_frames * 12; i += NL_FIELD_THREADS) s_pose[i] = 0.f;
+    for (int i = threadIdx.x; i < a.n_frames * 12; i += NL_FIELD_THREADS) s_pose[i] = 0.0;
     for (int i = lane; i < TB_SLOTS; i += 64) s_key[i] = -1;
     for (int i = lane; i < TB_SLOTS * NL_C; i += 64) s_val[i] = 0.f;
     FSTAMP(0);
@@ -174,9 +174,25 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
     if (per_group * TB_GROUPS < TB_MIN_SPAN) per_group = TB_MIN_SPAN / TB_GROUPS;
     const int span = per_group * TB_GROUPS;
     const int nchunks = (P + span - 1) / span;
-    float pa[12]; int pf = -1;                                  // running pose partials (corner-0 lane) of the current frame
+    // pose partials (corner-0 lane).  The sums cancel heavily (rays in all directions), so they are carried in fp64: fp32 over
+    // the few samples of one ray (ra: sum dx, sum depth * dx), folded at every ray change into the workgroup's fp64 accumulators
+    // in LDS (ds_add_f64) and from there to memory (global_atomic_add_f64) - the result is independent of the summation order
+    // to ~1e-13, i.e. reproducible run to run after the optimiser's rounding to fp32.
+    int pf = -1, pr = -1;
+    float ra[6], rds[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 12; ++i) pa[i] = 0.f;
+    for (int i = 0; i < 6; ++i) ra[i] = 0.f;
+    auto fold_ray = [&]() {
+        if (pf < 0) return;
+        double* sp = s_pose + 12 * pf;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            atomicAdd(sp + i, (double)ra[i]);
+            const double t = (double)ra[3 + i];
+            atomicAdd(sp + 3 + 3 * i, t * (double)rds[0]); atomicAdd(sp + 4 + 3 * i, t * (double)rds[1]); atomicAdd(sp + 5 + 3 * i, t * (double)rds[2]);
+            ra[i] = 0.f; ra[3 + i] = 0.f;
+        }
+    };
     for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const int s_end = min(P, (chunk + 1) * span);
         int cur_vox = -1, row = -1;
@@ -266,20 +282,17 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
             for (int i = 0; i < 8; ++i) dot[i] = __shfl(dotk, lane0 + i);
             if (k != 0) continue;
             float dp[3]; nl_trilinear_dp(g.p, dot, dp);
-            const int f = a.frame_id ? a.frame_id[g.ray] : 0;
-            if (f != pf) {
-                if (pf >= 0) { for (int i = 0; i < 12; ++i) atomicAdd(s_pose + 12 * pf + i, pa[i]); }
-#pragma unroll
-                for (int i = 0; i < 12; ++i) pa[i] = 0.f;
-                pf = f;
+            if (g.ray != pr) {
+                fold_ray();
+                pr = g.ray;
+                rds[0] = a.rays_d_sensor[3 * g.ray]; rds[1] = a.rays_d_sensor[3 * g.ray + 1]; rds[2] = a.rays_d_sensor[3 * g.ray + 2];
+                pf = a.frame_id ? a.frame_id[g.ray] : 0;
             }
-            const float ds0 = a.rays_d_sensor[3 * g.ray], ds1 = a.rays_d_sensor[3 * g.ray + 1], ds2 = a.rays_d_sensor[3 * g.ray + 2];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const float dx = dp[i] / a.voxel_size;
-                pa[i] += dx;
-                const float t = g.depth * dx;
-                pa[3 + 3 * i] += t * ds0; pa[4 + 3 * i] += t * ds1; pa[5 + 3 * i] += t * ds2;
+                ra[i] += dx;
+                ra[3 + i] += g.depth * dx;
             }
         }
         FSTAMP(2);
@@ -302,10 +315,10 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
         }
     }
     if (a.want_pose_grad) {
-        if (pf >= 0) { for (int i = 0; i < 12; ++i) atomicAdd(s_pose + 12 * pf + i, pa[i]); }
+        fold_ray();
         __syncthreads();
         for (int i = threadIdx.x; i < a.n_frames * 12; i += NL_FIELD_THREADS)
-            if (s_pose[i] != 0.f) atomicAdd(a.g_pose + i, s_pose[i]);
+            if (s_pose[i] != 0.0) atomicAdd(a.g_pose + i, s_pose[i]);
     }
 }
 
@@ -373,7 +386,7 @@ int nl_field_set_debug_buffer(void* dbg) { g_field_dbg = (long long*)dbg; return
 int nl_trilinear_bwd(const void* loss_scalars, const int* s_vox, const float* s_depth, const int* s_ray,
                      const float* rays_d_world, const float* rays_d_sensor, const int* frame_id, const float* poses, int n_frames,
                      const float* centres, const int* vertex_rows, const void* emb, float voxel_size,
-                     const float* dX, float* g_emb, float* g_pose, int nblocks, void* stream)
+                     const float* dX, float* g_emb, double* g_pose, int nblocks, void* stream)
 {
     FieldArgs a;
     int rc = fill_args(a, loss_scalars, s_vox, s_depth, s_ray, rays_d_world, rays_d_sensor, frame_id, poses, n_frames, centres, vertex_rows, emb, voxel_size);

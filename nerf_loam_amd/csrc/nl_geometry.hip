@@ -573,6 +573,7 @@ struct SampleArgs {
     const float* cos_gt; const float* gt_dist;
     float step_size; float tau; float max_depth;
     unsigned seed; int use_hash_noise; int tail_always; int ray_id_base;
+    const unsigned* seed_mix;   // optional device word (the optimiser's step counter) folded into the seed: fresh jitter per iteration
     int* counters; double* dcounters;
     int* samp_count;            // [N]  (0 for rays without hits)
     const int* samp_off;        // [N]  exclusive scan of samp_count (emit pass)
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample_par(SampleArgs a)
         if (tot > 10.0f * NL_FILL_DEPTH) guard = 1;
         const float c = a.cos_gt[r], d = a.gt_dist[r];
         const unsigned rid = (unsigned)(r + a.ray_id_base);
-        const unsigned seed = a.seed;
+        const unsigned seed = a.seed_mix ? a.seed + 0x9E3779B9u * (*a.seed_mix) : a.seed;
         const bool hash = a.use_hash_noise != 0;
         auto noise = [&](int step) -> float { return hash ? nl_noise(seed, rid, (unsigned)step) : 0.5f; };
         const int off = EMIT ? a.samp_off[r] : 0;
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample(SampleArgs a)
         SSTAMP(2);
         const float c = a.cos_gt[r], d = a.gt_dist[r];
         const unsigned rid = (unsigned)(r + a.ray_id_base);
-        const unsigned seed = a.seed;
+        const unsigned seed = a.seed_mix ? a.seed + 0x9E3779B9u * (*a.seed_mix) : a.seed;
         const bool hash = a.use_hash_noise != 0;
         auto noise = [&](int step) -> float { return hash ? nl_noise(seed, rid, (unsigned)step) : 0.5f; };
         if (!guard) {
@@ -1023,7 +1024,7 @@ int nl_compact_hit_rays(int N, const int* hit_count, const int* hit_rank, int* r
 int nl_sample_rays(int emit, int N, const int* hit_idx, const float* hit_t0, const float* hit_t1, const int* hit_count,
                    const int* hit_rank, const int* ray_of_rank, const float* cos_gt, const float* gt_dist,
                    float step_size, float tau, float max_depth, unsigned seed, int use_hash_noise, int tail_always, int ray_id_base,
-                   int* counters, int* samp_count, const int* samp_off, int capacity,
+                   const unsigned* seed_mix, int* counters, int* samp_count, const int* samp_off, int capacity,
                    int* s_vox, float* s_depth, float* s_dist, int* s_ray, void* stream)
 {
     if (N <= 0 || !hit_idx || !hit_t0 || !hit_t1 || !hit_count || !hit_rank || !ray_of_rank || !cos_gt || !gt_dist || !counters || !samp_count)
@@ -1033,6 +1034,7 @@ int nl_sample_rays(int emit, int N, const int* hit_idx, const float* hit_t0, con
     a.N = N; a.hit_idx = hit_idx; a.hit_t0 = hit_t0; a.hit_t1 = hit_t1; a.hit_count = hit_count; a.hit_rank = hit_rank;
     a.ray_of_rank = ray_of_rank; a.cos_gt = cos_gt; a.gt_dist = gt_dist; a.step_size = step_size; a.tau = tau; a.max_depth = max_depth;
     a.seed = seed; a.use_hash_noise = use_hash_noise; a.tail_always = tail_always; a.ray_id_base = ray_id_base;
+    a.seed_mix = seed_mix;
     a.counters = counters; a.dcounters = (double*)(counters + NL_CNT_INTS);
     a.samp_count = samp_count; a.samp_off = samp_off; a.capacity = capacity;
     a.s_vox = s_vox; a.s_depth = s_depth; a.s_dist = s_dist; a.s_ray = s_ray;

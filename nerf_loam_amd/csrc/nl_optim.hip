@@ -100,14 +100,15 @@ __global__ void k_pose_matrix(const float* __restrict__ pose6, float* __restrict
 
 // pose gradient tail + Adam: g_pose[f] = (dL/dt[3], dL/dR[9]) -> dL/d(t,w) -> Adam (if enabled) ->
 // refreshed pose matrices.  grad6_out (optional) receives the 6-vector gradient; g_pose is cleared.
-__device__ __forceinline__ void pose_step_one(int f, float* __restrict__ pose6, float* __restrict__ g_pose, float* __restrict__ m,
+__device__ __forceinline__ void pose_step_one(int f, float* __restrict__ pose6, double* __restrict__ g_pose, float* __restrict__ m,
                                               float* __restrict__ v, const int* __restrict__ enable, float* __restrict__ grad6_out,
                                               float* __restrict__ poses12, const NlAdamHyper& h, int apply)
 {
-    float g6[6], gw[3];
-    nl_rodrigues_bwd(pose6 + 6 * f + 3, g_pose + 12 * f + 3, gw);
-    for (int i = 0; i < 3; ++i) { g6[i] = g_pose[12 * f + i]; g6[3 + i] = gw[i]; }
-    for (int i = 0; i < 12; ++i) g_pose[12 * f + i] = 0.f;
+    float g6[6], gw[3], G[9];
+    for (int i = 0; i < 9; ++i) G[i] = (float)g_pose[12 * f + 3 + i];          // fp64 sums (nl_field.hip), one rounding to fp32 here
+    nl_rodrigues_bwd(pose6 + 6 * f + 3, G, gw);
+    for (int i = 0; i < 3; ++i) { g6[i] = (float)g_pose[12 * f + i]; g6[3 + i] = gw[i]; }
+    for (int i = 0; i < 12; ++i) g_pose[12 * f + i] = 0.0;
     if (grad6_out) for (int i = 0; i < 6; ++i) grad6_out[6 * f + i] = g6[i];
     if (apply && (!enable || enable[f])) {
         for (int i = 0; i < 6; ++i) nl_adam_f32(&pose6[6 * f + i], g6[i], &m[6 * f + i], &v[6 * f + i], h);
@@ -118,7 +119,7 @@ __device__ __forceinline__ void pose_step_one(int f, float* __restrict__ pose6, 
     for (int i = 0; i < 3; ++i) poses12[12 * f + 9 + i] = pose6[6 * f + i];
 }
 
-__global__ void k_pose_step(float* __restrict__ pose6, float* __restrict__ g_pose, float* __restrict__ m, float* __restrict__ v,
+__global__ void k_pose_step(float* __restrict__ pose6, double* __restrict__ g_pose, float* __restrict__ m, float* __restrict__ v,
                             const int* __restrict__ enable, float* __restrict__ grad6_out, float* __restrict__ poses12,
                             int F, const NlAdamHyper* __restrict__ hp, int apply)
 {
@@ -137,8 +138,28 @@ struct OptimArgs {
     int* state; double lr_emb, lr_dec, lr_pose;
     uint16_t* emb; float* g_emb; uint16_t* emb_m; uint16_t* emb_v; long long n_emb; int nb_emb;
     float* params; const float* grad; float* dm; float* dv; float* W2T; uint16_t* W2X; uint16_t* W2TX; int nb_dec;
-    float* pose6; float* g_pose; float* pm; float* pv; const int* enable; float* grad6_out; float* poses12; int F; int apply_pose;
+    float* pose6; double* g_pose; float* pm; float* pv; const int* enable; float* grad6_out; float* poses12; int F; int apply_pose;
+    const int* counters; int skip_mode;
 };
+
+// "The iteration was unusable" decided ON THE DEVICE, so that the host loop needs no per-iteration read-back.  The reference skips
+// the optimiser step when render_rays returns None (no ray hit a voxel: render_helpers.py:216-217; the sampler's guard
+// :232-233) - mapping carries on with the next iteration (:407-410), tracking stops (:486-489).  Here: no hit ray anywhere
+// (R_GLOBAL == 0), the guard flag, or a sample-buffer overflow (reported to the host at the end of the call, which raises).
+// skip_mode 1 = skip this step only, 2 = sticky: once one step was skipped every later one is (tracking's `break`).
+// A skipped step clears the gradient accumulators, touches no parameter or moment and does not advance the step counter;
+// state[2] counts skipped steps, state[3] latches the overflow flag.
+__device__ __forceinline__ bool optim_skip(const int* __restrict__ counters, const int* __restrict__ state, int skip_mode)
+{
+    if (!counters || skip_mode == 0) return false;
+    if (counters[NLC_R_GLOBAL] == 0 || counters[NLC_GUARD] != 0 || counters[NLC_OVERFLOW] != 0) return true;
+    return skip_mode == 2 && reinterpret_cast<volatile const int*>(state)[2] > 0;
+}
+__device__ __forceinline__ void optim_note_skip(const int* __restrict__ counters, int* __restrict__ state)
+{
+    state[2] = state[2] + 1;
+    if (counters[NLC_OVERFLOW] != 0) state[3] = 1;
+}
 #define OPT_DEC_REST (NL_DEC_PARAMS - NL_W * NL_W - NL_W)            // W1, b1, b2, b3 (w3 rides with the W2 rows)
 #define OPT_DEC_BLOCKS (NL_W + (OPT_DEC_REST + 255) / 256)
 
@@ -148,6 +169,17 @@ __global__ void __launch_bounds__(256) k_optim_step(OptimArgs a)
     const int step = *reinterpret_cast<volatile const int*>(a.state) + 1;       // read once, before anybody can advance it
     const int b = blockIdx.x, tid = threadIdx.x;
     const int role = b < a.nb_emb ? 0 : (b < a.nb_emb + a.nb_dec ? 1 : 2);
+    if (optim_skip(a.counters, a.state, a.skip_mode)) {             // uniform over the launch: every thread reads the same words
+        if (role == 0) {
+            for (long long i = (long long)b * 256 + tid; i < a.n_emb; i += (long long)a.nb_emb * 256)
+                if (a.g_emb[i] != 0.0f) a.g_emb[i] = 0.0f;
+        } else if (role == 2) {
+            const int f = (b - a.nb_emb - a.nb_dec) * 256 + tid;
+            if (f < a.F) for (int i = 0; i < 12; ++i) a.g_pose[12 * f + i] = 0.0;
+        }
+        if (gridDim.x == 1) { __syncthreads(); if (tid == 0) optim_note_skip(a.counters, a.state); }
+        return;
+    }
     if (tid == 0) s_h = nl_adam_hyper(role == 0 ? a.lr_emb : (role == 1 ? a.lr_dec : a.lr_pose), step, 0.9, 0.999, 1e-8);
     __syncthreads();
     const NlAdamHyper h = s_h;
@@ -202,7 +234,11 @@ __global__ void __launch_bounds__(256) k_optim_step(OptimArgs a)
 
 // advance the step counter after a multi-workgroup k_optim_step (a last-workgroup ticket costs more than this launch: thousands
 // of same-address device-scope atomics, profiles/r01_m_optimiser_step.txt)
-__global__ void k_adam_advance(int* __restrict__ state) { state[0] = state[0] + 1; }
+__global__ void k_adam_advance(int* __restrict__ state, const int* __restrict__ counters, int skip_mode)
+{
+    if (optim_skip(counters, state, skip_mode)) optim_note_skip(counters, state);
+    else state[0] = state[0] + 1;
+}
 
 // Multi-GPU (nerf_loam_amd/dist.py): every rank all-gathers its whole counter block (one small collective) and this kernel
 // folds the gathered blocks into the local one - instead of one collective per quantity and a dozen tiny torch kernels.
@@ -305,7 +341,7 @@ int nl_pose_matrices(const float* pose6, float* poses12, int F, void* stream)
     return NL_OK;
 }
 
-int nl_pose_step(float* pose6, float* g_pose, float* m, float* v, const int* enable, float* grad6_out, float* poses12,
+int nl_pose_step(float* pose6, double* g_pose, float* m, float* v, const int* enable, float* grad6_out, float* poses12,
                  int F, const int* state, int apply, void* stream)
 {
     if (!pose6 || !g_pose || !m || !v || !poses12 || F <= 0 || !state) return NL_ERR_INVALID_ARG;
@@ -318,10 +354,10 @@ int nl_pose_step(float* pose6, float* g_pose, float* m, float* v, const int* ena
 int nl_optimiser_step(int* state, double lr_emb, double lr_dec, double lr_pose,
                       void* emb, float* g_emb, void* emb_m, void* emb_v, long long n_emb,
                       float* dec_params, const float* dec_grad, float* dec_m, float* dec_v, float* dec_ws,
-                      float* pose6, float* g_pose, float* pose_m, float* pose_v, const int* pose_enable, float* grad6_out,
-                      float* poses12, int F, int apply_pose, void* stream)
+                      float* pose6, double* g_pose, float* pose_m, float* pose_v, const int* pose_enable, float* grad6_out,
+                      float* poses12, int F, int apply_pose, const int* counters, int skip_mode, void* stream)
 {
-    if (!state) return NL_ERR_INVALID_ARG;
+    if (!state || skip_mode < 0 || skip_mode > 2 || (skip_mode && !counters)) return NL_ERR_INVALID_ARG;
     if (emb && (!g_emb || !emb_m || !emb_v || n_emb <= 0)) return NL_ERR_INVALID_ARG;
     if (dec_params && (!dec_grad || !dec_m || !dec_v || !dec_ws)) return NL_ERR_INVALID_ARG;
     if (pose6 && (!g_pose || !pose_m || !pose_v || !poses12 || F <= 0)) return NL_ERR_INVALID_ARG;
@@ -336,10 +372,11 @@ int nl_optimiser_step(int* state, double lr_emb, double lr_dec, double lr_pose,
     a.nb_dec = dec_params ? OPT_DEC_BLOCKS : 0;
     a.pose6 = pose6; a.g_pose = g_pose; a.pm = pose_m; a.pv = pose_v; a.enable = pose_enable; a.grad6_out = grad6_out;
     a.poses12 = poses12; a.F = pose6 ? F : 0; a.apply_pose = apply_pose;
+    a.counters = counters; a.skip_mode = skip_mode;
     const int nb_pose = pose6 ? nl_div_up(F, 256) : 0;
     const int nb = a.nb_emb + a.nb_dec + nb_pose;
     hipLaunchKernelGGL(k_optim_step, dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
-    if (nb > 1) hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+    if (nb > 1) hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, state, counters, skip_mode);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

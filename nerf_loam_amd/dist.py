@@ -9,16 +9,17 @@ The reference has no distributed code.  Rays are independent up to 
   2. after counting  : all-reduce SUM of the loss normalisers (front / sdf mask counts, the
                        padded-slot constants) and MAX of S = max samples per ray
                        (criterion.py:84-88 weights and the R*S mean divisor are global quantities).
-  3. after backward  : all-reduce SUM of one flat fp32 buffer [decoder grads | pose partials |
-                       embedding-gradient accumulators]; every rank then applies the identical
-                       optimiser step to its replica.
+  3. after backward  : all-reduce SUM of one flat fp32 buffer [decoder grads | embedding-gradient
+                       accumulators] and of the fp64 pose partials [F,12]; every rank then applies the
+                       identical optimiser step to its replica.
 
 One process per GPU, torch.distributed backend "nccl" (= RCCL on ROCm); on CPU test rigs "gloo".
 Exchanges 1 and 2 are latency-bound, so each is ONE collective: every rank all-gathers its whole 96-byte counter block
 and a one-block kernel (nl_dist_merge_counters) folds the gathered blocks into the local one (sums, max, rank offset) -
 not one collective per quantity plus a dozen tiny torch kernels.  Exchange 3 all-reduces the gradients IN PLACE: the
-decoder gradient, the pose partials and the embedding accumulators are re-homed once into one flat buffer
-[decoder | pose | embeddings], so there is nothing to pack or unpack (0.28 MB + 64 B per embedding row).
+decoder gradient and the embedding accumulators are re-homed once into one flat buffer [decoder | embeddings], so there is
+nothing to pack or unpack (0.28 MB + 64 B per embedding row); the fp64 pose partials (96 B per frame) go in their own
+collective, issued first so that it runs under the large one.
 Known deviation under sharding: the sampler's tail loop consults the hit list of the first ray
 of its batch row (sample_gpu.cu:231); when that ray lives on another rank the own list is used.
 """
@@ -93,9 +94,9 @@ class RayShardedExchange:
         self._merge(eng.counters, 2)
 
     def _adopt(self, eng, dec):
-        """re-home dec.grad, eng.g_pose, eng.g_emb into ONE flat buffer (views keep shape and contents); redone when the
+        """re-home dec.grad, eng.g_emb into ONE flat buffer (views keep shape and contents); redone when the
         engine reallocated one of them (new map size)"""
-        parts = [dec.grad, eng.g_pose, eng.g_emb]
+        parts = [dec.grad, eng.g_emb]
         f = self._flat
         if f is not None:
             off, ok = 0, True
@@ -111,19 +112,20 @@ class RayShardedExchange:
             v.copy_(p)
             views.append(v)
             off += p.numel()
-        dec.grad, eng.g_pose, eng.g_emb = views
+        dec.grad, eng.g_emb = views
         self._flat = f
 
     # exchange 3
     def after_backward(self, eng, dec, train_decoder, want_emb_grad, want_pose_grad):
-        """ONE in-place collective over the contiguous range of [decoder | pose | embeddings] that covers what was computed
-        (an unused part in between is all zeros: the accumulators are cleared by the optimiser step)"""
-        if not (train_decoder or want_pose_grad or want_emb_grad):
+        """the fp64 pose partials, then ONE in-place collective over the part of [decoder | embeddings] that was computed"""
+        if want_pose_grad:
+            dist.all_reduce(eng.g_pose[:eng.F], op=dist.ReduceOp.SUM, group=self.group)
+        if not (train_decoder or want_emb_grad):
             return
         self._adopt(eng, dec)
-        nd, npz = dec.grad.numel(), eng.g_pose.numel()
-        lo = 0 if train_decoder else (nd if want_pose_grad else nd + npz)
-        hi = self._flat.numel() if want_emb_grad else (nd + npz if want_pose_grad else nd)
+        nd = dec.grad.numel()
+        lo = 0 if train_decoder else nd
+        hi = self._flat.numel() if want_emb_grad else nd
         dist.all_reduce(self._flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
 
     def reduce_loss_sums(self):

@@ -73,7 +73,8 @@ class LidarFrame(nn.Module):
         if sc is None or sc["dirs"].device != torch.device(device):
             sc = dict(dirs=self.rays_d.reshape(-1, 3).float().contiguous().to(device),
                       points=self.points.reshape(-1, 3).float().contiguous().to(device),
-                      cos=self.pointsCos.reshape(-1).float().contiguous().to(device))
+                      cos=self.pointsCos.reshape(-1).float().contiguous().to(device),
+                      mask_u8=torch.zeros(self.num_point, dtype=torch.uint8, device=device))
             self._device_scan = sc
         return sc
 

@@ -61,11 +61,12 @@ def compact_hit_rays(N, hit_count, hit_rank, ray_of_rank):
 
 
 def sample_rays(emit, N, hit_idx, hit_t0, hit_t1, hit_count, hit_rank, ray_of_rank, cos_gt, gt_dist, step_size, tau, max_depth,
-                seed, use_hash_noise, tail_always, ray_id_base, counters, samp_count, samp_off, capacity, s_vox, s_depth, s_dist, s_ray):
+                seed, use_hash_noise, tail_always, ray_id_base, seed_mix, counters, samp_count, samp_off, capacity, s_vox, s_depth, s_dist,
+                s_ray):
     check(L.lib().nl_sample_rays(int(emit), int(N), ptr(hit_idx), ptr(hit_t0), ptr(hit_t1), ptr(hit_count), ptr(hit_rank), ptr(ray_of_rank),
                                  ptr(cos_gt), ptr(gt_dist), float(step_size), float(tau), float(max_depth),
                                  ctypes.c_uint(int(seed) & 0xFFFFFFFF), int(use_hash_noise), int(tail_always), int(ray_id_base),
-                                 ptr(counters), ptr(samp_count), ptr(samp_off), int(capacity), ptr(s_vox), ptr(s_depth), ptr(s_dist),
+                                 ptr(seed_mix), ptr(counters), ptr(samp_count), ptr(samp_off), int(capacity), ptr(s_vox), ptr(s_depth), ptr(s_dist),
                                  ptr(s_ray), stream_ptr()), "nl_sample_rays")
 
 
@@ -142,14 +143,14 @@ def pose_matrices(pose6, poses12):
     check(L.lib().nl_pose_matrices(ptr(pose6), ptr(poses12), pose6.shape[0], stream_ptr()), "nl_pose_matrices")
 
 
-def optimiser_step(state, lr_emb, lr_dec, lr_pose, emb, dec, pose):
+def optimiser_step(state, lr_emb, lr_dec, lr_pose, emb, dec, pose, counters=None, skip_mode=0):
     """one launch for the whole optimiser step; emb = (emb, g_acc, m, v) or None, dec = (params, grad, m, v, workspace) or None,
-    pose = (pose6, g_pose, m, v, enable, grad6_out, poses12, apply) or None"""
+    pose = (pose6, g_pose, m, v, enable, grad6_out, poses12, apply) or None; skip_mode: see include/nerfloam_hip.h"""
     e = [ptr(t) for t in emb] + [emb[0].numel()] if emb else [None] * 4 + [0]
     d = [ptr(t) for t in dec] if dec else [None] * 5
     q = [ptr(t) for t in pose[:7]] + [pose[0].shape[0], int(pose[7])] if pose else [None] * 7 + [0, 0]
-    check(L.lib().nl_optimiser_step(ptr(state), float(lr_emb), float(lr_dec), float(lr_pose), *e, *d, *q, stream_ptr()),
-          "nl_optimiser_step")
+    check(L.lib().nl_optimiser_step(ptr(state), float(lr_emb), float(lr_dec), float(lr_pose), *e, *d, *q, ptr(counters), int(skip_mode),
+                                    stream_ptr()), "nl_optimiser_step")
 
 
 def pose_step(pose6, g_pose, m, v, enable, grad6_out, poses12, state, apply):

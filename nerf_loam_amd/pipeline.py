@@ -138,6 +138,19 @@ class DecoderDevice:
         self.grad = torch.zeros_like(self.params)
         self.refresh()
 
+    @classmethod
+    def from_flat(cls, flat):
+        """from a device tensor holding the parameter block (W1 b1 W2 b2 W3 b3): no host round trip"""
+        self = cls.__new__(cls)
+        assert flat.numel() == L.NL_DEC_PARAMS and flat.is_cuda
+        self.params = flat.detach().to(F32).contiguous().clone()
+        self.W2T = torch.empty(L.NL_DEC_WS_FLOATS, dtype=F32, device=flat.device)
+        self.m = torch.zeros_like(self.params)
+        self.v = torch.zeros_like(self.params)
+        self.grad = torch.zeros_like(self.params)
+        self.refresh()
+        return self
+
     def refresh(self):
         ops.decoder_transpose_w2(self.params, self.W2T)
 
@@ -177,7 +190,7 @@ class SdfEngine:
         self.pose_m = torch.zeros(self.F_cap, 6, dtype=F32, device=d)
         self.pose_v = torch.zeros(self.F_cap, 6, dtype=F32, device=d)
         self.pose_enable = torch.zeros(self.F_cap, dtype=I32, device=d)
-        self.g_pose = torch.zeros(self.F_cap, 12, dtype=F32, device=d)
+        self.g_pose = torch.zeros(self.F_cap, 12, dtype=torch.float64, device=d)     # fp64 accumulators (nl_trilinear_bwd)
         self.pose_grad6 = torch.zeros(self.F_cap, 6, dtype=F32, device=d)
         # per-ray workspace
         self.rays_d_world = torch.empty(N, 3, dtype=F32, device=d)
@@ -219,7 +232,7 @@ class SdfEngine:
         self.hook_after_intersect = None
         self.hook_after_count = None
         self.hook_after_backward = None
-        self.timers = None       # bench: {"decoder": (start, end), "wgrad2": (start==decoder end, end)} torch.cuda.Event pairs
+        self.timers = None       # bench: {stage: (start, end)} torch.cuda.Event pairs, see _mark
 
     # ------------------------------------------------------------------ inputs
     def set_rays(self, rays_d_sensor, points_gt, cos_gt, frame_id=None):
@@ -252,7 +265,9 @@ class SdfEngine:
             need = 264 + 2 * M + (M + 1023) // 1024 + 8
             if getattr(self, "_sel_ws", None) is None or self._sel_ws.numel() < need:
                 self._sel_ws = torch.empty(need, dtype=I32, device=self.dev)
-            mask = torch.empty(M, dtype=torch.uint8, device=self.dev) if want_masks else None
+            mask = sc.get("mask_u8")                        # a caller-owned [M] uint8 buffer receives the boolean sample mask
+            if mask is None and want_masks:
+                mask = torch.empty(M, dtype=torch.uint8, device=self.dev)
             ops.select_rays(M, n, (int(seed) * 1000003 + f) & 0xFFFFFFFF, sc["dirs"], sc["points"], sc["cos"], f,
                             self.rays_d_sensor[total:], self.points_gt[total:], self.cos_gt[total:], self.frame_id[total:],
                             mask, self._sel_ws)
@@ -272,15 +287,20 @@ class SdfEngine:
         self.pose_enable[:self.F].copy_(torch.as_tensor(en))
         ops.pose_matrices(self.pose6[:self.F], self.poses12)
 
-    def begin_call(self, m: MapDevice, dec: DecoderDevice = None):
+    def begin_call(self, m: MapDevice, dec: DecoderDevice = None, emb_state=True):
         """A fresh torch.optim.Adam is created per bundle_adjust_frames / track_frame call
-        (render_helpers.py:353,448): reset optimiser state."""
+        (render_helpers.py:353,448): reset optimiser state.  emb_state=False (tracking, forward-only queries): the call never
+        touches the embedding gradient accumulators / moments, so they are neither allocated nor cleared (160 B per row)."""
         self.adam_state.zero_()
         self.graph = None
         self.pose_m.zero_()
         self.pose_v.zero_()
+        self.g_pose.zero_()                                  # a previous call may have aborted between backward and the optimiser step
+        self.pose_grad6.zero_()
         E = m.n_rows
-        if self.g_emb is None or self.g_emb.shape[0] != E:
+        if not emb_state:
+            pass
+        elif self.g_emb is None or self.g_emb.shape[0] != E:
             self.g_emb = torch.zeros(E, L.NL_C, dtype=F32, device=self.dev)
             self.emb_m = torch.zeros(E, L.NL_C, dtype=torch.int16, device=self.dev)
             self.emb_v = torch.zeros(E, L.NL_C, dtype=torch.int16, device=self.dev)
@@ -293,46 +313,66 @@ class SdfEngine:
 
     # ------------------------------------------------------------------ one iteration
     def forward_backward(self, m: MapDevice, dec: DecoderDevice, cfg: IterConfig, train_decoder=True, want_emb_grad=True,
-                         want_pose_grad=True, ray_id_base=0):
+                         want_pose_grad=True, ray_id_base=0, fresh_noise=False):
+        """fresh_noise: fold the device-side optimiser step counter into the sampler seed, so every iteration of a call draws
+        new jitter like the reference's uniform_() (voxel_helpers.py:298-303) - also under hipGraph replay.  Off = the jitter is a
+        pure function of (cfg.noise_seed, ray, step): what the oracle-parity tests need."""
         N = self.N
         c = self.counters
+        tm = self._mark
         c.zero_()
+        tm("intersect", 0)
         ops.ray_intersect(N, self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self.poses12, m.blk_hdr, m.blk_ids, m.root_side,
                           m.voxel_size, cfg.max_distance, self.rays_d_world, self.gt_dist, self.hit_idx, self.hit_t0, self.hit_t1,
                           self.hit_count, c, self.ray_of_rank)
         # hit-ray ranks + compaction + R (and R_GLOBAL: overwritten by the multi-GPU hook) in one launch (two beyond 4096 rays)
         ops.scan_hit_rays(self.hit_count, self.hit_rank, self.ray_of_rank, N, c[L.NLC_R:L.NLC_R + 1], c[L.NLC_R_GLOBAL:L.NLC_R_GLOBAL + 1],
                           self.scan_ws)
+        tm("intersect", 1)
         if self.hook_after_intersect is not None:
             self.hook_after_intersect(self)                      # fills NLC_R_GLOBAL / NLC_R_OFFSET / global NLC_HMAX
         seed = 0 if cfg.noise_seed is None else cfg.noise_seed
         use_hash = 0 if cfg.noise_seed is None else 1
         args = (N, self.hit_idx, self.hit_t0, self.hit_t1, self.hit_count, self.hit_rank, self.ray_of_rank, self.cos_gt, self.gt_dist,
-                cfg.step_size, cfg.truncation, cfg.max_distance, seed, use_hash, int(cfg.tail_always), ray_id_base, c, self.samp_count)
+                cfg.step_size, cfg.truncation, cfg.max_distance, seed, use_hash, int(cfg.tail_always), ray_id_base,
+                self.adam_state if fresh_noise else None, c, self.samp_count)
+        tm("sample", 0)
         ops.sample_rays(0, *args, None, self.P_cap, None, None, None, None)
         ops.exclusive_scan(self.samp_count, self.samp_off, N, 0, c[L.NLC_P:L.NLC_P + 1], self.scan_ws)
         if self.hook_after_count is not None:
             self.hook_after_count(self)                          # all-reduce of the loss normalisers
         ops.loss_finalize(c, self.loss_scalars, cfg.fs_weight, cfg.sdf_weight, cfg.truncation, cfg.max_distance, self.P_cap)
         ops.sample_rays(1, *args, self.samp_off, self.P_cap, self.s_vox, self.s_depth, self.s_dist, self.s_ray)
+        tm("sample", 1)
+        tm("gather", 0)
         ops.gather_trilinear(self.loss_scalars, self.s_vox, self.s_depth, self.s_ray, self.rays_d_world, self.frame_id, self.poses12,
                              self.F, m.centres, m.vertex_rows, m.emb, m.voxel_size, self.X, self.field_blocks)
-        if self.timers is not None:
-            self.timers["decoder"][0].record()
+        tm("gather", 1)
+        tm("decoder", 0)
         ops.decoder_fwd_bwd(self.loss_scalars, self.X, dec.params, dec.W2T, self.s_ray, self.s_depth, self.cos_gt, self.gt_dist,
                             self.sdf, self.dsdf, self.dX, self.partials, self.relu2_mask, self.n_slabs, int(train_decoder), c)
-        if self.timers is not None:
-            self.timers["decoder"][1].record()
+        tm("decoder", 1)
         if train_decoder:
+            tm("wgrad2", 0)
             ops.decoder_wgrad2(self.loss_scalars, self.X, dec.params, self.dsdf, self.relu2_mask, self.partials, self.n_slabs)
-            if self.timers is not None:
-                self.timers["wgrad2"][1].record()
+            tm("wgrad2", 1)
+            tm("reduce", 0)
             ops.reduce_partials(self.partials, self.n_slabs, L.NL_DEC_PARAMS, dec.grad)
+            tm("reduce", 1)
+        tm("scatter", 0)
         ops.trilinear_bwd(self.loss_scalars, self.s_vox, self.s_depth, self.s_ray, self.rays_d_world, self.rays_d_sensor, self.frame_id,
                           self.poses12, self.F, m.centres, m.vertex_rows, m.emb, m.voxel_size, self.dX,
                           self.g_emb if want_emb_grad else None, self.g_pose if want_pose_grad else None, 2 * self.field_blocks)
+        tm("scatter", 1)
         if self.hook_after_backward is not None:
             self.hook_after_backward(self, dec, train_decoder, want_emb_grad, want_pose_grad)
+
+    def _mark(self, stage, which):
+        """bench / probes: self.timers = {stage: (start, end)} torch.cuda.Event pairs on the launch stream; stages: intersect,
+        sample, gather, decoder, wgrad2, reduce, scatter, optim"""
+        t = self.timers
+        if t is not None and stage in t:
+            t[stage][which].record()
 
     def forward_only(self, m: MapDevice, dec: DecoderDevice, cfg: IterConfig, ray_id_base=0):
         """render_rays without gradients (render_helpers.py:190-318): intersect, sample, gather, decoder forward."""
@@ -347,7 +387,7 @@ class SdfEngine:
         seed = 0 if cfg.noise_seed is None else cfg.noise_seed
         args = (N, self.hit_idx, self.hit_t0, self.hit_t1, self.hit_count, self.hit_rank, self.ray_of_rank, self.cos_gt, self.gt_dist,
                 cfg.step_size, cfg.truncation, cfg.max_distance, seed, 0 if cfg.noise_seed is None else 1, int(cfg.tail_always),
-                ray_id_base, c, self.samp_count)
+                ray_id_base, None, c, self.samp_count)
         ops.sample_rays(0, *args, None, self.P_cap, None, None, None, None)
         ops.exclusive_scan(self.samp_count, self.samp_off, N, 0, c[L.NLC_P:L.NLC_P + 1], self.scan_ws)
         ops.loss_finalize(c, self.loss_scalars, cfg.fs_weight, cfg.sdf_weight, cfg.truncation, cfg.max_distance, self.P_cap)
@@ -359,27 +399,38 @@ class SdfEngine:
         return P
 
     def optimiser_step(self, m: MapDevice, dec: DecoderDevice, cfg: IterConfig, update_emb=True, update_decoder=True, update_pose=True,
-                       lr_pose=None):
-        """optim.step() of render_helpers.py:421-423 / :508-510 on the device-resident parameters."""
+                       lr_pose=None, skip_mode=0):
+        """optim.step() of render_helpers.py:421-423 / :508-510 on the device-resident parameters.  skip_mode 1 / 2: the kernel itself
+        leaves an unusable iteration (no hit ray, sampler guard, sample overflow) without a step - see call_status()."""
+        self._mark("optim", 0)
         ops.optimiser_step(self.adam_state, cfg.lr_emb, cfg.lr_dec, cfg.lr_pose if lr_pose is None else lr_pose,
                            (m.emb, self.g_emb, self.emb_m, self.emb_v) if update_emb else None,
                            (dec.params, dec.grad, dec.m, dec.v, dec.W2T) if update_decoder else None,
                            (self.pose6[:self.F], self.g_pose, self.pose_m, self.pose_v, self.pose_enable, self.pose_grad6, self.poses12,
-                            update_pose))
+                            update_pose), self.counters if skip_mode else None, skip_mode)
+        self._mark("optim", 1)
+
+    def call_status(self):
+        """(steps taken, steps skipped as unusable, overflow seen) since begin_call - ONE small read-back per call instead of one
+        per iteration"""
+        st = self.adam_state[:4].cpu().numpy()
+        return int(st[0]), int(st[2]), bool(st[3])
 
     # ------------------------------------------------------------------ hipGraph
     def capture_iteration(self, m: MapDevice, dec: DecoderDevice, cfg: IterConfig, **flags):
         """Capture forward_backward + optimiser_step into a hipGraph (torch.cuda.CUDAGraph).  Possible because the launch
         sequence is fixed, every data-dependent size lives in device memory and the optimiser step counter is on the
         device.  Ray buffers / poses may be rewritten between replays (set_rays / set_poses write in place)."""
-        fb = {k: flags[k] for k in ("train_decoder", "want_emb_grad", "want_pose_grad", "ray_id_base") if k in flags}
-        op = {k: flags[k] for k in ("update_emb", "update_decoder", "update_pose", "lr_pose") if k in flags}
+        fb = {k: flags[k] for k in ("train_decoder", "want_emb_grad", "want_pose_grad", "ray_id_base", "fresh_noise") if k in flags}
+        op = {k: flags[k] for k in ("update_emb", "update_decoder", "update_pose", "lr_pose", "skip_mode") if k in flags}
         state0 = self.adam_state.clone()
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(side):                       # warm-up outside capture (allocator, lazy module load)
             self.forward_backward(m, dec, cfg, **fb)
-            self.g_emb.zero_(); self.g_pose.zero_()
+            if self.g_emb is not None:
+                self.g_emb.zero_()
+            self.g_pose.zero_()
         torch.cuda.current_stream(self.dev).wait_stream(side)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):

@@ -7,11 +7,15 @@ learning-rate rule (render_helpers.py:449-450).  What differs is everything unde
 into SdfEngine per iteration (a fixed sequence of HIP kernels, device-resident state) instead of
 ~100 torch ops, autograd and a torch.optim.Adam object.
 
-Kept from the reference on purpose: rays are re-drawn every iteration on the host with the
-reference's Gumbel top-k (LidarFrame.sample_rays), so a seeded run selects the same rays.
+The loops run WITHOUT a host synchronisation: the ray subset of every iteration is drawn on the device
+(RAY_SELECTION), the sampler jitter is re-drawn per iteration from the device-side step counter, an
+unusable iteration is recognised and skipped by the optimiser kernel itself, the decoder block stays
+resident between calls, and one small read-back at the end of the call reports what happened.
 Dropped (no observable effect): torch.cuda.empty_cache() calls, the unused autograd.grad pass of
 render_helpers.py:293-297 (B10), decoder .grad accumulation during tracking (B11)."""
+from collections import OrderedDict
 from copy import deepcopy
+import os
 
 import numpy as np
 import torch
@@ -19,11 +23,28 @@ import torch
 from . import _lib as L
 from .pipeline import DecoderDevice, IterConfig, MapDevice, SdfEngine
 
-_ENGINES = {}
+_ENGINES = OrderedDict()
+MAX_CACHED_ENGINES = 4          # (device, ray capacity, frame capacity) -> SdfEngine, least recently used evicted
 
-# "host": rays are re-drawn every iteration with the reference's Gumbel top-k on the CPU generator (a seeded run picks the
-# rays the reference would pick on its CPU path); "device": nl_select_rays - same distribution, no host work, no H2D copies
-RAY_SELECTION = "host"
+# "device" (default): nl_select_rays draws every iteration's ray subset on the GPU from the resident scan - the reference's
+# distribution (a uniformly random N-subset, dataset order kept; lidarFrame.py:55-57), no host RNG, no top-k on the CPU, no H2D
+# copy.  "host": the reference's own Gumbel top-k on the global CPU torch generator (LidarFrame.sample_rays) + upload: a seeded
+# run then picks exactly the rays the reference's CPU path would pick (the sampler jitter comes from a private generator and
+# does not advance the global one).
+RAY_SELECTION = os.environ.get("NL_RAY_SELECTION", "device")
+
+_PRIVATE_GEN = None
+
+
+def _draw_seed():
+    """seeds of the device-side random streams (ray subsets, sampler jitter) come from a PRIVATE generator, itself seeded once
+    from torch's global seed: reproducible under torch.manual_seed, and the global CPU stream the reference's sample_rays
+    consumes is left untouched"""
+    global _PRIVATE_GEN
+    if _PRIVATE_GEN is None:
+        _PRIVATE_GEN = torch.Generator()
+        _PRIVATE_GEN.manual_seed((torch.initial_seed() * 0x9E3779B1 + 0x7F4A7C15) & 0x7FFFFFFFFFFFFFFF)
+    return int(torch.randint(0, 2 ** 31 - 1, (1,), generator=_PRIVATE_GEN).item())
 
 
 def _engine(n_rays, n_frames, device):
@@ -32,6 +53,10 @@ def _engine(n_rays, n_frames, device):
     if eng is None:
         eng = SdfEngine(max_rays=key[1], samples_per_ray_cap=96, max_frames=key[2], device=device)
         _ENGINES[key] = eng
+        while len(_ENGINES) > MAX_CACHED_ENGINES:
+            _ENGINES.popitem(last=False)
+    else:
+        _ENGINES.move_to_end(key)
     return eng
 
 
@@ -45,17 +70,34 @@ def _map_device(map_states, voxel_size, device):
     return md
 
 
+def _decoder_version(sdf_network):
+    return tuple((p.data_ptr(), p._version) for p in sdf_network.param_list())
+
+
 def _decoder_device(sdf_network, device):
-    p = sdf_network.flat_params(device).cpu().numpy()
-    return DecoderDevice(p[L.OFF_W1:L.OFF_B1], p[L.OFF_B1:L.OFF_W2], p[L.OFF_W2:L.OFF_B2], p[L.OFF_B2:L.OFF_W3],
-                         p[L.OFF_W3:L.OFF_B3], p[L.OFF_B3:], device=device)
+    """device-resident parameter block + operand planes of the decoder module, kept between calls: rebuilt only when somebody
+    else wrote the module's parameters (tensor version counters) - no per-call D2H / H2D round trip"""
+    cached = getattr(sdf_network, "_nl_device", None)
+    ver = _decoder_version(sdf_network)
+    if cached is not None and cached[0] == ver and cached[1].params.device == torch.device(device):
+        return cached[1]
+    p = sdf_network.flat_params(device)
+    dec = DecoderDevice.from_flat(p)
+    sdf_network._nl_device = (ver, dec)
+    return dec
+
+
+def _decoder_writeback(sdf_network, dec):
+    with torch.no_grad():
+        sdf_network.load_flat(dec.params)
+    sdf_network._nl_device = (_decoder_version(sdf_network), dec)
 
 
 def _cfg(loss_criteria, voxel_size, step_size, max_distance, lrs=(0.0, 0.0, 0.0)):
     return IterConfig(voxel_size=float(voxel_size), step_size=float(step_size), max_distance=float(max_distance),
                       truncation=float(loss_criteria.truncation), sdf_weight=float(loss_criteria.sdf_weight),
                       fs_weight=float(loss_criteria.fs_weight), lr_emb=lrs[0], lr_dec=lrs[1], lr_pose=lrs[2],
-                      noise_seed=int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
+                      noise_seed=_draw_seed())
 
 
 def _gather_rays(frames, N_rays, track=False):
@@ -68,23 +110,27 @@ def _gather_rays(frames, N_rays, track=False):
     return torch.cat(d).float(), torch.cat(p).float(), torch.cat(c).float(), torch.cat(f)
 
 
-def _set_rays(eng, frames, N_rays, track=False):
+def _set_rays(eng, frames, N_rays, seed, track=False):
     if RAY_SELECTION == "device":
-        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-        masks = eng.select_rays([fr.device_scan(eng.dev) for fr in frames], N_rays, seed, want_masks=True)
-        for fr, mk in zip(frames, masks):
-            fr.sample_mask = mk.bool().reshape(-1, 1)
+        scans = [fr.device_scan(eng.dev) for fr in frames]
+        eng.select_rays(scans, N_rays, seed)
+        for fr, sc in zip(frames, scans):                 # the reference's boolean sample_mask attribute: a view of the buffer the
+            fr.sample_mask = sc["mask_u8"].view(torch.bool).view(-1, 1)     # selection kernel wrote (no extra launch, no copy)
     else:
         eng.set_rays(*_gather_rays(frames, N_rays, track=track))
 
 
-def _usable(eng):
-    st = eng.stats()                                      # one small D2H read: the reference syncs far more often
-    if st["overflow"]:                                    # not the reference's "returns None" case: fail loudly, do not skip silently
-        raise L.NerfLoamHipError(f"sample buffers too small: the iteration produced more than {eng.P_cap} valid samples "
+def _finish_call(eng, what):
+    """the ONE host read-back of a call (the iterations themselves never synchronise): how many optimiser steps the device
+    skipped as unusable, and whether a sample buffer overflowed - not the reference's "returns None" case: fail loudly"""
+    steps, skipped, overflow = eng.call_status()
+    if overflow:
+        raise L.NerfLoamHipError(f"sample buffers too small: an iteration produced more than {eng.P_cap} valid samples "
                                  f"({eng.P_cap // max(eng.N_cap, 1)} per ray on average are provided for); step_size is too fine for "
                                  "nerf_loam_amd.render_helpers._engine's samples_per_ray_cap")
-    return st["R"] > 0 and st["P"] > 0 and not st["guard"], st
+    for _ in range(skipped if what == "Mapping" else min(skipped, 1)):
+        print(f"Encouter a bug while {what}, currently not be fixed, " + ("Continue!!" if what == "Mapping" else "Restarting!!"))
+    return steps, skipped
 
 
 def bundle_adjust_frames(keyframe_graph, embeddings, map_states, sdf_network, loss_criteria, voxel_size, step_size,
@@ -103,18 +149,16 @@ def bundle_adjust_frames(keyframe_graph, embeddings, map_states, sdf_network, lo
     eng.begin_call(m, dec)                                # fresh Adam per call (render_helpers.py:353)
     if profiler is not None:
         profiler.tok("mapping_add_optim")
-    for it in range(num_iterations):
-        _set_rays(eng, keyframe_graph, N_rays)
-        eng.forward_backward(m, dec, cfg, train_decoder=update_decoder, want_emb_grad=True, want_pose_grad=any(optimise))
-        ok, _ = _usable(eng)
-        if not ok:
-            print("Encouter a bug while Mapping, currently not be fixed, Continue!!")
-            eng.g_emb.zero_(); eng.g_pose.zero_()
-            continue
-        eng.optimiser_step(m, dec, cfg, update_emb=True, update_decoder=update_decoder, update_pose=any(optimise))
+    seed0 = _draw_seed()
+    for it in range(num_iterations):                      # no host synchronisation inside the loop: an unusable iteration is
+        _set_rays(eng, keyframe_graph, N_rays, seed0 + it)    # recognised and skipped by the optimiser kernel itself (skip_mode)
+        eng.forward_backward(m, dec, cfg, train_decoder=update_decoder, want_emb_grad=True, want_pose_grad=any(optimise),
+                             fresh_noise=True)
+        eng.optimiser_step(m, dec, cfg, update_emb=True, update_decoder=update_decoder, update_pose=any(optimise), skip_mode=1)
+    _finish_call(eng, "Mapping")
     with torch.no_grad():
         if update_decoder:
-            sdf_network.load_flat(dec.params)
+            _decoder_writeback(sdf_network, dec)
         p6 = eng.pose6[:len(keyframe_graph)].cpu()
         for i, kf in enumerate(keyframe_graph):
             if optimise[i]:
@@ -133,19 +177,14 @@ def track_frame(frame_pose, curr_frame, map_states, sdf_network, loss_criteria, 
     init_pose = deepcopy(frame_pose)
     lr = learning_rate * 2 if curr_frame.index < 2 else learning_rate / 3
     eng.set_poses(init_pose.data.detach().cpu().numpy()[None], [1])
-    eng.begin_call(m, None)
-    hit_mask = None
-    for it in range(num_iterations):
-        _set_rays(eng, [curr_frame], N_rays, track=True)
-        eng.forward_backward(m, dec, cfg, train_decoder=False, want_emb_grad=False, want_pose_grad=True)
-        ok, _ = _usable(eng)
-        if not ok:
-            print("Encouter a bug while Tracking, currently not be fixed, Restarting!!")
-            hit_mask = None
-            eng.g_pose.zero_()
-            break
-        hit_mask = (eng.hit_count[:eng.N] > 0)
-        eng.optimiser_step(m, dec, cfg, update_emb=False, update_decoder=False, update_pose=True, lr_pose=lr)
+    eng.begin_call(m, None, emb_state=False)
+    seed0 = _draw_seed()
+    for it in range(num_iterations):                      # sticky skip = the reference's `break` at the first unusable iteration
+        _set_rays(eng, [curr_frame], N_rays, seed0 + it, track=True)
+        eng.forward_backward(m, dec, cfg, train_decoder=False, want_emb_grad=False, want_pose_grad=True, fresh_noise=True)
+        eng.optimiser_step(m, dec, cfg, update_emb=False, update_decoder=False, update_pose=True, lr_pose=lr, skip_mode=2)
+    _, skipped = _finish_call(eng, "Tracking")
+    hit_mask = None if skipped else (eng.hit_count[:eng.N] > 0)
     with torch.no_grad():
         init_pose.data.copy_(eng.pose6[0].to(init_pose.data.device))
     return init_pose, hit_mask

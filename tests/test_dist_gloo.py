@@ -26,7 +26,7 @@ def _worker(rank, world, port, out_q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         c = torch.zeros(L.NL_CNT_BYTES // 4, dtype=torch.int32)
-        eng = SimpleNamespace(counters=c, g_pose=torch.full((2, 12), float(rank + 1)), g_emb=torch.full((5, 16), 10.0 * (rank + 1)),
+        eng = SimpleNamespace(counters=c, g_pose=torch.full((2, 12), float(rank + 1), dtype=torch.float64), F=2, g_emb=torch.full((5, 16), 10.0 * (rank + 1)),
                               hook_after_intersect=None, hook_after_count=None, hook_after_backward=None)
         dec = SimpleNamespace(grad=torch.arange(7, dtype=torch.float32) * (rank + 1))
         ex = D.RayShardedExchange(eng)

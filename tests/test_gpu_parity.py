@@ -162,8 +162,13 @@ def compare_iteration(eng, m, dec, out, cfgP, train_decoder, sdf_tol=1e-4):
     ds = eng.dsdf[:Pn].cpu().numpy()
     ref_ds = out["dsdf"][out["valid"]]
     np.testing.assert_allclose(ds, ref_ds, rtol=1e-3, atol=1e-9 + 1e-5 * np.abs(ref_ds).max())
+    # dX: a hidden unit whose pre-activation is ~0 may fall on the other side of the ReLU under a different summation order
+    # (a few of P x 512 units); such a sample's dX moves by that unit's contribution.  Element-wise bar on all but a
+    # vanishing fraction of the elements, norm bar on everything.
     dX = eng.dX[:Pn].cpu().numpy()
-    np.testing.assert_allclose(dX, out["dfeat"], rtol=0, atol=2e-5 * np.abs(out["dfeat"]).max())
+    bad = np.abs(dX - out["dfeat"]) > 2e-5 * np.abs(out["dfeat"]).max()
+    assert bad.mean() < 5e-4, bad.mean()
+    assert np.linalg.norm((dX - out["dfeat"]).astype(np.float64)) <= 1e-3 * np.linalg.norm(out["dfeat"].astype(np.float64))
     if train_decoder:
         g = nl_split(dec.grad.cpu().numpy())
         for n_, ref in out["grad_dec"].items():
@@ -172,7 +177,7 @@ def compare_iteration(eng, m, dec, out, cfgP, train_decoder, sdf_tol=1e-4):
     return r
 
 
-POSE_GRAD_RTOL = 2e-3
+POSE_GRAD_RTOL = 1e-4            # fp64-accumulated partials: what is left is the fp32 round-off of the per-sample terms themselves
 
 
 def nl_split(flat):
@@ -308,8 +313,8 @@ def test_tracking_matches_oracle_and_golden(nl, golden_dir, case):
             ok = ~_tie_rays(outs[0])
             assert np.abs(r["sdf"] - g["it0_sdf"])[ok].max() < 1e-4
         eng.optimiser_step(m, dec, cfgP, update_emb=False, update_decoder=False, update_pose=True, lr_pose=float(g["lr"]))
-        np.testing.assert_allclose(eng.pose_grad6[0].cpu().numpy(), outs[it]["grad_pose"][0], rtol=5e-3,
-                                   atol=1e-6 + 2e-4 * np.abs(outs[it]["grad_pose"][0]).max())
+        np.testing.assert_allclose(eng.pose_grad6[0].cpu().numpy(), outs[it]["grad_pose"][0], rtol=POSE_GRAD_RTOL if it == 0 else 5e-3,
+                                   atol=1e-6 + 1e-4 * np.abs(outs[it]["grad_pose"][0]).max())
         pose = eng.pose6[0].cpu().numpy()
     np.testing.assert_allclose(pose, pose_o, rtol=0, atol=2e-5)
     np.testing.assert_allclose(pose, g["pose_final"], rtol=0, atol=3e-4)                  # reference golden
@@ -570,7 +575,7 @@ def test_one_launch_optimiser_step_equals_the_separate_kernels(nl, groups):
             params=dev(r.normal(scale=0.05, size=L.NL_DEC_PARAMS).astype(np.float32)), grad=torch.zeros(L.NL_DEC_PARAMS, device="cuda"),
             m=torch.zeros(L.NL_DEC_PARAMS, device="cuda"), v=torch.zeros(L.NL_DEC_PARAMS, device="cuda"),
             ws=torch.zeros(L.NL_DEC_WS_FLOATS, device="cuda"),
-            pose6=dev(r.normal(scale=0.1, size=(F, 6)).astype(np.float32)), g_pose=torch.zeros(F, 12, device="cuda"),
+            pose6=dev(r.normal(scale=0.1, size=(F, 6)).astype(np.float32)), g_pose=torch.zeros(F, 12, dtype=torch.float64, device="cuda"),
             pose_m=torch.zeros(F, 6, device="cuda"), pose_v=torch.zeros(F, 6, device="cuda"),
             enable=dev(np.array([0, 1, 1], np.int32)), grad6=torch.zeros(F, 6, device="cuda"), poses12=torch.zeros(F, 12, device="cuda"))
         ops.decoder_transpose_w2(st["params"], st["ws"])
@@ -582,7 +587,7 @@ def test_one_launch_optimiser_step_equals_the_separate_kernels(nl, groups):
         ge = rng.normal(scale=1e-2, size=(n_rows, 16)).astype(np.float32)
         ge[rng.random(n_rows) < 0.5] = 0.0                            # untouched rows never move
         gd = rng.normal(scale=1e-2, size=L.NL_DEC_PARAMS).astype(np.float32)
-        gp = rng.normal(scale=1e-1, size=(F, 12)).astype(np.float32)
+        gp = rng.normal(scale=1e-1, size=(F, 12))                     # fp64 accumulators (nl_trilinear_bwd)
         for st in (a, b):
             st["g_emb"].copy_(dev(ge)); st["grad"].copy_(dev(gd)); st["g_pose"].copy_(dev(gp))
         apply_pose = step != 1

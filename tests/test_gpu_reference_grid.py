@@ -54,7 +54,8 @@ def intersect_like_the_wrapper(mod, o, d, centres, structure, voxel, n_max=20):
     N = len(o)
     G = min(256, int(2 * 10 ** 9 / (centres.size + structure.size)))
     K = int(np.ceil(N / G)); Ht = K * G
-    rs = np.concatenate([o, o[:Ht - N]]).reshape(G, K, 3); rd = np.concatenate([d, d[:Ht - N]]).reshape(G, K, 3)
+    fill = np.arange(Ht) % N                              # the wrapper pads with the first rays (it needs N >= G / 2; cyclic here)
+    rs = o[fill].reshape(G, K, 3); rd = d[fill].reshape(G, K, 3)
     pts = dev(centres)[None].expand(G, -1, -1).contiguous(); ch = dev(structure)[None].expand(G, -1, -1).contiguous()
     idx, t0, t1 = mod.svo_intersect(dev(rs), dev(rd), pts, ch, float(voxel), n_max)
     torch.cuda.synchronize()
@@ -72,7 +73,7 @@ def sample_like_the_wrapper(mod, idx, t0, t1, step_size, noise_seed):
     G = 200; L = int(np.ceil(R / G)); Ht = G * L
     pad = lambda a: np.concatenate([a, np.repeat(a[:1], Ht - R, 0)], 0)     # noqa: E731
     T = int(np.ceil(pad(steps)).max()) + P
-    noise = pad(O.hash_noise(noise_seed, np.arange(R), T))
+    noise = O.hash_noise(noise_seed, np.arange(R), T)
     a = [pad(x).reshape(G, L, -1) for x in (idx, t0, t1, noise, probs)]
     st = pad(steps).reshape(G, L)
     outs = []
