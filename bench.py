@@ -136,16 +136,25 @@ def cpu_baseline(w, n_rays=32768, warm=2, reps=5, n_rays_1t=8192, reps_1t=3, see
         return len(sel), float(np.median(ts))
 
     cores = int(torch.get_num_threads())
-    n_all, t_all = run(n_rays, warm, reps)
-    torch.set_num_threads(1)
-    try:
-        n_1, t_1 = run(n_rays_1t, 1, reps_1t)
-    finally:
-        torch.set_num_threads(cores)
-    return dict(value=n_all / t_all, unit="rays/s", cores=cores, kind="port",
-                sample=f"{n_all} rays (every {max(1, N // n_rays)}th return of the same 64x2048 scan), 1 mapping iteration incl. Adam, "
-                       f"{warm} warm-up + {reps} timed, median {t_all * 1e3:.0f} ms/iter; numpy/C oracle port, GEMMs on {cores} torch-CPU threads "
-                       "(the numpy / C stages are single-threaded)",
+    res = {}
+    for thr, (n, w_, r_) in ((cores, (n_rays, warm, reps)), (min(16, cores), (n_rays, 1, 3)), (1, (n_rays_1t, 1, reps_1t))):
+        if thr in res:
+            continue
+        torch.set_num_threads(thr)
+        try:
+            res[thr] = run(n, w_, r_) + (w_, r_)
+        finally:
+            torch.set_num_threads(cores)
+    best = max((t for t in res if t != 1), key=lambda t: res[t][0] / res[t][1])
+    n_b, t_b, w_b, r_b = res[best]
+    n_1, t_1 = res[1][:2]
+    every = max(1, N // n_rays)
+    return dict(value=n_b / t_b, unit="rays/s", cores=best, kind="port",
+                sample=f"{n_b} rays (every {every}th return of the same 64x2048 scan), 1 mapping iteration incl. Adam, "
+                       f"{w_b} warm-up + {r_b} timed, median {t_b * 1e3:.0f} ms/iter; numpy/C oracle port, GEMMs on {best} torch-CPU threads "
+                       f"of {os.cpu_count()} host cores (the numpy / C stages are single-threaded)",
+                by_threads={str(t): dict(value=res[t][0] / res[t][1], rays=res[t][0], ms_per_iter=res[t][1] * 1e3, warmup=res[t][2], timed=res[t][3])
+                            for t in res},
                 single_thread=dict(value=n_1 / t_1, unit="rays/s", cores=1,
                                    sample=f"{n_1} rays, 1 warm-up + {reps_1t} timed, median {t_1 * 1e3:.0f} ms/iter, torch.set_num_threads(1)"))
 
@@ -231,11 +240,14 @@ def stage_rooflines(eng, w, cfg, train_dec, steps=5):
     N, P_, E = eng.N, st["P"], w["n_rows"]
     nhits = int(eng.hit_count[:N].sum().item())
     touched = int((eng.emb_m != 0).any(1).sum().item())                    # embedding rows the call has touched (they carry moments)
+    n_vox = int(torch.unique(eng.s_vox[:P_]).numel())                      # distinct voxels the samples fall in
     by = {
         "intersect": N * (28 + 20) + nhits * 12,                            # dir, gt point, cos in; world dir, gt dist, count + hit list out
         "sample": 2 * (nhits * 12 + N * 16) + P_ * 16 + N * 8,              # both passes read the hit lists; (voxel, depth, dist, ray) out
-        "gather": P_ * (12 + 32 + 256 + 64),                                # sample record, 8 row ids, 8 bf16 rows, X out
-        "scatter": P_ * (12 + 64 + 32 + 256) + touched * 64 * 2,            # + dX in; every touched accumulator row read-modify-written once
+        # every distinct datum once: the 8 row ids of a voxel and a touched embedding row are read once however many samples share
+        # them (they do: ~8 samples per ray run through 3-4 voxels); what scales with the samples is the record, X and dX
+        "gather": P_ * (12 + 64) + n_vox * 32 + touched * 32,               # sample record in, X out; row ids per voxel, bf16 rows
+        "scatter": P_ * (12 + 64) + n_vox * 32 + touched * (32 + 64 * 2),   # + dX in; every touched accumulator row read-modify-written once
         "optim": touched * 16 * 20 + (E - touched) * 16 * 8 + (70401 * 28 + 1835008 if train_dec else 0),
         "reduce": (eng.n_slabs + 1) * 70401 * 4,
     }
@@ -482,11 +494,11 @@ def main():
             rf["end_to_end"] = {"sum_of_bounds_ms": float(sum(bounds.values())), "ms_per_step": dt / args.steps * 1e3,
                                 "frac": float(sum(bounds.values())) / (dt / args.steps * 1e3), "bounds_ms": bounds, "stage_ms": stage_ms,
                                 "note": "decoder kernels: matrix-pipe bound of their instruction mix; every other stage: algorithmic bytes / 8 TB/s"}
+            out["pose_refine"] = pose_refine_bench(w, device)      # launch-bound loops first: the oracle's BLAS threads keep spinning
+            if not args.no_api_path:                               # for a while after use and slow the launching thread down
+                out["api_path"] = api_path_bench(w, device)
             if not args.no_parity:
                 out["parity"] = parity_check(eng, w, cfg, train_dec)
-            out["pose_refine"] = pose_refine_bench(w, device)
-            if not args.no_api_path:
-                out["api_path"] = api_path_bench(w, device)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))

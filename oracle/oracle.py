@@ -504,13 +504,19 @@ def decoder_backward(ds, cache, dp, want_wgrad=True):
     dh1 = _mm(dh2, dp.W2) * (h1 > 0)
     dx = _mm(dh1, dp.W1)
     if want_wgrad:
-        g["W3"] = _mm(ds2.T, h2)
-        g["b3"] = ds2.sum(0)
-        g["W2"] = _mm(dh2.T, h1)
-        g["b2"] = dh2.sum(0)
-        g["W1"] = _mm(dh1.T, x)
-        g["b1"] = dh1.sum(0)
-        g = {k: v.astype(f32) for k, v in g.items()}
+        # sums over the samples: fp32 GEMMs / row sums per chunk of 32 768 samples, the chunks combined in fp64 - a plain fp32
+        # reduction over a full scan's 1.1 M samples (numpy adds rows sequentially along axis 0) carries ~1e-4 of round-off,
+        # more than the kernels under test
+        acc = {k: 0.0 for k in ("W3", "b3", "W2", "b2", "W1", "b1")}
+        for c0 in range(0, len(ds2), 32768):
+            sl = slice(c0, c0 + 32768)
+            acc["W3"] = acc["W3"] + _mm(ds2[sl].T, h2[sl]).astype(np.float64)
+            acc["b3"] = acc["b3"] + ds2[sl].sum(0, dtype=np.float64)
+            acc["W2"] = acc["W2"] + _mm(dh2[sl].T, h1[sl]).astype(np.float64)
+            acc["b2"] = acc["b2"] + dh2[sl].sum(0, dtype=np.float64)
+            acc["W1"] = acc["W1"] + _mm(dh1[sl].T, x[sl]).astype(np.float64)
+            acc["b1"] = acc["b1"] + dh1[sl].sum(0, dtype=np.float64)
+        g = {k: np.asarray(v).astype(f32) for k, v in acc.items()}
     return dx.astype(f32), g
 
 

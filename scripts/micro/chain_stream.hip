@@ -1,0 +1,143 @@
+// micro-benchmark for the register-chained decoder design: ONE wave per SIMD (256-thread workgroups, one per
+// CU), every wave owns 32 samples whose activations stay in registers as MFMA B operands (lane = sample), and streams the
+// bf16 weight planes (the A operands, 1 KB fragments in MFMA order) straight from L2 into registers:
+//   forward : 8 output tiles x 16 k-steps x (3 A planes x 3 B planes) = 1152 v_mfma_f32_32x32x16_bf16, 384 fragments
+//   dgrad   : 8 output tiles x 16 k-steps x 3 A planes x S sample sub-tiles (S = 1 or 2: mask fragments are cheap), 384 fragments
+// Question: does the weight stream (each of the 4 waves of a CU loads every fragment itself: L1 / L2 served) keep the matrix pipe
+// fed at one wave per SIMD?  Ideal = 32 cycles per MFMA.
+// Build: hipcc --offload-arch=gfx950 -O3 chain_stream.hip -o chain_stream
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define PLANE (256 * 256 * 2)
+
+__device__ __forceinline__ uint4 bload4(rsrc_t r, int voff, int soff) { return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); }
+
+// RING: k-steps of A fragments in flight (register ring); LOAD: stream from memory or use constants; SUB: dgrad sample sub-tiles
+template <int RING, bool LOAD, int SUB>
+__global__ __launch_bounds__(256, 1) void k_chain(const unsigned short* Wf, const unsigned short* Wd, const uint4* Hinit, float* out,
+                                                  long long* cyc, int tiles)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Wf), 0, 3 * PLANE, 0x00020000);
+    const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Wd), 0, 3 * PLANE, 0x00020000);
+    const int voff = lane * 16;
+    uint4 hb[16][3];                                     // this wave's H1 operand planes: 192 registers, live through the forward
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) hb[s][p] = Hinit[(s * 3 + p) * 64 + lane];
+    f32x16 total;
+    for (int r = 0; r < 16; ++r) total[r] = 0.f;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int tile = 0; tile < tiles; ++tile) {
+        // ---------------- forward: 8 x 16 k-steps, 9 MFMAs per k-step ----------------
+        {
+            uint4 aq[RING][3];
+#pragma unroll
+            for (int j = 0; j < RING - 1; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) aq[j][p] = LOAD ? bload4(rf, voff, p * PLANE + j * 1024) : make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+#pragma unroll 1
+            for (int nt = 0; nt < 8; ++nt) {
+                f32x16 c;
+                for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int jn = nt * 16 + s + RING - 1;            // linear k-step to prefetch
+                    if (LOAD) {
+                        const int so = (jn & 127) * 1024;
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) aq[(s + RING - 1) % RING][p] = bload4(rf, voff, p * PLANE + so);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int pa = 0; pa < 3; ++pa)
+#pragma unroll
+                        for (int pb = 0; pb < 3; ++pb)
+                            c = MFMA(__builtin_bit_cast(bf16x8, aq[s % RING][pa]), __builtin_bit_cast(bf16x8, hb[s][pb]), c);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) total[r] += c[r] > 0.f ? c[r] : 0.f;
+            }
+        }
+        // ---------------- dgrad: 8 x 16 k-steps, 3 MFMAs per k-step and sample sub-tile ----------------
+        {
+            uint4 aq[RING][3];
+            uint4 mk[SUB];
+#pragma unroll
+            for (int u = 0; u < SUB; ++u) mk[u] = hb[u][0];
+#pragma unroll
+            for (int j = 0; j < RING - 1; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) aq[j][p] = LOAD ? bload4(rd, voff, p * PLANE + j * 1024) : make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+#pragma unroll 1
+            for (int kt = 0; kt < 8; ++kt) {
+                f32x16 c[SUB];
+#pragma unroll
+                for (int u = 0; u < SUB; ++u) for (int r = 0; r < 16; ++r) c[u][r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int jn = kt * 16 + s + RING - 1;
+                    if (LOAD) {
+                        const int so = (jn & 127) * 1024;
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) aq[(s + RING - 1) % RING][p] = bload4(rd, voff, p * PLANE + so);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int pa = 0; pa < 3; ++pa)
+#pragma unroll
+                        for (int u = 0; u < SUB; ++u)
+                            c[u] = MFMA(__builtin_bit_cast(bf16x8, aq[s % RING][pa]), __builtin_bit_cast(bf16x8, mk[u]), c[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < SUB; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) total[r] += c[u][r];
+            }
+        }
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    float sres = 0.f;
+    for (int r = 0; r < 16; ++r) sres += total[r];
+    out[blockIdx.x * 256 + tid] = sres;
+    if (lane == 0) cyc[blockIdx.x * 4 + (tid >> 6)] = t1 - t0;
+}
+
+template <int RING, bool LOAD, int SUB>
+static void run(const char* tag, const unsigned short* Wf, const unsigned short* Wd, const uint4* Hinit)
+{
+    const int blocks = 256, tiles = 40;
+    float* out; long long* cyc;
+    (void)hipMalloc(&out, sizeof(float) * 256 * blocks); (void)hipMalloc(&cyc, 8 * 4 * blocks);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((k_chain<RING, LOAD, SUB>), dim3(blocks), dim3(256), 0, 0, Wf, Wd, Hinit, out, cyc, 2);
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((k_chain<RING, LOAD, SUB>), dim3(blocks), dim3(256), 0, 0, Wf, Wd, Hinit, out, cyc, tiles);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    long long h[8]; (void)hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost);
+    const double mf = (1152.0 + 384.0 * SUB) * tiles;
+    const double samples = 32.0 * (SUB == 1 ? 1.0 : 1.0) * tiles * 4 * blocks;   // forward samples per launch
+    printf("%-40s ring %d: %6.1f cycles/MFMA (ideal 32), %8.0f cycles/wave-tile, %.3f ms, %.2f us per 1e3 fwd samples\n", tag, RING,
+           (double)h[0] / mf, (double)h[0] / tiles, ms, ms * 1e3 / (samples / 1e3));
+    (void)hipFree(out); (void)hipFree(cyc);
+}
+
+int main()
+{
+    unsigned short *Wf, *Wd; uint4* H;
+    (void)hipMalloc(&Wf, 3 * PLANE); (void)hipMalloc(&Wd, 3 * PLANE); (void)hipMalloc(&H, 48 * 64 * 16);
+    (void)hipMemset(Wf, 0, 3 * PLANE); (void)hipMemset(Wd, 0, 3 * PLANE); (void)hipMemset(H, 0, 48 * 64 * 16);
+    run<2, false, 1>("no loads, dgrad 32 samples", Wf, Wd, H);
+    run<2, true, 1>("weights from L2, dgrad 32 samples", Wf, Wd, H);
+    run<4, true, 1>("weights from L2, dgrad 32 samples", Wf, Wd, H);
+    run<8, true, 1>("weights from L2, dgrad 32 samples", Wf, Wd, H);
+    run<4, true, 2>("weights from L2, dgrad 64 samples", Wf, Wd, H);
+    run<8, true, 2>("weights from L2, dgrad 64 samples", Wf, Wd, H);
+    return 0;
+}
