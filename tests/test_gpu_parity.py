@@ -171,14 +171,17 @@ def compare_iteration(eng, m, dec, out, cfgP, train_decoder, sdf_tol=1e-4):
     assert np.linalg.norm((dX - out["dfeat"]).astype(np.float64)) <= 1e-3 * np.linalg.norm(out["dfeat"].astype(np.float64))
     if train_decoder:
         # a flipped hidden unit of layer 2 (see dX above) at sample i moves row j of dW2, b2[j], W3[j] by that sample's
-        # contribution |dsdf_i| x |H1_i| - visible next to max|grad| on a small scene with a few large loss gradients.  So: the
-        # element-wise bar on all but 2 % of a tensor's elements, a norm bar on everything.
+        # contribution |dsdf_i| x |H1_i| - visible next to max|grad| on a small scene with a few large loss gradients - and,
+        # through dH1_i, EVERY element of dW1 / db1 a little.  So: a norm bar on every tensor; the element-wise bar on all but
+        # 2 % of the elements of the layer-2 / output tensors (no flip: all of them pass it, as the maicity / kitti cases show).
         g = nl_split(dec.grad.cpu().numpy())
         for n_, ref in out["grad_dec"].items():
             got = g[n_].reshape(ref.shape)
             bad = np.abs(got - ref) > 5e-5 * np.abs(ref).max() + 1e-9
-            assert bad.mean() <= 0.02, (n_, bad.mean())
-            assert np.linalg.norm((got - ref).astype(np.float64)) <= 2e-3 * np.linalg.norm(ref.astype(np.float64)) + 1e-12, n_
+            rel = np.linalg.norm((got - ref).astype(np.float64)) / (np.linalg.norm(ref.astype(np.float64)) + 1e-30)
+            assert rel <= 2e-3, (n_, rel, bad.mean())
+            if n_ not in ("W1", "b1"):
+                assert bad.mean() <= 0.02, (n_, rel, bad.mean())
     return r
 
 
