@@ -29,7 +29,7 @@ extern "C" {
 #define NL_CNT_DOUBLES 4        /* ... followed by double sums: counter block = 16*4 + 4*8 bytes */
 #define NL_LOSS_SCALARS_BYTES 48
 #define NL_DEC_PARAMS 70401     /* W1[256x16] b1[256] W2[256x256] b2[256] W3[256] b3[1] */
-#define NL_DEC_WS_FLOATS 262144    /* decoder weight workspace: W2^T fp32 + 2 x 3 bf16 operand planes */
+#define NL_DEC_WS_FLOATS 458752    /* decoder weight workspace: W2^T fp32 + 4 x 3 bf16 operand planes (two kernel families) */
 #define NL_EMB_CHANNELS 16
 
 /* Multi-GPU ray sharding: fold the all-gathered counter blocks gathered[world][NL_CNT_INTS + 2*NL_CNT_DOUBLES] (ints) into
@@ -133,6 +133,10 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
 /* second half of the decoder weight gradient: dW2 = dH2^T H1 into partials[slab][W2 block] (train only) */
 int nl_decoder_wgrad2(const void* loss_scalars, const float* X, const float* params, const float* dsdf, const unsigned* relu2_mask,
                       float* partials, int nslabs, void* stream);
+/* sum of the per-workgroup slabs partials[nslabs][NL_DEC_PARAMS] written by nl_decoder_fwd_bwd + nl_decoder_wgrad2 into the decoder
+ * gradient grad_out[NL_DEC_PARAMS].  Works for either kernel family (the register-chained one, gemm mode 3, leaves raw dW2 / db2
+ * accumulators in the slabs and obtains dW2, db2 and dW3 from them while summing). */
+int nl_decoder_reduce(const float* partials, int nslabs, const float* params, float* grad_out, void* stream);
 /* dW2 kernel selection: 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32), 1 = bf16 matrix cores on the exact
  * formulation dW2[j][k] = w3_j * sum_i m(i,j) * (dsdf_i * H1[i][k]) with the {0,1} mask m as A operand and the fp32
  * B operand split into three bf16 terms (exact products, fp32 accumulation; default). */

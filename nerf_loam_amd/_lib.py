@@ -14,7 +14,7 @@ NL_CNT_BYTES = NL_CNT_INTS * 4 + NL_CNT_DOUBLES * 8
 NL_LOSS_SCALARS_BYTES = 48
 NL_ADAM_STATE_BYTES = 112
 NL_DEC_PARAMS = 70401
-NL_DEC_WS_FLOATS = 262144        # decoder weight workspace: W2^T fp32 + 2 x 3 bf16 operand planes (include/nerfloam_hip.h)
+NL_DEC_WS_FLOATS = 458752        # decoder weight workspace: W2^T fp32 + 4 x 3 bf16 operand planes (include/nerfloam_hip.h)
 NL_C = 16
 NL_W = 256
 OFF_W1, OFF_B1 = 0, 256 * 16
@@ -67,6 +67,7 @@ _SIGS = {
     "nl_decoder_set_wgrad2_mode": ([_I], _I),
     "nl_decoder_get_wgrad2_mode": ([], _I),
     "nl_reduce_partials": ([_P, _I, _I, _P, _P], _I),
+    "nl_decoder_reduce": ([_P, _I, _P, _P, _P], _I),
     "nl_decoder_transpose_w2": ([_P, _P, _P], _I),
     "nl_trilinear_bwd": ([_P] * 8 + [_I] + [_P] * 3 + [_F] + [_P] * 3 + [_I, _P], _I),
     "nl_unpack_samples": ([_P] * 6 + [_I] + [_P] * 4, _I),
@@ -113,7 +114,7 @@ def lib():
             fn.restype = res
         if os.environ.get("NL_GEMM_MODE"):
             if L.nl_decoder_set_gemm_mode(int(os.environ["NL_GEMM_MODE"])) != 0:
-                raise NerfLoamHipError("NL_GEMM_MODE must be 0, 1 or 2")
+                raise NerfLoamHipError("NL_GEMM_MODE must be 0 .. 4")
         if os.environ.get("NL_SAMPLER_MODE"):
             L.nl_geometry_set_sampler_mode(int(os.environ["NL_SAMPLER_MODE"]))
         if os.environ.get("NL_WGRAD2_MODE"):                # A/B switch for measurements (default: the library's own default)

@@ -769,6 +769,11 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2(const NlLossS
 #define WX_TOTAL (WX_OFF_DS + 2 * DEC_M * 4)
 
 
+// NAT (the register-chained family, nl_decoder_chain.hip): the mask words come in NATURAL order - word (32-sample tile, unit), bit b
+// = sample b - so the k-slot order inside a half tile is the sample order (the producer stores its 4-row groups as 8-byte pieces),
+// the accumulators are flushed RAW (G = dW2 / w3) and g[n] = sum_i m2(i,n) dsdf_i goes into the slab's b2 block: nl_decoder_reduce
+// turns them into dW2, db2 and dW3 (identities in nl_decoder_chain.hip's header).
+template <bool NAT>
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLossScalars* __restrict__ lsp, const float* __restrict__ X,
                                                                       const float* __restrict__ params, const float* __restrict__ dsdf,
                                                                       const unsigned* __restrict__ relu2_mask, float* __restrict__ partials)
@@ -842,6 +847,16 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
             const float s0 = r0 - trunc_bf16(r0), s1 = r1 - trunc_bf16(r1);
             lo[q] = pack_hi16(s0, s1);
         }
+        if (NAT) {                                       // slot = sample row: rows 8 q + 4 lh + (0..3) of this lane -> 8-byte pieces
+            unsigned char* dst = sB + opaque(col * WX_STRIDE + 8 * lh + 64 * sub);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                *reinterpret_cast<uint2*>(dst + 16 * q4) = make_uint2(hi[2 * q4], hi[2 * q4 + 1]);
+                *reinterpret_cast<uint2*>(dst + WX_PLANE + 16 * q4) = make_uint2(mid[2 * q4], mid[2 * q4 + 1]);
+                *reinterpret_cast<uint2*>(dst + 2 * WX_PLANE + 16 * q4) = make_uint2(lo[2 * q4], lo[2 * q4 + 1]);
+            }
+            return;
+        }
         unsigned char* dst = sB + opaque(col * WX_STRIDE + 32 * lh + 64 * sub);
         uint4* d0 = reinterpret_cast<uint4*>(dst);
         d0[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]); d0[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
@@ -854,9 +869,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
     // 6 groups (k-step, plane) of 8 MFMAs; the 4 B fragments of the NEXT group are read while this group's MFMAs run.
     auto consume = [&](int pb, int sub) {
         const unsigned* mk = sMask + pb * DEC_THREADS + l31;
-        unsigned mwd[2][2];                              // [row tile jt][producer lane half]
+        unsigned mwd[2][2];                              // [row tile jt][producer lane half]; NAT: [jt][0] = the word of (sub, unit)
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) { mwd[jt][0] = mk[(2 * wj + jt) * 64]; mwd[jt][1] = mk[(2 * wj + jt) * 64 + 32]; }
+        for (int jt = 0; jt < 2; ++jt) {
+            if (NAT) { mwd[jt][0] = mk[256 * sub + 64 * wj + 32 * jt]; mwd[jt][1] = 0u; }
+            else     { mwd[jt][0] = mk[(2 * wj + jt) * 64]; mwd[jt][1] = mk[(2 * wj + jt) * 64 + 32]; }
+        }
         const unsigned char* bsrc = sB + opaque((128 * wk + l31) * WX_STRIDE + 16 * lh + 64 * sub);
         uint4 bfr[2][4];
 #pragma unroll
@@ -868,7 +886,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
             if (p3 == 0) {
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt) {
-                    const unsigned byte = (mwd[jt][s2] >> (16 * sub + 8 * lh)) & 0xFFu;
+                    const unsigned byte = NAT ? (mwd[jt][0] >> (8 * (2 * s2 + lh))) & 0xFFu : (mwd[jt][s2] >> (16 * sub + 8 * lh)) & 0xFFu;
                     af[jt] = __builtin_bit_cast(bf16x8, sLut[byte]);
                 }
             }
@@ -897,7 +915,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
     if (blockIdx.x < ntiles) produce(0, 0);
     __syncthreads();
     int par = 0;
+    float gsum = 0.f;                                    // NAT: g[unit] over this thread's 32-sample half tiles
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
+        if (NAT) {                                       // thread = (half tile tid >> 8, unit tid & 255): its word and the half's dsdf
+            const unsigned word = sMask[par * DEC_THREADS + tid];
+            const float* dsp = sdS + par * DEC_M + 32 * (tid >> 8);
+#pragma unroll
+            for (int b = 0; b < 32; ++b) gsum += ((word >> b) & 1u) ? dsp[b] : 0.f;
+        }
         // step A: inputs of the next tile -> the other buffers; planes of this tile's second half; MFMAs of its first half
         stage_inputs(par ^ 1);
         prefetch(tile + 2 * gridDim.x);
@@ -915,10 +940,17 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = 64 * wj + 32 * jt + d32_row(r, lh);
-            const float w3j = params[NL_OFF_W3 + j];
+            const float w3j = NAT ? 1.f : params[NL_OFF_W3 + j];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) base[NL_OFF_W2 + j * NL_W + 128 * wk + 32 * kt + l31] = w3j * acc[jt][kt][r];
         }
+    if (NAT) {                                           // raw g[n]: the two half-tile threads of a unit combined through LDS
+        __syncthreads();
+        float* sg = reinterpret_cast<float*>(smem);
+        if (tid >= 256) sg[tid - 256] = gsum;
+        __syncthreads();
+        if (tid < 256) base[NL_OFF_B2 + tid] = gsum + sg[tid];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1030,7 +1062,19 @@ __global__ void k_mfma_selftest(const float* A32, const float* B32, float* D32, 
 static long long* g_dec_dbg = nullptr;
 static int g_gemm_mode = 1;              // 0: fp32 MFMA GEMMs, 1: bf16 MFMA on the exact-product formulations (gemm_x9 / gemm_mask_x),
                                          // 2: as 1 with six of the nine forward products (gemm_x9<.., 6>)
+static int g_chain_six = 0;              // gemm mode 4 = the chained family (3) with the six-product forward GEMM
 static int g_wgrad2_mode = 1;            // 0: fp32 MFMA (k_decoder_wgrad2), 1: exact 0/1-mask x 3-term bf16 split (k_decoder_wgrad2_x)
+
+extern "C" {
+/* nl_decoder_chain.hip */
+int nl_decoder_chain_fwd_bwd(const void* loss_scalars, const float* X, const float* params, const float* ws, const int* s_ray,
+                             const float* s_depth, const float* cos_gt, const float* gt_dist, float* sdf, float* dsdf, float* dX,
+                             float* partials, unsigned* relu2_nat, int nslabs, int train_decoder, int six_products, int* counters,
+                             void* stream);
+int nl_decoder_chain_forward(const float* X, const float* params, const float* ws, int P, float* sdf, int nblocks, int six_products,
+                             void* stream);
+int nl_decoder_chain_reduce(const float* partials, int nslabs, const float* params, float* grad_out, void* stream);
+}
 
 extern "C" {
 
@@ -1047,8 +1091,8 @@ int nl_decoder_get_wgrad2_mode(void) { return g_wgrad2_mode; }
  * 2 = as 1 with six of the nine forward products (the dropped ones are below 2^-24 of a product: below the rounding of the
  * fp32 accumulation).  PREPARED FOR ROUND 2: compiles, the kernels of modes 0 / 1 are instruction-identical with and without
  * it, but it has not run on a GPU yet - nothing selects it by default and no test covers it. */
-int nl_decoder_set_gemm_mode(int mode) { if (mode < 0 || mode > 2) return NL_ERR_INVALID_ARG; g_gemm_mode = mode; return NL_OK; }
-int nl_decoder_get_gemm_mode(void) { return g_gemm_mode; }
+int nl_decoder_set_gemm_mode(int mode) { if (mode < 0 || mode > 4) return NL_ERR_INVALID_ARG; g_chain_six = mode == 4; g_gemm_mode = mode == 4 ? 3 : mode; return NL_OK; }
+int nl_decoder_get_gemm_mode(void) { return g_gemm_mode == 3 && g_chain_six ? 4 : g_gemm_mode; }
 
 int nl_decoder_grid_hint(void)
 {
@@ -1071,6 +1115,9 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
     a.relu2_mask = relu2_mask;
     a.dcounters = (double*)(counters + NL_CNT_INTS);
     a.dbg = g_dec_dbg;
+    if (g_gemm_mode == 3)
+        return nl_decoder_chain_fwd_bwd(loss_scalars, X, params, W2T, s_ray, s_depth, cos_gt, gt_dist, sdf, dsdf, dX, partials, relu2_mask,
+                                        nslabs, train_decoder, g_chain_six, counters, stream);
     const dim3 g(nslabs), b(DEC_THREADS);
     if (g_gemm_mode == 2) {
         if (train_decoder) hipLaunchKernelGGL((k_decoder<true, true, 6>), g, b, 0, (hipStream_t)stream, a);
@@ -1091,8 +1138,11 @@ int nl_decoder_wgrad2(const void* loss_scalars, const float* X, const float* par
                       float* partials, int nslabs, void* stream)
 {
     if (!loss_scalars || !X || !params || !dsdf || !relu2_mask || !partials || nslabs <= 0) return NL_ERR_INVALID_ARG;
-    if (g_wgrad2_mode == 1)
-        hipLaunchKernelGGL(k_decoder_wgrad2_x, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,
+    if (g_gemm_mode == 3)                                 // the register-chained family writes natural-order ReLU words
+        hipLaunchKernelGGL(k_decoder_wgrad2_x<true>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,
+                           params, dsdf, relu2_mask, partials);
+    else if (g_wgrad2_mode == 1)
+        hipLaunchKernelGGL(k_decoder_wgrad2_x<false>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,
                            params, dsdf, relu2_mask, partials);
     else
         hipLaunchKernelGGL(k_decoder_wgrad2, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,
@@ -1105,6 +1155,7 @@ int nl_decoder_forward(const float* X, const float* params, const float* W2T, in
 {
     if (!X || !params || !W2T || !sdf || P < 0 || nblocks <= 0) return NL_ERR_INVALID_ARG;
     if (P == 0) return NL_OK;
+    if (g_gemm_mode == 3) return nl_decoder_chain_forward(X, params, W2T, P, sdf, nblocks, g_chain_six, stream);
     if (g_gemm_mode == 2) hipLaunchKernelGGL((k_decoder_fwd<true, 6>), dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
     else if (g_gemm_mode == 1) hipLaunchKernelGGL(k_decoder_fwd<true>, dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
     else                  hipLaunchKernelGGL(k_decoder_fwd<false>, dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
@@ -1118,6 +1169,15 @@ int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, voi
     hipLaunchKernelGGL(k_reduce_partials, dim3(nl_div_up(n, 64)), dim3(256), 0, (hipStream_t)stream, partials, nslabs, n, out);
     NL_LAUNCH_CHECK();
     return NL_OK;
+}
+
+/* sum of the per-workgroup weight-gradient slabs of nl_decoder_fwd_bwd + nl_decoder_wgrad2 into the decoder gradient (either
+ * kernel family: the chained one applies the dW2 / db2 / dW3 identities while summing) */
+int nl_decoder_reduce(const float* partials, int nslabs, const float* params, float* grad_out, void* stream)
+{
+    if (!partials || !params || !grad_out || nslabs <= 0) return NL_ERR_INVALID_ARG;
+    if (g_gemm_mode == 3) return nl_decoder_chain_reduce(partials, nslabs, params, grad_out, stream);
+    return nl_reduce_partials(partials, nslabs, NL_DEC_PARAMS, grad_out, stream);
 }
 
 int nl_mfma_selftest(const float* A32, const float* B32, float* D32, const float* A16, const float* B16, float* D16, void* stream)

@@ -107,6 +107,10 @@ def reduce_partials(partials, nslabs, n, out):
     check(L.lib().nl_reduce_partials(ptr(partials), int(nslabs), int(n), ptr(out), stream_ptr()), "nl_reduce_partials")
 
 
+def decoder_reduce(partials, nslabs, params, grad_out):
+    check(L.lib().nl_decoder_reduce(ptr(partials), int(nslabs), ptr(params), ptr(grad_out), stream_ptr()), "nl_decoder_reduce")
+
+
 def decoder_transpose_w2(params, W2T):
     check(L.lib().nl_decoder_transpose_w2(ptr(params), ptr(W2T), stream_ptr()), "nl_decoder_transpose_w2")
 

@@ -357,7 +357,7 @@ class SdfEngine:
             ops.decoder_wgrad2(self.loss_scalars, self.X, dec.params, self.dsdf, self.relu2_mask, self.partials, self.n_slabs)
             tm("wgrad2", 1)
             tm("reduce", 0)
-            ops.reduce_partials(self.partials, self.n_slabs, L.NL_DEC_PARAMS, dec.grad)
+            ops.decoder_reduce(self.partials, self.n_slabs, dec.params, dec.grad)
             tm("reduce", 1)
         tm("scatter", 0)
         ops.trilinear_bwd(self.loss_scalars, self.s_vox, self.s_depth, self.s_ray, self.rays_d_world, self.rays_d_sensor, self.frame_id,

@@ -362,3 +362,29 @@ def test_six_of_nine_split_products_stay_below_fp32_accumulation_noise():
     rms = lambda s_: float(np.sqrt((((s_ - exact) / scale) ** 2).mean()))
     assert rms(s9) < 1e-15
     assert np.abs(s6 - exact).max() / scale.max() < 2.0 ** -23 and rms(s6) < 0.5 * rms(f32)
+
+
+def test_chained_decoder_operand_slot_order(hh):
+    """nl_decoder_chain.hip chains layers through the register file: the 16 accumulator registers of a lane (rows (r & 3) + 8 (r >> 2)
+    + 4 lh of the 32x32 MFMA result, lane = sample) are fed back as two B-operand fragments, so the weight planes must be stored in
+    exactly that slot order.  nl_chain_slot is the inverse of the accumulator row map, and nl_chain_a_index is a bijection of
+    (row, contraction unit) onto a plane in [row tile][k-step][lane][8] order with the MFMA A-operand lane map."""
+    unit_of = np.zeros(32, np.int32); slot_of = np.zeros(96, np.int32); a_index = np.zeros(65536, np.int64)
+    hh.hh_chain_layout(p(unit_of), p(slot_of), p(a_index))
+    slot_of = slot_of.reshape(32, 3)
+    assert sorted(unit_of.tolist()) == list(range(32))                                   # the accumulator rows cover the tile
+    for lh in range(2):
+        for r in range(16):
+            u = unit_of[lh * 16 + r]
+            assert u == (r & 3) + 8 * (r >> 2) + 4 * lh                                   # cdna: 32x32 C/D row map
+            half, l, e = slot_of[u]
+            assert (l, 8 * half + e) == (lh, r)                                           # register r of lane half lh <-> fragment (half, e)
+    a = a_index.reshape(256, 256)
+    assert sorted(a.reshape(-1).tolist()) == list(range(65536))                           # bijection onto the plane
+    row, c = 77, 201
+    t_, rem = divmod(int(a[row, c]), 16 * 64 * 8)
+    s_, rem = divmod(rem, 64 * 8)
+    lane, e = divmod(rem, 8)
+    assert t_ == row >> 5 and (lane & 31) == (row & 31)                                   # A operand: lane = output row inside its tile
+    half, l, e2 = slot_of[c & 31]
+    assert s_ == 2 * (c >> 5) + half and (lane >> 5) == l and e == e2                     # k-step / lane half / element = the unit's slot

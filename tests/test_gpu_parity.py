@@ -13,7 +13,9 @@ import helpers as H
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
-BACKWARD_MODES = [0, 1, 2]          # 0: fp32 MFMA GEMMs, 1: exact bf16 splits (default), 2: six-product forward (opt-in, not exact)
+# decoder kernel families / arithmetic: 0: fp32 MFMA GEMMs, 1: exact bf16 splits, LDS-activation kernel, 2: 1 with the six-product
+# forward (opt-in, not exact), 3: exact bf16 splits, register-chained kernel (nl_decoder_chain.hip), 4: 3 with the six-product forward
+BACKWARD_MODES = [0, 1, 2, 3, 4]
 # goldens with the mapper / tracker settings of the kitti (voxel 0.3 m) and ncd (step 0.04 m, up to 58 samples per ray) configs
 EXTRA_GOLDENS = ["map_kitti_1f_1it", "map_ncd_1f_1it"]
 EXTRA_TRACK_GOLDENS = ["track_kitti_2it", "track_ncd_2it"]
@@ -253,7 +255,8 @@ def _tie_rays(out):
     return ((t0[:, 1:] == t0[:, :-1]) & (idx[:, 1:] != -1)).any(1)
 
 
-def test_mapping_three_steps_track_oracle(nl, golden_dir):
+@pytest.mark.parametrize("backward_mode", [1, 3], indirect=True)
+def test_mapping_three_steps_track_oracle(nl, golden_dir, backward_mode):
     """3 Adam iterations (embeddings bf16 + decoder + pose), same ray masks: parameters after each
     step stay within round-off of the oracle's; final state close to the reference golden."""
     g = np.load(os.path.join(golden_dir, "map_1f_3it.npz"))
@@ -295,8 +298,9 @@ def test_mapping_three_steps_track_oracle(nl, golden_dir):
     np.testing.assert_allclose(pose[:3], g["poses_final"][0][:3], rtol=0, atol=5e-3)     # reference golden
 
 
+@pytest.mark.parametrize("backward_mode", [1, 3], indirect=True)
 @pytest.mark.parametrize("case", ["track_2it"] + EXTRA_TRACK_GOLDENS)
-def test_tracking_matches_oracle_and_golden(nl, golden_dir, case):
+def test_tracking_matches_oracle_and_golden(nl, golden_dir, case, backward_mode):
     g = np.load(os.path.join(golden_dir, case + ".npz"))
     sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]),
                               voxel=float(g["voxel_size"]) if "voxel_size" in g.files else H.VOXEL)
@@ -345,7 +349,8 @@ def full_scan_scene():
     return dict(points=pts, cos=cos, pose=pose, ms=ms)
 
 
-def test_full_scan_matches_the_oracle(nl):
+@pytest.mark.parametrize("backward_mode", [1, 3], indirect=True)
+def test_full_scan_matches_the_oracle(nl, backward_mode):
     """one whole mapping iteration on all 131 072 rays of the synthetic scan against the oracle run on the same inputs:
     hit lists, sample layout and depths bit for bit (C restatement of the two CUDA kernels at full size, incl. the
     position-dependent sampler tail in the reference's [200, L, P] batch layout), sdf / loss / dsdf / dX / decoder, embedding
@@ -430,8 +435,8 @@ def test_full_scan_invariants(nl):
     lib = nl["L"].lib()
     old = lib.nl_decoder_get_wgrad2_mode(), lib.nl_decoder_get_gemm_mode()
     res = []
-    for mode in (0, 1):
-        assert lib.nl_decoder_set_wgrad2_mode(mode) == 0 and lib.nl_decoder_set_gemm_mode(mode) == 0
+    for mode in (0, 1, 3):
+        assert lib.nl_decoder_set_wgrad2_mode(min(mode, 1)) == 0 and lib.nl_decoder_set_gemm_mode(mode) == 0
         eng.g_emb.zero_(); eng.g_pose.zero_()
         eng.forward_backward(m, dec, cfg)
         res.append((P.DecoderDevice.split(dec.grad.cpu().numpy()), eng.dX[:Pn].cpu().numpy().astype(np.float64), eng.sdf[:Pn].cpu().numpy()))
@@ -441,16 +446,18 @@ def test_full_scan_invariants(nl):
         assert eng.forward_only(m, dec, cfg) == Pn
         assert np.array_equal(eng.sdf[:Pn].cpu().numpy(), res[-1][2])                      # forward-only kernel: same arithmetic
     lib.nl_decoder_set_wgrad2_mode(old[0]); lib.nl_decoder_set_gemm_mode(old[1])
-    assert np.abs(res[0][2] - res[1][2]).max() <= 2e-6                                     # sdf: |values| ~ 0.1, 256-term sums
+    assert np.abs(res[0][2] - res[1][2]).max() <= 2e-6 and np.abs(res[0][2] - res[2][2]).max() <= 2e-6    # sdf: |values| ~ 0.1, 256-term sums
     # dX: a hidden unit whose pre-activation is ~0 can fall on either side of the ReLU under a different summation order
     # (a handful of the 1.1 M x 256 units), so compare in norm and element-wise on all but a vanishing fraction
-    dx0, dx1 = res[0][1], res[1][1]
+    dx0 = res[0][1]
     assert np.abs(dx0).max() > 0
-    assert np.linalg.norm(dx0 - dx1) <= 1e-3 * np.linalg.norm(dx0)                        # ~1e2 flipped units of 2.8e8
-    assert (np.abs(dx0 - dx1) > 2e-5 * np.abs(dx0).max()).mean() < 1e-4
-    for name in ("W1", "b1", "W2", "b2", "W3"):                                            # ~1.1 M terms per element
-        g0, g1 = res[0][0][name].astype(np.float64), res[1][0][name].astype(np.float64)
-        assert np.abs(g0).max() > 0 and np.abs(g0 - g1).max() <= 5e-5 * np.abs(g0).max(), name
+    for other in (1, 2):
+        dx1 = res[other][1]
+        assert np.linalg.norm(dx0 - dx1) <= 1e-3 * np.linalg.norm(dx0)                    # ~1e2 flipped units of 2.8e8
+        assert (np.abs(dx0 - dx1) > 2e-5 * np.abs(dx0).max()).mean() < 1e-4
+        for name in ("W1", "b1", "W2", "b2", "W3"):                                  # ~1.1 M terms per element
+            g0, g1 = res[0][0][name].astype(np.float64), res[other][0][name].astype(np.float64)
+            assert np.abs(g0).max() > 0 and np.abs(g0 - g1).max() <= 5e-5 * np.abs(g0).max(), (name, other)
 
 
 def test_intersect_cap_and_overflow_paths(nl):
