@@ -49,10 +49,10 @@ def matrix_pipe_model(kernel, gemm_mode, wgrad2_mode, train):
     if kernel == "decoder":
         alg = FLOPS_PER_SAMPLE_DECODER if train else FLOPS_PER_SAMPLE_DECODER_FROZEN
         small = L1 * (3 if train else 2)                        # layer-1 forward, dX, (dW1)
-        if gemm_mode in (1, 2):                                 # forward: 3x3 split (mode 2: six of the nine products),
-            return alg, small, (9 if gemm_mode == 1 else 6) * G + 3 * G     # dgrad: {0,1} mask x 3-term split
+        if gemm_mode in (1, 2, 3, 4):                           # forward: 3x3 split (modes 2, 4: six of the nine products),
+            return alg, small, (9 if gemm_mode in (1, 3) else 6) * G + 3 * G    # dgrad: {0,1} mask x 3-term split; 3 / 4 = chained kernel
         return alg, small + 2 * G, 0
-    if wgrad2_mode == 1:
+    if wgrad2_mode == 1 or gemm_mode >= 3:
         return FLOPS_PER_SAMPLE_WGRAD2, L1, 3 * G               # H1 rebuilt on fp32 MFMA; mask x 3-term split
     return FLOPS_PER_SAMPLE_WGRAD2, L1 + G, 0
 
@@ -460,12 +460,13 @@ def main():
     stage_ms, stage_bytes, hbm_entries = stage_rooflines(eng, w, cfg, train_dec) if world == 1 else ({}, {}, [])
     if rank == 0:
         gm, wm = _lib.lib().nl_decoder_get_gemm_mode(), _lib.lib().nl_decoder_get_wgrad2_mode()
-        rf = roofline_entry("k_decoder<train>" if train_dec else "k_decoder<frozen>", "decoder", dec_ms, P_local, gm, wm, train_dec)
+        kname = ("k_decoder_chain" if gm >= 3 else "k_decoder") + ("<train>" if train_dec else "<frozen>")
+        rf = roofline_entry(kname, "decoder", dec_ms, P_local, gm, wm, train_dec)
         rf = {"bound": "mfma", **rf,
-              "traffic": pmc_traffic(("k_decoder<true, %s>" if train_dec else "k_decoder<false, %s>") % ("true" if gm >= 1 else "false")) if gm != 2 else None,
+              "traffic": pmc_traffic(("k_decoder<true, %s>" if train_dec else "k_decoder<false, %s>") % ("true" if gm >= 1 else "false")) if gm in (0, 1) else None,
               "traffic_source": "committed rocprofv3 PMC passes of this command (newest profiles/r*_pmc_summary.json), not measured in this run",
               "peak_note": ("matrix-pipe bound of the kernel's instruction mix: "
-                            + (f"256-deep GEMMs as {'exact-product ' if gm == 1 else ''}bf16 splits ({9 if gm == 1 else 6} + 3 MFMAs per fp32 product, 2500 TF pipe), "
+                            + (f"256-deep GEMMs as {'exact-product ' if gm in (1, 3) else ''}bf16 splits ({9 if gm in (1, 3) else 6} + 3 MFMAs per fp32 product, 2500 TF pipe), "
                                "K=16 layers on the fp32 pipe (157.3 TF)" if gm >= 1 else "all GEMMs on the fp32 pipe (157.3 TF)")),
               "second_kernel": (roofline_entry("k_decoder_wgrad2_x" if wm == 1 else "k_decoder_wgrad2", "wgrad2", wg_ms, P_local, gm, wm, True)
                                 if train_dec else None)}

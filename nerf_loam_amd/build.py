@@ -24,6 +24,28 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+SVO_TORCH_SRC = os.path.join(HERE, "torch_ext", "svo_torch.cpp")
+SVO_TORCH_OUT = os.path.join(HERE, "libnl_svo_torch.so")
+
+
+def build_torch_ext(force=False):
+    """libnl_svo_torch.so: TORCH_LIBRARY(svo, ...) - the reference's torch.classes.svo.Octree / torch.ops.svo.encode names -
+    over the C ABI of libnerfloam_hip.so (host code only: g++ with the torch headers, linked against the library next to it)"""
+    deps = [SVO_TORCH_SRC, OUT, os.path.join(HERE, "..", "include", "nerfloam_hip.h")]
+    if not force and os.path.exists(SVO_TORCH_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(SVO_TORCH_OUT) for d in deps):
+        return SVO_TORCH_OUT
+    import torch
+    from torch.utils import cpp_extension as ce
+    inc = [f"-I{p}" for p in ce.include_paths()] + ["-I" + os.path.join(HERE, "..", "include")]
+    libdir = ce.library_paths()[0]
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-w",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", *inc, SVO_TORCH_SRC,
+           "-L" + HERE, "-l:libnerfloam_hip.so", "-L" + libdir, "-ltorch", "-ltorch_cpu", "-lc10",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + libdir, "-o", SVO_TORCH_OUT]
+    subprocess.check_call(cmd)
+    return SVO_TORCH_OUT
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
@@ -50,3 +72,4 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_torch_ext(force="--force" in sys.argv))

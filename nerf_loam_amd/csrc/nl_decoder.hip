@@ -1070,7 +1070,7 @@ extern "C" {
 int nl_decoder_chain_fwd_bwd(const void* loss_scalars, const float* X, const float* params, const float* ws, const int* s_ray,
                              const float* s_depth, const float* cos_gt, const float* gt_dist, float* sdf, float* dsdf, float* dX,
                              float* partials, unsigned* relu2_nat, int nslabs, int train_decoder, int six_products, int* counters,
-                             void* stream);
+                             void* dbg, void* stream);
 int nl_decoder_chain_forward(const float* X, const float* params, const float* ws, int P, float* sdf, int nblocks, int six_products,
                              void* stream);
 int nl_decoder_chain_reduce(const float* partials, int nslabs, const float* params, float* grad_out, void* stream);
@@ -1117,7 +1117,7 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
     a.dbg = g_dec_dbg;
     if (g_gemm_mode == 3)
         return nl_decoder_chain_fwd_bwd(loss_scalars, X, params, W2T, s_ray, s_depth, cos_gt, gt_dist, sdf, dsdf, dX, partials, relu2_mask,
-                                        nslabs, train_decoder, g_chain_six, counters, stream);
+                                        nslabs, train_decoder, g_chain_six, counters, g_dec_dbg, stream);
     const dim3 g(nslabs), b(DEC_THREADS);
     if (g_gemm_mode == 2) {
         if (train_decoder) hipLaunchKernelGGL((k_decoder<true, true, 6>), g, b, 0, (hipStream_t)stream, a);

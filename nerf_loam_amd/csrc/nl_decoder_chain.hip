@@ -49,7 +49,10 @@ struct ChainArgs {
     float* partials;            // [gridDim.x][NL_DEC_PARAMS]: W1, b1, b3 regions (train)
     unsigned* relu2_nat;        // [ceil(P/32)][256]: bit b of word (tile, unit) = ReLU of H2[32 tile + b][unit] (train)
     double* dcounters;
+    long long* dbg;             // optional [16 tiles][16] shader-clock stamps of workgroup 0 / wave 0 (profiling aid)
 };
+#define CH_STAMP(slot)                                                                          \
+    do { if (a.dbg && blockIdx.x == 0 && tid == 0 && tile_no < 16) a.dbg[tile_no * 16 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 __device__ __forceinline__ uint4 ch_bload4(rsrc_t r, int voff, int soff)
 {
@@ -110,7 +113,9 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_decoder_chain(ChainArgs a)
     const int mw_r = (l31 & 3) + 4 * (l31 >> 3), mw_hi = (l31 >> 2) & 1;
 
     const int ntiles = (P + 31) >> 5;
-    for (int tile = blockIdx.x * 4 + w; tile < ntiles; tile += gridDim.x * 4) {
+    int tile_no = 0;
+    for (int tile = blockIdx.x * 4 + w; tile < ntiles; tile += gridDim.x * 4, ++tile_no) {
+        CH_STAMP(0);
         const int row0 = tile << 5, g = row0 + l31;
         const bool live = g < P;
         // ---------------- inputs: this lane's sample, channels 8 lh .. 8 lh + 7 ----------------
@@ -135,6 +140,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_decoder_chain(ChainArgs a)
 #pragma unroll
             for (int p = 0; p < 3; ++p) aq[j][p] = ch_bload4(rsA, voff, p * CH_PLANE_BYTES + j * 1024);
 
+        CH_STAMP(1);
         // ---------------- layer 1: H1^T = relu(W1 X^T + b1), split into three bf16 operand planes (registers) ----------------
         uint4 hb[16][3];
         unsigned m1w[4] = {0u, 0u, 0u, 0u};
@@ -167,6 +173,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_decoder_chain(ChainArgs a)
             m1w[ut >> 1] |= bits << (16 * (ut & 1));
         }
 
+        CH_STAMP(2);
         // ---------------- layer 2 + output layer: s = w3 . relu(W2 H1 + b2) + b3, H2 never stored ----------------
         float spart = 0.f;
         unsigned m2w[4] = {0u, 0u, 0u, 0u};
@@ -214,6 +221,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_decoder_chain(ChainArgs a)
             m2w[2] = (m2w[2] >> 16) | (m2w[3] << 16); m2w[3] = (m2w[3] >> 16) | (bits << 16);
             if (MODE == 2 && lh == 0) a.relu2_nat[(size_t)tile * NL_W + 32 * nt + l31] = mword;
         }
+        CH_STAMP(3);
         const float sv = (spart + __shfl_xor(spart, 32)) + b3;
         if (MODE == 0) {
             if (live && lh == 0) a.sdf[g] = sv;
@@ -232,6 +240,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_decoder_chain(ChainArgs a)
                 if (MODE == 2) aB3 += ds;
             }
         }
+        CH_STAMP(4);
         // ---------------- dgrad: dH1^T = ((w3 W2)^T mask^T) * dsdf * [H1 > 0]; layer-1 backward per 32-unit tile ----------------
         uint4 mf[16];
 #pragma unroll
@@ -263,6 +272,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_decoder_chain(ChainArgs a)
                 for (int pa = 0; pa < 3; ++pa)
                     gacc = MFMA_BF16(__builtin_bit_cast(bf16x8, aq[s % CH_RING][pa]), __builtin_bit_cast(bf16x8, mf[s]), gacc);
             }
+            if (kt == 0) CH_STAMP(5);                            // after the first tile's 48 MFMAs: stream start-up + one dgrad tile
             const unsigned b1bits = (m1w[kt >> 1] >> (16 * (kt & 1))) & 0xFFFFu;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -302,7 +312,9 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_decoder_chain(ChainArgs a)
                 aw[0] = w0; aw[64] = w1; ab[0] = b0; ab[64] = b1;
             }
             __builtin_amdgcn_wave_barrier();
+            if (kt == 0) CH_STAMP(6);                            // one tile's layer-1 backward
         }
+        CH_STAMP(7);
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -404,12 +416,13 @@ extern "C" {
 int nl_decoder_chain_fwd_bwd(const void* loss_scalars, const float* X, const float* params, const float* ws, const int* s_ray,
                              const float* s_depth, const float* cos_gt, const float* gt_dist, float* sdf, float* dsdf, float* dX,
                              float* partials, unsigned* relu2_nat, int nslabs, int train_decoder, int six_products, int* counters,
-                             void* stream)
+                             void* dbg, void* stream)
 {
     ChainArgs a;
     a.ls = (const NlLossScalars*)loss_scalars; a.P = 0; a.X = X; a.params = params; a.ws = ws; a.s_ray = s_ray; a.s_depth = s_depth;
     a.cos_gt = cos_gt; a.gt_dist = gt_dist; a.sdf = sdf; a.dsdf = dsdf; a.dX = dX; a.partials = partials; a.relu2_nat = relu2_nat;
     a.dcounters = (double*)(counters + NL_CNT_INTS);
+    a.dbg = (long long*)dbg;
     const dim3 g(nslabs), b(CH_THREADS);
     hipStream_t st = (hipStream_t)stream;
     if (train_decoder) {
@@ -429,6 +442,7 @@ int nl_decoder_chain_forward(const float* X, const float* params, const float* w
     ChainArgs a;
     a.ls = nullptr; a.P = P; a.X = X; a.params = params; a.ws = ws; a.s_ray = nullptr; a.s_depth = nullptr; a.cos_gt = nullptr;
     a.gt_dist = nullptr; a.sdf = sdf; a.dsdf = nullptr; a.dX = nullptr; a.partials = nullptr; a.relu2_nat = nullptr; a.dcounters = nullptr;
+    a.dbg = nullptr;
     const int need = nl_div_up(nl_div_up(P, 32), 4);
     const dim3 g(nblocks < need ? nblocks : need), b(CH_THREADS);
     if (six_products) hipLaunchKernelGGL((k_decoder_chain<0, 6>), g, b, 0, (hipStream_t)stream, a);

@@ -31,6 +31,23 @@ def encode(coords):
     return torch.from_numpy(key.astype(np.int64)).reshape(-1, 1)
 
 
+def load_torch_library():
+    """Register the reference's TorchScript names - torch.classes.svo.Octree, torch.classes.svo.Octant, torch.ops.svo.encode
+    (bindings.cpp:4-31) - from nerf_loam_amd/libnl_svo_torch.so and return its path.  The reference loads its own build with
+    `torch.classes.load_library(<absolute path>)` (src/mapping.py:19-20): pointing that line at the returned path is the whole
+    change its Mapping needs.  (This module's `Octree` below is the same octree behind a plain Python class, with the extra
+    incremental-export methods the device-resident Mapping uses.)"""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnl_svo_torch.so")
+    if not os.path.exists(path):
+        from . import build
+        build.build()
+        build.build_torch_ext()
+    L.lib()                                                  # libnerfloam_hip.so first (torch's HIP runtime before ours, _lib.lib())
+    torch.classes.load_library(path)
+    return path
+
+
 class Octree:
     def __init__(self):
         self._h = None

