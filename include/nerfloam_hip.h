@@ -94,6 +94,15 @@ int nl_select_rays(int M, int n_select, unsigned seed, const float* rays_d, cons
                    float* out_rays_d, float* out_points, float* out_cos, int* out_frame_id, unsigned char* mask_out,
                    int* workspace, void* stream);
 
+/* The same selection for ALL frames of a call in two launches (n << M: a window around the expected threshold key, exact k-th largest
+ * among the few candidates inside it; same subset as nl_select_rays).  Host arrays of F entries each; out_off[f] = first output
+ * slot of frame f.  Returns 4 (capacity) for shapes outside the method's range - fall back to nl_select_rays per frame.
+ * workspace: NL_SELECT_BATCH_WS_INTS(F) ints, zero-filled ONCE at allocation; parity alternates 0 / 1 from call to call. */
+#define NL_SELECT_BATCH_WS_INTS(F) ((F) * (8 + 4 * 128 + 2 * 4096))
+int nl_select_rays_batch(int F, const int* M, const int* n_select, const unsigned* seed, const float* const* rays_d,
+                         const float* const* points, const float* const* cos_in, unsigned char* const* mask_out, const int* out_off,
+                         float* out_rays_d, float* out_points, float* out_cos, int* out_frame_id, int* workspace, int parity, void* stream);
+
 /* ray_sample: voxel_helpers.py:571-598 + :262-347 + sample_gpu.cu:133-239.
  * emit = 0: per-ray sample count, S_max and the geometry-only loss normalisers (criterion.py:67-88);
  * emit = 1: compacted (voxel, depth, dist, ray) records at samp_off[ray] (capacity-checked).

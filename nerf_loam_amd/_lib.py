@@ -15,6 +15,8 @@ NL_LOSS_SCALARS_BYTES = 48
 NL_ADAM_STATE_BYTES = 112
 NL_DEC_PARAMS = 70401
 NL_DEC_WS_FLOATS = 458752        # decoder weight workspace: W2^T fp32 + 4 x 3 bf16 operand planes (include/nerfloam_hip.h)
+NL_SEL_BATCH_WS_INTS_PER_FRAME = 8 + 4 * 128 + 2 * 4096     # NL_SELECT_BATCH_WS_INTS(1)
+NL_SEL_MAX_FRAMES = 8
 NL_C = 16
 NL_W = 256
 OFF_W1, OFF_B1 = 0, 256 * 16
@@ -62,6 +64,7 @@ _SIGS = {
     "nl_geometry_set_sampler_mode": ([_I], _I),
     "nl_dist_merge_counters": ([_P, _I, _I, _I, _P, _P], _I),
     "nl_select_rays": ([_I, _I, ctypes.c_uint, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P], _I),
+    "nl_select_rays_batch": ([_I] + [_P] * 13 + [_I, _P], _I),
     "nl_decoder_set_gemm_mode": ([_I], _I),
     "nl_decoder_get_gemm_mode": ([], _I),
     "nl_decoder_set_wgrad2_mode": ([_I], _I),

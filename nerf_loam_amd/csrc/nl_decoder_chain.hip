@@ -113,26 +113,31 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_decoder_chain(ChainArgs a)
     const int mw_r = (l31 & 3) + 4 * (l31 >> 3), mw_hi = (l31 >> 2) & 1;
 
     const int ntiles = (P + 31) >> 5;
+    // inputs of a tile: this lane's sample (channels 8 lh .. 8 lh + 7) and its loss geometry; the NEXT tile's are fetched under the
+    // current tile's backward phase
+    float4 nx0 = make_float4(0.f, 0.f, 0.f, 0.f), nx1 = nx0;
+    float ncz = 0.f, ncd = 0.f;
+    auto fetch_inputs = [&](int tile) {
+        const int gg = (tile << 5) + l31;
+        nx0 = make_float4(0.f, 0.f, 0.f, 0.f); nx1 = nx0; ncz = 0.f; ncd = 0.f;
+        if (tile < ntiles && gg < P) {
+            const float4* xp = reinterpret_cast<const float4*>(a.X + (size_t)gg * NL_C + 8 * lh);
+            nx0 = xp[0]; nx1 = xp[1];
+            if (MODE >= 1) {
+                const int ray = a.s_ray[gg];
+                ncz = a.s_depth[gg] * a.cos_gt[ray]; ncd = a.gt_dist[ray];
+            }
+        }
+    };
+    fetch_inputs(blockIdx.x * 4 + w);
     int tile_no = 0;
     for (int tile = blockIdx.x * 4 + w; tile < ntiles; tile += gridDim.x * 4, ++tile_no) {
         CH_STAMP(0);
         const int row0 = tile << 5, g = row0 + l31;
         const bool live = g < P;
-        // ---------------- inputs: this lane's sample, channels 8 lh .. 8 lh + 7 ----------------
-        float xf[8];
-        {
-            float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
-            if (live) {
-                const float4* xp = reinterpret_cast<const float4*>(a.X + (size_t)g * NL_C + 8 * lh);
-                x0 = xp[0]; x1 = xp[1];
-            }
-            xf[0] = x0.x; xf[1] = x0.y; xf[2] = x0.z; xf[3] = x0.w; xf[4] = x1.x; xf[5] = x1.y; xf[6] = x1.z; xf[7] = x1.w;
-        }
-        float cz = 0.f, cd = 0.f;
-        if (MODE >= 1 && live) {
-            const int ray = a.s_ray[g];
-            cz = a.s_depth[g] * a.cos_gt[ray]; cd = a.gt_dist[ray];
-        }
+        const float xf[8] = {nx0.x, nx0.y, nx0.z, nx0.w, nx1.x, nx1.y, nx1.z, nx1.w};
+        const float cz = ncz, cd = ncd;
+        if (MODE == 0) fetch_inputs(tile + gridDim.x * 4);
         // first k-steps of the forward weight stream: in flight under layer 1
         uint4 aq[CH_RING][3];
 #pragma unroll
@@ -242,6 +247,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_decoder_chain(ChainArgs a)
         }
         CH_STAMP(4);
         // ---------------- dgrad: dH1^T = ((w3 W2)^T mask^T) * dsdf * [H1 > 0]; layer-1 backward per 32-unit tile ----------------
+        fetch_inputs(tile + gridDim.x * 4);                     // the next tile's inputs arrive under this tile's backward
         uint4 mf[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) mf[s] = sLut[(m2w[s >> 2] >> (8 * (s & 3))) & 0xFFu];

@@ -81,6 +81,131 @@ __global__ void k_sel_gather(int M, const int* __restrict__ flags, const int* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-launch selection for n << M (the live shapes: 2048 / 4096 of ~131 072 returns per frame, several frames per call).
+// The keys are uniform, so the n-th largest one is known in advance up to the fluctuation of a binomial count: T0 = 2^32 (1 - n/M),
+// +- a window of W = 16 sigma + 64 keys' worth, sigma = sqrt(n (1 - n/M)).  Pass A classifies every key - above the window: surely
+// selected (counted per wave, the waves own contiguous index ranges), inside it: a candidate (appended to a small list, a few
+// hundred to a few thousand keys) - and pass B finds the exact threshold among the candidates (radix select in LDS, every
+// workgroup for itself), derives each wave's output rank base from the per-wave counts and the candidates below its range, and
+// emits the selected rays in dataset order.  Same subset as the radix path: the n largest keys, exactly.  All frames of a call
+// go through the same two launches (grid.y = frame).  If a count ever fell outside the window (probability ~1e-50) the fail
+// word is set and the caller falls back to nl_select_rays.
+// ---------------------------------------------------------------------------------------------
+#define SEL_MAX_FRAMES 8
+#define SEL_CAP 4096                                    // candidates per frame (LDS: 16 KB keys + 16 KB indices)
+#define SEL_MAXB 128                                    // workgroups per frame
+#define SEL_WS_INTS_PER_FRAME (8 + 4 * SEL_MAXB + 2 * SEL_CAP)      // [cand_n[2], fail, pad..][sure per wave][cand keys][cand idx]
+
+struct SelFrame {
+    const float* d; const float* p; const float* c; unsigned char* mask;
+    int M, n, out_off, frame; unsigned seed, lo, hi; int nblk, wchunk;
+};
+struct SelArgs { SelFrame f[SEL_MAX_FRAMES]; int* ws; float* out_d; float* out_p; float* out_c; int* out_frame; int parity; };
+
+__global__ __launch_bounds__(256) void k_sel_window_a(SelArgs a)
+{
+    const SelFrame fr = a.f[blockIdx.y];
+    if ((int)blockIdx.x >= fr.nblk) return;
+    int* ws = a.ws + (size_t)blockIdx.y * SEL_WS_INTS_PER_FRAME;
+    const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wstart = gw * fr.wchunk, wend = min(fr.M, wstart + fr.wchunk);
+    int sure = 0;
+    for (int i0 = wstart; i0 < wend; i0 += 64) {
+        const int i = i0 + lane;
+        const unsigned key = i < wend ? nl_select_key(fr.seed, (unsigned)i) : 0u;
+        const bool live = i < wend;
+        sure += __popcll(__ballot(live && key > fr.hi));
+        if (live && key >= fr.lo && key <= fr.hi) {
+            const int pos = atomicAdd(&ws[a.parity], 1);
+            if (pos < SEL_CAP) { ws[8 + 4 * SEL_MAXB + pos] = (int)key; ws[8 + 4 * SEL_MAXB + SEL_CAP + pos] = i; }
+        }
+    }
+    if (lane == 0) ws[8 + gw] = sure;
+}
+
+__global__ __launch_bounds__(256) void k_sel_window_b(SelArgs a)
+{
+    __shared__ unsigned s_key[SEL_CAP];
+    __shared__ int s_idx[SEL_CAP];
+    __shared__ int s_hist[256];
+    __shared__ int s_red[8];
+    __shared__ unsigned s_T;
+    __shared__ int s_take;
+    const SelFrame fr = a.f[blockIdx.y];
+    if ((int)blockIdx.x >= fr.nblk) return;
+    int* ws = a.ws + (size_t)blockIdx.y * SEL_WS_INTS_PER_FRAME;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, gw = blockIdx.x * 4 + w;
+    const int cand_n = ws[a.parity];
+    const int C = min(cand_n, SEL_CAP);
+    if (blockIdx.x == 0 && tid == 0) ws[a.parity ^ 1] = 0;       // the other slot: last read by the previous call's pass B, used by the next call
+    for (int i = tid; i < C; i += 256) { s_key[i] = (unsigned)ws[8 + 4 * SEL_MAXB + i]; s_idx[i] = ws[8 + 4 * SEL_MAXB + SEL_CAP + i]; }
+    // surely selected keys: all of them, and those in the waves before this one
+    int tot = 0, before = 0;
+    for (int j = tid; j < 4 * fr.nblk; j += 256) { const int v = ws[8 + j]; tot += v; }
+    for (int j = lane; j < gw; j += 64) before += ws[8 + j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { tot += __shfl_xor(tot, off); before += __shfl_xor(before, off); }
+    if (lane == 0) s_red[w] = tot;
+    __syncthreads();
+    const int total_sure = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    const int k = fr.n - total_sure;                             // candidates to take: the k largest of them
+    const bool fail = k < 0 || k > C || cand_n > SEL_CAP;
+    if (fail && blockIdx.x == 0 && tid == 0) ws[2] = 1;
+    // exact k-th largest candidate key: 4-pass radix select over the LDS copy (k == 0: nothing is taken)
+    unsigned prefix = 0u; int rem = k;
+    if (k > 0 && !fail) {
+        for (int pass = 3; pass >= 0; --pass) {
+            s_hist[tid] = 0;
+            __syncthreads();
+            const int shift = 8 * pass;
+            const unsigned hi_mask = pass == 3 ? 0u : (0xFFFFFFFFu << (shift + 8));
+            for (int i = tid; i < C; i += 256) {
+                const unsigned key = s_key[i];
+                if ((key & hi_mask) == (prefix & hi_mask)) atomicAdd(&s_hist[(key >> shift) & 255u], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int d = 255, above = 0;
+                for (; d > 0; --d) { if (above + s_hist[d] >= rem) break; above += s_hist[d]; }
+                s_T = prefix | ((unsigned)d << shift); s_take = rem - above;
+            }
+            __syncthreads();
+            prefix = s_T; rem = s_take;
+            __syncthreads();
+        }
+    }
+    const bool take = k > 0 && !fail;
+    const unsigned T = prefix;
+    // selected candidates in front of this wave's range
+    const int wstart = gw * fr.wchunk, wend = min(fr.M, wstart + fr.wchunk);
+    int cb = 0;
+    if (take) for (int i = lane; i < C; i += 64) cb += (s_key[i] >= T && s_idx[i] < wstart) ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cb += __shfl_xor(cb, off);
+    int rank = before + cb;
+    const int cap = fr.n;
+    for (int i0 = wstart; i0 < wend; i0 += 64) {
+        const int i = i0 + lane;
+        const bool live = i < wend;
+        const unsigned key = live ? nl_select_key(fr.seed, (unsigned)i) : 0u;
+        const bool sel = live && (key > fr.hi || (take && key >= T && key >= fr.lo));
+        const unsigned long long bal = __ballot(sel);
+        if (live && fr.mask) fr.mask[i] = sel ? 1 : 0;
+        if (sel) {
+            const int o = rank + __popcll(bal & ((1ull << lane) - 1ull));
+            if (o < cap) {
+                const size_t oo = (size_t)(fr.out_off + o);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { a.out_d[3 * oo + c] = fr.d[3 * (size_t)i + c]; a.out_p[3 * oo + c] = fr.p[3 * (size_t)i + c]; }
+                a.out_c[oo] = fr.c[i];
+                if (a.out_frame) a.out_frame[oo] = fr.frame;
+            }
+        }
+        rank += __popcll(bal);
+    }
+}
+
 extern "C" {
 
 int nl_select_rays(int M, int n_select, unsigned seed, const float* rays_d, const float* points, const float* cos_in, int frame,
@@ -109,6 +234,44 @@ int nl_select_rays(int M, int n_select, unsigned seed, const float* rays_d, cons
     if (rc != NL_OK) return rc;
     hipLaunchKernelGGL(k_sel_gather, dim3(blocks), dim3(256), 0, st, M, flags, rank, rays_d, points, cos_in, frame,
                        n_select < M ? n_select : M, out_rays_d, out_points, out_cos, out_frame_id);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+/* All frames of a call in two launches (k_sel_window_a / _b above).  Returns NL_ERR_CAPACITY when a frame's shape is outside the
+ * window method's range (n close to M, or a candidate window above SEL_CAP keys): use nl_select_rays per frame then.
+ * workspace: NL_SELECT_BATCH_WS_INTS(F) ints, ZERO-FILLED once by the caller at allocation; parity alternates 0 / 1 between calls
+ * (the candidate counter of one call is cleared by the next one's second pass).  ws[f][2] != 0 afterwards = the window was missed
+ * (never observed; ~1e-50) and the selection of that call is incomplete. */
+int nl_select_rays_batch(int F, const int* M, const int* n_select, const unsigned* seed, const float* const* rays_d,
+                         const float* const* points, const float* const* cos_in, unsigned char* const* mask_out, const int* out_off,
+                         float* out_rays_d, float* out_points, float* out_cos, int* out_frame_id, int* workspace, int parity, void* stream)
+{
+    if (F <= 0 || F > SEL_MAX_FRAMES || !M || !n_select || !seed || !rays_d || !points || !cos_in || !out_off || !out_rays_d || !out_points ||
+        !out_cos || !workspace || (parity != 0 && parity != 1))
+        return NL_ERR_INVALID_ARG;
+    SelArgs a;
+    int max_blk = 1;
+    for (int f = 0; f < F; ++f) {
+        const int m = M[f], n = n_select[f];
+        if (m <= 0 || n <= 0 || !rays_d[f] || !points[f] || !cos_in[f]) return NL_ERR_INVALID_ARG;
+        if (n >= m) return NL_ERR_CAPACITY;
+        const double p = (double)n / (double)m, sigma = sqrt((double)n * (1.0 - p)), W = 16.0 * sigma + 64.0;
+        if (2.0 * W + 64.0 > (double)SEL_CAP) return NL_ERR_CAPACITY;
+        const double T0 = 4294967296.0 * (1.0 - p), delta = W / (double)m * 4294967296.0;
+        const double lo = T0 - delta, hi = T0 + delta;
+        if (lo < 1.0 || hi > 4294967294.0) return NL_ERR_CAPACITY;
+        SelFrame& fr = a.f[f];
+        fr.d = rays_d[f]; fr.p = points[f]; fr.c = cos_in[f]; fr.mask = mask_out ? mask_out[f] : nullptr;
+        fr.M = m; fr.n = n; fr.out_off = out_off[f]; fr.frame = f; fr.seed = seed[f]; fr.lo = (unsigned)lo; fr.hi = (unsigned)hi;
+        int nblk = nl_div_up(m, 1024); if (nblk > SEL_MAXB) nblk = SEL_MAXB;
+        fr.nblk = nblk;
+        fr.wchunk = nl_div_up(nl_div_up(m, 4 * nblk), 64) * 64;
+        if (nblk > max_blk) max_blk = nblk;
+    }
+    a.ws = workspace; a.out_d = out_rays_d; a.out_p = out_points; a.out_c = out_cos; a.out_frame = out_frame_id; a.parity = parity;
+    hipLaunchKernelGGL(k_sel_window_a, dim3(max_blk, F), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_sel_window_b, dim3(max_blk, F), dim3(256), 0, (hipStream_t)stream, a);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

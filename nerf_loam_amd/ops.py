@@ -172,6 +172,22 @@ def select_rays(M, n_select, seed, rays_d, points, cos_in, frame, out_rays_d, ou
                                  stream_ptr()), "nl_select_rays")
 
 
+def select_rays_batch(Ms, ns, seeds, rays_d, points, cos_in, masks, out_off, out_rays_d, out_points, out_cos, out_frame_id, workspace, parity):
+    """all frames of a call in two launches; returns False (nothing launched) when a frame's shape is outside the window method's
+    range - the caller then uses select_rays per frame"""
+    F = len(Ms)
+    I, U, PP = ctypes.c_int * F, ctypes.c_uint * F, ctypes.c_void_p * F
+    rc = L.lib().nl_select_rays_batch(F, I(*[int(m) for m in Ms]), I(*[int(n) for n in ns]), U(*[int(s) & 0xFFFFFFFF for s in seeds]),
+                                      PP(*[t.data_ptr() for t in rays_d]), PP(*[t.data_ptr() for t in points]),
+                                      PP(*[t.data_ptr() for t in cos_in]), PP(*[(t.data_ptr() if t is not None else None) for t in masks]),
+                                      I(*[int(x) for x in out_off]), ptr(out_rays_d), ptr(out_points), ptr(out_cos), ptr(out_frame_id),
+                                      ptr(workspace), int(parity), stream_ptr())
+    if rc == 4:
+        return False
+    check(rc, "nl_select_rays_batch")
+    return True
+
+
 def scan_hit_rays(hit_count, hit_rank, ray_of_rank, N, total_out, total_out2, workspace):
     check(L.lib().nl_scan_hit_rays(ptr(hit_count), ptr(hit_rank), ptr(ray_of_rank), int(N), ptr(total_out), ptr(total_out2), ptr(workspace),
                                    stream_ptr()), "nl_scan_hit_rays")

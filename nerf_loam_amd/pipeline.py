@@ -257,6 +257,24 @@ class SdfEngine:
         Deterministic in (seed, M, n_rays).  Returns the boolean masks (device) when want_masks."""
         total = 0
         masks = []
+        # every frame in the same two launches when the shapes allow it (n << M: the live configurations)
+        Ms = [int(sc["dirs"].shape[0]) for sc in scans]
+        ns = [min(int(n_rays), M) for M in Ms]
+        if sum(ns) > self.N_cap:
+            raise L.NerfLoamHipError(f"{sum(ns)} rays exceed engine capacity {self.N_cap}")
+        if len(scans) <= L.NL_SEL_MAX_FRAMES and all(sc["dirs"].is_contiguous() and sc["points"].is_contiguous() for sc in scans):
+            if getattr(self, "_selb_ws", None) is None:
+                self._selb_ws = torch.zeros(L.NL_SEL_MAX_FRAMES * L.NL_SEL_BATCH_WS_INTS_PER_FRAME, dtype=I32, device=self.dev)
+                self._selb_parity = 0
+            mks = [sc.get("mask_u8") if sc.get("mask_u8") is not None else (torch.empty(M, dtype=torch.uint8, device=self.dev) if want_masks else None)
+                   for sc, M in zip(scans, Ms)]
+            offs = [sum(ns[:f]) for f in range(len(ns))]
+            if ops.select_rays_batch(Ms, ns, [(int(seed) * 1000003 + f) & 0xFFFFFFFF for f in range(len(scans))],
+                                     [sc["dirs"] for sc in scans], [sc["points"] for sc in scans], [sc["cos"] for sc in scans], mks, offs,
+                                     self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self._selb_ws, self._selb_parity):
+                self._selb_parity ^= 1
+                self.N = sum(ns)
+                return mks if want_masks else None
         for f, sc in enumerate(scans):
             M = int(sc["dirs"].shape[0])
             n = min(int(n_rays), M)
@@ -414,6 +432,10 @@ class SdfEngine:
         """(steps taken, steps skipped as unusable, overflow seen) since begin_call - ONE small read-back per call instead of one
         per iteration"""
         st = self.adam_state[:4].cpu().numpy()
+        ws = getattr(self, "_selb_ws", None)
+        if ws is not None and bool(ws.view(L.NL_SEL_MAX_FRAMES, -1)[:, 2].any().item()):
+            raise L.NerfLoamHipError("on-device ray selection missed its threshold window (nl_select_rays_batch): the selected ray set of "
+                                     "this call is incomplete")
         return int(st[0]), int(st[2]), bool(st[3])
 
     # ------------------------------------------------------------------ hipGraph

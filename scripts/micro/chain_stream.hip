@@ -128,16 +128,125 @@ static void run(const char* tag, const unsigned short* Wf, const unsigned short*
     (void)hipFree(out); (void)hipFree(cyc);
 }
 
+
+// LDS-shared weight stream: the four waves of the workgroup load each fragment ONCE (LDS-DMA, 12 fragments per wave and stage of
+// 16 k-steps), synchronise once per stage, and read their A operands from LDS (ds_read_b128).  Two 48 KB stages.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+template <int SUB>
+__global__ __launch_bounds__(256, 1) void k_chain_lds(const unsigned short* Wf, const unsigned short* Wd, const uint4* Hinit, float* out,
+                                                      long long* cyc, int tiles)
+{
+    __shared__ __attribute__((aligned(16))) uint4 ring[2][48][64];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint4 hb[16][3];
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) hb[s][p] = Hinit[(s * 3 + p) * 64 + lane];
+    f32x16 total;
+    for (int r = 0; r < 16; ++r) total[r] = 0.f;
+    // stage j of a tile: j < 8 forward tile j (planes Wf), else dgrad tile j - 8 (planes Wd); fragment f = 3 s + p
+    auto issue = [&](int j, int buf) {
+        const unsigned short* base = (j & 8) ? Wd : Wf;
+        const int t = j & 7;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int f = w * 12 + i, s = f / 3, p = f % 3;
+            const char* src = reinterpret_cast<const char*>(base) + (size_t)p * PLANE + (size_t)(t * 16 + s) * 1024 + lane * 16;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)&ring[buf][f][0], 16, 0, 0);
+        }
+    };
+    issue(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0)
+    __syncthreads();
+    const long long t0 = __builtin_readcyclecounter();
+    for (int tile = 0; tile < tiles; ++tile) {
+#pragma unroll 1
+        for (int j = 0; j < 16; ++j) {
+            issue((j + 1) & 15, (j + 1) & 1);
+            const uint4 (*rb)[64] = ring[j & 1];
+            // A fragments of k-step s + 1 are read from LDS while the MFMAs of k-step s run (one wave per SIMD: nobody else hides it)
+            uint4 af[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[0][p] = rb[p][lane];
+            if (j < 8) {
+                f32x16 c;
+                for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    if (s + 1 < 16) {
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) af[(s + 1) & 1][p] = rb[3 * (s + 1) + p][lane];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int pa = 0; pa < 3; ++pa)
+#pragma unroll
+                        for (int pb = 0; pb < 3; ++pb) c = MFMA(__builtin_bit_cast(bf16x8, af[s & 1][pa]), __builtin_bit_cast(bf16x8, hb[s][pb]), c);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) total[r] += c[r] > 0.f ? c[r] : 0.f;
+            } else {
+                f32x16 c[SUB];
+#pragma unroll
+                for (int u = 0; u < SUB; ++u) for (int r = 0; r < 16; ++r) c[u][r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    if (s + 1 < 16) {
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) af[(s + 1) & 1][p] = rb[3 * (s + 1) + p][lane];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+#pragma unroll
+                        for (int u = 0; u < SUB; ++u) c[u] = MFMA(__builtin_bit_cast(bf16x8, af[s & 1][p]), __builtin_bit_cast(bf16x8, hb[u][0]), c[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < SUB; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) total[r] += c[u][r];
+            }
+            __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0): this wave's DMA pieces of the next stage have landed
+            __syncthreads();
+        }
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    float sres = 0.f;
+    for (int r = 0; r < 16; ++r) sres += total[r];
+    out[blockIdx.x * 256 + tid] = sres;
+    if (lane == 0) cyc[blockIdx.x * 4 + (tid >> 6)] = t1 - t0;
+}
+
+template <int SUB>
+static void run_lds(const char* tag, const unsigned short* Wf, const unsigned short* Wd, const uint4* Hinit)
+{
+    const int blocks = 256, tiles = 40;
+    float* out; long long* cyc;
+    (void)hipMalloc(&out, sizeof(float) * 256 * blocks); (void)hipMalloc(&cyc, 8 * 4 * blocks);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((k_chain_lds<SUB>), dim3(blocks), dim3(256), 0, 0, Wf, Wd, Hinit, out, cyc, 2);
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((k_chain_lds<SUB>), dim3(blocks), dim3(256), 0, 0, Wf, Wd, Hinit, out, cyc, tiles);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    long long h[8]; (void)hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost);
+    const double mf = (1152.0 + 384.0 * SUB) * tiles;
+    printf("%-40s        : %6.1f cycles/MFMA (ideal 32), %8.0f cycles/wave-tile, %.3f ms  [err %s]\n", tag, (double)h[0] / mf, (double)h[0] / tiles, ms,
+           hipGetErrorString(hipGetLastError()));
+    (void)hipFree(out); (void)hipFree(cyc);
+}
+
 int main()
 {
     unsigned short *Wf, *Wd; uint4* H;
     (void)hipMalloc(&Wf, 3 * PLANE); (void)hipMalloc(&Wd, 3 * PLANE); (void)hipMalloc(&H, 48 * 64 * 16);
     (void)hipMemset(Wf, 0, 3 * PLANE); (void)hipMemset(Wd, 0, 3 * PLANE); (void)hipMemset(H, 0, 48 * 64 * 16);
     run<2, false, 1>("no loads, dgrad 32 samples", Wf, Wd, H);
-    run<2, true, 1>("weights from L2, dgrad 32 samples", Wf, Wd, H);
     run<4, true, 1>("weights from L2, dgrad 32 samples", Wf, Wd, H);
-    run<8, true, 1>("weights from L2, dgrad 32 samples", Wf, Wd, H);
     run<4, true, 2>("weights from L2, dgrad 64 samples", Wf, Wd, H);
-    run<8, true, 2>("weights from L2, dgrad 64 samples", Wf, Wd, H);
+    run_lds<1>("weights shared through LDS, dgrad 32", Wf, Wd, H);
+    run_lds<2>("weights shared through LDS, dgrad 64", Wf, Wd, H);
     return 0;
 }

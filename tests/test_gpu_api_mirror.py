@@ -119,6 +119,50 @@ def test_device_ray_selection_is_the_exact_top_n_subset(M, n):
         assert abs(hits.mean() - 40 * n / M) < 1e-9 and hits.max() <= 8     # Binomial(40, 1/64): P(> 8) ~ 1e-8 per ray
 
 
+@pytest.mark.parametrize("shapes", [[(131072, 2048)], [(131072, 4096)] * 4, [(90001, 2048), (131072, 2048), (65536, 1024)], [(20000, 512)]])
+def test_two_launch_selection_equals_the_radix_selection(shapes):
+    """nl_select_rays_batch (window around the expected threshold, all frames in two launches) picks exactly the subset
+    nl_select_rays (4-pass radix select per frame) picks: same rays, same order, same masks; its fail word stays clear"""
+    from nerf_loam_amd import _lib as L, ops, pipeline as P
+    rng = np.random.default_rng(len(shapes))
+    scans = []
+    for M, _ in shapes:
+        scans.append(dict(dirs=torch.from_numpy(rng.normal(size=(M, 3)).astype(np.float32)).cuda(),
+                          points=torch.from_numpy(rng.normal(size=(M, 3)).astype(np.float32)).cuda(),
+                          cos=torch.from_numpy(rng.random(M).astype(np.float32)).cuda()))
+    n = shapes[0][1]
+    assert all(nn == n for _, nn in shapes) or True
+    total = sum(nn for _, nn in shapes)
+    eng = P.SdfEngine(max_rays=total + 8, samples_per_ray_cap=4, max_frames=8)
+    for seed in (1, 77, 123456):
+        # reference: the radix path, frame by frame
+        ref = dict(d=torch.zeros(total, 3, device="cuda"), p=torch.zeros(total, 3, device="cuda"), c=torch.zeros(total, device="cuda"),
+                   f=torch.zeros(total, dtype=torch.int32, device="cuda"))
+        off, ref_masks = 0, []
+        for f, (sc, (M, nn)) in enumerate(zip(scans, shapes)):
+            ws = torch.empty(264 + 2 * M + (M + 1023) // 1024 + 8, dtype=torch.int32, device="cuda")
+            mk = torch.empty(M, dtype=torch.uint8, device="cuda")
+            ops.select_rays(M, nn, (seed * 1000003 + f) & 0xFFFFFFFF, sc["dirs"], sc["points"], sc["cos"], f, ref["d"][off:], ref["p"][off:],
+                            ref["c"][off:], ref["f"][off:], mk, ws)
+            ref_masks.append(mk); off += nn
+        if len({nn for _, nn in shapes}) == 1:
+            masks = eng.select_rays(scans, n, seed, want_masks=True)
+        else:                                                     # per-frame counts differ: drive the batch entry point directly
+            ws = torch.zeros(L.NL_SEL_MAX_FRAMES * L.NL_SEL_BATCH_WS_INTS_PER_FRAME, dtype=torch.int32, device="cuda")
+            masks = [torch.empty(M, dtype=torch.uint8, device="cuda") for M, _ in shapes]
+            offs = [sum(nn for _, nn in shapes[:f]) for f in range(len(shapes))]
+            assert ops.select_rays_batch([M for M, _ in shapes], [nn for _, nn in shapes], [(seed * 1000003 + f) & 0xFFFFFFFF for f in range(len(shapes))],
+                                         [sc["dirs"] for sc in scans], [sc["points"] for sc in scans], [sc["cos"] for sc in scans], masks, offs,
+                                         eng.rays_d_sensor, eng.points_gt, eng.cos_gt, eng.frame_id, ws, 0)
+            assert not ws.view(L.NL_SEL_MAX_FRAMES, -1)[:, 2].any()
+        torch.cuda.synchronize()
+        assert torch.equal(eng.rays_d_sensor[:total], ref["d"]) and torch.equal(eng.points_gt[:total], ref["p"])
+        assert torch.equal(eng.cos_gt[:total], ref["c"]) and torch.equal(eng.frame_id[:total], ref["f"])
+        for a_, b_ in zip(masks, ref_masks):
+            assert torch.equal(a_, b_)
+    assert getattr(eng, "_selb_ws", None) is None or not eng._selb_ws.view(L.NL_SEL_MAX_FRAMES, -1)[:, 2].any()
+
+
 def test_mapping_and_tracking_with_device_ray_selection():
     """the reference loop with rays re-drawn ON THE DEVICE every iteration (render_helpers.RAY_SELECTION = "device")"""
     from nerf_loam_amd import render_helpers as RH
