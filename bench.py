@@ -314,10 +314,12 @@ def api_path_bench(w, device, iters=20):
         cfg = P.IterConfig(step_size=step)
         eng.begin_call(m, w["dec"])
 
+        eng.bind(m, w["dec"], cfg, train_decoder=train, want_emb_grad=emb_grad, want_pose_grad=pose_grad, update_emb=emb_grad,
+                 update_decoder=train, update_pose=pose_grad)
+
         def loop():
             for _ in range(iters):
-                eng.forward_backward(m, w["dec"], cfg, train_decoder=train, want_emb_grad=emb_grad, want_pose_grad=pose_grad)
-                eng.optimiser_step(m, w["dec"], cfg, update_emb=emb_grad, update_decoder=train, update_pose=pose_grad)
+                eng.run_bound()                                  # one C call per iteration (nl_iteration), like the API path
         return timed(loop)
     out["engine_2048x1_ms_per_iter"] = engine_loop(2048, 1, 0.1, True, True, True)
     out["engine_4096x4_frozen_decoder_ms_per_iter"] = engine_loop(4096, 4, 0.1, False, True, False)
@@ -361,6 +363,16 @@ def pose_refine_bench(w, device, steps=200):
             one()
         torch.cuda.synchronize()
         out[f"ms_per_step_{mode}"] = (time.perf_counter() - t0) / steps * 1e3
+    eng.graph = None
+    eng.bind(w["map"], w["dec"], cfg, **flags)
+    for _ in range(10):
+        eng.run_bound()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.run_bound()
+    torch.cuda.synchronize()
+    out["ms_per_step_one_c_call"] = (time.perf_counter() - t0) / steps * 1e3
     # the reference's track_frame re-draws its 2048 rays every iteration (LidarFrame.sample_rays on the CPU + H2D copy):
     # same step with the rays re-drawn on the device from the resident scan (nl_select_rays)
     scan = dict(dirs=torch.from_numpy(np.ascontiguousarray(w["dirs"])).to(device), points=torch.from_numpy(np.ascontiguousarray(w["points"])).to(device),

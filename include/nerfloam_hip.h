@@ -213,6 +213,36 @@ int nl_optimiser_step(int* state, double lr_emb, double lr_dec, double lr_pose,
                       float* pose6, double* g_pose, float* pose_m, float* pose_v, const int* pose_enable, float* grad6_out,
                       float* poses12, int F, int apply_pose, const int* counters, int skip_mode, void* stream);
 
+/* ---- one call per iteration.  The whole launch sequence of an SDF iteration (render_helpers.py:356-423 mapping / :452-512
+ * tracking) issued from C: stages bit 0 = intersect .. backward (everything nl_ray_intersect .. nl_trilinear_bwd above, counter
+ * block cleared first), bit 1 = nl_optimiser_step.  The descriptor is plain C: device pointers + hyper-parameters; fill it once
+ * per optimisation call, change N / seeds / flags between iterations.  Same kernels, same results as the stage-wise calls; what
+ * it removes is the host's per-launch cost (~15 launches x ~250 marshalled arguments per iteration from Python). */
+typedef struct NlIterDesc {
+    /* rays of this iteration (sensor frame) and the frames' poses */
+    int N, F;
+    const float* rays_d_sensor; const float* points_gt; const float* cos_gt; const int* frame_id;
+    float* pose6; float* poses12; float* pose_m; float* pose_v; const int* pose_enable; double* g_pose; float* pose_grad6;
+    /* map: traversal blocks, reference layouts, embedding table (bf16) */
+    const void* blk_hdr; const void* blk_ids; int root_side; float voxel_size;
+    const float* centres; const int* vertex_rows; void* emb; long long n_emb_elems;
+    /* per-ray and per-sample workspaces (P_cap samples) */
+    float* rays_d_world; float* gt_dist; int* hit_idx; float* hit_t0; float* hit_t1; int* hit_count; int* hit_rank; int* ray_of_rank;
+    int* samp_count; int* samp_off; int* scan_ws;
+    int P_cap; int* s_vox; float* s_depth; float* s_dist; int* s_ray; float* X; float* dX; float* sdf; float* dsdf; unsigned* relu2_mask;
+    int* counters; void* loss_scalars; int* adam_state;
+    /* decoder block, weight workspace, gradient, Adam moments, per-workgroup slabs */
+    float* dec_params; float* dec_ws; float* dec_grad; float* dec_m; float* dec_v; float* partials; int n_slabs, field_blocks;
+    /* embedding gradient accumulators and moments (bf16) */
+    float* g_emb; void* emb_m; void* emb_v;
+    /* hyper-parameters */
+    float step_size, max_distance, truncation, sdf_weight, fs_weight;
+    double lr_emb, lr_dec, lr_pose;
+    unsigned noise_seed; int use_hash_noise, tail_always, ray_id_base, fresh_noise;
+    int train_decoder, want_emb_grad, want_pose_grad, update_emb, update_decoder, update_pose, skip_mode;
+} NlIterDesc;
+int nl_iteration(const NlIterDesc* desc, int stages, void* stream);
+
 /* ---- (b2) host octree behind torch.classes.svo.Octree (third_party/sparse_octree/src/bindings.cpp:4-31) */
 void* nl_octree_create(long long grid_dim);                              /* Octree::init   octree.cpp:36-50   */
 void nl_octree_destroy(void* h);

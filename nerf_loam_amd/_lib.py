@@ -37,6 +37,31 @@ class NerfLoamHipError(RuntimeError):
     pass
 
 
+def _iter_desc_fields():
+    P_, I_, F_, D_, LL_, U_ = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_longlong, ctypes.c_uint
+    f = [("N", I_), ("F", I_)]
+    f += [(n, P_) for n in ("rays_d_sensor", "points_gt", "cos_gt", "frame_id")]
+    f += [(n, P_) for n in ("pose6", "poses12", "pose_m", "pose_v", "pose_enable", "g_pose", "pose_grad6")]
+    f += [("blk_hdr", P_), ("blk_ids", P_), ("root_side", I_), ("voxel_size", F_)]
+    f += [("centres", P_), ("vertex_rows", P_), ("emb", P_), ("n_emb_elems", LL_)]
+    f += [(n, P_) for n in ("rays_d_world", "gt_dist", "hit_idx", "hit_t0", "hit_t1", "hit_count", "hit_rank", "ray_of_rank", "samp_count",
+                            "samp_off", "scan_ws")]
+    f += [("P_cap", I_)] + [(n, P_) for n in ("s_vox", "s_depth", "s_dist", "s_ray", "X", "dX", "sdf", "dsdf", "relu2_mask")]
+    f += [("counters", P_), ("loss_scalars", P_), ("adam_state", P_)]
+    f += [(n, P_) for n in ("dec_params", "dec_ws", "dec_grad", "dec_m", "dec_v", "partials")] + [("n_slabs", I_), ("field_blocks", I_)]
+    f += [("g_emb", P_), ("emb_m", P_), ("emb_v", P_)]
+    f += [(n, F_) for n in ("step_size", "max_distance", "truncation", "sdf_weight", "fs_weight")]
+    f += [("lr_emb", D_), ("lr_dec", D_), ("lr_pose", D_)]
+    f += [("noise_seed", U_)] + [(n, I_) for n in ("use_hash_noise", "tail_always", "ray_id_base", "fresh_noise")]
+    f += [(n, I_) for n in ("train_decoder", "want_emb_grad", "want_pose_grad", "update_emb", "update_decoder", "update_pose", "skip_mode")]
+    return f
+
+
+class NlIterDesc(ctypes.Structure):
+    """ctypes mirror of NlIterDesc (include/nerfloam_hip.h): field order and types must match (tests/test_c_abi_exports.py)"""
+    _fields_ = _iter_desc_fields()
+
+
 _lib = None
 
 _P, _I, _F, _D, _LL, _U = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_longlong, ctypes.c_uint
@@ -81,6 +106,7 @@ _SIGS = {
     "nl_pose_matrices": ([_P, _P, _I, _P], _I),
     "nl_pose_step": ([_P] * 7 + [_I, _P, _I, _P], _I),
     "nl_optimiser_step": ([_P, _D, _D, _D] + [_P] * 4 + [_LL] + [_P] * 5 + [_P] * 7 + [_I, _I, _P, _I, _P], _I),
+    "nl_iteration": ([_P, _I, _P], _I),
     "nl_octree_create": ([_LL], _P),
     "nl_octree_destroy": ([_P], None),
     "nl_octree_insert": ([_P, _P, _LL], _I),

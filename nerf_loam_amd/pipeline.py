@@ -13,6 +13,7 @@ The only torch ops on the path are a memset and two 4-byte device copies.
 
 Multi-GPU (dist.py): rays are sharded; the three exchange points are marked `hook_*`.
 """
+import ctypes
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -233,6 +234,8 @@ class SdfEngine:
         self.hook_after_count = None
         self.hook_after_backward = None
         self.timers = None       # bench: {stage: (start, end)} torch.cuda.Event pairs, see _mark
+        self._desc = L.NlIterDesc()
+        self._bound = None
 
     # ------------------------------------------------------------------ inputs
     def set_rays(self, rays_d_sensor, points_gt, cos_gt, frame_id=None):
@@ -293,6 +296,38 @@ class SdfEngine:
             total += n
         self.N = total
         return masks if want_masks else None
+
+    def prepare_selection(self, scans, n_rays):
+        """marshal the frame list of a call ONCE (select_rays re-builds its argument arrays on every call); then reselect(seed) is
+        one C call per iteration.  Returns False when the shapes need the per-frame radix path (use select_rays then)."""
+        F = len(scans)
+        Ms = [int(sc["dirs"].shape[0]) for sc in scans]
+        ns = [min(int(n_rays), M) for M in Ms]
+        if F > L.NL_SEL_MAX_FRAMES or sum(ns) > self.N_cap or any(sc.get("mask_u8") is None for sc in scans):
+            return False
+        if getattr(self, "_selb_ws", None) is None:
+            self._selb_ws = torch.zeros(L.NL_SEL_MAX_FRAMES * L.NL_SEL_BATCH_WS_INTS_PER_FRAME, dtype=I32, device=self.dev)
+            self._selb_parity = 0
+        I, U, PP = ctypes.c_int * F, ctypes.c_uint * F, ctypes.c_void_p * F
+        self._sel_prepared = dict(
+            F=F, M=I(*Ms), n=I(*ns), seed=U(*([0] * F)), d=PP(*[sc["dirs"].data_ptr() for sc in scans]),
+            p=PP(*[sc["points"].data_ptr() for sc in scans]), c=PP(*[sc["cos"].data_ptr() for sc in scans]),
+            mk=PP(*[sc["mask_u8"].data_ptr() for sc in scans]), off=I(*[sum(ns[:f]) for f in range(F)]), total=sum(ns), keep=scans)
+        return self.reselect(0, dry=True)
+
+    def reselect(self, seed, dry=False):
+        q = self._sel_prepared
+        for f in range(q["F"]):
+            q["seed"][f] = (int(seed) * 1000003 + f) & 0xFFFFFFFF
+        rc = L.lib().nl_select_rays_batch(q["F"], q["M"], q["n"], q["seed"], q["d"], q["p"], q["c"], q["mk"], q["off"],
+                                          self.rays_d_sensor.data_ptr(), self.points_gt.data_ptr(), self.cos_gt.data_ptr(),
+                                          self.frame_id.data_ptr(), self._selb_ws.data_ptr(), self._selb_parity, L.stream_ptr())
+        if rc == 4:                                            # shapes outside the window method's range: nothing was launched
+            return False
+        L.check(rc, "nl_select_rays_batch")
+        self._selb_parity ^= 1
+        self.N = q["total"]
+        return True
 
     def set_poses(self, pose6, optimise=None):
         """pose6 [F,6] = (t, w) like se3pose.OptimizablePose.data; optimise[f] = pose is in the optimiser."""
@@ -437,6 +472,42 @@ class SdfEngine:
             raise L.NerfLoamHipError("on-device ray selection missed its threshold window (nl_select_rays_batch): the selected ray set of "
                                      "this call is incomplete")
         return int(st[0]), int(st[2]), bool(st[3])
+
+    # ------------------------------------------------------------------ one C call per iteration
+    def bind(self, m: MapDevice, dec: DecoderDevice, cfg: IterConfig, train_decoder=True, want_emb_grad=True, want_pose_grad=True,
+             update_emb=True, update_decoder=True, update_pose=True, lr_pose=None, skip_mode=0, fresh_noise=False, ray_id_base=0):
+        """Fill the engine's NlIterDesc (include/nerfloam_hip.h) for a run of iterations on (m, dec, cfg): every device pointer and
+        hyper-parameter once, so that run_bound() is ONE ctypes call per iteration instead of ~15 calls with ~250 marshalled
+        arguments.  Call again when the map, the decoder, the configuration or the flags change (tensors are looked up here, not in
+        the loop).  Not used when multi-GPU hooks or stage timers are installed (forward_backward / optimiser_step then)."""
+        d = self._desc
+        pt = lambda t: None if t is None else t.data_ptr()          # noqa: E731
+        for name in ("rays_d_sensor", "points_gt", "cos_gt", "frame_id", "pose6", "poses12", "pose_m", "pose_v", "pose_enable", "g_pose", "pose_grad6",
+                     "rays_d_world", "gt_dist", "hit_idx", "hit_t0", "hit_t1", "hit_count", "hit_rank", "ray_of_rank", "samp_count", "samp_off",
+                     "scan_ws", "s_vox", "s_depth", "s_dist", "s_ray", "X", "dX", "sdf", "dsdf", "relu2_mask", "counters", "loss_scalars",
+                     "adam_state", "partials", "g_emb", "emb_m", "emb_v"):
+            setattr(d, name, pt(getattr(self, name)))
+        d.blk_hdr, d.blk_ids, d.root_side, d.voxel_size = pt(m.blk_hdr), pt(m.blk_ids), int(m.root_side), float(m.voxel_size)
+        d.centres, d.vertex_rows, d.emb, d.n_emb_elems = pt(m.centres), pt(m.vertex_rows), pt(m.emb), int(m.emb.numel())
+        d.dec_params, d.dec_ws, d.dec_grad, d.dec_m, d.dec_v = pt(dec.params), pt(dec.W2T), pt(dec.grad), pt(dec.m), pt(dec.v)
+        d.P_cap, d.n_slabs, d.field_blocks = self.P_cap, self.n_slabs, self.field_blocks
+        d.step_size, d.max_distance, d.truncation = cfg.step_size, cfg.max_distance, cfg.truncation
+        d.sdf_weight, d.fs_weight = cfg.sdf_weight, cfg.fs_weight
+        d.lr_emb, d.lr_dec, d.lr_pose = cfg.lr_emb, cfg.lr_dec, cfg.lr_pose if lr_pose is None else lr_pose
+        d.noise_seed = (0 if cfg.noise_seed is None else int(cfg.noise_seed)) & 0xFFFFFFFF
+        d.use_hash_noise, d.tail_always = int(cfg.noise_seed is not None), int(cfg.tail_always)
+        d.ray_id_base, d.fresh_noise = int(ray_id_base), int(fresh_noise)
+        d.train_decoder, d.want_emb_grad, d.want_pose_grad = int(train_decoder), int(want_emb_grad), int(want_pose_grad)
+        d.update_emb, d.update_decoder, d.update_pose, d.skip_mode = int(update_emb), int(update_decoder), int(update_pose), int(skip_mode)
+        if want_emb_grad or update_emb:
+            assert self.g_emb is not None, "begin_call(emb_state=True) first"
+        self._bound = (m, dec)                                       # keeps the tensors the descriptor points at alive
+
+    def run_bound(self, stages=3):
+        """one iteration of the bound configuration: stages bit 0 = forward + backward, bit 1 = optimiser step"""
+        d = self._desc
+        d.N, d.F = self.N, self.F
+        L.check(L.lib().nl_iteration(ctypes.byref(d), int(stages), L.stream_ptr()), "nl_iteration")
 
     # ------------------------------------------------------------------ hipGraph
     def capture_iteration(self, m: MapDevice, dec: DecoderDevice, cfg: IterConfig, **flags):

@@ -110,14 +110,18 @@ def _gather_rays(frames, N_rays, track=False):
     return torch.cat(d).float(), torch.cat(p).float(), torch.cat(c).float(), torch.cat(f)
 
 
-def _set_rays(eng, frames, N_rays, seed, track=False):
-    if RAY_SELECTION == "device":
-        scans = [fr.device_scan(eng.dev) for fr in frames]
-        eng.select_rays(scans, N_rays, seed)
-        for fr, sc in zip(frames, scans):                 # the reference's boolean sample_mask attribute: a view of the buffer the
-            fr.sample_mask = sc["mask_u8"].view(torch.bool).view(-1, 1)     # selection kernel wrote (no extra launch, no copy)
-    else:
-        eng.set_rays(*_gather_rays(frames, N_rays, track=track))
+def _ray_drawer(eng, frames, N_rays, track=False):
+    """-> draw(seed): puts the iteration's ray subset of every frame into the engine.  Device selection: the frame list is
+    marshalled once per call, every draw is one C call (two launches for all frames); the frames' boolean `sample_mask`
+    attribute (the reference's, lidarFrame.py:55-57) is a view of the buffer the selection kernel writes."""
+    if RAY_SELECTION != "device":
+        return lambda seed: eng.set_rays(*_gather_rays(frames, N_rays, track=track))
+    scans = [fr.device_scan(eng.dev) for fr in frames]
+    for fr, sc in zip(frames, scans):
+        fr.sample_mask = sc["mask_u8"].view(torch.bool).view(-1, 1)
+    if eng.prepare_selection(scans, N_rays):
+        return eng.reselect
+    return lambda seed: eng.select_rays(scans, N_rays, seed)
 
 
 def _finish_call(eng, what):
@@ -150,11 +154,16 @@ def bundle_adjust_frames(keyframe_graph, embeddings, map_states, sdf_network, lo
     if profiler is not None:
         profiler.tok("mapping_add_optim")
     seed0 = _draw_seed()
-    for it in range(num_iterations):                      # no host synchronisation inside the loop: an unusable iteration is
-        _set_rays(eng, keyframe_graph, N_rays, seed0 + it)    # recognised and skipped by the optimiser kernel itself (skip_mode)
-        eng.forward_backward(m, dec, cfg, train_decoder=update_decoder, want_emb_grad=True, want_pose_grad=any(optimise),
-                             fresh_noise=True)
-        eng.optimiser_step(m, dec, cfg, update_emb=True, update_decoder=update_decoder, update_pose=any(optimise), skip_mode=1)
+    draw = _ray_drawer(eng, keyframe_graph, N_rays)
+    draw(seed0)
+    # one C call per iteration (nl_iteration: ~15 launches); no host synchronisation inside the loop: an unusable iteration is
+    # recognised and skipped by the optimiser kernel itself (skip_mode), fresh sampler jitter comes from the device step counter
+    eng.bind(m, dec, cfg, train_decoder=update_decoder, want_emb_grad=True, want_pose_grad=any(optimise), update_emb=True,
+             update_decoder=update_decoder, update_pose=any(optimise), skip_mode=1, fresh_noise=True)
+    for it in range(num_iterations):
+        if it:
+            draw(seed0 + it)
+        eng.run_bound()
     _finish_call(eng, "Mapping")
     with torch.no_grad():
         if update_decoder:
@@ -179,10 +188,14 @@ def track_frame(frame_pose, curr_frame, map_states, sdf_network, loss_criteria, 
     eng.set_poses(init_pose.data.detach().cpu().numpy()[None], [1])
     eng.begin_call(m, None, emb_state=False)
     seed0 = _draw_seed()
-    for it in range(num_iterations):                      # sticky skip = the reference's `break` at the first unusable iteration
-        _set_rays(eng, [curr_frame], N_rays, seed0 + it, track=True)
-        eng.forward_backward(m, dec, cfg, train_decoder=False, want_emb_grad=False, want_pose_grad=True, fresh_noise=True)
-        eng.optimiser_step(m, dec, cfg, update_emb=False, update_decoder=False, update_pose=True, lr_pose=lr, skip_mode=2)
+    draw = _ray_drawer(eng, [curr_frame], N_rays, track=True)
+    draw(seed0)
+    eng.bind(m, dec, cfg, train_decoder=False, want_emb_grad=False, want_pose_grad=True, update_emb=False, update_decoder=False,
+             update_pose=True, lr_pose=lr, skip_mode=2, fresh_noise=True)       # sticky skip = the reference's `break`
+    for it in range(num_iterations):
+        if it:
+            draw(seed0 + it)
+        eng.run_bound()
     _, skipped = _finish_call(eng, "Tracking")
     hit_mask = None if skipped else (eng.hit_count[:eng.N] > 0)
     with torch.no_grad():

@@ -54,6 +54,32 @@ def test_header_is_plain_c_and_every_entry_links_from_c(tmp_path):
     assert int(n_syms) == len(syms) and int(version) >= 100 and int(leaves) == 2 and int(nodes) > 2
 
 
+def test_iteration_descriptor_mirror_matches_the_c_struct(tmp_path):
+    """nerf_loam_amd._lib.NlIterDesc (ctypes) against NlIterDesc of include/nerfloam_hip.h: same size, same offset for every field
+    (a C program prints offsetof for each field name of the mirror)"""
+    import ctypes
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    names = [n for n, _ in _lib.NlIterDesc._fields_]
+    src = ['#include "nerfloam_hip.h"', "#include <stddef.h>", "#include <stdio.h>", "int main(void) {",
+           '    printf("%zu", sizeof(NlIterDesc));'] + [f'    printf(" %zu", offsetof(NlIterDesc, {n}));' for n in names] + ["    return 0;", "}"]
+    c = tmp_path / "desc.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "desc"
+    r = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    vals = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True).stdout.split()]
+    assert vals[0] == ctypes.sizeof(_lib.NlIterDesc)
+    assert vals[1:] == [getattr(_lib.NlIterDesc, n).offset for n in names]
+    hdr = open(os.path.join(ROOT, "include", "nerfloam_hip.h")).read()
+    body = hdr[hdr.index("typedef struct NlIterDesc {"):hdr.index("} NlIterDesc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    declared = re.findall(r"[\*\s,]([A-Za-z_][A-Za-z0-9_]*)\s*[;,]", body)
+    assert declared == names, (declared, names)                   # every field of the C struct is mirrored, in order
+
+
 def test_header_constants_match_binding():
     src = open(os.path.join(ROOT, "include", "nerfloam_hip.h")).read()
     consts = dict(re.findall(r"#define\s+(NL_[A-Z_]+)\s+(\d+)", src))

@@ -541,6 +541,44 @@ def test_fused_intersect_and_sampler_edge_cases(nl, vox_kind):
     assert np.isfinite(r["sdf"]).all()
 
 
+def test_one_call_iteration_equals_the_stage_calls(nl, golden_dir):
+    """nl_iteration (one C call per iteration, SdfEngine.bind / run_bound) issues exactly the launches of forward_backward +
+    optimiser_step: same sdf bit for bit, same pose / decoder trajectory over 3 iterations (embedding atomics: tolerance)"""
+    g = np.load(os.path.join(golden_dir, "map_1f_3it.npz"))
+    outs = {}
+    for mode in ("stages", "one_call"):
+        sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]))
+        sc["ms"].id2row = g["id_table"].copy()
+        masks = H.unpack_masks(g["masks"], len(sc["points"]))
+        dec_np = O.decoder_init(int(g["seed"]))
+        m, dec, eng = make_engine(nl, sc, dec_np, int(masks[0][0].sum()))
+        cfgP = nl["P"].IterConfig(step_size=float(g["step_size"]))
+        fr = O.select_rays(sc["points"], sc["cos"], g["poses0"][0].copy(), masks[0][0])
+        eng.set_rays(fr.rays_d, fr.points, fr.cos); eng.set_poses(fr.pose[None], [1])
+        eng.begin_call(m, dec)
+        if mode == "one_call":
+            eng.bind(m, dec, cfgP, train_decoder=True)
+        sdf0 = None
+        for it in range(3):
+            if mode == "one_call":
+                eng.run_bound(1)
+                if it == 0:
+                    sdf0 = eng.sdf[:eng.stats()["P"]].cpu().numpy().copy()
+                eng.run_bound(2)
+            else:
+                eng.forward_backward(m, dec, cfgP, train_decoder=True)
+                if it == 0:
+                    sdf0 = eng.sdf[:eng.stats()["P"]].cpu().numpy().copy()
+                eng.optimiser_step(m, dec, cfgP)
+        torch.cuda.synchronize()
+        outs[mode] = (eng.pose6[0].cpu().numpy(), dec.params.cpu().numpy(), m.emb_bits().copy(), int(eng.adam_state[0].item()), sdf0)
+    assert outs["stages"][3] == outs["one_call"][3] == 3
+    assert np.array_equal(outs["stages"][4], outs["one_call"][4])
+    np.testing.assert_allclose(outs["one_call"][0], outs["stages"][0], rtol=0, atol=2e-6)
+    assert (np.abs(outs["one_call"][1] - outs["stages"][1]) > 5e-5).mean() < 2e-3
+    assert (outs["one_call"][2] != outs["stages"][2]).mean() < 5e-3
+
+
 def test_hipgraph_replay_matches_eager(nl, golden_dir):
     """The captured launch sequence (forward+backward+Adam, device-side step counter) replayed 3x gives the same
     pose / decoder trajectory as 3 eager iterations (embedding atomics are order-nondeterministic: tolerance)."""
