@@ -101,7 +101,8 @@ int nl_select_rays(int M, int n_select, unsigned seed, const float* rays_d, cons
 #define NL_SELECT_BATCH_WS_INTS(F) ((F) * (8 + 4 * 128 + 2 * 4096))
 int nl_select_rays_batch(int F, const int* M, const int* n_select, const unsigned* seed, const float* const* rays_d,
                          const float* const* points, const float* const* cos_in, unsigned char* const* mask_out, const int* out_off,
-                         float* out_rays_d, float* out_points, float* out_cos, int* out_frame_id, int* workspace, int parity, void* stream);
+                         float* out_rays_d, float* out_points, float* out_cos, int* out_frame_id, int* workspace, int parity,
+                         int* fail_word /* optional device word set to 1 when the window was missed */, void* stream);
 
 /* ray_sample: voxel_helpers.py:571-598 + :262-347 + sample_gpu.cu:133-239.
  * emit = 0: per-ray sample count, S_max and the geometry-only loss normalisers (criterion.py:67-88);

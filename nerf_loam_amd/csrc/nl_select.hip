@@ -101,13 +101,18 @@ struct SelFrame {
     const float* d; const float* p; const float* c; unsigned char* mask;
     int M, n, out_off, frame; unsigned seed, lo, hi; int nblk, wchunk;
 };
-struct SelArgs { SelFrame f[SEL_MAX_FRAMES]; int* ws; float* out_d; float* out_p; float* out_c; int* out_frame; int parity; };
+struct SelArgs { SelFrame f[SEL_MAX_FRAMES]; int* ws; float* out_d; float* out_p; float* out_c; int* out_frame; int parity; int* fail_word; };
 
 __global__ __launch_bounds__(256) void k_sel_window_a(SelArgs a)
 {
     const SelFrame fr = a.f[blockIdx.y];
     if ((int)blockIdx.x >= fr.nblk) return;
     int* ws = a.ws + (size_t)blockIdx.y * SEL_WS_INTS_PER_FRAME;
+    // candidates are collected per workgroup in LDS and appended with ONE global atomic per workgroup (a same-address device atomic
+    // costs ~12 ns: two thousand of them, one per candidate, would be most of this kernel's time)
+    __shared__ int s_ck[256], s_ci[256], s_cnt, s_base;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
     const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int wstart = gw * fr.wchunk, wend = min(fr.M, wstart + fr.wchunk);
     int sure = 0;
@@ -117,11 +122,23 @@ __global__ __launch_bounds__(256) void k_sel_window_a(SelArgs a)
         const bool live = i < wend;
         sure += __popcll(__ballot(live && key > fr.hi));
         if (live && key >= fr.lo && key <= fr.hi) {
-            const int pos = atomicAdd(&ws[a.parity], 1);
-            if (pos < SEL_CAP) { ws[8 + 4 * SEL_MAXB + pos] = (int)key; ws[8 + 4 * SEL_MAXB + SEL_CAP + pos] = i; }
+            const int q = atomicAdd(&s_cnt, 1);
+            if (q < 256) { s_ck[q] = (int)key; s_ci[q] = i; }
+            else {                                               // a workgroup with > 256 candidates (expected ~16): straight to memory
+                const int pos = atomicAdd(&ws[a.parity], 1);
+                if (pos < SEL_CAP) { ws[8 + 4 * SEL_MAXB + pos] = (int)key; ws[8 + 4 * SEL_MAXB + SEL_CAP + pos] = i; }
+            }
         }
     }
     if (lane == 0) ws[8 + gw] = sure;
+    __syncthreads();
+    const int cnt = min(s_cnt, 256);
+    if (threadIdx.x == 0 && cnt > 0) s_base = atomicAdd(&ws[a.parity], cnt);
+    __syncthreads();
+    if ((int)threadIdx.x < cnt) {
+        const int pos = s_base + threadIdx.x;
+        if (pos < SEL_CAP) { ws[8 + 4 * SEL_MAXB + pos] = s_ck[threadIdx.x]; ws[8 + 4 * SEL_MAXB + SEL_CAP + pos] = s_ci[threadIdx.x]; }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_sel_window_b(SelArgs a)
@@ -151,7 +168,7 @@ __global__ __launch_bounds__(256) void k_sel_window_b(SelArgs a)
     const int total_sure = s_red[0] + s_red[1] + s_red[2] + s_red[3];
     const int k = fr.n - total_sure;                             // candidates to take: the k largest of them
     const bool fail = k < 0 || k > C || cand_n > SEL_CAP;
-    if (fail && blockIdx.x == 0 && tid == 0) ws[2] = 1;
+    if (fail && blockIdx.x == 0 && tid == 0) { ws[2] = 1; if (a.fail_word) *a.fail_word = 1; }
     // exact k-th largest candidate key: 4-pass radix select over the LDS copy (k == 0: nothing is taken)
     unsigned prefix = 0u; int rem = k;
     if (k > 0 && !fail) {
@@ -165,10 +182,28 @@ __global__ __launch_bounds__(256) void k_sel_window_b(SelArgs a)
                 if ((key & hi_mask) == (prefix & hi_mask)) atomicAdd(&s_hist[(key >> shift) & 255u], 1);
             }
             __syncthreads();
-            if (tid == 0) {
-                int d = 255, above = 0;
-                for (; d > 0; --d) { if (above + s_hist[d] >= rem) break; above += s_hist[d]; }
-                s_T = prefix | ((unsigned)d << shift); s_take = rem - above;
+            if (w == 0) {                                        // digit = the largest d with count(digit >= d) >= rem: one wave, four bins
+                const int h0 = s_hist[4 * lane], h1 = s_hist[4 * lane + 1], h2 = s_hist[4 * lane + 2], h3 = s_hist[4 * lane + 3];    // per lane
+                const int mine = h0 + h1 + h2 + h3;
+                int suf = mine;                                  // keys whose digit lies in this lane's bins or above
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_down(suf, off); if (lane + off < 64) suf += v; }
+                const unsigned long long bal = __ballot(suf >= rem);
+                const int top = bal ? 63 - __clzll(bal) : 0;     // (rem <= C: some lane qualifies; lane 0 otherwise, like the serial scan)
+                if (lane == top) {
+                    int above = suf - mine, d;                   // keys whose digit lies in a higher lane's bins
+                    if (above + h3 >= rem) d = 4 * lane + 3;
+                    else {
+                        above += h3;
+                        if (above + h2 >= rem) d = 4 * lane + 2;
+                        else {
+                            above += h2;
+                            if (above + h1 >= rem) d = 4 * lane + 1;
+                            else { above += h1; d = 4 * lane; }
+                        }
+                    }
+                    s_T = prefix | ((unsigned)d << shift); s_take = rem - above;
+                }
             }
             __syncthreads();
             prefix = s_T; rem = s_take;
@@ -241,11 +276,12 @@ int nl_select_rays(int M, int n_select, unsigned seed, const float* rays_d, cons
 /* All frames of a call in two launches (k_sel_window_a / _b above).  Returns NL_ERR_CAPACITY when a frame's shape is outside the
  * window method's range (n close to M, or a candidate window above SEL_CAP keys): use nl_select_rays per frame then.
  * workspace: NL_SELECT_BATCH_WS_INTS(F) ints, ZERO-FILLED once by the caller at allocation; parity alternates 0 / 1 between calls
- * (the candidate counter of one call is cleared by the next one's second pass).  ws[f][2] != 0 afterwards = the window was missed
- * (never observed; ~1e-50) and the selection of that call is incomplete. */
+ * (the candidate counter of one call is cleared by the next one's second pass).  ws[f][2] != 0 afterwards (and *fail_word = 1, if
+ * given) = the window was missed (never observed; ~1e-50) and the selection of that call is incomplete. */
 int nl_select_rays_batch(int F, const int* M, const int* n_select, const unsigned* seed, const float* const* rays_d,
                          const float* const* points, const float* const* cos_in, unsigned char* const* mask_out, const int* out_off,
-                         float* out_rays_d, float* out_points, float* out_cos, int* out_frame_id, int* workspace, int parity, void* stream)
+                         float* out_rays_d, float* out_points, float* out_cos, int* out_frame_id, int* workspace, int parity,
+                         int* fail_word, void* stream)
 {
     if (F <= 0 || F > SEL_MAX_FRAMES || !M || !n_select || !seed || !rays_d || !points || !cos_in || !out_off || !out_rays_d || !out_points ||
         !out_cos || !workspace || (parity != 0 && parity != 1))
@@ -269,7 +305,7 @@ int nl_select_rays_batch(int F, const int* M, const int* n_select, const unsigne
         fr.wchunk = nl_div_up(nl_div_up(m, 4 * nblk), 64) * 64;
         if (nblk > max_blk) max_blk = nblk;
     }
-    a.ws = workspace; a.out_d = out_rays_d; a.out_p = out_points; a.out_c = out_cos; a.out_frame = out_frame_id; a.parity = parity;
+    a.ws = workspace; a.out_d = out_rays_d; a.out_p = out_points; a.out_c = out_cos; a.out_frame = out_frame_id; a.parity = parity; a.fail_word = fail_word;
     hipLaunchKernelGGL(k_sel_window_a, dim3(max_blk, F), dim3(256), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(k_sel_window_b, dim3(max_blk, F), dim3(256), 0, (hipStream_t)stream, a);
     NL_LAUNCH_CHECK();

@@ -172,7 +172,8 @@ def select_rays(M, n_select, seed, rays_d, points, cos_in, frame, out_rays_d, ou
                                  stream_ptr()), "nl_select_rays")
 
 
-def select_rays_batch(Ms, ns, seeds, rays_d, points, cos_in, masks, out_off, out_rays_d, out_points, out_cos, out_frame_id, workspace, parity):
+def select_rays_batch(Ms, ns, seeds, rays_d, points, cos_in, masks, out_off, out_rays_d, out_points, out_cos, out_frame_id, workspace, parity,
+                      fail_word=None):
     """all frames of a call in two launches; returns False (nothing launched) when a frame's shape is outside the window method's
     range - the caller then uses select_rays per frame"""
     F = len(Ms)
@@ -181,7 +182,7 @@ def select_rays_batch(Ms, ns, seeds, rays_d, points, cos_in, masks, out_off, out
                                       PP(*[t.data_ptr() for t in rays_d]), PP(*[t.data_ptr() for t in points]),
                                       PP(*[t.data_ptr() for t in cos_in]), PP(*[(t.data_ptr() if t is not None else None) for t in masks]),
                                       I(*[int(x) for x in out_off]), ptr(out_rays_d), ptr(out_points), ptr(out_cos), ptr(out_frame_id),
-                                      ptr(workspace), int(parity), stream_ptr())
+                                      ptr(workspace), int(parity), ptr(fail_word), stream_ptr())
     if rc == 4:
         return False
     check(rc, "nl_select_rays_batch")

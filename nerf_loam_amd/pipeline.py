@@ -188,11 +188,18 @@ class SdfEngine:
         # poses
         self.pose6 = torch.zeros(self.F_cap, 6, dtype=F32, device=d)
         self.poses12 = torch.zeros(self.F_cap, 12, dtype=F32, device=d)
-        self.pose_m = torch.zeros(self.F_cap, 6, dtype=F32, device=d)
-        self.pose_v = torch.zeros(self.F_cap, 6, dtype=F32, device=d)
+        # the small per-call optimiser state lives in ONE buffer, cleared by one memset per call (begin_call):
+        # [g_pose f64 F x 12 | adam_state 28 i32 | pose_m F x 6 | pose_v F x 6 | pose_grad6 F x 6]
+        Fc = self.F_cap
+        self._call_state = torch.zeros(Fc * 24 + L.NL_ADAM_STATE_BYTES // 4 + 3 * Fc * 6, dtype=I32, device=d)
+        o = Fc * 24
+        self.adam_state = self._call_state[o:o + L.NL_ADAM_STATE_BYTES // 4]
+        o += L.NL_ADAM_STATE_BYTES // 4
+        self.pose_m = self._call_state[o:o + Fc * 6].view(F32).view(Fc, 6)
+        self.pose_v = self._call_state[o + Fc * 6:o + 2 * Fc * 6].view(F32).view(Fc, 6)
         self.pose_enable = torch.zeros(self.F_cap, dtype=I32, device=d)
-        self.g_pose = torch.zeros(self.F_cap, 12, dtype=torch.float64, device=d)     # fp64 accumulators (nl_trilinear_bwd)
-        self.pose_grad6 = torch.zeros(self.F_cap, 6, dtype=F32, device=d)
+        self.g_pose = self._call_state[:Fc * 24].view(torch.float64).view(Fc, 12)     # fp64 accumulators (nl_trilinear_bwd)
+        self.pose_grad6 = self._call_state[o + 2 * Fc * 6:o + 3 * Fc * 6].view(F32).view(Fc, 6)
         # per-ray workspace
         self.rays_d_world = torch.empty(N, 3, dtype=F32, device=d)
         self.gt_dist = torch.empty(N, dtype=F32, device=d)
@@ -227,7 +234,7 @@ class SdfEngine:
         self.g_emb = None
         self.emb_m = None
         self.emb_v = None
-        self.adam_state = torch.zeros(L.NL_ADAM_STATE_BYTES // 4, dtype=I32, device=d)   # device step counter + hyper-parameters
+        # (adam_state: device step counter + hyper-parameters, a slice of _call_state above)
         self.graph = None
         # multi-GPU hooks (dist.py installs them); identity on one GPU
         self.hook_after_intersect = None
@@ -274,7 +281,8 @@ class SdfEngine:
             offs = [sum(ns[:f]) for f in range(len(ns))]
             if ops.select_rays_batch(Ms, ns, [(int(seed) * 1000003 + f) & 0xFFFFFFFF for f in range(len(scans))],
                                      [sc["dirs"] for sc in scans], [sc["points"] for sc in scans], [sc["cos"] for sc in scans], mks, offs,
-                                     self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self._selb_ws, self._selb_parity):
+                                     self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self._selb_ws, self._selb_parity,
+                                     self.adam_state[3:4]):
                 self._selb_parity ^= 1
                 self.N = sum(ns)
                 return mks if want_masks else None
@@ -313,15 +321,16 @@ class SdfEngine:
             F=F, M=I(*Ms), n=I(*ns), seed=U(*([0] * F)), d=PP(*[sc["dirs"].data_ptr() for sc in scans]),
             p=PP(*[sc["points"].data_ptr() for sc in scans]), c=PP(*[sc["cos"].data_ptr() for sc in scans]),
             mk=PP(*[sc["mask_u8"].data_ptr() for sc in scans]), off=I(*[sum(ns[:f]) for f in range(F)]), total=sum(ns), keep=scans)
-        return self.reselect(0, dry=True)
+        return True
 
-    def reselect(self, seed, dry=False):
+    def reselect(self, seed):
         q = self._sel_prepared
         for f in range(q["F"]):
             q["seed"][f] = (int(seed) * 1000003 + f) & 0xFFFFFFFF
         rc = L.lib().nl_select_rays_batch(q["F"], q["M"], q["n"], q["seed"], q["d"], q["p"], q["c"], q["mk"], q["off"],
                                           self.rays_d_sensor.data_ptr(), self.points_gt.data_ptr(), self.cos_gt.data_ptr(),
-                                          self.frame_id.data_ptr(), self._selb_ws.data_ptr(), self._selb_parity, L.stream_ptr())
+                                          self.frame_id.data_ptr(), self._selb_ws.data_ptr(), self._selb_parity,
+                                          self.adam_state.data_ptr() + 12, L.stream_ptr())
         if rc == 4:                                            # shapes outside the window method's range: nothing was launched
             return False
         L.check(rc, "nl_select_rays_batch")
@@ -344,23 +353,21 @@ class SdfEngine:
         """A fresh torch.optim.Adam is created per bundle_adjust_frames / track_frame call
         (render_helpers.py:353,448): reset optimiser state.  emb_state=False (tracking, forward-only queries): the call never
         touches the embedding gradient accumulators / moments, so they are neither allocated nor cleared (160 B per row)."""
-        self.adam_state.zero_()
-        self.graph = None
-        self.pose_m.zero_()
-        self.pose_v.zero_()
-        self.g_pose.zero_()                                  # a previous call may have aborted between backward and the optimiser step
-        self.pose_grad6.zero_()
+        self._call_state.zero_()                             # adam state, pose moments, g_pose / pose_grad6 (a previous call may have
+        self.graph = None                                    # aborted between backward and the optimiser step): one memset
         E = m.n_rows
         if not emb_state:
             pass
         elif self.g_emb is None or self.g_emb.shape[0] != E:
-            self.g_emb = torch.zeros(E, L.NL_C, dtype=F32, device=self.dev)
-            self.emb_m = torch.zeros(E, L.NL_C, dtype=torch.int16, device=self.dev)
-            self.emb_v = torch.zeros(E, L.NL_C, dtype=torch.int16, device=self.dev)
+            self._emb_state = torch.zeros(2 * E * L.NL_C, dtype=F32, device=self.dev)       # [g_emb f32 | emb_m bf16 | emb_v bf16]
+            self.g_emb = self._emb_state[:E * L.NL_C].view(E, L.NL_C)
+            mv = self._emb_state[E * L.NL_C:].view(torch.int16)
+            self.emb_m = mv[:E * L.NL_C].view(E, L.NL_C)
+            self.emb_v = mv[E * L.NL_C:].view(E, L.NL_C)
         else:
-            self.g_emb.zero_()
-            self.emb_m.zero_()
-            self.emb_v.zero_()
+            self._emb_state.zero_()
+            if self.g_emb.data_ptr() != self._emb_state.data_ptr():      # re-homed into the multi-GPU exchange buffer (dist.py)
+                self.g_emb.zero_()
         if dec is not None:
             dec.reset_state()
 
@@ -467,11 +474,14 @@ class SdfEngine:
         """(steps taken, steps skipped as unusable, overflow seen) since begin_call - ONE small read-back per call instead of one
         per iteration"""
         st = self.adam_state[:4].cpu().numpy()
-        ws = getattr(self, "_selb_ws", None)
-        if ws is not None and bool(ws.view(L.NL_SEL_MAX_FRAMES, -1)[:, 2].any().item()):
-            raise L.NerfLoamHipError("on-device ray selection missed its threshold window (nl_select_rays_batch): the selected ray set of "
-                                     "this call is incomplete")
         return int(st[0]), int(st[2]), bool(st[3])
+
+    def call_status_and_poses(self):
+        """call_status() + the frames' current pose6, in ONE device-to-host copy"""
+        o = self.F_cap * 24
+        both = torch.cat([self._call_state[o:o + 4], self.pose6[:self.F].reshape(-1).view(I32)]).cpu()
+        st = both[:4].numpy()
+        return (int(st[0]), int(st[2]), bool(st[3])), both[4:].view(F32).view(self.F, 6)
 
     # ------------------------------------------------------------------ one C call per iteration
     def bind(self, m: MapDevice, dec: DecoderDevice, cfg: IterConfig, train_decoder=True, want_emb_grad=True, want_pose_grad=True,

@@ -126,15 +126,17 @@ def _ray_drawer(eng, frames, N_rays, track=False):
 
 def _finish_call(eng, what):
     """the ONE host read-back of a call (the iterations themselves never synchronise): how many optimiser steps the device
-    skipped as unusable, and whether a sample buffer overflowed - not the reference's "returns None" case: fail loudly"""
-    steps, skipped, overflow = eng.call_status()
+    skipped as unusable, whether a sample buffer overflowed (not the reference's "returns None" case: fail loudly), and the
+    frames' poses"""
+    (steps, skipped, overflow), poses = eng.call_status_and_poses()
     if overflow:
-        raise L.NerfLoamHipError(f"sample buffers too small: an iteration produced more than {eng.P_cap} valid samples "
-                                 f"({eng.P_cap // max(eng.N_cap, 1)} per ray on average are provided for); step_size is too fine for "
-                                 "nerf_loam_amd.render_helpers._engine's samples_per_ray_cap")
+        raise L.NerfLoamHipError(f"the call is invalid: an iteration produced more than {eng.P_cap} valid samples "
+                                 f"({eng.P_cap // max(eng.N_cap, 1)} per ray on average are provided for: step_size too fine for "
+                                 "nerf_loam_amd.render_helpers._engine's samples_per_ray_cap), or the on-device ray selection missed its "
+                                 "threshold window")
     for _ in range(skipped if what == "Mapping" else min(skipped, 1)):
         print(f"Encouter a bug while {what}, currently not be fixed, " + ("Continue!!" if what == "Mapping" else "Restarting!!"))
-    return steps, skipped
+    return steps, skipped, poses
 
 
 def bundle_adjust_frames(keyframe_graph, embeddings, map_states, sdf_network, loss_criteria, voxel_size, step_size,
@@ -164,11 +166,10 @@ def bundle_adjust_frames(keyframe_graph, embeddings, map_states, sdf_network, lo
         if it:
             draw(seed0 + it)
         eng.run_bound()
-    _finish_call(eng, "Mapping")
+    _, _, p6 = _finish_call(eng, "Mapping")
     with torch.no_grad():
         if update_decoder:
             _decoder_writeback(sdf_network, dec)
-        p6 = eng.pose6[:len(keyframe_graph)].cpu()
         for i, kf in enumerate(keyframe_graph):
             if optimise[i]:
                 kf.pose.data.copy_(p6[i].to(kf.pose.data.device))
@@ -196,10 +197,10 @@ def track_frame(frame_pose, curr_frame, map_states, sdf_network, loss_criteria, 
         if it:
             draw(seed0 + it)
         eng.run_bound()
-    _, skipped = _finish_call(eng, "Tracking")
+    _, skipped, p6 = _finish_call(eng, "Tracking")
     hit_mask = None if skipped else (eng.hit_count[:eng.N] > 0)
     with torch.no_grad():
-        init_pose.data.copy_(eng.pose6[0].to(init_pose.data.device))
+        init_pose.data.copy_(p6[0].to(init_pose.data.device))
     return init_pose, hit_mask
 
 
