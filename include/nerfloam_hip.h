@@ -114,8 +114,14 @@ int nl_select_rays_batch(int F, const int* M, const int* n_select, const unsigne
 int nl_sample_rays(int emit, int N, const int* hit_idx, const float* hit_t0, const float* hit_t1, const int* hit_count,
                    const int* hit_rank, const int* ray_of_rank, const float* cos_gt, const float* gt_dist,
                    float step_size, float tau, float max_depth, unsigned seed, int use_hash_noise, int tail_always, int ray_id_base,
-                   const unsigned* seed_mix, int* counters, int* samp_count, const int* samp_off, int capacity,
+                   const unsigned* seed_mix, const int* row_first /* multi-GPU: nl_dist_row_first table, else NULL */,
+                   int* counters, int* samp_count, const int* samp_off, int capacity,
                    int* s_vox, float* s_depth, float* s_dist, int* s_ray, void* stream);
+/* Multi-GPU ray sharding: hit lists of the batch rows' first rays owned by this rank -> table[n_entries][1 + NL_MAX_HITS] =
+ * (count, idx + 1, ...), zeros for rows owned elsewhere; SUM-all-reduce the table and pass it to nl_sample_rays (the sampler's
+ * closing loop reads the first ray of a ray's batch row, sample_gpu.cu:231).  n_entries >= 200 * ceil(ceil(R_global / 200) / 800). */
+int nl_dist_row_first(const int* counters, const int* hit_idx, const int* hit_count, const int* ray_of_rank, int* table, int n_entries,
+                      void* stream);
 
 /* global loss normalisers from the counter block (criterion.py:84-88 weights, :65 mean divisor R*S) */
 int nl_loss_finalize(int* counters, void* loss_scalars, float fs_weight, float sdf_weight, float tau, float max_depth,
@@ -213,6 +219,15 @@ int nl_optimiser_step(int* state, double lr_emb, double lr_dec, double lr_pose,
                       float* dec_params, const float* dec_grad, float* dec_m, float* dec_v, float* dec_ws,
                       float* pose6, double* g_pose, float* pose_m, float* pose_v, const int* pose_enable, float* grad6_out,
                       float* poses12, int F, int apply_pose, const int* counters, int skip_mode, void* stream);
+
+/* ---- multi-GPU: embedding-gradient exchange over the rows an iteration touches (nerf_loam_amd/dist.py).  Every rank marks the rows
+ * of the voxels its rays hit in a zero-filled bitmap of ceil(E / 32) words; after an OR-all-reduce of the bitmap the union's rows
+ * are packed in row order into buf[capacity][16] (prefix = exclusive scan of the word popcounts), SUM-all-reduced and unpacked. */
+int nl_dist_mark_rows(int N, const int* hit_idx, const int* hit_count, const int* vertex_rows, unsigned* bitmap, void* stream);
+int nl_dist_rows_prefix(const unsigned* bitmap, int n_words, int* prefix, int* total, int* workspace /* n_words + ceil(n_words / 1024) + 8 ints */,
+                        void* stream);
+int nl_dist_rows_move(int direction /* 0 pack, 1 unpack */, const unsigned* bitmap, const int* prefix, int n_words, float* g_emb, float* buf,
+                      int capacity, int* fail_word, void* stream);
 
 /* ---- one call per iteration.  The whole launch sequence of an SDF iteration (render_helpers.py:356-423 mapping / :452-512
  * tracking) issued from C: stages bit 0 = intersect .. backward (everything nl_ray_intersect .. nl_trilinear_bwd above, counter

@@ -76,7 +76,8 @@ _SIGS = {
     "nl_exclusive_scan_i32": ([_P, _P, _I, _I, _P, _P, _P], _I),
     "nl_compact_hit_rays": ([_I, _P, _P, _P, _P], _I),
     "nl_scan_hit_rays": ([_P, _P, _P, _I, _P, _P, _P, _P], _I),
-    "nl_sample_rays": ([_I, _I] + [_P] * 8 + [_F, _F, _F, _U, _I, _I, _I] + [_P, _P, _P, _P, _I] + [_P] * 5, _I),
+    "nl_sample_rays": ([_I, _I] + [_P] * 8 + [_F, _F, _F, _U, _I, _I, _I] + [_P, _P, _P, _P, _P, _I] + [_P] * 5, _I),
+    "nl_dist_row_first": ([_P, _P, _P, _P, _P, _I, _P], _I),
     "nl_loss_finalize": ([_P, _P, _F, _F, _F, _F, _I, _P], _I),
     "nl_gather_trilinear": ([_P] * 7 + [_I] + [_P] * 3 + [_F, _P, _I, _P], _I),
     "nl_gather_points": ([_I] + [_P] * 5 + [_F, _P, _P], _I),
@@ -107,6 +108,9 @@ _SIGS = {
     "nl_pose_step": ([_P] * 7 + [_I, _P, _I, _P], _I),
     "nl_optimiser_step": ([_P, _D, _D, _D] + [_P] * 4 + [_LL] + [_P] * 5 + [_P] * 7 + [_I, _I, _P, _I, _P], _I),
     "nl_iteration": ([_P, _I, _P], _I),
+    "nl_dist_mark_rows": ([_I, _P, _P, _P, _P, _P], _I),
+    "nl_dist_rows_prefix": ([_P, _I, _P, _P, _P, _P], _I),
+    "nl_dist_rows_move": ([_I, _P, _P, _I, _P, _P, _I, _P, _P], _I),
     "nl_octree_create": ([_LL], _P),
     "nl_octree_destroy": ([_P], None),
     "nl_octree_insert": ([_P, _P, _LL], _I),

@@ -215,6 +215,7 @@ struct NlTailCtx {
     int j_in_row;               // j   = this ray's index inside its row chunk
     const int* row_first_idx;   // hit list (stride 1) of the row's first ray in the chunk
     int row_first_count;        // number of valid entries in that list (entries beyond it read as -1)
+    int row_first_bias;         // the list stores idx + bias (1 for a list received from another rank, nl_dist_row_first)
     bool tail_always;
 };
 
@@ -261,7 +262,7 @@ NL_HD int nl_sample_walk_core(GetI idx, GetF0 t0, GetF1 t1, int P, float tot, fl
         ++curr_bin; ++s;
         if (curr_bin >= P) break;
         curr_idx = idx(curr_bin);
-        if ((tc.tail_always ? curr_idx : (curr_bin < tc.row_first_count ? tc.row_first_idx[curr_bin] : -1)) == -1) break;
+        if ((tc.tail_always ? curr_idx : (curr_bin < tc.row_first_count ? tc.row_first_idx[curr_bin] - tc.row_first_bias : -1)) == -1) break;
         curr_min_depth = t0(curr_bin); curr_max_depth = t1(curr_bin);
         z_low = curr_min_depth;
     }
@@ -367,7 +368,7 @@ NL_HD int nl_walk_tail(int T, float step, int nb, int P, GetI idx, GetC cum, Get
         ++bin; ++s;
         if (bin >= P) break;
         curr_idx = idx(bin);
-        if ((tc.tail_always ? curr_idx : (bin < tc.row_first_count ? tc.row_first_idx[bin] : -1)) == -1) break;
+        if ((tc.tail_always ? curr_idx : (bin < tc.row_first_count ? tc.row_first_idx[bin] - tc.row_first_bias : -1)) == -1) break;
         zl = t0(bin); curr_max_depth = t1(bin);
     }
     return s;
@@ -403,6 +404,14 @@ NL_HD void nl_sampler_layout(int r, int R, int* j_in_row, int* rays_in_row, int*
     *rays_in_row = rem < NL_SAMPLER_CHUNK ? rem : NL_SAMPLER_CHUNK;
     int first = g * L + c0;
     *row_first_rank = first < R ? first : 0;     // padding rows replicate hit-ray 0
+}
+
+// index of a row-first hit-rank in the table of nl_dist_row_first: [batch row 200][chunk ceil(L / 800)]
+NL_HD int nl_row_first_entry(int first_rank, int R) {
+    const int L = (R + NL_SAMPLER_G - 1) / NL_SAMPLER_G;
+    const int nch = (L + NL_SAMPLER_CHUNK - 1) / NL_SAMPLER_CHUNK;
+    const int g = first_rank / L, c = (first_rank - g * L) / NL_SAMPLER_CHUNK;
+    return g * nch + c;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -573,6 +573,7 @@ struct SampleArgs {
     const float* cos_gt; const float* gt_dist;
     float step_size; float tau; float max_depth;
     unsigned seed; int use_hash_noise; int tail_always; int ray_id_base;
+    const int* row_first;       // multi-GPU: [entries][1 + NL_MAX_HITS] = (count, idx + 1 ...) of every batch row's first ray (nl_dist_row_first), or NULL
     const unsigned* seed_mix;   // optional device word (the optimiser's step counter) folded into the seed: fresh jitter per iteration
     int* counters; double* dcounters;
     int* samp_count;            // [N]  (0 for rays without hits)
@@ -668,11 +669,18 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample_par(SampleArgs a)
                 const int rank = a.hit_rank[r] + a.counters[NLC_R_OFFSET];
                 int first_rank;
                 nl_sampler_layout(rank, Rg, &tc.j_in_row, &tc.rays_in_row, &first_rank);
-                // single-GPU: the row's first ray is local.  (multi-GPU: see dist.py)
+                // single-GPU: the row's first ray is local.  multi-GPU: it may live on another rank - the ranks exchange the 200 x
+                // ceil(L / 800) row-first hit lists (nl_dist_row_first + one all-reduce, dist.py), stored as idx + 1
                 const int first_local = first_rank - a.counters[NLC_R_OFFSET];
-                const int first_ray = (first_local >= 0 && first_local < a.counters[NLC_R]) ? a.ray_of_rank[first_local] : r;
+                const bool is_local = first_local >= 0 && first_local < a.counters[NLC_R];
+                const int first_ray = is_local ? a.ray_of_rank[first_local] : r;
                 tc.row_first_idx = a.hit_idx + (size_t)first_ray * NL_MAX_HITS;
                 tc.row_first_count = a.hit_count[first_ray];
+                tc.row_first_bias = 0;
+                if (!is_local && a.row_first) {
+                    const int* e = a.row_first + (size_t)nl_row_first_entry(first_rank, Rg) * (1 + NL_MAX_HITS);
+                    tc.row_first_idx = e + 1; tc.row_first_count = e[0]; tc.row_first_bias = 1;
+                }
                 tc.tail_always = a.tail_always != 0;
                 cnt = nl_walk_tail(T, step, nb, P, get_i, get_c, get_0, get_1, tc, noise, emit);
             }
@@ -760,11 +768,17 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample(SampleArgs a)
         NlTailCtx tc;
         int first_rank;
         nl_sampler_layout(rank, Rg, &tc.j_in_row, &tc.rays_in_row, &first_rank);
-        // single-GPU: the row's first ray is local.  (multi-GPU: ranks exchange these lists; see dist.py)
+        // single-GPU: the row's first ray is local.  multi-GPU: see k_sample_par above
         const int first_local = first_rank - a.counters[NLC_R_OFFSET];
-        const int first_ray = (first_local >= 0 && first_local < a.counters[NLC_R]) ? a.ray_of_rank[first_local] : r;
+        const bool is_local = first_local >= 0 && first_local < a.counters[NLC_R];
+        const int first_ray = is_local ? a.ray_of_rank[first_local] : r;
         tc.row_first_idx = a.hit_idx + (size_t)first_ray * NL_MAX_HITS;
         tc.row_first_count = a.hit_count[first_ray];
+        tc.row_first_bias = 0;
+        if (!is_local && a.row_first) {
+            const int* e = a.row_first + (size_t)nl_row_first_entry(first_rank, Rg) * (1 + NL_MAX_HITS);
+            tc.row_first_idx = e + 1; tc.row_first_count = e[0]; tc.row_first_bias = 1;
+        }
         tc.tail_always = a.tail_always != 0;
         SSTAMP(2);
         const float c = a.cos_gt[r], d = a.gt_dist[r];
@@ -915,6 +929,28 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_inverse_cdf_raw(
 // =============================================================================================
 // C ABI launchers (declared in include/nerfloam_hip.h)
 // =============================================================================================
+// row-first hit lists of this rank (nl_dist_row_first): 32 lanes per table entry
+__global__ void k_dist_row_first(const int* __restrict__ counters, const int* __restrict__ hit_idx, const int* __restrict__ hit_count,
+                                 const int* __restrict__ ray_of_rank, int* __restrict__ table, int n_entries)
+{
+    const int e = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+    if (e >= n_entries || l > NL_MAX_HITS) return;
+    const int Rg = counters[NLC_R_GLOBAL], off = counters[NLC_R_OFFSET], R = counters[NLC_R];
+    const int L = (Rg + NL_SAMPLER_G - 1) / NL_SAMPLER_G;
+    const int nch = L > 0 ? (L + NL_SAMPLER_CHUNK - 1) / NL_SAMPLER_CHUNK : 1;
+    int v = 0;
+    if (L > 0 && e < NL_SAMPLER_G * nch) {
+        int first = (e / nch) * L + (e % nch) * NL_SAMPLER_CHUNK;
+        if (first >= Rg) first = 0;                                  // padding rows replicate hit-ray 0
+        const int loc = first - off;
+        if (loc >= 0 && loc < R) {
+            const int ray = ray_of_rank[loc], cnt = hit_count[ray];
+            v = l == 0 ? cnt : (l - 1 < cnt ? hit_idx[(size_t)ray * NL_MAX_HITS + l - 1] + 1 : 0);
+        }
+    }
+    table[(size_t)e * (1 + NL_MAX_HITS) + l] = v;
+}
+
 extern "C" {
 
 int nl_svo_intersect(const float* ray_start, const float* ray_dir, const float* points, const int* children,
@@ -1024,7 +1060,7 @@ int nl_compact_hit_rays(int N, const int* hit_count, const int* hit_rank, int* r
 int nl_sample_rays(int emit, int N, const int* hit_idx, const float* hit_t0, const float* hit_t1, const int* hit_count,
                    const int* hit_rank, const int* ray_of_rank, const float* cos_gt, const float* gt_dist,
                    float step_size, float tau, float max_depth, unsigned seed, int use_hash_noise, int tail_always, int ray_id_base,
-                   const unsigned* seed_mix, int* counters, int* samp_count, const int* samp_off, int capacity,
+                   const unsigned* seed_mix, const int* row_first, int* counters, int* samp_count, const int* samp_off, int capacity,
                    int* s_vox, float* s_depth, float* s_dist, int* s_ray, void* stream)
 {
     if (N <= 0 || !hit_idx || !hit_t0 || !hit_t1 || !hit_count || !hit_rank || !ray_of_rank || !cos_gt || !gt_dist || !counters || !samp_count)
@@ -1034,7 +1070,7 @@ int nl_sample_rays(int emit, int N, const int* hit_idx, const float* hit_t0, con
     a.N = N; a.hit_idx = hit_idx; a.hit_t0 = hit_t0; a.hit_t1 = hit_t1; a.hit_count = hit_count; a.hit_rank = hit_rank;
     a.ray_of_rank = ray_of_rank; a.cos_gt = cos_gt; a.gt_dist = gt_dist; a.step_size = step_size; a.tau = tau; a.max_depth = max_depth;
     a.seed = seed; a.use_hash_noise = use_hash_noise; a.tail_always = tail_always; a.ray_id_base = ray_id_base;
-    a.seed_mix = seed_mix;
+    a.seed_mix = seed_mix; a.row_first = row_first;
     a.counters = counters; a.dcounters = (double*)(counters + NL_CNT_INTS);
     a.samp_count = samp_count; a.samp_off = samp_off; a.capacity = capacity;
     a.s_vox = s_vox; a.s_depth = s_depth; a.s_dist = s_dist; a.s_ray = s_ray;
@@ -1048,6 +1084,21 @@ int nl_sample_rays(int emit, int N, const int* hit_idx, const float* hit_t0, con
         if (emit) hipLaunchKernelGGL(k_sample<true>, dim3(nl_div_up(N, NL_GEO_THREADS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);
         else      hipLaunchKernelGGL(k_sample<false>, dim3(nl_div_up(N, NL_GEO_THREADS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);
     }
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+/* Multi-GPU (dist.py): the sampler's closing loop consults the hit list of the FIRST ray of a ray's batch row (sample_gpu.cu:231,
+ * SURVEY B5); under ray sharding that ray may live on another rank.  After exchange 1 (global hit count, rank offset) every rank
+ * writes the lists of the row-first rays IT owns into table[entry][1 + NL_MAX_HITS] = (count, idx + 1, ...) and zeros elsewhere; one
+ * SUM all-reduce of the table then gives every rank every list (nl_sample_rays' row_first argument).  entries >= 200 *
+ * ceil(ceil(R_global / 200) / 800). */
+int nl_dist_row_first(const int* counters, const int* hit_idx, const int* hit_count, const int* ray_of_rank, int* table, int n_entries,
+                      void* stream)
+{
+    if (!counters || !hit_idx || !hit_count || !ray_of_rank || !table || n_entries <= 0) return NL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_dist_row_first, dim3(nl_div_up(n_entries, 8)), dim3(256), 0, (hipStream_t)stream, counters, hit_idx, hit_count,
+                       ray_of_rank, table, n_entries);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

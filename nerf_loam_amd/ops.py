@@ -61,12 +61,12 @@ def compact_hit_rays(N, hit_count, hit_rank, ray_of_rank):
 
 
 def sample_rays(emit, N, hit_idx, hit_t0, hit_t1, hit_count, hit_rank, ray_of_rank, cos_gt, gt_dist, step_size, tau, max_depth,
-                seed, use_hash_noise, tail_always, ray_id_base, seed_mix, counters, samp_count, samp_off, capacity, s_vox, s_depth, s_dist,
-                s_ray):
+                seed, use_hash_noise, tail_always, ray_id_base, seed_mix, row_first, counters, samp_count, samp_off, capacity, s_vox, s_depth,
+                s_dist, s_ray):
     check(L.lib().nl_sample_rays(int(emit), int(N), ptr(hit_idx), ptr(hit_t0), ptr(hit_t1), ptr(hit_count), ptr(hit_rank), ptr(ray_of_rank),
                                  ptr(cos_gt), ptr(gt_dist), float(step_size), float(tau), float(max_depth),
                                  ctypes.c_uint(int(seed) & 0xFFFFFFFF), int(use_hash_noise), int(tail_always), int(ray_id_base),
-                                 ptr(seed_mix), ptr(counters), ptr(samp_count), ptr(samp_off), int(capacity), ptr(s_vox), ptr(s_depth), ptr(s_dist),
+                                 ptr(seed_mix), ptr(row_first), ptr(counters), ptr(samp_count), ptr(samp_off), int(capacity), ptr(s_vox), ptr(s_depth), ptr(s_dist),
                                  ptr(s_ray), stream_ptr()), "nl_sample_rays")
 
 

@@ -237,6 +237,8 @@ class SdfEngine:
         # (adam_state: device step counter + hyper-parameters, a slice of _call_state above)
         self.graph = None
         # multi-GPU hooks (dist.py installs them); identity on one GPU
+        self.row_first = None    # multi-GPU: table of the batch rows' first-ray hit lists (dist.py, nl_dist_row_first)
+        self.hook_after_decoder_grads = None
         self.hook_after_intersect = None
         self.hook_after_count = None
         self.hook_after_backward = None
@@ -353,6 +355,8 @@ class SdfEngine:
         """A fresh torch.optim.Adam is created per bundle_adjust_frames / track_frame call
         (render_helpers.py:353,448): reset optimiser state.  emb_state=False (tracking, forward-only queries): the call never
         touches the embedding gradient accumulators / moments, so they are neither allocated nor cleared (160 B per row)."""
+        if getattr(self, "_exchange", None) is not None:
+            self._exchange.new_call()                            # multi-GPU: re-measure the touched-rows capacity
         self._call_state.zero_()                             # adam state, pose moments, g_pose / pose_grad6 (a previous call may have
         self.graph = None                                    # aborted between backward and the optimiser step): one memset
         E = m.n_rows
@@ -380,6 +384,7 @@ class SdfEngine:
         N = self.N
         c = self.counters
         tm = self._mark
+        self._map_for_exchange = m                               # multi-GPU hooks look the map's row table up here
         c.zero_()
         tm("intersect", 0)
         ops.ray_intersect(N, self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self.poses12, m.blk_hdr, m.blk_ids, m.root_side,
@@ -395,7 +400,7 @@ class SdfEngine:
         use_hash = 0 if cfg.noise_seed is None else 1
         args = (N, self.hit_idx, self.hit_t0, self.hit_t1, self.hit_count, self.hit_rank, self.ray_of_rank, self.cos_gt, self.gt_dist,
                 cfg.step_size, cfg.truncation, cfg.max_distance, seed, use_hash, int(cfg.tail_always), ray_id_base,
-                self.adam_state if fresh_noise else None, c, self.samp_count)
+                self.adam_state if fresh_noise else None, self.row_first, c, self.samp_count)
         tm("sample", 0)
         ops.sample_rays(0, *args, None, self.P_cap, None, None, None, None)
         ops.exclusive_scan(self.samp_count, self.samp_off, N, 0, c[L.NLC_P:L.NLC_P + 1], self.scan_ws)
@@ -419,6 +424,8 @@ class SdfEngine:
             tm("reduce", 0)
             ops.decoder_reduce(self.partials, self.n_slabs, dec.params, dec.grad)
             tm("reduce", 1)
+            if self.hook_after_decoder_grads is not None:
+                self.hook_after_decoder_grads(self, dec)         # multi-GPU: the decoder all-reduce starts under the embedding scatter
         tm("scatter", 0)
         ops.trilinear_bwd(self.loss_scalars, self.s_vox, self.s_depth, self.s_ray, self.rays_d_world, self.rays_d_sensor, self.frame_id,
                           self.poses12, self.F, m.centres, m.vertex_rows, m.emb, m.voxel_size, self.dX,
@@ -447,7 +454,7 @@ class SdfEngine:
         seed = 0 if cfg.noise_seed is None else cfg.noise_seed
         args = (N, self.hit_idx, self.hit_t0, self.hit_t1, self.hit_count, self.hit_rank, self.ray_of_rank, self.cos_gt, self.gt_dist,
                 cfg.step_size, cfg.truncation, cfg.max_distance, seed, 0 if cfg.noise_seed is None else 1, int(cfg.tail_always),
-                ray_id_base, None, c, self.samp_count)
+                ray_id_base, None, None, c, self.samp_count)
         ops.sample_rays(0, *args, None, self.P_cap, None, None, None, None)
         ops.exclusive_scan(self.samp_count, self.samp_off, N, 0, c[L.NLC_P:L.NLC_P + 1], self.scan_ws)
         ops.loss_finalize(c, self.loss_scalars, cfg.fs_weight, cfg.sdf_weight, cfg.truncation, cfg.max_distance, self.P_cap)

@@ -17,7 +17,7 @@ for n, step in ((2048, 0.04), (16384, 0.1)):
     c = eng.counters
     seed, N = 0, eng.N
     args = (N, eng.hit_idx, eng.hit_t0, eng.hit_t1, eng.hit_count, eng.hit_rank, eng.ray_of_rank, eng.cos_gt, eng.gt_dist,
-            cfg.step_size, cfg.truncation, cfg.max_distance, seed, 0, int(cfg.tail_always), 0, None, c, eng.samp_count)
+            cfg.step_size, cfg.truncation, cfg.max_distance, seed, 0, int(cfg.tail_always), 0, None, None, c, eng.samp_count)
     for emit in (0, 1):
         dbg = torch.zeros(max(nb, 64) * 8, dtype=torch.int64, device="cuda")
         L.lib().nl_geometry_set_debug_buffer(L.ptr(dbg))

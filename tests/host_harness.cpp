@@ -53,6 +53,7 @@ void hh_sample(int R, const int* idx, const float* t0, const float* t1, int P, f
         nl_sampler_layout(r, R, &tc.j_in_row, &tc.rays_in_row, &first);
         tc.row_first_idx = idx + (size_t)first * NL_MAX_HITS;
         tc.row_first_count = NL_MAX_HITS;
+        tc.row_first_bias = 0;
         tc.tail_always = (tail_always & 1) != 0;                       // bit 1 selects the step-parallel formulation
         const unsigned rid = ray_ids[r];
         auto noise = [&](int s) -> float { return use_hash ? nl_noise(seed, rid, (unsigned)s) : 0.5f; };

@@ -44,6 +44,7 @@ def _worker(rank, world, port, out_q):
         r2 = (int(c[L.NLC_NFS]), int(c[L.NLC_NSDF]), int(c[L.NLC_INV_SDF_RAYS]), int(c[L.NLC_INV_SDF_CNT]), int(c[L.NLC_SMAX]),
               int(c[L.NLC_P]), float(dbl[L.NLD_INV_D2]), float(dbl[L.NLD_INV_D2CNT]), float(dbl[L.NLD_FS_SQ]))
         # exchange 3
+        ex.after_decoder_grads(eng, dec)                        # (the engine calls it right after the slab reduction)
         ex.after_backward(eng, dec, True, True, True)
         r3 = (dec.grad.tolist(), float(eng.g_pose[0, 0]), float(eng.g_emb[0, 0]))
         ex.reduce_loss_sums()
