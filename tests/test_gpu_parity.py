@@ -809,7 +809,7 @@ def _sharded_vs_single(nl, golden_dir, monkeypatch, world, pad_rows=0, sparse_ro
         np.testing.assert_allclose(b["loss"], a["loss"], rtol=1e-12)
         for k in ("gdec", "gemb", "gpose", "params", "emb", "pose6"):
             assert np.array_equal(a[k], b[k]), k                                # all-reduced / replicas in lock-step: identical on every rank
-    for k, tol in (("gdec", 1e-5), ("gemb", 1e-5), ("gpose", 1e-9)):
+    for k, tol in (("gdec", 1e-5), ("gemb", 1e-5), ("gpose", 1e-6)):       # (gpose: fp32 over a ray's samples inside one lane group, then fp64)
         assert np.linalg.norm(a[k].astype(np.float64) - one[k]) <= tol * np.linalg.norm(one[k].astype(np.float64)), k
     assert np.abs(a["params"] - one["params"]).max() < 1e-5 and np.abs(a["pose6"] - one["pose6"]).max() < 1e-6
     return info
