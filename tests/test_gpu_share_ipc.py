@@ -1,0 +1,74 @@
+"""GPU (-m gpu): the mapper -> tracker hand-off ACROSS PROCESSES (reference: src/share.py:12-121, src/mapping.py:227-232,
+src/tracking.py:101-107, src/nerfloam.py:23-49).  The mapper process publishes into ShareData's device buffers; a second process,
+started with torch.multiprocessing (spawn), attaches to THE SAME device memory through HIP IPC handles and reads views: the
+version flip is visible without any host copy of the tensors, a leased snapshot is never overwritten in place, and the tracker's
+real work (do_tracking) runs on it."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from test_gpu_api_mirror import make_args
+
+pytestmark = pytest.mark.gpu
+
+
+def test_share_data_across_two_processes():
+    import torch.multiprocessing as mp
+    from nerf_loam_amd.lidar_frame import LidarFrame
+    from nerf_loam_amd.mapping import Mapping
+    from nerf_loam_amd.share import ShareData
+    import share_ipc_worker as W
+    torch.manual_seed(777)
+    pts, cos = H.scene_points(64, 64, 11)
+    mapper = Mapping(make_args())
+    f0 = LidarFrame(0, torch.from_numpy(pts), torch.from_numpy(cos), np.eye(4))
+    mapper.create_voxels(f0)
+    share = ShareData()
+    n, rows = mapper.svo.count_nodes(), mapper.dynamic_embeddings.shape[0]
+    share.reserve(2 * n, 2 * rows)
+    ctx = mp.get_context("spawn")
+    q_in, q_out = ctx.Queue(), ctx.Queue()
+    proc = ctx.Process(target=W.tracker_process, args=(share.handles(decoder_template=mapper.decoder), pts, cos, q_in, q_out))
+    proc.start()
+
+    def ask(msg):
+        q_in.put(msg)
+        r = q_out.get(timeout=300)
+        assert "error" not in r, r.get("error")
+        return r
+    try:
+        for _ in range(3):
+            mapper.do_mapping(share, f0, selection_method="current")          # publishes after every call
+        assert share.version == 3
+        r = ask("read")
+        assert r["version"] == 3 and r["n"] == n and r["rows"] == rows
+        assert r["emb_sum"] == float(mapper.dynamic_embeddings.float().abs().sum())                 # the same bytes, read in the other process
+        assert r["centres_sum"] == float(mapper.map_states["voxel_center_xyz"].double().sum())
+        assert r["dec_sum"] == float(mapper.decoder.pts_linears[1].weight.detach().double().abs().sum())
+        assert r["ptr"] != mapper.dynamic_embeddings.data_ptr()
+        # the mapper keeps optimising and publishes TWICE while the tracker still works on the snapshot it leased: not overwritten
+        snap_sum = r["emb_sum"]
+        with torch.no_grad():
+            mapper.dynamic_embeddings.add_(0.25)
+        mapper.update_share_data(share)
+        with torch.no_grad():
+            mapper.dynamic_embeddings.add_(0.25)
+        mapper.update_share_data(share)
+        torch.cuda.synchronize()
+        r2 = ask("recheck")
+        assert r2["emb_sum"] == snap_sum and r2["version_seen"] == 5          # sees the new version number, holds the old bytes
+        r3 = ask("read")
+        assert r3["version"] == 5 and r3["emb_sum"] == float(mapper.dynamic_embeddings.float().abs().sum()) and r3["emb_sum"] != snap_sum
+        with torch.no_grad():
+            mapper.dynamic_embeddings.sub_(0.5)
+        mapper.update_share_data(share)
+        t = ask("track")                                                      # do_tracking in the other process, on the shared snapshot
+        assert t["err1"] < 0.6 * t["err0"] and 0.9 < t["hit_ratio"] <= 1.0, t
+    finally:
+        q_in.put("stop")
+        proc.join(60)
+        if proc.is_alive():
+            proc.kill()
