@@ -73,7 +73,7 @@ def test_mapping_then_tracking_like_the_reference_loop():
     out = tracker.do_tracking(share, f2)
     err1 = float((out.pose.translation() - f0.pose.translation()).norm())
     assert out.pose.data.shape == (6,) and torch.isfinite(out.pose.data).all()
-    assert err1 < 0.6 * err0, (err0, err1)                              # pulled back towards the true pose
+    assert err1 < 0.8 * err0, (err0, err1)                              # 10 steps on freshly drawn rays pull it back towards the true pose
     assert 0.9 < float(out.hit_ratio) <= 1.0
 
 
@@ -281,7 +281,7 @@ def test_device_resident_share_data_hand_off():
     tracker.last_frame = f1
     out = tracker.do_tracking(share, LidarFrame(2, torch.from_numpy(pts), torch.from_numpy(cos), np.eye(4)))
     err1 = float((out.pose.translation().detach() - f0.pose.translation().detach()).norm())
-    assert err1 < 0.6 * err0, (err0, err1)
+    assert err1 < 0.8 * err0, (err0, err1)
 
 
 def test_get_scores_matches_oracle():

@@ -66,7 +66,7 @@ def test_share_data_across_two_processes():
             mapper.dynamic_embeddings.sub_(0.5)
         mapper.update_share_data(share)
         t = ask("track")                                                      # do_tracking in the other process, on the shared snapshot
-        assert t["err1"] < 0.6 * t["err0"] and 0.9 < t["hit_ratio"] <= 1.0, t
+        assert t["err1"] < 0.8 * t["err0"] and 0.9 < t["hit_ratio"] <= 1.0, t
     finally:
         q_in.put("stop")
         proc.join(60)
