@@ -165,7 +165,10 @@ int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, voi
  *   floats [0, 65536):        W2 transposed (fp32; forward GEMM B operand of gemm mode 0),
  *   floats [65536, 163840):   "W2X"  = w3_j * W2[j][k] as three bf16 planes (hi + mid + lo == the fp32 value exactly) in
  *                             MFMA-fragment order: dgrad GEMM B operand on the bf16 matrix cores,
- *   floats [163840, 262144):  "W2TX" = W2[n][k], same split and order: forward GEMM B operand on the bf16 matrix cores. */
+ *   floats [163840, 262144):  "W2TX" = W2[n][k], same split and order: forward GEMM B operand on the bf16 matrix cores,
+ *   floats [262144, 360448):  "W2A"  = W2[n][k] as three bf16 planes in the A-operand slot order of the register-chained family
+ *                             (gemm modes 3 / 4: H2^T = W2 H1^T, lane = sample),
+ *   floats [360448, 458752):  "W2XA" = w3_n * W2[n][k], same split, the chained family's dgrad A operand. */
 int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream);
 /* The two 256-deep GEMMs of nl_decoder_fwd_bwd / nl_decoder_forward: 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32),
  * 1 = bf16 matrix cores (v_mfma_f32_32x32x16_bf16) on exact-product formulations (default):
