@@ -6,19 +6,27 @@
 //   * nl_decoder.hip keeps the activations of a 64-sample tile in LDS, gives every wave 32 output COLUMNS, and synchronises the
 //     eight waves of a workgroup five times per tile; between the barriers the matrix pipes idle while the waves split H1 into
 //     operand planes, store 2-byte elements, reduce row sums with 31 shuffles, ...: 47.6 k cycles per tile against 30.7 k of MFMA.
-//   * here a wave owns 32 SAMPLES end to end.  All GEMMs are issued TRANSPOSED (D^T = B^T A^T: the weights are the A operand,
-//     the activations the B operand), so an accumulator tile holds, per lane, one sample and 16 hidden units - and those 16
-//     registers ARE two B-operand fragments of the next layer's MFMA (nl_chain_slot in nl_device_math.h: the weight planes
-//     are stored in that slot order by k_prepare_w2a).  H1, H2, the ReLU masks and dH2 never leave the register file; the row
-//     sum of the output layer is 16 in-lane FMAs and one shuffle; dL/dsdf is a lane constant.  No workgroup barrier, no
-//     activation traffic through LDS; the only LDS round trip is the 32x32 dH1 tile a wave transposes for itself to contract over
-//     samples (dX, dW1: K = 16 layers on the fp32 matrix cores, 16x16x4).
-//   * one wave per SIMD (256-thread workgroups, 512 registers per lane: three operand planes of H1 are 192 of them).  The weight
-//     planes stream from L2 into a register ring; the micro-benchmark of that stream is scripts/micro/chain_stream.hip.
+//   * here a wave owns its SAMPLES end to end (64 per pass: two 32-sample sub-tiles).  All GEMMs are issued TRANSPOSED
+//     (D^T = B^T A^T: the weights are the A operand, the activations the B operand), so an accumulator tile holds, per lane, one
+//     sample and 16 hidden units - and those 16 registers ARE two B-operand fragments of the next layer's MFMA (nl_chain_slot in
+//     nl_device_math.h: the weight planes are stored in that slot order by k_prepare_w2a).  H1, H2, the ReLU masks and dH2 never
+//     leave the register file; the row sum of the output layer is 16 in-lane FMAs and one shuffle; dL/dsdf is a lane constant.
+//     The only activation round trip through LDS is the 32x32 dH1 tile a wave transposes for itself to contract over samples
+//     (dX, dW1: K = 16 layers on the fp32 matrix cores, 16x16x4).
+//   * one wave per SIMD (256-thread workgroups, 512 registers per lane: three operand planes of H1 are 192 of them).
+//   * THE WEIGHT STREAM is what bounds this dataflow (scripts/micro/chain_stream.hip, profiles/experiments): a wave that streams its
+//     own A fragments occupies the texture-addresser path for 16 cycles per 1 KB fragment, four waves per CU load every fragment,
+//     and at 32 samples per wave a fragment feeds only 9 (forward) or 3 (dgrad) MFMAs.  So the four waves of a workgroup run in
+//     lock step and SHARE the planes through LDS: the workgroup walks 24 weight stages per pass (8 output tiles of the forward
+//     GEMM for sub-tile a, the same 8 for sub-tile b, 8 tiles of the dgrad over BOTH sub-tiles = 6 MFMAs per fragment); a stage
+//     is 48 fragments = 48 KB, double-buffered; every wave loads a quarter of the NEXT stage into registers and writes it to LDS
+//     (one fragment per k-step), one barrier per stage.  Memory instructions are interleaved ONE PER MFMA (sched_group_barrier):
+//     issued in groups they hold up the issue of the next MFMA (micro-benchmark: 39.5 -> 35.4 cycles per MFMA, floor 34.3).
 //
-// Weight gradients: dW1 / db1 / db3 accumulate in registers over all tiles of a wave and leave once per workgroup.  dW2 stays in
-// its own kernel (k_decoder_wgrad2_x, "natural" mask format below), which now also accumulates g[n] = sum_i m2(i,n) dsdf_i,
-// and two identities give the rest without keeping H2:
+// Weight gradients: dW1 / db1 accumulate per wave over all its tiles; between tiles they are parked in L2 (the W2 region of the
+// workgroup's own slab, which the dW2 kernel only writes afterwards) - ten registers per stage instead of eighty for the whole
+// kernel - and leave once per workgroup.  dW2 stays in its own kernel (k_decoder_wgrad2_x, "natural" mask format below), which also
+// accumulates g[n] = sum_i m2(i,n) dsdf_i, and two identities give the rest without keeping H2:
 //     db2[n] = w3_n g[n],    dW3[n] = sum_i dsdf_i h2[i][n] = sum_k W2[n][k] G[n][k] + b2[n] g[n],   G = dW2 / w3 (raw accumulators)
 // (h2 = m2 (H1 W2^T + b2)); nl_decoder_reduce applies them while summing the per-workgroup slabs.
 #include "nl_common.h"
@@ -34,11 +42,15 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #define CH_THREADS 256
 #define CH_W1_STRIDE 20                                 // floats per W1 row in LDS: conflict-free ds_read_b128 of half a row per lane
 #define CH_T_STRIDE 36                                  // floats per sample row of a wave's dH1 transposition tile
-#define CH_RING 4                                       // k-steps of weight fragments in flight (divides 16: static ring slots)
 #define CH_ACC_FLOATS (16 * 64 * 4 + 16 * 64)            // per wave: dW1 tiles [kt][ks][lane][4] + db1 partials [kt][ks][lane]
 #define CH_PLANE_BYTES (NL_W * NL_W * 2)
-#define CH_WS_W2A_OFF (NL_W * NL_W + 6 * NL_W * NL_W / 2)     // floats into the decoder weight workspace (nl_optim.hip)
-#define CH_WS_W2XA_OFF (NL_W * NL_W + 9 * NL_W * NL_W / 2)
+#define CH_WS_W2A_OFF (NL_W * NL_W + 6 * NL_W * NL_W / 2)     // floats into the decoder weight workspace (nl_optim.hip); W2XA follows W2A
+#define CH_STAGE_BYTES (16 * 1024)                      // one plane's share of a weight stage: 16 k-steps x 1 KB
+// scheduling classes of __builtin_amdgcn_sched_group_barrier
+#define SG_MFMA 0x008
+#define SG_VMEM_RD 0x020
+#define SG_DS_RD 0x100
+#define SG_DS_WR 0x200
 
 struct ChainArgs {
     const NlLossScalars* ls;    // NULL: forward only over P samples
@@ -46,13 +58,13 @@ struct ChainArgs {
     const float* X; const float* params; const float* ws;
     const int* s_ray; const float* s_depth; const float* cos_gt; const float* gt_dist;
     float* sdf; float* dsdf; float* dX;
-    float* partials;            // [gridDim.x][NL_DEC_PARAMS]: W1, b1, b3 regions (train)
+    float* partials;            // [gridDim.x][NL_DEC_PARAMS]: W1, b1, b3 regions (train); the W2 region is this kernel's scratch
     unsigned* relu2_nat;        // [ceil(P/32)][256]: bit b of word (tile, unit) = ReLU of H2[32 tile + b][unit] (train)
     double* dcounters;
-    long long* dbg;             // optional [16 tiles][16] shader-clock stamps of workgroup 0 / wave 0 (profiling aid)
+    long long* dbg;             // optional [16 passes][16] shader-clock stamps of workgroup 0 / wave 0 (profiling aid)
 };
 #define CH_STAMP(slot)                                                                          \
-    do { if (a.dbg && blockIdx.x == 0 && tid == 0 && tile_no < 16) a.dbg[tile_no * 16 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+    do { if (a.dbg && blockIdx.x == 0 && tid == 0 && pass_no < 16) a.dbg[pass_no * 16 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 __device__ __forceinline__ uint4 ch_bload4(rsrc_t r, int voff, int soff)
 {
@@ -63,6 +75,19 @@ __device__ __forceinline__ unsigned ch_pack_hi16(float a, float b)
     return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);      // (lo = bf16 of a, hi = bf16 of b), truncating
 }
 __device__ __forceinline__ float ch_trunc(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
+// Long-lived prefetched values are pinned to the accumulation half of the register file: a value whose uses all want an AGPR is
+// loaded there directly and stays there; left to itself the allocator spills such values to scratch right after the load - i.e. it
+// waits for the load (HBM latency) on the spot, which is exactly what a prefetch must not do.
+__device__ __forceinline__ float ch_from_acc(float x) { float v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(x)); return v; }
+__device__ __forceinline__ void ch_keep_in_acc(float x) { asm volatile("" ::"a"(x)); }
+// Stage barrier: the workgroup's LDS traffic is ordered (lgkmcnt(0)), its GLOBAL traffic is not waited for - __syncthreads() would also
+// drain vmcnt, i.e. stall every stage on the input prefetch of the next pass (HBM latency), the mask-word and accumulator stores
+__device__ __forceinline__ void ch_stage_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 // MODE 0: forward only (sdf).  1: forward + loss gradient + dgrad + dX (frozen decoder: tracking, mapping after freeze_frame).
 // 2: 1 + decoder weight gradients (dW1, db1, db3 here; the ReLU words of H2 for the dW2 kernel).
@@ -70,14 +95,12 @@ __device__ __forceinline__ float ch_trunc(float x) { return __uint_as_float(__fl
 template <int MODE, int NP>
 __global__ __launch_bounds__(CH_THREADS, 1) void k_decoder_chain(ChainArgs a)
 {
+    __shared__ __attribute__((aligned(16))) uint4 sRing[2][48][64];       // two weight stages: fragment f = 3 s + p of the stage, lane-major
     __shared__ __attribute__((aligned(16))) float sW1[NL_W * CH_W1_STRIDE];
     __shared__ __attribute__((aligned(16))) float sTab[3 * 256];          // b1 | b2 | w3 in accumulator order [tile][lh][r]
     __shared__ __attribute__((aligned(16))) uint4 sLut[256];              // byte -> 8 bf16 (1.0 where the bit is set)
-    __shared__ __attribute__((aligned(16))) float sT[4 * 32 * CH_T_STRIDE];
-    // MODE 2: every wave's running dW1 (16 accumulator tiles of 16x16) and db1 partials live HERE between tiles - 80 registers
-    // per lane otherwise, on top of the three H1 operand planes - in the lane-major order a ds_read_b128 / ds_write_b128 wants
-    __shared__ __attribute__((aligned(16))) float sAccW[MODE == 2 ? 4 * CH_ACC_FLOATS : 4];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    __shared__ __attribute__((aligned(16))) float sT[4 * 2 * 32 * CH_T_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5, l15 = lane & 15, lq = lane >> 4;
     const float* params = a.params;
     for (int i = tid; i < NL_W * NL_C; i += CH_THREADS) sW1[(i >> 4) * CH_W1_STRIDE + (i & 15)] = params[NL_OFF_W1 + i];
@@ -91,243 +114,317 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_decoder_chain(ChainArgs a)
         e.w = ((tid & 64) ? 0x3F80u : 0u) | ((tid & 128) ? 0x3F800000u : 0u);
         sLut[tid] = e;
     }
-    __syncthreads();
     NlLossScalars ls;
     int P = a.P;
     if (MODE >= 1) { ls = *a.ls; P = ls.P; }
     const float b3 = params[NL_OFF_B3];
-    const rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ws + CH_WS_W2A_OFF), 0, 3 * CH_PLANE_BYTES, 0x00020000);
-    const rsrc_t rsXA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ws + CH_WS_W2XA_OFF), 0, 3 * CH_PLANE_BYTES, 0x00020000);
+    // one resource over W2A | W2XA (adjacent in the workspace): a run-time choice between two resources would become a waterfall loop
+    const rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ws + CH_WS_W2A_OFF), 0, 6 * CH_PLANE_BYTES, 0x00020000);
     const int voff = lane * 16;
-    float* sTw = sT + w * (32 * CH_T_STRIDE);
+    float* sTw = sT + w * (2 * 32 * CH_T_STRIDE);
+
+    // ---- the weight stages: NST per pass, walked cyclically.  Stage q < 16: forward output tile q & 7 (planes W2A); q >= 16: dgrad tile
+    //      q - 16 (planes W2XA).  This wave moves fragments 12 w .. 12 w + 11 of a stage: one per k-step, written to LDS four k-steps later.
+    constexpr int NST = MODE == 0 ? 16 : 24;
+    uint4 st[5];
+    auto stage_soff = [&](int q) { return q >= 16 ? 3 * CH_PLANE_BYTES + (q - 16) * CH_STAGE_BYTES : (q & 7) * CH_STAGE_BYTES; };
+    auto fill_load = [&](int q, int i) {
+        const int f = 12 * w + i;
+        st[i % 5] = ch_bload4(rsW, voff, stage_soff(q) + (f % 3) * CH_PLANE_BYTES + (f / 3) * 1024);
+    };
+    auto fill_store = [&](int buf, int i) { sRing[buf][12 * w + i][lane] = st[i % 5]; };
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { fill_load(0, i); fill_store(0, i); }
+    __syncthreads();
+    int lbuf = 0;
+    uint4 af[2][3];                                      // A fragments of the current / next k-step; af[0] is preloaded across stage boundaries
+#pragma unroll
+    for (int p = 0; p < 3; ++p) af[0][p] = sRing[0][p][lane];
 
     // weight-gradient accumulators (MODE 2)
     float aB3 = 0.f;
     double lossFs = 0.0, lossSdf = 0.0;
-    float* sAw = sAccW + (MODE == 2 ? w * CH_ACC_FLOATS : 0);
-    if (MODE == 2) {
-        for (int i = lane; i < CH_ACC_FLOATS; i += 64) sAw[i] = 0.f;
-        __builtin_amdgcn_wave_barrier();
-    }
+    float* accw = MODE == 2 ? a.partials + (size_t)blockIdx.x * NL_DEC_PARAMS + NL_OFF_W2 + w * CH_ACC_FLOATS : nullptr;
     // ReLU-word assembly (MODE 2): lane j < 32 collects the word of unit j of the current 32-unit tile
     const int mw_r = (l31 & 3) + 4 * (l31 >> 3), mw_hi = (l31 >> 2) & 1;
 
-    const int ntiles = (P + 31) >> 5;
-    // inputs of a tile: this lane's sample (channels 8 lh .. 8 lh + 7) and its loss geometry; the NEXT tile's are fetched under the
-    // current tile's backward phase
-    float4 nx0 = make_float4(0.f, 0.f, 0.f, 0.f), nx1 = nx0;
-    float ncz = 0.f, ncd = 0.f;
-    auto fetch_inputs = [&](int tile) {
-        const int gg = (tile << 5) + l31;
-        nx0 = make_float4(0.f, 0.f, 0.f, 0.f); nx1 = nx0; ncz = 0.f; ncd = 0.f;
-        if (tile < ntiles && gg < P) {
-            const float4* xp = reinterpret_cast<const float4*>(a.X + (size_t)gg * NL_C + 8 * lh);
-            nx0 = xp[0]; nx1 = xp[1];
-            if (MODE >= 1) {
-                const int ray = a.s_ray[gg];
-                ncz = a.s_depth[gg] * a.cos_gt[ray]; ncd = a.gt_dist[ray];
+    const int nsub = (P + 31) >> 5, npass = (nsub + 1) >> 1;
+    // inputs of a pass: this lane's sample of either sub-tile (channels 8 lh .. 8 lh + 7) and its loss geometry; the NEXT pass's are
+    // fetched under the current pass's backward phase
+    float4 nx[2][2];
+    float ncz[2], ncd[2];
+    auto fetch_inputs = [&](int pass) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int gg = ((2 * pass + u) << 5) + l31;
+            nx[u][0] = make_float4(0.f, 0.f, 0.f, 0.f); nx[u][1] = nx[u][0]; ncz[u] = 0.f; ncd[u] = 0.f;
+            if (gg < P) {
+                const float4* xp = reinterpret_cast<const float4*>(a.X + (size_t)gg * NL_C + 8 * lh);
+                nx[u][0] = xp[0]; nx[u][1] = xp[1];
+                if (MODE >= 1) {
+                    const int ray = a.s_ray[gg];
+                    ncz[u] = a.s_depth[gg] * a.cos_gt[ray]; ncd[u] = a.gt_dist[ray];
+                }
             }
         }
     };
     fetch_inputs(blockIdx.x * 4 + w);
-    int tile_no = 0;
-    for (int tile = blockIdx.x * 4 + w; tile < ntiles; tile += gridDim.x * 4, ++tile_no) {
+    int pass_no = 0;
+    // the four waves walk the stages in lock step: a wave whose pass lies beyond the data computes on zeros and writes nothing
+    for (int base = blockIdx.x * 4; base < npass; base += gridDim.x * 4, ++pass_no) {
         CH_STAMP(0);
-        const int row0 = tile << 5, g = row0 + l31;
-        const bool live = g < P;
-        const float xf[8] = {nx0.x, nx0.y, nx0.z, nx0.w, nx1.x, nx1.y, nx1.z, nx1.w};
-        const float cz = ncz, cd = ncd;
-        if (MODE == 0) fetch_inputs(tile + gridDim.x * 4);
-        // first k-steps of the forward weight stream: in flight under layer 1
-        uint4 aq[CH_RING][3];
+        const int pass = base + w;
+        float xin[2][8], cz[2], cd[2];
 #pragma unroll
-        for (int j = 0; j < CH_RING - 1; ++j)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) aq[j][p] = ch_bload4(rsA, voff, p * CH_PLANE_BYTES + j * 1024);
-
-        CH_STAMP(1);
-        // ---------------- layer 1: H1^T = relu(W1 X^T + b1), split into three bf16 operand planes (registers) ----------------
-        uint4 hb[16][3];
-        unsigned m1w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int ut = 0; ut < 8; ++ut) {
-            f32x16 c;
-            {
-                const float4* tb = reinterpret_cast<const float4*>(sTab + ut * 32 + lh * 16);
-                const float4 t0 = tb[0], t1 = tb[1], t2 = tb[2], t3 = tb[3];
-                c[0] = t0.x; c[1] = t0.y; c[2] = t0.z; c[3] = t0.w; c[4] = t1.x; c[5] = t1.y; c[6] = t1.z; c[7] = t1.w;
-                c[8] = t2.x; c[9] = t2.y; c[10] = t2.z; c[11] = t2.w; c[12] = t3.x; c[13] = t3.y; c[14] = t3.z; c[15] = t3.w;
-            }
-            const float4* wr = reinterpret_cast<const float4*>(sW1 + (32 * ut + l31) * CH_W1_STRIDE + 8 * lh);
-            const float4 w0 = wr[0], w1 = wr[1];
-            c = MFMA32(w0.x, xf[0], c); c = MFMA32(w0.y, xf[1], c); c = MFMA32(w0.z, xf[2], c); c = MFMA32(w0.w, xf[3], c);
-            c = MFMA32(w1.x, xf[4], c); c = MFMA32(w1.y, xf[5], c); c = MFMA32(w1.z, xf[6], c); c = MFMA32(w1.w, xf[7], c);
-            unsigned bits = 0u, hi[8], mid[8], lo[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float h0 = fmaxf(c[2 * q], 0.f), h1 = fmaxf(c[2 * q + 1], 0.f);
-                bits |= (h0 > 0.f ? (1u << (2 * q)) : 0u) | (h1 > 0.f ? (2u << (2 * q)) : 0u);
-                hi[q] = ch_pack_hi16(h0, h1);
-                const float r0 = h0 - ch_trunc(h0), r1 = h1 - ch_trunc(h1);
-                mid[q] = ch_pack_hi16(r0, r1);
-                lo[q] = ch_pack_hi16(r0 - ch_trunc(r0), r1 - ch_trunc(r1));
-            }
-            hb[2 * ut][0] = make_uint4(hi[0], hi[1], hi[2], hi[3]); hb[2 * ut + 1][0] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
-            hb[2 * ut][1] = make_uint4(mid[0], mid[1], mid[2], mid[3]); hb[2 * ut + 1][1] = make_uint4(mid[4], mid[5], mid[6], mid[7]);
-            hb[2 * ut][2] = make_uint4(lo[0], lo[1], lo[2], lo[3]); hb[2 * ut + 1][2] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
-            m1w[ut >> 1] |= bits << (16 * (ut & 1));
+        for (int u = 0; u < 2; ++u) {
+            xin[u][0] = ch_from_acc(nx[u][0].x); xin[u][1] = ch_from_acc(nx[u][0].y); xin[u][2] = ch_from_acc(nx[u][0].z); xin[u][3] = ch_from_acc(nx[u][0].w);
+            xin[u][4] = ch_from_acc(nx[u][1].x); xin[u][5] = ch_from_acc(nx[u][1].y); xin[u][6] = ch_from_acc(nx[u][1].z); xin[u][7] = ch_from_acc(nx[u][1].w);
+            cz[u] = ch_from_acc(ncz[u]); cd[u] = ch_from_acc(ncd[u]);
         }
-
-        CH_STAMP(2);
-        // ---------------- layer 2 + output layer: s = w3 . relu(W2 H1 + b2) + b3, H2 never stored ----------------
-        float spart = 0.f;
-        unsigned m2w[4] = {0u, 0u, 0u, 0u};
+        if (MODE == 0) fetch_inputs(pass + gridDim.x * 4);
+        unsigned m1w[2][4], m2w[2][4];
+        float ds[2] = {0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tile = 2 * pass + u, g = (tile << 5) + l31;
+            const bool live = g < P;
+            // ---------------- layer 1: H1^T = relu(W1 X^T + b1), split into three bf16 operand planes (registers) ----------------
+            uint4 hb[16][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { m1w[u][q] = 0u; m2w[u][q] = 0u; }
+#pragma unroll
+            for (int ut = 0; ut < 8; ++ut) {
+                f32x16 c;
+                {
+                    const float4* tb = reinterpret_cast<const float4*>(sTab + ut * 32 + lh * 16);
+                    const float4 t0 = tb[0], t1 = tb[1], t2 = tb[2], t3 = tb[3];
+                    c[0] = t0.x; c[1] = t0.y; c[2] = t0.z; c[3] = t0.w; c[4] = t1.x; c[5] = t1.y; c[6] = t1.z; c[7] = t1.w;
+                    c[8] = t2.x; c[9] = t2.y; c[10] = t2.z; c[11] = t2.w; c[12] = t3.x; c[13] = t3.y; c[14] = t3.z; c[15] = t3.w;
+                }
+                const float4* wr = reinterpret_cast<const float4*>(sW1 + (32 * ut + l31) * CH_W1_STRIDE + 8 * lh);
+                const float4 w0 = wr[0], w1 = wr[1];
+                c = MFMA32(w0.x, xin[u][0], c); c = MFMA32(w0.y, xin[u][1], c); c = MFMA32(w0.z, xin[u][2], c); c = MFMA32(w0.w, xin[u][3], c);
+                c = MFMA32(w1.x, xin[u][4], c); c = MFMA32(w1.y, xin[u][5], c); c = MFMA32(w1.z, xin[u][6], c); c = MFMA32(w1.w, xin[u][7], c);
+                unsigned bits = 0u, hi[8], mid[8], lo[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float h0 = fmaxf(c[2 * q], 0.f), h1 = fmaxf(c[2 * q + 1], 0.f);
+                    bits |= (h0 > 0.f ? (1u << (2 * q)) : 0u) | (h1 > 0.f ? (2u << (2 * q)) : 0u);
+                    hi[q] = ch_pack_hi16(h0, h1);
+                    const float r0 = h0 - ch_trunc(h0), r1 = h1 - ch_trunc(h1);
+                    mid[q] = ch_pack_hi16(r0, r1);
+                    lo[q] = ch_pack_hi16(r0 - ch_trunc(r0), r1 - ch_trunc(r1));
+                }
+                hb[2 * ut][0] = make_uint4(hi[0], hi[1], hi[2], hi[3]); hb[2 * ut + 1][0] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+                hb[2 * ut][1] = make_uint4(mid[0], mid[1], mid[2], mid[3]); hb[2 * ut + 1][1] = make_uint4(mid[4], mid[5], mid[6], mid[7]);
+                hb[2 * ut][2] = make_uint4(lo[0], lo[1], lo[2], lo[3]); hb[2 * ut + 1][2] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+                m1w[u][ut >> 1] |= bits << (16 * (ut & 1));
+                // materialise the word HERE: left alone, the compiler sinks the 256 compares to where the dgrad first reads the
+                // words and keeps every fp32 H1 value alive (and spilled) until then
+                asm volatile("" : "+v"(m1w[u][ut >> 1]));
+            }
+            CH_STAMP(1 + 3 * u);
+            // ---------------- layer 2 + output layer: s = w3 . relu(W2 H1 + b2) + b3, H2 never stored ----------------
+            float spart = 0.f;
 #pragma unroll 1
-        for (int nt = 0; nt < 8; ++nt) {
-            f32x16 h;
-            {
-                const float4* tb = reinterpret_cast<const float4*>(sTab + 256 + nt * 32 + lh * 16);
-                const float4 t0 = tb[0], t1 = tb[1], t2 = tb[2], t3 = tb[3];
-                h[0] = t0.x; h[1] = t0.y; h[2] = t0.z; h[3] = t0.w; h[4] = t1.x; h[5] = t1.y; h[6] = t1.z; h[7] = t1.w;
-                h[8] = t2.x; h[9] = t2.y; h[10] = t2.z; h[11] = t2.w; h[12] = t3.x; h[13] = t3.y; h[14] = t3.z; h[15] = t3.w;
-            }
+            for (int nt = 0; nt < 8; ++nt) {
+                const int qn = (8 * u + nt + 1) % NST;                      // the stage this one fills
+                f32x16 h;
+                {
+                    const float4* tb = reinterpret_cast<const float4*>(sTab + 256 + nt * 32 + lh * 16);
+                    const float4 t0 = tb[0], t1 = tb[1], t2 = tb[2], t3 = tb[3];
+                    h[0] = t0.x; h[1] = t0.y; h[2] = t0.z; h[3] = t0.w; h[4] = t1.x; h[5] = t1.y; h[6] = t1.z; h[7] = t1.w;
+                    h[8] = t2.x; h[9] = t2.y; h[10] = t2.z; h[11] = t2.w; h[12] = t3.x; h[13] = t3.y; h[14] = t3.z; h[15] = t3.w;
+                }
+                __builtin_amdgcn_sched_barrier(0);                          // the reads above stay out of the pipelined region below
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int so = ((nt * 16 + s + CH_RING - 1) & 127) * 1024;      // (wraps at the end: three harmless extra loads)
+                for (int s = 0; s < 16; ++s) {
+                    if (s + 1 < 16) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) aq[(s + CH_RING - 1) % CH_RING][p] = ch_bload4(rsA, voff, p * CH_PLANE_BYTES + so);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int pa = 0; pa < 3; ++pa)
-#pragma unroll
-                    for (int pb = 0; pb < 3; ++pb) {
-                        if (NP == 6 && pa + pb > 2) continue;
-                        h = MFMA_BF16(__builtin_bit_cast(bf16x8, aq[s % CH_RING][pa]), __builtin_bit_cast(bf16x8, hb[s][pb]), h);
+                        for (int p = 0; p < 3; ++p) af[(s + 1) & 1][p] = sRing[lbuf][3 * (s + 1) + p][lane];
                     }
-            }
-            const float4* tw = reinterpret_cast<const float4*>(sTab + 512 + nt * 32 + lh * 16);
-            const float4 w0 = tw[0], w1 = tw[1], w2 = tw[2], w3 = tw[3];
-            const float wv[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
-            unsigned bits = 0u, mword = 0u;
+                    if (s >= 4) fill_store(lbuf ^ 1, s - 4);
+                    if (s < 12) fill_load(qn, s);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float hv = fmaxf(h[r], 0.f);
-                const bool on = hv > 0.f;
-                bits |= on ? (1u << r) : 0u;
-                spart = fmaf(hv, wv[r], spart);
-                if (MODE == 2) {
-                    const unsigned long long bal = __ballot(on);
-                    const unsigned pick = mw_hi ? (unsigned)(bal >> 32) : (unsigned)bal;
-                    mword = (mw_r == r) ? pick : mword;
+                    for (int pa = 0; pa < 3; ++pa)
+#pragma unroll
+                        for (int pb = 0; pb < 3; ++pb) {
+                            if (NP == 6 && pa + pb > 2) continue;
+                            h = MFMA_BF16(__builtin_bit_cast(bf16x8, af[s & 1][pa]), __builtin_bit_cast(bf16x8, hb[s][pb]), h);
+                        }
+                    // one memory instruction in the shadow of each MFMA
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) { __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0); __builtin_amdgcn_sched_group_barrier(SG_DS_RD, 1, 0); }
+                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0); __builtin_amdgcn_sched_group_barrier(SG_DS_WR, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0); __builtin_amdgcn_sched_group_barrier(SG_VMEM_RD, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, NP - 5, 0);
+                }
+                ch_stage_barrier();                                         // next stage complete in LDS; this one free to be refilled
+                lbuf ^= 1;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) af[0][p] = sRing[lbuf][p][lane];
+                const float4* tw = reinterpret_cast<const float4*>(sTab + 512 + nt * 32 + lh * 16);
+                const float4 w0 = tw[0], w1 = tw[1], w2 = tw[2], w3 = tw[3];
+                const float wv[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+                unsigned bits = 0u, mword = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float hv = fmaxf(h[r], 0.f);
+                    const bool on = hv > 0.f;
+                    bits |= on ? (1u << r) : 0u;
+                    spart = fmaf(hv, wv[r], spart);
+                    if (MODE == 2) {
+                        const unsigned long long bal = __ballot(on);
+                        const unsigned pick = mw_hi ? (unsigned)(bal >> 32) : (unsigned)bal;
+                        mword = (mw_r == r) ? pick : mword;
+                    }
+                }
+                // 128-bit shift register: after the 8th tile, tile nt sits in bits [16 nt, 16 nt + 16)
+                m2w[u][0] = (m2w[u][0] >> 16) | (m2w[u][1] << 16); m2w[u][1] = (m2w[u][1] >> 16) | (m2w[u][2] << 16);
+                m2w[u][2] = (m2w[u][2] >> 16) | (m2w[u][3] << 16); m2w[u][3] = (m2w[u][3] >> 16) | (bits << 16);
+                asm volatile("" : "+v"(m2w[u][3]));
+                if (MODE == 2 && lh == 0 && tile < nsub) a.relu2_nat[(size_t)tile * NL_W + 32 * nt + l31] = mword;
+            }
+            CH_STAMP(2 + 3 * u);
+            const float sv = (spart + __shfl_xor(spart, 32)) + b3;
+            if (MODE == 0) {
+                if (live && lh == 0) a.sdf[g] = sv;
+            } else if (live) {
+                // ---------------- loss gradient (criterion.py): a lane constant ----------------
+                bool f, m;
+                nl_loss_masks(cz[u], cd[u], ls.tau, ls.max_depth, &f, &m);
+                float q1, q2;
+                ds[u] = nl_loss_grad(sv, cz[u], cd[u], f, m, ls, &q1, &q2);
+                if (lh == 0) {
+                    a.sdf[g] = sv; a.dsdf[g] = ds[u];
+                    lossFs += (double)q1; lossSdf += (double)q2;
+                    if (MODE == 2) aB3 += ds[u];
                 }
             }
-            // 128-bit shift register: after the 8th tile, tile nt sits in bits [16 nt, 16 nt + 16)
-            m2w[0] = (m2w[0] >> 16) | (m2w[1] << 16); m2w[1] = (m2w[1] >> 16) | (m2w[2] << 16);
-            m2w[2] = (m2w[2] >> 16) | (m2w[3] << 16); m2w[3] = (m2w[3] >> 16) | (bits << 16);
-            if (MODE == 2 && lh == 0) a.relu2_nat[(size_t)tile * NL_W + 32 * nt + l31] = mword;
+            CH_STAMP(3 + 3 * u);
         }
-        CH_STAMP(3);
-        const float sv = (spart + __shfl_xor(spart, 32)) + b3;
-        if (MODE == 0) {
-            if (live && lh == 0) a.sdf[g] = sv;
-            continue;
-        }
-        // ---------------- loss gradient (criterion.py): a lane constant ----------------
-        float ds = 0.f;
-        if (live) {
-            bool f, m;
-            nl_loss_masks(cz, cd, ls.tau, ls.max_depth, &f, &m);
-            float q1, q2;
-            ds = nl_loss_grad(sv, cz, cd, f, m, ls, &q1, &q2);
-            if (lh == 0) {
-                a.sdf[g] = sv; a.dsdf[g] = ds;
-                lossFs += (double)q1; lossSdf += (double)q2;
-                if (MODE == 2) aB3 += ds;
-            }
-        }
-        CH_STAMP(4);
-        // ---------------- dgrad: dH1^T = ((w3 W2)^T mask^T) * dsdf * [H1 > 0]; layer-1 backward per 32-unit tile ----------------
-        fetch_inputs(tile + gridDim.x * 4);                     // the next tile's inputs arrive under this tile's backward
-        uint4 mf[16];
+        if (MODE == 0) continue;
+        // ---------------- dgrad over both sub-tiles: dH1^T = ((w3 W2)^T mask^T) * dsdf * [H1 > 0]; layer-1 backward per 32-unit tile ----------------
+        fetch_inputs(pass + gridDim.x * 4);                     // the next pass's inputs arrive under this pass's backward
+        uint4 mf[2][16];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) mf[s] = sLut[(m2w[s >> 2] >> (8 * (s & 3))) & 0xFFu];
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int j = 0; j < CH_RING - 1; ++j)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) aq[j][p] = ch_bload4(rsXA, voff, p * CH_PLANE_BYTES + j * 1024);
-        float xw[8];
+            for (int s = 0; s < 16; ++s) mf[u][s] = sLut[(m2w[u][s >> 2] >> (8 * (s & 3))) & 0xFFu];
+        float xw[2][8];
         if (MODE == 2) {
 #pragma unroll
-            for (int ii = 0; ii < 8; ++ii) { const int gi = row0 + 4 * ii + lq; xw[ii] = gi < P ? a.X[(size_t)gi * NL_C + l15] : 0.f; }
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int ii = 0; ii < 8; ++ii) { const int gi = ((2 * pass + u) << 5) + 4 * ii + lq; xw[u][ii] = gi < P ? a.X[(size_t)gi * NL_C + l15] : 0.f; }
         }
-        f32x4 dxa[2];
+        f32x4 dxa[2][2];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) for (int r = 0; r < 4; ++r) dxa[sub][r] = 0.f;
-#pragma unroll
+        for (int u = 0; u < 2; ++u) for (int sub = 0; sub < 2; ++sub) for (int r = 0; r < 4; ++r) dxa[u][sub][r] = 0.f;
+        CH_STAMP(7);
+#pragma unroll 1
         for (int kt = 0; kt < 8; ++kt) {
-            f32x16 gacc;
+            const int qn = (16 + kt + 1) % NST;
+            f32x16 gacc[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
+            for (int u = 0; u < 2; ++u) for (int r = 0; r < 16; ++r) gacc[u][r] = 0.f;
+            // this wave's dW1 / db1 accumulators of units 32 kt .. 32 kt + 31: parked in L2 between passes
+            f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+            float b0 = 0.f, b1 = 0.f;
+            f32x4* aw = MODE == 2 ? reinterpret_cast<f32x4*>(accw + (2 * kt * 64 + lane) * 4) : nullptr;
+            float* ab = MODE == 2 ? accw + 16 * 64 * 4 + 2 * kt * 64 + lane : nullptr;
+            if (MODE == 2 && pass_no > 0) { w0 = aw[0]; w1 = aw[64]; b0 = ab[0]; b1 = ab[64]; }
+            if (kt == 0) CH_STAMP(11);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const int so = ((kt * 16 + s + CH_RING - 1) & 127) * 1024;
+                if (s + 1 < 16) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) aq[(s + CH_RING - 1) % CH_RING][p] = ch_bload4(rsXA, voff, p * CH_PLANE_BYTES + so);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int p = 0; p < 3; ++p) af[(s + 1) & 1][p] = sRing[lbuf][3 * (s + 1) + p][lane];
+                }
+                if (s >= 4) fill_store(lbuf ^ 1, s - 4);
+                if (s < 12) fill_load(qn, s);
 #pragma unroll
                 for (int pa = 0; pa < 3; ++pa)
-                    gacc = MFMA_BF16(__builtin_bit_cast(bf16x8, aq[s % CH_RING][pa]), __builtin_bit_cast(bf16x8, mf[s]), gacc);
-            }
-            if (kt == 0) CH_STAMP(5);                            // after the first tile's 48 MFMAs: stream start-up + one dgrad tile
-            const unsigned b1bits = (m1w[kt >> 1] >> (16 * (kt & 1))) & 0xFFFFu;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4 v;
-                v.x = gacc[4 * q] * (((b1bits >> (4 * q)) & 1u) ? ds : 0.f);
-                v.y = gacc[4 * q + 1] * (((b1bits >> (4 * q + 1)) & 1u) ? ds : 0.f);
-                v.z = gacc[4 * q + 2] * (((b1bits >> (4 * q + 2)) & 1u) ? ds : 0.f);
-                v.w = gacc[4 * q + 3] * (((b1bits >> (4 * q + 3)) & 1u) ? ds : 0.f);
-                *reinterpret_cast<float4*>(sTw + l31 * CH_T_STRIDE + 8 * q + 4 * lh) = v;       // column = unit nl_chain_unit(r, lh)
+                    for (int u = 0; u < 2; ++u)
+                        gacc[u] = MFMA_BF16(__builtin_bit_cast(bf16x8, af[s & 1][pa]), __builtin_bit_cast(bf16x8, mf[u][s]), gacc[u]);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0); __builtin_amdgcn_sched_group_barrier(SG_DS_RD, 1, 0); }
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0); __builtin_amdgcn_sched_group_barrier(SG_DS_WR, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0); __builtin_amdgcn_sched_group_barrier(SG_VMEM_RD, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+            }
+            if (kt == 0) CH_STAMP(12);
+            ch_stage_barrier();
+            lbuf ^= 1;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[0][p] = sRing[lbuf][p][lane];
+            if (kt == 0) CH_STAMP(8);                            // after the first dgrad stage's 96 MFMAs
+            const unsigned m1a = kt < 4 ? (kt < 2 ? m1w[0][0] : m1w[0][1]) : (kt < 6 ? m1w[0][2] : m1w[0][3]);
+            const unsigned m1b = kt < 4 ? (kt < 2 ? m1w[1][0] : m1w[1][1]) : (kt < 6 ? m1w[1][2] : m1w[1][3]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float* sTu = sTw + u * (32 * CH_T_STRIDE);
+                const unsigned b1bits = ((u ? m1b : m1a) >> (16 * (kt & 1))) & 0xFFFFu;
+                const float dsu = ds[u];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 v;
+                    v.x = gacc[u][4 * q] * (((b1bits >> (4 * q)) & 1u) ? dsu : 0.f);
+                    v.y = gacc[u][4 * q + 1] * (((b1bits >> (4 * q + 1)) & 1u) ? dsu : 0.f);
+                    v.z = gacc[u][4 * q + 2] * (((b1bits >> (4 * q + 2)) & 1u) ? dsu : 0.f);
+                    v.w = gacc[u][4 * q + 3] * (((b1bits >> (4 * q + 3)) & 1u) ? dsu : 0.f);
+                    *reinterpret_cast<float4*>(sTu + l31 * CH_T_STRIDE + 8 * q + 4 * lh) = v;       // column = unit nl_chain_unit(r, lh)
+                }
             }
             __builtin_amdgcn_wave_barrier();                     // same-wave LDS write -> read (in order in hardware; pins the compiler)
-            // dX[i][c] += sum_k dH1[i][32 kt + k] W1[32 kt + k][c]   (16x16x4 fp32: A = dH1 rows of one 16-sample half, B = W1 rows)
-            {
-                const float* ta = sTw + l15 * CH_T_STRIDE + lq;
-                const float* wb = sW1 + (32 * kt + lq) * CH_W1_STRIDE + l15;
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    const float bw = wb[4 * kk * CH_W1_STRIDE];
-                    dxa[0] = MFMA16(ta[4 * kk], bw, dxa[0]);
-                    dxa[1] = MFMA16(ta[16 * CH_T_STRIDE + 4 * kk], bw, dxa[1]);
+            for (int u = 0; u < 2; ++u) {
+                const float* sTu = sTw + u * (32 * CH_T_STRIDE);
+                // dX[i][c] += sum_k dH1[i][32 kt + k] W1[32 kt + k][c]   (16x16x4 fp32: A = dH1 rows of one 16-sample half, B = W1 rows)
+                {
+                    const float* ta = sTu + l15 * CH_T_STRIDE + lq;
+                    const float* wb = sW1 + (32 * kt + lq) * CH_W1_STRIDE + l15;
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        const float bw = wb[4 * kk * CH_W1_STRIDE];
+                        dxa[u][0] = MFMA16(ta[4 * kk], bw, dxa[u][0]);
+                        dxa[u][1] = MFMA16(ta[16 * CH_T_STRIDE + 4 * kk], bw, dxa[u][1]);
+                    }
+                }
+                if (MODE == 2) {
+                    // dW1[32 kt + k][c] += sum_i dH1[i][32 kt + k] X[i][c]   (A = dH1 columns of one 16-unit half, B = X rows)
+                    const float* ta = sTu + lq * CH_T_STRIDE + l15;
+#pragma unroll
+                    for (int ii = 0; ii < 8; ++ii) {
+                        const float a0 = ta[4 * ii * CH_T_STRIDE], a1 = ta[4 * ii * CH_T_STRIDE + 16];
+                        w0 = MFMA16(a0, xw[u][ii], w0);
+                        w1 = MFMA16(a1, xw[u][ii], w1);
+                        b0 += a0; b1 += a1;
+                    }
                 }
             }
-            if (MODE == 2) {
-                // dW1[32 kt + k][c] += sum_i dH1[i][32 kt + k] X[i][c]   (A = dH1 columns of one 16-unit half, B = X rows)
-                const float* ta = sTw + lq * CH_T_STRIDE + l15;
-                f32x4* aw = reinterpret_cast<f32x4*>(sAw + (2 * kt * 64 + lane) * 4);
-                float* ab = sAw + 16 * 64 * 4 + 2 * kt * 64 + lane;
-                f32x4 w0 = aw[0], w1 = aw[64];
-                float b0 = ab[0], b1 = ab[64];
-#pragma unroll
-                for (int ii = 0; ii < 8; ++ii) {
-                    const float a0 = ta[4 * ii * CH_T_STRIDE], a1 = ta[4 * ii * CH_T_STRIDE + 16];
-                    w0 = MFMA16(a0, xw[ii], w0);
-                    w1 = MFMA16(a1, xw[ii], w1);
-                    b0 += a0; b1 += a1;
-                }
-                aw[0] = w0; aw[64] = w1; ab[0] = b0; ab[64] = b1;
-            }
+            if (MODE == 2) { aw[0] = w0; aw[64] = w1; ab[0] = b0; ab[64] = b1; }
             __builtin_amdgcn_wave_barrier();
-            if (kt == 0) CH_STAMP(6);                            // one tile's layer-1 backward
+            if (kt == 0) CH_STAMP(9);                            // one stage's layer-1 backward (both sub-tiles)
         }
-        CH_STAMP(7);
+        CH_STAMP(10);
+        if (MODE == 2) {
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gi = row0 + 16 * sub + 4 * lq + r;
-                if (gi < P) a.dX[(size_t)gi * NL_C + l15] = dxa[sub][r];
-            }
+                for (int ii = 0; ii < 8; ++ii) ch_keep_in_acc(xw[u][ii]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gi = ((2 * pass + u) << 5) + 16 * sub + 4 * lq + r;
+                    if (gi < P) a.dX[(size_t)gi * NL_C + l15] = dxa[u][sub][r];
+                }
     }
     if (MODE == 0) return;
 
@@ -337,33 +434,34 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_decoder_chain(ChainArgs a)
     if (lane == 0 && (lossFs != 0.0 || lossSdf != 0.0)) { atomicAdd(&a.dcounters[NLD_FS_SQ], lossFs); atomicAdd(&a.dcounters[NLD_SDF_SQ], lossSdf); }
     if (MODE != 2) return;
 
-    // ---------------- weight-gradient slab of this workgroup: the four waves' accumulators summed in LDS, one wave at a time ----------
-    __syncthreads();                                             // every wave is done with sW1 / sTab
-    float* sAcc = sW1;                                           // [4096] dW1 | [256] db1 | [1] db3  (20 KB region)
+    // ---------------- weight-gradient slab of this workgroup: the four waves' parked accumulators summed in a fixed order ----------
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) aB3 += __shfl_xor(aB3, off);
-    for (int round = 0; round < 4; ++round) {
-        if (w == round) {
-#pragma unroll 1
-            for (int t = 0; t < 16; ++t) {                          // t = 2 kt + ks: units 16 t .. 16 t + 15
-                const f32x4 v = *reinterpret_cast<const f32x4*>(sAw + (t * 64 + lane) * 4);
-                float b = sAw[16 * 64 * 4 + t * 64 + lane];
-                b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int idx = (16 * t + 4 * lq + r) * NL_C + l15;
-                    sAcc[idx] = (round ? sAcc[idx] : 0.f) + v[r];
-                }
-                if (lq == 0) { const int idx = 4096 + 16 * t + l15; sAcc[idx] = (round ? sAcc[idx] : 0.f) + b; }
-            }
-            if (lane == 0) sAcc[4352] = (round ? sAcc[4352] : 0.f) + aB3;
-        }
-        __syncthreads();
-    }
+    if (lane == 0) sTab[w] = aB3;
+    __threadfence();
+    __syncthreads();                                             // every wave's last accumulator stores are visible
     float* base = a.partials + (size_t)blockIdx.x * NL_DEC_PARAMS;
-    for (int i = tid; i < NL_W * NL_C; i += CH_THREADS) base[NL_OFF_W1 + i] = sAcc[i];
-    base[NL_OFF_B1 + tid] = sAcc[4096 + tid];
-    if (tid == 0) base[NL_OFF_B3] = sAcc[4352];
+    const float* acc0 = base + NL_OFF_W2;
+    const bool any = blockIdx.x * 4 < npass;                     // a workgroup without a pass never wrote its scratch
+    for (int i = tid; i < NL_W * NL_C; i += CH_THREADS) {
+        const int u = i >> 4, c = i & 15, e = ((u >> 4) * 64 + ((u >> 2) & 3) * 16 + c) * 4 + (u & 3);
+        float s = 0.f;
+        if (any) s = ((acc0[e] + acc0[CH_ACC_FLOATS + e]) + acc0[2 * CH_ACC_FLOATS + e]) + acc0[3 * CH_ACC_FLOATS + e];
+        base[NL_OFF_W1 + i] = s;
+    }
+    {
+        const int e = 16 * 64 * 4 + (tid >> 4) * 64 + (tid & 15);
+        float s = 0.f;
+        if (any) {
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                const float* ap = acc0 + ww * CH_ACC_FLOATS + e;
+                s += ((ap[0] + ap[16]) + ap[32]) + ap[48];
+            }
+        }
+        base[NL_OFF_B1 + tid] = s;
+    }
+    if (tid == 0) base[NL_OFF_B3] = ((sTab[0] + sTab[1]) + sTab[2]) + sTab[3];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -449,7 +547,7 @@ int nl_decoder_chain_forward(const float* X, const float* params, const float* w
     a.ls = nullptr; a.P = P; a.X = X; a.params = params; a.ws = ws; a.s_ray = nullptr; a.s_depth = nullptr; a.cos_gt = nullptr;
     a.gt_dist = nullptr; a.sdf = sdf; a.dsdf = nullptr; a.dX = nullptr; a.partials = nullptr; a.relu2_nat = nullptr; a.dcounters = nullptr;
     a.dbg = nullptr;
-    const int need = nl_div_up(nl_div_up(P, 32), 4);
+    const int need = nl_div_up(nl_div_up(P, 64), 4);
     const dim3 g(nblocks < need ? nblocks : need), b(CH_THREADS);
     if (six_products) hipLaunchKernelGGL((k_decoder_chain<0, 6>), g, b, 0, (hipStream_t)stream, a);
     else              hipLaunchKernelGGL((k_decoder_chain<0, 9>), g, b, 0, (hipStream_t)stream, a);

@@ -19,13 +19,17 @@ for train in (True, False):
     torch.cuda.synchronize()
     L.lib().nl_decoder_set_debug_buffer(None)
     if CHAIN:
-        d = dbg.cpu().numpy().reshape(16, 16)[:, :8]
-        names = ["inputs", "layer1", "layer2+out", "loss", "dgrad tile 0 (+stream start)", "L1bwd tile 0", "7 more dgrad+L1bwd tiles"]
+        d = dbg.cpu().numpy().reshape(16, 16)[:, :11]
+        names = ["layer1 a", "layer2+out a (8 stages)", "loss a", "layer1 b", "layer2+out b (8 stages)", "loss b", "dgrad set-up (mask fragments, X)",
+                 "dgrad stage 0 (96 MFMAs)", "L1bwd stage 0 (both sub-tiles)", "7 more dgrad + L1bwd stages"]
         ph = np.diff(d[1:9], axis=1)
-        print("train" if train else "frozen", "chained kernel, cycles per 32-sample wave tile (mean over tiles 1..8):")
+        print("train" if train else "frozen", "chained kernel, cycles per 64-sample wave pass (mean over passes 1..8):")
         for n, v in zip(names, ph.mean(0)):
-            print(f"  {n:32s} {v:10.0f}")
-        print("  total/tile", (d[2:9, 0] - d[1:8, 0]).mean())
+            print(f"  {n:36s} {v:10.0f}")
+        full = dbg.cpu().numpy().reshape(16, 16)
+        print("  [stage 0: set-up end -> loop start %d, MFMA loop %d, barrier wait %d]" % tuple(
+            np.mean(x) for x in (full[1:9, 11] - full[1:9, 7], full[1:9, 12] - full[1:9, 11], full[1:9, 8] - full[1:9, 12])))
+        print("  total/pass", (d[2:9, 0] - d[1:8, 0]).mean(), " = per 64 samples and CU:", (d[2:9, 0] - d[1:8, 0]).mean() / 4)
         continue
     d = dbg.cpu().numpy().reshape(16, 16)[:, :11]
     names = ["A:loadX", "B:H1", "C:loop", "C:epi", "D:loss", "E:dH2", "F:loop", "F:epi", "H:dH1", "I:L1bwd"]
