@@ -58,3 +58,15 @@ enum {
     } while (0)
 
 static inline int nl_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+#ifdef __HIPCC__
+// Workgroup barrier that orders the workgroup's LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).  __syncthreads() also drains
+// vmcnt: every barrier then waits for the global loads in flight (the next tile's input prefetch: HBM latency) and for the
+// acknowledgement of earlier global stores.  Use where the waves exchange data through LDS and nothing through global memory.
+__device__ __forceinline__ void nl_lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#endif

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
                 }
             }
         }
-        __syncthreads();
+        nl_lds_barrier();
         DBG_STAMP(2);
         // ---------------- C: H2 = relu(H1 W2^T + b2), s = H2 w3 + b3 ----------------
         f32x16 h0, h1;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             const float tot = halfwave_rowsum(h0, h1, w3c, l31);               // entry e = l31 of [h0 rows | h1 rows]
             sS[w * DEC_M + (l31 >> 4) * 32 + d32_row(l31 & 15, lh)] = tot;     // this wave's 32 columns of 64 distinct rows
         }
-        __syncthreads();
+        nl_lds_barrier();
         DBG_STAMP(4);
         // ---------------- D: sdf, loss gradient (criterion.py): every wave computes all 64 rows (lane = row) for itself;
         //                  wave 0 owns the global outputs and the loss sums ----------------
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             // one word per thread, thread-major per tile: k_decoder_wgrad2's thread (same wave/lane) reads it back
             if (TRAIN) a.relu2_mask[(size_t)tile * DEC_THREADS + tid] = mw;
         }
-        __syncthreads();
+        nl_lds_barrier();
         DBG_STAMP(6);
         // ---------------- F: dH1 = (dH2 W2) * [H1 > 0]  (kept in registers) ----------------
         f32x16 g0v, g1v;
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
                 if (TRAIN) aB1 += g0v[r] + g1v[r];
             }
         }
-        if (!XG) __syncthreads();                       // fp32 path: dH1 overwrites the dH2 tile other waves may still be reading
+        if (!XG) nl_lds_barrier();                       // fp32 path: dH1 overwrites the dH2 tile other waves may still be reading
         DBG_STAMP(8);
         // ---------------- H: dH1 -> LDS ----------------
         {
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { db[D32_RR(r) * LDH] = g0v[r]; db[(32 + D32_RR(r)) * LDH] = g1v[r]; }
         }
-        __syncthreads();
+        nl_lds_barrier();
         DBG_STAMP(9);
         // ---------------- I: waves 0-3: dX[16 rows each] = dH1 W1 -> global ; waves 4-7: dW1 += dH1^T X ----------------
         if (w < 4) {
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             cz = pz; cd = pd;
             prefetch(tile + 2 * gridDim.x);
         }
-        __syncthreads();
+        nl_lds_barrier();
         DBG_STAMP(10);
     }
 

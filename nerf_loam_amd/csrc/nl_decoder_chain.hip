@@ -30,6 +30,7 @@
 //     db2[n] = w3_n g[n],    dW3[n] = sum_i dsdf_i h2[i][n] = sum_k W2[n][k] G[n][k] + b2[n] g[n],   G = dW2 / w3 (raw accumulators)
 // (h2 = m2 (H1 W2^T + b2)); nl_decoder_reduce applies them while summing the per-workgroup slabs.
 #include "nl_common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -80,15 +81,6 @@ __device__ __forceinline__ float ch_trunc(float x) { return __uint_as_float(__fl
 // waits for the load (HBM latency) on the spot, which is exactly what a prefetch must not do.
 __device__ __forceinline__ float ch_from_acc(float x) { float v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(x)); return v; }
 __device__ __forceinline__ void ch_keep_in_acc(float x) { asm volatile("" ::"a"(x)); }
-// Stage barrier: the workgroup's LDS traffic is ordered (lgkmcnt(0)), its GLOBAL traffic is not waited for - __syncthreads() would also
-// drain vmcnt, i.e. stall every stage on the input prefetch of the next pass (HBM latency), the mask-word and accumulator stores
-__device__ __forceinline__ void ch_stage_barrier()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
 // MODE 0: forward only (sdf).  1: forward + loss gradient + dgrad + dX (frozen decoder: tracking, mapping after freeze_frame).
 // 2: 1 + decoder weight gradients (dW1, db1, db3 here; the ReLU words of H2 for the dW2 kernel).
 // NP: partial products of the forward GEMM (9 = exact, 6 = without lo x lo, lo x mid, mid x lo: gemm mode 2's arithmetic)
@@ -225,66 +217,77 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_decoder_chain(ChainArgs a)
             }
             CH_STAMP(1 + 3 * u);
             // ---------------- layer 2 + output layer: s = w3 . relu(W2 H1 + b2) + b3, H2 never stored ----------------
+            // A stage is 16 k-steps x NP MFMAs, one issue slot each (a scheduling barrier closes every slot: the order below IS the
+            // schedule).  The stage's own memory instructions and the EPILOGUE OF THE PREVIOUS output tile (ReLU, row-sum FMAs, mask
+            // bits, the ReLU words of the dW2 kernel) ride in the slots, a few VALU instructions each: a VALU instruction next to an
+            // MFMA costs 1-2 cycles of matrix pipe, a block of them after the loop its full 5-6 (scripts/micro/mfma_valu.hip).
             float spart = 0.f;
-#pragma unroll 1
-            for (int nt = 0; nt < 8; ++nt) {
+            f32x16 h;
+            float hp[16];                                                 // the previous tile's pre-activations (copied out of the accumulator)
+            float wv[16], hv = 0.f;
+            unsigned ebits = 0u, mword = 0u;
+            constexpr int IPE = MODE == 2 ? 4 : 2;                         // epilogue items per element
+            auto epi_item = [&](int slot, int ntp) {
+                if (slot < 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(sTab + 512 + ntp * 32 + lh * 16 + 4 * slot);
+                    wv[4 * slot] = t.x; wv[4 * slot + 1] = t.y; wv[4 * slot + 2] = t.z; wv[4 * slot + 3] = t.w;
+                    if (slot == 0) { ebits = 0u; mword = 0u; }
+                    return;
+                }
+                const int k = slot - 4;
+                if (k < 16 * IPE) {
+                    const int r = k / IPE, part = k % IPE;
+                    if (part == 0) { hv = fmaxf(hp[r], 0.f); ebits |= hv > 0.f ? (1u << r) : 0u; }
+                    else if (part == 1) spart = fmaf(hv, wv[r], spart);
+                    else if (part == 2) {
+                        const unsigned long long bal = __ballot(hv > 0.f);
+                        const unsigned pick = mw_hi ? (unsigned)(bal >> 32) : (unsigned)bal;
+                        mword = (mw_r == r) ? pick : mword;
+                    }
+                    return;
+                }
+                if (k == 16 * IPE) {
+                    // 128-bit shift register: after the 8th tile, tile nt sits in bits [16 nt, 16 nt + 16)
+                    m2w[u][0] = (m2w[u][0] >> 16) | (m2w[u][1] << 16); m2w[u][1] = (m2w[u][1] >> 16) | (m2w[u][2] << 16);
+                    m2w[u][2] = (m2w[u][2] >> 16) | (m2w[u][3] << 16); m2w[u][3] = (m2w[u][3] >> 16) | (ebits << 16);
+                    if (MODE == 2 && lh == 0 && tile < nsub) a.relu2_nat[(size_t)tile * NL_W + 32 * ntp + l31] = mword;
+                }
+            };
+            auto fwd_stage = [&](auto prev_tag, int nt) {
+                constexpr bool PREV = decltype(prev_tag)::value;
                 const int qn = (8 * u + nt + 1) % NST;                      // the stage this one fills
-                f32x16 h;
                 {
                     const float4* tb = reinterpret_cast<const float4*>(sTab + 256 + nt * 32 + lh * 16);
                     const float4 t0 = tb[0], t1 = tb[1], t2 = tb[2], t3 = tb[3];
                     h[0] = t0.x; h[1] = t0.y; h[2] = t0.z; h[3] = t0.w; h[4] = t1.x; h[5] = t1.y; h[6] = t1.z; h[7] = t1.w;
                     h[8] = t2.x; h[9] = t2.y; h[10] = t2.z; h[11] = t2.w; h[12] = t3.x; h[13] = t3.y; h[14] = t3.z; h[15] = t3.w;
                 }
-                __builtin_amdgcn_sched_barrier(0);                          // the reads above stay out of the pipelined region below
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
-                    if (s + 1 < 16) {
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) af[(s + 1) & 1][p] = sRing[lbuf][3 * (s + 1) + p][lane];
+                    for (int m = 0; m < NP; ++m) {
+                        const int pa = NP == 9 ? m / 3 : (m < 3 ? 0 : (m < 5 ? 1 : 2)), pb = NP == 9 ? m % 3 : (m < 3 ? m : (m < 5 ? m - 3 : 0));
+                        h = MFMA_BF16(__builtin_bit_cast(bf16x8, af[s & 1][pa]), __builtin_bit_cast(bf16x8, hb[s][pb]), h);
+                        if (m < 3 && s + 1 < 16) af[(s + 1) & 1][m] = sRing[lbuf][3 * (s + 1) + m][lane];
+                        if (m == 3 && s >= 4) fill_store(lbuf ^ 1, s - 4);
+                        if (m == 4 && s < 12) fill_load(qn, s);
+                        if (PREV) epi_item(NP * s + m, nt - 1);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (s >= 4) fill_store(lbuf ^ 1, s - 4);
-                    if (s < 12) fill_load(qn, s);
-#pragma unroll
-                    for (int pa = 0; pa < 3; ++pa)
-#pragma unroll
-                        for (int pb = 0; pb < 3; ++pb) {
-                            if (NP == 6 && pa + pb > 2) continue;
-                            h = MFMA_BF16(__builtin_bit_cast(bf16x8, af[s & 1][pa]), __builtin_bit_cast(bf16x8, hb[s][pb]), h);
-                        }
-                    // one memory instruction in the shadow of each MFMA
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) { __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0); __builtin_amdgcn_sched_group_barrier(SG_DS_RD, 1, 0); }
-                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0); __builtin_amdgcn_sched_group_barrier(SG_DS_WR, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0); __builtin_amdgcn_sched_group_barrier(SG_VMEM_RD, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, NP - 5, 0);
                 }
-                ch_stage_barrier();                                         // next stage complete in LDS; this one free to be refilled
+                nl_lds_barrier();                                         // next stage complete in LDS; this one free to be refilled
                 lbuf ^= 1;
 #pragma unroll
                 for (int p = 0; p < 3; ++p) af[0][p] = sRing[lbuf][p][lane];
-                const float4* tw = reinterpret_cast<const float4*>(sTab + 512 + nt * 32 + lh * 16);
-                const float4 w0 = tw[0], w1 = tw[1], w2 = tw[2], w3 = tw[3];
-                const float wv[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
-                unsigned bits = 0u, mword = 0u;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float hv = fmaxf(h[r], 0.f);
-                    const bool on = hv > 0.f;
-                    bits |= on ? (1u << r) : 0u;
-                    spart = fmaf(hv, wv[r], spart);
-                    if (MODE == 2) {
-                        const unsigned long long bal = __ballot(on);
-                        const unsigned pick = mw_hi ? (unsigned)(bal >> 32) : (unsigned)bal;
-                        mword = (mw_r == r) ? pick : mword;
-                    }
-                }
-                // 128-bit shift register: after the 8th tile, tile nt sits in bits [16 nt, 16 nt + 16)
-                m2w[u][0] = (m2w[u][0] >> 16) | (m2w[u][1] << 16); m2w[u][1] = (m2w[u][1] >> 16) | (m2w[u][2] << 16);
-                m2w[u][2] = (m2w[u][2] >> 16) | (m2w[u][3] << 16); m2w[u][3] = (m2w[u][3] >> 16) | (bits << 16);
-                asm volatile("" : "+v"(m2w[u][3]));
-                if (MODE == 2 && lh == 0 && tile < nsub) a.relu2_nat[(size_t)tile * NL_W + 32 * nt + l31] = mword;
-            }
+                for (int r = 0; r < 16; ++r) hp[r] = h[r];
+            };
+            fwd_stage(std::false_type{}, 0);
+#pragma unroll 1
+            for (int nt = 1; nt < 8; ++nt) fwd_stage(std::true_type{}, nt);
+#pragma unroll
+            for (int slot = 0; slot < 4 + 16 * IPE + 1; ++slot) epi_item(slot, 7);       // the last tile's epilogue: nothing left to hide it under
             CH_STAMP(2 + 3 * u);
             const float sv = (spart + __shfl_xor(spart, 32)) + b3;
             if (MODE == 0) {
@@ -322,93 +325,148 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_decoder_chain(ChainArgs a)
 #pragma unroll
         for (int u = 0; u < 2; ++u) for (int sub = 0; sub < 2; ++sub) for (int r = 0; r < 4; ++r) dxa[u][sub][r] = 0.f;
         CH_STAMP(7);
-#pragma unroll 1
-        for (int kt = 0; kt < 8; ++kt) {
+        // A dgrad stage is 16 k-steps x 6 MFMAs = 96 issue slots.  The layer-1 backward of the PREVIOUS stage's tile rides in their
+        // shadow (the order below IS the schedule: a scheduling barrier closes every slot):
+        //   slots  0..39  the 32 raw dgrad values per lane -> * dsdf * [H1 > 0] -> the wave's transposition tiles in LDS (8 x 16 B per lane)
+        //   k-step 7      operand reads of units 0, 1;  k-steps 8..15: the reads of the next two units, one per slot, and after the
+        //                 sixth bf16 MFMA a BURST of the 8 (train) / 4 (frozen) 16x16x4 fp32 MFMAs of two units - alternating the two
+        //                 MFMA kinds one by one costs ~10 cycles per switch (scripts/micro/mfma_shapes.hip: 84 cycles per pair, not 64).
+        //                 unit j = (sub-tile u = j >> 3, i = j & 7): dX of both 16-sample halves over units 4 i .. 4 i + 3 of the tile,
+        //                 dW1 of both 16-unit halves over samples 4 i .. 4 i + 3 (+ db1)
+        f32x16 gacc[2], gprev[2];
+        f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0, wl0 = w0, wl1 = w0;      // dW1 / db1 of the tile in its layer-1 backward; wl*, bl*: loaded for the next
+        float b0 = 0.f, b1 = 0.f, bl0 = 0.f, bl1 = 0.f;
+        float2 rta[4], raa[4];                                            // operands of two unit pairs in flight
+        float rbw[4];
+        float4 wv4;                                                       // the float4 being assembled for the transposition tile
+        auto l1bwd_reads = [&](int j, int part, int ktp) {                 // operand reads of unit j: three LDS instructions
+            const int u = j >> 3, i = j & 7;
+            const float* sTu = sTw + u * (32 * CH_T_STRIDE);
+            if (part == 0) {          // dX A operand: dH1 rows l15 / 16 + l15, units lq + 4 i
+                rta[j & 3].x = sTu[l15 * CH_T_STRIDE + lq + 4 * i]; rta[j & 3].y = sTu[(16 + l15) * CH_T_STRIDE + lq + 4 * i];
+            } else if (part == 1) {   // dX B operand: W1 rows of those units
+                rbw[j & 3] = sW1[(32 * ktp + lq + 4 * i) * CH_W1_STRIDE + l15];
+            } else if (MODE == 2) {   // dW1 A operand: dH1 columns l15 / 16 + l15, samples lq + 4 i
+                raa[j & 3].x = sTu[(lq + 4 * i) * CH_T_STRIDE + l15]; raa[j & 3].y = sTu[(lq + 4 * i) * CH_T_STRIDE + l15 + 16];
+            }
+        };
+        auto l1bwd_unit = [&](int j) {
+            const int u = j >> 3, i = j & 7;
+            dxa[u][0] = MFMA16(rta[j & 3].x, rbw[j & 3], dxa[u][0]);
+            dxa[u][1] = MFMA16(rta[j & 3].y, rbw[j & 3], dxa[u][1]);
+            if (MODE == 2) {
+                w0 = MFMA16(raa[j & 3].x, xw[u][i], w0); w1 = MFMA16(raa[j & 3].y, xw[u][i], w1);
+                b0 += raa[j & 3].x; b1 += raa[j & 3].y;
+            }
+        };
+        auto l1bwd_item = [&](int s, int m, int ktp) {                     // ktp: the tile (stage) whose layer-1 backward this is
+            const int slot = 6 * s + m;
+            if (slot < 40) {
+                const int j = slot / 5, u = j >> 2, q = j & 3, part = slot % 5;
+                const unsigned bits = (m1w[u][0] >> (4 * q)) & 0xFu;        // m1w is shifted down 16 bits per tile (end of dgrad_stage)
+                const float dsu = ds[u];
+                if (part == 0) wv4.x = gprev[u][4 * q] * ((bits & 1u) ? dsu : 0.f);
+                else if (part == 1) wv4.y = gprev[u][4 * q + 1] * ((bits & 2u) ? dsu : 0.f);
+                else if (part == 2) wv4.z = gprev[u][4 * q + 2] * ((bits & 4u) ? dsu : 0.f);
+                else if (part == 3) wv4.w = gprev[u][4 * q + 3] * ((bits & 8u) ? dsu : 0.f);
+                else *reinterpret_cast<float4*>(sTw + u * (32 * CH_T_STRIDE) + l31 * CH_T_STRIDE + 8 * q + 4 * lh) = wv4;   // column = unit nl_chain_unit(r, lh)
+                return;
+            }
+            if (s < 7) return;
+            if (s + 1 < 16 || s == 7) {                                  // reads of the pair the NEXT k-step multiplies
+                const int jn = 2 * (s - 7) + m / 3;
+                if (jn < 16) l1bwd_reads(jn, m % 3, ktp);
+            }
+            if (s >= 8 && m == 5) { l1bwd_unit(2 * (s - 8)); l1bwd_unit(2 * (s - 8) + 1); }
+        };
+        auto acc_ptrs = [&](int kt, f32x4*& aw, float*& ab) {
+            aw = reinterpret_cast<f32x4*>(accw + (2 * kt * 64 + lane) * 4);
+            ab = accw + 16 * 64 * 4 + 2 * kt * 64 + lane;
+        };
+        auto dgrad_stage = [&](auto prev_tag, int kt) {
+            constexpr bool PREV = decltype(prev_tag)::value;
             const int qn = (16 + kt + 1) % NST;
-            f32x16 gacc[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) for (int r = 0; r < 16; ++r) gacc[u][r] = 0.f;
-            // this wave's dW1 / db1 accumulators of units 32 kt .. 32 kt + 31: parked in L2 between passes
-            f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
-            float b0 = 0.f, b1 = 0.f;
-            f32x4* aw = MODE == 2 ? reinterpret_cast<f32x4*>(accw + (2 * kt * 64 + lane) * 4) : nullptr;
-            float* ab = MODE == 2 ? accw + 16 * 64 * 4 + 2 * kt * 64 + lane : nullptr;
-            if (MODE == 2 && pass_no > 0) { w0 = aw[0]; w1 = aw[64]; b0 = ab[0]; b1 = ab[64]; }
-            if (kt == 0) CH_STAMP(11);
+            if (MODE == 2 && pass_no > 0) {                       // this tile's parked accumulators: needed one stage from now
+                f32x4* aw; float* ab; acc_ptrs(kt, aw, ab);
+                wl0 = aw[0]; wl1 = aw[64]; bl0 = ab[0]; bl1 = ab[64];
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                if (s + 1 < 16) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) af[(s + 1) & 1][p] = sRing[lbuf][3 * (s + 1) + p][lane];
+                for (int m = 0; m < 6; ++m) {
+                    gacc[m & 1] = MFMA_BF16(__builtin_bit_cast(bf16x8, af[s & 1][m >> 1]), __builtin_bit_cast(bf16x8, mf[m & 1][s]), gacc[m & 1]);
+                    if (m < 3 && s + 1 < 16) af[(s + 1) & 1][m] = sRing[lbuf][3 * (s + 1) + m][lane];
+                    if (m == 3 && s >= 4) fill_store(lbuf ^ 1, s - 4);
+                    if (m == 4 && s < 12) fill_load(qn, s);
+                    if (PREV) l1bwd_item(s, m, kt - 1);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (s >= 4) fill_store(lbuf ^ 1, s - 4);
-                if (s < 12) fill_load(qn, s);
-#pragma unroll
-                for (int pa = 0; pa < 3; ++pa)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-                        gacc[u] = MFMA_BF16(__builtin_bit_cast(bf16x8, af[s & 1][pa]), __builtin_bit_cast(bf16x8, mf[u][s]), gacc[u]);
-#pragma unroll
-                for (int q = 0; q < 3; ++q) { __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0); __builtin_amdgcn_sched_group_barrier(SG_DS_RD, 1, 0); }
-                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0); __builtin_amdgcn_sched_group_barrier(SG_DS_WR, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0); __builtin_amdgcn_sched_group_barrier(SG_VMEM_RD, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
             }
-            if (kt == 0) CH_STAMP(12);
-            ch_stage_barrier();
+            if (PREV && MODE == 2) { f32x4* aw; float* ab; acc_ptrs(kt - 1, aw, ab); aw[0] = w0; aw[64] = w1; ab[0] = b0; ab[64] = b1; }
+            if (PREV) {                                          // the next tile's H1 ReLU bits move to the low half-word
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    m1w[u][0] = (m1w[u][0] >> 16) | (m1w[u][1] << 16); m1w[u][1] = (m1w[u][1] >> 16) | (m1w[u][2] << 16);
+                    m1w[u][2] = (m1w[u][2] >> 16) | (m1w[u][3] << 16); m1w[u][3] >>= 16;
+                }
+            }
+            nl_lds_barrier();
             lbuf ^= 1;
 #pragma unroll
             for (int p = 0; p < 3; ++p) af[0][p] = sRing[lbuf][p][lane];
-            if (kt == 0) CH_STAMP(8);                            // after the first dgrad stage's 96 MFMAs
-            const unsigned m1a = kt < 4 ? (kt < 2 ? m1w[0][0] : m1w[0][1]) : (kt < 6 ? m1w[0][2] : m1w[0][3]);
-            const unsigned m1b = kt < 4 ? (kt < 2 ? m1w[1][0] : m1w[1][1]) : (kt < 6 ? m1w[1][2] : m1w[1][3]);
+            gprev[0] = gacc[0]; gprev[1] = gacc[1];
+            w0 = wl0; w1 = wl1; b0 = bl0; b1 = bl1;
+        };
+        dgrad_stage(std::false_type{}, 0);
+        CH_STAMP(8);
+#pragma unroll 1
+        for (int kt = 1; kt < 8; ++kt) dgrad_stage(std::true_type{}, kt);
+        CH_STAMP(9);
+        // the last tile's layer-1 backward: nothing left to hide it under
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                float* sTu = sTw + u * (32 * CH_T_STRIDE);
-                const unsigned b1bits = ((u ? m1b : m1a) >> (16 * (kt & 1))) & 0xFFFFu;
-                const float dsu = ds[u];
+        for (int u = 0; u < 2; ++u) {
+            float* sTu = sTw + u * (32 * CH_T_STRIDE);
+            const unsigned b1bits = m1w[u][0] & 0xFFFFu;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 v;
-                    v.x = gacc[u][4 * q] * (((b1bits >> (4 * q)) & 1u) ? dsu : 0.f);
-                    v.y = gacc[u][4 * q + 1] * (((b1bits >> (4 * q + 1)) & 1u) ? dsu : 0.f);
-                    v.z = gacc[u][4 * q + 2] * (((b1bits >> (4 * q + 2)) & 1u) ? dsu : 0.f);
-                    v.w = gacc[u][4 * q + 3] * (((b1bits >> (4 * q + 3)) & 1u) ? dsu : 0.f);
-                    *reinterpret_cast<float4*>(sTu + l31 * CH_T_STRIDE + 8 * q + 4 * lh) = v;       // column = unit nl_chain_unit(r, lh)
-                }
+            for (int q = 0; q < 4; ++q) {
+                float4 v;
+                v.x = gprev[u][4 * q] * (((b1bits >> (4 * q)) & 1u) ? ds[u] : 0.f);
+                v.y = gprev[u][4 * q + 1] * (((b1bits >> (4 * q + 1)) & 1u) ? ds[u] : 0.f);
+                v.z = gprev[u][4 * q + 2] * (((b1bits >> (4 * q + 2)) & 1u) ? ds[u] : 0.f);
+                v.w = gprev[u][4 * q + 3] * (((b1bits >> (4 * q + 3)) & 1u) ? ds[u] : 0.f);
+                *reinterpret_cast<float4*>(sTu + l31 * CH_T_STRIDE + 8 * q + 4 * lh) = v;
             }
-            __builtin_amdgcn_wave_barrier();                     // same-wave LDS write -> read (in order in hardware; pins the compiler)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const float* sTu = sTw + u * (32 * CH_T_STRIDE);
-                // dX[i][c] += sum_k dH1[i][32 kt + k] W1[32 kt + k][c]   (16x16x4 fp32: A = dH1 rows of one 16-sample half, B = W1 rows)
-                {
-                    const float* ta = sTu + l15 * CH_T_STRIDE + lq;
-                    const float* wb = sW1 + (32 * kt + lq) * CH_W1_STRIDE + l15;
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        const float bw = wb[4 * kk * CH_W1_STRIDE];
-                        dxa[u][0] = MFMA16(ta[4 * kk], bw, dxa[u][0]);
-                        dxa[u][1] = MFMA16(ta[16 * CH_T_STRIDE + 4 * kk], bw, dxa[u][1]);
-                    }
-                }
-                if (MODE == 2) {
-                    // dW1[32 kt + k][c] += sum_i dH1[i][32 kt + k] X[i][c]   (A = dH1 columns of one 16-unit half, B = X rows)
-                    const float* ta = sTu + lq * CH_T_STRIDE + l15;
-#pragma unroll
-                    for (int ii = 0; ii < 8; ++ii) {
-                        const float a0 = ta[4 * ii * CH_T_STRIDE], a1 = ta[4 * ii * CH_T_STRIDE + 16];
-                        w0 = MFMA16(a0, xw[u][ii], w0);
-                        w1 = MFMA16(a1, xw[u][ii], w1);
-                        b0 += a0; b1 += a1;
-                    }
-                }
-            }
-            if (MODE == 2) { aw[0] = w0; aw[64] = w1; ab[0] = b0; ab[64] = b1; }
-            __builtin_amdgcn_wave_barrier();
-            if (kt == 0) CH_STAMP(9);                            // one stage's layer-1 backward (both sub-tiles)
         }
+        __builtin_amdgcn_wave_barrier();                         // same-wave LDS write -> read (in order in hardware; pins the compiler)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float* sTu = sTw + u * (32 * CH_T_STRIDE);
+            {
+                const float* ta = sTu + l15 * CH_T_STRIDE + lq;
+                const float* wb = sW1 + (32 * 7 + lq) * CH_W1_STRIDE + l15;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const float bw = wb[4 * kk * CH_W1_STRIDE];
+                    dxa[u][0] = MFMA16(ta[4 * kk], bw, dxa[u][0]);
+                    dxa[u][1] = MFMA16(ta[16 * CH_T_STRIDE + 4 * kk], bw, dxa[u][1]);
+                }
+            }
+            if (MODE == 2) {
+                const float* ta = sTu + lq * CH_T_STRIDE + l15;
+#pragma unroll
+                for (int ii = 0; ii < 8; ++ii) {
+                    const float a0 = ta[4 * ii * CH_T_STRIDE], a1 = ta[4 * ii * CH_T_STRIDE + 16];
+                    w0 = MFMA16(a0, xw[u][ii], w0);
+                    w1 = MFMA16(a1, xw[u][ii], w1);
+                    b0 += a0; b1 += a1;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (MODE == 2) { f32x4* aw; float* ab; acc_ptrs(7, aw, ab); aw[0] = w0; aw[64] = w1; ab[0] = b0; ab[64] = b1; }
         CH_STAMP(10);
         if (MODE == 2) {
 #pragma unroll

@@ -21,14 +21,11 @@ for train in (True, False):
     if CHAIN:
         d = dbg.cpu().numpy().reshape(16, 16)[:, :11]
         names = ["layer1 a", "layer2+out a (8 stages)", "loss a", "layer1 b", "layer2+out b (8 stages)", "loss b", "dgrad set-up (mask fragments, X)",
-                 "dgrad stage 0 (96 MFMAs)", "L1bwd stage 0 (both sub-tiles)", "7 more dgrad + L1bwd stages"]
+                 "dgrad stage 0 (96 MFMAs)", "dgrad stages 1-7 + L1bwd of 0-6 in their shadow", "L1bwd of stage 7 (exposed)"]
         ph = np.diff(d[1:9], axis=1)
         print("train" if train else "frozen", "chained kernel, cycles per 64-sample wave pass (mean over passes 1..8):")
         for n, v in zip(names, ph.mean(0)):
             print(f"  {n:36s} {v:10.0f}")
-        full = dbg.cpu().numpy().reshape(16, 16)
-        print("  [stage 0: set-up end -> loop start %d, MFMA loop %d, barrier wait %d]" % tuple(
-            np.mean(x) for x in (full[1:9, 11] - full[1:9, 7], full[1:9, 12] - full[1:9, 11], full[1:9, 8] - full[1:9, 12])))
         print("  total/pass", (d[2:9, 0] - d[1:8, 0]).mean(), " = per 64 samples and CU:", (d[2:9, 0] - d[1:8, 0]).mean() / 4)
         continue
     d = dbg.cpu().numpy().reshape(16, 16)[:, :11]
