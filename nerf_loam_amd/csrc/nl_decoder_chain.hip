@@ -34,6 +34,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -184,28 +185,56 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_decoder_chain(ChainArgs a)
             uint4 hb[16][3];
 #pragma unroll
             for (int q = 0; q < 4; ++q) { m1w[u][q] = 0u; m2w[u][q] = 0u; }
-#pragma unroll
-            for (int ut = 0; ut < 8; ++ut) {
-                f32x16 c;
-                {
-                    const float4* tb = reinterpret_cast<const float4*>(sTab + ut * 32 + lh * 16);
-                    const float4 t0 = tb[0], t1 = tb[1], t2 = tb[2], t3 = tb[3];
-                    c[0] = t0.x; c[1] = t0.y; c[2] = t0.z; c[3] = t0.w; c[4] = t1.x; c[5] = t1.y; c[6] = t1.z; c[7] = t1.w;
-                    c[8] = t2.x; c[9] = t2.y; c[10] = t2.z; c[11] = t2.w; c[12] = t3.x; c[13] = t3.y; c[14] = t3.z; c[15] = t3.w;
-                }
+            // software pipeline over the eight 32-unit tiles: slot k of tile ut = the k-th fp32 MFMA of tile ut + 1 (a dependent chain:
+            // 64 cycles each) + the split of value pair k of tile ut (~20 VALU instructions) - neither phase waits for the other.
+            // VALU diet: the packed word of a plane, shifted / masked, IS the pair of truncated values; the two residuals are one
+            // packed subtraction.
+            auto l1_bias = [&](int ut, f32x16& c) {
+                const float4* tb = reinterpret_cast<const float4*>(sTab + ut * 32 + lh * 16);
+                const float4 t0 = tb[0], t1 = tb[1], t2 = tb[2], t3 = tb[3];
+                c[0] = t0.x; c[1] = t0.y; c[2] = t0.z; c[3] = t0.w; c[4] = t1.x; c[5] = t1.y; c[6] = t1.z; c[7] = t1.w;
+                c[8] = t2.x; c[9] = t2.y; c[10] = t2.z; c[11] = t2.w; c[12] = t3.x; c[13] = t3.y; c[14] = t3.z; c[15] = t3.w;
+            };
+            f32x16 cc;
+            float wrow[8];
+            auto l1_weights = [&](int ut) {
                 const float4* wr = reinterpret_cast<const float4*>(sW1 + (32 * ut + l31) * CH_W1_STRIDE + 8 * lh);
                 const float4 w0 = wr[0], w1 = wr[1];
-                c = MFMA32(w0.x, xin[u][0], c); c = MFMA32(w0.y, xin[u][1], c); c = MFMA32(w0.z, xin[u][2], c); c = MFMA32(w0.w, xin[u][3], c);
-                c = MFMA32(w1.x, xin[u][4], c); c = MFMA32(w1.y, xin[u][5], c); c = MFMA32(w1.z, xin[u][6], c); c = MFMA32(w1.w, xin[u][7], c);
+                wrow[0] = w0.x; wrow[1] = w0.y; wrow[2] = w0.z; wrow[3] = w0.w; wrow[4] = w1.x; wrow[5] = w1.y; wrow[6] = w1.z; wrow[7] = w1.w;
+            };
+            f32x16 cn;                                                    // bias of the tile after the next one: read one tile ahead
+            float wnext[8];
+            l1_bias(0, cc); l1_weights(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cc = MFMA32(wrow[k], xin[u][k], cc);
+            l1_bias(1, cn); l1_weights(1);
+#pragma unroll
+            for (int ut = 0; ut < 8; ++ut) {
+                float cp[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cp[r] = cc[r];
+                if (ut + 1 < 8) {
+                    cc = cn;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) wnext[k] = wrow[k];
+                    if (ut + 2 < 8) { l1_bias(ut + 2, cn); l1_weights(ut + 2); }
+                }
                 unsigned bits = 0u, hi[8], mid[8], lo[8];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    const float h0 = fmaxf(c[2 * q], 0.f), h1 = fmaxf(c[2 * q + 1], 0.f);
-                    bits |= (h0 > 0.f ? (1u << (2 * q)) : 0u) | (h1 > 0.f ? (2u << (2 * q)) : 0u);
-                    hi[q] = ch_pack_hi16(h0, h1);
-                    const float r0 = h0 - ch_trunc(h0), r1 = h1 - ch_trunc(h1);
-                    mid[q] = ch_pack_hi16(r0, r1);
-                    lo[q] = ch_pack_hi16(r0 - ch_trunc(r0), r1 - ch_trunc(r1));
+                    if (ut + 1 < 8) cc = MFMA32(wnext[q], xin[u][q], cc);
+                    f32x2 hv; hv.x = fmaxf(cp[2 * q], 0.f); hv.y = fmaxf(cp[2 * q + 1], 0.f);
+                    bits |= (hv.x > 0.f ? (1u << (2 * q)) : 0u) | (hv.y > 0.f ? (2u << (2 * q)) : 0u);
+                    hi[q] = ch_pack_hi16(hv.x, hv.y);
+                    f32x2 t; t.x = __uint_as_float(hi[q] << 16); t.y = __uint_as_float(hi[q] & 0xFFFF0000u);
+                    const f32x2 r = hv - t;
+                    mid[q] = ch_pack_hi16(r.x, r.y);
+                    f32x2 t2; t2.x = __uint_as_float(mid[q] << 16); t2.y = __uint_as_float(mid[q] & 0xFFFF0000u);
+                    const f32x2 r2 = r - t2;
+                    lo[q] = ch_pack_hi16(r2.x, r2.y);
+                    asm volatile("" : "+v"(hi[q]), "+v"(mid[q]), "+v"(lo[q]));      // computed HERE (the compiler would sink the split to the first use)
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 hb[2 * ut][0] = make_uint4(hi[0], hi[1], hi[2], hi[3]); hb[2 * ut + 1][0] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
                 hb[2 * ut][1] = make_uint4(mid[0], mid[1], mid[2], mid[3]); hb[2 * ut + 1][1] = make_uint4(mid[4], mid[5], mid[6], mid[7]);

@@ -20,8 +20,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
                  : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) \
                  : "v"(a), "v"(b), "v"(ha), "v"(hb))
 
-template <int N>
-__global__ __launch_bounds__(256, 1) void k_mv(float* out, long long* cyc, int iters)
+template <int N, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_mv(float* out, long long* cyc, int iters)
 {
     f32x16 c0, c1, c2, c3;
     for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; c2[r] = 0.f; c3[r] = 0.f; }
@@ -42,25 +42,30 @@ __global__ __launch_bounds__(256, 1) void k_mv(float* out, long long* cyc, int i
     float s = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;
     for (int r = 0; r < 16; ++r) s += c0[r] + c1[r] + c2[r] + c3[r];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) { cyc[2 * (threadIdx.x >> 6)] = t0; cyc[2 * (threadIdx.x >> 6) + 1] = t1; }
 }
 
-template <int N>
+template <int N, int THREADS = 256>
 static void run()
 {
     float* out; long long* cyc;
-    (void)hipMalloc(&out, sizeof(float) * 256 * 256); (void)hipMalloc(&cyc, 8 * 256);
+    (void)hipMalloc(&out, sizeof(float) * 256 * THREADS); (void)hipMalloc(&cyc, 8 * 256);
     const int iters = 4096;
-    hipLaunchKernelGGL(k_mv<N>, dim3(256), dim3(256), 0, 0, out, cyc, 16);
-    hipLaunchKernelGGL(k_mv<N>, dim3(256), dim3(256), 0, 0, out, cyc, iters);
+    hipLaunchKernelGGL((k_mv<N, THREADS>), dim3(256), dim3(THREADS), 0, 0, out, cyc, 16);
+    hipLaunchKernelGGL((k_mv<N, THREADS>), dim3(256), dim3(THREADS), 0, 0, out, cyc, iters);
     (void)hipDeviceSynchronize();
-    long long h[4]; (void)hipMemcpy(h, cyc, 32, hipMemcpyDeviceToHost);
-    printf("32x32x16 bf16 MFMA + %d independent v_fma_f32: %6.1f cycles per MFMA\n", N, (double)h[0] / (4.0 * iters));
+    long long hh[16]; (void)hipMemcpy(hh, cyc, 128, hipMemcpyDeviceToHost);
+    long long lo = hh[0], hi = hh[1];
+    for (int w = 0; w < THREADS / 64; ++w) { lo = hh[2 * w] < lo ? hh[2 * w] : lo; hi = hh[2 * w + 1] > hi ? hh[2 * w + 1] : hi; }
+    long long h[1] = {hi - lo};                          // first start to last end over the waves of workgroup 0
+    printf("%d wave(s) per SIMD, 32x32x16 bf16 MFMA + %d independent v_fma_f32: %6.1f cycles per MFMA and SIMD\n", THREADS / 256, N,
+           (double)h[0] / (4.0 * iters * (THREADS / 256)));
     (void)hipFree(out); (void)hipFree(cyc);
 }
 
 int main()
 {
     run<0>(); run<1>(); run<2>(); run<4>(); run<6>(); run<8>();
+    run<0, 512>(); run<2, 512>(); run<4, 512>(); run<6, 512>(); run<8, 512>();
     return 0;
 }
