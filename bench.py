@@ -327,6 +327,33 @@ def api_path_bench(w, device, iters=20):
     return out
 
 
+def shard_probe_bench(w, device, full_ms, steps=12):
+    """What one rank of a K-GPU run does, measured on this GPU: the whole iteration (no exchanges) on rank 0's interleaved share of
+    the scan (nerf_loam_amd.dist.interleaved_order, the order bench.py shards by).  T(1) / T(share) bounds the strong-scaling
+    efficiency before the exchanges (scripts/shard_probe.py measures every rank)."""
+    from nerf_loam_amd import pipeline as P, dist as D
+    N = len(w["points"])
+    out = {"full_scan_ms": full_ms}
+    for K in (2, 4, 8):
+        lo, hi = D.shard_bounds(N, 0, K)
+        sel = D.interleaved_order(N, K)[lo:hi]
+        eng = P.SdfEngine(max_rays=len(sel), samples_per_ray_cap=48, device=device)
+        eng.set_rays(w["dirs"][sel], w["points"][sel], w["cos"][sel]); eng.set_poses(w["pose"][None], [1])
+        cfg = P.IterConfig()
+        eng.begin_call(w["map"], w["dec"])
+        eng.bind(w["map"], w["dec"], cfg, train_decoder=True)
+        for _ in range(4):
+            eng.run_bound()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.run_bound()
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / steps * 1e3
+        out[f"rank_share_1_of_{K}"] = {"rays": int(len(sel)), "ms_per_step": t, "t1_over_t": full_ms / t}
+        del eng
+    return out
+
+
 def pose_refine_bench(w, device, steps=200):
     """M2: ms per pose-refine step (track_frame iteration, render_helpers.py:452-512): 2048 rays, step 0.2*voxel,
     decoder + embeddings frozen, 6-dof pose Adam; rays resident, the launch sequence replayed as a hipGraph."""
@@ -508,6 +535,7 @@ def main():
                                 "frac": float(sum(bounds.values())) / (dt / args.steps * 1e3), "bounds_ms": bounds, "stage_ms": stage_ms,
                                 "note": "decoder kernels: matrix-pipe bound of their instruction mix; every other stage: algorithmic bytes / 8 TB/s"}
             out["pose_refine"] = pose_refine_bench(w, device)      # launch-bound loops first: the oracle's BLAS threads keep spinning
+            out["shard_probe"] = shard_probe_bench(w, device, dt / args.steps * 1e3)
             if not args.no_api_path:                               # for a while after use and slow the launching thread down
                 out["api_path"] = api_path_bench(w, device)
             if not args.no_parity:

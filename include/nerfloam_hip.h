@@ -84,6 +84,13 @@ int nl_compact_hit_rays(int N, const int* hit_count, const int* hit_rank, int* r
  * ray_of_rank[rank] = ray, number of hit rays -> *total_out and, if not NULL, *total_out2 */
 int nl_scan_hit_rays(const int* hit_count, int* hit_rank, int* ray_of_rank, int N, int* total_out, int* total_out2, int* workspace,
                      void* stream);
+/* nl_ray_intersect + nl_scan_hit_rays in one call (ray_of_rank doubles as the intersect kernel's scratch list, as in the stage-wise
+ * sequence).  Up to 4096 rays - the reference's live shapes, where an iteration is launch-bound - the fallback pass of the
+ * intersect and the scan are ONE launch; beyond, the same launches as the two calls.  Same results. */
+int nl_ray_intersect_scan(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
+                          const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
+                          float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
+                          int* counters, int* ray_of_rank, int* hit_rank, int* total_out, int* total_out2, int* scan_ws, void* stream);
 
 /* On-device ray selection (LidarFrame.sample_rays -> sampling_without_replacement, src/lidarFrame.py:55-57,
  * src/utils/sample_util.py:4-19): a uniformly random subset of n_select of the frame's M returns, kept in dataset order,
@@ -126,6 +133,10 @@ int nl_dist_row_first(const int* counters, const int* hit_idx, const int* hit_co
 /* global loss normalisers from the counter block (criterion.py:84-88 weights, :65 mean divisor R*S) */
 int nl_loss_finalize(int* counters, void* loss_scalars, float fs_weight, float sdf_weight, float tau, float max_depth,
                      int capacity, void* stream);
+/* nl_exclusive_scan_i32(samp_count -> samp_off, total -> counters[NLC_P]) + nl_loss_finalize: one launch up to 4096 rays, the same
+ * launches as the two calls beyond.  workspace as for nl_exclusive_scan_i32. */
+int nl_scan_samples_finalize(const int* samp_count, int* samp_off, int N, int* counters, void* loss_scalars, float fs_weight, float sdf_weight,
+                             float tau, float max_depth, int capacity, int* workspace, void* stream);
 
 /* get_features: render_helpers.py:74-93 + :39-70 (gather + trilinear interpolation) -> X[P,16] */
 int nl_gather_trilinear(const void* loss_scalars, const int* s_vox, const float* s_depth, const int* s_ray,
@@ -222,6 +233,14 @@ int nl_optimiser_step(int* state, double lr_emb, double lr_dec, double lr_pose,
                       float* dec_params, const float* dec_grad, float* dec_m, float* dec_v, float* dec_ws,
                       float* pose6, double* g_pose, float* pose_m, float* pose_v, const int* pose_enable, float* grad6_out,
                       float* poses12, int F, int apply_pose, const int* counters, int skip_mode, void* stream);
+/* the same step, ending with the hand-over of the counter block (NL_CNT_BYTES at counters_rw): copied to counters_copy and cleared
+ * by the launch's last step, so that the next iteration starts without a memset launch (both NULL: nl_optimiser_step) */
+int nl_optimiser_step_ex(int* state, double lr_emb, double lr_dec, double lr_pose,
+                         void* emb_bf16, float* g_emb, void* emb_m_bf16, void* emb_v_bf16, long long n_emb,
+                         float* dec_params, const float* dec_grad, float* dec_m, float* dec_v, float* dec_ws,
+                         float* pose6, double* g_pose, float* pose_m, float* pose_v, const int* pose_enable, float* grad6_out,
+                         float* poses12, int F, int apply_pose, const int* counters, int skip_mode, int* counters_rw, int* counters_copy,
+                         void* stream);
 
 /* ---- multi-GPU: embedding-gradient exchange over the rows an iteration touches (nerf_loam_amd/dist.py).  Every rank marks the rows
  * of the voxels its rays hit in a zero-filled bitmap of ceil(E / 32) words; after an OR-all-reduce of the bitmap the union's rows
@@ -234,7 +253,8 @@ int nl_dist_rows_move(int direction /* 0 pack, 1 unpack */, const unsigned* bitm
 
 /* ---- one call per iteration.  The whole launch sequence of an SDF iteration (render_helpers.py:356-423 mapping / :452-512
  * tracking) issued from C: stages bit 0 = intersect .. backward (everything nl_ray_intersect .. nl_trilinear_bwd above, counter
- * block cleared first), bit 1 = nl_optimiser_step.  The descriptor is plain C: device pointers + hyper-parameters; fill it once
+ * block cleared first), bit 1 = nl_optimiser_step.  It issues the fused forms
+ * (nl_ray_intersect_scan, nl_scan_samples_finalize, nl_optimiser_step_ex) of the stage calls.  The descriptor is plain C: device pointers + hyper-parameters; fill it once
  * per optimisation call, change N / seeds / flags between iterations.  Same kernels, same results as the stage-wise calls; what
  * it removes is the host's per-launch cost (~15 launches x ~250 marshalled arguments per iteration from Python). */
 typedef struct NlIterDesc {
@@ -259,6 +279,9 @@ typedef struct NlIterDesc {
     double lr_emb, lr_dec, lr_pose;
     unsigned noise_seed; int use_hash_noise, tail_always, ray_id_base, fresh_noise;
     int train_decoder, want_emb_grad, want_pose_grad, update_emb, update_decoder, update_pose, skip_mode;
+    /* optional counter hand-over: with counters_copy set, a stages == 3 call ends by copying the counter block there and clearing
+     * it; the host sets counters_clean = 1 afterwards and the next call skips its memset launch (0: the block is cleared first) */
+    int* counters_copy; int counters_clean;
 } NlIterDesc;
 int nl_iteration(const NlIterDesc* desc, int stages, void* stream);
 

@@ -54,6 +54,7 @@ def _iter_desc_fields():
     f += [("lr_emb", D_), ("lr_dec", D_), ("lr_pose", D_)]
     f += [("noise_seed", U_)] + [(n, I_) for n in ("use_hash_noise", "tail_always", "ray_id_base", "fresh_noise")]
     f += [(n, I_) for n in ("train_decoder", "want_emb_grad", "want_pose_grad", "update_emb", "update_decoder", "update_pose", "skip_mode")]
+    f += [("counters_copy", P_), ("counters_clean", I_)]
     return f
 
 
@@ -79,6 +80,8 @@ _SIGS = {
     "nl_sample_rays": ([_I, _I] + [_P] * 8 + [_F, _F, _F, _U, _I, _I, _I] + [_P, _P, _P, _P, _P, _I] + [_P] * 5, _I),
     "nl_dist_row_first": ([_P, _P, _P, _P, _P, _I, _P], _I),
     "nl_loss_finalize": ([_P, _P, _F, _F, _F, _F, _I, _P], _I),
+    "nl_scan_samples_finalize": ([_P, _P, _I, _P, _P, _F, _F, _F, _F, _I, _P, _P], _I),
+    "nl_ray_intersect_scan": ([_I] + [_P] * 7 + [_I, _F, _F] + [_P] * 13, _I),
     "nl_gather_trilinear": ([_P] * 7 + [_I] + [_P] * 3 + [_F, _P, _I, _P], _I),
     "nl_gather_points": ([_I] + [_P] * 5 + [_F, _P, _P], _I),
     "nl_decoder_fwd_bwd": ([_P] * 13 + [_I, _I, _P, _P], _I),
@@ -107,6 +110,7 @@ _SIGS = {
     "nl_pose_matrices": ([_P, _P, _I, _P], _I),
     "nl_pose_step": ([_P] * 7 + [_I, _P, _I, _P], _I),
     "nl_optimiser_step": ([_P, _D, _D, _D] + [_P] * 4 + [_LL] + [_P] * 5 + [_P] * 7 + [_I, _I, _P, _I, _P], _I),
+    "nl_optimiser_step_ex": ([_P, _D, _D, _D] + [_P] * 4 + [_LL] + [_P] * 5 + [_P] * 7 + [_I, _I, _P, _I, _P, _P, _P], _I),
     "nl_iteration": ([_P, _I, _P], _I),
     "nl_dist_mark_rows": ([_I, _P, _P, _P, _P, _P], _I),
     "nl_dist_rows_prefix": ([_P, _I, _P, _P, _P, _P], _I),

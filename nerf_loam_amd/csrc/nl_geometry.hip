@@ -96,15 +96,23 @@ __device__ __forceinline__ bool slab_inv(const float o[3], const float inv[3], f
     return true;
 }
 
-__global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_dfs(
-    int N, const float* __restrict__ rays_d_sensor, const float* __restrict__ points_gt,
-    const float* __restrict__ cos_gt, const int* __restrict__ frame_id, const float* __restrict__ poses,
-    const int2* __restrict__ blk_hdr, const int4* __restrict__ blk_ids, int root_side,
-    float voxel_size, float max_distance,
-    float* __restrict__ rays_d_world, float* __restrict__ gt_dist,
-    int* __restrict__ hit_idx, float* __restrict__ hit_t0, float* __restrict__ hit_t1,
-    int* __restrict__ hit_count, int* __restrict__ counters, const int* __restrict__ ray_list)
+// The sequential DFS over the work items [first_block, ...) of `n_blocks` workgroups: body of k_ray_intersect_dfs, also called by the
+// one-workgroup hit-ray scan (k_scan_hits_fused) for the rays the work-list kernel handed over (normally none).
+struct DfsArgs {
+    int N; const float* rays_d_sensor; const float* points_gt; const float* cos_gt; const int* frame_id; const float* poses;
+    const int2* blk_hdr; const int4* blk_ids; int root_side; float voxel_size, max_distance;
+    float* rays_d_world; float* gt_dist; int* hit_idx; float* hit_t0; float* hit_t1; int* hit_count; int* counters; const int* ray_list;
+};
+__device__ __forceinline__ void dfs_rays(const DfsArgs& a, int first_block, int n_blocks)
 {
+    const int N = a.N;
+    const float* __restrict__ rays_d_sensor = a.rays_d_sensor; const float* __restrict__ points_gt = a.points_gt;
+    const float* __restrict__ cos_gt = a.cos_gt; const int* __restrict__ frame_id = a.frame_id; const float* __restrict__ poses = a.poses;
+    const int2* __restrict__ blk_hdr = a.blk_hdr; const int4* __restrict__ blk_ids = a.blk_ids;
+    const int root_side = a.root_side; const float voxel_size = a.voxel_size, max_distance = a.max_distance;
+    float* __restrict__ rays_d_world = a.rays_d_world; float* __restrict__ gt_dist = a.gt_dist;
+    int* __restrict__ hit_idx = a.hit_idx; float* __restrict__ hit_t0 = a.hit_t0; float* __restrict__ hit_t1 = a.hit_t1;
+    int* __restrict__ hit_count = a.hit_count; int* __restrict__ counters = a.counters; const int* __restrict__ ray_list = a.ray_list;
     __shared__ int s_base[NL_MAX_LEVELS * NL_GEO_THREADS];
     __shared__ unsigned char s_mask[NL_MAX_LEVELS * NL_GEO_THREADS];
     __shared__ unsigned char s_has[NL_MAX_LEVELS * NL_GEO_THREADS];
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_dfs(
     __syncthreads();
     // ray_list != null: fallback pass over the rays the queue kernel could not finish (count in counters[NLC_ISECT_OVF])
     const int n_work = ray_list ? counters[NLC_ISECT_OVF] : N;
-    for (int w0 = blockIdx.x * NL_GEO_THREADS; w0 < n_work; w0 += gridDim.x * NL_GEO_THREADS) {
+    for (int w0 = first_block * NL_GEO_THREADS; w0 < n_work; w0 += n_blocks * NL_GEO_THREADS) {
     const int wi = w0 + threadIdx.x;
     const int r = wi < n_work ? (ray_list ? ray_list[wi] : wi) : N;
     int valid = 0;
@@ -213,6 +221,8 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_dfs(
     __syncthreads();
     if (threadIdx.x == 0 && s_hmax > 0) atomicMax(&counters[NLC_HMAX], s_hmax);
 }
+
+__global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_dfs(DfsArgs a) { dfs_rays(a, blockIdx.x, gridDim.x); }
 
 // ---------------------------------------------------------------------------------------------
 // Work-list version of the same traversal: FOUR lanes per ray work through a per-ray LDS stack of pending node
@@ -520,9 +530,8 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_finish(const int* __res
 // ~1 us per chunk behind a ~4.8 us launch; the two-launch version costs 2 x 4.8 us at any of these sizes, so it wins from
 // 5 chunks on (16 384 rays: 20.8 us in one block, profiles/r01_m_timeline_latency_bound_steps.txt).
 #define NL_SCAN_ONE_BLOCK_MAX 4096
-__global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_one_block(const int* __restrict__ in, int* __restrict__ out, int n, int flag_mode,
-                                                                    int* __restrict__ ray_of_rank, int* __restrict__ total_out,
-                                                                    int* __restrict__ total_out2)
+__device__ __forceinline__ int scan_one_block(const int* __restrict__ in, int* __restrict__ out, int n, int flag_mode,
+                                              int* __restrict__ ray_of_rank, int* __restrict__ total_out, int* __restrict__ total_out2)
 {
     __shared__ int s_wave[NL_GEO_THREADS / 64];
     int carry = 0;
@@ -548,6 +557,25 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_one_block(const int* __
         carry += tot;
     }
     if (threadIdx.x == 0) { *total_out = carry; if (total_out2) *total_out2 = carry; }
+    return carry;
+}
+__global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_one_block(const int* __restrict__ in, int* __restrict__ out, int n, int flag_mode,
+                                                                    int* __restrict__ ray_of_rank, int* __restrict__ total_out,
+                                                                    int* __restrict__ total_out2)
+{
+    scan_one_block(in, out, n, flag_mode, ray_of_rank, total_out, total_out2);
+}
+// Launch-bound regime (<= NL_SCAN_ONE_BLOCK_MAX rays: the reference's live shapes): the hit-ray scan also runs the DFS fallback of
+// the rays the work-list intersect kernel handed over - a launch of its own otherwise, for a list that is empty on ordinary scans
+__global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_hits_fused(DfsArgs a, int* __restrict__ hit_rank, int* __restrict__ ray_of_rank,
+                                                                     int* __restrict__ total_out, int* __restrict__ total_out2)
+{
+    if (a.counters[NLC_ISECT_OVF] > 0) {                 // uniform over the workgroup
+        dfs_rays(a, 0, 1);
+        __threadfence_block();
+        __syncthreads();
+    }
+    scan_one_block(a.hit_count, hit_rank, a.N, 1, ray_of_rank, total_out, total_out2);
 }
 
 // ray_of_rank[rank] = ray  for rays with hit_count > 0   (the reference's boolean-mask compaction
@@ -846,10 +874,9 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample(SampleArgs a)
 }
 
 // one thread: global loss normalisers (criterion.py:84-88, :65 mean divisor) from the counters
-__global__ void k_loss_finalize(int* __restrict__ counters, NlLossScalars* __restrict__ ls,
-                                float fs_weight, float sdf_weight, float tau, float max_depth, int capacity)
+__device__ __forceinline__ void loss_finalize_one(int* __restrict__ counters, NlLossScalars* __restrict__ ls,
+                                                  float fs_weight, float sdf_weight, float tau, float max_depth, int capacity)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int R = counters[NLC_R_GLOBAL], S = counters[NLC_SMAX];
     const int n_fs = counters[NLC_NFS] + (S * counters[NLC_INV_FS_RAYS] - counters[NLC_INV_FS_CNT]);
     const int n_sdf = counters[NLC_NSDF] + (S * counters[NLC_INV_SDF_RAYS] - counters[NLC_INV_SDF_CNT]);
@@ -865,6 +892,20 @@ __global__ void k_loss_finalize(int* __restrict__ counters, NlLossScalars* __res
     o.R = R; o.S_max = S; o.P = counters[NLC_P]; o.pad = 0;
     if (counters[NLC_P] > capacity) { counters[NLC_OVERFLOW] = 1; o.P = capacity; }
     *ls = o;
+}
+__global__ void k_loss_finalize(int* __restrict__ counters, NlLossScalars* __restrict__ ls,
+                                float fs_weight, float sdf_weight, float tau, float max_depth, int capacity)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    loss_finalize_one(counters, ls, fs_weight, sdf_weight, tau, max_depth, capacity);
+}
+// the sample-offset scan of the launch-bound regime with the loss normalisers behind it (thread 0 wrote counters[NLC_P] itself)
+__global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_samples_finalize(const int* __restrict__ samp_count, int* __restrict__ samp_off, int n,
+                                                                           int* __restrict__ counters, NlLossScalars* __restrict__ ls,
+                                                                           float fs_weight, float sdf_weight, float tau, float max_depth, int capacity)
+{
+    scan_one_block(samp_count, samp_off, n, 0, nullptr, counters + NLC_P, nullptr);
+    if (threadIdx.x == 0) loss_finalize_one(counters, ls, fs_weight, sdf_weight, tau, max_depth, capacity);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -981,10 +1022,13 @@ int nl_inverse_cdf_sampling(const int* pts_idx, const float* min_depth, const fl
     return NL_OK;
 }
 
-int nl_ray_intersect(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
-                     const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
-                     float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
-                     int* counters, int* scratch_rays, void* stream)
+static int scan_launch(const int* in, int* out, int n, int flag_mode, int* ray_of_rank, int* total_out, int* total_out2, int* workspace,
+                       void* stream);
+
+static int intersect_launch(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
+                            const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
+                            float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
+                            int* counters, int* scratch_rays, int* hit_rank, int* total_out, int* total_out2, int* scan_ws, void* stream)
 {
     if (N <= 0 || !rays_d_sensor || !points_gt || !cos_gt || !poses || !blk_ids || !blk_hdr || root_side < 2 || !rays_d_world || !gt_dist ||
         !hit_idx || !hit_t0 || !hit_t1 || !hit_count || !counters || !scratch_rays) return NL_ERR_INVALID_ARG;
@@ -996,11 +1040,38 @@ int nl_ray_intersect(int N, const float* rays_d_sensor, const float* points_gt, 
                        N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, (const int2*)blk_hdr, (const int4*)blk_ids, root_side, voxel_size, max_distance,
                        rays_d_world, gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, scratch_rays);
     // rays whose LDS queue / hit list overflowed (none on ordinary scans): sequential DFS, device-side count
-    hipLaunchKernelGGL(k_ray_intersect_dfs, dim3(32), dim3(NL_GEO_THREADS), 0, st,
-                       N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, (const int2*)blk_hdr, (const int4*)blk_ids, root_side, voxel_size, max_distance,
-                       rays_d_world, gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, (const int*)scratch_rays);
+    const DfsArgs da = {N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, (const int2*)blk_hdr, (const int4*)blk_ids, root_side, voxel_size,
+                        max_distance, rays_d_world, gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, (const int*)scratch_rays};
+    if (hit_rank && N <= NL_SCAN_ONE_BLOCK_MAX) {        // launch-bound regime: fallback + hit-ray scan in one launch
+        hipLaunchKernelGGL(k_scan_hits_fused, dim3(1), dim3(NL_GEO_THREADS), 0, st, da, hit_rank, scratch_rays, total_out, total_out2);
+        NL_LAUNCH_CHECK();
+        return NL_OK;
+    }
+    hipLaunchKernelGGL(k_ray_intersect_dfs, dim3(32), dim3(NL_GEO_THREADS), 0, st, da);
     NL_LAUNCH_CHECK();
+    if (hit_rank) return scan_launch(hit_count, hit_rank, N, 1, scratch_rays, total_out, total_out2, scan_ws, stream);
     return NL_OK;
+}
+
+int nl_ray_intersect(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
+                     const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
+                     float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
+                     int* counters, int* scratch_rays, void* stream)
+{
+    return intersect_launch(N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, blk_hdr, blk_ids, root_side, voxel_size, max_distance, rays_d_world,
+                            gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, scratch_rays, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+/* nl_ray_intersect + nl_scan_hit_rays (ray_of_rank == the intersect kernel's scratch list, as in the stage-wise sequence): one
+ * launch fewer up to NL_SCAN_ONE_BLOCK_MAX rays, the same launches beyond */
+int nl_ray_intersect_scan(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
+                          const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
+                          float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
+                          int* counters, int* ray_of_rank, int* hit_rank, int* total_out, int* total_out2, int* scan_ws, void* stream)
+{
+    if (!hit_rank || !total_out || !scan_ws) return NL_ERR_INVALID_ARG;
+    return intersect_launch(N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, blk_hdr, blk_ids, root_side, voxel_size, max_distance, rays_d_world,
+                            gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, ray_of_rank, hit_rank, total_out, total_out2, scan_ws, stream);
 }
 
 static int scan_launch(const int* in, int* out, int n, int flag_mode, int* ray_of_rank, int* total_out, int* total_out2,
@@ -1111,6 +1182,23 @@ int nl_loss_finalize(int* counters, void* loss_scalars, float fs_weight, float s
                        fs_weight, sdf_weight, tau, max_depth, capacity);
     NL_LAUNCH_CHECK();
     return NL_OK;
+}
+
+/* nl_exclusive_scan_i32(samp_count -> samp_off, total -> counters[NLC_P]) + nl_loss_finalize: one launch up to
+ * NL_SCAN_ONE_BLOCK_MAX rays, the same launches beyond */
+int nl_scan_samples_finalize(const int* samp_count, int* samp_off, int N, int* counters, void* loss_scalars, float fs_weight, float sdf_weight,
+                             float tau, float max_depth, int capacity, int* workspace, void* stream)
+{
+    if (N <= 0 || !samp_count || !samp_off || !counters || !loss_scalars || !workspace) return NL_ERR_INVALID_ARG;
+    if (N <= NL_SCAN_ONE_BLOCK_MAX) {
+        hipLaunchKernelGGL(k_scan_samples_finalize, dim3(1), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, samp_count, samp_off, N, counters,
+                           (NlLossScalars*)loss_scalars, fs_weight, sdf_weight, tau, max_depth, capacity);
+        NL_LAUNCH_CHECK();
+        return NL_OK;
+    }
+    const int rc = scan_launch(samp_count, samp_off, N, 0, nullptr, counters + NLC_P, nullptr, workspace, stream);
+    if (rc != NL_OK) return rc;
+    return nl_loss_finalize(counters, loss_scalars, fs_weight, sdf_weight, tau, max_depth, capacity, stream);
 }
 
 }  // extern "C"

@@ -9,7 +9,7 @@
 #include "../../include/nerfloam_hip.h"
 
 // counter-block slots used here (nl_common.h: NLC_R, NLC_P, NLC_R_GLOBAL; the block is NL_CNT_INTS ints + NL_CNT_DOUBLES doubles)
-enum { IT_R = 0, IT_P = 3, IT_R_GLOBAL = 13, IT_OK = 0, IT_ERR_INVALID_ARG = 1, IT_ERR_LAUNCH = 2 };
+enum { IT_R = 0, IT_R_GLOBAL = 13, IT_OK = 0, IT_ERR_INVALID_ARG = 1, IT_ERR_LAUNCH = 2 };
 
 extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
 {
@@ -19,17 +19,19 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
 #define NL_TRY(call) do { rc = (call); if (rc != IT_OK) return rc; } while (0)
     if (stages & 1) {
         int* c = d->counters;
-        if (hipMemsetAsync(c, 0, NL_CNT_INTS * 4 + NL_CNT_DOUBLES * 8, st) != hipSuccess) return IT_ERR_LAUNCH;
-        NL_TRY(nl_ray_intersect(d->N, d->rays_d_sensor, d->points_gt, d->cos_gt, d->frame_id, d->poses12, d->blk_hdr, d->blk_ids, d->root_side,
-                                d->voxel_size, d->max_distance, d->rays_d_world, d->gt_dist, d->hit_idx, d->hit_t0, d->hit_t1, d->hit_count, c,
-                                d->ray_of_rank, stream));
-        NL_TRY(nl_scan_hit_rays(d->hit_count, d->hit_rank, d->ray_of_rank, d->N, c + IT_R, c + IT_R_GLOBAL, d->scan_ws, stream));
+        // the counter block starts an iteration zeroed: by the previous iteration's last kernel when that handed it over
+        // (counters_copy + counters_clean, set by the host after a stages == 3 call), by a memset launch otherwise
+        if (!(d->counters_copy && d->counters_clean) &&
+            hipMemsetAsync(c, 0, NL_CNT_INTS * 4 + NL_CNT_DOUBLES * 8, st) != hipSuccess) return IT_ERR_LAUNCH;
+        NL_TRY(nl_ray_intersect_scan(d->N, d->rays_d_sensor, d->points_gt, d->cos_gt, d->frame_id, d->poses12, d->blk_hdr, d->blk_ids, d->root_side,
+                                     d->voxel_size, d->max_distance, d->rays_d_world, d->gt_dist, d->hit_idx, d->hit_t0, d->hit_t1, d->hit_count, c,
+                                     d->ray_of_rank, d->hit_rank, c + IT_R, c + IT_R_GLOBAL, d->scan_ws, stream));
         const unsigned* mix = d->fresh_noise ? (const unsigned*)d->adam_state : nullptr;
         NL_TRY(nl_sample_rays(0, d->N, d->hit_idx, d->hit_t0, d->hit_t1, d->hit_count, d->hit_rank, d->ray_of_rank, d->cos_gt, d->gt_dist,
                               d->step_size, d->truncation, d->max_distance, d->noise_seed, d->use_hash_noise, d->tail_always, d->ray_id_base, mix, nullptr,
                               c, d->samp_count, nullptr, d->P_cap, nullptr, nullptr, nullptr, nullptr, stream));
-        NL_TRY(nl_exclusive_scan_i32(d->samp_count, d->samp_off, d->N, 0, c + IT_P, d->scan_ws, stream));
-        NL_TRY(nl_loss_finalize(c, d->loss_scalars, d->fs_weight, d->sdf_weight, d->truncation, d->max_distance, d->P_cap, stream));
+        NL_TRY(nl_scan_samples_finalize(d->samp_count, d->samp_off, d->N, c, d->loss_scalars, d->fs_weight, d->sdf_weight, d->truncation,
+                                        d->max_distance, d->P_cap, d->scan_ws, stream));
         NL_TRY(nl_sample_rays(1, d->N, d->hit_idx, d->hit_t0, d->hit_t1, d->hit_count, d->hit_rank, d->ray_of_rank, d->cos_gt, d->gt_dist,
                               d->step_size, d->truncation, d->max_distance, d->noise_seed, d->use_hash_noise, d->tail_always, d->ray_id_base, mix, nullptr,
                               c, d->samp_count, d->samp_off, d->P_cap, d->s_vox, d->s_depth, d->s_dist, d->s_ray, stream));
@@ -46,11 +48,13 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
                                 d->want_pose_grad ? d->g_pose : nullptr, 2 * d->field_blocks, stream));
     }
     if (stages & 2) {
-        NL_TRY(nl_optimiser_step(d->adam_state, d->lr_emb, d->lr_dec, d->lr_pose,
-                                 d->update_emb ? d->emb : nullptr, d->g_emb, d->emb_m, d->emb_v, d->n_emb_elems,
-                                 d->update_decoder ? d->dec_params : nullptr, d->dec_grad, d->dec_m, d->dec_v, d->dec_ws,
-                                 d->pose6, d->g_pose, d->pose_m, d->pose_v, d->pose_enable, d->pose_grad6, d->poses12, d->F, d->update_pose,
-                                 d->skip_mode ? d->counters : nullptr, d->skip_mode, stream));
+        const bool hand_over = d->counters_copy && (stages & 1);       // only a whole iteration leaves the block to the next one
+        NL_TRY(nl_optimiser_step_ex(d->adam_state, d->lr_emb, d->lr_dec, d->lr_pose,
+                                    d->update_emb ? d->emb : nullptr, d->g_emb, d->emb_m, d->emb_v, d->n_emb_elems,
+                                    d->update_decoder ? d->dec_params : nullptr, d->dec_grad, d->dec_m, d->dec_v, d->dec_ws,
+                                    d->pose6, d->g_pose, d->pose_m, d->pose_v, d->pose_enable, d->pose_grad6, d->poses12, d->F, d->update_pose,
+                                    d->skip_mode ? d->counters : nullptr, d->skip_mode, hand_over ? d->counters : nullptr,
+                                    hand_over ? d->counters_copy : nullptr, stream));
     }
 #undef NL_TRY
     return IT_OK;

@@ -155,7 +155,8 @@ struct OptimArgs {
     float* params; const float* grad; float* dm; float* dv; float* W2T; uint16_t* W2X; uint16_t* W2TX; uint16_t* W2A; uint16_t* W2XA; int nb_dec;
     float* pose6; double* g_pose; float* pm; float* pv; const int* enable; float* grad6_out; float* poses12; int F; int apply_pose;
     const int* counters; int skip_mode;
-};
+    int* snap_src; int* snap_dst;        // optional: the counter block is copied to snap_dst and CLEARED by the launch's last step, so that the
+};                                       // next iteration needs no memset launch (nl_iteration); the host reads the copy
 
 // "The iteration was unusable" decided ON THE DEVICE, so that the host loop needs no per-iteration read-back.  The reference skips
 // the optimiser step when render_rays returns None (no ray hit a voxel: render_helpers.py:216-217; the sampler's guard
@@ -175,6 +176,12 @@ __device__ __forceinline__ void optim_note_skip(const int* __restrict__ counters
     state[2] = state[2] + 1;
     if (counters[NLC_OVERFLOW] != 0) state[3] = 1;
 }
+// end of an iteration: hand the counter block to the host-visible copy and leave it zeroed for the next iteration (one thread)
+__device__ __forceinline__ void counters_hand_over(int* __restrict__ src, int* __restrict__ dst)
+{
+    if (!src || !dst) return;
+    for (int i = 0; i < NL_CNT_BYTES / 4; ++i) { dst[i] = src[i]; src[i] = 0; }
+}
 #define OPT_DEC_REST (NL_DEC_PARAMS - NL_W * NL_W - NL_W)            // W1, b1, b2, b3 (w3 rides with the W2 rows)
 #define OPT_DEC_BLOCKS (NL_W + (OPT_DEC_REST + 255) / 256)
 
@@ -192,7 +199,7 @@ __global__ void __launch_bounds__(256) k_optim_step(OptimArgs a)
             const int f = (b - a.nb_emb - a.nb_dec) * 256 + tid;
             if (f < a.F) for (int i = 0; i < 12; ++i) a.g_pose[12 * f + i] = 0.0;
         }
-        if (gridDim.x == 1) { __syncthreads(); if (tid == 0) optim_note_skip(a.counters, a.state); }
+        if (gridDim.x == 1) { __syncthreads(); if (tid == 0) { optim_note_skip(a.counters, a.state); counters_hand_over(a.snap_src, a.snap_dst); } }
         return;
     }
     if (tid == 0) s_h = nl_adam_hyper(role == 0 ? a.lr_emb : (role == 1 ? a.lr_dec : a.lr_pose), step, 0.9, 0.999, 1e-8);
@@ -250,15 +257,20 @@ __global__ void __launch_bounds__(256) k_optim_step(OptimArgs a)
         const int f = (b - a.nb_emb - a.nb_dec) * 256 + tid;
         if (f < a.F) pose_step_one(f, a.pose6, a.g_pose, a.pm, a.pv, a.enable, a.grad6_out, a.poses12, h, a.apply_pose);
     }
-    if (gridDim.x == 1 && tid == 0) a.state[0] = step;               // (tid 0 read the old value before the barrier above)
+    if (gridDim.x == 1 && tid == 0) {                                // (every thread read the state / counter words before the barrier above)
+        a.state[0] = step;
+        counters_hand_over(a.snap_src, a.snap_dst);
+    }
 }
 
 // advance the step counter after a multi-workgroup k_optim_step (a last-workgroup ticket costs more than this launch: thousands
 // of same-address device-scope atomics, profiles/r01_m_optimiser_step.txt)
-__global__ void k_adam_advance(int* __restrict__ state, const int* __restrict__ counters, int skip_mode)
+__global__ void k_adam_advance(int* __restrict__ state, const int* __restrict__ counters, int skip_mode, int* __restrict__ snap_src,
+                               int* __restrict__ snap_dst)
 {
     if (optim_skip(counters, state, skip_mode)) optim_note_skip(counters, state);
     else state[0] = state[0] + 1;
+    counters_hand_over(snap_src, snap_dst);
 }
 
 // Multi-GPU (nerf_loam_amd/dist.py): every rank all-gathers its whole counter block (one small collective) and this kernel
@@ -374,11 +386,14 @@ int nl_pose_step(float* pose6, double* g_pose, float* m, float* v, const int* en
     return NL_OK;
 }
 
-int nl_optimiser_step(int* state, double lr_emb, double lr_dec, double lr_pose,
-                      void* emb, float* g_emb, void* emb_m, void* emb_v, long long n_emb,
-                      float* dec_params, const float* dec_grad, float* dec_m, float* dec_v, float* dec_ws,
-                      float* pose6, double* g_pose, float* pose_m, float* pose_v, const int* pose_enable, float* grad6_out,
-                      float* poses12, int F, int apply_pose, const int* counters, int skip_mode, void* stream)
+/* nl_optimiser_step + the end-of-iteration hand-over of the counter block: its words are copied to counters_copy and CLEARED by
+ * the launch's last step (nl_iteration: the next iteration then starts without a memset launch; the host reads the copy) */
+int nl_optimiser_step_ex(int* state, double lr_emb, double lr_dec, double lr_pose,
+                         void* emb, float* g_emb, void* emb_m, void* emb_v, long long n_emb,
+                         float* dec_params, const float* dec_grad, float* dec_m, float* dec_v, float* dec_ws,
+                         float* pose6, double* g_pose, float* pose_m, float* pose_v, const int* pose_enable, float* grad6_out,
+                         float* poses12, int F, int apply_pose, const int* counters, int skip_mode, int* counters_rw, int* counters_copy,
+                         void* stream)
 {
     if (!state || skip_mode < 0 || skip_mode > 2 || (skip_mode && !counters)) return NL_ERR_INVALID_ARG;
     if (emb && (!g_emb || !emb_m || !emb_v || n_emb <= 0)) return NL_ERR_INVALID_ARG;
@@ -398,12 +413,23 @@ int nl_optimiser_step(int* state, double lr_emb, double lr_dec, double lr_pose,
     a.pose6 = pose6; a.g_pose = g_pose; a.pm = pose_m; a.pv = pose_v; a.enable = pose_enable; a.grad6_out = grad6_out;
     a.poses12 = poses12; a.F = pose6 ? F : 0; a.apply_pose = apply_pose;
     a.counters = counters; a.skip_mode = skip_mode;
+    a.snap_src = counters_copy ? counters_rw : nullptr; a.snap_dst = counters_rw ? counters_copy : nullptr;
     const int nb_pose = pose6 ? nl_div_up(F, 256) : 0;
     const int nb = a.nb_emb + a.nb_dec + nb_pose;
     hipLaunchKernelGGL(k_optim_step, dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
-    if (nb > 1) hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, state, counters, skip_mode);
+    if (nb > 1) hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, state, counters, skip_mode, a.snap_src, a.snap_dst);
     NL_LAUNCH_CHECK();
     return NL_OK;
+}
+
+int nl_optimiser_step(int* state, double lr_emb, double lr_dec, double lr_pose,
+                      void* emb, float* g_emb, void* emb_m, void* emb_v, long long n_emb,
+                      float* dec_params, const float* dec_grad, float* dec_m, float* dec_v, float* dec_ws,
+                      float* pose6, double* g_pose, float* pose_m, float* pose_v, const int* pose_enable, float* grad6_out,
+                      float* poses12, int F, int apply_pose, const int* counters, int skip_mode, void* stream)
+{
+    return nl_optimiser_step_ex(state, lr_emb, lr_dec, lr_pose, emb, g_emb, emb_m, emb_v, n_emb, dec_params, dec_grad, dec_m, dec_v, dec_ws, pose6,
+                                g_pose, pose_m, pose_v, pose_enable, grad6_out, poses12, F, apply_pose, counters, skip_mode, nullptr, nullptr, stream);
 }
 
 int nl_device_count(void)

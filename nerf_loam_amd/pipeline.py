@@ -223,7 +223,10 @@ class SdfEngine:
         self.dsdf = torch.empty(P, dtype=F32, device=d)
         self.relu2_mask = torch.empty(P * 8 + 1024, dtype=I32, device=d)     # [tiles][512] ReLU bit words
         # counters + loss scalars
-        self.counters = torch.zeros(L.NL_CNT_BYTES // 4, dtype=I32, device=d)
+        self._counters2 = torch.zeros(2 * (L.NL_CNT_BYTES // 4), dtype=I32, device=d)
+        self.counters = self._counters2[:L.NL_CNT_BYTES // 4]           # the live block the kernels count into
+        self.counters_copy = self._counters2[L.NL_CNT_BYTES // 4:]      # run_bound(): the finished iteration's block (live one cleared)
+        self._stats_from_copy = False
         self.loss_scalars = torch.zeros(L.NL_LOSS_SCALARS_BYTES // 4, dtype=I32, device=d)
         # decoder partial slabs (one per persistent workgroup)
         self.n_slabs = int(L.lib().nl_decoder_grid_hint())
@@ -386,6 +389,8 @@ class SdfEngine:
         tm = self._mark
         self._map_for_exchange = m                               # multi-GPU hooks look the map's row table up here
         c.zero_()
+        self._stats_from_copy = False                            # stage-wise iterations count into (and leave) the live block
+        self._desc.counters_clean = 0
         tm("intersect", 0)
         ops.ray_intersect(N, self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self.poses12, m.blk_hdr, m.blk_ids, m.root_side,
                           m.voxel_size, cfg.max_distance, self.rays_d_world, self.gt_dist, self.hit_idx, self.hit_t0, self.hit_t1,
@@ -518,6 +523,7 @@ class SdfEngine:
         d.update_emb, d.update_decoder, d.update_pose, d.skip_mode = int(update_emb), int(update_decoder), int(update_pose), int(skip_mode)
         if want_emb_grad or update_emb:
             assert self.g_emb is not None, "begin_call(emb_state=True) first"
+        d.counters_copy, d.counters_clean = pt(self.counters_copy), 0
         self._bound = (m, dec)                                       # keeps the tensors the descriptor points at alive
 
     def run_bound(self, stages=3):
@@ -525,6 +531,12 @@ class SdfEngine:
         d = self._desc
         d.N, d.F = self.N, self.F
         L.check(L.lib().nl_iteration(ctypes.byref(d), int(stages), L.stream_ptr()), "nl_iteration")
+        # a whole iteration ends with its counter block handed to counters_copy and the live block cleared for the next one
+        # (no memset launch then); a forward-only call leaves the block in place
+        whole = (int(stages) & 3) == 3
+        d.counters_clean = int(whole)
+        if int(stages) & 1:
+            self._stats_from_copy = whole
 
     # ------------------------------------------------------------------ hipGraph
     def capture_iteration(self, m: MapDevice, dec: DecoderDevice, cfg: IterConfig, **flags):
@@ -556,7 +568,7 @@ class SdfEngine:
     # ------------------------------------------------------------------ read-back (tests, API parity)
     def stats(self):
         """Host copy of the counter block (synchronises)."""
-        c = self.counters.cpu().numpy()
+        c = (self.counters_copy if self._stats_from_copy else self.counters).cpu().numpy()
         ints = c[:L.NL_CNT_INTS]
         dbl = c[L.NL_CNT_INTS:].view(np.float64)
         ls = self.loss_scalars.cpu().numpy()

@@ -500,6 +500,95 @@ def test_intersect_cap_and_overflow_paths(nl):
     assert np.array_equal(np.where(live, eng.hit_t1[:n, :Hm].cpu().numpy(), np.float32(50)), o1)
 
 
+def test_fused_scan_launches_equal_the_separate_calls(nl):
+    """nl_ray_intersect_scan (intersect fallback + hit-ray scan in one launch up to 4096 rays) and nl_scan_samples_finalize (sample
+    scan + loss normalisers in one launch) against the separate calls, on the scene whose rays overflow the work-list kernel - the
+    fallback has to run INSIDE the scan kernel - and beyond 4096 rays (same launches as the separate calls)."""
+    P, ops, L = nl["P"], nl["ops"], nl["L"]
+    xs, ys, zs = np.meshgrid(np.arange(10000, 10048), np.arange(10000, 10040), np.arange(10000, 10003), indexing="ij")
+    vox = np.stack([xs, ys, zs], -1).reshape(-1, 3).astype(np.int32)
+    oc = O.Octree(); oc.init(256 * 256 * 4, 16, 0.2); oc.insert(vox)
+    v, c, f = oc.get_centres_and_children()
+    centres, structure = O.grid_features(v, c, 0.2)
+    m = P.MapDevice(centres, structure, f, np.zeros(len(centres), np.int32), np.zeros((1, 16), np.uint16), 0.2)
+    origin = np.array([1999.0, 2003.7, 2000.31], np.float32)
+    pose = np.concatenate([origin, np.zeros(3, np.float32)])
+    lib = L.lib()
+    for n in (4096, 6000):
+        rng = np.random.default_rng(5)
+        tgt = np.stack([rng.uniform(2000.0, 2009.6, n), rng.uniform(2000.0, 2008.0, n), rng.uniform(1998.5, 2002.0, n)], -1).astype(np.float32)
+        d = tgt - origin; d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        res = []
+        for fused in (False, True):
+            eng = P.SdfEngine(max_rays=n, samples_per_ray_cap=8)
+            eng.set_rays(d, np.ones_like(d), np.ones(n, np.float32)); eng.set_poses(pose[None], [0])
+            eng.counters.zero_()
+            c0 = eng.counters
+            if fused:
+                L.check(lib.nl_ray_intersect_scan(n, L.ptr(eng.rays_d_sensor), L.ptr(eng.points_gt), L.ptr(eng.cos_gt), L.ptr(eng.frame_id),
+                                                  L.ptr(eng.poses12), L.ptr(m.blk_hdr), L.ptr(m.blk_ids), int(m.root_side), 0.2, 50.0,
+                                                  L.ptr(eng.rays_d_world), L.ptr(eng.gt_dist), L.ptr(eng.hit_idx), L.ptr(eng.hit_t0), L.ptr(eng.hit_t1),
+                                                  L.ptr(eng.hit_count), L.ptr(c0), L.ptr(eng.ray_of_rank), L.ptr(eng.hit_rank),
+                                                  L.ptr(c0[L.NLC_R:]), L.ptr(c0[L.NLC_R_GLOBAL:]), L.ptr(eng.scan_ws), L.stream_ptr()), "isect_scan")
+            else:
+                ops.ray_intersect(n, eng.rays_d_sensor, eng.points_gt, eng.cos_gt, eng.frame_id, eng.poses12, m.blk_hdr, m.blk_ids, m.root_side, 0.2,
+                                  50.0, eng.rays_d_world, eng.gt_dist, eng.hit_idx, eng.hit_t0, eng.hit_t1, eng.hit_count, c0, eng.ray_of_rank)
+                ops.scan_hit_rays(eng.hit_count, eng.hit_rank, eng.ray_of_rank, n, c0[L.NLC_R:], c0[L.NLC_R_GLOBAL:], eng.scan_ws)
+            # a stand-in sample count per ray (the hit count) through the two forms of the second scan
+            eng.samp_count[:n].copy_(eng.hit_count[:n])
+            if fused:
+                L.check(lib.nl_scan_samples_finalize(L.ptr(eng.samp_count), L.ptr(eng.samp_off), n, L.ptr(c0), L.ptr(eng.loss_scalars), 1.0, 2.0, 0.3,
+                                                     50.0, 10 ** 9, L.ptr(eng.scan_ws), L.stream_ptr()), "scan_finalize")
+            else:
+                ops.exclusive_scan(eng.samp_count, eng.samp_off, n, 0, c0[L.NLC_P:], eng.scan_ws)
+                ops.loss_finalize(c0, eng.loss_scalars, 1.0, 2.0, 0.3, 50.0, 10 ** 9)
+            torch.cuda.synchronize()
+            res.append({k: getattr(eng, k)[:n].cpu().numpy().copy() for k in ("hit_idx", "hit_t0", "hit_t1", "hit_count", "hit_rank", "samp_off")})
+            res[-1]["counters"] = c0.cpu().numpy().copy(); res[-1]["ls"] = eng.loss_scalars.cpu().numpy().copy()
+            R = int(res[-1]["counters"][L.NLC_R])
+            res[-1]["ray_of_rank"] = eng.ray_of_rank[:R].cpu().numpy().copy()
+        assert res[0]["counters"][L.NLC_ISECT_OVF] > 0                                # the fallback pass really had work
+        assert np.array_equal(res[0]["hit_count"], res[1]["hit_count"])
+        live = np.arange(res[0]["hit_idx"].shape[1])[None, :] < res[0]["hit_count"][:, None]      # slots past a ray's count are never written
+        for k in res[0]:
+            x, y = res[0][k], res[1][k]
+            if k in ("hit_idx", "hit_t0", "hit_t1"):
+                x, y = np.where(live, x, 0), np.where(live, y, 0)
+            assert np.array_equal(x, y), (n, k)
+
+
+def test_counter_hand_over_between_bound_iterations(nl):
+    """run_bound(): a whole iteration ends with its counter block copied to counters_copy and the live block cleared (the next
+    iteration then has no memset launch); stats() reads the copy and equals the stage-wise iteration's; a forward-only call in
+    between leaves the live block in place and the following whole iteration clears it first."""
+    sc = H.build_oracle_scene(16, 128, 7)
+    dec_np = O.decoder_init(7)
+    pose = np.array([2000.01, 1999.98, 2000.0, 0.003, -0.002, 0.008], np.float32)
+    fr = O.select_rays(sc["points"], sc["cos"], pose, np.ones(len(sc["points"]), bool))
+    m, dec, eng = make_engine(nl, sc, dec_np, len(fr.rays_d))
+    cfg = nl["P"].IterConfig()
+    load_frames(eng, [fr])
+    eng.begin_call(m, dec)
+    eng.forward_backward(m, dec, cfg, train_decoder=True)
+    ref = eng.stats()
+    eng.optimiser_step(m, dec, cfg)
+    m2, dec2, eng2 = make_engine(nl, sc, dec_np, len(fr.rays_d))
+    load_frames(eng2, [fr])
+    eng2.begin_call(m2, dec2)
+    eng2.bind(m2, dec2, cfg, train_decoder=True, want_pose_grad=False, update_pose=False)      # fixed pose: R and P stay what they are
+    eng2.run_bound()
+    st = eng2.stats()
+    assert np.array_equal(st["ints"], ref["ints"]) and np.allclose(st["dbl"], ref["dbl"], rtol=1e-12)
+    assert int(eng2.counters.abs().sum()) == 0 and eng2._desc.counters_clean == 1     # handed over: live block cleared
+    eng2.run_bound()                                                                  # second whole iteration: no memset, still consistent
+    st2 = eng2.stats()
+    assert st2["R"] == ref["R"] and st2["overflow"] == 0 and int(eng2.counters.abs().sum()) == 0
+    eng2.run_bound(stages=1)                                                          # forward only: block stays live and dirty
+    assert eng2._desc.counters_clean == 0 and eng2.stats()["R"] == ref["R"] and int(eng2.counters.abs().sum()) != 0
+    eng2.run_bound()                                                                  # cleared by the memset this time
+    assert eng2.stats()["R"] == ref["R"] and eng2.stats()["P"] == st2["P"]
+
+
 @pytest.mark.parametrize("vox_kind", ["single", "block", "row30"])
 def test_fused_intersect_and_sampler_edge_cases(nl, vox_kind):
     """Hand-built octrees and degenerate rays (axis-parallel, origin inside a voxel, along faces/edges/corners,
