@@ -188,7 +188,8 @@ def compare_iteration(eng, m, dec, out, cfgP, train_decoder, sdf_tol=1e-4):
     return r
 
 
-POSE_GRAD_RTOL = 1e-4            # fp64-accumulated partials: what is left is the fp32 round-off of the per-sample terms themselves
+POSE_GRAD_RTOL = 1e-5            # fp64-accumulated partials: what is left is the fp32 round-off of the per-sample terms themselves
+                                 # (measured: <= 2e-6 relative on the large components; the absolute term covers the cancelling ones)
 
 
 def nl_split(flat):
@@ -247,7 +248,7 @@ def compare_emb_and_pose_grads(nl, eng, m, dec, out, cfgP, nf, train):
     eng.optimiser_step(m, dec, cfgP, update_decoder=train, update_pose=False)           # computes grad6, no pose update
     g6 = eng.pose_grad6[:nf].cpu().numpy()
     for f in range(nf):
-        atol = (1e-3 if getattr(eng, "_relu_flips_seen", False) else 1e-4) * np.abs(out["grad_pose"][f]).max()
+        atol = (1e-3 if getattr(eng, "_relu_flips_seen", False) else 5e-5) * np.abs(out["grad_pose"][f]).max()
         np.testing.assert_allclose(g6[f], out["grad_pose"][f], rtol=POSE_GRAD_RTOL, atol=1e-6 + atol)
 
 
@@ -290,7 +291,13 @@ def test_mapping_three_steps_track_oracle(nl, golden_dir, backward_mode):
     emb = m.emb_bits()
     mism = (emb != ms_o.emb).mean()
     assert mism < 5e-3, mism
-    d = np.abs(O.bf16_to_f32(emb) - O.bf16_to_f32(ms_o.emb))
+    ref_e = O.bf16_to_f32(ms_o.emb)
+    d = np.abs(O.bf16_to_f32(emb) - ref_e)
+    # a mismatching element is a different bf16 rounding of (nearly) the same update: one ulp per step, not a different step
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref_e), 2.0 ** -100))) - 7)
+    # (measured: 7e-5 / 2e-3 of the elements mismatch in gemm mode 1 / 3; all but 9e-6 / 3e-4 of them by at most 3 ulp - the rest sit
+    # behind a ReLU flip of step 1: a near-zero later gradient changes sign and Adam's step with it, bounded by the steps themselves)
+    assert (d > 3 * ulp + 1e-12).mean() < 1e-3
     assert d.max() <= 3 * 0.03 + 1e-6
     dn = dec.numpy()
     for n_ in dec_np.names():
