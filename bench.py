@@ -535,9 +535,9 @@ def main():
                                 "frac": float(sum(bounds.values())) / (dt / args.steps * 1e3), "bounds_ms": bounds, "stage_ms": stage_ms,
                                 "note": "decoder kernels: matrix-pipe bound of their instruction mix; every other stage: algorithmic bytes / 8 TB/s"}
             out["pose_refine"] = pose_refine_bench(w, device)      # launch-bound loops first: the oracle's BLAS threads keep spinning
-            out["shard_probe"] = shard_probe_bench(w, device, dt / args.steps * 1e3)
             if not args.no_api_path:                               # for a while after use and slow the launching thread down
-                out["api_path"] = api_path_bench(w, device)
+                out["shard_probe"] = shard_probe_bench(w, device, dt / args.steps * 1e3)   # (same kernels at other sizes: kept out of the
+                out["api_path"] = api_path_bench(w, device)                                #  profiled command's per-kernel averages)
             if not args.no_parity:
                 out["parity"] = parity_check(eng, w, cfg, train_dec)
         if not args.no_cpu_baseline and world == 1:
