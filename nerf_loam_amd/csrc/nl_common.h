@@ -29,6 +29,7 @@ enum {
     NLC_R_OFFSET,       // multi-GPU: number of hit rays on lower ranks (global rank of local hit-ray 0)
     NLC_R_GLOBAL,       // multi-GPU: global number of hit rays (== NLC_R on one GPU)
     NLC_ISECT_OVF,      // rays handed from the queue intersect kernel to the sequential DFS fallback
+    NLC_TICKET,         // workgroups of the fused sampler that have finished (the last one computes the loss normalisers)
     NL_CNT_INTS = 16
 };
 enum {

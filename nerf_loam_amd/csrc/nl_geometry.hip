@@ -757,6 +757,204 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample_par(SampleArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The sampler of the launch-bound regime (<= 8192 rays) as ONE launch instead of four (count pass, offset scan, loss normalisers,
+// emit pass): every workgroup walks its 32 rays ONCE - the emit callback counts the loss masks and parks the samples in LDS -,
+// obtains its global sample offset by decoupled look-back over the workgroups before it (status words tagged with the call's
+// epoch: nothing to clear between iterations), writes the samples out, and the last workgroup to finish computes the loss
+// normalisers.  Offsets are the exclusive prefix in ray order: the same samples at the same places as the four-launch sequence.
+// A ray with more than SF_CAP samples makes its workgroup walk a second time, straight to memory (correct, just slower).
+// ---------------------------------------------------------------------------------------------
+#define SF_CAP 96
+__device__ __forceinline__ void loss_finalize_one(int* __restrict__ counters, NlLossScalars* __restrict__ ls,
+                                                  float fs_weight, float sdf_weight, float tau, float max_depth, int capacity);
+#define SF_STATUS_AGG 1ull
+#define SF_STATUS_PREFIX 2ull
+struct SampleFusedArgs {
+    SampleArgs s;
+    int* samp_off_out;
+    unsigned long long* wg_state;   // [gridDim.x]: epoch << 34 | status << 32 | value
+    unsigned epoch;
+    NlLossScalars* ls; float fs_weight, sdf_weight;
+};
+__global__ __launch_bounds__(NL_GEO_THREADS) void k_sample_fused(SampleFusedArgs fa)
+{
+    const SampleArgs& a = fa.s;
+    __shared__ int s_red[8];
+    __shared__ double s_dred[2];
+    __shared__ int s_i[SP_RAYS * NL_MAX_HITS];
+    __shared__ float s_0[SP_RAYS * NL_MAX_HITS], s_1[SP_RAYS * NL_MAX_HITS], s_c[SP_RAYS * NL_MAX_HITS];
+    __shared__ float s_tot[SP_RAYS];
+    __shared__ int s_nb[SP_RAYS], s_cnt[SP_RAYS], s_excl[SP_RAYS];
+    __shared__ int b_vox[SP_RAYS * SF_CAP];
+    __shared__ float b_depth[SP_RAYS * SF_CAP], b_dist[SP_RAYS * SF_CAP];
+    __shared__ int s_base, s_ovf, s_last;
+    if (threadIdx.x < 8) s_red[threadIdx.x] = 0;
+    if (threadIdx.x < 2) s_dred[threadIdx.x] = 0.0;
+    if (threadIdx.x == 0) { s_ovf = 0; s_last = 0; }
+    __syncthreads();
+    const int rl = threadIdx.x / SP_LPR, j = threadIdx.x % SP_LPR;
+    const int r = blockIdx.x * SP_RAYS + rl;
+    int cnt = 0, nfs = 0, nsdf = 0, inv_fs = 0, inv_sdf = 0, guard = 0;
+    double inv_d2 = 0.0;
+    const bool live = r < a.N && a.hit_count[r] > 0;
+    int* my_i = s_i + rl * NL_MAX_HITS; float* my_0 = s_0 + rl * NL_MAX_HITS; float* my_1 = s_1 + rl * NL_MAX_HITS; float* my_c = s_c + rl * NL_MAX_HITS;
+    const int P = a.counters[NLC_HMAX];
+    if (live) {
+        const int nh = a.hit_count[r];
+        for (int l = j; l < NL_MAX_HITS; l += SP_LPR) {          // row tails beyond the ray's own hits are padding
+            const bool v = l < nh;
+            my_i[l] = v ? a.hit_idx[(size_t)r * NL_MAX_HITS + l] : -1;
+            my_0[l] = v ? a.hit_t0[(size_t)r * NL_MAX_HITS + l] : a.max_depth;
+            my_1[l] = v ? a.hit_t1[(size_t)r * NL_MAX_HITS + l] : a.max_depth;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();                               // a ray's lanes sit in one wave
+    auto get_i = [&](int b) { return my_i[b]; };
+    auto get_0 = [&](int b) { return my_0[b]; };
+    auto get_1 = [&](int b) { return my_1[b]; };
+    auto get_c = [&](int b) { return my_c[b]; };
+    if (live && j == 0) {
+        float tot = 0.0f;
+        for (int l = 0; l < P; ++l) { const int i_ = my_i[l]; tot = tot + ((i_ == -1) ? 0.0f : (my_1[l] - my_0[l])); }
+        s_tot[rl] = tot;
+        s_nb[rl] = nl_walk_plan(get_i, get_0, get_1, P, tot, [&](int b, float c) { my_c[b] = c; });
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float tot = live ? s_tot[rl] : 0.0f;
+    const int nb = live ? s_nb[rl] : 0;
+    if (live && tot > 10.0f * NL_FILL_DEPTH) guard = 1;
+    const float c = live ? a.cos_gt[r] : 0.0f, d = live ? a.gt_dist[r] : 0.0f;
+    const unsigned rid = (unsigned)(r + a.ray_id_base);
+    const unsigned seed = a.seed_mix ? a.seed + 0x9E3779B9u * (*a.seed_mix) : a.seed;
+    const bool hash = a.use_hash_noise != 0;
+    auto noise = [&](int step) -> float { return hash ? nl_noise(seed, rid, (unsigned)step) : 0.5f; };
+    // one walk of this lane's share of the ray's steps (+ the closing loop on lane 0); returns the sample count on lane 0
+    auto walk = [&](auto emit) -> int {
+        int n = 0;
+        const float steps = tot / a.step_size;
+        const float step = (float)(1.0 / (double)steps);
+        const int T = (int)ceilf(steps);
+        for (int cs = j; cs < T; cs += SP_LPR) nl_walk_step(cs, step, nb, get_i, get_c, get_0, get_1, noise, emit);
+        if (j == 0) {
+            NlTailCtx tc;
+            const int Rg = a.counters[NLC_R_GLOBAL];
+            const int rank = a.hit_rank[r] + a.counters[NLC_R_OFFSET];
+            int first_rank;
+            nl_sampler_layout(rank, Rg, &tc.j_in_row, &tc.rays_in_row, &first_rank);
+            const int first_local = first_rank - a.counters[NLC_R_OFFSET];
+            const bool is_local = first_local >= 0 && first_local < a.counters[NLC_R];
+            const int first_ray = is_local ? a.ray_of_rank[first_local] : r;
+            tc.row_first_idx = a.hit_idx + (size_t)first_ray * NL_MAX_HITS;
+            tc.row_first_count = a.hit_count[first_ray];
+            tc.row_first_bias = 0;
+            if (!is_local && a.row_first) {
+                const int* e = a.row_first + (size_t)nl_row_first_entry(first_rank, Rg) * (1 + NL_MAX_HITS);
+                tc.row_first_idx = e + 1; tc.row_first_count = e[0]; tc.row_first_bias = 1;
+            }
+            tc.tail_always = a.tail_always != 0;
+            n = nl_walk_tail(T, step, nb, P, get_i, get_c, get_0, get_1, tc, noise, emit);
+        }
+        return n;
+    };
+    if (live && !guard) {
+        auto emit = [&](int s_, int vox, float depth, float dist) {
+            bool f, m;
+            nl_loss_masks(depth * c, d, a.tau, a.max_depth, &f, &m);
+            nfs += f ? 1 : 0; nsdf += m ? 1 : 0;
+            if (s_ < SF_CAP) { const int q = rl * SF_CAP + s_; b_vox[q] = vox; b_depth[q] = depth; b_dist[q] = dist < 0.0f ? 0.0f : dist; }
+            else s_ovf = 1;
+        };
+        cnt = walk(emit);
+    }
+    if (live && j == 0) {
+        bool f, m;
+        nl_loss_masks(NL_FILL_DEPTH * c, d, a.tau, a.max_depth, &f, &m);
+        if (!guard) { inv_fs = f ? 1 : 0; inv_sdf = m ? 1 : 0; inv_d2 = m ? (double)d * (double)d : 0.0; }
+    }
+    if (j == 0) s_cnt[rl] = cnt;
+    // the loss normalisers' sums (as in the count pass)
+    {
+        int vmax = cnt, v1 = nfs, v2 = nsdf, v3 = inv_fs, v4 = inv_fs * cnt, v5 = inv_sdf, v6 = inv_sdf * cnt, v7 = guard;
+        double d1 = inv_d2, d2 = inv_d2 * (double)cnt;
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) {
+            vmax = max(vmax, __shfl_xor(vmax, o2));
+            v1 += __shfl_xor(v1, o2); v2 += __shfl_xor(v2, o2); v3 += __shfl_xor(v3, o2); v4 += __shfl_xor(v4, o2);
+            v5 += __shfl_xor(v5, o2); v6 += __shfl_xor(v6, o2); v7 += __shfl_xor(v7, o2);
+            d1 += __shfl_xor(d1, o2); d2 += __shfl_xor(d2, o2);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(&s_red[0], vmax);
+            atomicAdd(&s_red[1], v1); atomicAdd(&s_red[2], v2); atomicAdd(&s_red[3], v3); atomicAdd(&s_red[4], v4);
+            atomicAdd(&s_red[5], v5); atomicAdd(&s_red[6], v6); atomicAdd(&s_red[7], v7);
+            atomicAdd(&s_dred[0], d1); atomicAdd(&s_dred[1], d2);
+        }
+    }
+    __syncthreads();
+    // this workgroup's sample offset: exclusive prefix over the rays inside it + look-back over the workgroups before it
+    if (threadIdx.x < 64) {
+        const int t = threadIdx.x;
+        int v = t < SP_RAYS ? s_cnt[t] : 0, inc = v;
+#pragma unroll
+        for (int o2 = 1; o2 < 64; o2 <<= 1) { const int u = __shfl_up(inc, o2); if (t >= o2) inc += u; }
+        if (t < SP_RAYS) s_excl[t] = inc - v;
+        const int agg = __shfl(inc, 63);
+        if (t == 0) {
+            const unsigned long long tag = (unsigned long long)fa.epoch << 34;
+            const int b = blockIdx.x;
+            int base = 0;
+            if (b > 0) {
+                __hip_atomic_store(&fa.wg_state[b], tag | (SF_STATUS_AGG << 32) | (unsigned)agg, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                for (int i = b - 1; i >= 0; --i) {
+                    unsigned long long w;
+                    do { w = __hip_atomic_load(&fa.wg_state[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while ((w >> 34) != fa.epoch || ((w >> 32) & 3ull) == 0ull);
+                    base += (int)(unsigned)(w & 0xFFFFFFFFull);
+                    if (((w >> 32) & 3ull) == SF_STATUS_PREFIX) break;
+                }
+            }
+            __hip_atomic_store(&fa.wg_state[b], tag | (SF_STATUS_PREFIX << 32) | (unsigned)(base + agg), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            s_base = base;
+            if (b == (int)gridDim.x - 1) a.counters[NLC_P] = base + agg;
+            if (s_red[0] > 0) atomicMax(&a.counters[NLC_SMAX], s_red[0]);
+            if (s_red[1]) atomicAdd(&a.counters[NLC_NFS], s_red[1]);
+            if (s_red[2]) atomicAdd(&a.counters[NLC_NSDF], s_red[2]);
+            if (s_red[3]) atomicAdd(&a.counters[NLC_INV_FS_RAYS], s_red[3]);
+            if (s_red[4]) atomicAdd(&a.counters[NLC_INV_FS_CNT], s_red[4]);
+            if (s_red[5]) atomicAdd(&a.counters[NLC_INV_SDF_RAYS], s_red[5]);
+            if (s_red[6]) atomicAdd(&a.counters[NLC_INV_SDF_CNT], s_red[6]);
+            if (s_red[7]) atomicMax(&a.counters[NLC_GUARD], 1);
+            if (s_dred[0] != 0.0) atomicAdd(&a.dcounters[NLD_INV_D2], s_dred[0]);
+            if (s_dred[1] != 0.0) atomicAdd(&a.dcounters[NLD_INV_D2CNT], s_dred[1]);
+            __threadfence();
+            if (atomicAdd(&a.counters[NLC_TICKET], 1) == (int)gridDim.x - 1) s_last = 1;
+        }
+    }
+    __syncthreads();
+    const int off = s_base + s_excl[rl];
+    if (r < a.N && j == 0) { a.samp_count[r] = cnt; fa.samp_off_out[r] = off; }
+    const int cap = a.capacity;
+    if (!s_ovf) {
+        const int n = s_cnt[rl];
+        for (int q = j; q < n; q += SP_LPR) {
+            const int p = off + q, bq = rl * SF_CAP + q;
+            if (p < cap) { a.s_vox[p] = b_vox[bq]; a.s_depth[p] = b_depth[bq]; a.s_dist[p] = b_dist[bq]; a.s_ray[p] = r; }
+        }
+    } else if (live && !guard) {                                  // a ray outgrew the LDS buffer: walk again, straight to memory
+        auto emit = [&](int s_, int vox, float depth, float dist) {
+            const int p = off + s_;
+            if (p < cap) { a.s_vox[p] = vox; a.s_depth[p] = depth; a.s_dist[p] = dist < 0.0f ? 0.0f : dist; a.s_ray[p] = r; }
+        };
+        (void)walk(emit);
+    }
+    if (s_last && threadIdx.x == 0) {                              // every workgroup's sums and the total are in: the loss normalisers
+        __threadfence();
+        loss_finalize_one(a.counters, fa.ls, fa.fs_weight, fa.sdf_weight, a.tau, a.max_depth, a.capacity);
+    }
+}
+
 template <bool EMIT>
 __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample(SampleArgs a)
 {
@@ -1155,6 +1353,48 @@ int nl_sample_rays(int emit, int N, const int* hit_idx, const float* hit_t0, con
         if (emit) hipLaunchKernelGGL(k_sample<true>, dim3(nl_div_up(N, NL_GEO_THREADS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);
         else      hipLaunchKernelGGL(k_sample<false>, dim3(nl_div_up(N, NL_GEO_THREADS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);
     }
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+int nl_scan_samples_finalize(const int* samp_count, int* samp_off, int N, int* counters, void* loss_scalars, float fs_weight, float sdf_weight,
+                             float tau, float max_depth, int capacity, int* workspace, void* stream);
+
+/* count pass + sample-offset scan + loss normalisers + emit pass as ONE launch (k_sample_fused) up to 8192 rays; beyond, the four
+ * launches.  state: >= 8 * ceil(N / 32) bytes of device memory that only this function touches (never cleared: epoch-tagged);
+ * epoch: a number that differs from call to call (30 bits used). */
+int nl_sample_rays_fused(int N, const int* hit_idx, const float* hit_t0, const float* hit_t1, const int* hit_count,
+                         const int* hit_rank, const int* ray_of_rank, const float* cos_gt, const float* gt_dist,
+                         float step_size, float tau, float max_depth, unsigned seed, int use_hash_noise, int tail_always, int ray_id_base,
+                         const unsigned* seed_mix, int* counters, int* samp_count, int* samp_off, int capacity,
+                         int* s_vox, float* s_depth, float* s_dist, int* s_ray, void* loss_scalars, float fs_weight, float sdf_weight,
+                         void* state, unsigned epoch, int* scan_ws, void* stream)
+{
+    if (N <= 0 || !hit_idx || !hit_t0 || !hit_t1 || !hit_count || !hit_rank || !ray_of_rank || !cos_gt || !gt_dist || !counters || !samp_count ||
+        !samp_off || !s_vox || !s_depth || !s_dist || !s_ray || !loss_scalars || !scan_ws) return NL_ERR_INVALID_ARG;
+    if (N > 8192 || !state) {
+        int rc = nl_sample_rays(0, N, hit_idx, hit_t0, hit_t1, hit_count, hit_rank, ray_of_rank, cos_gt, gt_dist, step_size, tau, max_depth, seed,
+                                use_hash_noise, tail_always, ray_id_base, seed_mix, nullptr, counters, samp_count, nullptr, capacity, nullptr, nullptr,
+                                nullptr, nullptr, stream);
+        if (rc != NL_OK) return rc;
+        rc = nl_scan_samples_finalize(samp_count, samp_off, N, counters, loss_scalars, fs_weight, sdf_weight, tau, max_depth, capacity, scan_ws, stream);
+        if (rc != NL_OK) return rc;
+        return nl_sample_rays(1, N, hit_idx, hit_t0, hit_t1, hit_count, hit_rank, ray_of_rank, cos_gt, gt_dist, step_size, tau, max_depth, seed,
+                              use_hash_noise, tail_always, ray_id_base, seed_mix, nullptr, counters, samp_count, samp_off, capacity, s_vox, s_depth,
+                              s_dist, s_ray, stream);
+    }
+    SampleFusedArgs fa;
+    SampleArgs& a = fa.s;
+    a.N = N; a.hit_idx = hit_idx; a.hit_t0 = hit_t0; a.hit_t1 = hit_t1; a.hit_count = hit_count; a.hit_rank = hit_rank;
+    a.ray_of_rank = ray_of_rank; a.cos_gt = cos_gt; a.gt_dist = gt_dist; a.step_size = step_size; a.tau = tau; a.max_depth = max_depth;
+    a.seed = seed; a.use_hash_noise = use_hash_noise; a.tail_always = tail_always; a.ray_id_base = ray_id_base;
+    a.seed_mix = seed_mix; a.row_first = nullptr;
+    a.counters = counters; a.dcounters = (double*)(counters + NL_CNT_INTS);
+    a.samp_count = samp_count; a.samp_off = samp_off; a.capacity = capacity;
+    a.s_vox = s_vox; a.s_depth = s_depth; a.s_dist = s_dist; a.s_ray = s_ray;
+    fa.samp_off_out = samp_off; fa.wg_state = (unsigned long long*)state; fa.epoch = epoch & 0x3FFFFFFFu;
+    fa.ls = (NlLossScalars*)loss_scalars; fa.fs_weight = fs_weight; fa.sdf_weight = sdf_weight;
+    hipLaunchKernelGGL(k_sample_fused, dim3(nl_div_up(N, SP_RAYS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, fa);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

@@ -564,6 +564,59 @@ def test_fused_scan_launches_equal_the_separate_calls(nl):
             assert np.array_equal(x, y), (n, k)
 
 
+@pytest.mark.parametrize("step_size,cap", [(0.1, 64), (0.01, 640)])
+def test_one_launch_sampler_equals_the_four_launch_sequence(nl, step_size, cap):
+    """nl_sample_rays_fused (walk once, samples parked in LDS, offsets by decoupled look-back, loss normalisers by the last workgroup)
+    against count pass + scan + finalize + emit pass: same counts, offsets, samples, counters and loss scalars - also when rays
+    outgrow the LDS buffer (step 0.01: several hundred samples per ray, second walk straight to memory), over repeated calls (the
+    look-back words are never cleared, only epoch-tagged) and with the per-iteration jitter word."""
+    P, ops, L = nl["P"], nl["ops"], nl["L"]
+    lib = L.lib()
+    sc = H.build_oracle_scene(16, 256, 3)
+    ms = sc["ms"]
+    pose = np.array([2000.01, 1999.98, 2000.0, 0.003, -0.002, 0.008], np.float32)
+    fr = O.select_rays(sc["points"], sc["cos"], pose, np.ones(len(sc["points"]), bool))
+    n = len(fr.rays_d)
+    assert 2048 < n <= 8192
+    m = P.MapDevice(ms.centres, ms.structure, ms.vertex_idx, ms.id2row, ms.emb, ms.voxel_size)
+    mixw = torch.tensor([5], dtype=torch.int32, device="cuda")
+    res = {}
+    for kind in ("four", "fused", "fused_again"):
+        if kind != "fused_again":
+            eng = P.SdfEngine(max_rays=n, samples_per_ray_cap=cap)
+            eng.set_rays(fr.rays_d, fr.points, fr.cos); eng.set_poses(pose[None], [1])
+        c0 = eng.counters
+        c0.zero_()
+        ops.ray_intersect(n, eng.rays_d_sensor, eng.points_gt, eng.cos_gt, eng.frame_id, eng.poses12, m.blk_hdr, m.blk_ids, m.root_side, m.voxel_size,
+                          50.0, eng.rays_d_world, eng.gt_dist, eng.hit_idx, eng.hit_t0, eng.hit_t1, eng.hit_count, c0, eng.ray_of_rank)
+        ops.scan_hit_rays(eng.hit_count, eng.hit_rank, eng.ray_of_rank, n, c0[L.NLC_R:], c0[L.NLC_R_GLOBAL:], eng.scan_ws)
+        common = (L.ptr(eng.hit_idx), L.ptr(eng.hit_t0), L.ptr(eng.hit_t1), L.ptr(eng.hit_count), L.ptr(eng.hit_rank), L.ptr(eng.ray_of_rank),
+                  L.ptr(eng.cos_gt), L.ptr(eng.gt_dist), float(step_size), 0.3, 50.0, 77, 1, 0, 0, L.ptr(mixw))
+        if kind == "four":
+            L.check(lib.nl_sample_rays(0, n, *common, None, L.ptr(c0), L.ptr(eng.samp_count), None, eng.P_cap, None, None, None, None, L.stream_ptr()), "count")
+            L.check(lib.nl_scan_samples_finalize(L.ptr(eng.samp_count), L.ptr(eng.samp_off), n, L.ptr(c0), L.ptr(eng.loss_scalars), 1.0, 2.0, 0.3, 50.0,
+                                                 eng.P_cap, L.ptr(eng.scan_ws), L.stream_ptr()), "scan")
+            L.check(lib.nl_sample_rays(1, n, *common, None, L.ptr(c0), L.ptr(eng.samp_count), L.ptr(eng.samp_off), eng.P_cap, L.ptr(eng.s_vox),
+                                       L.ptr(eng.s_depth), L.ptr(eng.s_dist), L.ptr(eng.s_ray), L.stream_ptr()), "emit")
+        else:
+            L.check(lib.nl_sample_rays_fused(n, *common, L.ptr(c0), L.ptr(eng.samp_count), L.ptr(eng.samp_off), eng.P_cap, L.ptr(eng.s_vox),
+                                             L.ptr(eng.s_depth), L.ptr(eng.s_dist), L.ptr(eng.s_ray), L.ptr(eng.loss_scalars), 1.0, 2.0,
+                                             L.ptr(eng.sample_state), 41 if kind == "fused" else 42, L.ptr(eng.scan_ws), L.stream_ptr()), "fused")
+        torch.cuda.synchronize()
+        cnt = c0.cpu().numpy().copy(); cnt[L.NLC_TICKET] = 0
+        Pn = int(cnt[L.NLC_P])
+        res[kind] = dict(counters=cnt, ls=eng.loss_scalars.cpu().numpy().copy(), samp_count=eng.samp_count[:n].cpu().numpy().copy(),
+                         samp_off=eng.samp_off[:n].cpu().numpy().copy(), **{k: getattr(eng, k)[:min(Pn, eng.P_cap)].cpu().numpy().copy()
+                                                                           for k in ("s_vox", "s_depth", "s_dist", "s_ray")})
+    assert res["four"]["counters"][L.NLC_P] > 20 * 2048 * (10 if step_size < 0.05 else 1) // 10
+    assert res["four"]["counters"][L.NLC_OVERFLOW] == 0
+    if step_size < 0.05:
+        assert res["four"]["counters"][L.NLC_SMAX] > 96                                 # the LDS buffer really overflowed
+    for kind in ("fused", "fused_again"):
+        for k in res["four"]:
+            assert np.array_equal(res["four"][k], res[kind][k]), (kind, k)
+
+
 def test_counter_hand_over_between_bound_iterations(nl):
     """run_bound(): a whole iteration ends with its counter block copied to counters_copy and the live block cleared (the next
     iteration then has no memset launch); stats() reads the copy and equals the stage-wise iteration's; a forward-only call in
@@ -585,6 +638,7 @@ def test_counter_hand_over_between_bound_iterations(nl):
     eng2.bind(m2, dec2, cfg, train_decoder=True, want_pose_grad=False, update_pose=False)      # fixed pose: R and P stay what they are
     eng2.run_bound()
     st = eng2.stats()
+    st["ints"][nl["L"].NLC_TICKET] = 0                                                # (the one-launch sampler's workgroup ticket)
     assert np.array_equal(st["ints"], ref["ints"]) and np.allclose(st["dbl"], ref["dbl"], rtol=1e-12)
     assert int(eng2.counters.abs().sum()) == 0 and eng2._desc.counters_clean == 1     # handed over: live block cleared
     eng2.run_bound()                                                                  # second whole iteration: no memset, still consistent
