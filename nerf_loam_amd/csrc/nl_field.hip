@@ -136,6 +136,9 @@ __global__ __launch_bounds__(NL_FIELD_THREADS) void k_gather_points(int P, const
 #define TB_PROBES 16
 #define TB_GROUPS (NL_FIELD_THREADS / 8)                 // 8-lane groups per workgroup
 #define TB_MIN_SPAN 256                                 // samples per workgroup: at least this many (aggregation), else P / grid
+#define TB_SMALL_P 524288                               // below: the kernel is a latency chain over a group's samples, not atomics-bound:
+#define TB_MIN_SPAN_SMALL 64                            // shorter spans (2 samples per 8-lane group instead of 8; 1 measured worse).
+                                                        // 2048 rays + embeddings: iteration 0.217 -> 0.184 ms; 4096 x 4: 0.371 -> 0.341
 
 __device__ __forceinline__ int tb_insert(int* s_key, int key)
 {
@@ -171,7 +174,8 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
     // the P samples are split EVENLY over the workgroups (one span each, one table flush each): with fixed-size chunks
     // P = 1.05 x grid x chunk would send 5 % of the workgroups through a second chunk and double the kernel's time
     int per_group = (P + (int)gridDim.x * TB_GROUPS - 1) / ((int)gridDim.x * TB_GROUPS);
-    if (per_group * TB_GROUPS < TB_MIN_SPAN) per_group = TB_MIN_SPAN / TB_GROUPS;
+    const int min_span = P < TB_SMALL_P ? TB_MIN_SPAN_SMALL : TB_MIN_SPAN;
+    if (per_group * TB_GROUPS < min_span) per_group = min_span / TB_GROUPS;
     const int span = per_group * TB_GROUPS;
     const int nchunks = (P + span - 1) / span;
     // pose partials (corner-0 lane).  The sums cancel heavily (rays in all directions), so they are carried in fp64: fp32 over
