@@ -156,6 +156,8 @@ def lib():
                 raise NerfLoamHipError("NL_GEMM_MODE must be 0 .. 4")
         if os.environ.get("NL_SAMPLER_MODE"):
             L.nl_geometry_set_sampler_mode(int(os.environ["NL_SAMPLER_MODE"]))
+        if os.environ.get("NL_LANES_PER_RAY"):              # A/B switch for measurements: lanes per ray of the work-list intersect
+            L.nl_geometry_set_lanes_per_ray(int(os.environ["NL_LANES_PER_RAY"]))
         if os.environ.get("NL_WGRAD2_MODE"):                # A/B switch for measurements (default: the library's own default)
             if L.nl_decoder_set_wgrad2_mode(int(os.environ["NL_WGRAD2_MODE"])) != 0:
                 raise NerfLoamHipError("NL_WGRAD2_MODE must be 0 or 1")

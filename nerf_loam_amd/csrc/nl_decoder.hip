@@ -928,11 +928,11 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
         prefetch(tile + 2 * gridDim.x);
         produce(par, 1);
         consume(par, 0);
-        __syncthreads();
+        nl_lds_barrier();
         // step B: planes of the next tile's first half (its inputs were published by the barrier above); MFMAs of this tile's second half
         if (tile + gridDim.x < ntiles) produce(par ^ 1, 0);
         consume(par, 1);
-        __syncthreads();
+        nl_lds_barrier();
     }
     float* base = partials + (size_t)blockIdx.x * NL_DEC_PARAMS;
 #pragma unroll
