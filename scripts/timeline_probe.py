@@ -2,8 +2,9 @@
 of it, from a rocprofv3 --kernel-trace of two loops -
    section 1: the pose-refinement step of tracking (2048 rays, decoder + embeddings frozen, eager launches),
    section 2: the same step replayed as a hipGraph,
-   section 3: one rank's share of an 8-GPU mapping iteration (16 384 interleaved rays, trainable decoder).
-Sections are separated in the trace by runs of k_pose_matrix launches (2, 3, 4 of them), which occur nowhere else in the loops.
+   section 3: one rank's share of an 8-GPU mapping iteration (16 384 interleaved rays, trainable decoder),
+   sections 4, 5: sections 1 and 3 through one C call per iteration (nl_iteration, what the API loops use: fused launches).
+Sections are separated in the trace by runs of k_pose_matrix launches (2, 3, ... of them), which occur nowhere else in the loops.
 
     run   : the workload (under rocprofv3; also prints the untraced-equivalent wall time per step measured by the host)
     parse : python scripts/timeline_probe.py parse <kernel_trace.csv>
@@ -46,7 +47,9 @@ def parse(path, out=sys.stdout):
         if cur is not None:
             cur.append(r)
     titles = {1: "pose-refinement step, 2048 rays, eager", 2: "pose-refinement step, 2048 rays, hipGraph replay",
-              3: "rank share of an 8-GPU mapping iteration: 16 384 interleaved rays, trainable decoder, eager"}
+              3: "rank share of an 8-GPU mapping iteration: 16 384 interleaved rays, trainable decoder, eager",
+              4: "pose-refinement step, 2048 rays, one C call per iteration (nl_iteration: fused launches)",
+              5: "rank share of an 8-GPU mapping iteration, one C call per iteration"}
     for sid in sorted(sections):
         ks = sections[sid]
         anchors = [i for i, r in enumerate(ks) if ANCHOR in r[0]]
@@ -136,7 +139,15 @@ def run():
         e2.optimiser_step(w["map"], w["dec"], cfg2)
     shard(); mark(4)
     print(f"section 3 host-timed: {timed(shard, 40):.4f} ms/step", flush=True)
-    mark(5)
+    # sections 4 + 5: the same two steps through ONE C call per iteration (nl_iteration: the fused launches)
+    eng.graph = None
+    eng.bind(w["map"], w["dec"], cfg, **fb, **op)
+    eng.run_bound(); mark(5)
+    print(f"section 4 host-timed: {timed(eng.run_bound, 100):.4f} ms/step", flush=True)
+    e2.bind(w["map"], w["dec"], cfg2, train_decoder=True)
+    e2.run_bound(); mark(6)
+    print(f"section 5 host-timed: {timed(e2.run_bound, 40):.4f} ms/step", flush=True)
+    mark(7)
 
 
 if __name__ == "__main__":
