@@ -31,7 +31,6 @@
 #define LDX 17
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -841,16 +840,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const float h0 = fmaxf(c0[2 * q] + b1c, 0.f), h1 = fmaxf(c0[2 * q + 1] + b1c, 0.f);
-            // (VALU diet of nl_decoder_chain.hip: the packed word of a plane, shifted / masked, IS the pair of truncated values;
-            //  the two residuals are one packed subtraction)
-            f32x2 v; v.x = h0 * ds[D32_RR(2 * q)]; v.y = h1 * ds[D32_RR(2 * q + 1)];
-            hi[q] = pack_hi16(v.x, v.y);
-            f32x2 t; t.x = __uint_as_float(hi[q] << 16); t.y = __uint_as_float(hi[q] & 0xFFFF0000u);
-            const f32x2 r = v - t;
-            mid[q] = pack_hi16(r.x, r.y);
-            f32x2 t2; t2.x = __uint_as_float(mid[q] << 16); t2.y = __uint_as_float(mid[q] & 0xFFFF0000u);
-            const f32x2 r2 = r - t2;
-            lo[q] = pack_hi16(r2.x, r2.y);
+            const float v0 = h0 * ds[D32_RR(2 * q)], v1 = h1 * ds[D32_RR(2 * q + 1)];
+            hi[q] = pack_hi16(v0, v1);
+            const float r0 = v0 - trunc_bf16(v0), r1 = v1 - trunc_bf16(v1);
+            mid[q] = pack_hi16(r0, r1);
+            const float s0 = r0 - trunc_bf16(r0), s1 = r1 - trunc_bf16(r1);
+            lo[q] = pack_hi16(s0, s1);
         }
         if (NAT) {                                       // slot = sample row: rows 8 q + 4 lh + (0..3) of this lane -> 8-byte pieces
             unsigned char* dst = sB + opaque(col * WX_STRIDE + 8 * lh + 64 * sub);
