@@ -135,15 +135,16 @@ int nl_loss_finalize(int* counters, void* loss_scalars, float fs_weight, float s
                      int capacity, void* stream);
 /* nl_sample_rays(count) + nl_exclusive_scan_i32 + nl_loss_finalize + nl_sample_rays(emit) as ONE launch up to 8192 rays (single
  * GPU: no row_first table): every workgroup walks its rays once, parks the samples in LDS, obtains its offset by decoupled
- * look-back over the workgroups before it (state: >= 8 * ceil(N / 32) bytes only this function touches, zero-initialised once;
- * epoch: differs from call to call) and the last workgroup computes the loss normalisers.  Same samples at the same places.
+ * look-back over the workgroups before it (state: >= 8 * (1 + ceil(N / 32)) bytes only this function touches, zero-initialised
+ * once: word 0 counts the launches on the device, so a captured launch can be replayed) and the last workgroup computes the loss
+ * normalisers.  Same samples at the same places.
  * Beyond 8192 rays or with state == NULL: the four launches. */
 int nl_sample_rays_fused(int N, const int* hit_idx, const float* hit_t0, const float* hit_t1, const int* hit_count,
                          const int* hit_rank, const int* ray_of_rank, const float* cos_gt, const float* gt_dist,
                          float step_size, float truncation, float max_depth, unsigned noise_seed, int use_hash_noise, int tail_always,
                          int ray_id_base, const unsigned* seed_mix, int* counters, int* samp_count, int* samp_off, int capacity,
                          int* s_vox, float* s_depth, float* s_dist, int* s_ray, void* loss_scalars, float fs_weight, float sdf_weight,
-                         void* state, unsigned epoch, int* scan_ws, void* stream);
+                         void* state, int* scan_ws, void* stream);
 /* nl_exclusive_scan_i32(samp_count -> samp_off, total -> counters[NLC_P]) + nl_loss_finalize: one launch up to 4096 rays, the same
  * launches as the two calls beyond.  workspace as for nl_exclusive_scan_i32. */
 int nl_scan_samples_finalize(const int* samp_count, int* samp_off, int N, int* counters, void* loss_scalars, float fs_weight, float sdf_weight,
@@ -293,9 +294,9 @@ typedef struct NlIterDesc {
     /* optional counter hand-over: with counters_copy set, a stages == 3 call ends by copying the counter block there and clearing
      * it; the host sets counters_clean = 1 afterwards and the next call skips its memset launch (0: the block is cleared first) */
     int* counters_copy; int counters_clean;
-    /* optional state of the one-launch sampler (nl_sample_rays_fused): >= 8 * ceil(N / 32) bytes, zero-initialised once, and a
-     * number that differs from call to call (NULL: the four-launch sampler sequence) */
-    void* sample_state; unsigned sample_epoch;
+    /* optional state of the one-launch sampler (nl_sample_rays_fused): >= 8 * (1 + ceil(N / 32)) bytes, zero-initialised once
+     * (NULL: the four-launch sampler sequence) */
+    void* sample_state;
 } NlIterDesc;
 int nl_iteration(const NlIterDesc* desc, int stages, void* stream);
 

@@ -55,7 +55,7 @@ def _iter_desc_fields():
     f += [("noise_seed", U_)] + [(n, I_) for n in ("use_hash_noise", "tail_always", "ray_id_base", "fresh_noise")]
     f += [(n, I_) for n in ("train_decoder", "want_emb_grad", "want_pose_grad", "update_emb", "update_decoder", "update_pose", "skip_mode")]
     f += [("counters_copy", P_), ("counters_clean", I_)]
-    f += [("sample_state", P_), ("sample_epoch", U_)]
+    f += [("sample_state", P_)]
     return f
 
 
@@ -82,7 +82,7 @@ _SIGS = {
     "nl_dist_row_first": ([_P, _P, _P, _P, _P, _I, _P], _I),
     "nl_loss_finalize": ([_P, _P, _F, _F, _F, _F, _I, _P], _I),
     "nl_scan_samples_finalize": ([_P, _P, _I, _P, _P, _F, _F, _F, _F, _I, _P, _P], _I),
-    "nl_sample_rays_fused": ([_I] + [_P] * 8 + [_F, _F, _F, _U, _I, _I, _I] + [_P] * 4 + [_I] + [_P] * 5 + [_F, _F, _P, _U, _P, _P], _I),
+    "nl_sample_rays_fused": ([_I] + [_P] * 8 + [_F, _F, _F, _U, _I, _I, _I] + [_P] * 4 + [_I] + [_P] * 5 + [_F, _F, _P, _P, _P], _I),
     "nl_ray_intersect_scan": ([_I] + [_P] * 7 + [_I, _F, _F] + [_P] * 13, _I),
     "nl_gather_trilinear": ([_P] * 7 + [_I] + [_P] * 3 + [_F, _P, _I, _P], _I),
     "nl_gather_points": ([_I] + [_P] * 5 + [_F, _P, _P], _I),

@@ -773,8 +773,7 @@ __device__ __forceinline__ void loss_finalize_one(int* __restrict__ counters, Nl
 struct SampleFusedArgs {
     SampleArgs s;
     int* samp_off_out;
-    unsigned long long* wg_state;   // [gridDim.x]: epoch << 34 | status << 32 | value
-    unsigned epoch;
+    unsigned long long* wg_state;   // [0]: the call counter (epoch of the next launch - 1); [1 + b]: epoch << 34 | status << 32 | value
     NlLossScalars* ls; float fs_weight, sdf_weight;
 };
 __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample_fused(SampleFusedArgs fa)
@@ -789,6 +788,10 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample_fused(SampleFusedArgs
     __shared__ int b_vox[SP_RAYS * SF_CAP];
     __shared__ float b_depth[SP_RAYS * SF_CAP], b_dist[SP_RAYS * SF_CAP];
     __shared__ int s_base, s_ovf, s_last;
+    // the launch's epoch lives in device memory and is advanced by the last workgroup to finish (after every workgroup has read
+    // it): nothing to pass or clear from the host, and a captured launch can be replayed
+    const unsigned epoch = ((unsigned)*reinterpret_cast<volatile unsigned long long*>(fa.wg_state) + 1u) & 0x3FFFFFFFu;
+    unsigned long long* const wg_words = fa.wg_state + 1;
     if (threadIdx.x < 8) s_red[threadIdx.x] = 0;
     if (threadIdx.x < 2) s_dred[threadIdx.x] = 0.0;
     if (threadIdx.x == 0) { s_ovf = 0; s_last = 0; }
@@ -902,18 +905,18 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample_fused(SampleFusedArgs
         for (int o2 = 1; o2 < 64; o2 <<= 1) { const int u = __shfl_up(inc, o2); if (t >= o2) inc += u; }
         if (t < SP_RAYS) s_excl[t] = inc - v;
         const int agg = __shfl(inc, 63);
-        const unsigned long long tag = (unsigned long long)fa.epoch << 34;
+        const unsigned long long tag = (unsigned long long)epoch << 34;
         const int b = blockIdx.x;
         int base = 0;
         if (b > 0) {
             // look-back, 64 predecessors per step (one per lane): a lane spins until its word carries this call's epoch; the window is
             // summed up to and including the nearest published PREFIX, or entirely (all aggregates) and the next window follows
-            if (t == 0) __hip_atomic_store(&fa.wg_state[b], tag | (SF_STATUS_AGG << 32) | (unsigned)agg, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == 0) __hip_atomic_store(&wg_words[b], tag | (SF_STATUS_AGG << 32) | (unsigned)agg, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             for (int hi = b - 1; hi >= 0; hi -= 64) {
                 const int i = hi - t;
                 unsigned long long w = tag | (SF_STATUS_AGG << 32);                     // lanes before workgroup 0: empty aggregates
                 if (i >= 0) {
-                    do { w = __hip_atomic_load(&fa.wg_state[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while ((w >> 34) != fa.epoch || ((w >> 32) & 3ull) == 0ull);
+                    do { w = __hip_atomic_load(&wg_words[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while ((w >> 34) != epoch || ((w >> 32) & 3ull) == 0ull);
                 }
                 const unsigned long long pm = __ballot(((w >> 32) & 3ull) == SF_STATUS_PREFIX);
                 const int first = pm ? __ffsll((long long)pm) - 1 : 64;                   // nearest predecessor with a prefix (lane index)
@@ -925,7 +928,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample_fused(SampleFusedArgs
             }
         }
         if (t == 0) {
-            __hip_atomic_store(&fa.wg_state[b], tag | (SF_STATUS_PREFIX << 32) | (unsigned)(base + agg), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&wg_words[b], tag | (SF_STATUS_PREFIX << 32) | (unsigned)(base + agg), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             s_base = base;
             if (b == (int)gridDim.x - 1) a.counters[NLC_P] = base + agg;
             if (s_red[0] > 0) atomicMax(&a.counters[NLC_SMAX], s_red[0]);
@@ -961,6 +964,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample_fused(SampleFusedArgs
     }
     if (s_last && threadIdx.x == 0) {                              // every workgroup's sums and the total are in: the loss normalisers
         __threadfence();
+        *reinterpret_cast<volatile unsigned long long*>(fa.wg_state) = (unsigned long long)epoch;   // the next launch's epoch differs
         loss_finalize_one(a.counters, fa.ls, fa.fs_weight, fa.sdf_weight, a.tau, a.max_depth, a.capacity);
     }
 }
@@ -1371,14 +1375,14 @@ int nl_scan_samples_finalize(const int* samp_count, int* samp_off, int N, int* c
                              float tau, float max_depth, int capacity, int* workspace, void* stream);
 
 /* count pass + sample-offset scan + loss normalisers + emit pass as ONE launch (k_sample_fused) up to 8192 rays; beyond, the four
- * launches.  state: >= 8 * ceil(N / 32) bytes of device memory that only this function touches (never cleared: epoch-tagged);
- * epoch: a number that differs from call to call (30 bits used). */
+ * launches.  state: >= 8 * (1 + ceil(N / 32)) bytes of device memory that only this function touches, zero-initialised once
+ * (word 0 counts the launches: the look-back words are tagged with it and never cleared). */
 int nl_sample_rays_fused(int N, const int* hit_idx, const float* hit_t0, const float* hit_t1, const int* hit_count,
                          const int* hit_rank, const int* ray_of_rank, const float* cos_gt, const float* gt_dist,
                          float step_size, float tau, float max_depth, unsigned seed, int use_hash_noise, int tail_always, int ray_id_base,
                          const unsigned* seed_mix, int* counters, int* samp_count, int* samp_off, int capacity,
                          int* s_vox, float* s_depth, float* s_dist, int* s_ray, void* loss_scalars, float fs_weight, float sdf_weight,
-                         void* state, unsigned epoch, int* scan_ws, void* stream)
+                         void* state, int* scan_ws, void* stream)
 {
     if (N <= 0 || !hit_idx || !hit_t0 || !hit_t1 || !hit_count || !hit_rank || !ray_of_rank || !cos_gt || !gt_dist || !counters || !samp_count ||
         !samp_off || !s_vox || !s_depth || !s_dist || !s_ray || !loss_scalars || !scan_ws) return NL_ERR_INVALID_ARG;
@@ -1402,7 +1406,7 @@ int nl_sample_rays_fused(int N, const int* hit_idx, const float* hit_t0, const f
     a.counters = counters; a.dcounters = (double*)(counters + NL_CNT_INTS);
     a.samp_count = samp_count; a.samp_off = samp_off; a.capacity = capacity;
     a.s_vox = s_vox; a.s_depth = s_depth; a.s_dist = s_dist; a.s_ray = s_ray;
-    fa.samp_off_out = samp_off; fa.wg_state = (unsigned long long*)state; fa.epoch = epoch & 0x3FFFFFFFu;
+    fa.samp_off_out = samp_off; fa.wg_state = (unsigned long long*)state;
     fa.ls = (NlLossScalars*)loss_scalars; fa.fs_weight = fs_weight; fa.sdf_weight = sdf_weight;
     hipLaunchKernelGGL(k_sample_fused, dim3(nl_div_up(N, SP_RAYS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, fa);
     NL_LAUNCH_CHECK();

@@ -31,7 +31,7 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
         NL_TRY(nl_sample_rays_fused(d->N, d->hit_idx, d->hit_t0, d->hit_t1, d->hit_count, d->hit_rank, d->ray_of_rank, d->cos_gt, d->gt_dist,
                                     d->step_size, d->truncation, d->max_distance, d->noise_seed, d->use_hash_noise, d->tail_always, d->ray_id_base, mix,
                                     c, d->samp_count, d->samp_off, d->P_cap, d->s_vox, d->s_depth, d->s_dist, d->s_ray, d->loss_scalars, d->fs_weight,
-                                    d->sdf_weight, d->sample_state, d->sample_epoch, d->scan_ws, stream));
+                                    d->sdf_weight, d->sample_state, d->scan_ws, stream));
         NL_TRY(nl_gather_trilinear(d->loss_scalars, d->s_vox, d->s_depth, d->s_ray, d->rays_d_world, d->frame_id, d->poses12, d->F, d->centres,
                                    d->vertex_rows, d->emb, d->voxel_size, d->X, d->field_blocks, stream));
         NL_TRY(nl_decoder_fwd_bwd(d->loss_scalars, d->X, d->dec_params, d->dec_ws, d->s_ray, d->s_depth, d->cos_gt, d->gt_dist, d->sdf, d->dsdf,

@@ -227,7 +227,7 @@ class SdfEngine:
         self.counters = self._counters2[:L.NL_CNT_BYTES // 4]           # the live block the kernels count into
         self.counters_copy = self._counters2[L.NL_CNT_BYTES // 4:]      # run_bound(): the finished iteration's block (live one cleared)
         self._stats_from_copy = False
-        self.sample_state = torch.zeros(max(1, (N + 31) // 32), dtype=torch.int64, device=d)   # look-back words of the one-launch sampler
+        self.sample_state = torch.zeros(1 + max(1, (N + 31) // 32), dtype=torch.int64, device=d)   # launch counter + look-back words of the one-launch sampler
         self.loss_scalars = torch.zeros(L.NL_LOSS_SCALARS_BYTES // 4, dtype=I32, device=d)
         # decoder partial slabs (one per persistent workgroup)
         self.n_slabs = int(L.lib().nl_decoder_grid_hint())
@@ -532,7 +532,6 @@ class SdfEngine:
         """one iteration of the bound configuration: stages bit 0 = forward + backward, bit 1 = optimiser step"""
         d = self._desc
         d.N, d.F = self.N, self.F
-        d.sample_epoch = (d.sample_epoch + 1) & 0x3FFFFFFF or 1           # never 0: the look-back words start zeroed
         L.check(L.lib().nl_iteration(ctypes.byref(d), int(stages), L.stream_ptr()), "nl_iteration")
         # a whole iteration ends with its counter block handed to counters_copy and the live block cleared for the next one
         # (no memset launch then); a forward-only call leaves the block in place

@@ -601,7 +601,7 @@ def test_one_launch_sampler_equals_the_four_launch_sequence(nl, step_size, cap):
         else:
             L.check(lib.nl_sample_rays_fused(n, *common, L.ptr(c0), L.ptr(eng.samp_count), L.ptr(eng.samp_off), eng.P_cap, L.ptr(eng.s_vox),
                                              L.ptr(eng.s_depth), L.ptr(eng.s_dist), L.ptr(eng.s_ray), L.ptr(eng.loss_scalars), 1.0, 2.0,
-                                             L.ptr(eng.sample_state), 41 if kind == "fused" else 42, L.ptr(eng.scan_ws), L.stream_ptr()), "fused")
+                                             L.ptr(eng.sample_state), L.ptr(eng.scan_ws), L.stream_ptr()), "fused")
         torch.cuda.synchronize()
         cnt = c0.cpu().numpy().copy(); cnt[L.NLC_TICKET] = 0
         Pn = int(cnt[L.NLC_P])
