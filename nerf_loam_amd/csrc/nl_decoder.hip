@@ -387,8 +387,6 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 #pragma unroll
         for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) accW1[t][r] = 0.f;
     }
-    for (int i = tid; i < NL_W * NL_C; i += DEC_THREADS) sW1[i] = a.params[NL_OFF_W1 + i];
-
     // software prefetch of the next tile's inputs: the X slice (2 floats per thread) and the loss inputs of row `lane`
     // (every wave keeps its own copy: the loss gradient is recomputed per wave, which removes a workgroup barrier)
     const int xe = tid * 2, xi = xe >> 4, xc = xe & 15;
@@ -406,6 +404,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         }
     };
     prefetch(blockIdx.x);
+    // (W1 -> LDS under the first tile's input loads: the loss inputs are a two-level dependent chain; at the live shapes a workgroup
+    //  sees two tiles in all and the kernel's start is on the critical path of the step)
+    for (int i = tid; i < NL_W * NL_C; i += DEC_THREADS) sW1[i] = a.params[NL_OFF_W1 + i];
     {   // phase A of the first tile: X -> LDS buffer 0
         float* sX = lds + S_X;
         sX[xi * LDX + xc] = xv.x; sX[xi * LDX + xc + 1] = xv.y;
