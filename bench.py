@@ -76,7 +76,9 @@ def pmc_traffic(kernel):
     if not files:
         return None
     try:
-        return float(json.load(open(files[-1]))[kernel]["hbm_bytes_per_launch"])
+        table = json.load(open(files[-1]))
+        key = next(k for k in table if k == kernel or k.startswith(kernel.rstrip(">") + ","))      # (template arguments may follow)
+        return float(table[key]["hbm_bytes_per_launch"])
     except Exception:
         return None
 
