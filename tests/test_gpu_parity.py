@@ -761,6 +761,51 @@ def test_hipgraph_replay_matches_eager(nl, golden_dir):
     assert (outs["graph"][2] != outs["eager"][2]).mean() < 5e-3
 
 
+def test_captured_one_call_iteration_replays(nl, golden_dir):
+    """nl_iteration (fused launches: the one-launch sampler's look-back words are tagged with a launch counter kept in device
+    memory, the counter block is handed over by the optimiser's last step) captured into a hipGraph and replayed: the same
+    trajectory as calling it eagerly - nothing in the sequence depends on a host-side per-call argument."""
+    g = np.load(os.path.join(golden_dir, "map_1f_3it.npz"))
+    outs = {}
+    for mode in ("eager", "graph"):
+        sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]))
+        sc["ms"].id2row = g["id_table"].copy()
+        masks = H.unpack_masks(g["masks"], len(sc["points"]))
+        dec_np = O.decoder_init(int(g["seed"]))
+        m, dec, eng = make_engine(nl, sc, dec_np, int(masks[0][0].sum()))
+        cfgP = nl["P"].IterConfig(step_size=float(g["step_size"]))
+        fr = O.select_rays(sc["points"], sc["cos"], g["poses0"][0].copy(), masks[0][0])
+        eng.set_rays(fr.rays_d, fr.points, fr.cos); eng.set_poses(fr.pose[None], [1])
+        eng.begin_call(m, dec)
+        eng.bind(m, dec, cfgP, train_decoder=True)
+        eng.run_bound()                                                           # iteration 1 (eager in both modes; leaves the counter block handed over)
+        if mode == "graph":
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                torch.cuda.synchronize()
+            with torch.cuda.graph(gr):
+                eng.run_bound()                                                   # captured, not executed
+            for _ in range(3):
+                gr.replay()
+        else:
+            for _ in range(3):
+                eng.run_bound()
+        torch.cuda.synchronize()
+        st = eng.stats()
+        outs[mode] = (eng.pose6[0].cpu().numpy(), dec.params.cpu().numpy(), m.emb_bits().copy(), int(eng.adam_state[0].item()), st["P"], st["R"],
+                      eng.samp_off[:eng.N].cpu().numpy().copy(), eng.s_depth[:st["P"]].cpu().numpy().copy())
+    assert outs["eager"][3] == outs["graph"][3] == 4 and outs["eager"][4] == outs["graph"][4] > 0 and outs["eager"][5] == outs["graph"][5]
+    np.testing.assert_allclose(outs["graph"][0], outs["eager"][0], rtol=0, atol=2e-6)
+    d = np.abs(outs["graph"][1] - outs["eager"][1])
+    assert (d > 5e-5).mean() < 2e-3
+    assert (outs["graph"][2] != outs["eager"][2]).mean() < 5e-3
+    # the last iteration's sample layout: offsets exact; depths follow the (round-off-different) poses
+    assert np.array_equal(outs["graph"][6], outs["eager"][6])
+    np.testing.assert_allclose(outs["graph"][7], outs["eager"][7], rtol=0, atol=1e-4)
+
+
 @pytest.mark.parametrize("groups", ["all", "emb+pose", "pose", "decoder"])
 def test_one_launch_optimiser_step_equals_the_separate_kernels(nl, groups):
     """nl_optimiser_step (one launch) against nl_adam_prepare + nl_adam_embeddings + nl_adam_f32 + nl_decoder_transpose_w2 +
