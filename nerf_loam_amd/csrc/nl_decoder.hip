@@ -1075,10 +1075,7 @@ int nl_decoder_chain_fwd_bwd(const void* loss_scalars, const float* X, const flo
 int nl_decoder_chain_forward(const float* X, const float* params, const float* ws, int P, float* sdf, int nblocks, int six_products,
                              void* stream);
 int nl_decoder_chain_reduce(const float* partials, int nslabs, const float* params, float* grad_out, void* stream);
-/* nl_decoder_pair.hip */
-int nl_decoder_pair_fwd_bwd(const void* loss_scalars, const float* X, const float* params, const float* ws, const int* s_ray,
-                            const float* s_depth, const float* cos_gt, const float* gt_dist, float* sdf, float* dsdf, float* dX,
-                            float* partials, unsigned* relu2_mask, int nslabs, int train_decoder, int* counters, void* dbg, void* stream);
+
 }
 
 extern "C" {
@@ -1096,7 +1093,7 @@ int nl_decoder_get_wgrad2_mode(void) { return g_wgrad2_mode; }
  * 2 = as 1 with six of the nine forward products (the dropped ones are below 2^-24 of a product: below the rounding of the
  * fp32 accumulation).  PREPARED FOR ROUND 2: compiles, the kernels of modes 0 / 1 are instruction-identical with and without
  * it, but it has not run on a GPU yet - nothing selects it by default and no test covers it. */
-int nl_decoder_set_gemm_mode(int mode) { if (mode < 0 || mode > 5) return NL_ERR_INVALID_ARG; g_chain_six = mode == 4; g_gemm_mode = mode == 4 ? 3 : mode; return NL_OK; }
+int nl_decoder_set_gemm_mode(int mode) { if (mode < 0 || mode > 4) return NL_ERR_INVALID_ARG; g_chain_six = mode == 4; g_gemm_mode = mode == 4 ? 3 : mode; return NL_OK; }
 int nl_decoder_get_gemm_mode(void) { return g_gemm_mode == 3 && g_chain_six ? 4 : g_gemm_mode; }
 
 int nl_decoder_grid_hint(void)
@@ -1120,9 +1117,6 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
     a.relu2_mask = relu2_mask;
     a.dcounters = (double*)(counters + NL_CNT_INTS);
     a.dbg = g_dec_dbg;
-    if (g_gemm_mode == 5)                                 // two tiles in flight per workgroup (nl_decoder_pair.hip), mode 1's arithmetic
-        return nl_decoder_pair_fwd_bwd(loss_scalars, X, params, W2T, s_ray, s_depth, cos_gt, gt_dist, sdf, dsdf, dX, partials, relu2_mask, nslabs,
-                                       train_decoder, counters, g_dec_dbg, stream);
     if (g_gemm_mode == 3)
         return nl_decoder_chain_fwd_bwd(loss_scalars, X, params, W2T, s_ray, s_depth, cos_gt, gt_dist, sdf, dsdf, dX, partials, relu2_mask,
                                         nslabs, train_decoder, g_chain_six, counters, g_dec_dbg, stream);
@@ -1165,7 +1159,7 @@ int nl_decoder_forward(const float* X, const float* params, const float* W2T, in
     if (P == 0) return NL_OK;
     if (g_gemm_mode == 3) return nl_decoder_chain_forward(X, params, W2T, P, sdf, nblocks, g_chain_six, stream);
     if (g_gemm_mode == 2) hipLaunchKernelGGL((k_decoder_fwd<true, 6>), dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
-    else if (g_gemm_mode == 1 || g_gemm_mode == 5) hipLaunchKernelGGL(k_decoder_fwd<true>, dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
+    else if (g_gemm_mode == 1) hipLaunchKernelGGL(k_decoder_fwd<true>, dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
     else                  hipLaunchKernelGGL(k_decoder_fwd<false>, dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
     NL_LAUNCH_CHECK();
     return NL_OK;

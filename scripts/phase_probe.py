@@ -10,8 +10,7 @@ eng = P.SdfEngine(max_rays=len(w["points"]), samples_per_ray_cap=48)
 eng.set_rays(w["dirs"], w["points"], w["cos"]); eng.set_poses(w["pose"][None], [1])
 cfg = P.IterConfig(); eng.begin_call(w["map"], w["dec"])
 dbg = torch.zeros(256, dtype=torch.int64, device="cuda")
-CHAIN = L.lib().nl_decoder_get_gemm_mode() in (3, 4)
-PAIR = L.lib().nl_decoder_get_gemm_mode() == 5
+CHAIN = L.lib().nl_decoder_get_gemm_mode() >= 3
 for train in (True, False):
     for _ in range(2):
         eng.forward_backward(w["map"], w["dec"], cfg, train_decoder=train)
@@ -19,15 +18,6 @@ for train in (True, False):
     eng.forward_backward(w["map"], w["dec"], cfg, train_decoder=train)
     torch.cuda.synchronize()
     L.lib().nl_decoder_set_debug_buffer(None)
-    if PAIR:
-        d = dbg.cpu().numpy().reshape(16, 16)[:, :10]
-        names = ["B:H1 (+set barrier)", "wait turn C", "C:loop", "C:epi (+barrier)", "D,E (+barrier)", "wait turn F", "F:loop", "F:epi+H (+barrier)", "I:L1bwd (+barrier)"]
-        ph = np.diff(d[2:10], axis=1)
-        print("train" if train else "frozen", "paired-sets kernel, set 0, cycles per 32-sample tile (mean over tiles 2..9):")
-        for n, v in zip(names, ph.mean(0)):
-            print(f"  {n:24s} {v:10.0f}")
-        print("  total/tile", (d[3:10, 0] - d[2:9, 0]).mean(), " = per 64 samples and CU (two sets):", (d[3:10, 0] - d[2:9, 0]).mean())
-        continue
     if CHAIN:
         d = dbg.cpu().numpy().reshape(16, 16)[:, :11]
         names = ["layer1 a", "layer2+out a (8 stages)", "loss a", "layer1 b", "layer2+out b (8 stages)", "loss b", "dgrad set-up (mask fragments, X)",
