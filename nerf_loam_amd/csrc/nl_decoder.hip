@@ -280,22 +280,21 @@ __device__ __forceinline__ void gemm_x9(i32x4 rsX, int w, int lane, const unsign
 #pragma unroll
     for (int g = 0; g < 48; ++g) {
         const int s = g / 3;
-        if (g % 3 == 0 && s + RING - 1 < 16) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p) bq[(s + RING - 1) % RING][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + nt_off + (s + RING - 1) * 1024);
-        }
-        if (g + 1 < 48) {
-            const int sn = (g + 1) / 3, pn = 2 - (g + 1) % 3;
-            aq[(g + 1) & 1][0] = *reinterpret_cast<const uint4*>(a0 + pn * X_PLANE_BYTES + 32 * sn);
-            aq[(g + 1) & 1][1] = *reinterpret_cast<const uint4*>(a0 + pn * X_PLANE_BYTES + 32 * SM_STRIDE * 2 + 32 * sn);
-        }
-        if (PIN) __builtin_amdgcn_sched_barrier(0);      // pin the prefetches above this group's MFMAs (see gemm_mask_x)
+        // one memory instruction after every second MFMA (the group's three memory instructions spread over its six MFMAs) instead
+        // of all of them above the group: bunched, they hold up the issue of the next MFMA (scripts/micro/chain_stream.hip)
         const bf16x8 fa0 = __builtin_bit_cast(bf16x8, aq[g & 1][0]), fa1 = __builtin_bit_cast(bf16x8, aq[g & 1][1]);
+        const int sn = (g + 1) / 3, pn = 2 - (g + 1) % 3;
 #pragma unroll
         for (int pb = 2; pb >= 0; --pb) {
-            if (NP == 6 && (2 - g % 3) + pb > 2) continue;             // A plane (2 - g % 3) x B plane pb: keep hi/mid/lo index sums <= 2
-            const bf16x8 fb = __builtin_bit_cast(bf16x8, bq[s % RING][pb]);
-            c0 = MFMA_BF16(fa0, fb, c0); c1 = MFMA_BF16(fa1, fb, c1);
+            if (!(NP == 6 && (2 - g % 3) + pb > 2)) {                  // A plane (2 - g % 3) x B plane pb: keep hi/mid/lo index sums <= 2
+                const bf16x8 fb = __builtin_bit_cast(bf16x8, bq[s % RING][pb]);
+                c0 = MFMA_BF16(fa0, fb, c0); c1 = MFMA_BF16(fa1, fb, c1);
+            }
+            if (pb == 2 && g + 1 < 48) aq[(g + 1) & 1][0] = *reinterpret_cast<const uint4*>(a0 + pn * X_PLANE_BYTES + 32 * sn);
+            if (pb == 1 && g + 1 < 48) aq[(g + 1) & 1][1] = *reinterpret_cast<const uint4*>(a0 + pn * X_PLANE_BYTES + 32 * SM_STRIDE * 2 + 32 * sn);
+            if (pb == 0 && s + RING - 1 < 16)
+                bq[(s + RING - 1) % RING][g % 3] = bload4(rsX, voff, (g % 3) * W2X_PLANE_BYTES + nt_off + (s + RING - 1) * 1024);
+            if (PIN) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
