@@ -156,7 +156,10 @@ __global__ __launch_bounds__(256) void k_sel_window_b(SelArgs a)
     const int cand_n = ws[a.parity];
     const int C = min(cand_n, SEL_CAP);
     if (blockIdx.x == 0 && tid == 0) ws[a.parity ^ 1] = 0;       // the other slot: last read by the previous call's pass B, used by the next call
-    for (int i = tid; i < C; i += 256) { s_key[i] = (unsigned)ws[8 + 4 * SEL_MAXB + i]; s_idx[i] = ws[8 + 4 * SEL_MAXB + SEL_CAP + i]; }
+    // candidates relative to the window's lower edge, scaled so that the window fills the 32-bit range: the raw keys of a window
+    // share their leading byte(s), and the first radix pass would serialise every candidate on two or three LDS bins
+    const int sh = __clz((int)((fr.hi - fr.lo) | 1u));
+    for (int i = tid; i < C; i += 256) { s_key[i] = ((unsigned)ws[8 + 4 * SEL_MAXB + i] - fr.lo) << sh; s_idx[i] = ws[8 + 4 * SEL_MAXB + SEL_CAP + i]; }
     // surely selected keys: all of them, and those in the waves before this one
     int tot = 0, before = 0;
     for (int j = tid; j < 4 * fr.nblk; j += 256) { const int v = ws[8 + j]; tot += v; }
@@ -211,7 +214,8 @@ __global__ __launch_bounds__(256) void k_sel_window_b(SelArgs a)
         }
     }
     const bool take = k > 0 && !fail;
-    const unsigned T = prefix;
+    const unsigned T = prefix;                                   // in the scaled space of s_key
+    const unsigned Tkey = (prefix >> sh) + fr.lo;                // the same threshold as a raw key
     // selected candidates in front of this wave's range
     const int wstart = gw * fr.wchunk, wend = min(fr.M, wstart + fr.wchunk);
     int cb = 0;
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256) void k_sel_window_b(SelArgs a)
         const int i = i0 + lane;
         const bool live = i < wend;
         const unsigned key = live ? nl_select_key(fr.seed, (unsigned)i) : 0u;
-        const bool sel = live && (key > fr.hi || (take && key >= T && key >= fr.lo));
+        const bool sel = live && (key > fr.hi || (take && key >= Tkey && key >= fr.lo));
         const unsigned long long bal = __ballot(sel);
         if (live && fr.mask) fr.mask[i] = sel ? 1 : 0;
         if (sel) {
