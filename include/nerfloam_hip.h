@@ -169,6 +169,20 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
                        const int* s_ray, const float* s_depth, const float* cos_gt, const float* gt_dist,
                        float* sdf, float* dsdf, float* dX, float* partials, unsigned* relu2_mask, int nslabs, int train_decoder,
                        int* counters, void* stream);
+/* The same four decoder entry points with the kernel selection passed per call instead of taken from the process-wide defaults
+ * (nl_decoder_set_gemm_mode / nl_decoder_set_wgrad2_mode below): kernel_modes = NL_KERNEL_MODES(gemm_mode, wgrad2_mode), either
+ * mode -1 (or kernel_modes == 0) = the process default.  All calls of one iteration (fwd_bwd, wgrad2, reduce) must agree: the slab
+ * formats differ between the families.  NlIterDesc.kernel_modes carries the same word for nl_iteration. */
+#define NL_KERNEL_MODES(gemm_mode, wgrad2_mode) ((((gemm_mode) + 1) & 0xFF) | ((((wgrad2_mode) + 1) & 0xFF) << 8))
+int nl_decoder_fwd_bwd_m(const void* loss_scalars, const float* X, const float* params, const float* W2T,
+                         const int* s_ray, const float* s_depth, const float* cos_gt, const float* gt_dist,
+                         float* sdf, float* dsdf, float* dX, float* partials, unsigned* relu2_mask, int nslabs, int train_decoder,
+                         int* counters, int kernel_modes, void* stream);
+int nl_decoder_wgrad2_m(const void* loss_scalars, const float* X, const float* params, const float* dsdf, const unsigned* relu2_mask,
+                        float* partials, int nslabs, int kernel_modes, void* stream);
+int nl_decoder_reduce_m(const float* partials, int nslabs, const float* params, float* grad_out, int kernel_modes, void* stream);
+int nl_decoder_forward_m(const float* X, const float* params, const float* W2T, int P, float* sdf, int nblocks, int kernel_modes,
+                         void* stream);
 /* second half of the decoder weight gradient: dW2 = dH2^T H1 into partials[slab][W2 block] (train only) */
 int nl_decoder_wgrad2(const void* loss_scalars, const float* X, const float* params, const float* dsdf, const unsigned* relu2_mask,
                       float* partials, int nslabs, void* stream);
@@ -199,7 +213,10 @@ int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream);
  *   dgrad    dH1[i][k] = dsdf_i * sum_j m(i,j) * (w3_j W2[j][k]),  m = the {0,1} ReLU mask as A operand, B split in three.
  * Accumulation is fp32 in both modes; results differ by summation order only.
  * 2 = mode 1 with six of the nine forward products (without lo x lo, lo x mid, mid x lo: below 2^-24 of a product, i.e. below the
- *     rounding of the fp32 accumulation; two thirds of the matrix-pipe time).  Prepared, not yet verified on a GPU: not a default. */
+ *     rounding of the fp32 accumulation; two thirds of the matrix-pipe time).  Opt-in: not exact, never a default.
+ * 3 = the register-chained kernel family (nl_decoder_chain.hip) with all nine products, 4 = that family with six.
+ * These two setters change the PROCESS-WIDE DEFAULT used by the entry points without a kernel_modes argument (A/B measurements,
+ * NL_GEMM_MODE / NL_WGRAD2_MODE of the Python package); callers that need their own selection pass it per call (*_m, NlIterDesc). */
 int nl_decoder_set_gemm_mode(int mode);
 int nl_decoder_get_gemm_mode(void);
 
@@ -297,6 +314,8 @@ typedef struct NlIterDesc {
     /* optional state of the one-launch sampler (nl_sample_rays_fused): >= 8 * (1 + ceil(N / 32)) bytes, zero-initialised once
      * (NULL: the four-launch sampler sequence) */
     void* sample_state;
+    /* decoder kernel selection of this descriptor: NL_KERNEL_MODES(gemm_mode, wgrad2_mode); 0 = the process defaults */
+    int kernel_modes;
 } NlIterDesc;
 int nl_iteration(const NlIterDesc* desc, int stages, void* stream);
 

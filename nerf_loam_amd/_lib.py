@@ -56,6 +56,7 @@ def _iter_desc_fields():
     f += [(n, I_) for n in ("train_decoder", "want_emb_grad", "want_pose_grad", "update_emb", "update_decoder", "update_pose", "skip_mode")]
     f += [("counters_copy", P_), ("counters_clean", I_)]
     f += [("sample_state", P_)]
+    f += [("kernel_modes", I_)]
     return f
 
 
@@ -89,6 +90,10 @@ _SIGS = {
     "nl_decoder_fwd_bwd": ([_P] * 13 + [_I, _I, _P, _P], _I),
     "nl_decoder_wgrad2": ([_P] * 6 + [_I, _P], _I),
     "nl_decoder_forward": ([_P, _P, _P, _I, _P, _I, _P], _I),
+    "nl_decoder_fwd_bwd_m": ([_P] * 13 + [_I, _I, _P, _I, _P], _I),
+    "nl_decoder_wgrad2_m": ([_P] * 6 + [_I, _I, _P], _I),
+    "nl_decoder_forward_m": ([_P, _P, _P, _I, _P, _I, _I, _P], _I),
+    "nl_decoder_reduce_m": ([_P, _I, _P, _P, _I, _P], _I),
     "nl_field_set_debug_buffer": ([_P], _I),
     "nl_geometry_set_debug_buffer": ([_P], _I),
     "nl_geometry_set_lanes_per_ray": ([_I], _I),
@@ -181,6 +186,16 @@ def ptr(t):
         return None
     assert t.is_contiguous(), "nerfloam_hip needs contiguous tensors"
     return ctypes.c_void_p(t.data_ptr())
+
+
+def kernel_modes(gemm_mode=None, wgrad2_mode=None):
+    """NL_KERNEL_MODES of include/nerfloam_hip.h: the decoder kernel selection of one call / one NlIterDesc; None = the process
+    default (NL_GEMM_MODE / NL_WGRAD2_MODE, nl_decoder_set_*_mode)"""
+    g = -1 if gemm_mode is None else int(gemm_mode)
+    w = -1 if wgrad2_mode is None else int(wgrad2_mode)
+    if not (-1 <= g <= 4 and -1 <= w <= 1):
+        raise ValueError(f"gemm_mode {gemm_mode} / wgrad2_mode {wgrad2_mode}: 0..4 / 0..1 or None")
+    return ((g + 1) & 0xFF) | (((w + 1) & 0xFF) << 8)
 
 
 def stream_ptr():

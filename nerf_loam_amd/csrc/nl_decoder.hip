@@ -1090,10 +1090,26 @@ int nl_decoder_get_wgrad2_mode(void) { return g_wgrad2_mode; }
  * 1 = bf16 matrix cores on exact-product formulations (default): forward = both operands split into three bf16 terms, all
  * nine partial products; dgrad = {0,1} ReLU mask x three-term split of w3_j W2[j][k].  fp32 accumulation in both.
  * 2 = as 1 with six of the nine forward products (the dropped ones are below 2^-24 of a product: below the rounding of the
- * fp32 accumulation).  PREPARED FOR ROUND 2: compiles, the kernels of modes 0 / 1 are instruction-identical with and without
- * it, but it has not run on a GPU yet - nothing selects it by default and no test covers it. */
+ * fp32 accumulation): opt-in, not exact.  3 / 4 = the register-chained family with nine / six products.  Process-wide DEFAULTS:
+ * the *_m entry points and NlIterDesc.kernel_modes take the selection per call. */
 int nl_decoder_set_gemm_mode(int mode) { if (mode < 0 || mode > 4) return NL_ERR_INVALID_ARG; g_chain_six = mode == 4; g_gemm_mode = mode == 4 ? 3 : mode; return NL_OK; }
 int nl_decoder_get_gemm_mode(void) { return g_gemm_mode == 3 && g_chain_six ? 4 : g_gemm_mode; }
+
+}  // extern "C"
+
+struct DecModes { int gemm, six, wgrad2; };
+// kernel_modes = NL_KERNEL_MODES(gemm_mode, wgrad2_mode) of include/nerfloam_hip.h; a zero field = the process default
+static bool resolve_modes(int kernel_modes, DecModes* m)
+{
+    const int g = (kernel_modes & 0xFF) - 1, w = ((kernel_modes >> 8) & 0xFF) - 1;
+    if (g > 4 || w > 1 || (kernel_modes >> 16) != 0) return false;
+    m->gemm = g < 0 ? g_gemm_mode : (g == 4 ? 3 : g);
+    m->six = g < 0 ? g_chain_six : (g == 4);
+    m->wgrad2 = w < 0 ? g_wgrad2_mode : w;
+    return true;
+}
+
+extern "C" {
 
 int nl_decoder_grid_hint(void)
 {
@@ -1102,11 +1118,13 @@ int nl_decoder_grid_hint(void)
     return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 }
 
-int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* params, const float* W2T,
-                       const int* s_ray, const float* s_depth, const float* cos_gt, const float* gt_dist,
-                       float* sdf, float* dsdf, float* dX, float* partials, unsigned* relu2_mask, int nslabs, int train_decoder,
-                       int* counters, void* stream)
+int nl_decoder_fwd_bwd_m(const void* loss_scalars, const float* X, const float* params, const float* W2T,
+                         const int* s_ray, const float* s_depth, const float* cos_gt, const float* gt_dist,
+                         float* sdf, float* dsdf, float* dX, float* partials, unsigned* relu2_mask, int nslabs, int train_decoder,
+                         int* counters, int kernel_modes, void* stream)
 {
+    DecModes km;
+    if (!resolve_modes(kernel_modes, &km)) return NL_ERR_INVALID_ARG;
     if (!loss_scalars || !X || !params || !W2T || !s_ray || !s_depth || !cos_gt || !gt_dist || !sdf || !dsdf || !dX || !counters)
         return NL_ERR_INVALID_ARG;
     if (nslabs <= 0 || (train_decoder && (!partials || !relu2_mask))) return NL_ERR_INVALID_ARG;
@@ -1116,14 +1134,14 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
     a.relu2_mask = relu2_mask;
     a.dcounters = (double*)(counters + NL_CNT_INTS);
     a.dbg = g_dec_dbg;
-    if (g_gemm_mode == 3)
+    if (km.gemm == 3)
         return nl_decoder_chain_fwd_bwd(loss_scalars, X, params, W2T, s_ray, s_depth, cos_gt, gt_dist, sdf, dsdf, dX, partials, relu2_mask,
-                                        nslabs, train_decoder, g_chain_six, counters, g_dec_dbg, stream);
+                                        nslabs, train_decoder, km.six, counters, g_dec_dbg, stream);
     const dim3 g(nslabs), b(DEC_THREADS);
-    if (g_gemm_mode == 2) {
+    if (km.gemm == 2) {
         if (train_decoder) hipLaunchKernelGGL((k_decoder<true, true, 6>), g, b, 0, (hipStream_t)stream, a);
         else               hipLaunchKernelGGL((k_decoder<false, true, 6>), g, b, 0, (hipStream_t)stream, a);
-    } else if (g_gemm_mode == 1) {
+    } else if (km.gemm == 1) {
         if (train_decoder) hipLaunchKernelGGL((k_decoder<true, true>), g, b, 0, (hipStream_t)stream, a);
         else               hipLaunchKernelGGL((k_decoder<false, true>), g, b, 0, (hipStream_t)stream, a);
     } else {
@@ -1134,15 +1152,26 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
     return NL_OK;
 }
 
-// dW2 slab of the decoder weight gradient (second persistent kernel; needs nl_decoder_fwd_bwd's dsdf + relu2_mask)
-int nl_decoder_wgrad2(const void* loss_scalars, const float* X, const float* params, const float* dsdf, const unsigned* relu2_mask,
-                      float* partials, int nslabs, void* stream)
+int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* params, const float* W2T,
+                       const int* s_ray, const float* s_depth, const float* cos_gt, const float* gt_dist,
+                       float* sdf, float* dsdf, float* dX, float* partials, unsigned* relu2_mask, int nslabs, int train_decoder,
+                       int* counters, void* stream)
 {
+    return nl_decoder_fwd_bwd_m(loss_scalars, X, params, W2T, s_ray, s_depth, cos_gt, gt_dist, sdf, dsdf, dX, partials, relu2_mask, nslabs,
+                                train_decoder, counters, 0, stream);
+}
+
+// dW2 slab of the decoder weight gradient (second persistent kernel; needs nl_decoder_fwd_bwd's dsdf + relu2_mask)
+int nl_decoder_wgrad2_m(const void* loss_scalars, const float* X, const float* params, const float* dsdf, const unsigned* relu2_mask,
+                        float* partials, int nslabs, int kernel_modes, void* stream)
+{
+    DecModes km;
+    if (!resolve_modes(kernel_modes, &km)) return NL_ERR_INVALID_ARG;
     if (!loss_scalars || !X || !params || !dsdf || !relu2_mask || !partials || nslabs <= 0) return NL_ERR_INVALID_ARG;
-    if (g_gemm_mode == 3)                                 // the register-chained family writes natural-order ReLU words
+    if (km.gemm == 3)                                 // the register-chained family writes natural-order ReLU words
         hipLaunchKernelGGL(k_decoder_wgrad2_x<true>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,
                            params, dsdf, relu2_mask, partials);
-    else if (g_wgrad2_mode == 1)
+    else if (km.wgrad2 == 1)
         hipLaunchKernelGGL(k_decoder_wgrad2_x<false>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,
                            params, dsdf, relu2_mask, partials);
     else
@@ -1152,16 +1181,29 @@ int nl_decoder_wgrad2(const void* loss_scalars, const float* X, const float* par
     return NL_OK;
 }
 
-int nl_decoder_forward(const float* X, const float* params, const float* W2T, int P, float* sdf, int nblocks, void* stream)
+int nl_decoder_wgrad2(const void* loss_scalars, const float* X, const float* params, const float* dsdf, const unsigned* relu2_mask,
+                      float* partials, int nslabs, void* stream)
 {
+    return nl_decoder_wgrad2_m(loss_scalars, X, params, dsdf, relu2_mask, partials, nslabs, 0, stream);
+}
+
+int nl_decoder_forward_m(const float* X, const float* params, const float* W2T, int P, float* sdf, int nblocks, int kernel_modes, void* stream)
+{
+    DecModes km;
+    if (!resolve_modes(kernel_modes, &km)) return NL_ERR_INVALID_ARG;
     if (!X || !params || !W2T || !sdf || P < 0 || nblocks <= 0) return NL_ERR_INVALID_ARG;
     if (P == 0) return NL_OK;
-    if (g_gemm_mode == 3) return nl_decoder_chain_forward(X, params, W2T, P, sdf, nblocks, g_chain_six, stream);
-    if (g_gemm_mode == 2) hipLaunchKernelGGL((k_decoder_fwd<true, 6>), dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
-    else if (g_gemm_mode == 1) hipLaunchKernelGGL(k_decoder_fwd<true>, dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
+    if (km.gemm == 3) return nl_decoder_chain_forward(X, params, W2T, P, sdf, nblocks, km.six, stream);
+    if (km.gemm == 2) hipLaunchKernelGGL((k_decoder_fwd<true, 6>), dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
+    else if (km.gemm == 1) hipLaunchKernelGGL(k_decoder_fwd<true>, dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
     else                  hipLaunchKernelGGL(k_decoder_fwd<false>, dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
     NL_LAUNCH_CHECK();
     return NL_OK;
+}
+
+int nl_decoder_forward(const float* X, const float* params, const float* W2T, int P, float* sdf, int nblocks, void* stream)
+{
+    return nl_decoder_forward_m(X, params, W2T, P, sdf, nblocks, 0, stream);
 }
 
 int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, void* stream)
@@ -1174,11 +1216,18 @@ int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, voi
 
 /* sum of the per-workgroup weight-gradient slabs of nl_decoder_fwd_bwd + nl_decoder_wgrad2 into the decoder gradient (either
  * kernel family: the chained one applies the dW2 / db2 / dW3 identities while summing) */
+int nl_decoder_reduce_m(const float* partials, int nslabs, const float* params, float* grad_out, int kernel_modes, void* stream)
+{
+    DecModes km;
+    if (!resolve_modes(kernel_modes, &km)) return NL_ERR_INVALID_ARG;
+    if (!partials || !params || !grad_out || nslabs <= 0) return NL_ERR_INVALID_ARG;
+    if (km.gemm == 3) return nl_decoder_chain_reduce(partials, nslabs, params, grad_out, stream);
+    return nl_reduce_partials(partials, nslabs, NL_DEC_PARAMS, grad_out, stream);
+}
+
 int nl_decoder_reduce(const float* partials, int nslabs, const float* params, float* grad_out, void* stream)
 {
-    if (!partials || !params || !grad_out || nslabs <= 0) return NL_ERR_INVALID_ARG;
-    if (g_gemm_mode == 3) return nl_decoder_chain_reduce(partials, nslabs, params, grad_out, stream);
-    return nl_reduce_partials(partials, nslabs, NL_DEC_PARAMS, grad_out, stream);
+    return nl_decoder_reduce_m(partials, nslabs, params, grad_out, 0, stream);
 }
 
 int nl_mfma_selftest(const float* A32, const float* B32, float* D32, const float* A16, const float* B16, float* D16, void* stream)

@@ -34,11 +34,11 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
                                     d->sdf_weight, d->sample_state, d->scan_ws, stream));
         NL_TRY(nl_gather_trilinear(d->loss_scalars, d->s_vox, d->s_depth, d->s_ray, d->rays_d_world, d->frame_id, d->poses12, d->F, d->centres,
                                    d->vertex_rows, d->emb, d->voxel_size, d->X, d->field_blocks, stream));
-        NL_TRY(nl_decoder_fwd_bwd(d->loss_scalars, d->X, d->dec_params, d->dec_ws, d->s_ray, d->s_depth, d->cos_gt, d->gt_dist, d->sdf, d->dsdf,
-                                  d->dX, d->partials, d->relu2_mask, d->n_slabs, d->train_decoder, c, stream));
+        NL_TRY(nl_decoder_fwd_bwd_m(d->loss_scalars, d->X, d->dec_params, d->dec_ws, d->s_ray, d->s_depth, d->cos_gt, d->gt_dist, d->sdf, d->dsdf,
+                                    d->dX, d->partials, d->relu2_mask, d->n_slabs, d->train_decoder, c, d->kernel_modes, stream));
         if (d->train_decoder) {
-            NL_TRY(nl_decoder_wgrad2(d->loss_scalars, d->X, d->dec_params, d->dsdf, d->relu2_mask, d->partials, d->n_slabs, stream));
-            NL_TRY(nl_decoder_reduce(d->partials, d->n_slabs, d->dec_params, d->dec_grad, stream));
+            NL_TRY(nl_decoder_wgrad2_m(d->loss_scalars, d->X, d->dec_params, d->dsdf, d->relu2_mask, d->partials, d->n_slabs, d->kernel_modes, stream));
+            NL_TRY(nl_decoder_reduce_m(d->partials, d->n_slabs, d->dec_params, d->dec_grad, d->kernel_modes, stream));
         }
         NL_TRY(nl_trilinear_bwd(d->loss_scalars, d->s_vox, d->s_depth, d->s_ray, d->rays_d_world, d->rays_d_sensor, d->frame_id, d->poses12, d->F,
                                 d->centres, d->vertex_rows, d->emb, d->voxel_size, d->dX, d->want_emb_grad ? d->g_emb : nullptr,

@@ -88,27 +88,30 @@ def gather_points(xyz, vox, centres, vertex_rows, emb, voxel_size, X):
 
 
 def decoder_fwd_bwd(loss_scalars, X, params, W2T, s_ray, s_depth, cos_gt, gt_dist, sdf, dsdf, dX, partials, relu2_mask, nslabs,
-                    train_decoder, counters):
-    check(L.lib().nl_decoder_fwd_bwd(ptr(loss_scalars), ptr(X), ptr(params), ptr(W2T), ptr(s_ray), ptr(s_depth), ptr(cos_gt), ptr(gt_dist),
-                                     ptr(sdf), ptr(dsdf), ptr(dX), ptr(partials), ptr(relu2_mask), int(nslabs), int(train_decoder),
-                                     ptr(counters), stream_ptr()), "nl_decoder_fwd_bwd")
+                    train_decoder, counters, modes=0):
+    """modes: _lib.kernel_modes(gemm_mode, wgrad2_mode) - the kernel selection of this call (0: the process defaults); the
+    fwd_bwd / wgrad2 / reduce calls of one iteration must use the same word"""
+    check(L.lib().nl_decoder_fwd_bwd_m(ptr(loss_scalars), ptr(X), ptr(params), ptr(W2T), ptr(s_ray), ptr(s_depth), ptr(cos_gt), ptr(gt_dist),
+                                       ptr(sdf), ptr(dsdf), ptr(dX), ptr(partials), ptr(relu2_mask), int(nslabs), int(train_decoder),
+                                       ptr(counters), int(modes), stream_ptr()), "nl_decoder_fwd_bwd_m")
 
 
-def decoder_wgrad2(loss_scalars, X, params, dsdf, relu2_mask, partials, nslabs):
-    check(L.lib().nl_decoder_wgrad2(ptr(loss_scalars), ptr(X), ptr(params), ptr(dsdf), ptr(relu2_mask), ptr(partials), int(nslabs),
-                                    stream_ptr()), "nl_decoder_wgrad2")
+def decoder_wgrad2(loss_scalars, X, params, dsdf, relu2_mask, partials, nslabs, modes=0):
+    check(L.lib().nl_decoder_wgrad2_m(ptr(loss_scalars), ptr(X), ptr(params), ptr(dsdf), ptr(relu2_mask), ptr(partials), int(nslabs),
+                                      int(modes), stream_ptr()), "nl_decoder_wgrad2_m")
 
 
-def decoder_forward(X, params, W2T, P, sdf, nblocks):
-    check(L.lib().nl_decoder_forward(ptr(X), ptr(params), ptr(W2T), int(P), ptr(sdf), int(nblocks), stream_ptr()), "nl_decoder_forward")
+def decoder_forward(X, params, W2T, P, sdf, nblocks, modes=0):
+    check(L.lib().nl_decoder_forward_m(ptr(X), ptr(params), ptr(W2T), int(P), ptr(sdf), int(nblocks), int(modes), stream_ptr()),
+          "nl_decoder_forward_m")
 
 
 def reduce_partials(partials, nslabs, n, out):
     check(L.lib().nl_reduce_partials(ptr(partials), int(nslabs), int(n), ptr(out), stream_ptr()), "nl_reduce_partials")
 
 
-def decoder_reduce(partials, nslabs, params, grad_out):
-    check(L.lib().nl_decoder_reduce(ptr(partials), int(nslabs), ptr(params), ptr(grad_out), stream_ptr()), "nl_decoder_reduce")
+def decoder_reduce(partials, nslabs, params, grad_out, modes=0):
+    check(L.lib().nl_decoder_reduce_m(ptr(partials), int(nslabs), ptr(params), ptr(grad_out), int(modes), stream_ptr()), "nl_decoder_reduce_m")
 
 
 def decoder_transpose_w2(params, W2T):

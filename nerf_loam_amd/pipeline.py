@@ -172,8 +172,12 @@ class DecoderDevice:
 
 
 class SdfEngine:
-    def __init__(self, max_rays, samples_per_ray_cap=48, max_frames=8, device="cuda"):
+    def __init__(self, max_rays, samples_per_ray_cap=48, max_frames=8, device="cuda", gemm_mode=None, wgrad2_mode=None):
+        """gemm_mode / wgrad2_mode: the decoder kernel selection of THIS engine (include/nerfloam_hip.h: 0 fp32 matrix cores,
+        1 exact-product bf16 splits, ...); None = the process default (NL_GEMM_MODE / NL_WGRAD2_MODE).  Carried per call
+        (NL_KERNEL_MODES), so engines with different selections coexist in one process."""
         L.require_gpu()
+        self.kernel_modes = L.kernel_modes(gemm_mode, wgrad2_mode)
         self.dev = torch.device(device)
         self.N_cap = int(max_rays)
         self.P_cap = int(max_rays) * int(samples_per_ray_cap)
@@ -421,14 +425,15 @@ class SdfEngine:
         tm("gather", 1)
         tm("decoder", 0)
         ops.decoder_fwd_bwd(self.loss_scalars, self.X, dec.params, dec.W2T, self.s_ray, self.s_depth, self.cos_gt, self.gt_dist,
-                            self.sdf, self.dsdf, self.dX, self.partials, self.relu2_mask, self.n_slabs, int(train_decoder), c)
+                            self.sdf, self.dsdf, self.dX, self.partials, self.relu2_mask, self.n_slabs, int(train_decoder), c,
+                            self.kernel_modes)
         tm("decoder", 1)
         if train_decoder:
             tm("wgrad2", 0)
-            ops.decoder_wgrad2(self.loss_scalars, self.X, dec.params, self.dsdf, self.relu2_mask, self.partials, self.n_slabs)
+            ops.decoder_wgrad2(self.loss_scalars, self.X, dec.params, self.dsdf, self.relu2_mask, self.partials, self.n_slabs, self.kernel_modes)
             tm("wgrad2", 1)
             tm("reduce", 0)
-            ops.decoder_reduce(self.partials, self.n_slabs, dec.params, dec.grad)
+            ops.decoder_reduce(self.partials, self.n_slabs, dec.params, dec.grad, self.kernel_modes)
             tm("reduce", 1)
             if self.hook_after_decoder_grads is not None:
                 self.hook_after_decoder_grads(self, dec)         # multi-GPU: the decoder all-reduce starts under the embedding scatter
@@ -468,7 +473,7 @@ class SdfEngine:
         ops.gather_trilinear(self.loss_scalars, self.s_vox, self.s_depth, self.s_ray, self.rays_d_world, self.frame_id, self.poses12,
                              self.F, m.centres, m.vertex_rows, m.emb, m.voxel_size, self.X, self.field_blocks)
         P = int(c[L.NLC_P].item())                                        # host sync: a forward-only query returns data anyway
-        ops.decoder_forward(self.X, dec.params, dec.W2T, min(P, self.P_cap), self.sdf, self.n_slabs)
+        ops.decoder_forward(self.X, dec.params, dec.W2T, min(P, self.P_cap), self.sdf, self.n_slabs, self.kernel_modes)
         return P
 
     def optimiser_step(self, m: MapDevice, dec: DecoderDevice, cfg: IterConfig, update_emb=True, update_decoder=True, update_pose=True,
@@ -526,6 +531,7 @@ class SdfEngine:
             assert self.g_emb is not None, "begin_call(emb_state=True) first"
         d.counters_copy, d.counters_clean = pt(self.counters_copy), 0
         d.sample_state = pt(self.sample_state)
+        d.kernel_modes = self.kernel_modes
         self._bound = (m, dec)                                       # keeps the tensors the descriptor points at alive
 
     def run_bound(self, stages=3):

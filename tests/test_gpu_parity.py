@@ -258,6 +258,62 @@ def _tie_rays(out):
     return ((t0[:, 1:] == t0[:, :-1]) & (idx[:, 1:] != -1)).any(1)
 
 
+def test_engines_carry_their_own_kernel_modes(nl, golden_dir):
+    """The kernel selection travels with the call (NL_KERNEL_MODES in the *_m entry points and NlIterDesc), not with the process:
+    two engines with different selections alternate in one process, each bit-identical to a run under the matching process
+    default, on the stage-wise path and on the one-call path; the process default is never touched."""
+    lib = nl["L"].lib()
+    g = np.load(os.path.join(golden_dir, "map_1f_1it.npz"))
+    sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]))
+    sc["ms"].id2row = g["id_table"].copy()
+    masks = H.unpack_masks(g["masks"], len(sc["points"]))
+    dec_np = O.decoder_init(int(g["seed"]))
+    frames = [O.select_rays(sc["points"], sc["cos"], g["poses0"][0].copy(), masks[0][0], optimize_pose=True)]
+    cfgP = nl["P"].IterConfig(step_size=float(g["step_size"]))
+    n = len(frames[0].rays_d)
+    default = lib.nl_decoder_get_gemm_mode(), lib.nl_decoder_get_wgrad2_mode()
+
+    def run(one_call, gemm=None, wgrad2=None):
+        P = nl["P"]
+        ms = sc["ms"]
+        m = P.MapDevice(ms.centres, ms.structure, ms.vertex_idx, ms.id2row, ms.emb, ms.voxel_size)
+        dec = P.DecoderDevice(dec_np.W1, dec_np.b1, dec_np.W2, dec_np.b2, dec_np.W3, dec_np.b3)
+        eng = P.SdfEngine(max_rays=n, samples_per_ray_cap=64, max_frames=2, gemm_mode=gemm, wgrad2_mode=wgrad2)
+        load_frames(eng, frames)
+        eng.begin_call(m, dec)
+        if one_call:
+            eng.bind(m, dec, cfgP, train_decoder=True)
+            eng.run_bound(1)
+        else:
+            eng.forward_backward(m, dec, cfgP, train_decoder=True)
+        Pn = eng.stats()["P"]
+        return {"sdf": eng.sdf[:Pn].cpu().numpy(), "dX": eng.dX[:Pn].cpu().numpy(), "gdec": dec.grad.cpu().numpy(), "P": Pn}
+
+    for one_call in (False, True):
+        got = {}
+        for gemm, wg in ((0, 0), (1, 1), (3, 1), (0, 0), (1, 1)):              # alternating selections, process default untouched
+            r = run(one_call, gemm, wg)
+            assert (lib.nl_decoder_get_gemm_mode(), lib.nl_decoder_get_wgrad2_mode()) == default
+            if (gemm, wg) in got:
+                for k in ("sdf", "dX", "gdec"):
+                    assert np.array_equal(got[(gemm, wg)][k], r[k]), (one_call, gemm, k)
+            got[(gemm, wg)] = r
+        try:
+            for gemm, wg in ((0, 0), (1, 1), (3, 1)):                           # the same selection as the process default: same bits
+                assert lib.nl_decoder_set_gemm_mode(gemm) == 0 and lib.nl_decoder_set_wgrad2_mode(wg) == 0
+                r = run(one_call)
+                for k in ("sdf", "dX", "gdec"):
+                    assert np.array_equal(got[(gemm, wg)][k], r[k]), (one_call, gemm, k)
+        finally:
+            lib.nl_decoder_set_gemm_mode(default[0]); lib.nl_decoder_set_wgrad2_mode(default[1])
+        # the selections are different kernels (not a silently ignored argument) that agree to rounding
+        assert not np.array_equal(got[(0, 0)]["sdf"], got[(1, 1)]["sdf"]) or not np.array_equal(got[(0, 0)]["gdec"], got[(1, 1)]["gdec"])
+        assert np.abs(got[(0, 0)]["sdf"] - got[(1, 1)]["sdf"]).max() < 1e-5 and np.abs(got[(3, 1)]["sdf"] - got[(1, 1)]["sdf"]).max() < 1e-5
+    with pytest.raises(ValueError):
+        nl["P"].SdfEngine(max_rays=8, gemm_mode=7)
+    assert lib.nl_decoder_forward_m(None, None, None, 0, None, 1, 0x0600, None) != 0       # wgrad2 mode 5: rejected
+
+
 @pytest.mark.parametrize("backward_mode", [1, 3], indirect=True)
 def test_mapping_three_steps_track_oracle(nl, golden_dir, backward_mode):
     """3 Adam iterations (embeddings bf16 + decoder + pose), same ray masks: parameters after each
