@@ -765,7 +765,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2(const NlLossS
 #define WX_OFF_LUT (3 * WX_PLANE)
 #define WX_OFF_MASK (WX_OFF_LUT + 256 * 16)
 #define WX_OFF_X (WX_OFF_MASK + 2 * DEC_THREADS * 4)
-#define WX_OFF_DS (WX_OFF_X + 2 * DEC_M * LDX * 4)
+#define WXX_STRIDE 48                                   // bytes per sample row of an X plane: 16 bf16 + 16 pad (conflict-free ds_read_b128)
+#define WXX_PLANE (DEC_M * WXX_STRIDE)
+#define WX_OFF_DS (WX_OFF_X + 2 * 3 * WXX_PLANE)
 #define WX_TOTAL (WX_OFF_DS + 2 * DEC_M * 4)
 
 
@@ -782,7 +784,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
     unsigned char* sB = smem;
     uint4* sLut = reinterpret_cast<uint4*>(smem + WX_OFF_LUT);
     unsigned* sMask = reinterpret_cast<unsigned*>(smem + WX_OFF_MASK);
-    float* sX = reinterpret_cast<float*>(smem + WX_OFF_X);
+    unsigned char* sXp = smem + WX_OFF_X;                // X tile as three bf16 planes [parity][plane][64 rows][48 B]
     float* sdS = reinterpret_cast<float*>(smem + WX_OFF_DS);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int col = 32 * w + l31;                        // producer role: H1 column of this lane
@@ -790,9 +792,26 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
     const int P = lsp->P;
     const int ntiles = (P + DEC_M - 1) / DEC_M;
     const float b1c = params[NL_OFF_B1 + col];
-    float w1r[NL_C / 2];
+    // layer 1 on the bf16 matrix cores, exact products like the 256-deep GEMMs: X and W1 as three bf16 terms each, nine K = 16
+    // MFMAs per half tile (288 pipe cycles) instead of eight fp32 ones (512).  B fragments (W1 row of this lane's column, k = 8 lh + e)
+    // stay in registers for the whole kernel.
+    uint4 w1p[3];
+    {
+        const float4* wr = reinterpret_cast<const float4*>(params + NL_OFF_W1 + col * NL_C + 8 * lh);
+        const float4 wa = wr[0], wb = wr[1];
+        const float v[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+        unsigned q[3][4];
 #pragma unroll
-    for (int kk = 0; kk < NL_C / 2; ++kk) w1r[kk] = params[NL_OFF_W1 + col * NL_C + 2 * kk + lh];
+        for (int e = 0; e < 4; ++e) {
+            const float a0 = v[2 * e], a1 = v[2 * e + 1];
+            q[0][e] = pack_hi16(a0, a1);
+            const float r0 = a0 - trunc_bf16(a0), r1 = a1 - trunc_bf16(a1);
+            q[1][e] = pack_hi16(r0, r1);
+            q[2][e] = pack_hi16(r0 - trunc_bf16(r0), r1 - trunc_bf16(r1));
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) w1p[pl] = make_uint4(q[pl][0], q[pl][1], q[pl][2], q[pl][3]);
+    }
     if (tid < 256) {                                     // byte -> 8 bf16 (1.0 where the bit is set)
         uint4 e;
         e.x = ((tid & 1) ? 0x3F80u : 0u) | ((tid & 2) ? 0x3F800000u : 0u);
@@ -822,20 +841,30 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
     };
     // inputs of a tile -> LDS buffers of parity `pb` (X tile, dsdf and mask words are double-buffered by tile parity)
     auto stage_inputs = [&](int pb) {
-        float* sx = sX + pb * (DEC_M * LDX);
-        sx[xi * LDX + xc] = xv.x; sx[xi * LDX + xc + 1] = xv.y;
+        unsigned* sx = reinterpret_cast<unsigned*>(sXp + pb * (3 * WXX_PLANE) + xi * WXX_STRIDE + 2 * xc);
+        const float r0 = xv.x - trunc_bf16(xv.x), r1 = xv.y - trunc_bf16(xv.y);
+        sx[0] = pack_hi16(xv.x, xv.y);
+        sx[WXX_PLANE / 4] = pack_hi16(r0, r1);
+        sx[2 * WXX_PLANE / 4] = pack_hi16(r0 - trunc_bf16(r0), r1 - trunc_bf16(r1));
         if (tid < DEC_M) sdS[pb * DEC_M + tid] = pds;
         sMask[pb * DEC_THREADS + tid] = pmk;
     };
     // producer of one 32-sample half tile: v = dsdf_i * relu(X W1^T + b1)[i][col], split into 3 bf16 planes, k-slot order
     auto produce = [&](int pb, int sub) {
-        const float* sx = sX + pb * (DEC_M * LDX) + opaque((32 * sub + l31) * LDX + lh);
+        const unsigned char* sx = sXp + pb * (3 * WXX_PLANE) + opaque((32 * sub + l31) * WXX_STRIDE + 16 * lh);
         const float* ds = sdS + pb * DEC_M + opaque(32 * sub + 4 * lh);
         f32x16 c0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) c0[r] = 0.f;
+        {
+            bf16x8 xa[3];
 #pragma unroll
-        for (int kk = 0; kk < NL_C / 2; ++kk) c0 = MFMA32(sx[2 * kk], w1r[kk], c0);
+            for (int pl = 0; pl < 3; ++pl) xa[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sx + pl * WXX_PLANE));
+#pragma unroll
+            for (int pa = 2; pa >= 0; --pa)                  // smallest terms first
+#pragma unroll
+                for (int pq = 2; pq >= 0; --pq) c0 = MFMA_BF16(xa[pa], __builtin_bit_cast(bf16x8, w1p[pq]), c0);
+        }
         unsigned hi[8], mid[8], lo[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
