@@ -49,11 +49,13 @@ def matrix_pipe_model(kernel, gemm_mode, wgrad2_mode, train):
     if kernel == "decoder":
         alg = FLOPS_PER_SAMPLE_DECODER if train else FLOPS_PER_SAMPLE_DECODER_FROZEN
         small = L1 * (3 if train else 2)                        # layer-1 forward, dX, (dW1)
-        if gemm_mode in (1, 2, 3, 4):                           # forward: 3x3 split (modes 2, 4: six of the nine products),
-            return alg, small, (9 if gemm_mode in (1, 3) else 6) * G + 3 * G    # dgrad: {0,1} mask x 3-term split; 3 / 4 = chained kernel
+        if gemm_mode in (1, 2):                                 # forward: 3x3 split (mode 2: six of the nine products), dgrad: {0,1} mask x
+            return alg, small - L1, (9 if gemm_mode == 1 else 6) * G + 3 * G + 9 * L1   # 3-term split; layer-1 forward: 3x3 split too
+        if gemm_mode in (3, 4):                                 # the chained family: layer 1 on the fp32 pipe
+            return alg, small, (9 if gemm_mode == 3 else 6) * G + 3 * G
         return alg, small + 2 * G, 0
     if wgrad2_mode == 1 or gemm_mode >= 3:
-        return FLOPS_PER_SAMPLE_WGRAD2, L1, 3 * G               # H1 rebuilt on fp32 MFMA; mask x 3-term split
+        return FLOPS_PER_SAMPLE_WGRAD2, 0, 3 * G + 9 * L1       # H1 rebuilt as 3x3 bf16 products; mask x 3-term split
     return FLOPS_PER_SAMPLE_WGRAD2, L1 + G, 0
 
 
@@ -508,7 +510,7 @@ def main():
               "traffic_source": "committed rocprofv3 PMC passes of this command (newest profiles/r*_pmc_summary.json), not measured in this run",
               "peak_note": ("matrix-pipe bound of the kernel's instruction mix: "
                             + (f"256-deep GEMMs as {'exact-product ' if gm in (1, 3) else ''}bf16 splits ({9 if gm in (1, 3) else 6} + 3 MFMAs per fp32 product, 2500 TF pipe), "
-                               "K=16 layers on the fp32 pipe (157.3 TF)" if gm >= 1 else "all GEMMs on the fp32 pipe (157.3 TF)")),
+                               "layer-1 forward as nine bf16 products too, dX / dW1 (K=16) on the fp32 pipe (157.3 TF)" if gm >= 1 else "all GEMMs on the fp32 pipe (157.3 TF)")),
               "second_kernel": (roofline_entry("k_decoder_wgrad2_x" if wm == 1 else "k_decoder_wgrad2", "wgrad2", wg_ms, P_local, gm, wm, True)
                                 if train_dec else None)}
         out = {

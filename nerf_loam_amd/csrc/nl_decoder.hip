@@ -116,6 +116,24 @@ __device__ __forceinline__ unsigned pack_hi16(float a, float b)
     return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
 }
 __device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
+// two fp32 values as three packed bf16 pairs: a = hi + mid + lo exactly (nl_split3_bf16's terms, by truncation)
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned* hi, unsigned* mid, unsigned* lo)
+{
+    const float r0 = a - trunc_bf16(a), r1 = b - trunc_bf16(b);
+    *hi = pack_hi16(a, b); *mid = pack_hi16(r0, r1); *lo = pack_hi16(r0 - trunc_bf16(r0), r1 - trunc_bf16(r1));
+}
+// layer 1 on the bf16 matrix cores: this lane's B fragments, W1[col][8 lh + e] (e = 0..7) as three bf16 terms
+__device__ __forceinline__ void l1_w1_fragments(const float* __restrict__ params, int col, int lh, uint4 (&out)[3])
+{
+    const float4* wr = reinterpret_cast<const float4*>(params + NL_OFF_W1 + col * NL_C + 8 * lh);
+    const float4 wa = wr[0], wb = wr[1];
+    const float v[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+    unsigned q[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split3_pair(v[2 * e], v[2 * e + 1], &q[0][e], &q[1][e], &q[2][e]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) out[pl] = make_uint4(q[pl][0], q[pl][1], q[pl][2], q[pl][3]);
+}
 
 // LICM hoists every "base + constant" LDS address out of the persistent tile loop into its own VGPR (dozens of them);
 // laundering the base through an empty asm inside the loop keeps ONE base register and lets the constants fold into the
@@ -248,6 +266,18 @@ __device__ __forceinline__ void gemm_mask_x_rolled(i32x4 rsX, int w, int lane, c
 #define X_PLANE_BYTES (X_PLANE_ELEMS * 2)
 #define NL_DEC_WS_W2TX_OFF (NL_DEC_WS_W2X_OFF + 3 * NL_W * NL_W / 2)       // floats
 
+// bf16 mode, layer 1 on the bf16 matrix cores as well (exact 3 x 3 term products, nine K = 16 MFMAs per 32-row sub-tile instead of
+// eight fp32 ones): W1 as B fragments [wave][plane][lane][16 B] and the X tile as three planes [64 rows][32 B], in LDS the bf16 mode
+// leaves unused (between the H1 planes and the fp32 X tiles; the last X plane behind the carve)
+#define XG_W1X_OFF (3 * X_PLANE_BYTES)
+#define XG_W1X_BYTES (8 * 3 * 64 * 16)
+#define XG_XP_BYTES (DEC_M * 32)
+#define XG_XP01_OFF (XG_W1X_OFF + XG_W1X_BYTES)
+#define XG_XP2_OFF (S_TOTAL * 4)
+#define S_ALLOC (S_TOTAL + XG_XP_BYTES / 4)
+static_assert(XG_XP01_OFF + 2 * XG_XP_BYTES <= S_X * 4, "layer-1 operands overlap the fp32 X tiles");
+static_assert(S_ALLOC * 4 <= 163840, "LDS");
+
 #define X9_RING 3                                       // B fragments 2 k-steps (18 MFMAs = 576 pipe cycles each) ahead
 __device__ __forceinline__ void gemm_x9_prefetch(i32x4 rsX, int w, int lane, uint4 (&bq)[X9_RING][3])
 {
@@ -357,7 +387,7 @@ __device__ __forceinline__ float halfwave_rowsum(const f32x16& h0, const f32x16&
 template <bool TRAIN, bool XG, int NP = 9>               // NP: partial products of the forward GEMM (gemm_x9); XG: both 256-deep GEMMs on the bf16 matrix cores (exact-product formulations)
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float lds[S_TOTAL];
+    __shared__ __attribute__((aligned(16))) float lds[S_ALLOC];
     // XG: the three bf16 planes of H1 occupy the first 101 KB.  Once the forward GEMM has consumed them, the bf16 mask
     // tile (phases E/F) aliases plane 0 and the fp32 dH1 tile (phases H/I) aliases planes 1-2: F reads and H writes
     // never overlap, so no barrier separates them.
@@ -406,10 +436,26 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
     // (W1 -> LDS under the first tile's input loads: the loss inputs are a two-level dependent chain; at the live shapes a workgroup
     //  sees two tiles in all and the kernel's start is on the critical path of the step)
     for (int i = tid; i < NL_W * NL_C; i += DEC_THREADS) sW1[i] = a.params[NL_OFF_W1 + i];
-    {   // phase A of the first tile: X -> LDS buffer 0
-        float* sX = lds + S_X;
-        sX[xi * LDX + xc] = xv.x; sX[xi * LDX + xc + 1] = xv.y;
+    unsigned char* const ldsb = reinterpret_cast<unsigned char*>(lds);
+    // X tile of the next phase B: fp32 (dW1 of the trainable decoder reads it in phase I) and, in the bf16 mode, three bf16 planes
+    auto stage_x = [&](float* sXf) {
+        if (!XG || TRAIN) { sXf[xi * LDX + xc] = xv.x; sXf[xi * LDX + xc + 1] = xv.y; }
+        if (XG) {
+            unsigned q0, q1, q2;
+            split3_pair(xv.x, xv.y, &q0, &q1, &q2);
+            const int o = opaque(xi * 32 + 2 * xc);
+            *reinterpret_cast<unsigned*>(ldsb + XG_XP01_OFF + o) = q0;
+            *reinterpret_cast<unsigned*>(ldsb + XG_XP01_OFF + XG_XP_BYTES + o) = q1;
+            *reinterpret_cast<unsigned*>(ldsb + XG_XP2_OFF + o) = q2;
+        }
+    };
+    if (XG) {   // this lane's B fragments of layer 1, parked in LDS (the kernel has no registers to spare)
+        uint4 wq[3];
+        l1_w1_fragments(a.params, col, lh, wq);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint4*>(ldsb + XG_W1X_OFF + ((w * 3 + pl) * 64 + lane) * 16) = wq[pl];
     }
+    stage_x(lds + S_X);                                  // phase A of the first tile: X -> LDS buffer 0
     float cz = pz, cd = pd;
     prefetch(blockIdx.x + gridDim.x);
     __syncthreads();
@@ -427,12 +473,29 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             f32x16 c0, c1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
-            const float* xb = sX + opaque(l31 * LDX + lh);
-            const float* wb = sW1 + opaque(col * NL_C + lh);
+            if (XG) {
+                const unsigned char* xq = ldsb + opaque(l31 * 32 + 16 * lh);
+                const unsigned char* wq = ldsb + opaque(XG_W1X_OFF + (w * 3 * 64 + lane) * 16);
+                bf16x8 xa0[3], xa1[3], wf[3];
 #pragma unroll
-            for (int kk = 0; kk < NL_C / 2; ++kk) {
-                const float bw = wb[2 * kk];
-                c0 = MFMA32(xb[2 * kk], bw, c0); c1 = MFMA32(xb[32 * LDX + 2 * kk], bw, c1);
+                for (int pl = 0; pl < 3; ++pl) {
+                    const int po = pl < 2 ? XG_XP01_OFF + pl * XG_XP_BYTES : XG_XP2_OFF;
+                    xa0[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xq + po));
+                    xa1[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xq + po + 32 * 32));
+                    wf[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wq + pl * 64 * 16));
+                }
+#pragma unroll
+                for (int pa = 2; pa >= 0; --pa)               // smallest terms first
+#pragma unroll
+                    for (int pq = 2; pq >= 0; --pq) { c0 = MFMA_BF16(xa0[pa], wf[pq], c0); c1 = MFMA_BF16(xa1[pa], wf[pq], c1); }
+            } else {
+                const float* xb = sX + opaque(l31 * LDX + lh);
+                const float* wb = sW1 + opaque(col * NL_C + lh);
+#pragma unroll
+                for (int kk = 0; kk < NL_C / 2; ++kk) {
+                    const float bw = wb[2 * kk];
+                    c0 = MFMA32(xb[2 * kk], bw, c0); c1 = MFMA32(xb[32 * LDX + 2 * kk], bw, c1);
+                }
             }
             if (XG) {
                 gemm_x9_prefetch(rsW2TX, w, lane, bq9);          // W2 planes of the first k-steps: in flight across the barrier
@@ -615,8 +678,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         }
         // ---------------- A (next tile): X -> the other LDS buffer; issue the loads of the tile after it ----------------
         {
-            float* sXn = lds + S_X + ((tile_no + 1) & 1) * (DEC_M * LDX);
-            sXn[xi * LDX + xc] = xv.x; sXn[xi * LDX + xc + 1] = xv.y;
+            stage_x(lds + S_X + ((tile_no + 1) & 1) * (DEC_M * LDX));
             cz = pz; cd = pd;
             prefetch(tile + 2 * gridDim.x);
         }
@@ -796,22 +858,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
     // MFMAs per half tile (288 pipe cycles) instead of eight fp32 ones (512).  B fragments (W1 row of this lane's column, k = 8 lh + e)
     // stay in registers for the whole kernel.
     uint4 w1p[3];
-    {
-        const float4* wr = reinterpret_cast<const float4*>(params + NL_OFF_W1 + col * NL_C + 8 * lh);
-        const float4 wa = wr[0], wb = wr[1];
-        const float v[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-        unsigned q[3][4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float a0 = v[2 * e], a1 = v[2 * e + 1];
-            q[0][e] = pack_hi16(a0, a1);
-            const float r0 = a0 - trunc_bf16(a0), r1 = a1 - trunc_bf16(a1);
-            q[1][e] = pack_hi16(r0, r1);
-            q[2][e] = pack_hi16(r0 - trunc_bf16(r0), r1 - trunc_bf16(r1));
-        }
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) w1p[pl] = make_uint4(q[pl][0], q[pl][1], q[pl][2], q[pl][3]);
-    }
+    l1_w1_fragments(params, col, lh, w1p);
     if (tid < 256) {                                     // byte -> 8 bf16 (1.0 where the bit is set)
         uint4 e;
         e.x = ((tid & 1) ? 0x3F80u : 0u) | ((tid & 2) ? 0x3F800000u : 0u);
@@ -842,10 +889,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
     // inputs of a tile -> LDS buffers of parity `pb` (X tile, dsdf and mask words are double-buffered by tile parity)
     auto stage_inputs = [&](int pb) {
         unsigned* sx = reinterpret_cast<unsigned*>(sXp + pb * (3 * WXX_PLANE) + xi * WXX_STRIDE + 2 * xc);
-        const float r0 = xv.x - trunc_bf16(xv.x), r1 = xv.y - trunc_bf16(xv.y);
-        sx[0] = pack_hi16(xv.x, xv.y);
-        sx[WXX_PLANE / 4] = pack_hi16(r0, r1);
-        sx[2 * WXX_PLANE / 4] = pack_hi16(r0 - trunc_bf16(r0), r1 - trunc_bf16(r1));
+        split3_pair(xv.x, xv.y, &sx[0], &sx[WXX_PLANE / 4], &sx[2 * WXX_PLANE / 4]);
         if (tid < DEC_M) sdS[pb * DEC_M + tid] = pds;
         sMask[pb * DEC_THREADS + tid] = pmk;
     };
@@ -991,8 +1035,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
                                                                  const float* __restrict__ W2T, int P, float* __restrict__ sdf)
 {
     constexpr int H1_FLOATS = XG ? 3 * X_PLANE_BYTES / 4 : DEC_M * LDH;
-    __shared__ __attribute__((aligned(16))) float lds[H1_FLOATS + DEC_M * LDX + 8 * DEC_M];
-    float* sH1 = lds; float* sX = lds + H1_FLOATS; float* sS = sX + DEC_M * LDX;
+    constexpr int XS_FLOATS = XG ? 3 * XG_XP_BYTES / 4 : DEC_M * LDX;      // bf16 mode: the X tile as three bf16 planes [64][32 B]
+    __shared__ __attribute__((aligned(16))) float lds[H1_FLOATS + XS_FLOATS + 8 * DEC_M];
+    float* sH1 = lds; float* sX = lds + H1_FLOATS; float* sS = sX + XS_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int col = 32 * w + l31;
     const float* W1 = params + NL_OFF_W1;
@@ -1000,8 +1045,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
     const i32x4 rsW2TX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W2T + NL_DEC_WS_W2TX_OFF), 0, 3 * W2X_PLANE_BYTES, 0x00020000);
     const float b1c = params[NL_OFF_B1 + col], b2c = params[NL_OFF_B2 + col], w3c = params[NL_OFF_W3 + col], b3 = params[NL_OFF_B3];
     float w1r[NL_C / 2];
+    uint4 w1p[3];
+    if (XG) l1_w1_fragments(params, col, lh, w1p);
+    else {
 #pragma unroll
-    for (int kk = 0; kk < NL_C / 2; ++kk) w1r[kk] = W1[col * NL_C + 2 * kk + lh];
+        for (int kk = 0; kk < NL_C / 2; ++kk) w1r[kk] = W1[col * NL_C + 2 * kk + lh];
+    }
     const int ntiles = (P + DEC_M - 1) / DEC_M;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * DEC_M;
@@ -1009,7 +1058,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
             const int e = tid * 2, i = e >> 4, c = e & 15;
             float2 v = make_float2(0.f, 0.f);
             if (row0 + i < P) v = *reinterpret_cast<const float2*>(X + (size_t)(row0 + i) * NL_C + c);
-            sX[i * LDX + c] = v.x; sX[i * LDX + c + 1] = v.y;
+            if (XG) {
+                unsigned* d = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(sX) + i * 32 + 2 * c);
+                split3_pair(v.x, v.y, &d[0], &d[XG_XP_BYTES / 4], &d[2 * XG_XP_BYTES / 4]);
+            } else { sX[i * LDX + c] = v.x; sX[i * LDX + c + 1] = v.y; }
         }
         __syncthreads();
         uint4 bq9[X9_RING][3];
@@ -1017,9 +1069,26 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
             f32x16 c0, c1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
-            const float* xb = sX + opaque(l31 * LDX + lh);
+            if (XG) {                                     // the same nine products in the same order as k_decoder's phase B
+                const unsigned char* xq = reinterpret_cast<const unsigned char*>(sX) + opaque(l31 * 32 + 16 * lh);
+                bf16x8 xa0[3], xa1[3];
 #pragma unroll
-            for (int kk = 0; kk < NL_C / 2; ++kk) { c0 = MFMA32(xb[2 * kk], w1r[kk], c0); c1 = MFMA32(xb[32 * LDX + 2 * kk], w1r[kk], c1); }
+                for (int pl = 0; pl < 3; ++pl) {
+                    xa0[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xq + pl * XG_XP_BYTES));
+                    xa1[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xq + pl * XG_XP_BYTES + 32 * 32));
+                }
+#pragma unroll
+                for (int pa = 2; pa >= 0; --pa)
+#pragma unroll
+                    for (int pq = 2; pq >= 0; --pq) {
+                        const bf16x8 wf = __builtin_bit_cast(bf16x8, w1p[pq]);
+                        c0 = MFMA_BF16(xa0[pa], wf, c0); c1 = MFMA_BF16(xa1[pa], wf, c1);
+                    }
+            } else {
+                const float* xb = sX + opaque(l31 * LDX + lh);
+#pragma unroll
+                for (int kk = 0; kk < NL_C / 2; ++kk) { c0 = MFMA32(xb[2 * kk], w1r[kk], c0); c1 = MFMA32(xb[32 * LDX + 2 * kk], w1r[kk], c1); }
+            }
             if (XG) {
                 gemm_x9_prefetch(rsW2TX, w, lane, bq9);
                 store_h1_planes(reinterpret_cast<unsigned short*>(lds), col, lh, c0, c1, b1c);
