@@ -439,8 +439,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under torch.distributed.run, the
+        # same launch the driver uses); rank 0 of that job prints the line
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus} needs {args.gpus} devices, this box has {n_dev}")
+        import socket
+        import subprocess
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} processes (or none: bench.py starts them itself)")
     from nerf_loam_amd import _lib, pipeline as P, dist as D
     _lib.require_gpu()
     torch.cuda.set_device(local_rank)

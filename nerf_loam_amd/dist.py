@@ -156,7 +156,14 @@ class RayShardedExchange:
         lib, sp = L.lib(), L.stream_ptr()
         st["bitmap"].zero_()
         L.check(lib.nl_dist_mark_rows(eng.N, L.ptr(eng.hit_idx), L.ptr(eng.hit_count), L.ptr(m.vertex_rows), L.ptr(st["bitmap"]), sp), "nl_dist_mark_rows")
-        dist.all_reduce(st["bitmap"], op=dist.ReduceOp.BOR, group=self.group)
+        # union of the ranks' bitmaps: all-gather + OR (ProcessGroupNCCL / RCCL has no bitwise reduction: ReduceOp.BOR raises there)
+        if st.get("gathered") is None or st["gathered"].numel() != self.world * st["nw"]:
+            st["gathered"] = torch.empty(self.world * st["nw"], dtype=torch.int32, device=st["bitmap"].device)
+        dist.all_gather_into_tensor(st["gathered"], st["bitmap"], group=self.group)
+        g = st["gathered"].view(self.world, st["nw"])
+        torch.bitwise_or(g[0], g[1], out=st["bitmap"]) if self.world > 1 else st["bitmap"].copy_(g[0])
+        for r in range(2, self.world):
+            st["bitmap"].bitwise_or_(g[r])
         L.check(lib.nl_dist_rows_prefix(L.ptr(st["bitmap"]), st["nw"], L.ptr(st["prefix"]), L.ptr(st["total"]), L.ptr(st["ws"]), sp), "nl_dist_rows_prefix")
         if self._rows_cap is None:                       # first iteration of a call: ONE host read, the capacity of the whole call
             u = int(st["total"].item())

@@ -283,9 +283,7 @@ class SdfEngine:
         if sum(ns) > self.N_cap:
             raise L.NerfLoamHipError(f"{sum(ns)} rays exceed engine capacity {self.N_cap}")
         if len(scans) <= L.NL_SEL_MAX_FRAMES and all(sc["dirs"].is_contiguous() and sc["points"].is_contiguous() for sc in scans):
-            if getattr(self, "_selb_ws", None) is None:
-                self._selb_ws = torch.zeros(L.NL_SEL_MAX_FRAMES * L.NL_SEL_BATCH_WS_INTS_PER_FRAME, dtype=I32, device=self.dev)
-                self._selb_parity = 0
+            self._selb_frames(len(scans))
             mks = [sc.get("mask_u8") if sc.get("mask_u8") is not None else (torch.empty(M, dtype=torch.uint8, device=self.dev) if want_masks else None)
                    for sc, M in zip(scans, Ms)]
             offs = [sum(ns[:f]) for f in range(len(ns))]
@@ -315,6 +313,17 @@ class SdfEngine:
         self.N = total
         return masks if want_masks else None
 
+    def _selb_frames(self, F):
+        """workspace of nl_select_rays_batch.  A call clears the OTHER-parity candidate counter only of the frames it includes, so
+        when the frame count of this engine changes both counters of every frame are cleared (a frame skipped for an odd number
+        of calls would otherwise meet a stale counter)."""
+        if getattr(self, "_selb_ws", None) is None:
+            self._selb_ws = torch.zeros(L.NL_SEL_MAX_FRAMES * L.NL_SEL_BATCH_WS_INTS_PER_FRAME, dtype=I32, device=self.dev)
+            self._selb_parity = 0
+        elif getattr(self, "_selb_F", F) != F:
+            self._selb_ws.view(L.NL_SEL_MAX_FRAMES, -1)[:, :2].zero_()
+        self._selb_F = F
+
     def prepare_selection(self, scans, n_rays):
         """marshal the frame list of a call ONCE (select_rays re-builds its argument arrays on every call); then reselect(seed) is
         one C call per iteration.  Returns False when the shapes need the per-frame radix path (use select_rays then)."""
@@ -323,9 +332,7 @@ class SdfEngine:
         ns = [min(int(n_rays), M) for M in Ms]
         if F > L.NL_SEL_MAX_FRAMES or sum(ns) > self.N_cap or any(sc.get("mask_u8") is None for sc in scans):
             return False
-        if getattr(self, "_selb_ws", None) is None:
-            self._selb_ws = torch.zeros(L.NL_SEL_MAX_FRAMES * L.NL_SEL_BATCH_WS_INTS_PER_FRAME, dtype=I32, device=self.dev)
-            self._selb_parity = 0
+        self._selb_frames(F)
         I, U, PP = ctypes.c_int * F, ctypes.c_uint * F, ctypes.c_void_p * F
         self._sel_prepared = dict(
             F=F, M=I(*Ms), n=I(*ns), seed=U(*([0] * F)), d=PP(*[sc["dirs"].data_ptr() for sc in scans]),
@@ -508,6 +515,10 @@ class SdfEngine:
         hyper-parameter once, so that run_bound() is ONE ctypes call per iteration instead of ~15 calls with ~250 marshalled
         arguments.  Call again when the map, the decoder, the configuration or the flags change (tensors are looked up here, not in
         the loop).  Not used when multi-GPU hooks or stage timers are installed (forward_backward / optimiser_step then)."""
+        if any(h is not None for h in (self.hook_after_intersect, self.hook_after_count, self.hook_after_decoder_grads, self.hook_after_backward)):
+            raise L.NerfLoamHipError("bind() / run_bound(): stage hooks are installed on this engine (they run only on the stage-wise "
+                                     "path forward_backward + optimiser_step); a ray-sharded engine exchanges inside nl_iteration "
+                                     "through its communicator (dist.RayShardedExchange) instead")
         d = self._desc
         pt = lambda t: None if t is None else t.data_ptr()          # noqa: E731
         for name in ("rays_d_sensor", "points_gt", "cos_gt", "frame_id", "pose6", "poses12", "pose_m", "pose_v", "pose_enable", "g_pose", "pose_grad6",

@@ -120,7 +120,9 @@ def _ray_drawer(eng, frames, N_rays, track=False):
     for fr, sc in zip(frames, scans):
         fr.sample_mask = sc["mask_u8"].view(torch.bool).view(-1, 1)
     if eng.prepare_selection(scans, N_rays):
-        return eng.reselect
+        # reselect() returns False WITHOUT launching when the shapes leave the window method's range (n >= M, or a candidate
+        # window beyond its capacity: ~17 k rays per frame at M = 131 k): the per-frame radix path handles every shape
+        return lambda seed: eng.reselect(seed) or eng.select_rays(scans, N_rays, seed)
     return lambda seed: eng.select_rays(scans, N_rays, seed)
 
 

@@ -220,6 +220,15 @@ class ShareData:
                 return cur, ver
         return cur, ver
 
+    def _cache_entry(self, ver):
+        """per-version views / modules; older versions are dropped HERE as well as in _publish: a ShareData obtained through
+        attach() (the tracker process) never publishes, and every cached version holds a MapDevice (packed traversal blocks,
+        vertex rows: MBs of device memory) and a Decoder copy.  Single reader per process: there is one lease slot, and
+        whoever reads `states` / `decoder` last holds it."""
+        for v in [v for v in self._cache if v != ver]:
+            del self._cache[v]
+        return self._cache.setdefault(ver, {})
+
     def release(self):
         """give the lease back (optional: re-reading `states` moves it anyway)"""
         self._ctl[_LEASE] = -1
@@ -232,7 +241,7 @@ class ShareData:
             cur, ver = self._lease_current()
             if cur < 0 or not self._meta(cur)["has_decoder"] or self._decoder_template is None:
                 return None
-            ent = self._cache.setdefault(ver, {})
+            ent = self._cache_entry(ver)
             if "decoder" not in ent:
                 from copy import deepcopy
                 m = deepcopy(self._decoder_template)
@@ -264,7 +273,7 @@ class ShareData:
             meta = self._meta(cur)
             if not meta["has_states"]:
                 return None
-            ent = self._cache.setdefault(ver, {})
+            ent = self._cache_entry(ver)
             if "states" not in ent:
                 b = self._bufs[cur]
                 n, rows = meta["n"], meta["rows"]

@@ -976,16 +976,16 @@ class _ThreadRanks:
         out.copy_(torch.cat([x.reshape(-1) for x in self._exchange(inp)]))
 
     def all_reduce(self, t, op=None, group=None):
+        # strict: only what ProcessGroupNCCL (RCCL) implements - it raises on the bitwise ops (BAND / BOR / BXOR)
+        if op not in (self.ReduceOp.SUM, self.ReduceOp.MAX, self.ReduceOp.MIN, self.ReduceOp.PRODUCT, self.ReduceOp.AVG):
+            raise RuntimeError(f"Cannot use {op} with NCCL")
         st = torch.stack(self._exchange(t))
         if op == self.ReduceOp.MAX:
             t.copy_(st.max(0).values)
-        elif op == self.ReduceOp.BOR:
-            r = st[0]
-            for x in st[1:]:
-                r = r | x
-            t.copy_(r)
-        else:
+        elif op == self.ReduceOp.SUM:
             t.copy_(st.sum(0))
+        else:
+            raise NotImplementedError(op)
 
 
 def _sharded_vs_single(nl, golden_dir, monkeypatch, world, pad_rows=0, sparse_rows="auto"):
