@@ -33,6 +33,12 @@ MAX_CACHED_ENGINES = 4          # (device, ray capacity, frame capacity) -> SdfE
 # does not advance the global one).
 RAY_SELECTION = os.environ.get("NL_RAY_SELECTION", "device")
 
+# Sampler jitter (the reference draws torch `uniform_()` noise per iteration, voxel_helpers.py:298-303).  None (default): a seed
+# from the private generator per call, re-drawn on the device every iteration.  (seed, fresh): reproducible runs and the parity
+# tests - `seed` keys the counter-based noise hash(seed, ray index, step) the oracle and tests/golden/make_golden.py use;
+# fresh=False keeps the jitter a function of (seed, ray, step) only, i.e. the same in every iteration, like the goldens.
+SAMPLER_NOISE = None
+
 _PRIVATE_GEN = None
 
 
@@ -97,7 +103,11 @@ def _cfg(loss_criteria, voxel_size, step_size, max_distance, lrs=(0.0, 0.0, 0.0)
     return IterConfig(voxel_size=float(voxel_size), step_size=float(step_size), max_distance=float(max_distance),
                       truncation=float(loss_criteria.truncation), sdf_weight=float(loss_criteria.sdf_weight),
                       fs_weight=float(loss_criteria.fs_weight), lr_emb=lrs[0], lr_dec=lrs[1], lr_pose=lrs[2],
-                      noise_seed=_draw_seed())
+                      noise_seed=_draw_seed() if SAMPLER_NOISE is None else int(SAMPLER_NOISE[0]))
+
+
+def _fresh_noise():
+    return True if SAMPLER_NOISE is None else bool(SAMPLER_NOISE[1])
 
 
 def _gather_rays(frames, N_rays, track=False):
@@ -163,7 +173,7 @@ def bundle_adjust_frames(keyframe_graph, embeddings, map_states, sdf_network, lo
     # one C call per iteration (nl_iteration: ~15 launches); no host synchronisation inside the loop: an unusable iteration is
     # recognised and skipped by the optimiser kernel itself (skip_mode), fresh sampler jitter comes from the device step counter
     eng.bind(m, dec, cfg, train_decoder=update_decoder, want_emb_grad=True, want_pose_grad=any(optimise), update_emb=True,
-             update_decoder=update_decoder, update_pose=any(optimise), skip_mode=1, fresh_noise=True)
+             update_decoder=update_decoder, update_pose=any(optimise), skip_mode=1, fresh_noise=_fresh_noise())
     for it in range(num_iterations):
         if it:
             draw(seed0 + it)
@@ -194,7 +204,7 @@ def track_frame(frame_pose, curr_frame, map_states, sdf_network, loss_criteria, 
     draw = _ray_drawer(eng, [curr_frame], N_rays, track=True)
     draw(seed0)
     eng.bind(m, dec, cfg, train_decoder=False, want_emb_grad=False, want_pose_grad=True, update_emb=False, update_decoder=False,
-             update_pose=True, lr_pose=lr, skip_mode=2, fresh_noise=True)       # sticky skip = the reference's `break`
+             update_pose=True, lr_pose=lr, skip_mode=2, fresh_noise=_fresh_noise())       # sticky skip = the reference's `break`
     for it in range(num_iterations):
         if it:
             draw(seed0 + it)

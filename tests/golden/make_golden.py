@@ -234,8 +234,9 @@ def decoder_arrays(dec):
 
 
 def run_mapping_case(name, n_frames, n_rays, n_iter, seed, update_pose=True, update_decoder=True,
-                     n_beams=64, n_azimuth=48, VOXEL=VOXEL, step_factor=0.5, lrs=(0.03, 0.005, 0.001)):
-    """VOXEL / step_factor / lrs: mapper_specs voxel_size, step_size and learning rates of the dataset configs
+                     n_beams=64, n_azimuth=48, VOXEL=VOXEL, step_factor=0.5, lrs=(0.03, 0.005, 0.001), keep=None):
+    """keep: iterations whose render outputs are stored (None = all; the long trajectories store the first and the last one,
+    and every iteration's loss).  VOXEL / step_factor / lrs: mapper_specs voxel_size, step_size and learning rates of the dataset configs
     (configs/maicity: 0.2, 0.5, .03/.005/.001; configs/kitti: 0.3, 0.5, .01/.005/.001; configs/ncd: 0.2, 0.2, .002/.005/.001)"""
     _CAP.clear()
     sc = build_scene(n_beams, n_azimuth, seed, VOXEL)
@@ -289,14 +290,17 @@ def run_mapping_case(name, n_frames, n_rays, n_iter, seed, update_pose=True, upd
         out["decG_W1"], out["decG_b1"] = gd["pts_linears.0.weight"].numpy(), gd["pts_linears.0.bias"].numpy()
         out["decG_W2"], out["decG_b2"] = gd["pts_linears.1.weight"].numpy(), gd["pts_linears.1.bias"].numpy()
         out["decG_W3"], out["decG_b3"] = gd["sdf_out.weight"].numpy(), gd["sdf_out.bias"].numpy()
+    assert len(_CAP["render"]) == n_iter                      # (no iteration was skipped: the masks line up with the iterations)
     for it, r in enumerate(_CAP["render"]):
+        out[f"it{it}_loss"] = np.float32(_CAP["loss"][it]["loss"])
+        out[f"it{it}_fs_loss"] = np.float32(_CAP["loss"][it]["fs_loss"])
+        out[f"it{it}_sdf_loss"] = np.float32(_CAP["loss"][it]["sdf_loss"])
+        if keep is not None and it not in keep:
+            continue
         out[f"it{it}_sdf"] = r["sdf"]
         out[f"it{it}_z_vals"] = r["z_vals"]
         out[f"it{it}_valid"] = r["valid_mask"]
         out[f"it{it}_ray_mask"] = r["ray_mask"]
-        out[f"it{it}_loss"] = np.float32(_CAP["loss"][it]["loss"])
-        out[f"it{it}_fs_loss"] = np.float32(_CAP["loss"][it]["fs_loss"])
-        out[f"it{it}_sdf_loss"] = np.float32(_CAP["loss"][it]["sdf_loss"])
     i0 = _CAP["intersections"][0]
     out["it0_hit_idx"], out["it0_hit_t0"], out["it0_hit_t1"] = i0["intersected_voxel_idx"], i0["min_depth"], i0["max_depth"]
     path = os.path.join(HERE, name + ".npz")
@@ -305,7 +309,7 @@ def run_mapping_case(name, n_frames, n_rays, n_iter, seed, update_pose=True, upd
           f"R={out['it0_sdf'].shape} -> {os.path.getsize(path)/1e3:.0f} kB")
 
 
-def run_tracking_case(name, n_rays, n_iter, seed, frame_index=5, n_beams=64, n_azimuth=48, VOXEL=VOXEL, step_factor=0.2, lr=0.005):
+def run_tracking_case(name, n_rays, n_iter, seed, frame_index=5, n_beams=64, n_azimuth=48, VOXEL=VOXEL, step_factor=0.2, lr=0.005, keep=None):
     """VOXEL / step_factor / lr: mapper voxel_size and tracker_specs step_size, learning_rate of the dataset configs
     (maicity 0.2, 0.2, .005; kitti 0.3, 0.2, .06; ncd 0.2, 0.1, .04)"""
     _CAP.clear()
@@ -334,16 +338,21 @@ def run_tracking_case(name, n_rays, n_iter, seed, frame_index=5, n_beams=64, n_a
     out = dict(seed=seed, n_beams=n_beams, n_azimuth=n_azimuth, id_table=sc["id_table"].numpy()[:, 0],
                n_emb_rows=sc["emb"].shape[0], pose0=pose0, masks=np.packbits(np.stack(masks), axis=-1),
                pose_final=new_pose.data.detach().numpy(), pose_grad_last=new_pose.data.grad.numpy(),
-               hit_mask=hit_mask.numpy(), n_iter=n_iter, n_rays=n_rays, step_size=step_factor * VOXEL, voxel_size=VOXEL,
+               hit_mask=hit_mask.numpy() if hit_mask is not None else np.zeros(0, bool),
+               broke_at=len(_CAP.get("render", [])) if hit_mask is None else -1,     # the reference's `break` (render_rays returned None)
+               n_iter=n_iter, n_rays=n_rays, step_size=step_factor * VOXEL, voxel_size=VOXEL,
                lr=lr * 2 if frame_index < 2 else lr / 3, frame_index=frame_index)
+    assert len(_CAP["render"]) == (n_iter if hit_mask is not None else out["broke_at"])
     for it, r in enumerate(_CAP["render"]):
+        out[f"it{it}_loss"] = np.float32(_CAP["loss"][it]["loss"])
+        if keep is not None and it not in keep:
+            continue
         out[f"it{it}_sdf"] = r["sdf"]
         out[f"it{it}_z_vals"] = r["z_vals"]
         out[f"it{it}_valid"] = r["valid_mask"]
-        out[f"it{it}_loss"] = np.float32(_CAP["loss"][it]["loss"])
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
-    print(f"{name}: iters={len(_CAP['render'])} loss0={out['it0_loss']:.6f} -> {os.path.getsize(path)/1e3:.0f} kB")
+    print(f"{name}: iters={len(_CAP['render'])} broke_at={out['broke_at']} loss0={out['it0_loss']:.6f} -> {os.path.getsize(path)/1e3:.0f} kB")
 
 
 def run_se3_case():
@@ -395,6 +404,18 @@ CASES = {
                                                  step_factor=0.5, lrs=(0.01, 0.005, 0.001)),
     "track_kitti_2it": lambda: run_tracking_case("track_kitti_2it", n_rays=384, n_iter=2, seed=783, VOXEL=0.3, step_factor=0.2, lr=0.06),
     "track_ncd_2it": lambda: run_tracking_case("track_ncd_2it", n_rays=256, n_iter=2, seed=784, VOXEL=0.2, step_factor=0.1, lr=0.04),
+    # the reference's live iteration counts (configs/maicity/maicity.yaml:24,32: 20 / 20; configs/kitti/kitti.yaml:24,32: 25 / 25):
+    # a fresh bf16 Adam per call, 20 - 25 steps - what the API-level parity tests bound the drift against
+    "map_1f_20it": lambda: run_mapping_case("map_1f_20it", n_frames=1, n_rays=512, n_iter=20, seed=785, keep=(0, 19)),
+    "map_kitti_2f_25it_frozen": lambda: run_mapping_case("map_kitti_2f_25it_frozen", n_frames=2, n_rays=256, n_iter=25, seed=786, VOXEL=0.3,
+                                                         step_factor=0.5, lrs=(0.01, 0.005, 0.001), update_decoder=False, keep=(0, 24)),
+    "track_20it": lambda: run_tracking_case("track_20it", n_rays=512, n_iter=20, seed=787, keep=(0, 19)),
+    # seed 788: the untrained map sends the pose (Adam steps of lr / 3 = 0.02 m / rad) out of the scene and the reference's
+    # render_rays returns None in iteration 21 -> `break`, hit_mask None (render_helpers.py:486-489): the skip path, for free
+    "track_kitti_25it_break": lambda: run_tracking_case("track_kitti_25it_break", n_rays=384, n_iter=25, seed=788, VOXEL=0.3, step_factor=0.2,
+                                                        lr=0.06, keep=(0, 20)),
+    "track_kitti_25it": lambda: run_tracking_case("track_kitti_25it", n_rays=384, n_iter=25, seed=int(os.environ.get("NL_GOLDEN_SEED", 790)),
+                                                  VOXEL=0.3, step_factor=0.2, lr=0.06, keep=(0, 24)),
     "map_ncd_1f_1it": lambda: run_mapping_case("map_ncd_1f_1it", n_frames=1, n_rays=384, n_iter=1, seed=782, VOXEL=0.2,
                                                step_factor=0.2, lrs=(0.002, 0.005, 0.001)),
 }
