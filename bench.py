@@ -434,6 +434,8 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle parity check")
     ap.add_argument("--no-api-path", action="store_true", help="skip the bundle_adjust_frames / track_frame timings")
     ap.add_argument("--frozen-decoder", action="store_true", help="mapping with update_decoder=False (after freeze_frame)")
+    ap.add_argument("--rccl-world1", action="store_true", help="run the ray-sharded code path (RCCL communicator, exchanges inside nl_iteration) "
+                                                                "on ONE GPU with a world-size-1 process group: what a 1-GPU box can check of --gpus N")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -457,17 +459,21 @@ def main():
     _lib.require_gpu()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    shard = world > 1 or args.rccl_world1
+    if shard:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29571")
         import torch.distributed as tdist
-        tdist.init_process_group("nccl", device_id=device)
+        tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        tdist.barrier()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)      # RCCL prints a version banner through C stdio at communicator set-up: out before the JSON line
 
     w = build_workload(device)
     N = len(w["points"])
     lo, hi = D.shard_bounds(N, rank, world)
     eng = P.SdfEngine(max_rays=hi - lo, samples_per_ray_cap=48, device=device)
-    if world > 1:
-        D.RayShardedExchange(eng)
+    ex = D.RayShardedExchange(eng) if shard else None         # backend "rccl": the exchanges are issued from C inside nl_iteration
     # balanced shards: the scan is beam-major and beams differ several-fold in voxels/samples per ray, so each rank takes every
     # world-th return instead of a block of whole beams (identity for one GPU; scripts/shard_probe.py, profiles/r01_k_shard_probe.txt)
     order = D.interleaved_order(N, world)
@@ -478,12 +484,19 @@ def main():
     train_dec = not args.frozen_decoder
     eng.begin_call(w["map"], w["dec"])
 
+    if shard:
+        # ray-sharded: ONE C call per iteration (nl_iteration: kernels + the four RCCL collectives on the launch stream)
+        eng.bind(w["map"], w["dec"], cfg, train_decoder=train_dec, update_decoder=train_dec, ray_id_base=lo)
+
     def step():
+        if shard:
+            eng.run_bound()
+            return
         eng.forward_backward(w["map"], w["dec"], cfg, train_decoder=train_dec, ray_id_base=lo)
         eng.optimiser_step(w["map"], w["dec"], cfg, update_decoder=train_dec)
 
     def barrier():
-        if world > 1:
+        if shard:
             import torch.distributed as tdist
             tdist.barrier()
         torch.cuda.synchronize()
@@ -501,18 +514,50 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     eng.timers = None
-    if world > 1:
+    if shard:
         import torch.distributed as tdist
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         dt = float(t.item())
     st = eng.stats()
-    if st["overflow"] or st["guard"]:                    # a truncated sample set would overstate the throughput
-        raise SystemExit(f"bench invalid: sample overflow={st['overflow']} guard={st['guard']}")
+    if st["overflow"] or st["guard"] or eng.call_status()[2]:   # a truncated sample set would overstate the throughput
+        raise SystemExit(f"bench invalid: sample overflow={st['overflow']} guard={st['guard']} call_invalid={eng.call_status()[2]}")
+    P_local = st["P"]
+    sharded = None
+    if shard:
+        import torch.distributed as tdist
+        # (a) the same iterations without the communicator (every rank on its own share, no exchange): what the collectives cost;
+        # (b) a short stage-wise pass with the per-kernel events for the roofline object (the hooks run the same C exchanges)
+        d = eng._desc
+        comm_ptr, d.comm = d.comm, None
+        eng._exchange = None
+        for _ in range(2):
+            eng.run_bound()
+        barrier(); t1 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.run_bound()
+        barrier(); dt_local = time.perf_counter() - t1
+        d.comm, eng._exchange = comm_ptr, ex
+        ev = [{n: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for n in ("decoder", "wgrad2")} for _ in range(5)]
+        for k in range(5):
+            eng.timers = ev[k]
+            eng.forward_backward(w["map"], w["dec"], cfg, train_decoder=train_dec, ray_id_base=lo)
+            eng.optimiser_step(w["map"], w["dec"], cfg, update_decoder=train_dec)
+        barrier()
+        eng.timers = None
+        gathered = [None] * world
+        tdist.all_gather_object(gathered, dict(rank=rank, rays=int(hi - lo), valid_samples=int(P_local), hit_rays=int(st["R"])))
+        tl = torch.tensor([dt_local], dtype=torch.float64, device=device)
+        tdist.all_reduce(tl, op=tdist.ReduceOp.MAX)
+        sharded = dict(rccl_world=world, exchange_backend=ex.backend, embedding_exchange=("dense" if ex._rows_cap == "dense" else f"touched rows, capacity {ex._rows_cap}"),
+                       collectives_per_step=4, per_rank=gathered, ms_per_step_without_exchanges=float(tl.item()) / args.steps * 1e3,
+                       exchange_ms_per_step=(dt - float(tl.item())) / args.steps * 1e3,
+                       note="one C call per iteration (nl_iteration): counter all-gather + row-first all-reduce after the intersect, counter all-gather "
+                            "after the sampler, one grouped all-reduce [decoder grad | fp64 pose partials | embedding accumulators]; "
+                            "exchange_ms_per_step = this run minus the same iterations with the communicator removed")
     dec_ms = float(np.mean([e["decoder"][0].elapsed_time(e["decoder"][1]) for e in ev]))
     wg_ms = float(np.mean([e["wgrad2"][0].elapsed_time(e["wgrad2"][1]) for e in ev])) if train_dec else 0.0
-    P_local = st["P"]
-    stage_ms, stage_bytes, hbm_entries = stage_rooflines(eng, w, cfg, train_dec) if world == 1 else ({}, {}, [])
+    stage_ms, stage_bytes, hbm_entries = stage_rooflines(eng, w, cfg, train_dec) if not shard else ({}, {}, [])
     if rank == 0:
         gm, wm = _lib.lib().nl_decoder_get_gemm_mode(), _lib.lib().nl_decoder_get_wgrad2_mode()
         kname = ("k_decoder_chain" if gm >= 3 else "k_decoder") + ("<train>" if train_dec else "<frozen>")
@@ -541,7 +586,9 @@ def main():
                        "valid_samples_rank0": P_local, "max_samples_per_ray": st["S"], "parallelism": f"ray-shard x{world}" + (" (interleaved returns)" if world > 1 else "")},
             "roofline": rf,
         }
-        if world == 1:
+        if sharded is not None:
+            out["sharded"] = sharded
+        if not shard:
             # bandwidth-bound stages + the whole iteration against the sum of its per-kernel bounds
             rf["hbm"] = hbm_entries
             bounds = {"decoder": rf["matrix_pipe_bound_ms"], **{e["stage"]: e["algorithmic_bytes_per_launch"] / (HBM_PEAK_GBS * 1e9) * 1e3 for e in hbm_entries}}
@@ -556,10 +603,11 @@ def main():
                 out["api_path"] = api_path_bench(w, device)                                #  profiled command's per-kernel averages)
             if not args.no_parity:
                 out["parity"] = parity_check(eng, w, cfg, train_dec)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not shard:
             out["cpu_baseline"] = cpu_baseline(w)
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+    if shard:
         import torch.distributed as tdist
         tdist.destroy_process_group()
 

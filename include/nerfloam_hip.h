@@ -286,6 +286,7 @@ int nl_dist_rows_move(int direction /* 0 pack, 1 unpack */, const unsigned* bitm
  * (nl_ray_intersect_scan, nl_scan_samples_finalize, nl_optimiser_step_ex) of the stage calls.  The descriptor is plain C: device pointers + hyper-parameters; fill it once
  * per optimisation call, change N / seeds / flags between iterations.  Same kernels, same results as the stage-wise calls; what
  * it removes is the host's per-launch cost (~15 launches x ~250 marshalled arguments per iteration from Python). */
+struct NlComm;
 typedef struct NlIterDesc {
     /* rays of this iteration (sensor frame) and the frames' poses */
     int N, F;
@@ -316,8 +317,58 @@ typedef struct NlIterDesc {
     void* sample_state;
     /* decoder kernel selection of this descriptor: NL_KERNEL_MODES(gemm_mode, wgrad2_mode); 0 = the process defaults */
     int kernel_modes;
+    /* ---- ray-sharded multi-GPU iteration (NULL comm: one GPU).  With a communicator the call issues the exchanges itself, on
+     * `stream`, between the kernels (nl_exchange_* below) - a sharded iteration is still ONE C call and stays hipGraph-capturable.
+     *   xg_recv     [world][xg_stride] ints: receive side of the two counter all-gathers, xg_stride >= 24 (+ rows_words when the
+     *               touched-rows bitmaps travel with the second one); xg_send [xg_stride] ints: its send side
+     *   row_first   [row_first_entries][1 + NL_MAX_HITS] ints (nl_dist_row_first)
+     *   rows_mode   embedding-gradient exchange: 0 = dense all-reduce of g_emb, 1 = over the rows the iteration touches
+     *               (rows_bitmap / rows_prefix [rows_words], rows_total [1], rows_ws [rows_words + ceil(rows_words / 1024) + 8],
+     *               rows_buf [rows_cap][16] floats; the call is flagged invalid on the device when the union exceeds rows_cap) */
+    const struct NlComm* comm;
+    int* xg_send; int* xg_recv; int xg_stride;
+    int* row_first; int row_first_entries;
+    int rows_mode; unsigned* rows_bitmap; int* rows_prefix; int* rows_total; int* rows_ws; float* rows_buf; int rows_cap, rows_words;
 } NlIterDesc;
+/* stages: bit 0 = intersect .. backward (with a communicator: + the exchanges of the forward pass), bit 1 = optimiser step,
+ * bit 2 = the gradient exchange (only with a communicator; a whole sharded iteration = 7).  The bits exist separately so that the
+ * host can size the touched-rows exchange once per call between the backward pass and the gradient exchange of its first iteration. */
 int nl_iteration(const NlIterDesc* desc, int stages, void* stream);
+
+/* ---- communicator of the ray-sharded iteration: four entry points a backend provides.  All of them enqueue on `stream` and return
+ * 0 or an error code; buffers are device pointers.  Backends: nl_comm_init_rccl (librccl's ncclAllGather / ncclAllReduce /
+ * ncclGroupStart / ncclGroupEnd on an existing ncclComm_t - e.g. the one torch.distributed's ProcessGroupNCCL holds - resolved
+ * from the RCCL already loaded in the process), or any set of callbacks (nerf_loam_amd/dist.py: torch.distributed ops, used with
+ * non-RCCL process groups and by the virtual-rank tests). */
+#define NL_COMM_F32 0
+#define NL_COMM_F64 1
+#define NL_COMM_I32 2
+typedef struct NlComm {
+    int world, rank;
+    void* ctx;
+    int (*all_gather)(void* ctx, const void* send, void* recv, long long bytes_per_rank, void* stream);
+    int (*all_reduce_sum)(void* ctx, void* buf, long long count, int dtype, void* stream);      /* in place */
+    int (*group_begin)(void* ctx);       /* the all_reduce_sum calls up to group_end may be fused into one launch */
+    int (*group_end)(void* ctx);
+} NlComm;
+/* fills *out for an existing RCCL communicator (ncclComm_t passed as void*); NL_ERR_NO_DEVICE when no RCCL is loaded / loadable */
+int nl_comm_init_rccl(NlComm* out, void* nccl_comm, int world, int rank);
+/* The three exchange points of a sharded iteration, as nl_iteration issues them; also callable between the stage calls:
+ *  after_intersect: all-gather of the counter blocks -> global hit-ray count, this rank's hit-rank offset, global max hits
+ *                   (nl_dist_merge_counters stage 1); then the batch rows' first-ray hit lists (nl_dist_row_first) SUM-all-reduced:
+ *                   the sampler's closing loop reads the first ray of a ray's batch row (sample_gpu.cu:231), which may live elsewhere
+ *  after_sampling:  all-gather of [counter block | touched-rows bitmap] -> summed loss normalisers, max samples per ray
+ *                   (stage 2), nl_loss_finalize on the merged block, union bitmap + its prefix sums (rows_mode 1)
+ *  gradients:       ONE grouped SUM all-reduce of the decoder gradient (train_decoder), the fp64 pose partials (want_pose_grad)
+ *                   and the embedding accumulators (want_emb_grad: dense, or packed touched rows) */
+int nl_exchange_after_intersect(const NlIterDesc* desc, void* stream);
+int nl_exchange_after_sampling(const NlIterDesc* desc, void* stream);
+int nl_exchange_gradients(const NlIterDesc* desc, void* stream);
+/* gathered blocks `stride` ints apart (nl_dist_merge_counters: stride = the block itself) */
+int nl_dist_merge_counters_strided(const int* gathered, int stride_ints, int world, int rank, int stage, int* counters, void* stream);
+/* union[w] = OR over ranks of gathered[r * stride_ints + offset_ints + w]; then nl_dist_rows_prefix on the union */
+int nl_dist_rows_union_prefix(const int* gathered, int stride_ints, int offset_ints, int world, unsigned* union_bitmap, int n_words, int* prefix,
+                              int* total, int* workspace, void* stream);
 
 /* ---- (b2) host octree behind torch.classes.svo.Octree (third_party/sparse_octree/src/bindings.cpp:4-31) */
 void* nl_octree_create(long long grid_dim);                              /* Octree::init   octree.cpp:36-50   */

@@ -57,12 +57,27 @@ def _iter_desc_fields():
     f += [("counters_copy", P_), ("counters_clean", I_)]
     f += [("sample_state", P_)]
     f += [("kernel_modes", I_)]
+    # ray-sharded multi-GPU iteration (NULL comm: one GPU)
+    f += [("comm", P_), ("xg_send", P_), ("xg_recv", P_), ("xg_stride", I_), ("row_first", P_), ("row_first_entries", I_)]
+    f += [("rows_mode", I_), ("rows_bitmap", P_), ("rows_prefix", P_), ("rows_total", P_), ("rows_ws", P_), ("rows_buf", P_), ("rows_cap", I_), ("rows_words", I_)]
     return f
 
 
 class NlIterDesc(ctypes.Structure):
     """ctypes mirror of NlIterDesc (include/nerfloam_hip.h): field order and types must match (tests/test_c_abi_exports.py)"""
     _fields_ = _iter_desc_fields()
+
+
+# communicator of the ray-sharded iteration (NlComm, include/nerfloam_hip.h)
+NL_COMM_F32, NL_COMM_F64, NL_COMM_I32 = 0, 1, 2
+NL_COMM_ALL_GATHER = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p)
+NL_COMM_ALL_REDUCE = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p)
+NL_COMM_GROUP = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)
+
+
+class NlComm(ctypes.Structure):
+    _fields_ = [("world", ctypes.c_int), ("rank", ctypes.c_int), ("ctx", ctypes.c_void_p), ("all_gather", NL_COMM_ALL_GATHER),
+                ("all_reduce_sum", NL_COMM_ALL_REDUCE), ("group_begin", NL_COMM_GROUP), ("group_end", NL_COMM_GROUP)]
 
 
 _lib = None
@@ -119,6 +134,12 @@ _SIGS = {
     "nl_optimiser_step": ([_P, _D, _D, _D] + [_P] * 4 + [_LL] + [_P] * 5 + [_P] * 7 + [_I, _I, _P, _I, _P], _I),
     "nl_optimiser_step_ex": ([_P, _D, _D, _D] + [_P] * 4 + [_LL] + [_P] * 5 + [_P] * 7 + [_I, _I, _P, _I, _P, _P, _P], _I),
     "nl_iteration": ([_P, _I, _P], _I),
+    "nl_comm_init_rccl": ([_P, _P, _I, _I], _I),
+    "nl_exchange_after_intersect": ([_P, _P], _I),
+    "nl_exchange_after_sampling": ([_P, _P], _I),
+    "nl_exchange_gradients": ([_P, _P], _I),
+    "nl_dist_merge_counters_strided": ([_P, _I, _I, _I, _I, _P, _P], _I),
+    "nl_dist_rows_union_prefix": ([_P, _I, _I, _I, _P, _I, _P, _P, _P, _P], _I),
     "nl_dist_mark_rows": ([_I, _P, _P, _P, _P, _P], _I),
     "nl_dist_rows_prefix": ([_P, _I, _P, _P, _P, _P], _I),
     "nl_dist_rows_move": ([_I, _P, _P, _I, _P, _P, _I, _P, _P], _I),

@@ -32,6 +32,18 @@ __global__ void k_popcount_words(const unsigned* __restrict__ bitmap, int n_word
     if (i < n_words) counts[i] = __popc(bitmap[i]);
 }
 
+// union of the ranks' bitmaps as they arrive from the all-gather (RCCL has no bitwise reduction) + the word popcounts
+__global__ void k_union_popcount(const int* __restrict__ gathered, int stride, int offset, int world, unsigned* __restrict__ bitmap, int n_words,
+                                 int* __restrict__ counts)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_words) return;
+    unsigned u = 0u;
+    for (int r = 0; r < world; ++r) u |= (unsigned)gathered[(size_t)r * stride + offset + i];
+    bitmap[i] = u;
+    counts[i] = __popc(u);
+}
+
 // PACK: rows of the union bitmap, in row order, g_emb[row] -> buf[slot]; UNPACK: buf[slot] -> g_emb[row].  16 lanes per row.
 template <bool PACK>
 __global__ void k_rows_move(const unsigned* __restrict__ bitmap, const int* __restrict__ prefix, int n_words, float* __restrict__ g_emb,
@@ -69,6 +81,18 @@ int nl_dist_rows_prefix(const unsigned* bitmap, int n_words, int* prefix, int* t
 {
     if (!bitmap || n_words <= 0 || !prefix || !total || !workspace) return NL_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_popcount_words, dim3(nl_div_up(n_words, 256)), dim3(256), 0, (hipStream_t)stream, bitmap, n_words, workspace);
+    NL_LAUNCH_CHECK();
+    return nl_exclusive_scan_i32(workspace, prefix, n_words, 0, total, workspace + n_words, stream);
+}
+
+int nl_dist_rows_union_prefix(const int* gathered, int stride_ints, int offset_ints, int world, unsigned* union_bitmap, int n_words, int* prefix,
+                              int* total, int* workspace, void* stream)
+{
+    if (!gathered || !union_bitmap || n_words <= 0 || !prefix || !total || !workspace || world <= 0 || offset_ints < 0 ||
+        stride_ints < offset_ints + n_words)
+        return NL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_union_popcount, dim3(nl_div_up(n_words, 256)), dim3(256), 0, (hipStream_t)stream, gathered, stride_ints, offset_ints, world,
+                       union_bitmap, n_words, workspace);
     NL_LAUNCH_CHECK();
     return nl_exclusive_scan_i32(workspace, prefix, n_words, 0, total, workspace + n_words, stream);
 }

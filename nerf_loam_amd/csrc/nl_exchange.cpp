@@ -1,0 +1,155 @@
+// nl_exchange.cpp -- the exchanges of the ray-sharded multi-GPU iteration, issued from C on the launch stream (host code only).
+//
+// The reference has no distributed code; north_star: "a scan's rays shard embarrassingly across the 8 GPUs of one node
+// with RCCL all-reduce of embedding and pose gradients over xGMI".  Rays are independent up to three reductions:
+//   1. after intersect : the sampler's tail quirk depends on a ray's GLOBAL hit rank and on the hit list of the first ray of its
+//                        batch row (sample_gpu.cu:231) -> all-gather of the 96-byte counter blocks, then a SUM
+//                        all-reduce of the 200 x ceil(L / 800) row-first hit lists (17 KB at the headline size; which rays
+//                        they are is known only after the first one)
+//   2. after sampling  : criterion.py:84-88 weights and the R*S mean divisor are global -> all-gather of the counter blocks, the
+//                        touched-rows bitmaps riding along
+//   3. gradients       : ONE grouped SUM all-reduce (decoder gradient | fp64 pose partials | embedding accumulators, dense or
+//                        packed touched rows); then every rank applies the identical optimiser step to its replica.
+// Four collectives per iteration, all on the stream the kernels run on: a sharded iteration is one C call (nl_iteration) with no
+// host work between its launches, and hipGraph-capturable (RCCL collectives are).
+//
+// RCCL binding: the functions are looked up in the RCCL the process has already loaded (torch ships its own librccl.so and
+// ProcessGroupNCCL hands out its ncclComm_t): no second RCCL, no second communicator.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include "../../include/nerfloam_hip.h"
+
+namespace {
+
+enum { X_OK = 0, X_ERR_INVALID_ARG = 1, X_ERR_LAUNCH = 2, X_ERR_NO_DEVICE = 3 };
+enum { CNT_STRIDE = NL_CNT_INTS + 2 * NL_CNT_DOUBLES };        // ints per counter block (24)
+
+// the subset of rccl.h this file needs (values are NCCL's public ABI: ncclDataType_t, ncclRedOp_t)
+typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*group_fn)(void);
+enum { RCCL_INT32 = 2, RCCL_FLOAT32 = 7, RCCL_FLOAT64 = 8, RCCL_INT8 = 0, RCCL_SUM = 0 };
+
+struct Rccl {
+    allgather_fn all_gather = nullptr;
+    allreduce_fn all_reduce = nullptr;
+    group_fn group_start = nullptr, group_end = nullptr;
+    bool ok = false;
+};
+
+Rccl& rccl()
+{
+    static Rccl r = [] {
+        Rccl x;
+        void* h = dlopen(nullptr, RTLD_NOW | RTLD_GLOBAL);                       // whatever RCCL the process already holds (torch's)
+        if (!h || !dlsym(h, "ncclAllReduce")) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h || !dlsym(h, "ncclAllReduce")) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return x;
+        x.all_gather = (allgather_fn)dlsym(h, "ncclAllGather");
+        x.all_reduce = (allreduce_fn)dlsym(h, "ncclAllReduce");
+        x.group_start = (group_fn)dlsym(h, "ncclGroupStart");
+        x.group_end = (group_fn)dlsym(h, "ncclGroupEnd");
+        x.ok = x.all_gather && x.all_reduce && x.group_start && x.group_end;
+        return x;
+    }();
+    return r;
+}
+
+int rccl_all_gather(void* ctx, const void* send, void* recv, long long bytes, void* stream)
+{
+    return rccl().all_gather(send, recv, (size_t)bytes, RCCL_INT8, ctx, (hipStream_t)stream) == 0 ? X_OK : X_ERR_LAUNCH;
+}
+int rccl_all_reduce_sum(void* ctx, void* buf, long long count, int dtype, void* stream)
+{
+    const int dt = dtype == NL_COMM_F32 ? RCCL_FLOAT32 : dtype == NL_COMM_F64 ? RCCL_FLOAT64 : dtype == NL_COMM_I32 ? RCCL_INT32 : -1;
+    if (dt < 0) return X_ERR_INVALID_ARG;
+    return rccl().all_reduce(buf, buf, (size_t)count, dt, RCCL_SUM, ctx, (hipStream_t)stream) == 0 ? X_OK : X_ERR_LAUNCH;
+}
+int rccl_group_begin(void*) { return rccl().group_start() == 0 ? X_OK : X_ERR_LAUNCH; }
+int rccl_group_end(void*) { return rccl().group_end() == 0 ? X_OK : X_ERR_LAUNCH; }
+
+bool comm_ok(const NlComm* c)
+{
+    return c && c->world >= 1 && c->rank >= 0 && c->rank < c->world && c->all_gather && c->all_reduce_sum && c->group_begin && c->group_end;
+}
+
+}  // namespace
+
+#define X_TRY(call) do { const int rc__ = (call); if (rc__ != X_OK) return rc__; } while (0)
+
+extern "C" {
+
+int nl_comm_init_rccl(NlComm* out, void* nccl_comm, int world, int rank)
+{
+    if (!out || !nccl_comm || world < 1 || rank < 0 || rank >= world) return X_ERR_INVALID_ARG;
+    if (!rccl().ok) return X_ERR_NO_DEVICE;
+    out->world = world; out->rank = rank; out->ctx = nccl_comm;
+    out->all_gather = rccl_all_gather; out->all_reduce_sum = rccl_all_reduce_sum;
+    out->group_begin = rccl_group_begin; out->group_end = rccl_group_end;
+    return X_OK;
+}
+
+int nl_exchange_after_intersect(const NlIterDesc* d, void* stream)
+{
+    if (!d || !comm_ok(d->comm) || !d->counters || !d->xg_recv || d->xg_stride < CNT_STRIDE || !d->row_first || d->row_first_entries <= 0)
+        return X_ERR_INVALID_ARG;
+    const NlComm* c = d->comm;
+    X_TRY(c->all_gather(c->ctx, d->counters, d->xg_recv, CNT_STRIDE * 4, stream));
+    X_TRY(nl_dist_merge_counters(d->xg_recv, c->world, c->rank, 1, d->counters, stream));
+    X_TRY(nl_dist_row_first(d->counters, d->hit_idx, d->hit_count, d->ray_of_rank, d->row_first, d->row_first_entries, stream));
+    return c->all_reduce_sum(c->ctx, d->row_first, (long long)d->row_first_entries * (1 + NL_MAX_HITS), NL_COMM_I32, stream);
+}
+
+int nl_exchange_after_sampling(const NlIterDesc* d, void* stream)
+{
+    if (!d || !comm_ok(d->comm) || !d->counters || !d->xg_recv || d->xg_stride < CNT_STRIDE || !d->loss_scalars) return X_ERR_INVALID_ARG;
+    const NlComm* c = d->comm;
+    const bool rows = d->want_emb_grad && d->rows_mode == 1;
+    if (!rows) {
+        X_TRY(c->all_gather(c->ctx, d->counters, d->xg_recv, CNT_STRIDE * 4, stream));
+        X_TRY(nl_dist_merge_counters(d->xg_recv, c->world, c->rank, 2, d->counters, stream));
+    } else {
+        // send block = [counter block | bitmap of the embedding rows this rank's hit voxels reference]
+        const int stride = CNT_STRIDE + d->rows_words;
+        if (!d->xg_send || d->xg_stride < stride || (stride & 1) || !d->rows_bitmap || !d->rows_prefix || !d->rows_total || !d->rows_ws || d->rows_words <= 0)
+            return X_ERR_INVALID_ARG;
+        hipStream_t st = (hipStream_t)stream;
+        if (hipMemcpyAsync(d->xg_send, d->counters, CNT_STRIDE * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return X_ERR_LAUNCH;
+        if (hipMemsetAsync(d->xg_send + CNT_STRIDE, 0, (size_t)d->rows_words * 4, st) != hipSuccess) return X_ERR_LAUNCH;
+        X_TRY(nl_dist_mark_rows(d->N, d->hit_idx, d->hit_count, d->vertex_rows, (unsigned*)(d->xg_send + CNT_STRIDE), stream));
+        X_TRY(c->all_gather(c->ctx, d->xg_send, d->xg_recv, (long long)stride * 4, stream));
+        X_TRY(nl_dist_merge_counters_strided(d->xg_recv, stride, c->world, c->rank, 2, d->counters, stream));
+        X_TRY(nl_dist_rows_union_prefix(d->xg_recv, stride, CNT_STRIDE, c->world, d->rows_bitmap, d->rows_words, d->rows_prefix, d->rows_total,
+                                        d->rows_ws, stream));
+    }
+    return nl_loss_finalize(d->counters, d->loss_scalars, d->fs_weight, d->sdf_weight, d->truncation, d->max_distance, d->P_cap, stream);
+}
+
+int nl_exchange_gradients(const NlIterDesc* d, void* stream)
+{
+    if (!d || !comm_ok(d->comm)) return X_ERR_INVALID_ARG;
+    const NlComm* c = d->comm;
+    const bool rows = d->want_emb_grad && d->rows_mode == 1;
+    int* fail = d->adam_state ? d->adam_state + 3 : nullptr;             // the latched "call invalid" word (nl_optimiser_step)
+    if (d->want_emb_grad && !d->g_emb) return X_ERR_INVALID_ARG;
+    if (rows) {
+        if (!d->rows_buf || d->rows_cap <= 0 || !d->rows_bitmap || !d->rows_prefix) return X_ERR_INVALID_ARG;
+        // slots beyond the union are never unpacked, so the buffer needs no clearing
+        X_TRY(nl_dist_rows_move(0, d->rows_bitmap, d->rows_prefix, d->rows_words, d->g_emb, d->rows_buf, d->rows_cap, fail, stream));
+    }
+    X_TRY(c->group_begin(c->ctx));
+    int rc = X_OK;
+    if (rc == X_OK && d->train_decoder) rc = c->all_reduce_sum(c->ctx, d->dec_grad, NL_DEC_PARAMS, NL_COMM_F32, stream);
+    if (rc == X_OK && d->want_pose_grad) rc = c->all_reduce_sum(c->ctx, d->g_pose, (long long)d->F * 12, NL_COMM_F64, stream);
+    if (rc == X_OK && d->want_emb_grad)
+        rc = rows ? c->all_reduce_sum(c->ctx, d->rows_buf, (long long)d->rows_cap * NL_EMB_CHANNELS, NL_COMM_F32, stream)
+                  : c->all_reduce_sum(c->ctx, d->g_emb, d->n_emb_elems, NL_COMM_F32, stream);
+    const int rc_end = c->group_end(c->ctx);
+    if (rc != X_OK) return rc;
+    if (rc_end != X_OK) return rc_end;
+    if (rows) X_TRY(nl_dist_rows_move(1, d->rows_bitmap, d->rows_prefix, d->rows_words, d->g_emb, d->rows_buf, d->rows_cap, fail, stream));
+    return X_OK;
+}
+
+}  // extern "C"

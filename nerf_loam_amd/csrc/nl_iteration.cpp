@@ -13,7 +13,8 @@ enum { IT_R = 0, IT_R_GLOBAL = 13, IT_OK = 0, IT_ERR_INVALID_ARG = 1, IT_ERR_LAU
 
 extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
 {
-    if (!d || d->N <= 0 || d->F <= 0 || !(stages & 3)) return IT_ERR_INVALID_ARG;
+    if (!d || d->N <= 0 || d->F <= 0 || !(stages & 7)) return IT_ERR_INVALID_ARG;
+    const bool sharded = d->comm != nullptr;                    // ray-sharded multi-GPU iteration: the exchanges of nl_exchange.cpp ride along
     hipStream_t st = (hipStream_t)stream;
     int rc = IT_OK;
 #define NL_TRY(call) do { rc = (call); if (rc != IT_OK) return rc; } while (0)
@@ -27,6 +28,19 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
                                      d->voxel_size, d->max_distance, d->rays_d_world, d->gt_dist, d->hit_idx, d->hit_t0, d->hit_t1, d->hit_count, c,
                                      d->ray_of_rank, d->hit_rank, c + IT_R, c + IT_R_GLOBAL, d->scan_ws, stream));
         const unsigned* mix = d->fresh_noise ? (const unsigned*)d->adam_state : nullptr;
+        if (sharded) {
+            // exchange 1 -> global hit ranks + the batch rows' first-ray hit lists; count, scan, emit on the local rays; exchange 2 ->
+            // global loss normalisers (+ the union of the touched embedding rows)
+            NL_TRY(nl_exchange_after_intersect(d, stream));
+            for (int emit = 0; emit < 2; ++emit) {
+                NL_TRY(nl_sample_rays(emit, d->N, d->hit_idx, d->hit_t0, d->hit_t1, d->hit_count, d->hit_rank, d->ray_of_rank, d->cos_gt, d->gt_dist,
+                                      d->step_size, d->truncation, d->max_distance, d->noise_seed, d->use_hash_noise, d->tail_always, d->ray_id_base,
+                                      mix, d->row_first, c, d->samp_count, emit ? d->samp_off : nullptr, d->P_cap, emit ? d->s_vox : nullptr,
+                                      emit ? d->s_depth : nullptr, emit ? d->s_dist : nullptr, emit ? d->s_ray : nullptr, stream));
+                if (!emit) NL_TRY(nl_exclusive_scan_i32(d->samp_count, d->samp_off, d->N, 0, c + 3 /* NLC_P */, d->scan_ws, stream));
+            }
+            NL_TRY(nl_exchange_after_sampling(d, stream));
+        } else
         // count pass + offset scan + loss normalisers + emit pass: one launch up to 8192 rays (needs sample_state), four beyond
         NL_TRY(nl_sample_rays_fused(d->N, d->hit_idx, d->hit_t0, d->hit_t1, d->hit_count, d->hit_rank, d->ray_of_rank, d->cos_gt, d->gt_dist,
                                     d->step_size, d->truncation, d->max_distance, d->noise_seed, d->use_hash_noise, d->tail_always, d->ray_id_base, mix,
@@ -44,6 +58,7 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
                                 d->centres, d->vertex_rows, d->emb, d->voxel_size, d->dX, d->want_emb_grad ? d->g_emb : nullptr,
                                 d->want_pose_grad ? d->g_pose : nullptr, 2 * d->field_blocks, stream));
     }
+    if ((stages & 4) && sharded) NL_TRY(nl_exchange_gradients(d, stream));
     if (stages & 2) {
         const bool hand_over = d->counters_copy && (stages & 1);       // only a whole iteration leaves the block to the next one
         NL_TRY(nl_optimiser_step_ex(d->adam_state, d->lr_emb, d->lr_dec, d->lr_pose,

@@ -277,9 +277,8 @@ __global__ void k_adam_advance(int* __restrict__ state, const int* __restrict__ 
 // folds the gathered blocks into the local one - instead of one collective per quantity and a dozen tiny torch kernels.
 //   stage 1 (after intersect): global hit-ray count, this rank's hit-rank offset, global max hits per ray
 //   stage 2 (after counting):  summed loss normalisers / flags, max samples per ray, summed padded-slot constants
-__global__ void k_dist_merge(const int* __restrict__ gathered, int world, int rank, int stage, int* __restrict__ counters)
+__global__ void k_dist_merge(const int* __restrict__ gathered, int STRIDE, int world, int rank, int stage, int* __restrict__ counters)
 {
-    constexpr int STRIDE = NL_CNT_INTS + 2 * NL_CNT_DOUBLES;
     const int t = threadIdx.x;
     if (stage == 1) {
         if (t == 0) {
@@ -311,12 +310,19 @@ __global__ void k_dist_merge(const int* __restrict__ gathered, int world, int ra
 
 extern "C" {
 
-int nl_dist_merge_counters(const int* gathered, int world, int rank, int stage, int* counters, void* stream)
+int nl_dist_merge_counters_strided(const int* gathered, int stride_ints, int world, int rank, int stage, int* counters, void* stream)
 {
-    if (!gathered || !counters || world <= 0 || rank < 0 || rank >= world || (stage != 1 && stage != 2)) return NL_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_dist_merge, dim3(1), dim3(64), 0, (hipStream_t)stream, gathered, world, rank, stage, counters);
+    if (!gathered || !counters || world <= 0 || rank < 0 || rank >= world || (stage != 1 && stage != 2) ||
+        stride_ints < NL_CNT_INTS + 2 * NL_CNT_DOUBLES || (stride_ints & 1))            // (the doubles of a block stay 8-byte aligned)
+        return NL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_dist_merge, dim3(1), dim3(64), 0, (hipStream_t)stream, gathered, stride_ints, world, rank, stage, counters);
     NL_LAUNCH_CHECK();
     return NL_OK;
+}
+
+int nl_dist_merge_counters(const int* gathered, int world, int rank, int stage, int* counters, void* stream)
+{
+    return nl_dist_merge_counters_strided(gathered, NL_CNT_INTS + 2 * NL_CNT_DOUBLES, world, rank, stage, counters, stream);
 }
 
 int nl_adam_prepare(int* state, double lr_emb, double lr_dec, double lr_pose, void* stream)

@@ -1,44 +1,46 @@
 """Ray-sharded data parallelism of the SDF iteration over the GPUs of one node (RCCL over xGMI).
 
-The reference has no distributed code.  Rays are independent up to three reductions
-(SURVEY 8e), which are the three exchange points of SdfEngine.forward_backward:
+The reference has no distributed code.  Rays are independent up to three reductions:
 
-  1. after intersect : all-gather (R_rank, Hmax_rank)  -> global hit-ray count / this rank's hit-rank
-                       offset (the sampler's tail quirk depends on a ray's GLOBAL rank)
-                       and the global max hit count.
-  2. after counting  : all-reduce SUM of the loss normalisers (front / sdf mask counts, the
-                       padded-slot constants) and MAX of S = max samples per ray
-                       (criterion.py:84-88 weights and the R*S mean divisor are global quantities).
-  3. after backward  : all-reduce SUM of the decoder gradient (started on a side stream as soon as the slabs are
-                       reduced: it runs under the embedding scatter kernel), of the fp64 pose partials [F,12] and of
-                       the embedding-gradient accumulators - dense ([E,16] fp32) on a small map, or only the rows
-                       the iteration touches (below); every rank then applies the identical optimiser step to
-                       its replica.
+  1. after intersect : the sampler's tail quirk depends on a ray's GLOBAL hit rank and on the hit list of the first ray of its batch
+                       row (sample_gpu.cu:231): all-gather of the 96-byte counter blocks (-> global hit-ray count, this
+                       rank's hit-rank offset, global max hits), then a SUM all-reduce of the 200 x ceil(L / 800) row-first hit lists
+                       (which rays those are is known only after the first collective).  With them the samples of a sharded run are
+                       bit-identical to the unsharded run.
+  2. after sampling  : criterion.py:84-88 weights and the R*S mean divisor are global: all-gather of the counter blocks (loss
+                       normalisers SUM, max samples per ray MAX), the touched-rows bitmaps riding along.
+  3. gradients       : ONE grouped SUM all-reduce of the decoder gradient, the fp64 pose partials [F,12] and the embedding accumulators -
+                       dense ([E,16] fp32) on a small map, or only the rows the iteration touches; every rank then applies the identical
+                       optimiser step to its replica.
 
-One process per GPU, torch.distributed backend "nccl" (= RCCL on ROCm); on CPU test rigs "gloo".
-Exchanges 1 and 2 are latency-bound, so each is ONE collective: every rank all-gathers its whole 96-byte counter block
-and a one-block kernel (nl_dist_merge_counters) folds the gathered blocks into the local one (sums, max, rank offset) -
-not one collective per quantity plus a dozen tiny torch kernels.  Exchange 3 all-reduces the gradients IN PLACE: the
-decoder gradient and the embedding accumulators are re-homed once into one flat buffer [decoder | embeddings], so there is
-nothing to pack or unpack (0.28 MB + 64 B per embedding row); the fp64 pose partials (96 B per frame) go in their own
-collective, issued first so that it runs under the large one.
-The sampler's tail loop consults the hit list of the first ray of a ray's batch row (sample_gpu.cu:231); under
-sharding that ray may live on another rank.  Exchange 1 therefore also all-reduces the 200 x ceil(L / 800) row-first hit lists
-(nl_dist_row_first: every rank fills the rows it owns, 84 B each), so the samples of a sharded run are bit-identical to the
-unsharded one (tests/test_gpu_parity.py).
+Where the exchanges run.  On the GPU they are issued FROM C, on the stream the kernels run on (csrc/nl_exchange.cpp: nl_exchange_* /
+inside nl_iteration), through a four-function communicator (NlComm, include/nerfloam_hip.h):
 
-Embedding gradients over touched rows (a long sequence has millions of rows, an iteration touches rays x hits x 8 at most):
-every rank marks the rows of the voxels its rays hit in a bitmap (E / 8 bytes), the bitmaps are OR-all-reduced, the union's rows
-are packed in row order into a [capacity, 16] buffer, SUM-all-reduced and unpacked (csrc/nl_dist.hip).  The capacity is fixed per
-call from the first iteration's count (x 1.5; one host read per call) - collective sizes must be known on the host - and a
-device flag invalidates the call if a later iteration exceeds it (never silently).  Dense when the union is most of the table.
-"""
+  backend "rccl"  : librccl's ncclAllGather / ncclAllReduce / ncclGroupStart / ncclGroupEnd on the ncclComm_t torch.distributed's
+                    ProcessGroupNCCL already holds (`_comm_ptr()`), resolved from the RCCL already loaded in the process.  A sharded
+                    iteration is ONE C call with no host work between its launches, and hipGraph-capturable (SdfEngine.capture_iteration).
+  backend "torch" : the same four entry points as ctypes callbacks onto torch.distributed collectives over the registered buffers - any
+                    process group works (and the virtual-rank tests' in-process stand-in).  Not capturable.
+
+Only all-gather and SUM all-reduce are used: ProcessGroupNCCL / RCCL has no bitwise reductions, the union of the touched-rows bitmaps is
+an all-gather + OR kernel.  Host tensors (the gloo test rig of tests/test_dist_gloo.py, no GPU in the loop) take the same exchanges
+through torch.distributed with the merge arithmetic in torch.
+
+Embedding gradients over touched rows (a long sequence has millions of rows, an iteration touches rays x hits x 8 at most): every rank
+marks the rows of the voxels its rays hit in a bitmap (E / 8 bytes, sent with exchange 2), the union's rows are packed in row order (prefix
+sum of the word popcounts: identical on every rank) into a [capacity, 16] buffer, SUM-all-reduced and unpacked.  The capacity is fixed
+per call from the first iteration's count (x 1.5; ONE host read per call, between the backward pass and the gradient exchange of the first
+iteration: collective sizes must be known on the host) and a device flag invalidates the call if a later iteration exceeds it (never
+silently).  Dense when the union is most of the table (the single-scan bench map)."""
+import ctypes
+
 import torch
 import torch.distributed as dist
 
 from . import _lib as L
 
 assert (L.NLC_NFS, L.NLC_GUARD) == (4, 11)          # the summed counters are the contiguous slots NFS .. GUARD (nl_common.h)
+CNT_STRIDE = L.NL_CNT_BYTES // 4                    # ints per counter block
 
 
 def shard_bounds(n, rank, world):
@@ -61,41 +63,204 @@ def interleaved_order(n, world):
     return idx[idx < n]
 
 
+def row_first_entries(n_rays_total):
+    """table size of nl_dist_row_first: 200 batch rows x ceil(L / 800) chunks, L = rays per batch row"""
+    return 200 * (((n_rays_total + 199) // 200 + 799) // 800)
+
+
+class _TorchComm:
+    """NlComm backend "torch": the four communicator entry points as ctypes callbacks onto torch.distributed collectives.  The C side
+    passes raw device pointers; the exchange registers every buffer it hands to the library, a pointer is resolved to the registered
+    tensor that contains it."""
+
+    def __init__(self, group, world, rank):
+        self.group, self.world, self.rank = group, world, rank
+        self.buffers = {}                    # data_ptr -> flat tensor
+        self.error = None
+        self._cb = (L.NL_COMM_ALL_GATHER(self._all_gather), L.NL_COMM_ALL_REDUCE(self._all_reduce), L.NL_COMM_GROUP(self._group),
+                    L.NL_COMM_GROUP(self._group))
+        self.struct = L.NlComm(world, rank, None, *self._cb)
+
+    def register(self, *tensors):
+        for t in tensors:
+            if t is not None:
+                self.buffers[t.data_ptr()] = t.detach().reshape(-1)
+
+    def _view(self, ptr, nbytes):
+        for base, t in self.buffers.items():
+            end = base + t.numel() * t.element_size()
+            if base <= ptr and ptr + nbytes <= end:
+                off = (ptr - base) // t.element_size()
+                return t[off:off + nbytes // t.element_size()]
+        raise L.NerfLoamHipError(f"communicator: pointer {ptr:#x} (+{nbytes}) is not inside a registered buffer")
+
+    def _guard(self, fn):
+        try:
+            fn()
+            return 0
+        except BaseException as e:            # noqa: BLE001 - a callback must not raise through C; re-raised by RayShardedExchange._check
+            self.error = e
+            return 2
+
+    def _all_gather(self, ctx, send, recv, nbytes, stream):
+        def run():
+            s = self._view(send, nbytes)
+            r = self._view(recv, nbytes * self.world)
+            assert s.dtype == r.dtype
+            dist.all_gather_into_tensor(r, s, group=self.group)
+        return self._guard(run)
+
+    def _all_reduce(self, ctx, buf, count, dtype, stream):
+        def run():
+            size = {L.NL_COMM_F32: 4, L.NL_COMM_F64: 8, L.NL_COMM_I32: 4}[dtype]
+            t = self._view(buf, count * size)
+            assert t.dtype == {L.NL_COMM_F32: torch.float32, L.NL_COMM_F64: torch.float64, L.NL_COMM_I32: torch.int32}[dtype]
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return self._guard(run)
+
+    def _group(self, ctx):
+        return 0
+
+
 class RayShardedExchange:
-    def __init__(self, engine, group=None, sparse_rows="auto"):
-        """sparse_rows: "auto" (touched-rows exchange when it moves less than half of the dense table), True, False"""
+    def __init__(self, engine, group=None, sparse_rows="auto", backend="auto"):
+        """sparse_rows: "auto" (touched-rows exchange when it moves less than half of the dense table), True, False.
+        backend: "rccl" | "torch" | "auto" (rccl when the process group is ProcessGroupNCCL and exposes its communicator)."""
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.eng = engine
-        dev = engine.counters.device
-        self._stride = L.NL_CNT_BYTES // 4
-        self._gather = torch.zeros(self.world * self._stride, dtype=torch.int32, device=dev)
-        self._flat = None
         self.sparse_rows = sparse_rows
-        self._row_first = None               # [entries][1 + NL_MAX_HITS] i32
-        self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-        self._dec_work = None
-        self._rows = None                    # touched-rows state: bitmap, prefix, buffers, capacity (per map size)
-        self._rows_cap = None                # per optimisation call: None = measure at the next iteration
+        self._rows = None                    # touched-rows state: bitmap, prefix, buffers (per map size)
+        self._rows_cap = None                # per optimisation call: None = measure at the next iteration, "dense", or the capacity
+        self.device = engine.counters.is_cuda
+        self._gather = torch.zeros(self.world * CNT_STRIDE, dtype=torch.int32, device=engine.counters.device)
         engine.hook_after_intersect = self.after_intersect
         engine.hook_after_count = self.after_count
-        engine.hook_after_decoder_grads = self.after_decoder_grads
         engine.hook_after_backward = self.after_backward
         engine._exchange = self
+        if self.device:
+            self._setup_device(backend)
+
+    # ------------------------------------------------------------------ device side: communicator + descriptor fields
+    def _setup_device(self, backend):
+        eng = self.eng
+        dev = eng.counters.device
+        self._torch_comm = None
+        if backend == "auto":
+            backend = "rccl" if self._nccl_comm_ptr() else "torch"
+        if backend == "rccl":
+            ptr = self._nccl_comm_ptr()
+            if not ptr:
+                raise L.NerfLoamHipError("backend 'rccl' needs a ProcessGroupNCCL with an initialised communicator "
+                                         "(init_process_group('nccl', device_id=...)); use backend='torch' otherwise")
+            self.comm = L.NlComm()
+            L.check(L.lib().nl_comm_init_rccl(ctypes.byref(self.comm), ctypes.c_void_p(ptr), self.world, self.rank), "nl_comm_init_rccl")
+        elif backend == "torch":
+            self._torch_comm = _TorchComm(self.group, self.world, self.rank)
+            self.comm = self._torch_comm.struct
+        else:
+            raise ValueError(backend)
+        self.backend = backend
+        self._entries = row_first_entries(eng.N_cap * self.world)
+        self._row_first = torch.zeros(self._entries, 1 + L.NL_MAX_HITS, dtype=torch.int32, device=dev)
+        eng.row_first = self._row_first
+        self._xg_stride = CNT_STRIDE
+        self._xg_send = None
+        self._xg_recv = self._gather
+        self._fill_desc()
+
+    def _nccl_comm_ptr(self):
+        try:
+            if dist.get_backend(self.group) != "nccl":
+                return 0
+            from torch.distributed import distributed_c10d as c10d
+            pg = self.group if self.group is not None else c10d._get_default_group()
+            be = pg._get_backend(self.eng.counters.device)
+            return int(be._comm_ptr())
+        except Exception:                    # noqa: BLE001 - no RCCL communicator to borrow: the torch backend carries the exchanges
+            return 0
+
+    def _fill_desc(self):
+        d, eng = self.eng._desc, self.eng
+        d.comm = ctypes.cast(ctypes.pointer(self.comm), ctypes.c_void_p)
+        d.xg_send = None if self._xg_send is None else self._xg_send.data_ptr()
+        d.xg_recv, d.xg_stride = self._xg_recv.data_ptr(), self._xg_stride
+        d.row_first, d.row_first_entries = self._row_first.data_ptr(), self._entries
+        st = self._rows
+        if st is None:
+            d.rows_mode, d.rows_bitmap, d.rows_prefix, d.rows_total, d.rows_ws, d.rows_buf, d.rows_cap, d.rows_words = 0, None, None, None, None, None, 0, 0
+        else:
+            d.rows_bitmap, d.rows_prefix, d.rows_total, d.rows_ws = (st[k].data_ptr() for k in ("bitmap", "prefix", "total", "ws"))
+            d.rows_words = st["nw"]
+            if isinstance(self._rows_cap, int):
+                d.rows_mode, d.rows_buf, d.rows_cap = 1, st["buf"].data_ptr(), self._rows_cap
+            else:                                                          # undecided: measure (mode 1 computes the union); dense: mode 0
+                d.rows_mode, d.rows_buf, d.rows_cap = (1 if self._rows_cap is None else 0), None, 0
+        if self._torch_comm is not None:
+            tc = self._torch_comm
+            tc.buffers.clear()
+            tc.register(eng.counters, self._xg_recv, self._xg_send, self._row_first, eng.g_pose, eng.g_emb, None if st is None else st.get("buf"))
+            dec = getattr(eng, "_dec_for_exchange", None)
+            if dec is not None:
+                tc.register(dec.grad)
+
+    def _check(self, rc, what):
+        if rc != 0 and self._torch_comm is not None and self._torch_comm.error is not None:
+            e, self._torch_comm.error = self._torch_comm.error, None
+            raise e
+        L.check(rc, what)
 
     def new_call(self):
         """a new optimisation call (new frames / ray counts): re-measure the touched-rows capacity at its first iteration"""
         self._rows_cap = None
 
-    def _merge(self, c, stage):
-        """fold the gathered counter blocks into the local block `c`"""
-        if c.is_cuda:
-            L.check(L.lib().nl_dist_merge_counters(L.ptr(self._gather), self.world, self.rank, stage, L.ptr(c),
-                                                   torch.cuda.current_stream().cuda_stream), "nl_dist_merge_counters")
+    def prepare(self, m, dec, want_emb_grad):
+        """(re)size the touched-rows state for the map's table and point the engine's descriptor at the exchange buffers; called by
+        SdfEngine.bind / forward_backward before the first exchange of an iteration"""
+        eng = self.eng
+        eng._dec_for_exchange = dec
+        if not self.device:
             return
-        # host tensors: the gloo test rig of tests/test_dist_gloo.py (no GPU in the loop) - same arithmetic in torch
-        g = self._gather.view(self.world, self._stride)
+        if want_emb_grad and self.sparse_rows is not False and eng.g_emb is not None:
+            E = eng.g_emb.shape[0]
+            st = self._rows
+            if st is None or st["E"] != E:
+                dev = eng.g_emb.device
+                nw = ((E + 31) // 32 + 1) & ~1                          # even: the doubles of the gathered counter blocks stay aligned
+                st = dict(E=E, nw=nw, bitmap=torch.zeros(nw, dtype=torch.int32, device=dev), prefix=torch.zeros(nw, dtype=torch.int32, device=dev),
+                          total=torch.zeros(1, dtype=torch.int32, device=dev), ws=torch.zeros(nw + (nw + 1023) // 1024 + 8, dtype=torch.int32, device=dev),
+                          buf=None)
+                self._rows = st
+                self._rows_cap = None
+                self._xg_stride = CNT_STRIDE + nw
+                self._xg_send = torch.zeros(self._xg_stride, dtype=torch.int32, device=dev)
+                self._xg_recv = torch.zeros(self.world * self._xg_stride, dtype=torch.int32, device=dev)
+        elif self.sparse_rows is False:
+            self._rows_cap = "dense"
+        self._fill_desc()
+
+    def rows_undecided(self):
+        return bool(self.device and self._rows is not None and self._rows_cap is None and self.eng._desc.want_emb_grad)
+
+    def decide_rows(self):
+        """first iteration of a call, after its backward pass: ONE host read of the union's row count fixes the exchange of the whole
+        call - dense, or touched rows with capacity 1.5 x the count"""
+        st = self._rows
+        E = st["E"]
+        u = int(st["total"].item())
+        cap = min(E, -(-int(1.5 * u + 1024) // 4096) * 4096)
+        if self.sparse_rows == "auto" and 2 * cap > E:
+            self._rows_cap = "dense"
+        else:
+            self._rows_cap = cap
+            if st["buf"] is None or st["buf"].shape[0] < cap:
+                st["buf"] = torch.zeros(cap, L.NL_C, dtype=torch.float32, device=self.eng.g_emb.device)
+        self._fill_desc()
+
+    # ------------------------------------------------------------------ host-tensor rig (gloo tests): the merge arithmetic in torch
+    def _merge_host(self, c, stage):
+        g = self._gather.view(self.world, CNT_STRIDE)
         if stage == 1:
             c[L.NLC_R_GLOBAL] = g[:, L.NLC_R].sum()
             c[L.NLC_R_OFFSET] = g[:self.rank, L.NLC_R].sum()
@@ -106,99 +271,73 @@ class RayShardedExchange:
             gd = g[:, L.NL_CNT_INTS:].contiguous().view(torch.float64)
             c[L.NL_CNT_INTS:].view(torch.float64)[L.NLD_INV_D2:L.NLD_INV_D2CNT + 1] = gd[:, L.NLD_INV_D2:L.NLD_INV_D2CNT + 1].sum(0)
 
-    # exchange 1
-    def after_intersect(self, eng):
-        dist.all_gather_into_tensor(self._gather, eng.counters, group=self.group)
-        self._merge(eng.counters, 1)
-        if eng.counters.is_cuda and getattr(eng, "hit_idx", None) is not None:
-            # the batch rows' first-ray hit lists (the sampler's tail loop reads them): every rank fills the rows it owns
-            n_total = eng.N_cap * self.world
-            entries = 200 * (((n_total + 199) // 200 + 799) // 800)              # 200 batch rows x ceil(L / 800) chunks
-            if self._row_first is None or self._row_first.shape[0] < entries:
-                self._row_first = torch.zeros(entries, 1 + L.NL_MAX_HITS, dtype=torch.int32, device=eng.counters.device)
-            L.check(L.lib().nl_dist_row_first(L.ptr(eng.counters), L.ptr(eng.hit_idx), L.ptr(eng.hit_count), L.ptr(eng.ray_of_rank),
-                                              L.ptr(self._row_first), self._row_first.shape[0], L.stream_ptr()), "nl_dist_row_first")
-            dist.all_reduce(self._row_first, op=dist.ReduceOp.SUM, group=self.group)
-            eng.row_first = self._row_first
+    def _merge(self, c, stage):
+        """fold the gathered counter blocks (self._gather) into the block `c`: the kernel on device tensors, torch on host tensors"""
+        if c.is_cuda:
+            L.check(L.lib().nl_dist_merge_counters(L.ptr(self._gather), self.world, self.rank, stage, L.ptr(c), L.stream_ptr()), "nl_dist_merge_counters")
+        else:
+            RayShardedExchange._merge_host(self, c, stage)
 
-    # exchange 2
-    def after_count(self, eng):
-        dist.all_gather_into_tensor(self._gather, eng.counters, group=self.group)
-        self._merge(eng.counters, 2)
-
-    # exchange 3a: the decoder gradient, as soon as it exists - on a side stream, under the embedding scatter kernel
-    def after_decoder_grads(self, eng, dec):
-        if self._side is None:
-            dist.all_reduce(dec.grad, op=dist.ReduceOp.SUM, group=self.group)
-            return
-        self._side.wait_stream(torch.cuda.current_stream(dec.grad.device))
-        with torch.cuda.stream(self._side):
-            dist.all_reduce(dec.grad, op=dist.ReduceOp.SUM, group=self.group)
-
-    def _rows_state(self, eng, E):
-        st = self._rows
-        if st is None or st["E"] != E:
-            dev = eng.g_emb.device
-            nw = (E + 31) // 32
-            st = dict(E=E, nw=nw, bitmap=torch.zeros(nw, dtype=torch.int32, device=dev), prefix=torch.zeros(nw, dtype=torch.int32, device=dev),
-                      total=torch.zeros(1, dtype=torch.int32, device=dev), ws=torch.zeros(nw + (nw + 1023) // 1024 + 8, dtype=torch.int32, device=dev),
-                      buf=None)
-            self._rows = st
-            self._rows_cap = None
-        return st
-
-    def _exchange_embedding_rows(self, eng, m):
-        """touched rows only; returns False when the dense exchange should be used for this call"""
-        E = eng.g_emb.shape[0]
-        st = self._rows_state(eng, E)
-        if self._rows_cap == "dense":
-            return False
-        lib, sp = L.lib(), L.stream_ptr()
-        st["bitmap"].zero_()
-        L.check(lib.nl_dist_mark_rows(eng.N, L.ptr(eng.hit_idx), L.ptr(eng.hit_count), L.ptr(m.vertex_rows), L.ptr(st["bitmap"]), sp), "nl_dist_mark_rows")
-        # union of the ranks' bitmaps: all-gather + OR (ProcessGroupNCCL / RCCL has no bitwise reduction: ReduceOp.BOR raises there)
-        if st.get("gathered") is None or st["gathered"].numel() != self.world * st["nw"]:
-            st["gathered"] = torch.empty(self.world * st["nw"], dtype=torch.int32, device=st["bitmap"].device)
-        dist.all_gather_into_tensor(st["gathered"], st["bitmap"], group=self.group)
-        g = st["gathered"].view(self.world, st["nw"])
-        torch.bitwise_or(g[0], g[1], out=st["bitmap"]) if self.world > 1 else st["bitmap"].copy_(g[0])
-        for r in range(2, self.world):
-            st["bitmap"].bitwise_or_(g[r])
-        L.check(lib.nl_dist_rows_prefix(L.ptr(st["bitmap"]), st["nw"], L.ptr(st["prefix"]), L.ptr(st["total"]), L.ptr(st["ws"]), sp), "nl_dist_rows_prefix")
-        if self._rows_cap is None:                       # first iteration of a call: ONE host read, the capacity of the whole call
-            u = int(st["total"].item())
-            cap = min(E, -(-int(1.5 * u + 1024) // 4096) * 4096)
-            if self.sparse_rows is False or (self.sparse_rows == "auto" and 2 * cap > E):
-                self._rows_cap = "dense"
-                return False
-            self._rows_cap = cap
-            if st["buf"] is None or st["buf"].shape[0] < cap:
-                st["buf"] = torch.zeros(cap, L.NL_C, dtype=torch.float32, device=eng.g_emb.device)
-        cap = self._rows_cap
-        buf = st["buf"][:cap]
-        buf.zero_()
-        fail = eng.adam_state[3:4]                       # latched "call invalid" word (SdfEngine.call_status)
-        L.check(lib.nl_dist_rows_move(0, L.ptr(st["bitmap"]), L.ptr(st["prefix"]), st["nw"], L.ptr(eng.g_emb), L.ptr(buf), cap, L.ptr(fail), sp),
-                "nl_dist_rows_move")
+    def host_touched_rows_exchange(self, g_emb, touched_rows):
+        """the touched-rows protocol on host tensors: bitmap of `touched_rows` -> all-gather + OR -> rows of the union packed in row order
+        -> SUM all-reduce -> unpacked.  Same steps as nl_dist_mark_rows / nl_dist_rows_union_prefix / nl_dist_rows_move + the collectives
+        of nl_exchange.cpp; returns the number of rows exchanged."""
+        E = g_emb.shape[0]
+        nw = (E + 31) // 32
+        bits = torch.zeros(nw * 32, dtype=torch.bool)
+        bits[touched_rows] = True
+        w = (bits.view(nw, 32).to(torch.int64) << torch.arange(32, dtype=torch.int64)).sum(1)
+        w = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)                       # the bitmap words, as the int32 the device holds
+        gathered = torch.zeros(self.world * nw, dtype=torch.int32)
+        dist.all_gather_into_tensor(gathered, w, group=self.group)
+        union = gathered.view(self.world, nw)[0].clone()
+        for r in range(1, self.world):
+            union |= gathered.view(self.world, nw)[r]
+        u64 = torch.where(union < 0, union.to(torch.int64) + 2 ** 32, union.to(torch.int64))
+        rows = torch.nonzero(((u64[:, None] >> torch.arange(32, dtype=torch.int64)) & 1).reshape(-1))[:, 0]
+        rows = rows[rows < E]
+        buf = g_emb[rows].contiguous()
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-        L.check(lib.nl_dist_rows_move(1, L.ptr(st["bitmap"]), L.ptr(st["prefix"]), st["nw"], L.ptr(eng.g_emb), L.ptr(buf), cap, L.ptr(fail), sp),
-                "nl_dist_rows_move")
-        return True
+        g_emb[rows] = buf
+        return int(rows.numel())
 
-    # exchange 3b
+    # ------------------------------------------------------------------ the three exchange points (stage-wise path + host rig)
+    def after_intersect(self, eng):
+        if self.device:
+            eng._desc.N = eng.N
+            self._check(L.lib().nl_exchange_after_intersect(ctypes.byref(eng._desc), L.stream_ptr()), "nl_exchange_after_intersect")
+            return
+        dist.all_gather_into_tensor(self._gather, eng.counters, group=self.group)
+        self._merge_host(eng.counters, 1)
+
+    def after_count(self, eng):
+        if self.device:
+            eng._desc.N = eng.N
+            self._check(L.lib().nl_exchange_after_sampling(ctypes.byref(eng._desc), L.stream_ptr()), "nl_exchange_after_sampling")
+            return
+        dist.all_gather_into_tensor(self._gather, eng.counters, group=self.group)
+        self._merge_host(eng.counters, 2)
+
     def after_backward(self, eng, dec, train_decoder, want_emb_grad, want_pose_grad, m=None):
-        """the fp64 pose partials, the embedding accumulators (touched rows or dense), and the join with the decoder all-reduce"""
+        if self.device:
+            if self.rows_undecided():
+                self.decide_rows()
+            eng._desc.F = eng.F
+            self._check(L.lib().nl_exchange_gradients(ctypes.byref(eng._desc), L.stream_ptr()), "nl_exchange_gradients")
+            return
+        if train_decoder:
+            dist.all_reduce(dec.grad, op=dist.ReduceOp.SUM, group=self.group)
         if want_pose_grad:
             dist.all_reduce(eng.g_pose[:eng.F], op=dist.ReduceOp.SUM, group=self.group)
         if want_emb_grad:
-            m = m if m is not None else getattr(eng, "_map_for_exchange", None)
-            sparse = (m is not None and eng.g_emb.is_cuda and self.sparse_rows is not False and self._exchange_embedding_rows(eng, m))
-            if not sparse:
+            touched = getattr(eng, "touched_rows", None)
+            if touched is not None and self.sparse_rows is not False:
+                self.host_touched_rows_exchange(eng.g_emb, touched)
+            else:
                 dist.all_reduce(eng.g_emb, op=dist.ReduceOp.SUM, group=self.group)
-        if train_decoder and self._side is not None:
-            torch.cuda.current_stream(dec.grad.device).wait_stream(self._side)
 
     def reduce_loss_sums(self):
+        """the squared-residual sums of the loss VALUE (logging only; the gradients never need them)"""
         c = self.eng.counters
         dbl = c[L.NL_CNT_INTS:].view(torch.float64)[L.NLD_FS_SQ:L.NLD_SDF_SQ + 1]
         dist.all_reduce(dbl, op=dist.ReduceOp.SUM, group=self.group)

@@ -11,7 +11,8 @@ max samples S, valid samples P, loss normalisers) stay in a device counter block
 runs WITHOUT a host synchronisation and with a fixed launch sequence (hipGraph-capturable).
 The only torch ops on the path are a memset and two 4-byte device copies.
 
-Multi-GPU (dist.py): rays are sharded; the three exchange points are marked `hook_*`.
+Multi-GPU (dist.py): rays are sharded; nl_iteration issues the exchanges itself (communicator in the descriptor), the stage-wise
+path reaches the same C exchange functions through the `hook_*` points.
 """
 import ctypes
 from dataclasses import dataclass, field
@@ -246,7 +247,7 @@ class SdfEngine:
         self.graph = None
         # multi-GPU hooks (dist.py installs them); identity on one GPU
         self.row_first = None    # multi-GPU: table of the batch rows' first-ray hit lists (dist.py, nl_dist_row_first)
-        self.hook_after_decoder_grads = None
+        self._exchange = None    # multi-GPU: dist.RayShardedExchange (its communicator rides in the descriptor: nl_iteration exchanges itself)
         self.hook_after_intersect = None
         self.hook_after_count = None
         self.hook_after_backward = None
@@ -399,7 +400,9 @@ class SdfEngine:
         N = self.N
         c = self.counters
         tm = self._mark
-        self._map_for_exchange = m                               # multi-GPU hooks look the map's row table up here
+        if self._exchange is not None:                           # multi-GPU: the hooks run the C exchanges on the engine's descriptor
+            self._fill_desc(m, dec, cfg, train_decoder=train_decoder, want_emb_grad=want_emb_grad, want_pose_grad=want_pose_grad,
+                            update_emb=want_emb_grad, ray_id_base=ray_id_base, fresh_noise=fresh_noise)
         c.zero_()
         self._stats_from_copy = False                            # stage-wise iterations count into (and leave) the live block
         self._desc.counters_clean = 0
@@ -442,8 +445,6 @@ class SdfEngine:
             tm("reduce", 0)
             ops.decoder_reduce(self.partials, self.n_slabs, dec.params, dec.grad, self.kernel_modes)
             tm("reduce", 1)
-            if self.hook_after_decoder_grads is not None:
-                self.hook_after_decoder_grads(self, dec)         # multi-GPU: the decoder all-reduce starts under the embedding scatter
         tm("scatter", 0)
         ops.trilinear_bwd(self.loss_scalars, self.s_vox, self.s_depth, self.s_ray, self.rays_d_world, self.rays_d_sensor, self.frame_id,
                           self.poses12, self.F, m.centres, m.vertex_rows, m.emb, m.voxel_size, self.dX,
@@ -515,10 +516,18 @@ class SdfEngine:
         hyper-parameter once, so that run_bound() is ONE ctypes call per iteration instead of ~15 calls with ~250 marshalled
         arguments.  Call again when the map, the decoder, the configuration or the flags change (tensors are looked up here, not in
         the loop).  Not used when multi-GPU hooks or stage timers are installed (forward_backward / optimiser_step then)."""
-        if any(h is not None for h in (self.hook_after_intersect, self.hook_after_count, self.hook_after_decoder_grads, self.hook_after_backward)):
-            raise L.NerfLoamHipError("bind() / run_bound(): stage hooks are installed on this engine (they run only on the stage-wise "
-                                     "path forward_backward + optimiser_step); a ray-sharded engine exchanges inside nl_iteration "
-                                     "through its communicator (dist.RayShardedExchange) instead")
+        if self._exchange is None and any(h is not None for h in (self.hook_after_intersect, self.hook_after_count, self.hook_after_backward)):
+            raise L.NerfLoamHipError("bind() / run_bound(): stage hooks are installed on this engine, and they run only on the stage-wise "
+                                     "path forward_backward + optimiser_step (a ray-sharded engine - dist.RayShardedExchange - is fine: "
+                                     "nl_iteration issues its exchanges itself through the descriptor's communicator)")
+        if self._exchange is not None and not self._exchange.device:
+            raise L.NerfLoamHipError("bind() / run_bound() need device tensors")
+        self._fill_desc(m, dec, cfg, train_decoder, want_emb_grad, want_pose_grad, update_emb, update_decoder, update_pose, lr_pose, skip_mode,
+                        fresh_noise, ray_id_base)
+        self._bound = (m, dec)                                       # keeps the tensors the descriptor points at alive
+
+    def _fill_desc(self, m, dec, cfg, train_decoder=True, want_emb_grad=True, want_pose_grad=True, update_emb=True, update_decoder=True,
+                   update_pose=True, lr_pose=None, skip_mode=0, fresh_noise=False, ray_id_base=0):
         d = self._desc
         pt = lambda t: None if t is None else t.data_ptr()          # noqa: E731
         for name in ("rays_d_sensor", "points_gt", "cos_gt", "frame_id", "pose6", "poses12", "pose_m", "pose_v", "pose_enable", "g_pose", "pose_grad6",
@@ -543,18 +552,34 @@ class SdfEngine:
         d.counters_copy, d.counters_clean = pt(self.counters_copy), 0
         d.sample_state = pt(self.sample_state)
         d.kernel_modes = self.kernel_modes
-        self._bound = (m, dec)                                       # keeps the tensors the descriptor points at alive
+        d.N, d.F = self.N, self.F
+        if self._exchange is not None:
+            self._exchange.prepare(m, dec, bool(want_emb_grad))
 
     def run_bound(self, stages=3):
         """one iteration of the bound configuration: stages bit 0 = forward + backward, bit 1 = optimiser step"""
         d = self._desc
         d.N, d.F = self.N, self.F
-        L.check(L.lib().nl_iteration(ctypes.byref(d), int(stages), L.stream_ptr()), "nl_iteration")
+        stages = int(stages)
+        ex = self._exchange
+        if ex is None:
+            L.check(L.lib().nl_iteration(ctypes.byref(d), stages, L.stream_ptr()), "nl_iteration")
+        elif not (stages & 1):
+            ex._check(L.lib().nl_iteration(ctypes.byref(d), stages, L.stream_ptr()), "nl_iteration")
+        elif ex.rows_undecided():
+            # first iteration of a call on a touched-rows map: forward + backward, ONE host read sizes the row exchange of the whole
+            # call (collective sizes must be known on the host), then the gradient exchange and the optimiser step
+            ex._check(L.lib().nl_iteration(ctypes.byref(d), 1, L.stream_ptr()), "nl_iteration")
+            ex.decide_rows()
+            ex._check(L.lib().nl_iteration(ctypes.byref(d), 4 | (stages & 2), L.stream_ptr()), "nl_iteration")
+            stages &= ~2                                         # (two calls: the counter block was not handed over - see below)
+        else:
+            ex._check(L.lib().nl_iteration(ctypes.byref(d), stages | 4, L.stream_ptr()), "nl_iteration")     # one C call, exchanges included
         # a whole iteration ends with its counter block handed to counters_copy and the live block cleared for the next one
         # (no memset launch then); a forward-only call leaves the block in place
-        whole = (int(stages) & 3) == 3
+        whole = (stages & 3) == 3
         d.counters_clean = int(whole)
-        if int(stages) & 1:
+        if stages & 1:
             self._stats_from_copy = whole
 
     # ------------------------------------------------------------------ hipGraph

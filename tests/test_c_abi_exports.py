@@ -101,3 +101,22 @@ def test_fails_loudly_without_gpu():
     from nerf_loam_amd import grid
     with pytest.raises(RuntimeError):
         grid.svo_intersect(torch.zeros(1, 2, 3), torch.zeros(1, 2, 3), torch.zeros(1, 1, 3), torch.zeros(1, 1, 9, dtype=torch.int32), 0.2, 20)
+
+
+def test_rccl_binding_resolves_from_the_rccl_torch_loaded():
+    """nl_comm_init_rccl (the communicator of the ray-sharded iteration) binds ncclAllGather / ncclAllReduce / ncclGroupStart / ncclGroupEnd
+    from the RCCL already in the process - torch's own copy - instead of loading a second one (two RCCLs = two sets of globals).  No
+    collective is issued here (no GPU); the world-1 RCCL run is tests/test_gpu_dist_rccl.py."""
+    import ctypes
+    import torch  # noqa: F401
+    import torch.distributed  # noqa: F401
+    lib = _lib.lib()
+    comm = _lib.NlComm()
+    dummy = ctypes.c_void_p(0x1000)
+    assert lib.nl_comm_init_rccl(ctypes.byref(comm), dummy, 2, 1) == 0
+    assert (comm.world, comm.rank, comm.ctx) == (2, 1, 0x1000)
+    assert all(ctypes.cast(f, ctypes.c_void_p).value for f in (comm.all_gather, comm.all_reduce_sum, comm.group_begin, comm.group_end))
+    assert lib.nl_comm_init_rccl(ctypes.byref(comm), dummy, 2, 2) != 0 and lib.nl_comm_init_rccl(ctypes.byref(comm), None, 1, 0) != 0
+    paths = {line.split()[-1] for line in open("/proc/self/maps") if "librccl" in line}
+    assert len(paths) == 1, paths                                    # one RCCL in the process
+    assert os.path.dirname(next(iter(paths))) == os.path.join(os.path.dirname(torch.__file__), "lib"), paths

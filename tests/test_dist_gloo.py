@@ -28,6 +28,12 @@ def _worker(rank, world, port, out_q):
         c = torch.zeros(L.NL_CNT_BYTES // 4, dtype=torch.int32)
         eng = SimpleNamespace(counters=c, g_pose=torch.full((2, 12), float(rank + 1), dtype=torch.float64), F=2, g_emb=torch.full((5, 16), 10.0 * (rank + 1)),
                               hook_after_intersect=None, hook_after_count=None, hook_after_backward=None)
+        dist_ops = []
+        for name in ("all_reduce", "all_gather_into_tensor"):            # record what travels: (collective, reduce op)
+            def rec(*a, _f=getattr(dist, name), _n=name, **k):
+                dist_ops.append((_n, str(k.get("op", ""))))
+                return _f(*a, **k)
+            setattr(D.dist, name, rec)
         dec = SimpleNamespace(grad=torch.arange(7, dtype=torch.float32) * (rank + 1))
         ex = D.RayShardedExchange(eng)
         assert eng.hook_after_intersect is not None
@@ -44,12 +50,19 @@ def _worker(rank, world, port, out_q):
         r2 = (int(c[L.NLC_NFS]), int(c[L.NLC_NSDF]), int(c[L.NLC_INV_SDF_RAYS]), int(c[L.NLC_INV_SDF_CNT]), int(c[L.NLC_SMAX]),
               int(c[L.NLC_P]), float(dbl[L.NLD_INV_D2]), float(dbl[L.NLD_INV_D2CNT]), float(dbl[L.NLD_FS_SQ]))
         # exchange 3
-        ex.after_decoder_grads(eng, dec)                        # (the engine calls it right after the slab reduction)
-        ex.after_backward(eng, dec, True, True, True)
+        ex.after_backward(eng, dec, True, True, True)           # decoder gradient, fp64 pose partials, dense embedding accumulators
         r3 = (dec.grad.tolist(), float(eng.g_pose[0, 0]), float(eng.g_emb[0, 0]))
         ex.reduce_loss_sums()
         r4 = float(dbl[L.NLD_FS_SQ])
-        out_q.put((rank, r1, r2, r3, r4))
+        # exchange 3 over touched rows: a 1000-row table, rank 0 touched rows {3, 31, 32, 700}, rank 1 {31, 64, 999}; only all-gather and
+        # SUM all-reduce travel (what ProcessGroupNCCL / RCCL implements: no bitwise reduction)
+        eng.g_emb = torch.zeros(1000, 16)
+        eng.touched_rows = torch.tensor([3, 31, 32, 700] if rank == 0 else [31, 64, 999])
+        eng.g_emb[eng.touched_rows] = float(rank + 1)
+        ex.after_backward(eng, dec, False, True, False)
+        r5 = (sorted(torch.nonzero(eng.g_emb.abs().sum(1))[:, 0].tolist()), eng.g_emb[[3, 31, 32, 64, 700, 999], 0].tolist())
+        assert {op for n, op in dist_ops if n == "all_reduce"} <= {"RedOpType.SUM", "ReduceOp.SUM"}, dist_ops
+        out_q.put((rank, r1, r2, r3, r4, r5))
     finally:
         dist.destroy_process_group()
 
@@ -65,7 +78,8 @@ def test_exchanges_world2_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, a1, a2, a3, a4), (_, b1, b2, b3, b4) = res
+    (_, a1, a2, a3, a4, a5), (_, b1, b2, b3, b4, b5) = res
+    assert a5 == b5 == ([3, 31, 32, 64, 700, 999], [1.0, 3.0, 1.0, 2.0, 1.0, 2.0])      # union of the rows, summed where both touched
     assert a1 == (210, 0, 10, 100) and b1 == (210, 100, 10, 110)            # global R, rank offsets, global Hmax, local R kept
     assert a2[:5] == b2[:5] == (11, 101, 4, 27, 19)                          # sums / max are global ...
     assert a2[6:8] == b2[6:8] == (4.5, 0.5)

@@ -988,7 +988,7 @@ class _ThreadRanks:
             raise NotImplementedError(op)
 
 
-def _sharded_vs_single(nl, golden_dir, monkeypatch, world, pad_rows=0, sparse_rows="auto"):
+def _sharded_vs_single(nl, golden_dir, monkeypatch, world, pad_rows=0, sparse_rows="auto", one_call=False):
     """ray-sharded iteration (the exchanges of nerf_loam_amd/dist.py, real kernels, `world` ranks as threads on one GPU) against the
     unsharded one on the same ray list"""
     import threading
@@ -1015,16 +1015,24 @@ def _sharded_vs_single(nl, golden_dir, monkeypatch, world, pad_rows=0, sparse_ro
         eng.set_rays(rays[lo:hi], pts[lo:hi], cos[lo:hi], fid[lo:hi])
         eng.set_poses(poses, [1] * nf)
         eng.begin_call(m, dec)
-        eng.forward_backward(m, dec, cfgP, train_decoder=True, ray_id_base=lo)
+        if one_call and ex is not None:                          # nl_iteration issues the exchanges itself (communicator in the descriptor)
+            eng.bind(m, dec, cfgP, train_decoder=True, ray_id_base=lo)
+            eng.run_bound(1)
+        else:
+            eng.forward_backward(m, dec, cfgP, train_decoder=True, ray_id_base=lo)
         torch.cuda.synchronize()
         st = eng.stats()
         if ex is not None:
             ex.reduce_loss_sums()
             info["rows_cap"] = ex._rows_cap
+            info["backend"] = ex.backend
         out = dict(P=st["P"], R=st["R"], S=st["S"], sdf=eng.sdf[:st["P"]].cpu().numpy(), depth=eng.s_depth[:st["P"]].cpu().numpy(),
                    vox=eng.s_vox[:st["P"]].cpu().numpy(), loss=eng.loss_value(cfgP)["loss"], gdec=dec.grad.cpu().numpy().copy(),
                    gemb=eng.g_emb.cpu().numpy().copy(), gpose=eng.g_pose.cpu().numpy().copy())
-        eng.optimiser_step(m, dec, cfgP)
+        if one_call and ex is not None:
+            eng.run_bound(2)
+        else:
+            eng.optimiser_step(m, dec, cfgP)
         torch.cuda.synchronize()
         assert not eng.call_status()[2]
         out.update(params=dec.params.cpu().numpy().copy(), emb=m.emb.cpu().numpy().copy(), pose6=eng.pose6[:nf].cpu().numpy().copy())
@@ -1066,13 +1074,17 @@ def _sharded_vs_single(nl, golden_dir, monkeypatch, world, pad_rows=0, sparse_ro
     return info
 
 
-def test_two_virtual_ranks_match_the_single_rank_iteration(nl, golden_dir, monkeypatch):
-    _sharded_vs_single(nl, golden_dir, monkeypatch, 2)
+@pytest.mark.parametrize("one_call", [False, True])
+def test_two_virtual_ranks_match_the_single_rank_iteration(nl, golden_dir, monkeypatch, one_call):
+    """the C exchanges (csrc/nl_exchange.cpp) through the callback communicator, from the stage-wise hooks and from inside nl_iteration"""
+    info = _sharded_vs_single(nl, golden_dir, monkeypatch, 2, one_call=one_call)
+    assert info["rows_cap"] == "dense" and info["backend"] == "torch"
 
 
-def test_eight_virtual_ranks_with_the_touched_rows_exchange(nl, golden_dir, monkeypatch):
+@pytest.mark.parametrize("one_call", [False, True])
+def test_eight_virtual_ranks_with_the_touched_rows_exchange(nl, golden_dir, monkeypatch, one_call):
     """8 ranks, an embedding table 30x the rows the iteration touches: the embedding gradients travel as [capacity, 16] touched rows"""
-    info = _sharded_vs_single(nl, golden_dir, monkeypatch, 8, pad_rows=400000, sparse_rows="auto")
+    info = _sharded_vs_single(nl, golden_dir, monkeypatch, 8, pad_rows=400000, sparse_rows="auto", one_call=one_call)
     assert isinstance(info["rows_cap"], int) and info["rows_cap"] < 100000
 
 
