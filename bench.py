@@ -49,12 +49,10 @@ def matrix_pipe_model(kernel, gemm_mode, wgrad2_mode, train):
     if kernel == "decoder":
         alg = FLOPS_PER_SAMPLE_DECODER if train else FLOPS_PER_SAMPLE_DECODER_FROZEN
         small = L1 * (3 if train else 2)                        # layer-1 forward, dX, (dW1)
-        if gemm_mode in (1, 2):                                 # forward: 3x3 split (mode 2: six of the nine products), dgrad: {0,1} mask x
-            return alg, small - L1, (9 if gemm_mode == 1 else 6) * G + 3 * G + 9 * L1   # 3-term split; layer-1 forward: 3x3 split too
-        if gemm_mode in (3, 4):                                 # the chained family: layer 1 on the fp32 pipe
-            return alg, small, (9 if gemm_mode == 3 else 6) * G + 3 * G
+        if gemm_mode in (1, 2, 3):                              # forward: 3x3 split (9, 8 or 6 of the nine products), dgrad: {0,1} mask x
+            return alg, small - L1, {1: 9, 3: 8, 2: 6}[gemm_mode] * G + 3 * G + 9 * L1   # 3-term split; layer-1 forward: 3x3 split too
         return alg, small + 2 * G, 0
-    if wgrad2_mode == 1 or gemm_mode >= 3:
+    if wgrad2_mode == 1:
         return FLOPS_PER_SAMPLE_WGRAD2, 0, 3 * G + 9 * L1       # H1 rebuilt as 3x3 bf16 products; mask x 3-term split
     return FLOPS_PER_SAMPLE_WGRAD2, L1 + G, 0
 
@@ -560,13 +558,13 @@ def main():
     stage_ms, stage_bytes, hbm_entries = stage_rooflines(eng, w, cfg, train_dec) if not shard else ({}, {}, [])
     if rank == 0:
         gm, wm = _lib.lib().nl_decoder_get_gemm_mode(), _lib.lib().nl_decoder_get_wgrad2_mode()
-        kname = ("k_decoder_chain" if gm >= 3 else "k_decoder") + ("<train>" if train_dec else "<frozen>")
+        kname = "k_decoder" + ("<train>" if train_dec else "<frozen>")
         rf = roofline_entry(kname, "decoder", dec_ms, P_local, gm, wm, train_dec)
         rf = {"bound": "mfma", **rf,
-              "traffic": pmc_traffic(("k_decoder<true, %s>" if train_dec else "k_decoder<false, %s>") % ("true" if gm >= 1 else "false")) if gm in (0, 1) else None,
+              "traffic": pmc_traffic(("k_decoder<true, %s>" if train_dec else "k_decoder<false, %s>") % ("true" if gm >= 1 else "false")),
               "traffic_source": "committed rocprofv3 PMC passes of this command (newest profiles/r*_pmc_summary.json), not measured in this run",
               "peak_note": ("matrix-pipe bound of the kernel's instruction mix: "
-                            + (f"256-deep GEMMs as {'exact-product ' if gm in (1, 3) else ''}bf16 splits ({9 if gm in (1, 3) else 6} + 3 MFMAs per fp32 product, 2500 TF pipe), "
+                            + (f"256-deep GEMMs as bf16 three-term splits ({ {1: 9, 3: 8, 2: 6}.get(gm, 9)} of 9 forward + 3 dgrad MFMAs per fp32 product, 2500 TF pipe), "
                                "layer-1 forward as nine bf16 products too, dX / dW1 (K=16) on the fp32 pipe (157.3 TF)" if gm >= 1 else "all GEMMs on the fp32 pipe (157.3 TF)")),
               "second_kernel": (roofline_entry("k_decoder_wgrad2_x" if wm == 1 else "k_decoder_wgrad2", "wgrad2", wg_ms, P_local, gm, wm, True)
                                 if train_dec else None)}
@@ -576,8 +574,9 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "dtype_note": ("fp32 values and fp32 accumulation throughout; the decoder's 256-deep GEMMs are evaluated on the bf16 "
-                           "matrix cores as exact-product splits (each fp32 operand = 3 bf16 terms exactly; ReLU masks are {0,1}), "
-                           "NL_GEMM_MODE=0 / NL_WGRAD2_MODE=0 select the plain fp32-MFMA kernels" if (gm >= 1 or wm == 1)
+                           "matrix cores as exact-product splits (each fp32 operand = 3 bf16 terms exactly; ReLU masks are {0,1}); the "
+                           "forward GEMM forms " + {1: "all nine", 3: "eight of the nine (without lo x lo: < 2^-30 of a product)", 2: "six of the nine"}.get(gm, "?")
+                           + " partial products; NL_GEMM_MODE=1 = all nine, NL_GEMM_MODE=0 / NL_WGRAD2_MODE=0 = the plain fp32-MFMA kernels" if (gm >= 1 or wm == 1)
                            else "fp32 MFMA kernels (NL_GEMM_MODE=0, NL_WGRAD2_MODE=0)"),
             "config": {"workload": "synthetic 64x2048 scan (131072 rays), 1 mapping iteration/step: intersect+sample+gather+"
                                    "decoder fwd/bwd+SDF loss+emb/decoder/pose grads+Adam; voxel 0.2 m, step 0.1 m, "

@@ -29,7 +29,7 @@ extern "C" {
 #define NL_CNT_DOUBLES 4        /* ... followed by double sums: counter block = 16*4 + 4*8 bytes */
 #define NL_LOSS_SCALARS_BYTES 48
 #define NL_DEC_PARAMS 70401     /* W1[256x16] b1[256] W2[256x256] b2[256] W3[256] b3[1] */
-#define NL_DEC_WS_FLOATS 458752    /* decoder weight workspace: W2^T fp32 + 4 x 3 bf16 operand planes (two kernel families) */
+#define NL_DEC_WS_FLOATS 262144    /* decoder weight workspace: W2^T fp32 + 2 x 3 bf16 operand planes */
 #define NL_EMB_CHANNELS 16
 
 /* Multi-GPU ray sharding: fold the all-gathered counter blocks gathered[world][NL_CNT_INTS + 2*NL_CNT_DOUBLES] (ints) into
@@ -171,8 +171,7 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
                        int* counters, void* stream);
 /* The same four decoder entry points with the kernel selection passed per call instead of taken from the process-wide defaults
  * (nl_decoder_set_gemm_mode / nl_decoder_set_wgrad2_mode below): kernel_modes = NL_KERNEL_MODES(gemm_mode, wgrad2_mode), either
- * mode -1 (or kernel_modes == 0) = the process default.  All calls of one iteration (fwd_bwd, wgrad2, reduce) must agree: the slab
- * formats differ between the families.  NlIterDesc.kernel_modes carries the same word for nl_iteration. */
+ * mode -1 (or kernel_modes == 0) = the process default.  NlIterDesc.kernel_modes carries the same word for nl_iteration. */
 #define NL_KERNEL_MODES(gemm_mode, wgrad2_mode) ((((gemm_mode) + 1) & 0xFF) | ((((wgrad2_mode) + 1) & 0xFF) << 8))
 int nl_decoder_fwd_bwd_m(const void* loss_scalars, const float* X, const float* params, const float* W2T,
                          const int* s_ray, const float* s_depth, const float* cos_gt, const float* gt_dist,
@@ -187,8 +186,7 @@ int nl_decoder_forward_m(const float* X, const float* params, const float* W2T, 
 int nl_decoder_wgrad2(const void* loss_scalars, const float* X, const float* params, const float* dsdf, const unsigned* relu2_mask,
                       float* partials, int nslabs, void* stream);
 /* sum of the per-workgroup slabs partials[nslabs][NL_DEC_PARAMS] written by nl_decoder_fwd_bwd + nl_decoder_wgrad2 into the decoder
- * gradient grad_out[NL_DEC_PARAMS].  Works for either kernel family (the register-chained one, gemm mode 3, leaves raw dW2 / db2
- * accumulators in the slabs and obtains dW2, db2 and dW3 from them while summing). */
+ * gradient grad_out[NL_DEC_PARAMS] */
 int nl_decoder_reduce(const float* partials, int nslabs, const float* params, float* grad_out, void* stream);
 /* dW2 kernel selection: 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32), 1 = bf16 matrix cores on the exact
  * formulation dW2[j][k] = w3_j * sum_i m(i,j) * (dsdf_i * H1[i][k]) with the {0,1} mask m as A operand and the fp32
@@ -202,19 +200,17 @@ int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, voi
  *   floats [0, 65536):        W2 transposed (fp32; forward GEMM B operand of gemm mode 0),
  *   floats [65536, 163840):   "W2X"  = w3_j * W2[j][k] as three bf16 planes (hi + mid + lo == the fp32 value exactly) in
  *                             MFMA-fragment order: dgrad GEMM B operand on the bf16 matrix cores,
- *   floats [163840, 262144):  "W2TX" = W2[n][k], same split and order: forward GEMM B operand on the bf16 matrix cores,
- *   floats [262144, 360448):  "W2A"  = W2[n][k] as three bf16 planes in the A-operand slot order of the register-chained family
- *                             (gemm modes 3 / 4: H2^T = W2 H1^T, lane = sample),
- *   floats [360448, 458752):  "W2XA" = w3_n * W2[n][k], same split, the chained family's dgrad A operand. */
+ *   floats [163840, 262144):  "W2TX" = W2[n][k], same split and order: forward GEMM B operand on the bf16 matrix cores. */
 int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream);
-/* The two 256-deep GEMMs of nl_decoder_fwd_bwd / nl_decoder_forward: 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32),
- * 1 = bf16 matrix cores (v_mfma_f32_32x32x16_bf16) on exact-product formulations (default):
- *   forward  H2 = H1 W2^T:  both operands split into three bf16 terms, all nine partial products (each exact in fp32);
+/* The two 256-deep GEMMs of nl_decoder_fwd_bwd / nl_decoder_forward: 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32);
+ * 1, 2, 3 = bf16 matrix cores (v_mfma_f32_32x32x16_bf16) on exact-product formulations:
+ *   forward  H2 = H1 W2^T:  both operands split into three bf16 terms (v = hi + mid + lo exactly), partial products exact in fp32;
  *   dgrad    dH1[i][k] = dsdf_i * sum_j m(i,j) * (w3_j W2[j][k]),  m = the {0,1} ReLU mask as A operand, B split in three.
- * Accumulation is fp32 in both modes; results differ by summation order only.
- * 2 = mode 1 with six of the nine forward products (without lo x lo, lo x mid, mid x lo: below 2^-24 of a product, i.e. below the
- *     rounding of the fp32 accumulation; two thirds of the matrix-pipe time).  Opt-in: not exact, never a default.
- * 3 = the register-chained kernel family (nl_decoder_chain.hip) with all nine products, 4 = that family with six.
+ * Accumulation is fp32 in every mode.
+ * 1 = all nine forward products: the exact fp32 x fp32 products (results differ from mode 0 by summation order only).
+ * 3 = eight of the nine (without lo x lo, below 2^-30 of a product = 2^-6 of one fp32 rounding; bound proven on the host in rational
+ *     arithmetic, tests/test_device_math_host.py): THE DEFAULT, 8/9 of the forward matrix-pipe time.
+ * 2 = six (also without lo x mid, mid x lo: below 2^-24 of a product): opt-in, never a default.
  * These two setters change the PROCESS-WIDE DEFAULT used by the entry points without a kernel_modes argument (A/B measurements,
  * NL_GEMM_MODE / NL_WGRAD2_MODE of the Python package); callers that need their own selection pass it per call (*_m, NlIterDesc). */
 int nl_decoder_set_gemm_mode(int mode);

@@ -289,13 +289,15 @@ __device__ __forceinline__ void gemm_x9_prefetch(i32x4 rsX, int w, int lane, uin
         for (int p = 0; p < 3; ++p) bq[s][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + nt_off + s * 1024);
 }
 
-// NP = 9: all nine partial products (exact).  NP = 6: without lo x lo, lo x mid, mid x lo - terms below 2^-24 of the product,
+// NP = 9: all nine partial products (exact).  NP = 8 (the default): without lo x lo - |x_lo| < 2^-15 |x| for both factors, so the
+// dropped term is below 2^-30 of the product, 2^-6 of one rounding of the fp32 accumulation that follows (bound checked in rational
+// arithmetic on the host, tests/test_device_math_host.py) - at 8/9 of the matrix-pipe time.  NP = 6: without lo x lo, lo x mid, mid x lo - terms below 2^-24 of the product,
 // i.e. below the rounding of the fp32 accumulation itself (measured on a 4096 x 256 x 256 case: rms error 7e-9 of sum|a||b|
 // against 2.6e-8 for an fp32 GEMM's own rounding) - at two thirds of the matrix-pipe time.
 template <bool PIN, int NP = 9>
 __device__ __forceinline__ void gemm_x9(i32x4 rsX, int w, int lane, const unsigned char* sP, uint4 (&bq)[X9_RING][3], f32x16& c0, f32x16& c1)
 {
-    static_assert(NP == 9 || NP == 6, "nine or six partial products");
+    static_assert(NP == 9 || NP == 8 || NP == 6, "nine, eight or six partial products");
     const int l31 = lane & 31, lh = lane >> 5;
     const int voff = lane * 16;
     const int nt_off = __builtin_amdgcn_readfirstlane(w) * 16 * 1024;     // wave-uniform scalar offset (no waterfall loops)
@@ -316,7 +318,8 @@ __device__ __forceinline__ void gemm_x9(i32x4 rsX, int w, int lane, const unsign
         const int sn = (g + 1) / 3, pn = 2 - (g + 1) % 3;
 #pragma unroll
         for (int pb = 2; pb >= 0; --pb) {
-            if (!(NP == 6 && (2 - g % 3) + pb > 2)) {                  // A plane (2 - g % 3) x B plane pb: keep hi/mid/lo index sums <= 2
+            // A plane (2 - g % 3) x B plane pb (0 = hi, 1 = mid, 2 = lo).  NP = 6 keeps the index sums <= 2, NP = 8 drops lo x lo only
+            if (!(NP == 6 && (2 - g % 3) + pb > 2) && !(NP == 8 && (2 - g % 3) + pb > 3)) {
                 const bf16x8 fb = __builtin_bit_cast(bf16x8, bq[s % RING][pb]);
                 c0 = MFMA_BF16(fa0, fb, c0); c1 = MFMA_BF16(fa1, fb, c1);
             }
@@ -833,11 +836,6 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2(const NlLossS
 #define WX_TOTAL (WX_OFF_DS + 2 * DEC_M * 4)
 
 
-// NAT (the register-chained family, nl_decoder_chain.hip): the mask words come in NATURAL order - word (32-sample tile, unit), bit b
-// = sample b - so the k-slot order inside a half tile is the sample order (the producer stores its 4-row groups as 8-byte pieces),
-// the accumulators are flushed RAW (G = dW2 / w3) and g[n] = sum_i m2(i,n) dsdf_i goes into the slab's b2 block: nl_decoder_reduce
-// turns them into dW2, db2 and dW3 (identities in nl_decoder_chain.hip's header).
-template <bool NAT>
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLossScalars* __restrict__ lsp, const float* __restrict__ X,
                                                                       const float* __restrict__ params, const float* __restrict__ dsdf,
                                                                       const unsigned* __restrict__ relu2_mask, float* __restrict__ partials)
@@ -920,16 +918,6 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
             const float s0 = r0 - trunc_bf16(r0), s1 = r1 - trunc_bf16(r1);
             lo[q] = pack_hi16(s0, s1);
         }
-        if (NAT) {                                       // slot = sample row: rows 8 q + 4 lh + (0..3) of this lane -> 8-byte pieces
-            unsigned char* dst = sB + opaque(col * WX_STRIDE + 8 * lh + 64 * sub);
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                *reinterpret_cast<uint2*>(dst + 16 * q4) = make_uint2(hi[2 * q4], hi[2 * q4 + 1]);
-                *reinterpret_cast<uint2*>(dst + WX_PLANE + 16 * q4) = make_uint2(mid[2 * q4], mid[2 * q4 + 1]);
-                *reinterpret_cast<uint2*>(dst + 2 * WX_PLANE + 16 * q4) = make_uint2(lo[2 * q4], lo[2 * q4 + 1]);
-            }
-            return;
-        }
         unsigned char* dst = sB + opaque(col * WX_STRIDE + 32 * lh + 64 * sub);
         uint4* d0 = reinterpret_cast<uint4*>(dst);
         d0[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]); d0[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
@@ -942,12 +930,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
     // 6 groups (k-step, plane) of 8 MFMAs; the 4 B fragments of the NEXT group are read while this group's MFMAs run.
     auto consume = [&](int pb, int sub) {
         const unsigned* mk = sMask + pb * DEC_THREADS + l31;
-        unsigned mwd[2][2];                              // [row tile jt][producer lane half]; NAT: [jt][0] = the word of (sub, unit)
+        unsigned mwd[2][2];                              // [row tile jt][producer lane half]
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-            if (NAT) { mwd[jt][0] = mk[256 * sub + 64 * wj + 32 * jt]; mwd[jt][1] = 0u; }
-            else     { mwd[jt][0] = mk[(2 * wj + jt) * 64]; mwd[jt][1] = mk[(2 * wj + jt) * 64 + 32]; }
-        }
+        for (int jt = 0; jt < 2; ++jt) { mwd[jt][0] = mk[(2 * wj + jt) * 64]; mwd[jt][1] = mk[(2 * wj + jt) * 64 + 32]; }
         const unsigned char* bsrc = sB + opaque((128 * wk + l31) * WX_STRIDE + 16 * lh + 64 * sub);
         uint4 bfr[2][4];
 #pragma unroll
@@ -959,7 +944,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
             if (p3 == 0) {
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt) {
-                    const unsigned byte = NAT ? (mwd[jt][0] >> (8 * (2 * s2 + lh))) & 0xFFu : (mwd[jt][s2] >> (16 * sub + 8 * lh)) & 0xFFu;
+                    const unsigned byte = (mwd[jt][s2] >> (16 * sub + 8 * lh)) & 0xFFu;
                     af[jt] = __builtin_bit_cast(bf16x8, sLut[byte]);
                 }
             }
@@ -988,14 +973,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
     if (blockIdx.x < ntiles) produce(0, 0);
     __syncthreads();
     int par = 0;
-    float gsum = 0.f;                                    // NAT: g[unit] over this thread's 32-sample half tiles
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
-        if (NAT) {                                       // thread = (half tile tid >> 8, unit tid & 255): its word and the half's dsdf
-            const unsigned word = sMask[par * DEC_THREADS + tid];
-            const float* dsp = sdS + par * DEC_M + 32 * (tid >> 8);
-#pragma unroll
-            for (int b = 0; b < 32; ++b) gsum += ((word >> b) & 1u) ? dsp[b] : 0.f;
-        }
         // step A: inputs of the next tile -> the other buffers; planes of this tile's second half; MFMAs of its first half
         stage_inputs(par ^ 1);
         prefetch(tile + 2 * gridDim.x);
@@ -1013,17 +991,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = 64 * wj + 32 * jt + d32_row(r, lh);
-            const float w3j = NAT ? 1.f : params[NL_OFF_W3 + j];
+            const float w3j = params[NL_OFF_W3 + j];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) base[NL_OFF_W2 + j * NL_W + 128 * wk + 32 * kt + l31] = w3j * acc[jt][kt][r];
         }
-    if (NAT) {                                           // raw g[n]: the two half-tile threads of a unit combined through LDS
-        __syncthreads();
-        float* sg = reinterpret_cast<float*>(smem);
-        if (tid >= 256) sg[tid - 256] = gsum;
-        __syncthreads();
-        if (tid < 256) base[NL_OFF_B2 + tid] = gsum + sg[tid];
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1158,22 +1129,9 @@ __global__ void k_mfma_selftest(const float* A32, const float* B32, float* D32, 
 }
 
 static long long* g_dec_dbg = nullptr;
-static int g_gemm_mode = 1;              // 0: fp32 MFMA GEMMs, 1: bf16 MFMA on the exact-product formulations (gemm_x9 / gemm_mask_x),
-                                         // 2: as 1 with six of the nine forward products (gemm_x9<.., 6>)
-static int g_chain_six = 0;              // gemm mode 4 = the chained family (3) with the six-product forward GEMM
+static int g_gemm_mode = 3;              // 0: fp32 MFMA GEMMs; bf16 MFMA on the exact-product formulations (gemm_x9 / gemm_mask_x) with
+                                         // 1: all nine forward products (exact), 3: eight (without lo x lo: the default), 2: six (opt-in)
 static int g_wgrad2_mode = 1;            // 0: fp32 MFMA (k_decoder_wgrad2), 1: exact 0/1-mask x 3-term bf16 split (k_decoder_wgrad2_x)
-
-extern "C" {
-/* nl_decoder_chain.hip */
-int nl_decoder_chain_fwd_bwd(const void* loss_scalars, const float* X, const float* params, const float* ws, const int* s_ray,
-                             const float* s_depth, const float* cos_gt, const float* gt_dist, float* sdf, float* dsdf, float* dX,
-                             float* partials, unsigned* relu2_nat, int nslabs, int train_decoder, int six_products, int* counters,
-                             void* dbg, void* stream);
-int nl_decoder_chain_forward(const float* X, const float* params, const float* ws, int P, float* sdf, int nblocks, int six_products,
-                             void* stream);
-int nl_decoder_chain_reduce(const float* partials, int nslabs, const float* params, float* grad_out, void* stream);
-
-}
 
 extern "C" {
 
@@ -1184,25 +1142,23 @@ int nl_decoder_set_debug_buffer(void* dbg) { g_dec_dbg = (long long*)dbg; return
  * Same arithmetic class (exact products, fp32 accumulation); selectable for A/B measurements and cross-checks. */
 int nl_decoder_set_wgrad2_mode(int mode) { if (mode < 0 || mode > 1) return NL_ERR_INVALID_ARG; g_wgrad2_mode = mode; return NL_OK; }
 int nl_decoder_get_wgrad2_mode(void) { return g_wgrad2_mode; }
-/* the two 256-deep GEMMs of the fused decoder kernels (forward H1 W2^T, dgrad dH2 W2): 0 = fp32 matrix cores,
- * 1 = bf16 matrix cores on exact-product formulations (default): forward = both operands split into three bf16 terms, all
- * nine partial products; dgrad = {0,1} ReLU mask x three-term split of w3_j W2[j][k].  fp32 accumulation in both.
- * 2 = as 1 with six of the nine forward products (the dropped ones are below 2^-24 of a product: below the rounding of the
- * fp32 accumulation): opt-in, not exact.  3 / 4 = the register-chained family with nine / six products.  Process-wide DEFAULTS:
- * the *_m entry points and NlIterDesc.kernel_modes take the selection per call. */
-int nl_decoder_set_gemm_mode(int mode) { if (mode < 0 || mode > 4) return NL_ERR_INVALID_ARG; g_chain_six = mode == 4; g_gemm_mode = mode == 4 ? 3 : mode; return NL_OK; }
-int nl_decoder_get_gemm_mode(void) { return g_gemm_mode == 3 && g_chain_six ? 4 : g_gemm_mode; }
+/* the two 256-deep GEMMs of the fused decoder kernels (forward H1 W2^T, dgrad dH2 W2): 0 = fp32 matrix cores; 1, 2, 3 = bf16
+ * matrix cores on exact-product formulations: forward = both operands split into three bf16 terms, dgrad = {0,1} ReLU mask x
+ * three-term split of w3_j W2[j][k], fp32 accumulation in both.  1 = all nine forward products (exact); 3 = eight, without lo x lo
+ * (below 2^-30 of a product: the default); 2 = six (the dropped ones are below 2^-24 of a product: opt-in).  Process-wide
+ * DEFAULTS: the *_m entry points and NlIterDesc.kernel_modes take the selection per call. */
+int nl_decoder_set_gemm_mode(int mode) { if (mode < 0 || mode > 3) return NL_ERR_INVALID_ARG; g_gemm_mode = mode; return NL_OK; }
+int nl_decoder_get_gemm_mode(void) { return g_gemm_mode; }
 
 }  // extern "C"
 
-struct DecModes { int gemm, six, wgrad2; };
+struct DecModes { int gemm, wgrad2; };
 // kernel_modes = NL_KERNEL_MODES(gemm_mode, wgrad2_mode) of include/nerfloam_hip.h; a zero field = the process default
 static bool resolve_modes(int kernel_modes, DecModes* m)
 {
     const int g = (kernel_modes & 0xFF) - 1, w = ((kernel_modes >> 8) & 0xFF) - 1;
-    if (g > 4 || w > 1 || (kernel_modes >> 16) != 0) return false;
-    m->gemm = g < 0 ? g_gemm_mode : (g == 4 ? 3 : g);
-    m->six = g < 0 ? g_chain_six : (g == 4);
+    if (g > 3 || w > 1 || (kernel_modes >> 16) != 0) return false;
+    m->gemm = g < 0 ? g_gemm_mode : g;
     m->wgrad2 = w < 0 ? g_wgrad2_mode : w;
     return true;
 }
@@ -1232,11 +1188,11 @@ int nl_decoder_fwd_bwd_m(const void* loss_scalars, const float* X, const float* 
     a.relu2_mask = relu2_mask;
     a.dcounters = (double*)(counters + NL_CNT_INTS);
     a.dbg = g_dec_dbg;
-    if (km.gemm == 3)
-        return nl_decoder_chain_fwd_bwd(loss_scalars, X, params, W2T, s_ray, s_depth, cos_gt, gt_dist, sdf, dsdf, dX, partials, relu2_mask,
-                                        nslabs, train_decoder, km.six, counters, g_dec_dbg, stream);
     const dim3 g(nslabs), b(DEC_THREADS);
-    if (km.gemm == 2) {
+    if (km.gemm == 3) {
+        if (train_decoder) hipLaunchKernelGGL((k_decoder<true, true, 8>), g, b, 0, (hipStream_t)stream, a);
+        else               hipLaunchKernelGGL((k_decoder<false, true, 8>), g, b, 0, (hipStream_t)stream, a);
+    } else if (km.gemm == 2) {
         if (train_decoder) hipLaunchKernelGGL((k_decoder<true, true, 6>), g, b, 0, (hipStream_t)stream, a);
         else               hipLaunchKernelGGL((k_decoder<false, true, 6>), g, b, 0, (hipStream_t)stream, a);
     } else if (km.gemm == 1) {
@@ -1266,11 +1222,8 @@ int nl_decoder_wgrad2_m(const void* loss_scalars, const float* X, const float* p
     DecModes km;
     if (!resolve_modes(kernel_modes, &km)) return NL_ERR_INVALID_ARG;
     if (!loss_scalars || !X || !params || !dsdf || !relu2_mask || !partials || nslabs <= 0) return NL_ERR_INVALID_ARG;
-    if (km.gemm == 3)                                 // the register-chained family writes natural-order ReLU words
-        hipLaunchKernelGGL(k_decoder_wgrad2_x<true>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,
-                           params, dsdf, relu2_mask, partials);
-    else if (km.wgrad2 == 1)
-        hipLaunchKernelGGL(k_decoder_wgrad2_x<false>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,
+    if (km.wgrad2 == 1)
+        hipLaunchKernelGGL(k_decoder_wgrad2_x, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,
                            params, dsdf, relu2_mask, partials);
     else
         hipLaunchKernelGGL(k_decoder_wgrad2, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,
@@ -1291,8 +1244,8 @@ int nl_decoder_forward_m(const float* X, const float* params, const float* W2T, 
     if (!resolve_modes(kernel_modes, &km)) return NL_ERR_INVALID_ARG;
     if (!X || !params || !W2T || !sdf || P < 0 || nblocks <= 0) return NL_ERR_INVALID_ARG;
     if (P == 0) return NL_OK;
-    if (km.gemm == 3) return nl_decoder_chain_forward(X, params, W2T, P, sdf, nblocks, km.six, stream);
-    if (km.gemm == 2) hipLaunchKernelGGL((k_decoder_fwd<true, 6>), dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
+    if (km.gemm == 3) hipLaunchKernelGGL((k_decoder_fwd<true, 8>), dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
+    else if (km.gemm == 2) hipLaunchKernelGGL((k_decoder_fwd<true, 6>), dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
     else if (km.gemm == 1) hipLaunchKernelGGL(k_decoder_fwd<true>, dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
     else                  hipLaunchKernelGGL(k_decoder_fwd<false>, dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
     NL_LAUNCH_CHECK();
@@ -1312,14 +1265,12 @@ int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, voi
     return NL_OK;
 }
 
-/* sum of the per-workgroup weight-gradient slabs of nl_decoder_fwd_bwd + nl_decoder_wgrad2 into the decoder gradient (either
- * kernel family: the chained one applies the dW2 / db2 / dW3 identities while summing) */
+/* sum of the per-workgroup weight-gradient slabs of nl_decoder_fwd_bwd + nl_decoder_wgrad2 into the decoder gradient */
 int nl_decoder_reduce_m(const float* partials, int nslabs, const float* params, float* grad_out, int kernel_modes, void* stream)
 {
     DecModes km;
     if (!resolve_modes(kernel_modes, &km)) return NL_ERR_INVALID_ARG;
     if (!partials || !params || !grad_out || nslabs <= 0) return NL_ERR_INVALID_ARG;
-    if (km.gemm == 3) return nl_decoder_chain_reduce(partials, nslabs, params, grad_out, stream);
     return nl_reduce_partials(partials, nslabs, NL_DEC_PARAMS, grad_out, stream);
 }
 

@@ -65,27 +65,6 @@ NL_HD void nl_split3_bf16(float v, uint16_t* hi, uint16_t* mid, uint16_t* lo) {
     *hi = (uint16_t)(a.u >> 16); *mid = (uint16_t)(b.u >> 16); *lo = (uint16_t)(r.u >> 16);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Register-chained decoder (nl_decoder_chain.hip): the 32x32 accumulator tile of v_mfma_*_32x32* holds, in lane (col, lh = lane
-// >> 5), register r, the row  (r & 3) + 8 (r >> 2) + 4 lh.  With lane = SAMPLE and rows = hidden units, a lane's 16 registers are
-// exactly two B-operand fragments (8 contraction slots each) of the next layer's MFMA - provided the weight operand uses the same
-// slot order.  These two functions ARE that order: unit u (0..31 inside its 32-unit tile) sits in register r = (u & 3) + 4 (u >> 3)
-// of lane half lh = (u >> 2) & 1, i.e. in k-step half r >> 3, element r & 7.
-// ---------------------------------------------------------------------------------------------
-NL_HD int nl_chain_unit(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
-NL_HD void nl_chain_slot(int u, int* half, int* lh, int* e) {
-    const int r = (u & 3) + 4 * (u >> 3);
-    *lh = (u >> 2) & 1; *half = r >> 3; *e = r & 7;
-}
-// element index (bf16 elements inside ONE plane) of the A-operand value with output row `row` (0..255) and contraction unit
-// `c` (0..255): planes are stored [row tile 8][k-step 16][lane 64][8 bf16], lane = 32 lh + (row & 31)
-NL_HD size_t nl_chain_a_index(int row, int c) {
-    int half, lh, e;
-    nl_chain_slot(c & 31, &half, &lh, &e);
-    const int s = 2 * (c >> 5) + half;
-    return ((size_t)(((row >> 5) * 16 + s) * 64 + 32 * lh + (row & 31))) * 8 + (size_t)e;
-}
-
 // ray-selection key (nl_select.hip): lowbias32 is a bijection on 32-bit integers, so keys of distinct rays never tie
 NL_HD uint32_t nl_select_key(uint32_t seed, uint32_t i) {
     uint32_t x = i ^ (seed * 0x9E3779B9u + 0x7F4A7C15u);

@@ -87,21 +87,6 @@ __global__ void k_prepare_w2x(const float* __restrict__ params, uint16_t* __rest
     }
 }
 
-// A-operand planes of the register-chained decoder (nl_decoder_chain.hip), slot order nl_chain_a_index (nl_device_math.h):
-//     W2A  (forward, H2^T = W2 H1^T):           row n, contraction unit k, value W2[n][k]
-//     W2XA (dgrad,   dH1^T = (w3 W2)^T mask^T): row k, contraction unit n, value w3_n * W2[n][k]
-__global__ void k_prepare_w2a(const float* __restrict__ params, uint16_t* __restrict__ W2A, uint16_t* __restrict__ W2XA)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;         // one thread per element of W2
-    if (t >= NL_W * NL_W) return;
-    const int n = t >> 8, k = t & 255;
-    const float v = params[NL_OFF_W2 + n * NL_W + k];
-    uint16_t* d = W2A + nl_chain_a_index(n, k);
-    nl_split3_bf16(v, &d[0], &d[NL_W * NL_W], &d[2 * NL_W * NL_W]);
-    d = W2XA + nl_chain_a_index(k, n);
-    nl_split3_bf16(params[NL_OFF_W3 + n] * v, &d[0], &d[NL_W * NL_W], &d[2 * NL_W * NL_W]);
-}
-
 // poses12[f] = [R(w) row-major | t]   from pose6[f] = [t, w]     (se3pose.py:18-35)
 __global__ void k_pose_matrix(const float* __restrict__ pose6, float* __restrict__ poses12, int F)
 {
@@ -152,7 +137,7 @@ __global__ void k_pose_step(float* __restrict__ pose6, double* __restrict__ g_po
 struct OptimArgs {
     int* state; double lr_emb, lr_dec, lr_pose;
     uint16_t* emb; float* g_emb; uint16_t* emb_m; uint16_t* emb_v; long long n_emb; int nb_emb;
-    float* params; const float* grad; float* dm; float* dv; float* W2T; uint16_t* W2X; uint16_t* W2TX; uint16_t* W2A; uint16_t* W2XA; int nb_dec;
+    float* params; const float* grad; float* dm; float* dv; float* W2T; uint16_t* W2X; uint16_t* W2TX; int nb_dec;
     float* pose6; double* g_pose; float* pm; float* pv; const int* enable; float* grad6_out; float* poses12; int F; int apply_pose;
     const int* counters; int skip_mode;
     int* snap_src; int* snap_dst;        // optional: the counter block is copied to snap_dst and CLEARED by the launch's last step, so that the
@@ -233,12 +218,6 @@ __global__ void __launch_bounds__(256) k_optim_step(OptimArgs a)
             }
             {   // dgrad planes: value w3_j * W2[j][k] at row index j (the reduction index), column k
                 uint16_t* d = a.W2X + (size_t)((((k >> 5) * 16 + (j >> 4)) * 64) + 32 * ((j >> 3) & 1) + (k & 31)) * 8 + (j & 7);
-                nl_split3_bf16(w3 * p, &d[0], &d[NL_W * NL_W], &d[2 * NL_W * NL_W]);
-            }
-            {   // the register-chained kernels' A-operand planes (k_prepare_w2a)
-                uint16_t* d = a.W2A + nl_chain_a_index(j, k);
-                nl_split3_bf16(p, &d[0], &d[NL_W * NL_W], &d[2 * NL_W * NL_W]);
-                d = a.W2XA + nl_chain_a_index(k, j);
                 nl_split3_bf16(w3 * p, &d[0], &d[NL_W * NL_W], &d[2 * NL_W * NL_W]);
             }
         } else {
@@ -368,8 +347,6 @@ int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream)
     hipLaunchKernelGGL(k_transpose_w2, dim3(NL_W / 32, NL_W / 32), dim3(32, 8), 0, (hipStream_t)stream, params, W2T);
     hipLaunchKernelGGL(k_prepare_w2x, dim3(8 * 16 * 64 / 256), dim3(256), 0, (hipStream_t)stream, params,
                        reinterpret_cast<uint16_t*>(W2T + NL_W * NL_W), reinterpret_cast<uint16_t*>(W2T + NL_W * NL_W + 3 * NL_W * NL_W / 2));
-    hipLaunchKernelGGL(k_prepare_w2a, dim3(NL_W * NL_W / 256), dim3(256), 0, (hipStream_t)stream, params,
-                       reinterpret_cast<uint16_t*>(W2T + NL_W * NL_W + 6 * NL_W * NL_W / 2), reinterpret_cast<uint16_t*>(W2T + NL_W * NL_W + 9 * NL_W * NL_W / 2));
     NL_LAUNCH_CHECK();
     return NL_OK;
 }
@@ -413,8 +390,6 @@ int nl_optimiser_step_ex(int* state, double lr_emb, double lr_dec, double lr_pos
     a.params = dec_params; a.grad = dec_grad; a.dm = dec_m; a.dv = dec_v; a.W2T = dec_ws;
     a.W2X = dec_ws ? reinterpret_cast<uint16_t*>(dec_ws + NL_W * NL_W) : nullptr;
     a.W2TX = dec_ws ? reinterpret_cast<uint16_t*>(dec_ws + NL_W * NL_W + 3 * NL_W * NL_W / 2) : nullptr;
-    a.W2A = dec_ws ? reinterpret_cast<uint16_t*>(dec_ws + NL_W * NL_W + 6 * NL_W * NL_W / 2) : nullptr;
-    a.W2XA = dec_ws ? reinterpret_cast<uint16_t*>(dec_ws + NL_W * NL_W + 9 * NL_W * NL_W / 2) : nullptr;
     a.nb_dec = dec_params ? OPT_DEC_BLOCKS : 0;
     a.pose6 = pose6; a.g_pose = g_pose; a.pm = pose_m; a.pv = pose_v; a.enable = pose_enable; a.grad6_out = grad6_out;
     a.poses12 = poses12; a.F = pose6 ? F : 0; a.apply_pose = apply_pose;

@@ -10,7 +10,6 @@ eng = P.SdfEngine(max_rays=len(w["points"]), samples_per_ray_cap=48)
 eng.set_rays(w["dirs"], w["points"], w["cos"]); eng.set_poses(w["pose"][None], [1])
 cfg = P.IterConfig(); eng.begin_call(w["map"], w["dec"])
 dbg = torch.zeros(256, dtype=torch.int64, device="cuda")
-CHAIN = L.lib().nl_decoder_get_gemm_mode() >= 3
 for train in (True, False):
     for _ in range(2):
         eng.forward_backward(w["map"], w["dec"], cfg, train_decoder=train)
@@ -18,16 +17,6 @@ for train in (True, False):
     eng.forward_backward(w["map"], w["dec"], cfg, train_decoder=train)
     torch.cuda.synchronize()
     L.lib().nl_decoder_set_debug_buffer(None)
-    if CHAIN:
-        d = dbg.cpu().numpy().reshape(16, 16)[:, :11]
-        names = ["layer1 a", "layer2+out a (8 stages)", "loss a", "layer1 b", "layer2+out b (8 stages)", "loss b", "dgrad set-up (mask fragments, X)",
-                 "dgrad stage 0 (96 MFMAs)", "dgrad stages 1-7 + L1bwd of 0-6 in their shadow", "L1bwd of stage 7 (exposed)"]
-        ph = np.diff(d[1:9], axis=1)
-        print("train" if train else "frozen", "chained kernel, cycles per 64-sample wave pass (mean over passes 1..8):")
-        for n, v in zip(names, ph.mean(0)):
-            print(f"  {n:36s} {v:10.0f}")
-        print("  total/pass", (d[2:9, 0] - d[1:8, 0]).mean(), " = per 64 samples and CU:", (d[2:9, 0] - d[1:8, 0]).mean() / 4)
-        continue
     d = dbg.cpu().numpy().reshape(16, 16)[:, :11]
     names = ["A:loadX", "B:H1", "C:loop", "C:epi", "D:loss", "E:dH2", "F:loop", "F:epi", "H:dH1", "I:L1bwd"]
     ph = np.diff(d[2:10], axis=1)

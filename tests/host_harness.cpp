@@ -116,12 +116,5 @@ void hh_select_key(int n, uint32_t seed, uint32_t* out)
     for (int i = 0; i < n; ++i) out[i] = nl_select_key(seed, (uint32_t)i);
 }
 
-// register-chained decoder: slot order of the MFMA operands (nl_decoder_chain.hip, k_prepare_w2a)
-void hh_chain_layout(int* unit_of /*[2][16]*/, int* slot_of /*[32][3]*/, long long* a_index /*[256][256]*/)
-{
-    for (int lh = 0; lh < 2; ++lh) for (int r = 0; r < 16; ++r) unit_of[lh * 16 + r] = nl_chain_unit(r, lh);
-    for (int u = 0; u < 32; ++u) nl_chain_slot(u, &slot_of[3 * u], &slot_of[3 * u + 1], &slot_of[3 * u + 2]);
-    for (int row = 0; row < 256; ++row) for (int c = 0; c < 256; ++c) a_index[row * 256 + c] = (long long)nl_chain_a_index(row, c);
-}
 
 }  // extern "C"

@@ -364,27 +364,43 @@ def test_six_of_nine_split_products_stay_below_fp32_accumulation_noise():
     assert np.abs(s6 - exact).max() / scale.max() < 2.0 ** -23 and rms(s6) < 0.5 * rms(f32)
 
 
-def test_chained_decoder_operand_slot_order(hh):
-    """nl_decoder_chain.hip chains layers through the register file: the 16 accumulator registers of a lane (rows (r & 3) + 8 (r >> 2)
-    + 4 lh of the 32x32 MFMA result, lane = sample) are fed back as two B-operand fragments, so the weight planes must be stored in
-    exactly that slot order.  nl_chain_slot is the inverse of the accumulator row map, and nl_chain_a_index is a bijection of
-    (row, contraction unit) onto a plane in [row tile][k-step][lane][8] order with the MFMA A-operand lane map."""
-    unit_of = np.zeros(32, np.int32); slot_of = np.zeros(96, np.int32); a_index = np.zeros(65536, np.int64)
-    hh.hh_chain_layout(p(unit_of), p(slot_of), p(a_index))
-    slot_of = slot_of.reshape(32, 3)
-    assert sorted(unit_of.tolist()) == list(range(32))                                   # the accumulator rows cover the tile
-    for lh in range(2):
-        for r in range(16):
-            u = unit_of[lh * 16 + r]
-            assert u == (r & 3) + 8 * (r >> 2) + 4 * lh                                   # cdna: 32x32 C/D row map
-            half, l, e = slot_of[u]
-            assert (l, 8 * half + e) == (lh, r)                                           # register r of lane half lh <-> fragment (half, e)
-    a = a_index.reshape(256, 256)
-    assert sorted(a.reshape(-1).tolist()) == list(range(65536))                           # bijection onto the plane
-    row, c = 77, 201
-    t_, rem = divmod(int(a[row, c]), 16 * 64 * 8)
-    s_, rem = divmod(rem, 64 * 8)
-    lane, e = divmod(rem, 8)
-    assert t_ == row >> 5 and (lane & 31) == (row & 31)                                   # A operand: lane = output row inside its tile
-    half, l, e2 = slot_of[c & 31]
-    assert s_ == 2 * (c >> 5) + half and (lane >> 5) == l and e == e2                     # k-step / lane half / element = the unit's slot
+def test_eight_product_forward_drops_less_than_2_to_the_minus_30_of_a_product(hh):
+    """The default forward GEMM of the decoder (gemm mode 3) forms eight of the nine partial products of the three-term splits: all but
+    x_lo * w_lo.  In exact rational arithmetic: (i) the eight products sum to x * w - x_lo * w_lo exactly; (ii) |x_lo| < 2^-15 |x| for
+    every fp32 x (truncation splits 24 significand bits 8 + 8 + 8: x_lo is what lies below bit 15 under the leading one), hence
+    |x_lo * w_lo| < 2^-30 |x * w| - 2^-6 of ONE rounding of the fp32 accumulation the products then enter (2^-24 relative), so the
+    dropped terms of a 256-deep dot product are bounded by 2^-30 sum |x_k| |w_k| against the accumulation's own ~2^-24 sum |x_k| |w_k|."""
+    from fractions import Fraction
+    rng = np.random.default_rng(1)
+    v = np.concatenate([rng.normal(size=60000).astype(np.float32), (rng.normal(size=20000) * 1e-5).astype(np.float32),
+                        (rng.normal(size=20000) * 1e5).astype(np.float32),
+                        rng.integers(0, 2 ** 32, 100000, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+    v = v[np.isfinite(v) & (np.abs(v) >= 2.0 ** -100) & (np.abs(v) < 2.0 ** 100)]
+    n = len(v) // 2 * 2
+    v = v[:n]
+    hi, mid, lo = (np.empty(n, np.uint16) for _ in range(3))
+    hh.hh_split3_bf16(n, p(v), p(hi), p(mid), p(lo))
+    f = lambda b: (b.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    H_, M_, L_ = f(hi), f(mid), f(lo)
+    assert (np.abs(L_) < np.abs(v.astype(np.float64)) * 2.0 ** -15).all()                 # (ii), all values incl. raw bit patterns
+    x, w = slice(0, n // 2), slice(n // 2, n)
+    # (i) + the bound, exactly, on a sample of pairs (Fractions of floats are exact)
+    for k in range(0, n // 2, 97):
+        xs = [Fraction(float(a[x][k])) for a in (H_, M_, L_)]
+        ws = [Fraction(float(a[w][k])) for a in (H_, M_, L_)]
+        exact = Fraction(float(v[x][k])) * Fraction(float(v[w][k]))
+        eight = sum(xs[a] * ws[b] for a in range(3) for b in range(3) if a + b < 4)
+        assert exact - eight == xs[2] * ws[2]
+        assert abs(xs[2] * ws[2]) * 2 ** 30 < abs(exact) or exact == 0
+    # a 256-deep dot product: the dropped part against the bound and against what fp32 accumulation loses anyway
+    X = rng.normal(size=(64, 256)).astype(np.float32); W = rng.normal(size=(64, 256)).astype(np.float32)
+    parts = []
+    for arr in (X, W):
+        h_, m_, l_ = (np.empty(arr.size, np.uint16) for _ in range(3))
+        hh.hh_split3_bf16(arr.size, p(np.ascontiguousarray(arr.reshape(-1))), p(h_), p(m_), p(l_))
+        parts.append([f(a).reshape(arr.shape) for a in (h_, m_, l_)])
+    dropped = np.abs((parts[0][2] * parts[1][2]).sum(1))                                  # float64: exact enough for a bound check
+    bound = (np.abs(X.astype(np.float64)) * np.abs(W.astype(np.float64))).sum(1) * 2.0 ** -30
+    assert (dropped <= bound).all()
+    fp32_acc = np.abs(np.cumsum((X * W).astype(np.float32), axis=1, dtype=np.float32)[:, -1].astype(np.float64) - (X.astype(np.float64) * W.astype(np.float64)).sum(1))
+    assert np.median(dropped) < 0.05 * max(np.median(fp32_acc), 1e-30)                    # far inside the accumulation's own round-off

@@ -13,9 +13,25 @@ import helpers as H
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
-# decoder kernel families / arithmetic: 0: fp32 MFMA GEMMs, 1: exact bf16 splits, LDS-activation kernel, 2: 1 with the six-product
-# forward (opt-in, not exact), 3: exact bf16 splits, register-chained kernel (nl_decoder_chain.hip), 4: 3 with the six-product forward
-BACKWARD_MODES = [0, 1, 2, 3, 4]
+# decoder GEMM arithmetic (include/nerfloam_hip.h nl_decoder_set_gemm_mode): 0: fp32 MFMA GEMMs, 1: bf16 matrix cores, all nine partial
+# products of the three-term splits (exact), 3: eight of them (without lo x lo: THE DEFAULT), 2: six (opt-in, not exact).  The default
+# runs on every golden; the exact / fp32 modes and the opt-in one on a subset (they are the same kernels with other template arguments).
+ITERATION_CASES = ([(c, 3) for c in ["map_1f_1it", "map_2f_2it_frozen", "map_kitti_1f_1it", "map_ncd_1f_1it"]]
+                   + [("map_1f_1it", 0), ("map_1f_1it", 1), ("map_kitti_1f_1it", 1), ("map_2f_2it_frozen", 0), ("map_1f_1it", 2)])
+# sdf bars per mode (max |sdf - oracle|; the north_star bar is 1e-4).  Measured on MI355X (round 3): 2e-8 .. 3e-8 in every mode on the
+# golden scenes (6e-7 on the full scan); against the reference goldens 0.9e-6 .. 1.8e-6 (the oracle's own distance from them)
+SDF_TOL = {0: 5e-7, 1: 5e-7, 3: 5e-7, 2: 5e-6}
+_METRICS = {}
+
+
+def record_metric(key, **kw):
+    import json
+    _METRICS.setdefault(key, {}).update({k: float(v) for k, v in kw.items()})
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(_METRICS, open(os.path.join(out, "parity_metrics.json"), "w"), indent=1, sort_keys=True)
+
+
 # goldens with the mapper / tracker settings of the kitti (voxel 0.3 m) and ncd (step 0.04 m, up to 58 samples per ray) configs
 EXTRA_GOLDENS = ["map_kitti_1f_1it", "map_ncd_1f_1it"]
 EXTRA_TRACK_GOLDENS = ["track_kitti_2it", "track_ncd_2it"]
@@ -209,8 +225,7 @@ def backward_mode(nl, request):
     lib.nl_decoder_set_wgrad2_mode(old[0]); lib.nl_decoder_set_gemm_mode(old[1])
 
 
-@pytest.mark.parametrize("backward_mode", BACKWARD_MODES, indirect=True)
-@pytest.mark.parametrize("case", ["map_1f_1it", "map_2f_2it_frozen"] + EXTRA_GOLDENS)
+@pytest.mark.parametrize("case,backward_mode", ITERATION_CASES, indirect=["backward_mode"])
 def test_iteration_matches_oracle_and_golden(nl, golden_dir, case, backward_mode):
     g = np.load(os.path.join(golden_dir, case + ".npz"))
     sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]),
@@ -229,11 +244,12 @@ def test_iteration_matches_oracle_and_golden(nl, golden_dir, case, backward_mode
     load_frames(eng, frames)
     eng.begin_call(m, dec)
     eng.forward_backward(m, dec, cfgP, train_decoder=train)
-    r = compare_iteration(eng, m, dec, out, cfgP, train)
+    r = compare_iteration(eng, m, dec, out, cfgP, train, sdf_tol=SDF_TOL[backward_mode])
     # against the REFERENCE outputs (goldens); rays whose hit list has exact t_min ties are unspecified there
     ok = ~_tie_rays(out)
     assert np.array_equal(r["valid_mask"][ok], g["it0_valid"][ok])
-    assert np.abs(r["sdf"] - g["it0_sdf"])[ok].max() < 1e-4
+    record_metric(f"{case}/mode{backward_mode}", sdf_vs_oracle=np.abs(r["sdf"] - out["sdf"]).max(), sdf_vs_golden=np.abs(r["sdf"] - g["it0_sdf"])[ok].max())
+    assert np.abs(r["sdf"] - g["it0_sdf"])[ok].max() < (2e-5 if backward_mode == 2 else 5e-6)
     compare_emb_and_pose_grads(nl, eng, m, dec, out, cfgP, nf, train)
 
 
@@ -310,7 +326,7 @@ def test_engines_carry_their_own_kernel_modes(nl, golden_dir):
         assert not np.array_equal(got[(0, 0)]["sdf"], got[(1, 1)]["sdf"]) or not np.array_equal(got[(0, 0)]["gdec"], got[(1, 1)]["gdec"])
         assert np.abs(got[(0, 0)]["sdf"] - got[(1, 1)]["sdf"]).max() < 1e-5 and np.abs(got[(3, 1)]["sdf"] - got[(1, 1)]["sdf"]).max() < 1e-5
     with pytest.raises(ValueError):
-        nl["P"].SdfEngine(max_rays=8, gemm_mode=7)
+        nl["P"].SdfEngine(max_rays=8, gemm_mode=4)
     assert lib.nl_decoder_forward_m(None, None, None, 0, None, 1, 0x0600, None) != 0       # wgrad2 mode 5: rejected
 
 
@@ -356,11 +372,20 @@ def test_mapping_three_steps_track_oracle(nl, golden_dir, backward_mode):
     assert (d > 3 * ulp + 1e-12).mean() < 1e-3
     assert d.max() <= 3 * 0.03 + 1e-6
     dn = dec.numpy()
+    worst = 0.0
     for n_ in dec_np.names():
         dd = np.abs(dn[n_].reshape(-1) - getattr(dec_np, n_).reshape(-1))
-        assert (dd > 5e-5).mean() < 5e-3, n_
-    np.testing.assert_allclose(pose, scans[0]["pose"], rtol=0, atol=3e-4)
-    np.testing.assert_allclose(pose[:3], g["poses_final"][0][:3], rtol=0, atol=5e-3)     # reference golden
+        worst = max(worst, float((dd > 5e-5).mean()))
+    record_metric(f"map_1f_3it/mode{backward_mode}", emb_mismatch=mism, emb_gt3ulp=(d > 3 * ulp + 1e-12).mean(), dec_frac_gt_5e5=worst,
+                  pose_vs_oracle=np.abs(pose - scans[0]["pose"]).max(), pose_t_vs_golden=np.abs(pose[:3] - g["poses_final"][0][:3]).max(),
+                  pose_w_vs_golden=np.abs(pose[3:] - g["poses_final"][0][3:]).max())
+    # measured (MI355X, modes 1 / 3): no decoder element beyond 5e-5 of the oracle's after three Adam steps; pose == oracle to 4e-9 rad /
+    # 0 ulp, == the reference golden to one fp32 ulp of the 2000 m offset (1.2e-4 m) / 1.2e-6 rad
+    assert worst < 1e-3, worst
+    np.testing.assert_allclose(pose[3:], scans[0]["pose"][3:], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(pose[:3], scans[0]["pose"][:3], rtol=0, atol=2.0 ** -13 + 1e-7)     # at most one ulp of 2000 m
+    np.testing.assert_allclose(pose[:3], g["poses_final"][0][:3], rtol=0, atol=2 * 2.0 ** -13 + 1e-7)     # reference golden: two ulp
+    np.testing.assert_allclose(pose[3:], g["poses_final"][0][3:], rtol=0, atol=1e-5)
 
 
 @pytest.mark.parametrize("backward_mode", [1, 3], indirect=True)
@@ -390,8 +415,11 @@ def test_tracking_matches_oracle_and_golden(nl, golden_dir, case, backward_mode)
             ok = ~_tie_rays(outs[0])
             assert np.abs(r["sdf"] - g["it0_sdf"])[ok].max() < 1e-4
         eng.optimiser_step(m, dec, cfgP, update_emb=False, update_decoder=False, update_pose=True, lr_pose=float(g["lr"]))
-        np.testing.assert_allclose(eng.pose_grad6[0].cpu().numpy(), outs[it]["grad_pose"][0], rtol=POSE_GRAD_RTOL if it == 0 else 5e-3,
-                                   atol=1e-6 + 1e-4 * np.abs(outs[it]["grad_pose"][0]).max())
+        g6, ref6 = eng.pose_grad6[0].cpu().numpy(), outs[it]["grad_pose"][0]
+        record_metric(f"{case}/mode{backward_mode}/it{it}", pose_grad_rel_to_max=np.abs(g6 - ref6).max() / np.abs(ref6).max())
+        # (iteration 2 starts from a pose that already differs from the oracle's in the last bits: the gradient is compared relative
+        #  to its largest component; measured <= 3e-5 there, <= 2e-6 in iteration 1)
+        np.testing.assert_allclose(g6, ref6, rtol=POSE_GRAD_RTOL if it == 0 else 2e-4, atol=1e-6 + 1e-4 * np.abs(ref6).max())
         pose = eng.pose6[0].cpu().numpy()
     np.testing.assert_allclose(pose, pose_o, rtol=0, atol=2e-5)
     np.testing.assert_allclose(pose, g["pose_final"], rtol=0, atol=3e-4)                  # reference golden
