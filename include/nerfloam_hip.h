@@ -225,6 +225,21 @@ int nl_trilinear_bwd(const void* loss_scalars, const int* s_vox, const float* s_
                      const float* centres, const int* vertex_rows, const void* emb_bf16, float voxel_size,
                      const float* dX, float* g_emb, double* g_pose, int nblocks, void* stream);
 
+/* Embedding rows touched since the optimiser of a call was created.  The reference's torch.optim.Adam sweeps the whole [E,16] table every
+ * step (render_helpers.py:341-353,421-423); a row that never received a gradient has zero gradient and zero moments and does not move, so
+ * sweeping only the touched rows is bit-identical - and on a KITTI-scale map (1e6 - 1e7 rows) the difference between an
+ * optimiser step that costs 160 B x E per iteration and one that costs 160 B x (rays x hits x 8).  flags: one bit per row (ceil(E / 32)
+ * words, zero-filled at allocation), list: the rows whose bit is set (capacity E), count: [1].  The scatter kernel records a row the first
+ * time it adds to its accumulators (nl_trilinear_bwd_t; the multi-GPU unpack: nl_dist_rows_move_t), the optimiser sweeps the list
+ * (nl_optimiser_step_t), nl_touched_rows_reset clears the listed rows' accumulators / moments / flags and empties the list at the start of
+ * the next call (a fresh Adam per call, render_helpers.py:353) - no E-sized memset.  NULL = the dense behaviour everywhere. */
+typedef struct NlTouchedRows { int* list; int* count; unsigned* flags; } NlTouchedRows;
+int nl_trilinear_bwd_t(const void* loss_scalars, const int* s_vox, const float* s_depth, const int* s_ray,
+                       const float* rays_d_world, const float* rays_d_sensor, const int* frame_id, const float* poses, int n_frames,
+                       const float* centres, const int* vertex_rows, const void* emb_bf16, float voxel_size,
+                       const float* dX, float* g_emb, double* g_pose, int nblocks, const NlTouchedRows* touched, void* stream);
+int nl_touched_rows_reset(const NlTouchedRows* touched, float* g_emb, void* emb_m_bf16, void* emb_v_bf16, void* stream);
+
 /* masked_scatter_ones (render_helpers.py:30-36,301): packed samples -> padded [R,S] tensors */
 int nl_unpack_samples(const void* loss_scalars, const int* s_ray, const int* samp_off, const int* hit_rank,
                       const float* sdf, const float* depth, int S_stride, float* out_sdf, float* out_z, unsigned char* out_valid,
@@ -267,6 +282,14 @@ int nl_optimiser_step_ex(int* state, double lr_emb, double lr_dec, double lr_pos
                          float* poses12, int F, int apply_pose, const int* counters, int skip_mode, int* counters_rw, int* counters_copy,
                          void* stream);
 
+/* nl_optimiser_step_ex with the embedding group sweeping the touched rows (touched == NULL: the whole table) */
+int nl_optimiser_step_t(int* state, double lr_emb, double lr_dec, double lr_pose,
+                        void* emb_bf16, float* g_emb, void* emb_m_bf16, void* emb_v_bf16, long long n_emb,
+                        float* dec_params, const float* dec_grad, float* dec_m, float* dec_v, float* dec_ws,
+                        float* pose6, double* g_pose, float* pose_m, float* pose_v, const int* pose_enable, float* grad6_out,
+                        float* poses12, int F, int apply_pose, const int* counters, int skip_mode, int* counters_rw, int* counters_copy,
+                        const NlTouchedRows* touched, void* stream);
+
 /* ---- multi-GPU: embedding-gradient exchange over the rows an iteration touches (nerf_loam_amd/dist.py).  Every rank marks the rows
  * of the voxels its rays hit in a zero-filled bitmap of ceil(E / 32) words; after an OR-all-reduce of the bitmap the union's rows
  * are packed in row order into buf[capacity][16] (prefix = exclusive scan of the word popcounts), SUM-all-reduced and unpacked. */
@@ -275,6 +298,10 @@ int nl_dist_rows_prefix(const unsigned* bitmap, int n_words, int* prefix, int* t
                         void* stream);
 int nl_dist_rows_move(int direction /* 0 pack, 1 unpack */, const unsigned* bitmap, const int* prefix, int n_words, float* g_emb, float* buf,
                       int capacity, int* fail_word, void* stream);
+
+/* nl_dist_rows_move recording the unpacked rows as touched (a row only other ranks' rays touched carries a gradient here as well) */
+int nl_dist_rows_move_t(int direction, const unsigned* bitmap, const int* prefix, int n_words, float* g_emb, float* buf, int capacity,
+                        int* fail_word, const NlTouchedRows* touched, void* stream);
 
 /* ---- one call per iteration.  The whole launch sequence of an SDF iteration (render_helpers.py:356-423 mapping / :452-512
  * tracking) issued from C: stages bit 0 = intersect .. backward (everything nl_ray_intersect .. nl_trilinear_bwd above, counter
@@ -325,6 +352,9 @@ typedef struct NlIterDesc {
     int* xg_send; int* xg_recv; int xg_stride;
     int* row_first; int row_first_entries;
     int rows_mode; unsigned* rows_bitmap; int* rows_prefix; int* rows_total; int* rows_ws; float* rows_buf; int rows_cap, rows_words;
+    /* touched-rows optimiser (NlTouchedRows above): with the three pointers set the scatter (and the multi-GPU unpack) record the rows they
+     * write; sparse_sweep != 0: the optimiser sweeps the list, 0: the whole table (e.g. after a dense multi-GPU gradient exchange) */
+    int* touched_list; int* touched_count; unsigned* touched_flags; int sparse_sweep;
 } NlIterDesc;
 /* stages: bit 0 = intersect .. backward (with a communicator: + the exchanges of the forward pass), bit 1 = optimiser step,
  * bit 2 = the gradient exchange (only with a communicator; a whole sharded iteration = 7).  The bits exist separately so that the

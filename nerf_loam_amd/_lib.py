@@ -60,12 +60,18 @@ def _iter_desc_fields():
     # ray-sharded multi-GPU iteration (NULL comm: one GPU)
     f += [("comm", P_), ("xg_send", P_), ("xg_recv", P_), ("xg_stride", I_), ("row_first", P_), ("row_first_entries", I_)]
     f += [("rows_mode", I_), ("rows_bitmap", P_), ("rows_prefix", P_), ("rows_total", P_), ("rows_ws", P_), ("rows_buf", P_), ("rows_cap", I_), ("rows_words", I_)]
+    f += [("touched_list", P_), ("touched_count", P_), ("touched_flags", P_), ("sparse_sweep", I_)]
     return f
 
 
 class NlIterDesc(ctypes.Structure):
     """ctypes mirror of NlIterDesc (include/nerfloam_hip.h): field order and types must match (tests/test_c_abi_exports.py)"""
     _fields_ = _iter_desc_fields()
+
+
+class NlTouchedRows(ctypes.Structure):
+    """rows of the embedding table touched since the optimiser of a call was created (include/nerfloam_hip.h)"""
+    _fields_ = [("list", ctypes.c_void_p), ("count", ctypes.c_void_p), ("flags", ctypes.c_void_p)]
 
 
 # communicator of the ray-sharded iteration (NlComm, include/nerfloam_hip.h)
@@ -134,6 +140,10 @@ _SIGS = {
     "nl_optimiser_step": ([_P, _D, _D, _D] + [_P] * 4 + [_LL] + [_P] * 5 + [_P] * 7 + [_I, _I, _P, _I, _P], _I),
     "nl_optimiser_step_ex": ([_P, _D, _D, _D] + [_P] * 4 + [_LL] + [_P] * 5 + [_P] * 7 + [_I, _I, _P, _I, _P, _P, _P], _I),
     "nl_iteration": ([_P, _I, _P], _I),
+    "nl_trilinear_bwd_t": ([_P] * 8 + [_I] + [_P] * 3 + [_F] + [_P] * 3 + [_I, _P, _P], _I),
+    "nl_touched_rows_reset": ([_P, _P, _P, _P, _P], _I),
+    "nl_optimiser_step_t": ([_P, _D, _D, _D] + [_P] * 4 + [_LL] + [_P] * 5 + [_P] * 7 + [_I, _I, _P, _I, _P, _P, _P, _P], _I),
+    "nl_dist_rows_move_t": ([_I, _P, _P, _I, _P, _P, _I, _P, _P, _P], _I),
     "nl_comm_init_rccl": ([_P, _P, _I, _I], _I),
     "nl_exchange_after_intersect": ([_P, _P], _I),
     "nl_exchange_after_sampling": ([_P, _P], _I),

@@ -50,7 +50,8 @@ enum {
 #define NL_OFF_B2 (NL_OFF_W2 + NL_W * NL_W)
 #define NL_OFF_W3 (NL_OFF_B2 + NL_W)
 #define NL_OFF_B3 (NL_OFF_W3 + NL_W)
-#define NL_DEC_PARAMS (NL_OFF_B3 + 1)      // 70401
+#define NL_DEC_PARAMS 70401
+static_assert(NL_DEC_PARAMS == NL_OFF_B3 + 1, "decoder parameter block");
 
 #define NL_LAUNCH_CHECK()                                   \
     do {                                                    \
@@ -61,6 +62,20 @@ enum {
 static inline int nl_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 #ifdef __HIPCC__
+// Embedding rows touched since the optimiser was created (NlTouchedRows of include/nerfloam_hip.h): one bit per row + the list of
+// the rows whose bit is set.  Whoever first adds to a row's gradient accumulators appends the row - the optimiser then sweeps the
+// list instead of the whole table (a row that was never touched has zero gradient and zero moments: Adam leaves it alone, so
+// skipping it is bit-identical to the dense sweep the reference's torch.optim.Adam performs).
+struct NlTouchedDev { int* list; int* count; unsigned* flags; };
+__device__ __forceinline__ void nl_touch_row(const NlTouchedDev& t, int row)
+{
+    if (!t.flags) return;
+    unsigned* wp = t.flags + (row >> 5);
+    const unsigned bit = 1u << (row & 31);
+    if (*reinterpret_cast<volatile unsigned*>(wp) & bit) return;               // the common case after the first iteration of a call
+    if (!(atomicOr(wp, bit) & bit)) t.list[atomicAdd(t.count, 1)] = row;
+}
+
 // Workgroup barrier that orders the workgroup's LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).  __syncthreads() also drains
 // vmcnt: every barrier then waits for the global loads in flight (the next tile's input prefetch: HBM latency) and for the
 // acknowledgement of earlier global stores.  Use where the waves exchange data through LDS and nothing through global memory.

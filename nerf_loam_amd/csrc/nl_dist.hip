@@ -7,6 +7,7 @@
 // (E / 8 bytes), the bitmaps are OR-all-reduced, and the union's rows are packed - in row order, via a prefix sum of the word
 // popcounts, identically on every rank - into a [capacity, 16] buffer that is SUM-all-reduced and unpacked in place.
 #include "nl_common.h"
+#include "../../include/nerfloam_hip.h"
 
 // bitmap bit of every embedding row referenced by a hit voxel of this rank's rays (superset of the rows with a gradient)
 __global__ void k_mark_touched_rows(int N, const int* __restrict__ hit_idx, const int* __restrict__ hit_count,
@@ -47,7 +48,7 @@ __global__ void k_union_popcount(const int* __restrict__ gathered, int stride, i
 // PACK: rows of the union bitmap, in row order, g_emb[row] -> buf[slot]; UNPACK: buf[slot] -> g_emb[row].  16 lanes per row.
 template <bool PACK>
 __global__ void k_rows_move(const unsigned* __restrict__ bitmap, const int* __restrict__ prefix, int n_words, float* __restrict__ g_emb,
-                            float* __restrict__ buf, int capacity, int* __restrict__ fail_word)
+                            float* __restrict__ buf, int capacity, int* __restrict__ fail_word, NlTouchedDev touched)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int bitpos = t >> 4, c = t & 15;                       // one (row, channel) per thread
@@ -59,12 +60,14 @@ __global__ void k_rows_move(const unsigned* __restrict__ bitmap, const int* __re
     if (slot >= capacity) { if (c == 0 && fail_word) *fail_word = 1; return; }
     const size_t row = (size_t)bitpos;
     if (PACK) buf[(size_t)slot * NL_C + c] = g_emb[row * NL_C + c];
-    else g_emb[row * NL_C + c] = buf[(size_t)slot * NL_C + c];
+    else {
+        g_emb[row * NL_C + c] = buf[(size_t)slot * NL_C + c];
+        if (c == 0) nl_touch_row(touched, (int)row);             // a row only OTHER ranks' rays touched now carries a gradient here as well
+    }
 }
 
 extern "C" {
 
-int nl_exclusive_scan_i32(const int* in, int* out, int n, int flag_mode, int* total_out, int* workspace, void* stream);
 
 /* bitmap[ceil(E / 32)] (zero-filled by the caller) |= rows of the voxels hit by the N rays */
 int nl_dist_mark_rows(int N, const int* hit_idx, const int* hit_count, const int* vertex_rows, unsigned* bitmap, void* stream)
@@ -98,15 +101,23 @@ int nl_dist_rows_union_prefix(const int* gathered, int stride_ints, int offset_i
 }
 
 /* direction 0: g_emb rows of the bitmap -> buf[capacity][16] (row order); 1: back.  *fail_word = 1 if the rows exceed capacity. */
+int nl_dist_rows_move_t(int direction, const unsigned* bitmap, const int* prefix, int n_words, float* g_emb, float* buf, int capacity,
+                        int* fail_word, const NlTouchedRows* touched, void* stream)
+{
+    if (!bitmap || !prefix || n_words <= 0 || !g_emb || !buf || capacity <= 0) return NL_ERR_INVALID_ARG;
+    NlTouchedDev t = {nullptr, nullptr, nullptr};
+    if (touched && touched->flags && touched->list && touched->count) { t.list = touched->list; t.count = touched->count; t.flags = touched->flags; }
+    const int nb = nl_div_up((long long)n_words * 32 * 16, 256);
+    if (direction == 0) hipLaunchKernelGGL(k_rows_move<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, bitmap, prefix, n_words, g_emb, buf, capacity, fail_word, t);
+    else                hipLaunchKernelGGL(k_rows_move<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, bitmap, prefix, n_words, g_emb, buf, capacity, fail_word, t);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
 int nl_dist_rows_move(int direction, const unsigned* bitmap, const int* prefix, int n_words, float* g_emb, float* buf, int capacity,
                       int* fail_word, void* stream)
 {
-    if (!bitmap || !prefix || n_words <= 0 || !g_emb || !buf || capacity <= 0) return NL_ERR_INVALID_ARG;
-    const int nb = nl_div_up((long long)n_words * 32 * 16, 256);
-    if (direction == 0) hipLaunchKernelGGL(k_rows_move<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, bitmap, prefix, n_words, g_emb, buf, capacity, fail_word);
-    else                hipLaunchKernelGGL(k_rows_move<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, bitmap, prefix, n_words, g_emb, buf, capacity, fail_word);
-    NL_LAUNCH_CHECK();
-    return NL_OK;
+    return nl_dist_rows_move_t(direction, bitmap, prefix, n_words, g_emb, buf, capacity, fail_word, nullptr, stream);
 }
 
 }  // extern "C"

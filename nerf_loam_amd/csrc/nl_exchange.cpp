@@ -148,7 +148,11 @@ int nl_exchange_gradients(const NlIterDesc* d, void* stream)
     const int rc_end = c->group_end(c->ctx);
     if (rc != X_OK) return rc;
     if (rc_end != X_OK) return rc_end;
-    if (rows) X_TRY(nl_dist_rows_move(1, d->rows_bitmap, d->rows_prefix, d->rows_words, d->g_emb, d->rows_buf, d->rows_cap, fail, stream));
+    if (rows) {
+        const NlTouchedRows touched = {d->touched_list, d->touched_count, d->touched_flags};
+        X_TRY(nl_dist_rows_move_t(1, d->rows_bitmap, d->rows_prefix, d->rows_words, d->g_emb, d->rows_buf, d->rows_cap, fail,
+                                  d->touched_flags ? &touched : nullptr, stream));
+    }
     return X_OK;
 }
 

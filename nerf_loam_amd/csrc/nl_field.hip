@@ -9,6 +9,7 @@
 //
 // Two lanes per sample, 8 channels (one 16-byte bf16 load per corner) each.
 #include "nl_common.h"
+#include "../../include/nerfloam_hip.h"
 
 #define NL_FIELD_THREADS 256
 #define NL_MAX_FRAMES 32
@@ -32,6 +33,7 @@ struct FieldArgs {
     int want_emb_grad;
     int want_pose_grad;
     long long* dbg;                 // optional [blocks][8] s_memtime stamps of thread 0 (profiling aid, k_trilinear_bwd)
+    NlTouchedDev touched;           // optional: rows whose accumulators receive a contribution are recorded (nl_touch_row)
 };
 #define FSTAMP(k) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
 
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
             if (flush) {
                 slot = tb_insert(s_key, row);
                 if (slot < 0) {                                     // table full: straight to memory
+                    nl_touch_row(a.touched, row);
                     float* dst = a.g_emb + (size_t)row * NL_C;
 #pragma unroll
                     for (int c = 0; c < NL_C; ++c) atomicAdd(dst + c, acc[c]);
@@ -309,6 +312,7 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
                 const int key = s_key[slot];
                 if (key >= 0) {
                     const float v = s_val[slot * NL_C + c];
+                    if (c == 0) nl_touch_row(a.touched, key);
                     if (v != 0.f) atomicAdd(a.g_emb + (size_t)key * NL_C + c, v);
                     s_val[slot * NL_C + c] = 0.f;
                 }
@@ -348,7 +352,7 @@ static int fill_args(FieldArgs& a, const void* ls, const int* s_vox, const float
                      const float* rays_d_world, const float* rays_d_sensor, const int* frame_id, const float* poses, int n_frames,
                      const float* centres, const int* vertex_rows, const void* emb, float voxel_size)
 {
-    a.dbg = nullptr;
+    a.dbg = nullptr; a.touched.list = nullptr; a.touched.count = nullptr; a.touched.flags = nullptr;
     if (!ls || !s_vox || !s_depth || !s_ray || !rays_d_world || !poses || !centres || !vertex_rows || !emb) return NL_ERR_INVALID_ARG;
     if (n_frames <= 0 || n_frames > NL_MAX_FRAMES) return NL_ERR_INVALID_ARG;
     a.ls = (const NlLossScalars*)ls; a.s_vox = s_vox; a.s_depth = s_depth; a.s_ray = s_ray; a.rays_d_world = rays_d_world;
@@ -387,19 +391,30 @@ int nl_gather_points(int P, const float* xyz, const int* vox, const float* centr
 /* profiling aid: device buffer [nblocks][8] int64 receiving s_memtime stamps of k_trilinear_bwd (NULL disables) */
 int nl_field_set_debug_buffer(void* dbg) { g_field_dbg = (long long*)dbg; return NL_OK; }
 
+int nl_trilinear_bwd_t(const void* loss_scalars, const int* s_vox, const float* s_depth, const int* s_ray,
+                       const float* rays_d_world, const float* rays_d_sensor, const int* frame_id, const float* poses, int n_frames,
+                       const float* centres, const int* vertex_rows, const void* emb, float voxel_size,
+                       const float* dX, float* g_emb, double* g_pose, int nblocks, const NlTouchedRows* touched, void* stream)
+{
+    FieldArgs a;
+    int rc = fill_args(a, loss_scalars, s_vox, s_depth, s_ray, rays_d_world, rays_d_sensor, frame_id, poses, n_frames, centres, vertex_rows, emb, voxel_size);
+    if (rc != NL_OK || !dX || nblocks <= 0 || (g_pose && !rays_d_sensor)) return NL_ERR_INVALID_ARG;
+    if (touched && touched->flags && (!touched->list || !touched->count)) return NL_ERR_INVALID_ARG;
+    a.dX = dX; a.g_emb = g_emb; a.g_pose = g_pose; a.want_emb_grad = g_emb != nullptr; a.want_pose_grad = g_pose != nullptr;
+    a.dbg = g_field_dbg;
+    if (touched && g_emb) { a.touched.list = touched->list; a.touched.count = touched->count; a.touched.flags = touched->flags; }
+    hipLaunchKernelGGL(k_trilinear_bwd, dim3(nblocks), dim3(NL_FIELD_THREADS), 0, (hipStream_t)stream, a);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
 int nl_trilinear_bwd(const void* loss_scalars, const int* s_vox, const float* s_depth, const int* s_ray,
                      const float* rays_d_world, const float* rays_d_sensor, const int* frame_id, const float* poses, int n_frames,
                      const float* centres, const int* vertex_rows, const void* emb, float voxel_size,
                      const float* dX, float* g_emb, double* g_pose, int nblocks, void* stream)
 {
-    FieldArgs a;
-    int rc = fill_args(a, loss_scalars, s_vox, s_depth, s_ray, rays_d_world, rays_d_sensor, frame_id, poses, n_frames, centres, vertex_rows, emb, voxel_size);
-    if (rc != NL_OK || !dX || nblocks <= 0 || (g_pose && !rays_d_sensor)) return NL_ERR_INVALID_ARG;
-    a.dX = dX; a.g_emb = g_emb; a.g_pose = g_pose; a.want_emb_grad = g_emb != nullptr; a.want_pose_grad = g_pose != nullptr;
-    a.dbg = g_field_dbg;
-    hipLaunchKernelGGL(k_trilinear_bwd, dim3(nblocks), dim3(NL_FIELD_THREADS), 0, (hipStream_t)stream, a);
-    NL_LAUNCH_CHECK();
-    return NL_OK;
+    return nl_trilinear_bwd_t(loss_scalars, s_vox, s_depth, s_ray, rays_d_world, rays_d_sensor, frame_id, poses, n_frames, centres, vertex_rows, emb,
+                              voxel_size, dX, g_emb, g_pose, nblocks, nullptr, stream);
 }
 
 int nl_unpack_samples(const void* loss_scalars, const int* s_ray, const int* samp_off, const int* hit_rank,

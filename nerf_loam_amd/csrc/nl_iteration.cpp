@@ -16,6 +16,8 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
     if (!d || d->N <= 0 || d->F <= 0 || !(stages & 7)) return IT_ERR_INVALID_ARG;
     const bool sharded = d->comm != nullptr;                    // ray-sharded multi-GPU iteration: the exchanges of nl_exchange.cpp ride along
     hipStream_t st = (hipStream_t)stream;
+    const NlTouchedRows touched_rows = {d->touched_list, d->touched_count, d->touched_flags};
+    const NlTouchedRows* touched = d->touched_flags ? &touched_rows : nullptr;      // rows written by the scatter are recorded
     int rc = IT_OK;
 #define NL_TRY(call) do { rc = (call); if (rc != IT_OK) return rc; } while (0)
     if (stages & 1) {
@@ -54,19 +56,19 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
             NL_TRY(nl_decoder_wgrad2_m(d->loss_scalars, d->X, d->dec_params, d->dsdf, d->relu2_mask, d->partials, d->n_slabs, d->kernel_modes, stream));
             NL_TRY(nl_decoder_reduce_m(d->partials, d->n_slabs, d->dec_params, d->dec_grad, d->kernel_modes, stream));
         }
-        NL_TRY(nl_trilinear_bwd(d->loss_scalars, d->s_vox, d->s_depth, d->s_ray, d->rays_d_world, d->rays_d_sensor, d->frame_id, d->poses12, d->F,
-                                d->centres, d->vertex_rows, d->emb, d->voxel_size, d->dX, d->want_emb_grad ? d->g_emb : nullptr,
-                                d->want_pose_grad ? d->g_pose : nullptr, 2 * d->field_blocks, stream));
+        NL_TRY(nl_trilinear_bwd_t(d->loss_scalars, d->s_vox, d->s_depth, d->s_ray, d->rays_d_world, d->rays_d_sensor, d->frame_id, d->poses12, d->F,
+                                  d->centres, d->vertex_rows, d->emb, d->voxel_size, d->dX, d->want_emb_grad ? d->g_emb : nullptr,
+                                  d->want_pose_grad ? d->g_pose : nullptr, 2 * d->field_blocks, touched, stream));
     }
     if ((stages & 4) && sharded) NL_TRY(nl_exchange_gradients(d, stream));
     if (stages & 2) {
         const bool hand_over = d->counters_copy && (stages & 1);       // only a whole iteration leaves the block to the next one
-        NL_TRY(nl_optimiser_step_ex(d->adam_state, d->lr_emb, d->lr_dec, d->lr_pose,
+        NL_TRY(nl_optimiser_step_t(d->adam_state, d->lr_emb, d->lr_dec, d->lr_pose,
                                     d->update_emb ? d->emb : nullptr, d->g_emb, d->emb_m, d->emb_v, d->n_emb_elems,
                                     d->update_decoder ? d->dec_params : nullptr, d->dec_grad, d->dec_m, d->dec_v, d->dec_ws,
                                     d->pose6, d->g_pose, d->pose_m, d->pose_v, d->pose_enable, d->pose_grad6, d->poses12, d->F, d->update_pose,
                                     d->skip_mode ? d->counters : nullptr, d->skip_mode, hand_over ? d->counters : nullptr,
-                                    hand_over ? d->counters_copy : nullptr, stream));
+                                    hand_over ? d->counters_copy : nullptr, d->sparse_sweep ? touched : nullptr, stream));
     }
 #undef NL_TRY
     return IT_OK;

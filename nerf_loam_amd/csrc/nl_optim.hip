@@ -5,6 +5,7 @@
 // Reference behaviour: torch.optim.Adam as constructed in src/variations/render_helpers.py:341-353
 // and :448-450 (default betas/eps, fresh state per call), src/se3pose.py:18-35 for the pose tail.
 #include "nl_common.h"
+#include "../../include/nerfloam_hip.h"
 
 // embeddings: g = bf16(fp32 accumulator) ; accumulator is reset for the next iteration
 // optimiser state block on the device: int32 step counter (+3 pad) followed by NlAdamHyper[3] = {embeddings, decoder,
@@ -141,7 +142,9 @@ struct OptimArgs {
     float* pose6; double* g_pose; float* pm; float* pv; const int* enable; float* grad6_out; float* poses12; int F; int apply_pose;
     const int* counters; int skip_mode;
     int* snap_src; int* snap_dst;        // optional: the counter block is copied to snap_dst and CLEARED by the launch's last step, so that the
-};                                       // next iteration needs no memset launch (nl_iteration); the host reads the copy
+                                         // next iteration needs no memset launch (nl_iteration); the host reads the copy
+    const int* touched_list; const int* touched_count;     // optional: the embedding group sweeps these rows instead of the whole table
+};
 
 // "The iteration was unusable" decided ON THE DEVICE, so that the host loop needs no per-iteration read-back.  The reference skips
 // the optimiser step when render_rays returns None (no ray hit a voxel: render_helpers.py:216-217; the sampler's guard
@@ -177,7 +180,11 @@ __global__ void __launch_bounds__(256) k_optim_step(OptimArgs a)
     const int b = blockIdx.x, tid = threadIdx.x;
     const int role = b < a.nb_emb ? 0 : (b < a.nb_emb + a.nb_dec ? 1 : 2);
     if (optim_skip(a.counters, a.state, a.skip_mode)) {             // uniform over the launch: every thread reads the same words
-        if (role == 0) {
+        if (role == 0 && a.touched_list) {
+            const long long n = (long long)*a.touched_count * NL_C;
+            for (long long e = (long long)b * 256 + tid; e < n; e += (long long)a.nb_emb * 256)
+                a.g_emb[(long long)a.touched_list[e >> 4] * NL_C + (e & 15)] = 0.0f;
+        } else if (role == 0) {
             for (long long i = (long long)b * 256 + tid; i < a.n_emb; i += (long long)a.nb_emb * 256)
                 if (a.g_emb[i] != 0.0f) a.g_emb[i] = 0.0f;
         } else if (role == 2) {
@@ -190,7 +197,21 @@ __global__ void __launch_bounds__(256) k_optim_step(OptimArgs a)
     if (tid == 0) s_h = nl_adam_hyper(role == 0 ? a.lr_emb : (role == 1 ? a.lr_dec : a.lr_pose), step, 0.9, 0.999, 1e-8);
     __syncthreads();
     const NlAdamHyper h = s_h;
-    if (role == 0) {
+    if (role == 0 && a.touched_list) {
+        // the rows touched since this optimiser was created (16 lanes per row); every other row has zero gradient and zero moments,
+        // i.e. the dense sweep below would leave it alone: same bits, cost proportional to the touched rows instead of the table
+        const long long n = (long long)*a.touched_count * NL_C;
+        for (long long e = (long long)b * 256 + tid; e < n; e += (long long)a.nb_emb * 256) {
+            const long long i = (long long)a.touched_list[e >> 4] * NL_C + (e & 15);
+            const float ga = a.g_emb[i];
+            const uint16_t pm = a.emb_m[i], pv = a.emb_v[i];
+            if (ga == 0.0f && pm == 0 && pv == 0) continue;
+            a.g_emb[i] = 0.0f;
+            uint16_t pp = a.emb[i], mm = pm, vv = pv;
+            nl_adam_bf16(&pp, nl_f32_to_bf16(ga), &mm, &vv, h);
+            a.emb[i] = pp; a.emb_m[i] = mm; a.emb_v[i] = vv;
+        }
+    } else if (role == 0) {
         for (long long i = (long long)b * 256 + tid; i < a.n_emb; i += (long long)a.nb_emb * 256) {
             const float ga = a.g_emb[i];
             const uint16_t pm = a.emb_m[i], pv = a.emb_v[i];
@@ -371,14 +392,15 @@ int nl_pose_step(float* pose6, double* g_pose, float* m, float* v, const int* en
 
 /* nl_optimiser_step + the end-of-iteration hand-over of the counter block: its words are copied to counters_copy and CLEARED by
  * the launch's last step (nl_iteration: the next iteration then starts without a memset launch; the host reads the copy) */
-int nl_optimiser_step_ex(int* state, double lr_emb, double lr_dec, double lr_pose,
-                         void* emb, float* g_emb, void* emb_m, void* emb_v, long long n_emb,
-                         float* dec_params, const float* dec_grad, float* dec_m, float* dec_v, float* dec_ws,
-                         float* pose6, double* g_pose, float* pose_m, float* pose_v, const int* pose_enable, float* grad6_out,
-                         float* poses12, int F, int apply_pose, const int* counters, int skip_mode, int* counters_rw, int* counters_copy,
-                         void* stream)
+int nl_optimiser_step_t(int* state, double lr_emb, double lr_dec, double lr_pose,
+                        void* emb, float* g_emb, void* emb_m, void* emb_v, long long n_emb,
+                        float* dec_params, const float* dec_grad, float* dec_m, float* dec_v, float* dec_ws,
+                        float* pose6, double* g_pose, float* pose_m, float* pose_v, const int* pose_enable, float* grad6_out,
+                        float* poses12, int F, int apply_pose, const int* counters, int skip_mode, int* counters_rw, int* counters_copy,
+                        const NlTouchedRows* touched, void* stream)
 {
     if (!state || skip_mode < 0 || skip_mode > 2 || (skip_mode && !counters)) return NL_ERR_INVALID_ARG;
+    if (touched && touched->list && !touched->count) return NL_ERR_INVALID_ARG;
     if (emb && (!g_emb || !emb_m || !emb_v || n_emb <= 0)) return NL_ERR_INVALID_ARG;
     if (dec_params && (!dec_grad || !dec_m || !dec_v || !dec_ws)) return NL_ERR_INVALID_ARG;
     if (pose6 && (!g_pose || !pose_m || !pose_v || !poses12 || F <= 0)) return NL_ERR_INVALID_ARG;
@@ -387,6 +409,8 @@ int nl_optimiser_step_ex(int* state, double lr_emb, double lr_dec, double lr_pos
     a.state = state; a.lr_emb = lr_emb; a.lr_dec = lr_dec; a.lr_pose = lr_pose;
     a.emb = (uint16_t*)emb; a.g_emb = g_emb; a.emb_m = (uint16_t*)emb_m; a.emb_v = (uint16_t*)emb_v; a.n_emb = emb ? n_emb : 0;
     a.nb_emb = emb ? (int)((n_emb + 255) / 256 < 4096 ? (n_emb + 255) / 256 : 4096) : 0;
+    a.touched_list = (emb && touched) ? touched->list : nullptr; a.touched_count = (emb && touched) ? touched->count : nullptr;
+    if (a.touched_list && a.nb_emb > 1024) a.nb_emb = 1024;        // the row count is on the device: a fixed grid strides over it
     a.params = dec_params; a.grad = dec_grad; a.dm = dec_m; a.dv = dec_v; a.W2T = dec_ws;
     a.W2X = dec_ws ? reinterpret_cast<uint16_t*>(dec_ws + NL_W * NL_W) : nullptr;
     a.W2TX = dec_ws ? reinterpret_cast<uint16_t*>(dec_ws + NL_W * NL_W + 3 * NL_W * NL_W / 2) : nullptr;
@@ -399,6 +423,44 @@ int nl_optimiser_step_ex(int* state, double lr_emb, double lr_dec, double lr_pos
     const int nb = a.nb_emb + a.nb_dec + nb_pose;
     hipLaunchKernelGGL(k_optim_step, dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
     if (nb > 1) hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, state, counters, skip_mode, a.snap_src, a.snap_dst);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+int nl_optimiser_step_ex(int* state, double lr_emb, double lr_dec, double lr_pose,
+                         void* emb, float* g_emb, void* emb_m, void* emb_v, long long n_emb,
+                         float* dec_params, const float* dec_grad, float* dec_m, float* dec_v, float* dec_ws,
+                         float* pose6, double* g_pose, float* pose_m, float* pose_v, const int* pose_enable, float* grad6_out,
+                         float* poses12, int F, int apply_pose, const int* counters, int skip_mode, int* counters_rw, int* counters_copy,
+                         void* stream)
+{
+    return nl_optimiser_step_t(state, lr_emb, lr_dec, lr_pose, emb, g_emb, emb_m, emb_v, n_emb, dec_params, dec_grad, dec_m, dec_v, dec_ws, pose6,
+                               g_pose, pose_m, pose_v, pose_enable, grad6_out, poses12, F, apply_pose, counters, skip_mode, counters_rw, counters_copy,
+                               nullptr, stream);
+}
+
+// begin of an optimisation call: the rows the PREVIOUS call touched get their gradient accumulators, moments and flag words
+// cleared (the reference constructs a fresh torch.optim.Adam per call, render_helpers.py:353), then the list is emptied - cost
+// proportional to the touched rows, not to the table
+__global__ void k_touched_reset(const int* __restrict__ list, const int* __restrict__ count, unsigned* __restrict__ flags,
+                                float* __restrict__ g_emb, uint16_t* __restrict__ emb_m, uint16_t* __restrict__ emb_v)
+{
+    const long long n = (long long)*count * NL_C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const int row = list[e >> 4];
+        const long long i = (long long)row * NL_C + (e & 15);
+        g_emb[i] = 0.0f; emb_m[i] = 0; emb_v[i] = 0;
+        if ((e & 15) == 0) flags[row >> 5] = 0u;                     // every bit of a word belongs to a listed row: all writers store 0
+    }
+}
+__global__ void k_touched_count_clear(int* count) { *count = 0; }
+
+int nl_touched_rows_reset(const NlTouchedRows* touched, float* g_emb, void* emb_m, void* emb_v, void* stream)
+{
+    if (!touched || !touched->list || !touched->count || !touched->flags || !g_emb || !emb_m || !emb_v) return NL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_touched_reset, dim3(1024), dim3(256), 0, (hipStream_t)stream, touched->list, touched->count, touched->flags, g_emb,
+                       (uint16_t*)emb_m, (uint16_t*)emb_v);
+    hipLaunchKernelGGL(k_touched_count_clear, dim3(1), dim3(1), 0, (hipStream_t)stream, touched->count);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

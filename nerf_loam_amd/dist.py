@@ -322,6 +322,7 @@ class RayShardedExchange:
         if self.device:
             if self.rows_undecided():
                 self.decide_rows()
+                eng._desc_touched()                              # dense exchange -> dense optimiser sweep for this call
             eng._desc.F = eng.F
             self._check(L.lib().nl_exchange_gradients(ctypes.byref(eng._desc), L.stream_ptr()), "nl_exchange_gradients")
             return

@@ -118,11 +118,23 @@ def decoder_transpose_w2(params, W2T):
     check(L.lib().nl_decoder_transpose_w2(ptr(params), ptr(W2T), stream_ptr()), "nl_decoder_transpose_w2")
 
 
+def touched_rows(t):
+    """(list, count, flags) tensors -> NlTouchedRows pointer argument, None -> NULL (dense optimiser sweep)"""
+    if t is None:
+        return None
+    return ctypes.byref(L.NlTouchedRows(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr()))
+
+
 def trilinear_bwd(loss_scalars, s_vox, s_depth, s_ray, rays_d_world, rays_d_sensor, frame_id, poses12, n_frames, centres, vertex_rows,
-                  emb, voxel_size, dX, g_emb, g_pose, nblocks):
-    check(L.lib().nl_trilinear_bwd(ptr(loss_scalars), ptr(s_vox), ptr(s_depth), ptr(s_ray), ptr(rays_d_world), ptr(rays_d_sensor),
-                                   ptr(frame_id), ptr(poses12), int(n_frames), ptr(centres), ptr(vertex_rows), ptr(emb), float(voxel_size),
-                                   ptr(dX), ptr(g_emb), ptr(g_pose), int(nblocks), stream_ptr()), "nl_trilinear_bwd")
+                  emb, voxel_size, dX, g_emb, g_pose, nblocks, touched=None):
+    """touched: (list, count, flags) - the rows whose accumulators receive a contribution are recorded (include/nerfloam_hip.h NlTouchedRows)"""
+    check(L.lib().nl_trilinear_bwd_t(ptr(loss_scalars), ptr(s_vox), ptr(s_depth), ptr(s_ray), ptr(rays_d_world), ptr(rays_d_sensor),
+                                     ptr(frame_id), ptr(poses12), int(n_frames), ptr(centres), ptr(vertex_rows), ptr(emb), float(voxel_size),
+                                     ptr(dX), ptr(g_emb), ptr(g_pose), int(nblocks), touched_rows(touched), stream_ptr()), "nl_trilinear_bwd")
+
+
+def touched_rows_reset(touched, g_emb, emb_m, emb_v):
+    check(L.lib().nl_touched_rows_reset(touched_rows(touched), ptr(g_emb), ptr(emb_m), ptr(emb_v), stream_ptr()), "nl_touched_rows_reset")
 
 
 def unpack_samples(loss_scalars, s_ray, samp_off, hit_rank, sdf, depth, S_stride, out_sdf, out_z, out_valid):
@@ -150,14 +162,15 @@ def pose_matrices(pose6, poses12):
     check(L.lib().nl_pose_matrices(ptr(pose6), ptr(poses12), pose6.shape[0], stream_ptr()), "nl_pose_matrices")
 
 
-def optimiser_step(state, lr_emb, lr_dec, lr_pose, emb, dec, pose, counters=None, skip_mode=0):
+def optimiser_step(state, lr_emb, lr_dec, lr_pose, emb, dec, pose, counters=None, skip_mode=0, touched=None):
     """one launch for the whole optimiser step; emb = (emb, g_acc, m, v) or None, dec = (params, grad, m, v, workspace) or None,
-    pose = (pose6, g_pose, m, v, enable, grad6_out, poses12, apply) or None; skip_mode: see include/nerfloam_hip.h"""
+    pose = (pose6, g_pose, m, v, enable, grad6_out, poses12, apply) or None; skip_mode: see include/nerfloam_hip.h; touched: the embedding
+    group sweeps these rows (NlTouchedRows) instead of the whole table"""
     e = [ptr(t) for t in emb] + [emb[0].numel()] if emb else [None] * 4 + [0]
     d = [ptr(t) for t in dec] if dec else [None] * 5
     q = [ptr(t) for t in pose[:7]] + [pose[0].shape[0], int(pose[7])] if pose else [None] * 7 + [0, 0]
-    check(L.lib().nl_optimiser_step(ptr(state), float(lr_emb), float(lr_dec), float(lr_pose), *e, *d, *q, ptr(counters), int(skip_mode),
-                                    stream_ptr()), "nl_optimiser_step")
+    check(L.lib().nl_optimiser_step_t(ptr(state), float(lr_emb), float(lr_dec), float(lr_pose), *e, *d, *q, ptr(counters), int(skip_mode),
+                                      None, None, touched_rows(touched), stream_ptr()), "nl_optimiser_step")
 
 
 def pose_step(pose6, g_pose, m, v, enable, grad6_out, poses12, state, apply):

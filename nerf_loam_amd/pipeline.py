@@ -173,11 +173,15 @@ class DecoderDevice:
 
 
 class SdfEngine:
-    def __init__(self, max_rays, samples_per_ray_cap=48, max_frames=8, device="cuda", gemm_mode=None, wgrad2_mode=None):
+    def __init__(self, max_rays, samples_per_ray_cap=48, max_frames=8, device="cuda", gemm_mode=None, wgrad2_mode=None, sparse_adam=True):
         """gemm_mode / wgrad2_mode: the decoder kernel selection of THIS engine (include/nerfloam_hip.h: 0 fp32 matrix cores,
         1 exact-product bf16 splits, ...); None = the process default (NL_GEMM_MODE / NL_WGRAD2_MODE).  Carried per call
         (NL_KERNEL_MODES), so engines with different selections coexist in one process."""
         L.require_gpu()
+        # sparse_adam: the embedding optimiser sweeps the rows touched since begin_call (bit-identical to the reference's dense sweep,
+        # include/nerfloam_hip.h NlTouchedRows) and begin_call clears only those - False = dense sweep + E-sized memset per call
+        self.sparse_adam = bool(sparse_adam)
+        self._touched, self._emb_cap, self._emb_dirty_dense = None, 0, False
         self.kernel_modes = L.kernel_modes(gemm_mode, wgrad2_mode)
         self.dev = torch.device(device)
         self.N_cap = int(max_rays)
@@ -378,18 +382,52 @@ class SdfEngine:
         E = m.n_rows
         if not emb_state:
             pass
-        elif self.g_emb is None or self.g_emb.shape[0] != E:
-            self._emb_state = torch.zeros(2 * E * L.NL_C, dtype=F32, device=self.dev)       # [g_emb f32 | emb_m bf16 | emb_v bf16]
-            self.g_emb = self._emb_state[:E * L.NL_C].view(E, L.NL_C)
-            mv = self._emb_state[E * L.NL_C:].view(torch.int16)
-            self.emb_m = mv[:E * L.NL_C].view(E, L.NL_C)
-            self.emb_v = mv[E * L.NL_C:].view(E, L.NL_C)
+        elif self.g_emb is None or E > self._emb_cap or E < self.g_emb.shape[0]:
+            # gradient accumulators + moments for `cap` rows, zero-filled ONCE: a growing map (rows are appended every frame) stays
+            # inside the allocation, and only rows a call touches are ever dirtied (and cleaned again through the touched-rows list)
+            cap = self._emb_cap = max(E, int(1.25 * E) + 4096) if self.sparse_adam else E
+            self._emb_state = torch.zeros(2 * cap * L.NL_C, dtype=F32, device=self.dev)     # [g_emb f32 | emb_m bf16 | emb_v bf16]
+            self._touched = ((torch.empty(cap, dtype=I32, device=self.dev), torch.zeros(1, dtype=I32, device=self.dev),
+                              torch.zeros((cap + 31) // 32, dtype=I32, device=self.dev)) if self.sparse_adam else None)
+            self._emb_dirty_dense = False
+            self._emb_views(E)
         else:
-            self._emb_state.zero_()
-            if self.g_emb.data_ptr() != self._emb_state.data_ptr():      # re-homed into the multi-GPU exchange buffer (dist.py)
-                self.g_emb.zero_()
+            if self._touched is None or self._emb_dirty_dense:
+                # dense bookkeeping (sparse_adam off, or the previous call exchanged dense gradients across GPUs: rows other ranks
+                # touched carry moments without being listed here): clear everything once
+                self._emb_state.zero_()
+                if self._touched is not None:
+                    self._touched[1].zero_(); self._touched[2].zero_()
+                self._emb_dirty_dense = False
+            else:
+                # a fresh Adam (render_helpers.py:353): accumulators / moments / flags of the rows the PREVIOUS call touched - cost
+                # proportional to those rows, not to the table
+                ops.touched_rows_reset(self._touched, self._emb_state[:self._emb_cap * L.NL_C], self._emb_mv[:self._emb_cap * L.NL_C],
+                                       self._emb_mv[self._emb_cap * L.NL_C:])
+            if E != self.g_emb.shape[0]:
+                self._emb_views(E)
         if dec is not None:
             dec.reset_state()
+
+    def _emb_views(self, E):
+        cap = self._emb_cap
+        self.g_emb = self._emb_state[:cap * L.NL_C].view(cap, L.NL_C)[:E]
+        self._emb_mv = self._emb_state[cap * L.NL_C:].view(torch.int16)
+        self.emb_m = self._emb_mv[:cap * L.NL_C].view(cap, L.NL_C)[:E]
+        self.emb_v = self._emb_mv[cap * L.NL_C:].view(cap, L.NL_C)[:E]
+
+    def touched_rows(self):
+        """(list, count, flags) for the optimiser's sparse sweep, or None when this call sweeps the table densely: sparse_adam off, or a
+        multi-GPU call whose embedding gradients are all-reduced densely (rows only other ranks touched are then not listed here, and the
+        next begin_call clears the whole state once).  The scatter records touched rows in either case."""
+        if self._touched is None:
+            return None
+        ex = self._exchange
+        if ex is not None and ex.device and not isinstance(ex._rows_cap, int):
+            if ex._rows_cap == "dense":
+                self._emb_dirty_dense = True
+            return None                                           # (undecided: re-evaluated once the first iteration sized the exchange)
+        return self._touched
 
     # ------------------------------------------------------------------ one iteration
     def forward_backward(self, m: MapDevice, dec: DecoderDevice, cfg: IterConfig, train_decoder=True, want_emb_grad=True,
@@ -448,7 +486,8 @@ class SdfEngine:
         tm("scatter", 0)
         ops.trilinear_bwd(self.loss_scalars, self.s_vox, self.s_depth, self.s_ray, self.rays_d_world, self.rays_d_sensor, self.frame_id,
                           self.poses12, self.F, m.centres, m.vertex_rows, m.emb, m.voxel_size, self.dX,
-                          self.g_emb if want_emb_grad else None, self.g_pose if want_pose_grad else None, 2 * self.field_blocks)
+                          self.g_emb if want_emb_grad else None, self.g_pose if want_pose_grad else None, 2 * self.field_blocks,
+                          self._touched if want_emb_grad else None)
         tm("scatter", 1)
         if self.hook_after_backward is not None:
             self.hook_after_backward(self, dec, train_decoder, want_emb_grad, want_pose_grad)
@@ -493,7 +532,7 @@ class SdfEngine:
                            (m.emb, self.g_emb, self.emb_m, self.emb_v) if update_emb else None,
                            (dec.params, dec.grad, dec.m, dec.v, dec.W2T) if update_decoder else None,
                            (self.pose6[:self.F], self.g_pose, self.pose_m, self.pose_v, self.pose_enable, self.pose_grad6, self.poses12,
-                            update_pose), self.counters if skip_mode else None, skip_mode)
+                            update_pose), self.counters if skip_mode else None, skip_mode, self.touched_rows() if update_emb else None)
         self._mark("optim", 1)
 
     def call_status(self):
@@ -555,6 +594,12 @@ class SdfEngine:
         d.N, d.F = self.N, self.F
         if self._exchange is not None:
             self._exchange.prepare(m, dec, bool(want_emb_grad))
+        self._desc_touched()
+
+    def _desc_touched(self):
+        d, t = self._desc, self._touched
+        d.touched_list, d.touched_count, d.touched_flags = (None, None, None) if t is None else (t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr())
+        d.sparse_sweep = int(self.touched_rows() is not None)
 
     def run_bound(self, stages=3):
         """one iteration of the bound configuration: stages bit 0 = forward + backward, bit 1 = optimiser step"""
@@ -571,6 +616,7 @@ class SdfEngine:
             # call (collective sizes must be known on the host), then the gradient exchange and the optimiser step
             ex._check(L.lib().nl_iteration(ctypes.byref(d), 1, L.stream_ptr()), "nl_iteration")
             ex.decide_rows()
+            self._desc_touched()                                 # (dense exchange -> dense optimiser sweep for this call)
             ex._check(L.lib().nl_iteration(ctypes.byref(d), 4 | (stages & 2), L.stream_ptr()), "nl_iteration")
             stages &= ~2                                         # (two calls: the counter block was not handed over - see below)
         else:

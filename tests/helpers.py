@@ -40,3 +40,19 @@ def scatter_rows(n_rows, rows, vals, base=None):
     out = np.zeros((n_rows, vals.shape[1]), np.uint16) if base is None else base.copy()
     out[rows] = vals
     return out
+
+
+def record_gpu_metric(key, **kw):
+    """measured numbers of the -m gpu tests -> gpurun_out/gpu_metrics.json (merged back from the GPU box; the bars in the tests were set
+    from these files)"""
+    import json
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "gpu_metrics.json")
+    try:
+        data = json.load(open(path))
+    except Exception:                                           # noqa: BLE001
+        data = {}
+    data.setdefault(key, {}).update({k: float(v) for k, v in kw.items()})
+    json.dump(data, open(path, "w"), indent=1, sort_keys=True)
