@@ -356,6 +356,116 @@ def shard_probe_bench(w, device, full_ms, steps=12):
     return out
 
 
+def build_large_map(w, device, n_scans=150, spacing=3.0):
+    """the synthetic scan inserted at `n_scans` poses `spacing` m apart along x (host octree, nerf_loam_amd.svo), N(0, 0.01^2) embeddings"""
+    from nerf_loam_amd import pipeline as P, synthetic as S
+    from nerf_loam_amd.svo import Octree
+    t0 = time.perf_counter()
+    oc = Octree()
+    oc.init(256 * 256 * 4, 16, 0.2)
+    poses = []
+    for i in range(n_scans):
+        pose = S.scan_pose(tx=spacing * i)
+        poses.append(pose)
+        oc.insert(S.voxel_coords(w["points"], np.eye(3, dtype=np.float32), pose[:3], 0.2))
+    centres, structure, vertex_idx = oc.export_device_layout()
+    flat = np.unique(vertex_idx[vertex_idx >= 0])
+    id2row = -np.ones(len(centres), np.int32)
+    id2row[flat] = np.arange(len(flat), dtype=np.int32)
+    E = len(flat)
+    emb = np.random.default_rng(778).normal(0, 0.01, (E, 16)).astype(np.float32)
+    emb_bits = (emb.view(np.uint32) >> 16).astype(np.uint16)
+    build_s = time.perf_counter() - t0
+    m = P.MapDevice(centres, structure, vertex_idx, id2row, emb_bits, 0.2, device=device)
+    return dict(centres=centres, structure=structure, vertex_idx=vertex_idx, id2row=id2row, E=E, map=m, poses=poses, build_s=build_s)
+
+
+def large_map_bench(w, device, n_scans=150, spacing=3.0, iters=20):
+    """The regime BASELINE configs 2 - 5 live in: a map accumulated over a trajectory (here `n_scans` synthetic scans `spacing` m apart
+    along the street canyon: >= 1e6 embedding rows, a deeper octree), not the single-scan map of the headline number.  On it: ms per
+    iteration of the one-C-call engine loop at the reference's live shapes (2048 rays x 1 frame trainable decoder, 4096 x 4 frozen) and
+    on the full scan, with the rays of the scan(s) in the middle of the trajectory; what begin_call and the optimiser step cost with the
+    touched-rows bookkeeping and with the dense one (sparse_adam=False: E-sized memset per call, sweep over all rows per iteration -
+    the reference's torch.optim.Adam); and the parity of one mapping iteration on this map against the oracle."""
+    from nerf_loam_amd import pipeline as P
+    pts, cos, dirs = w["points"], w["cos"], w["dirs"]
+    lm = build_large_map(w, device, n_scans, spacing)
+    centres, structure, vertex_idx, id2row, E, m, poses, build_s = (lm[k] for k in ("centres", "structure", "vertex_idx", "id2row", "E", "map", "poses", "build_s"))
+    dec = P.DecoderDevice(*[np.asarray(a, np.float32) for a in w["host"]["dec"]], device=device)
+    mid = n_scans // 2
+    out = {"scans": n_scans, "spacing_m": spacing, "octree_nodes": int(len(centres)), "embedding_rows": int(E), "root_side_voxels": int(m.root_side),
+           "host_build_s": round(build_s, 2), "single_scan_map_rows": w["n_rows"]}
+
+    def loop(n_rays, n_frames, train, sparse, full=False):
+        rs = np.random.default_rng(5)
+        if full:
+            sel, fid = np.arange(len(pts)), np.zeros(len(pts), np.int32)
+        else:
+            sel = np.concatenate([np.sort(rs.choice(len(pts), n_rays, replace=False)) for _ in range(n_frames)])
+            fid = np.repeat(np.arange(n_frames, dtype=np.int32), n_rays)
+        eng = P.SdfEngine(max_rays=len(sel), samples_per_ray_cap=48 if full else 96, max_frames=max(2, n_frames), device=device, sparse_adam=sparse)
+        eng.set_rays(dirs[sel], pts[sel], cos[sel], fid)
+        eng.set_poses(np.stack([poses[mid + f] for f in range(n_frames)]), [1] * n_frames)
+        cfg = P.IterConfig()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        tb, to, tc = [], [], []
+        for rep in range(4):
+            ev[0].record(); eng.begin_call(m, dec); ev[1].record()
+            eng.bind(m, dec, cfg, train_decoder=train, update_decoder=train, want_pose_grad=not full or True)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(iters - 1):
+                eng.run_bound()
+            eng.run_bound(1)
+            ev[2].record(); eng.run_bound(2); ev[3].record()
+            torch.cuda.synchronize()
+            if rep:
+                tc.append((time.perf_counter() - t1) / iters * 1e3); tb.append(ev[0].elapsed_time(ev[1])); to.append(ev[2].elapsed_time(ev[3]))
+        st = eng.stats()
+        assert not st["overflow"] and not eng.call_status()[2]
+        r = {"ms_per_iter": float(np.median(tc)), "begin_call_ms": float(np.median(tb)), "optimiser_ms": float(np.median(to)), "valid_samples": int(st["P"]),
+             "hit_rays": int(st["R"]), "max_hits": int(st["H"])}
+        if sparse:
+            r["touched_rows"] = int(eng._touched[1].item())
+        return r, eng
+
+    out["mapping_2048x1"], eng_small = loop(2048, 1, True, True)
+    out["mapping_2048x1_dense_bookkeeping"] = loop(2048, 1, True, False)[0]
+    out["ba_4096x4_frozen_decoder"] = loop(4096, 4, False, True)[0]
+    out["ba_4096x4_frozen_decoder_dense_bookkeeping"] = loop(4096, 4, False, False)[0]
+    out["full_scan_131072"] = loop(0, 1, True, True, full=True)[0]
+    # parity of one mapping iteration on this map against the oracle (2048 rays of the middle scan): geometry bit for bit, sdf / dsdf / dX
+    from oracle import oracle as O
+    eng = eng_small
+    rs = np.random.default_rng(5)
+    sel = np.sort(rs.choice(len(pts), 2048, replace=False))
+    emb_now = m.emb.cpu().numpy().view(np.uint16).copy()
+    dn = dec.numpy()
+    pose_now = eng.pose6[0].cpu().numpy().copy()
+    eng.forward_backward(m, dec, P.IterConfig(), train_decoder=True)
+    torch.cuda.synchronize()
+    st = eng.stats()
+    P_ = st["P"]
+    got = dict(hit_count=eng.hit_count[:2048].cpu().numpy(), depth=eng.s_depth[:P_].cpu().numpy(), vox=eng.s_vox[:P_].cpu().numpy(),
+               sdf=eng.sdf[:P_].cpu().numpy(), dsdf=eng.dsdf[:P_].cpu().numpy(), dX=eng.dX[:P_].cpu().numpy())
+    ms_o = O.MapState(centres, structure, vertex_idx, id2row, emb_now, 0.2)
+    dp = O.DecoderParams(dn["W1"], dn["b1"], dn["W2"], dn["b2"], dn["W3"], dn["b3"])
+    fr = O.Frame(dirs[sel], pts[sel], cos[sel], pose_now)
+    ref = O.render_and_grad(ms_o, dp, [fr], O.IterCfg(), want_emb_grad=False, want_dec_grad=False)
+    rr, ss = np.nonzero(ref["valid"])
+    geom = bool(P_ == ref["n_samples"] and np.array_equal(got["hit_count"] > 0, ref["hits"]) and np.array_equal(got["depth"], ref["z_vals"][rr, ss])
+                and np.array_equal(got["vox"], ref["s_idx"][rr, ss]))
+    par = {"rays": 2048, "valid_samples": int(P_), "geometry_bit_exact": geom}
+    if geom:
+        par.update(sdf_max_abs_err=float(np.abs(got["sdf"] - ref["sdf"][rr, ss]).max()),
+                   dsdf_max_err_rel_to_max=float(np.abs(got["dsdf"] - ref["dsdf"][rr, ss]).max() / max(np.abs(ref["dsdf"]).max(), 1e-30)),
+                   dX_rel_l2=float(np.linalg.norm((got["dX"] - ref["dfeat"]).astype(np.float64)) / max(np.linalg.norm(ref["dfeat"].astype(np.float64)), 1e-30)))
+        par["ok"] = bool(par["sdf_max_abs_err"] < 1e-4 and par["dsdf_max_err_rel_to_max"] < 1e-3 and par["dX_rel_l2"] < 1e-3)
+    else:
+        par["ok"] = False
+    out["parity_vs_oracle"] = par
+    return out
+
+
 def pose_refine_bench(w, device, steps=200):
     """M2: ms per pose-refine step (track_frame iteration, render_helpers.py:452-512): 2048 rays, step 0.2*voxel,
     decoder + embeddings frozen, 6-dof pose Adam; rays resident, the launch sequence replayed as a hipGraph."""
@@ -431,6 +541,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle parity check")
     ap.add_argument("--no-api-path", action="store_true", help="skip the bundle_adjust_frames / track_frame timings")
+    ap.add_argument("--no-large-map", action="store_true", help="skip the 150-scan / 1e6-row map leg")
     ap.add_argument("--frozen-decoder", action="store_true", help="mapping with update_decoder=False (after freeze_frame)")
     ap.add_argument("--rccl-world1", action="store_true", help="run the ray-sharded code path (RCCL communicator, exchanges inside nl_iteration) "
                                                                 "on ONE GPU with a world-size-1 process group: what a 1-GPU box can check of --gpus N")
@@ -600,6 +711,8 @@ def main():
             if not args.no_api_path:                               # for a while after use and slow the launching thread down
                 out["shard_probe"] = shard_probe_bench(w, device, dt / args.steps * 1e3)   # (same kernels at other sizes: kept out of the
                 out["api_path"] = api_path_bench(w, device)                                #  profiled command's per-kernel averages)
+            if not args.no_large_map:
+                out["large_map"] = large_map_bench(w, device)
             if not args.no_parity:
                 out["parity"] = parity_check(eng, w, cfg, train_dec)
         if not args.no_cpu_baseline and not shard:

@@ -118,6 +118,7 @@ _SIGS = {
     "nl_field_set_debug_buffer": ([_P], _I),
     "nl_geometry_set_debug_buffer": ([_P], _I),
     "nl_geometry_set_lanes_per_ray": ([_I], _I),
+    "nl_geometry_set_intersect_prune": ([_I], _I),
     "nl_geometry_set_sampler_mode": ([_I], _I),
     "nl_dist_merge_counters": ([_P, _I, _I, _I, _P, _P], _I),
     "nl_select_rays": ([_I, _I, ctypes.c_uint, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P], _I),

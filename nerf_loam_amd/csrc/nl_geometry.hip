@@ -238,8 +238,15 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_dfs(DfsArgs a)
 // more pending nodes per round - 16 lanes reach the minimum of one round per tree level (18) - and the traversal is a latency
 // chain per round, so small ray counts want 16 lanes (2048 rays: 77 us with 4 lanes, 52 with 8, 39 with 16); at 131 072 rays the
 // extra workgroups cost throughput (198 / 162 / 198 us) and 8 is best.  0 = choose by ray count (default: 16 lanes up to 16 384 rays).
-#define IQ_QCAP 32
-#define IQ_HCAP 24
+// A ray that meets more than 20 voxels (an accumulated map: the ground plane of every scan, walls behind walls) keeps the FIRST 20 in
+// DFS order like the reference's capped traversal: whenever its list holds more than 20 hits, the lanes of the ray rank them (DFS
+// order), keep the first 20 and remember the 20th as a threshold - later hits behind it and pending subtrees that lie entirely behind
+// it are dropped on the spot (the threshold only ever moves forward, so nothing dropped could have made the final 20).  A leaf-parent
+// expansion reserves room for all its hits at once or puts itself back on the stack until the list has been compacted (>= 8 free
+// slots afterwards: progress); a ray whose pending stack overflows is started again inside the kernel with cautious pops - the
+// sequential fallback is left with rays whose stack is too small even one node at a time.
+template <int LPR> struct IqCaps { static constexpr int Q = 32, H = 28; };      // 8 / 4 lanes per ray (large ray counts): 1.2 KB of LDS per ray
+template <> struct IqCaps<16> { static constexpr int Q = 64, H = 40; };         // 16 lanes per ray (up to 16 384 rays): 2 KB per ray
 
 __device__ __forceinline__ bool less_msb(unsigned a, unsigned b) { return a < b && a < (a ^ b); }
 // true if voxel 1 precedes voxel 2 in the reference's DFS order (= larger z-major Morton code)
@@ -290,10 +297,44 @@ struct ChildSlabs {
 };
 
 static int g_isect_lpr = 0;
+static int g_isect_prune = 1;           // 0 (tests): no first-20 pruning - a ray with more hits than its list holds goes to the sequential fallback
 static int g_sampler_mode = 2;          // 0: one lane per ray, sequential walk (k_sample); 1: step-parallel (k_sample_par); 2: by ray count
 __device__ long long* g_isect_dbg = nullptr;            // optional [blocks][8] stamps of thread 0 (profiling aid, nl_geometry_set_debug_buffer)
 #define ISTAMP(k, v) do { if (g_isect_dbg && threadIdx.x == 0) g_isect_dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)(v); } while (0)
 #define SSTAMP(k) do { if (g_isect_dbg && threadIdx.x == 0) g_isect_dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+
+// More than 20 hits on a ray's list (k_ray_intersect_q): its lanes rank them in DFS order (every lane its own entries against all), keep
+// the first 20 in that order, the 20th becomes the ray's pruning threshold.  Out of line: it is the rare path of a latency-bound loop.
+template <int IQ_LPR, int IQ_HCAP>
+__device__ __noinline__ void iq_compact(int* s_hid, int* s_hx, int* s_hy, int* s_hz, float* s_ht0, float* s_ht1, int* thr, int4* st, int a0, int nh_now, int j)
+{
+    constexpr int IQ_EPL = (IQ_HCAP + IQ_LPR - 1) / IQ_LPR;         // list entries per lane of a ray
+    int eid[IQ_EPL], ex[IQ_EPL], ey[IQ_EPL], ez[IQ_EPL], erk[IQ_EPL]; float e0[IQ_EPL], e1[IQ_EPL];
+#pragma unroll
+    for (int t = 0; t < IQ_EPL; ++t) {
+        const int i = j + t * IQ_LPR;
+        erk[t] = IQ_HCAP;
+        if (i < nh_now) {
+            eid[t] = s_hid[a0 + i]; ex[t] = s_hx[a0 + i]; ey[t] = s_hy[a0 + i]; ez[t] = s_hz[a0 + i]; e0[t] = s_ht0[a0 + i]; e1[t] = s_ht1[a0 + i];
+            int rk = 0;
+            for (int q = 0; q < nh_now; ++q) rk += dfs_before(s_hx[a0 + q], s_hy[a0 + q], s_hz[a0 + q], ex[t], ey[t], ez[t]) ? 1 : 0;
+            erk[t] = rk;                                            // voxels are distinct: the ranks are a permutation of 0 .. nh - 1
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();                               // every lane of the ray holds its entries in registers
+#pragma unroll
+    for (int t = 0; t < IQ_EPL; ++t) {
+        if (erk[t] < NL_MAX_HITS) {
+            const int a = a0 + erk[t];
+            s_hid[a] = eid[t]; s_hx[a] = ex[t]; s_hy[a] = ey[t]; s_hz[a] = ez[t]; s_ht0[a] = e0[t]; s_ht1[a] = e1[t];
+            if (erk[t] == NL_MAX_HITS - 1) { thr[1] = ex[t]; thr[2] = ey[t]; thr[3] = ez[t]; st->w = 1; }
+        }
+    }
+    if (j == 0) st->y = NL_MAX_HITS;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 template <int IQ_LPR>
 __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
@@ -303,13 +344,20 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
     float voxel_size, float max_distance,
     float* __restrict__ rays_d_world, float* __restrict__ gt_dist,
     int* __restrict__ hit_idx, float* __restrict__ hit_t0, float* __restrict__ hit_t1,
-    int* __restrict__ hit_count, int* __restrict__ counters, int* __restrict__ ovf_list)
+    int* __restrict__ hit_count, int* __restrict__ counters, int* __restrict__ ovf_list, int prune)
 {
-    constexpr int IQ_RAYS = NL_GEO_THREADS / IQ_LPR;
+    constexpr int IQ_RAYS = NL_GEO_THREADS / IQ_LPR, IQ_QCAP = IqCaps<IQ_LPR>::Q, IQ_HCAP = IqCaps<IQ_LPR>::H;
     __shared__ int4 s_q[IQ_RAYS * IQ_QCAP];
     __shared__ int s_hid[IQ_RAYS * IQ_HCAP], s_hx[IQ_RAYS * IQ_HCAP], s_hy[IQ_RAYS * IQ_HCAP], s_hz[IQ_RAYS * IQ_HCAP];
     __shared__ float s_ht0[IQ_RAYS * IQ_HCAP], s_ht1[IQ_RAYS * IQ_HCAP];
-    __shared__ int s_head[IQ_RAYS], s_tail[IQ_RAYS], s_nh[IQ_RAYS], s_ovf[IQ_RAYS];
+    // per-ray state in ONE 16-byte word, read once per round (the traversal is a latency chain: every dependent LDS access costs a
+    // round trip): x = stack height, y = hits on the list, z = overflow flag, w = pruning threshold set
+    __shared__ int4 s_st[IQ_RAYS];
+    __shared__ int s_thr[IQ_RAYS * 4];                              // (-, x, y, z): the ray's 20th hit in DFS order so far
+#define s_tail(r_) s_st[r_].x
+#define s_nh(r_) s_st[r_].y
+#define s_ovf(r_) s_st[r_].z
+#define s_thron(r_) s_st[r_].w
     __shared__ int s_hmax;
     if (threadIdx.x == 0) s_hmax = 0;
     ISTAMP(0, __builtin_readcyclecounter());
@@ -319,7 +367,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
     const bool live = r < N;
     float o[3] = {0.f, 0.f, 0.f}, inv[3] = {1.f, 1.f, 1.f};
     const float half_voxel = voxel_size * 0.5f;
-    if (j == 0) { s_head[rl] = 0; s_tail[rl] = 0; s_nh[rl] = 0; s_ovf[rl] = 0; }
+    if (j == 0) s_st[rl] = make_int4(0, 0, 0, 0);
     if (live) {
         const float* P = poses + 12 * (frame_id ? frame_id[r] : 0);
         const float s0 = rays_d_sensor[3 * r], s1 = rays_d_sensor[3 * r + 1], s2 = rays_d_sensor[3 * r + 2];
@@ -337,7 +385,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
             const int2 h0 = blk_hdr[0];
             if (slab_inv(o, inv, hs * voxel_size, hs * voxel_size, hs * voxel_size, half_voxel * fs, &tn, &tf) && h0.x >= 0) {
                 s_q[rl * IQ_QCAP] = make_int4(h0.x, 0, 0, (31 - __clz(root_side >> 1)) << 20);   // children of the root: side root/2
-                s_tail[rl] = 1;
+                s_tail(rl) = 1;
             }
         }
     }
@@ -346,17 +394,52 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
     // keeps the pending set as small as a DFS with all siblings pushed (a line meets at most 4 of a node's 8 children,
     // so <= 3 per level + 4), while still giving four independent memory round trips per ray per round.
     ISTAMP(1, __builtin_readcyclecounter());
+    bool strict = false;
     for (;;) {
-        const int height = (live && !s_ovf[rl]) ? s_tail[rl] : 0;
+        // The pending stack of a ray overflowed (all its lanes popping, each node pushing up to four children): start the ray again,
+        // this time popping only as many nodes per round as can push four children each - that never overflows unless the stack is
+        // too small for the ray one node at a time (then: the sequential fallback).  Uniform over the lanes of a ray.
+        int4 st = s_st[rl];
+        int ovf_now = live ? st.z : 1;
+        if (ovf_now == 1 && prune && live && !strict) {
+            strict = true; ovf_now = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();                       // every lane of the ray has seen the flags
+            if (j == 0) {
+                s_st[rl] = make_int4(0, 0, 0, 0);
+                const float fs = (float)root_side, hs = fs * 0.5f;
+                float tn, tf;
+                const int2 h0 = blk_hdr[0];
+                if (slab_inv(o, inv, hs * voxel_size, hs * voxel_size, hs * voxel_size, half_voxel * fs, &tn, &tf) && h0.x >= 0) {
+                    s_q[rl * IQ_QCAP] = make_int4(h0.x, 0, 0, (31 - __clz(root_side >> 1)) << 20);
+                    s_tail(rl) = 1;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            st = s_st[rl];
+        }
+        // more than 20 hits on the list: rank them in DFS order (every lane its own entries against all), keep the first 20 in that
+        // order, the 20th becomes the pruning threshold.  The condition is uniform over the lanes of a ray.
+        const int nh_now = !ovf_now ? st.y : 0;
+        bool thr_on = live && st.w != 0;
+        if (__builtin_expect(nh_now > NL_MAX_HITS && prune, 0)) {
+            thr_on = true;
+            iq_compact<IQ_LPR, IQ_HCAP>(s_hid, s_hx, s_hy, s_hz, s_ht0, s_ht1, s_thr + 4 * rl, &s_st[rl], rl * IQ_HCAP, nh_now, j);
+        }
+        const int height = !ovf_now ? st.x : 0;
         if (!__any(height > 0)) break;                              // wave-uniform: all 16 rays of this wave are done
         ++rounds;
-        const int k = height < IQ_LPR ? height : IQ_LPR;
+        // nodes popped this round: all the lanes can take; on the ray's second attempt only as many as can push four children each
+        // (a line meets at most four of a node's eight octants): 4 k <= QCAP - height + k
+        int k = height < IQ_LPR ? height : IQ_LPR;
+        if (strict) { const int room = (IQ_QCAP - height) / 3; k = k < room ? k : (room > 1 ? room : 1); }
         const bool mine = j < k;
         int4 e = make_int4(0, 0, 0, 0);
         if (mine) e = s_q[rl * IQ_QCAP + height - 1 - j];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();                           // every lane of the group has fetched its entry
-        if (j == 0 && height > 0) s_tail[rl] = height - k;
+        if (j == 0 && height > 0) s_tail(rl) = height - k;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (mine) {
@@ -370,33 +453,82 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
             const float fs = (float)cs, hs = fs * 0.5f, half = half_voxel * fs;
             ChildSlabs slabs;
             slabs.init(o, inv, px, py, pz, cs, hs, voxel_size, half);
+            // children that can still matter: with a threshold (the ray's 20th hit in DFS order so far) a voxel behind it can never be
+            // among the first 20, and neither can anything below a node whose DFS-first voxel - its max corner - lies behind it
+            unsigned keep = cs == 1 ? exist : has;
+            if (thr_on) {
+                const int tx = s_thr[4 * rl + 1], ty = s_thr[4 * rl + 2], tz = s_thr[4 * rl + 3];
+                const int top = cs - 1;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int cx = px + ((u & 1) ? cs : 0) + top, cy = py + ((u & 2) ? cs : 0) + top, cz = pz + ((u & 4) ? cs : 0) + top;
+                    if (!dfs_before(cx, cy, cz, tx, ty, tz)) keep &= ~(1u << u);
+                }
+            }
             if (cs == 1) {
                 const int ids[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+                if (!strict) {
+                    // first attempt: one slot per hit; a list that runs over (more than IQ_HCAP - 20 new hits since the last compaction)
+                    // starts the ray again in the careful mode below
 #pragma unroll
-                for (int u = 7; u >= 0; --u) {
-                    if (!((exist >> u) & 1u) || ids[u] < 0) continue;
-                    const int vx = px + (u & 1), vy = py + ((u >> 1) & 1), vz = pz + ((u >> 2) & 1);
-                    float tn, tf;
-                    if (slabs.hit(u, &tn, &tf)) {
-                        const int slot = atomicAdd(&s_nh[rl], 1);
-                        if (slot < IQ_HCAP) {
-                            const int a = rl * IQ_HCAP + slot;
-                            s_hid[a] = ids[u]; s_ht0[a] = tn; s_ht1[a] = tf; s_hx[a] = vx; s_hy[a] = vy; s_hz[a] = vz;
-                        } else s_ovf[rl] = 1;
+                    for (int u = 7; u >= 0; --u) {
+                        if (!((keep >> u) & 1u) || ids[u] < 0) continue;
+                        float tn, tf;
+                        if (slabs.hit(u, &tn, &tf)) {
+                            const int slot = atomicAdd(&s_nh(rl), 1);
+                            if (slot < IQ_HCAP) {
+                                const int a = rl * IQ_HCAP + slot;
+                                s_hid[a] = ids[u]; s_ht0[a] = tn; s_ht1[a] = tf;
+                                s_hx[a] = px + (u & 1); s_hy[a] = py + ((u >> 1) & 1); s_hz[a] = pz + ((u >> 2) & 1);
+                            } else s_ovf(rl) = 1;
+                        }
+                    }
+                } else {
+                    unsigned hm = 0u;
+#pragma unroll
+                    for (int u = 7; u >= 0; --u) {
+                        if (!((keep >> u) & 1u) || ids[u] < 0) continue;
+                        float tn, tf;
+                        if (slabs.hit(u, &tn, &tf)) hm |= 1u << u;
+                    }
+                    const int c = __popc(hm);
+                    if (c > 0) {
+                        // room for all of them, or none (no holes in the list): reserve with a compare-and-swap
+                        int base = -1, seen = nh_now > NL_MAX_HITS ? NL_MAX_HITS : nh_now;     // (a guess: the compare-and-swap corrects it)
+                        while (seen + c <= IQ_HCAP) {
+                            const int prev = atomicCAS(&s_nh(rl), seen, seen + c);
+                            if (prev == seen) { base = seen; break; }
+                            seen = prev;
+                        }
+                        if (base >= 0) {
+#pragma unroll
+                            for (int u = 7; u >= 0; --u) {
+                                if (!((hm >> u) & 1u)) continue;
+                                const int a = rl * IQ_HCAP + base++;
+                                float tn, tf;
+                                slabs.hit(u, &tn, &tf);              // (same operations on the same values as in the counting pass)
+                                s_hid[a] = ids[u]; s_ht0[a] = tn; s_ht1[a] = tf;
+                                s_hx[a] = px + (u & 1); s_hy[a] = py + ((u >> 1) & 1); s_hz[a] = pz + ((u >> 2) & 1);
+                            }
+                        } else {
+                            // the list is full until the next round's compaction (>= 8 free slots then): back on the stack (this pop freed a slot)
+                            const int slot = atomicAdd(&s_tail(rl), 1);
+                            if (slot < IQ_QCAP) s_q[rl * IQ_QCAP + slot] = e; else s_ovf(rl) = 2;
+                        }
                     }
                 }
             } else {
 #pragma unroll
                 for (int u = 7; u >= 0; --u) {
-                    if (!((has >> u) & 1u)) continue;
+                    if (!((keep >> u) & 1u)) continue;
                     const int cx = px + ((u & 1) ? cs : 0), cy = py + ((u & 2) ? cs : 0), cz = pz + ((u & 4) ? cs : 0);
                     float tn, tf;
                     if (slabs.hit(u, &tn, &tf)) {
                         const int cb = hdr.x + __popc(has & ((1u << u) - 1u));
-                        const int slot = atomicAdd(&s_tail[rl], 1);
+                        const int slot = atomicAdd(&s_tail(rl), 1);
                         if (slot < IQ_QCAP)
                             s_q[rl * IQ_QCAP + slot] = make_int4(cb, cx, cy, cz | ((csl - 1) << 20));
-                        else s_ovf[rl] = 1;
+                        else s_ovf(rl) = 1;
                     }
                 }
             }
@@ -408,8 +540,8 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
     // finalise: one lane per ray
     int valid = 0;
     if (live && j == 0) {
-        const int nh = s_nh[rl];
-        if (s_ovf[rl] || nh > IQ_HCAP) {
+        const int nh = s_nh(rl);
+        if (s_ovf(rl) || nh > IQ_HCAP) {
             ovf_list[atomicAdd(&counters[NLC_ISECT_OVF], 1)] = r;
             hit_count[r] = 0;                                       // rewritten by the DFS fallback pass
         } else {
@@ -452,6 +584,10 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
     __syncthreads();
     if (threadIdx.x == 0 && s_hmax > 0) atomicMax(&counters[NLC_HMAX], s_hmax);
 }
+#undef s_tail
+#undef s_nh
+#undef s_ovf
+#undef s_thron
 
 // ---------------------------------------------------------------------------------------------
 // Exclusive scan (int32), n <= 1024*1024: per-block (1024 items) scan + block sums, one block
@@ -1246,11 +1382,11 @@ static int intersect_launch(int N, const float* rays_d_sensor, const float* poin
         !hit_idx || !hit_t0 || !hit_t1 || !hit_count || !counters || !scratch_rays) return NL_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int lpr = g_isect_lpr ? g_isect_lpr : (N <= 16384 ? 16 : 8);
-    auto kq = lpr == 16 ? k_ray_intersect_q<16> : lpr == 8 ? k_ray_intersect_q<8> : lpr == 2 ? k_ray_intersect_q<2> : k_ray_intersect_q<4>;
+    auto kq = lpr == 16 ? k_ray_intersect_q<16> : lpr == 8 ? k_ray_intersect_q<8> : k_ray_intersect_q<4>;
     const int IQ_RAYS = NL_GEO_THREADS / lpr;
     hipLaunchKernelGGL(kq, dim3(nl_div_up(N, IQ_RAYS)), dim3(NL_GEO_THREADS), 0, st,
                        N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, (const int2*)blk_hdr, (const int4*)blk_ids, root_side, voxel_size, max_distance,
-                       rays_d_world, gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, scratch_rays);
+                       rays_d_world, gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, scratch_rays, g_isect_prune);
     // rays whose LDS queue / hit list overflowed (none on ordinary scans): sequential DFS, device-side count
     const DfsArgs da = {N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, (const int2*)blk_hdr, (const int4*)blk_ids, root_side, voxel_size,
                         max_distance, rays_d_world, gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, (const int*)scratch_rays};
@@ -1322,7 +1458,8 @@ int nl_scan_hit_rays(const int* hit_count, int* hit_rank, int* ray_of_rank, int 
 int nl_geometry_set_sampler_mode(int mode) { if (mode < 0 || mode > 2) return NL_ERR_INVALID_ARG; g_sampler_mode = mode; return NL_OK; }
 
 /* lanes per ray of the work-list intersect kernel: 0 = by ray count (default: 16 up to 16 384 rays, else 8), or 2 / 4 / 8 / 16 */
-int nl_geometry_set_lanes_per_ray(int lpr) { if (lpr != 0 && lpr != 2 && lpr != 4 && lpr != 8 && lpr != 16) return NL_ERR_INVALID_ARG; g_isect_lpr = lpr; return NL_OK; }
+int nl_geometry_set_intersect_prune(int on) { g_isect_prune = on ? 1 : 0; return NL_OK; }
+int nl_geometry_set_lanes_per_ray(int lpr) { if (lpr != 0 && lpr != 4 && lpr != 8 && lpr != 16) return NL_ERR_INVALID_ARG; g_isect_lpr = lpr; return NL_OK; }
 
 /* profiling aid: device buffer [blocks][8] int64: cycle stamps (start, after set-up, after traversal, after finalise) and the
  * round count of wave 0 of every workgroup of k_ray_intersect_q (NULL disables) */

@@ -553,10 +553,21 @@ def test_full_scan_invariants(nl):
             assert np.abs(g0).max() > 0 and np.abs(g0 - g1).max() <= 5e-5 * np.abs(g0).max(), (name, other)
 
 
-def test_intersect_cap_and_overflow_paths(nl):
+@pytest.mark.parametrize("prune,lpr", [(1, 0), (1, 8), (1, 4), (0, 0)])
+def test_intersect_cap_and_overflow_paths(nl, prune, lpr):
     """Dense voxel slab + grazing rays: up to ~60 voxels per ray.  Exercises the 20-hit cap (first 20 in the
-    reference's DFS order, before the t_min sort), the queue kernel's hit-list / queue overflow and the DFS
-    fallback pass; results must still be bit-identical to the oracle."""
+    reference's DFS order, before the t_min sort): prune = 1 - the work-list kernel ranks a ray's hits in DFS order whenever its list
+    holds more than 20, keeps the first 20 and drops everything behind the 20th from then on (no fallback needed on this scene);
+    prune = 0 - such rays overflow the list and are redone by the sequential DFS fallback pass.  Bit-identical to the oracle both ways."""
+    lib = nl["L"].lib()
+    assert lib.nl_geometry_set_intersect_prune(prune) == 0 and lib.nl_geometry_set_lanes_per_ray(lpr) == 0
+    try:
+        _intersect_cap_case(nl, prune)
+    finally:
+        lib.nl_geometry_set_intersect_prune(1); lib.nl_geometry_set_lanes_per_ray(0)
+
+
+def _intersect_cap_case(nl, prune):
     P, ops, L = nl["P"], nl["ops"], nl["L"]
     xs, ys, zs = np.meshgrid(np.arange(10000, 10048), np.arange(10000, 10040), np.arange(10000, 10003), indexing="ij")
     vox = np.stack([xs, ys, zs], -1).reshape(-1, 3).astype(np.int32)
@@ -580,7 +591,7 @@ def test_intersect_cap_and_overflow_paths(nl):
     ops.ray_intersect(n, eng.rays_d_sensor, eng.points_gt, eng.cos_gt, eng.frame_id, eng.poses12, m.blk_hdr, m.blk_ids, m.root_side, 0.2, 50.0,
                       eng.rays_d_world, eng.gt_dist, eng.hit_idx, eng.hit_t0, eng.hit_t1, eng.hit_count, eng.counters, eng.ray_of_rank)
     cnt = eng.counters.cpu().numpy()
-    assert cnt[L.NLC_ISECT_OVF] > 0                                               # the fallback pass really ran
+    assert (cnt[L.NLC_ISECT_OVF] == 0) if prune else (cnt[L.NLC_ISECT_OVF] > 0)      # pruned in place / the fallback pass really ran
     hc = eng.hit_count[:n].cpu().numpy()
     Hm = oi.shape[1]
     assert cnt[L.NLC_HMAX] == Hm == hc.max()
@@ -605,6 +616,14 @@ def test_fused_scan_launches_equal_the_separate_calls(nl):
     origin = np.array([1999.0, 2003.7, 2000.31], np.float32)
     pose = np.concatenate([origin, np.zeros(3, np.float32)])
     lib = L.lib()
+    lib.nl_geometry_set_intersect_prune(0)       # (rays beyond the work-list kernel's hit list go to the fallback: it is the path under test)
+    try:
+        _fused_scan_cases(P, ops, L, lib, m, origin, pose)
+    finally:
+        lib.nl_geometry_set_intersect_prune(1)
+
+
+def _fused_scan_cases(P, ops, L, lib, m, origin, pose):
     for n in (4096, 6000):
         rng = np.random.default_rng(5)
         tgt = np.stack([rng.uniform(2000.0, 2009.6, n), rng.uniform(2000.0, 2008.0, n), rng.uniform(1998.5, 2002.0, n)], -1).astype(np.float32)
