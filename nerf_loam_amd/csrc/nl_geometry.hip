@@ -344,8 +344,11 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
     float voxel_size, float max_distance,
     float* __restrict__ rays_d_world, float* __restrict__ gt_dist,
     int* __restrict__ hit_idx, float* __restrict__ hit_t0, float* __restrict__ hit_t1,
-    int* __restrict__ hit_count, int* __restrict__ counters, int* __restrict__ ovf_list, int prune)
+    int* __restrict__ hit_count, int* __restrict__ counters, int* __restrict__ ovf_list, int prune_flags)
 {
+    const int prune = prune_flags & 1;
+    const bool push_desc = (prune_flags & 2) == 0;                  // children pushed in descending octant order (bit 1, measurements: ascending)
+    int n_compact = 0;
     constexpr int IQ_RAYS = NL_GEO_THREADS / IQ_LPR, IQ_QCAP = IqCaps<IQ_LPR>::Q, IQ_HCAP = IqCaps<IQ_LPR>::H;
     __shared__ int4 s_q[IQ_RAYS * IQ_QCAP];
     __shared__ int s_hid[IQ_RAYS * IQ_HCAP], s_hx[IQ_RAYS * IQ_HCAP], s_hy[IQ_RAYS * IQ_HCAP], s_hz[IQ_RAYS * IQ_HCAP];
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
         const int nh_now = !ovf_now ? st.y : 0;
         bool thr_on = live && st.w != 0;
         if (__builtin_expect(nh_now > NL_MAX_HITS && prune, 0)) {
-            thr_on = true;
+            thr_on = true; ++n_compact;
             iq_compact<IQ_LPR, IQ_HCAP>(s_hid, s_hx, s_hy, s_hz, s_ht0, s_ht1, s_thr + 4 * rl, &s_st[rl], rl * IQ_HCAP, nh_now, j);
         }
         const int height = !ovf_now ? st.x : 0;
@@ -518,8 +521,12 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
                     }
                 }
             } else {
+                // (push order: ascending octants would make the stack pop the highest octant first, i.e. run ahead in the reference's DFS
+                //  order and find the final first 20 early; measured on the 150-scan map - profiles/r03_c_intersect_probe_large.txt - it
+                //  makes no systematic difference with 16 lanes popping at once, and the tail of many-hit rays is shorter descending)
 #pragma unroll
-                for (int u = 7; u >= 0; --u) {
+                for (int uu = 0; uu < 8; ++uu) {
+                    const int u = push_desc ? 7 - uu : uu;
                     if (!((keep >> u) & 1u)) continue;
                     const int cx = px + ((u & 1) ? cs : 0), cy = py + ((u & 2) ? cs : 0), cz = pz + ((u & 4) ? cs : 0);
                     float tn, tf;
@@ -536,7 +543,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    ISTAMP(2, __builtin_readcyclecounter()); ISTAMP(4, rounds);
+    ISTAMP(2, __builtin_readcyclecounter()); ISTAMP(4, rounds); ISTAMP(5, strict ? 1 : 0); ISTAMP(6, n_compact);
     // finalise: one lane per ray
     int valid = 0;
     if (live && j == 0) {
@@ -1458,7 +1465,7 @@ int nl_scan_hit_rays(const int* hit_count, int* hit_rank, int* ray_of_rank, int 
 int nl_geometry_set_sampler_mode(int mode) { if (mode < 0 || mode > 2) return NL_ERR_INVALID_ARG; g_sampler_mode = mode; return NL_OK; }
 
 /* lanes per ray of the work-list intersect kernel: 0 = by ray count (default: 16 up to 16 384 rays, else 8), or 2 / 4 / 8 / 16 */
-int nl_geometry_set_intersect_prune(int on) { g_isect_prune = on ? 1 : 0; return NL_OK; }
+int nl_geometry_set_intersect_prune(int on) { if (on < 0 || on > 3) return NL_ERR_INVALID_ARG; g_isect_prune = on; return NL_OK; }
 int nl_geometry_set_lanes_per_ray(int lpr) { if (lpr != 0 && lpr != 4 && lpr != 8 && lpr != 16) return NL_ERR_INVALID_ARG; g_isect_lpr = lpr; return NL_OK; }
 
 /* profiling aid: device buffer [blocks][8] int64: cycle stamps (start, after set-up, after traversal, after finalise) and the
