@@ -414,7 +414,7 @@ int nl_octree_export_delta(void* h, float voxel_size, int* ids, float* centres, 
 
 /* profiling aid: 256 x int64 device buffer receiving per-phase shader-clock stamps of workgroup 0 (NULL = off) */
 int nl_geometry_set_sampler_mode(int mode);     /* nl_sample_rays: 0 = sequential walk per ray, 1 = step-parallel, 2 = by ray count (default); same results */
-int nl_geometry_set_intersect_prune(int on);    /* nl_ray_intersect (tests): 0 = rays with more hits than the work-list kernel's list holds go to the sequential fallback instead of being pruned to the first 20 in place; 1 = default; + 2 (measurements) = children pushed in ascending octant order */
+int nl_geometry_set_intersect_prune(int on);    /* nl_ray_intersect (tests): 0 = rays with more hits than the work-list kernel's list holds go to the sequential fallback instead of being pruned to the first 20 in place; 1 = default */
 int nl_geometry_set_lanes_per_ray(int lpr);     /* nl_ray_intersect: 0 = by ray count (default), or 4 / 8 / 16 lanes per ray */
 int nl_geometry_set_debug_buffer(void* dbg);   /* [blocks][8] int64 stamps of nl_ray_intersect's work-list kernel */
 int nl_field_set_debug_buffer(void* dbg);      /* [blocks][8] int64 stamps of nl_trilinear_bwd's workgroups */

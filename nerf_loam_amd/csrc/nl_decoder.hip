@@ -332,23 +332,36 @@ __device__ __forceinline__ void gemm_x9(i32x4 rsX, int w, int lane, const unsign
     }
 }
 
+// value of the neighbouring lane (lane ^ 1) - the neighbouring output column of the 32x32 MFMA tile
+__device__ __forceinline__ float dpp_swap1(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ unsigned dpp_swap1u(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
+
 // H1 = relu(pre + b1) for this lane's column / 32 rows -> three bf16 planes in LDS (A operand of gemm_x9); returns the
-// lane's 32 ReLU bits (bit r: row d32_row(r, lh), bit 16 + r: row 32 + d32_row(r, lh)) for the dgrad epilogue
+// lane's 32 ReLU bits (bit r: row d32_row(r, lh), bit 16 + r: row 32 + d32_row(r, lh)) for the dgrad epilogue.
+// Two neighbouring lanes hold neighbouring columns (k, k + 1) of the same rows, and a row of a plane is k-contiguous: the even lane
+// takes the odd lane's value of row r, the odd lane the even lane's value of row r + 1 (one DPP move per value pair), so every lane
+// stores (k, k + 1) of ONE row as a dword - half the LDS store instructions, and none of the two-lanes-per-bank-word conflicts of
+// 16-bit stores.  The same bits land in the same places.
 __device__ __forceinline__ unsigned store_h1_planes(unsigned short* sP, int col, int lh, const f32x16& c0, const f32x16& c1, float b1c)
 {
-    unsigned short* pb = sP + opaque(4 * lh * SM_STRIDE + col);
+    const bool odd = (col & 1) != 0;
+    unsigned* pb = reinterpret_cast<unsigned*>(sP + opaque((4 * lh + (odd ? 1 : 0)) * SM_STRIDE + (col & ~1)));   // odd lanes: the odd rows
     unsigned m1 = 0u;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const float h = fmaxf((sub ? c1[r] : c0[r]) + b1c, 0.f);
-            m1 |= (h > 0.f) ? (1u << (16 * sub + r)) : 0u;
-            const float hi = trunc_bf16(h), r1 = h - hi, mid = trunc_bf16(r1), lo = r1 - mid;      // lo: <= 8 significant bits
-            unsigned short* d = pb + (32 * sub + D32_RR(r)) * SM_STRIDE;
-            d[0] = (unsigned short)(__float_as_uint(hi) >> 16);
-            d[X_PLANE_ELEMS] = (unsigned short)(__float_as_uint(mid) >> 16);
-            d[2 * X_PLANE_ELEMS] = (unsigned short)(__float_as_uint(lo) >> 16);
+        for (int r = 0; r < 16; r += 2) {
+            const float ha = fmaxf((sub ? c1[r] : c0[r]) + b1c, 0.f), hb = fmaxf((sub ? c1[r + 1] : c0[r + 1]) + b1c, 0.f);
+            m1 |= ((ha > 0.f) ? (1u << (16 * sub + r)) : 0u) | ((hb > 0.f) ? (1u << (16 * sub + r + 1)) : 0u);
+            const float got = dpp_swap1(odd ? ha : hb);            // even lane: the odd lane's row r; odd lane: the even lane's row r + 1
+            const float lo_k = odd ? got : ha, hi_k = odd ? hb : got;      // columns (k, k + 1) of this lane's row
+            unsigned q0, q1, q2;
+            split3_pair(lo_k, hi_k, &q0, &q1, &q2);
+            unsigned* d = pb + ((32 * sub + D32_RR(r)) * SM_STRIDE) / 2;
+            d[0] = q0; d[X_PLANE_ELEMS / 2] = q1; d[X_PLANE_ELEMS] = q2;
         }
     }
     return m1;
@@ -559,22 +572,31 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         {
             unsigned mw = 0u;                       // this lane's 32 ReLU bits: bit r = h0[r] > 0, bit 16+r = h1[r] > 0
             const float* dsb = sdS + opaque(4 * lh);
-            unsigned short* mb = reinterpret_cast<unsigned short*>(lds) + opaque(4 * lh * SM_STRIDE + col);
             float* db = sD + opaque(4 * lh * LDH + col);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float ds0 = dsb[D32_RR(r)], ds1 = dsb[32 + D32_RR(r)];
                 const bool on0 = h0[r] > 0.f, on1 = h1[r] > 0.f;
                 const float g0 = on0 ? ds0 * w3c : 0.f, g1 = on1 ? ds1 * w3c : 0.f;
-                if (XG) {                          // the 0/1 mask itself, as bf16, is the dgrad A operand
-                    mb[D32_RR(r) * SM_STRIDE] = on0 ? 0x3F80 : 0; mb[(32 + D32_RR(r)) * SM_STRIDE] = on1 ? 0x3F80 : 0;
-                } else {
-                    db[D32_RR(r) * LDH] = g0; db[(32 + D32_RR(r)) * LDH] = g1;
-                }
-                if (TRAIN) {
-                    aW3 = fmaf(ds0, h0[r], aW3); aW3 = fmaf(ds1, h1[r], aW3); aB2 += g0; aB2 += g1;
-                    mw |= (on0 ? (1u << r) : 0u) | (on1 ? (1u << (16 + r)) : 0u);
-                }
+                if (!XG) { db[D32_RR(r) * LDH] = g0; db[(32 + D32_RR(r)) * LDH] = g1; }
+                if (TRAIN) { aW3 = fmaf(ds0, h0[r], aW3); aW3 = fmaf(ds1, h1[r], aW3); aB2 += g0; aB2 += g1; }
+                if (XG || TRAIN) mw |= (on0 ? (1u << r) : 0u) | (on1 ? (1u << (16 + r)) : 0u);
+            }
+            if (XG) {
+                // the 0/1 mask itself, as bf16, is the dgrad A operand.  Neighbouring lanes = neighbouring columns of the same rows: with
+                // the neighbour's 32 bits (one DPP move) a lane stores columns (k, k + 1) of one row as a dword - the even lane the even
+                // accumulator rows, the odd lane the odd ones: 16 dword stores instead of 32 half-word stores
+                const bool odd = (col & 1) != 0;
+                const unsigned nb = dpp_swap1u(mw);
+                const unsigned lo_bits = odd ? nb : mw, hi_bits = odd ? mw : nb;        // columns k and k + 1
+                unsigned* mb = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(lds) + opaque((4 * lh + (odd ? 1 : 0)) * SM_STRIDE + (col & ~1)));
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const unsigned lb = (odd ? lo_bits >> 1 : lo_bits) >> (16 * sub + r), hb = (odd ? hi_bits >> 1 : hi_bits) >> (16 * sub + r);
+                        mb[((32 * sub + D32_RR(r)) * SM_STRIDE) / 2] = ((lb & 1u) ? 0x3F80u : 0u) | ((hb & 1u) ? 0x3F800000u : 0u);
+                    }
             }
             // one word per thread, thread-major per tile: k_decoder_wgrad2's thread (same wave/lane) reads it back
             if (TRAIN) a.relu2_mask[(size_t)tile * DEC_THREADS + tid] = mw;

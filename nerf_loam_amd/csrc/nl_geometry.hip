@@ -347,7 +347,6 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
     int* __restrict__ hit_count, int* __restrict__ counters, int* __restrict__ ovf_list, int prune_flags)
 {
     const int prune = prune_flags & 1;
-    const bool push_desc = (prune_flags & 2) == 0;                  // children pushed in descending octant order (bit 1, measurements: ascending)
     int n_compact = 0;
     constexpr int IQ_RAYS = NL_GEO_THREADS / IQ_LPR, IQ_QCAP = IqCaps<IQ_LPR>::Q, IQ_HCAP = IqCaps<IQ_LPR>::H;
     __shared__ int4 s_q[IQ_RAYS * IQ_QCAP];
@@ -398,40 +397,21 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
     // so <= 3 per level + 4), while still giving four independent memory round trips per ray per round.
     ISTAMP(1, __builtin_readcyclecounter());
     bool strict = false;
+    // The rounds of the traversal are a latency chain, so the loop that runs them holds nothing else: a ray that needs one of the two
+    // rare services leaves it (wave-uniform exit), is served below, and the rounds resume.
     for (;;) {
-        // The pending stack of a ray overflowed (all its lanes popping, each node pushing up to four children): start the ray again,
-        // this time popping only as many nodes per round as can push four children each - that never overflows unless the stack is
-        // too small for the ray one node at a time (then: the sequential fallback).  Uniform over the lanes of a ray.
-        int4 st = s_st[rl];
-        int ovf_now = live ? st.z : 1;
-        if (ovf_now == 1 && prune && live && !strict) {
-            strict = true; ovf_now = 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();                       // every lane of the ray has seen the flags
-            if (j == 0) {
-                s_st[rl] = make_int4(0, 0, 0, 0);
-                const float fs = (float)root_side, hs = fs * 0.5f;
-                float tn, tf;
-                const int2 h0 = blk_hdr[0];
-                if (slab_inv(o, inv, hs * voxel_size, hs * voxel_size, hs * voxel_size, half_voxel * fs, &tn, &tf) && h0.x >= 0) {
-                    s_q[rl * IQ_QCAP] = make_int4(h0.x, 0, 0, (31 - __clz(root_side >> 1)) << 20);
-                    s_tail(rl) = 1;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            st = s_st[rl];
-        }
-        // more than 20 hits on the list: rank them in DFS order (every lane its own entries against all), keep the first 20 in that
-        // order, the 20th becomes the pruning threshold.  The condition is uniform over the lanes of a ray.
-        const int nh_now = !ovf_now ? st.y : 0;
-        bool thr_on = live && st.w != 0;
-        if (__builtin_expect(nh_now > NL_MAX_HITS && prune, 0)) {
-            thr_on = true; ++n_compact;
-            iq_compact<IQ_LPR, IQ_HCAP>(s_hid, s_hx, s_hy, s_hz, s_ht0, s_ht1, s_thr + 4 * rl, &s_st[rl], rl * IQ_HCAP, nh_now, j);
-        }
-        const int height = !ovf_now ? st.x : 0;
-        if (!__any(height > 0)) break;                              // wave-uniform: all 16 rays of this wave are done
+    bool finished = false;
+    int4 st;
+    int ovf_now, nh_now, height;
+    bool thr_on;
+    for (;;) {
+        st = s_st[rl];
+        ovf_now = live ? st.z : 1;
+        nh_now = !ovf_now ? st.y : 0;
+        thr_on = live && st.w != 0;
+        height = !ovf_now ? st.x : 0;
+        if (__any(prune && live && ((ovf_now == 1 && !strict) || nh_now > NL_MAX_HITS))) break;       // a ray of this wave needs service
+        if (!__any(height > 0)) { finished = true; break; }        // wave-uniform: all rays of this wave are done
         ++rounds;
         // nodes popped this round: all the lanes can take; on the ray's second attempt only as many as can push four children each
         // (a line meets at most four of a node's eight octants): 4 k <= QCAP - height + k
@@ -522,11 +502,10 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
                 }
             } else {
                 // (push order: ascending octants would make the stack pop the highest octant first, i.e. run ahead in the reference's DFS
-                //  order and find the final first 20 early; measured on the 150-scan map - profiles/r03_c_intersect_probe_large.txt - it
-                //  makes no systematic difference with 16 lanes popping at once, and the tail of many-hit rays is shorter descending)
+                //  order and find the final first 20 early; measured on the 150-scan map with a run-time switch, since removed -
+                //  profiles/r03_c_intersect_probe_large.txt - it makes no systematic difference with 16 lanes popping at once)
 #pragma unroll
-                for (int uu = 0; uu < 8; ++uu) {
-                    const int u = push_desc ? 7 - uu : uu;
+                for (int u = 7; u >= 0; --u) {
                     if (!((keep >> u) & 1u)) continue;
                     const int cx = px + ((u & 1) ? cs : 0), cy = py + ((u & 2) ? cs : 0), cz = pz + ((u & 4) ? cs : 0);
                     float tn, tf;
@@ -542,6 +521,33 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+    if (finished) break;
+    // (1) The pending stack (or, on the first attempt, the hit list) of a ray overflowed - all its lanes popping, each node pushing
+    // up to four children: start the ray again, this time popping only as many nodes per round as can push four children each and
+    // reserving list slots before writing them.  That never overflows unless the stack is too small for the ray one node at a time
+    // (then: the sequential fallback).  Uniform over the lanes of a ray.
+    if (ovf_now == 1 && prune && live && !strict) {
+        strict = true;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();                           // every lane of the ray has seen the flags
+        if (j == 0) {
+            s_st[rl] = make_int4(0, 0, 0, 0);
+            const float fs = (float)root_side, hs = fs * 0.5f;
+            float tn, tf;
+            const int2 h0 = blk_hdr[0];
+            if (slab_inv(o, inv, hs * voxel_size, hs * voxel_size, hs * voxel_size, half_voxel * fs, &tn, &tf) && h0.x >= 0) {
+                s_q[rl * IQ_QCAP] = make_int4(h0.x, 0, 0, (31 - __clz(root_side >> 1)) << 20);
+                s_tail(rl) = 1;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else if (nh_now > NL_MAX_HITS && prune) {
+        // (2) more than 20 hits on the list: rank them in DFS order, keep the first 20, the 20th becomes the pruning threshold
+        ++n_compact;
+        iq_compact<IQ_LPR, IQ_HCAP>(s_hid, s_hx, s_hy, s_hz, s_ht0, s_ht1, s_thr + 4 * rl, &s_st[rl], rl * IQ_HCAP, nh_now, j);
+    }
     }
     ISTAMP(2, __builtin_readcyclecounter()); ISTAMP(4, rounds); ISTAMP(5, strict ? 1 : 0); ISTAMP(6, n_compact);
     // finalise: one lane per ray
@@ -1465,7 +1471,7 @@ int nl_scan_hit_rays(const int* hit_count, int* hit_rank, int* ray_of_rank, int 
 int nl_geometry_set_sampler_mode(int mode) { if (mode < 0 || mode > 2) return NL_ERR_INVALID_ARG; g_sampler_mode = mode; return NL_OK; }
 
 /* lanes per ray of the work-list intersect kernel: 0 = by ray count (default: 16 up to 16 384 rays, else 8), or 2 / 4 / 8 / 16 */
-int nl_geometry_set_intersect_prune(int on) { if (on < 0 || on > 3) return NL_ERR_INVALID_ARG; g_isect_prune = on; return NL_OK; }
+int nl_geometry_set_intersect_prune(int on) { g_isect_prune = on ? 1 : 0; return NL_OK; }
 int nl_geometry_set_lanes_per_ray(int lpr) { if (lpr != 0 && lpr != 4 && lpr != 8 && lpr != 16) return NL_ERR_INVALID_ARG; g_isect_lpr = lpr; return NL_OK; }
 
 /* profiling aid: device buffer [blocks][8] int64: cycle stamps (start, after set-up, after traversal, after finalise) and the

@@ -7,7 +7,7 @@ cp nerf_loam_amd/libnerfloam_hip.so /tmp/product.so
 for round in $(seq 1 ${ROUNDS:-2}); do
   for lib in ab_libs/*.so; do
     cp $lib nerf_loam_amd/libnerfloam_hip.so
-    timeout 300 python bench.py --no-cpu-baseline --no-parity --no-api-path 2>/dev/null | python -c "
+    timeout 300 python bench.py --no-cpu-baseline --no-parity --no-api-path --no-large-map 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 r = d['roofline']
