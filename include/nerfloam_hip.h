@@ -111,6 +111,13 @@ int nl_select_rays_batch(int F, const int* M, const int* n_select, const unsigne
                          float* out_rays_d, float* out_points, float* out_cos, int* out_frame_id, int* workspace, int parity,
                          int* fail_word /* optional device word set to 1 when the window was missed */, void* stream);
 
+/* the same with the frame id of every entry given explicitly (frame_ids[f] is written to out_frame_id; NULL: f): entries may then be
+ * (iteration, frame) pairs - all ray subsets of a whole optimisation call drawn up front, eight entries per call of this function */
+int nl_select_rays_batch_ex(int F, const int* M, const int* n_select, const unsigned* seed, const float* const* rays_d,
+                            const float* const* points, const float* const* cos_in, unsigned char* const* mask_out, const int* out_off,
+                            const int* frame_ids, float* out_rays_d, float* out_points, float* out_cos, int* out_frame_id, int* workspace,
+                            int parity, int* fail_word, void* stream);
+
 /* ray_sample: voxel_helpers.py:571-598 + :262-347 + sample_gpu.cu:133-239.
  * emit = 0: per-ray sample count, S_max and the geometry-only loss normalisers (criterion.py:67-88);
  * emit = 1: compacted (voxel, depth, dist, ray) records at samp_off[ray] (capacity-checked).

@@ -282,10 +282,10 @@ int nl_select_rays(int M, int n_select, unsigned seed, const float* rays_d, cons
  * workspace: NL_SELECT_BATCH_WS_INTS(F) ints, ZERO-FILLED once by the caller at allocation; parity alternates 0 / 1 between calls
  * (the candidate counter of one call is cleared by the next one's second pass).  ws[f][2] != 0 afterwards (and *fail_word = 1, if
  * given) = the window was missed (never observed; ~1e-50) and the selection of that call is incomplete. */
-int nl_select_rays_batch(int F, const int* M, const int* n_select, const unsigned* seed, const float* const* rays_d,
-                         const float* const* points, const float* const* cos_in, unsigned char* const* mask_out, const int* out_off,
-                         float* out_rays_d, float* out_points, float* out_cos, int* out_frame_id, int* workspace, int parity,
-                         int* fail_word, void* stream)
+int nl_select_rays_batch_ex(int F, const int* M, const int* n_select, const unsigned* seed, const float* const* rays_d,
+                            const float* const* points, const float* const* cos_in, unsigned char* const* mask_out, const int* out_off,
+                            const int* frame_ids, float* out_rays_d, float* out_points, float* out_cos, int* out_frame_id, int* workspace,
+                            int parity, int* fail_word, void* stream)
 {
     if (F <= 0 || F > SEL_MAX_FRAMES || !M || !n_select || !seed || !rays_d || !points || !cos_in || !out_off || !out_rays_d || !out_points ||
         !out_cos || !workspace || (parity != 0 && parity != 1))
@@ -303,7 +303,7 @@ int nl_select_rays_batch(int F, const int* M, const int* n_select, const unsigne
         if (lo < 1.0 || hi > 4294967294.0) return NL_ERR_CAPACITY;
         SelFrame& fr = a.f[f];
         fr.d = rays_d[f]; fr.p = points[f]; fr.c = cos_in[f]; fr.mask = mask_out ? mask_out[f] : nullptr;
-        fr.M = m; fr.n = n; fr.out_off = out_off[f]; fr.frame = f; fr.seed = seed[f]; fr.lo = (unsigned)lo; fr.hi = (unsigned)hi;
+        fr.M = m; fr.n = n; fr.out_off = out_off[f]; fr.frame = frame_ids ? frame_ids[f] : f; fr.seed = seed[f]; fr.lo = (unsigned)lo; fr.hi = (unsigned)hi;
         int nblk = nl_div_up(m, 1024); if (nblk > SEL_MAXB) nblk = SEL_MAXB;
         fr.nblk = nblk;
         fr.wchunk = nl_div_up(nl_div_up(m, 4 * nblk), 64) * 64;
@@ -314,6 +314,15 @@ int nl_select_rays_batch(int F, const int* M, const int* n_select, const unsigne
     hipLaunchKernelGGL(k_sel_window_b, dim3(max_blk, F), dim3(256), 0, (hipStream_t)stream, a);
     NL_LAUNCH_CHECK();
     return NL_OK;
+}
+
+int nl_select_rays_batch(int F, const int* M, const int* n_select, const unsigned* seed, const float* const* rays_d,
+                         const float* const* points, const float* const* cos_in, unsigned char* const* mask_out, const int* out_off,
+                         float* out_rays_d, float* out_points, float* out_cos, int* out_frame_id, int* workspace, int parity,
+                         int* fail_word, void* stream)
+{
+    return nl_select_rays_batch_ex(F, M, n_select, seed, rays_d, points, cos_in, mask_out, out_off, nullptr, out_rays_d, out_points, out_cos,
+                                   out_frame_id, workspace, parity, fail_word, stream);
 }
 
 }  // extern "C"

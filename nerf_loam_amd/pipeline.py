@@ -360,6 +360,57 @@ class SdfEngine:
         self.N = q["total"]
         return True
 
+    def predraw(self, scans, n_rays, seeds):
+        """Draw the ray subsets of ALL iterations of a call up front: (iteration, frame) pairs go through nl_select_rays_batch_ex eight at a
+        time - 2 launches per eight pairs instead of 2 per iteration inside the loop (at 2048 rays x 1 frame the two selection launches
+        were 10 % of an iteration).  The same subsets as reselect(seed) iteration by iteration: same keys, same seeds.  use_predrawn(it)
+        then points the iteration descriptor at iteration it's slice.  Returns False when the shapes need the per-frame radix path."""
+        F, iters = len(scans), len(seeds)
+        Ms = [int(sc["dirs"].shape[0]) for sc in scans]
+        ns = [min(int(n_rays), M) for M in Ms]
+        tot = sum(ns)
+        if tot > self.N_cap or F > L.NL_SEL_MAX_FRAMES or any(n >= M for n, M in zip(ns, Ms)) or not all(sc["dirs"].is_contiguous() for sc in scans):
+            return False
+        d = self.dev
+        pre = getattr(self, "_pre", None)
+        if pre is None or pre["iters"] < iters or pre["tot"] != tot or pre["Ms"] != Ms:
+            pre = dict(iters=iters, tot=tot, Ms=Ms, d=torch.empty(iters * tot, 3, dtype=F32, device=d), p=torch.empty(iters * tot, 3, dtype=F32, device=d),
+                       c=torch.empty(iters * tot, dtype=F32, device=d), f=torch.empty(iters * tot, dtype=I32, device=d),
+                       masks=[torch.empty(iters, M, dtype=torch.uint8, device=d) for M in Ms],
+                       ws=torch.zeros(-(-iters * F // L.NL_SEL_MAX_FRAMES) * L.NL_SEL_MAX_FRAMES * L.NL_SEL_BATCH_WS_INTS_PER_FRAME, dtype=I32, device=d),
+                       parity=0)
+            self._pre = pre
+        pairs = [(it, f) for it in range(iters) for f in range(F)]
+        lib, sp = L.lib(), L.stream_ptr()
+        per = L.NL_SEL_BATCH_WS_INTS_PER_FRAME
+        offs = [sum(ns[:f]) for f in range(F)]
+        for c0 in range(0, len(pairs), L.NL_SEL_MAX_FRAMES):
+            chunk = pairs[c0:c0 + L.NL_SEL_MAX_FRAMES]
+            n = len(chunk)
+            I, U, PP = ctypes.c_int * n, ctypes.c_uint * n, ctypes.c_void_p * n
+            rc = lib.nl_select_rays_batch_ex(
+                n, I(*[Ms[f] for _, f in chunk]), I(*[ns[f] for _, f in chunk]), U(*[(int(seeds[it]) * 1000003 + f) & 0xFFFFFFFF for it, f in chunk]),
+                PP(*[scans[f]["dirs"].data_ptr() for _, f in chunk]), PP(*[scans[f]["points"].data_ptr() for _, f in chunk]),
+                PP(*[scans[f]["cos"].data_ptr() for _, f in chunk]), PP(*[pre["masks"][f][it].data_ptr() for it, f in chunk]),
+                I(*[it * tot + offs[f] for it, f in chunk]), I(*[f for _, f in chunk]), pre["d"].data_ptr(), pre["p"].data_ptr(), pre["c"].data_ptr(),
+                pre["f"].data_ptr(), pre["ws"].data_ptr() + 4 * c0 * per, pre["parity"], self.adam_state.data_ptr() + 12, sp)
+            if rc == 4:
+                return False
+            L.check(rc, "nl_select_rays_batch_ex")
+        pre["parity"] ^= 1
+        pre["drawn"] = iters
+        return True
+
+    def use_predrawn(self, it):
+        """iteration `it` of the call runs on the ray subset predraw() drew for it (run_bound: the descriptor's ray pointers)"""
+        pre = self._pre
+        tot = pre["tot"]
+        d = self._desc
+        d.rays_d_sensor, d.points_gt = pre["d"].data_ptr() + 12 * it * tot, pre["p"].data_ptr() + 12 * it * tot
+        d.cos_gt, d.frame_id = pre["c"].data_ptr() + 4 * it * tot, pre["f"].data_ptr() + 4 * it * tot
+        self.N = tot
+        self._pre_it = it
+
     def set_poses(self, pose6, optimise=None):
         """pose6 [F,6] = (t, w) like se3pose.OptimizablePose.data; optimise[f] = pose is in the optimiser."""
         p = torch.as_tensor(np.asarray(pose6, np.float32)).reshape(-1, 6)

@@ -120,6 +120,21 @@ def _gather_rays(frames, N_rays, track=False):
     return torch.cat(d).float(), torch.cat(p).float(), torch.cat(c).float(), torch.cat(f)
 
 
+def _ray_plan(eng, frames, N_rays, seeds, track=False):
+    """-> use(it): makes iteration `it` of the call run on its ray subset.  Device selection: the subsets of ALL iterations are drawn up front
+    (SdfEngine.predraw: two launches per eight (iteration, frame) pairs), an iteration then only points the descriptor at its slice; the
+    frames' boolean `sample_mask` (the reference's, lidarFrame.py:55-57) ends as a view of the last iteration's mask.  Shapes outside the
+    window method's range and host selection: one draw per iteration (_ray_drawer)."""
+    if RAY_SELECTION == "device":
+        scans = [fr.device_scan(eng.dev) for fr in frames]
+        if eng.predraw(scans, N_rays, seeds):
+            for f, fr in enumerate(frames):
+                fr.sample_mask = eng._pre["masks"][f][len(seeds) - 1].view(torch.bool).view(-1, 1)
+            return eng.use_predrawn
+    draw = _ray_drawer(eng, frames, N_rays, track=track)
+    return lambda it: draw(seeds[it])
+
+
 def _ray_drawer(eng, frames, N_rays, track=False):
     """-> draw(seed): puts the iteration's ray subset of every frame into the engine.  Device selection: the frame list is
     marshalled once per call, every draw is one C call (two launches for all frames); the frames' boolean `sample_mask`
@@ -168,15 +183,13 @@ def bundle_adjust_frames(keyframe_graph, embeddings, map_states, sdf_network, lo
     if profiler is not None:
         profiler.tok("mapping_add_optim")
     seed0 = _draw_seed()
-    draw = _ray_drawer(eng, keyframe_graph, N_rays)
-    draw(seed0)
+    use = _ray_plan(eng, keyframe_graph, N_rays, [seed0 + it for it in range(num_iterations)])
     # one C call per iteration (nl_iteration: ~15 launches); no host synchronisation inside the loop: an unusable iteration is
     # recognised and skipped by the optimiser kernel itself (skip_mode), fresh sampler jitter comes from the device step counter
     eng.bind(m, dec, cfg, train_decoder=update_decoder, want_emb_grad=True, want_pose_grad=any(optimise), update_emb=True,
              update_decoder=update_decoder, update_pose=any(optimise), skip_mode=1, fresh_noise=_fresh_noise())
     for it in range(num_iterations):
-        if it:
-            draw(seed0 + it)
+        use(it)
         eng.run_bound()
     _, _, p6 = _finish_call(eng, "Mapping")
     with torch.no_grad():
@@ -201,13 +214,11 @@ def track_frame(frame_pose, curr_frame, map_states, sdf_network, loss_criteria, 
     eng.set_poses(init_pose.data.detach().cpu().numpy()[None], [1])
     eng.begin_call(m, None, emb_state=False)
     seed0 = _draw_seed()
-    draw = _ray_drawer(eng, [curr_frame], N_rays, track=True)
-    draw(seed0)
+    use = _ray_plan(eng, [curr_frame], N_rays, [seed0 + it for it in range(num_iterations)], track=True)
     eng.bind(m, dec, cfg, train_decoder=False, want_emb_grad=False, want_pose_grad=True, update_emb=False, update_decoder=False,
              update_pose=True, lr_pose=lr, skip_mode=2, fresh_noise=_fresh_noise())       # sticky skip = the reference's `break`
     for it in range(num_iterations):
-        if it:
-            draw(seed0 + it)
+        use(it)
         eng.run_bound()
     _, skipped, p6 = _finish_call(eng, "Tracking")
     hit_mask = None if skipped else (eng.hit_count[:eng.N] > 0)
