@@ -307,26 +307,17 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
         FSTAMP(2);
         flush_run(true);
         FSTAMP(3);
-        if (a.want_emb_grad && a.touched.flags) {
-            // rows whose accumulators receive their first contribution since begin_call go onto the touched-rows list.  The flag bit is
-            // set with a scattered atomic; the list position comes from ONE same-address atomic per workgroup (such an atomic costs
-            // ~12 ns whoever issues it: one per row was 0.6 ms per 20-iteration call at 2048 rays)
-            for (int i = lane; i < TB_SLOTS; i += 64) {
-                const int key = s_key[i];
-                if (key < 0) continue;
-                unsigned* wp = a.touched.flags + (key >> 5);
-                const unsigned bit = 1u << (key & 31);
-                if (*reinterpret_cast<volatile unsigned*>(wp) & bit) continue;
-                if (!(atomicOr(wp, bit) & bit)) s_new[atomicAdd(&s_new_n, 1)] = key;
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) s_new_base = s_new_n > 0 ? atomicAdd(a.touched.count, s_new_n) : 0;
-            __syncthreads();
-            for (int i = threadIdx.x; i < s_new_n; i += NL_FIELD_THREADS) a.touched.list[s_new_base + i] = s_new[i];
-            __syncthreads();
-            if (threadIdx.x == 0) s_new_n = 0;
-        }
         if (a.want_emb_grad) {
+            // rows whose accumulators receive their first contribution since begin_call go onto the touched-rows list (a.touched).  Their
+            // flag words are loaded first, so that the round trip runs under the flush below
+            int tkey[TB_SLOTS / 64]; unsigned tword[TB_SLOTS / 64];
+            if (a.touched.flags) {
+#pragma unroll
+                for (int t = 0; t < TB_SLOTS / 64; ++t) {
+                    tkey[t] = s_key[lane + 64 * t];
+                    tword[t] = tkey[t] >= 0 ? *reinterpret_cast<volatile unsigned*>(a.touched.flags + (tkey[t] >> 5)) : 0xFFFFFFFFu;
+                }
+            }
             // flush this wave's table: 16 lanes per slot (one channel each), touched rows only; slots are reset for the next span
             for (int base = 0; base < TB_SLOTS; base += 4) {
                 const int slot = base + (lane >> 4), c = lane & 15;
@@ -340,6 +331,24 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
             __builtin_amdgcn_wave_barrier();
             for (int i = lane; i < TB_SLOTS; i += 64) s_key[i] = -1;
             FSTAMP(5);
+            if (a.touched.flags) {
+                // the flag bit is set with a scattered atomic; the list position comes from ONE same-address atomic per workgroup (such
+                // an atomic costs ~12 ns whoever issues it: one per row was 0.6 ms per 20-iteration call at 2048 rays)
+#pragma unroll
+                for (int t = 0; t < TB_SLOTS / 64; ++t) {
+                    const unsigned bit = 1u << (tkey[t] & 31);
+                    if (tkey[t] >= 0 && !(tword[t] & bit) && !(atomicOr(a.touched.flags + (tkey[t] >> 5), bit) & bit)) s_new[atomicAdd(&s_new_n, 1)] = tkey[t];
+                }
+                __syncthreads();
+                if (s_new_n > 0) {                                  // uniform over the workgroup; after the first iterations of a call: rare
+                    if (threadIdx.x == 0) s_new_base = atomicAdd(a.touched.count, s_new_n);
+                    __syncthreads();
+                    for (int i = threadIdx.x; i < s_new_n; i += NL_FIELD_THREADS) a.touched.list[s_new_base + i] = s_new[i];
+                    __syncthreads();
+                    if (threadIdx.x == 0) s_new_n = 0;
+                    __syncthreads();
+                }
+            }
         }
     }
     if (a.want_pose_grad) {
