@@ -67,7 +67,10 @@ int nl_inverse_cdf_sampling(const int* pts_idx, const float* min_depth, const fl
  * once per map update; one block per interior node, numbered breadth-first): blk_hdr[B] = int2 (first child
  * block, exist mask | own-a-block mask << 8; children blocks are consecutive in octant order), blk_ids[B][8] =
  * child node ids, root_side = side of node 0 in voxels (voxel_structure[0][8]); block 0 is a pseudo block for the
- * root.  Node centres are recomputed from the lattice path ((xyz + side/2) * voxel_size, exact), not loaded.
+ * root: id slot 0 = node 0, slots 1..7 describe the single-child chain under the root (1 = its length n, 2 / 3 = the n octants, 3 bits
+ * each, level 0 first, 30 bits in slot 2, the rest in slot 3; 4 = the block the chain ends in; 5..7 = that block's lattice position;
+ * n = 0 and end block = the root's children block when the root branches) - the kernel runs the chain's slab tests in registers and
+ * starts its work-list at the chain's end.  Node centres are recomputed from the lattice path ((xyz + side/2) * voxel_size, exact), not loaded.
  * Outputs: rays_d_world[N,3], gt_dist[N] = ||p||*cos, hit_idx/t0/t1[N,20] (only the first hit_count[r]
  * entries of a row are written: sorted by t_min, culled), hit_count[N];
  * counters[NLC_HMAX] is raised (atomic max).  counters must be zeroed per iteration. */

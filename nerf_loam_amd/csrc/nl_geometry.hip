@@ -303,6 +303,32 @@ __device__ long long* g_isect_dbg = nullptr;            // optional [blocks][8] 
 #define ISTAMP(k, v) do { if (g_isect_dbg && threadIdx.x == 0) g_isect_dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)(v); } while (0)
 #define SSTAMP(k) do { if (g_isect_dbg && threadIdx.x == 0) g_isect_dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
 
+// First entry of a ray's work-list: the root's box, then the single-child chain under it (pack_children_blocks: the pseudo block's id
+// slots hold its length, octants and end) tested in registers with the arithmetic of an ordinary expansion - what the traversal would
+// do level by level, without the memory round trip per level.  false: the ray misses the tree.
+__device__ __forceinline__ bool iq_first_entry(const float o[3], const float inv[3], const int2* __restrict__ blk_hdr, const int4* __restrict__ blk_ids,
+                                               int root_side, float voxel_size, float half_voxel, int4* entry)
+{
+    const int4 c0 = blk_ids[0], c1 = blk_ids[1];                    // ids of the pseudo block: (root, n_chain, octants lo, octants hi | end block, x, y, z)
+    const int2 h0 = blk_hdr[0];
+    const float fs = (float)root_side, hs = fs * 0.5f;
+    float tn, tf;
+    if (!(slab_inv(o, inv, hs * voxel_size, hs * voxel_size, hs * voxel_size, half_voxel * fs, &tn, &tf) && h0.x >= 0)) return false;
+    int px = 0, py = 0, pz = 0, cs = root_side >> 1;
+    const int n_chain = c0.y;
+    for (int l = 0; l < n_chain; ++l) {
+        const int u = (int)((((unsigned long long)(unsigned)c0.w << 30) | (unsigned long long)(unsigned)c0.z) >> (3 * l)) & 7;
+        const float fcs = (float)cs;
+        ChildSlabs slabs;
+        slabs.init(o, inv, px, py, pz, cs, fcs * 0.5f, voxel_size, half_voxel * fcs);
+        if (!slabs.hit(u, &tn, &tf)) return false;
+        px += (u & 1) ? cs : 0; py += (u & 2) ? cs : 0; pz += (u & 4) ? cs : 0;
+        cs >>= 1;
+    }
+    *entry = make_int4(n_chain ? c1.x : h0.x, px, py, pz | ((31 - __clz(cs)) << 20));
+    return true;
+}
+
 // More than 20 hits on a ray's list (k_ray_intersect_q): its lanes rank them in DFS order (every lane its own entries against all), keep
 // the first 20 in that order, the 20th becomes the ray's pruning threshold.  Out of line: it is the rare path of a latency-bound loop.
 template <int IQ_LPR, int IQ_HCAP>
@@ -382,13 +408,8 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
             rays_d_world[3 * r] = d[0]; rays_d_world[3 * r + 1] = d[1]; rays_d_world[3 * r + 2] = d[2];
             const float gx = points_gt[3 * r], gy = points_gt[3 * r + 1], gz = points_gt[3 * r + 2];
             gt_dist[r] = sqrtf((gx * gx + gy * gy) + gz * gz) * cos_gt[r];
-            const float fs = (float)root_side, hs = fs * 0.5f;
-            float tn, tf;
-            const int2 h0 = blk_hdr[0];
-            if (slab_inv(o, inv, hs * voxel_size, hs * voxel_size, hs * voxel_size, half_voxel * fs, &tn, &tf) && h0.x >= 0) {
-                s_q[rl * IQ_QCAP] = make_int4(h0.x, 0, 0, (31 - __clz(root_side >> 1)) << 20);   // children of the root: side root/2
-                s_tail(rl) = 1;
-            }
+            int4 e0;
+            if (iq_first_entry(o, inv, blk_hdr, blk_ids, root_side, voxel_size, half_voxel, &e0)) { s_q[rl * IQ_QCAP] = e0; s_tail(rl) = 1; }
         }
     }
     __syncthreads();
@@ -533,13 +554,8 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
         __builtin_amdgcn_wave_barrier();                           // every lane of the ray has seen the flags
         if (j == 0) {
             s_st[rl] = make_int4(0, 0, 0, 0);
-            const float fs = (float)root_side, hs = fs * 0.5f;
-            float tn, tf;
-            const int2 h0 = blk_hdr[0];
-            if (slab_inv(o, inv, hs * voxel_size, hs * voxel_size, hs * voxel_size, half_voxel * fs, &tn, &tf) && h0.x >= 0) {
-                s_q[rl * IQ_QCAP] = make_int4(h0.x, 0, 0, (31 - __clz(root_side >> 1)) << 20);
-                s_tail(rl) = 1;
-            }
+            int4 e0;
+            if (iq_first_entry(o, inv, blk_hdr, blk_ids, root_side, voxel_size, half_voxel, &e0)) { s_q[rl * IQ_QCAP] = e0; s_tail(rl) = 1; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();

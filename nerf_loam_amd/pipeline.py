@@ -75,7 +75,30 @@ def pack_children_blocks(centres, structure):
                                  (exist * bits).sum(1) + ((owns * bits).sum(1) << 8)], 1).to(torch.int32))
         next_index += frontier.numel()
         frontier = chc[owns]                                           # parent-major, octant-minor: consecutive per parent
-    return torch.cat(ids).contiguous(), torch.cat(hdrs).contiguous()
+    blk_ids, blk_hdr = torch.cat(ids).contiguous(), torch.cat(hdrs).contiguous()
+    # Single-child chain under the root: the lattice is 262 144 voxels wide, a map a few hundred metres - the first ~8-10 levels of the tree
+    # have ONE child each.  Their slab tests need no memory (the geometry follows from the octants), so the traversal kernel evaluates them
+    # in registers and starts its work-list at the chain's end: one round trip per level saved on a pure latency chain.  The chain lives in the
+    # pseudo block's unused id slots: [1] = length, [2] / [3] = the octants (3 bits each, level 0 first), [4] = the block the work-list starts
+    # with, [5..7] = its lattice position.  (Blocks are numbered breadth-first: the chain's blocks are 1, 2, 3, ...)
+    if has_root:
+        head = blk_hdr[:40].cpu().numpy()
+        cs, b, pos, octs = root_side_of(structure) >> 1, 1, [0, 0, 0], []
+        while cs > 1 and b < len(head) and len(octs) < 20:
+            has = (int(head[b, 1]) >> 8) & 255
+            if has == 0 or has & (has - 1):                           # no child block, or several: the chain ends here
+                break
+            u = has.bit_length() - 1
+            octs.append(u)
+            pos = [pos[0] + (cs if u & 1 else 0), pos[1] + (cs if u & 2 else 0), pos[2] + (cs if u & 4 else 0)]
+            b, cs = int(head[b, 0]), cs >> 1
+        packed = sum(u << (3 * i) for i, u in enumerate(octs))
+        blk_ids[0, 1:8] = torch.tensor([len(octs), packed & 0x3FFFFFFF, packed >> 30, b, pos[0], pos[1], pos[2]], dtype=torch.int32, device=dev)
+    return blk_ids, blk_hdr
+
+
+def root_side_of(structure):
+    return int(structure[0, 8])
 
 
 class MapDevice:

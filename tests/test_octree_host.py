@@ -210,7 +210,19 @@ def test_children_block_layout_describes_the_tree_and_reproduces_the_oracle_hits
     ids, hdr = pack_children_blocks(torch.from_numpy(c), torch.from_numpy(st))
     ids, hdr = ids.numpy(), hdr.numpy()
     interior = (st[:, :8] > -1).any(1)
-    assert ids[0, 0] == 0 and hdr[0, 0] == 1 and (ids[0, 1:] == -1).all()
+    assert ids[0, 0] == 0 and hdr[0, 0] == 1
+    # the pseudo block's other id slots describe the single-child chain under the root (the traversal kernel runs its slab tests in
+    # registers): [1] length, [2] / [3] octants (3 bits each), [4] the block the work-list starts with, [5..7] its lattice position
+    n_chain, octs, end_blk, end_pos = int(ids[0, 1]), int(ids[0, 2]) | (int(ids[0, 3]) << 30), int(ids[0, 4]), ids[0, 5:8].tolist()
+    b, pos, cs = 1, [0, 0, 0], int(st[0, 8]) // 2
+    for lvl in range(n_chain):
+        has = (hdr[b, 1] >> 8) & 255
+        u = (octs >> (3 * lvl)) & 7
+        assert has == 1 << u and cs > 1                                 # exactly one child owns a block: a chain level
+        pos = [pos[0] + (cs if u & 1 else 0), pos[1] + (cs if u & 2 else 0), pos[2] + (cs if u & 4 else 0)]
+        b, cs = int(hdr[b, 0]), cs // 2
+    has_end = (hdr[b, 1] >> 8) & 255
+    assert (b, pos) == (end_blk, end_pos) and (cs == 1 or bin(has_end).count("1") != 1) and n_chain >= 5     # the chain ends where the tree branches
     seen_nodes, stack = 0, [(1, 0)]                                   # (block, the node whose children it lists)
     while stack:
         b, node = stack.pop()
