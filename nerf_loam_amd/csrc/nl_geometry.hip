@@ -408,8 +408,39 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
             rays_d_world[3 * r] = d[0]; rays_d_world[3 * r + 1] = d[1]; rays_d_world[3 * r + 2] = d[2];
             const float gx = points_gt[3 * r], gy = points_gt[3 * r + 1], gz = points_gt[3 * r + 2];
             gt_dist[r] = sqrtf((gx * gx + gy * gy) + gz * gz) * cos_gt[r];
-            int4 e0;
-            if (iq_first_entry(o, inv, blk_hdr, blk_ids, root_side, voxel_size, half_voxel, &e0)) { s_q[rl * IQ_QCAP] = e0; s_tail(rl) = 1; }
+        }
+    }
+    {
+        // first work-list entry (iq_first_entry's tests, spread over the ray's lanes: lane j takes chain levels j, j + LPR, ... - in one
+        // lane the nine levels of a one-scan map are a 13 k-cycle dependent chain of slab arithmetic, a third of the kernel at 2048 rays)
+        const int4 c0 = blk_ids[0], c1 = blk_ids[1];
+        const int2 h0 = blk_hdr[0];
+        const int n_chain = c0.y;
+        const unsigned long long octs = ((unsigned long long)(unsigned)c0.w << 30) | (unsigned long long)(unsigned)c0.z;
+        bool ok = live;
+        if (live) {
+            const float fs = (float)root_side, hs = fs * 0.5f;
+            float tn, tf;
+            ok = slab_inv(o, inv, hs * voxel_size, hs * voxel_size, hs * voxel_size, half_voxel * fs, &tn, &tf) && h0.x >= 0;
+            for (int l = j; l < n_chain && ok; l += IQ_LPR) {
+                int px = 0, py = 0, pz = 0, cs = root_side >> 1;
+                for (int i = 0; i < l; ++i) {                       // lattice position of level l's node: the octants above it
+                    const int u = (int)(octs >> (3 * i)) & 7;
+                    px += (u & 1) ? cs : 0; py += (u & 2) ? cs : 0; pz += (u & 4) ? cs : 0;
+                    cs >>= 1;
+                }
+                const float fcs = (float)cs;
+                ChildSlabs slabs;
+                slabs.init(o, inv, px, py, pz, cs, fcs * 0.5f, voxel_size, half_voxel * fcs);
+                ok = slabs.hit((int)(octs >> (3 * l)) & 7, &tn, &tf);
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < IQ_LPR; off <<= 1) ok = (__shfl_xor((int)ok, off) != 0) && ok;        // every lane of the ray: all levels hit
+        if (live && j == 0 && ok) {
+            const int cs_end = root_side >> (1 + n_chain);
+            s_q[rl * IQ_QCAP] = make_int4(n_chain ? c1.x : h0.x, n_chain ? c1.y : 0, n_chain ? c1.z : 0, (n_chain ? c1.w : 0) | ((31 - __clz(cs_end)) << 20));
+            s_tail(rl) = 1;
         }
     }
     __syncthreads();
@@ -566,44 +597,58 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
     }
     }
     ISTAMP(2, __builtin_readcyclecounter()); ISTAMP(4, rounds); ISTAMP(5, strict ? 1 : 0); ISTAMP(6, n_compact);
-    // finalise: one lane per ray
+    // finalise, all lanes of the ray (one lane sorting a ray's list by insertion was up to 22 k cycles, a quarter of the kernel at 2048 rays):
+    // every lane ranks its entries - (1) DFS order = descending z-major Morton order of the voxel, the first 20 stay (the reference's cap);
+    // (2) among those, stable by t_min (voxel_helpers.py:546: equal t_min keep their DFS order) - and writes them straight to their place in
+    // the ray's row, (3) culled (voxel_helpers.py:549-552).
     int valid = 0;
-    if (live && j == 0) {
-        const int nh = s_nh(rl);
-        if (s_ovf(rl) || nh > IQ_HCAP) {
+    {
+        constexpr int IQ_EPL = (IQ_HCAP + IQ_LPR - 1) / IQ_LPR;
+        const int nh = live ? s_nh(rl) : 0;
+        const bool ovf = live && (s_ovf(rl) != 0 || nh > IQ_HCAP);
+        if (ovf && j == 0) {
             ovf_list[atomicAdd(&counters[NLC_ISECT_OVF], 1)] = r;
             hit_count[r] = 0;                                       // rewritten by the DFS fallback pass
-        } else {
-            const int a0 = rl * IQ_HCAP;
-            // (1) DFS order = descending z-major Morton order of the voxel; keep the first 20 (the reference's cap)
-            for (int i = 1; i < nh; ++i) {
-                const int id = s_hid[a0 + i], x = s_hx[a0 + i], y = s_hy[a0 + i], z = s_hz[a0 + i];
-                const float t0 = s_ht0[a0 + i], t1 = s_ht1[a0 + i];
-                int q = i - 1;
-                while (q >= 0 && dfs_before(x, y, z, s_hx[a0 + q], s_hy[a0 + q], s_hz[a0 + q])) {
-                    s_hid[a0 + q + 1] = s_hid[a0 + q]; s_hx[a0 + q + 1] = s_hx[a0 + q]; s_hy[a0 + q + 1] = s_hy[a0 + q]; s_hz[a0 + q + 1] = s_hz[a0 + q];
-                    s_ht0[a0 + q + 1] = s_ht0[a0 + q]; s_ht1[a0 + q + 1] = s_ht1[a0 + q];
-                    --q;
-                }
-                s_hid[a0 + q + 1] = id; s_hx[a0 + q + 1] = x; s_hy[a0 + q + 1] = y; s_hz[a0 + q + 1] = z; s_ht0[a0 + q + 1] = t0; s_ht1[a0 + q + 1] = t1;
-            }
-            const int cnt = nh < NL_MAX_HITS ? nh : NL_MAX_HITS;
-            // (2) stable sort by t_min (voxel_helpers.py:546), (3) cull, write the ray's row
-            for (int i = 1; i < cnt; ++i) {
-                const int id = s_hid[a0 + i]; const float t0 = s_ht0[a0 + i], t1 = s_ht1[a0 + i];
-                int q = i - 1;
-                while (q >= 0 && s_ht0[a0 + q] > t0) { s_hid[a0 + q + 1] = s_hid[a0 + q]; s_ht0[a0 + q + 1] = s_ht0[a0 + q]; s_ht1[a0 + q + 1] = s_ht1[a0 + q]; --q; }
-                s_hid[a0 + q + 1] = id; s_ht0[a0 + q + 1] = t0; s_ht1[a0 + q + 1] = t1;
-            }
-            int* oi = hit_idx + (size_t)r * NL_MAX_HITS; float* o0 = hit_t0 + (size_t)r * NL_MAX_HITS; float* o1 = hit_t1 + (size_t)r * NL_MAX_HITS;
-            for (int i = 0; i < cnt; ++i) {
-                const float t0 = s_ht0[a0 + i], t1 = s_ht1[a0 + i];
-                const bool keep = !(t1 > 2.0f * max_distance) && !(t0 > max_distance);
-                if (keep) { ++valid; oi[i] = s_hid[a0 + i]; o0[i] = t0; o1[i] = t1; }
-                else { oi[i] = -1; o0[i] = max_distance; o1[i] = max_distance; }
-            }
-            hit_count[r] = valid;
         }
+        const int n = ovf ? 0 : nh;
+        const int a0 = rl * IQ_HCAP;
+        int eid[IQ_EPL], r1[IQ_EPL]; float e0[IQ_EPL], e1[IQ_EPL];
+#pragma unroll
+        for (int t = 0; t < IQ_EPL; ++t) {
+            const int i = j + t * IQ_LPR;
+            r1[t] = IQ_HCAP;
+            if (i < n) {
+                const int x = s_hx[a0 + i], y = s_hy[a0 + i], z = s_hz[a0 + i];
+                eid[t] = s_hid[a0 + i]; e0[t] = s_ht0[a0 + i]; e1[t] = s_ht1[a0 + i];
+                int rk = 0;
+                for (int q = 0; q < n; ++q) rk += dfs_before(s_hx[a0 + q], s_hy[a0 + q], s_hz[a0 + q], x, y, z) ? 1 : 0;
+                r1[t] = rk;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();                           // every lane of the ray is done with the coordinates
+#pragma unroll
+        for (int t = 0; t < IQ_EPL; ++t) { const int i = j + t * IQ_LPR; if (i < n) s_hx[a0 + i] = r1[t]; }      // DFS ranks, for the others' tie-breaks
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int* oi = hit_idx + (size_t)r * NL_MAX_HITS; float* o0 = hit_t0 + (size_t)r * NL_MAX_HITS; float* o1 = hit_t1 + (size_t)r * NL_MAX_HITS;
+#pragma unroll
+        for (int t = 0; t < IQ_EPL; ++t) {
+            if (r1[t] >= NL_MAX_HITS) continue;                     // (also: no entry)
+            int pos = 0;
+            for (int q = 0; q < n; ++q) {
+                const int rq = s_hx[a0 + q];
+                const float tq = s_ht0[a0 + q];
+                pos += (rq < NL_MAX_HITS && (tq < e0[t] || (tq == e0[t] && rq < r1[t]))) ? 1 : 0;
+            }
+            const bool keep = !(e1[t] > 2.0f * max_distance) && !(e0[t] > max_distance);
+            if (keep) { ++valid; oi[pos] = eid[t]; o0[pos] = e0[t]; o1[pos] = e1[t]; }
+            else { oi[pos] = -1; o0[pos] = max_distance; o1[pos] = max_distance; }
+        }
+#pragma unroll
+        for (int off = 1; off < IQ_LPR; off <<= 1) valid += __shfl_xor(valid, off);     // every lane of the ray: the ray's count
+        if (live && !ovf && j == 0) hit_count[r] = valid;
+        if (j != 0) valid = 0;
     }
     ISTAMP(3, __builtin_readcyclecounter());
     int wmax = valid;
