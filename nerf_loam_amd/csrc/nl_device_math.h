@@ -303,17 +303,15 @@ NL_HD void nl_walk_eval(int cs, float noise_cs, float step, int nb, GetC cum, Ge
     }
 }
 
-template <typename GetI, typename GetC, typename GetF0, typename GetF1, typename NoiseF, typename EmitF>
-NL_HD int nl_walk_step(int cs, float step, int nb, GetI idx, GetC cum, GetF0 t0, GetF1 t1, NoiseF noise, EmitF emit) {
+// nl_walk_step after its two evaluations: (bp_e, zp_e) = nl_walk_eval(cs - 1) (not looked at for cs == 0), (b, z) = nl_walk_eval(cs).
+// The GPU sampler hands a step's evaluation to the lane of the next step instead of evaluating every step twice.
+template <typename GetI, typename GetF0, typename GetF1, typename EmitF>
+NL_HD int nl_walk_step_from(int cs, int bp_e, float zp_e, int b, float z, int nb, GetI idx, GetF0 t0, GetF1 t1, EmitF emit) {
     int bp = 0; float zl = t0(0);
     if (cs > 0) {
-        float zp;
-        nl_walk_eval(cs - 1, noise(cs - 1), step, nb, cum, t0, t1, &bp, &zp);
-        if (bp >= nb) return 0;                              // the walk ended at an earlier step
-        zl = zp;
+        if (bp_e >= nb) return 0;                            // the walk ended at an earlier step
+        bp = bp_e; zl = zp_e;
     }
-    int b; float z;
-    nl_walk_eval(cs, noise(cs), step, nb, cum, t0, t1, &b, &z);
     for (int q = bp; q < b; ++q) {                           // closing samples of the intervals this step leaves behind
         const float d1 = t1(q);
         emit(cs + q, idx(q), (d1 + zl) * 0.5f, d1 - zl);
@@ -325,15 +323,26 @@ NL_HD int nl_walk_step(int cs, float step, int nb, GetI idx, GetC cum, GetF0 t0,
 }
 
 template <typename GetI, typename GetC, typename GetF0, typename GetF1, typename NoiseF, typename EmitF>
-NL_HD int nl_walk_tail(int T, float step, int nb, int P, GetI idx, GetC cum, GetF0 t0, GetF1 t1, const NlTailCtx& tc, NoiseF noise, EmitF emit) {
+NL_HD int nl_walk_step(int cs, float step, int nb, GetI idx, GetC cum, GetF0 t0, GetF1 t1, NoiseF noise, EmitF emit) {
+    int bp = 0; float zp = 0.0f;
+    if (cs > 0) nl_walk_eval(cs - 1, noise(cs - 1), step, nb, cum, t0, t1, &bp, &zp);
+    int b; float z;
+    nl_walk_eval(cs, noise(cs), step, nb, cum, t0, t1, &b, &z);
+    return nl_walk_step_from(cs, bp, zp, b, z, nb, idx, t0, t1, emit);
+}
+
+// nl_walk_tail after the evaluation of the last step: (bin_e, z_e) = eval(T - 1) (not looked at for T == 0); eval(cs, &bin, &z)
+// evaluates a step (the search for the step at which a ray ran out of intervals)
+template <typename GetI, typename GetF0, typename GetF1, typename EvalF, typename EmitF>
+NL_HD int nl_walk_tail_from(int T, int bin_e, float z_e, int nb, int P, GetI idx, GetF0 t0, GetF1 t1, const NlTailCtx& tc, EvalF eval, EmitF emit) {
     int bin = 0, s = 0; float zl = t0(0);
     if (T > 0) {
-        nl_walk_eval(T - 1, noise(T - 1), step, nb, cum, t0, t1, &bin, &zl);
+        bin = bin_e; zl = z_e;
         if (bin >= nb) {                                     // ran out of intervals during the steps: own samples = steps before the end
             int lo = 0, hi = T - 1;                          // first step whose bin is nb (bins are monotone in cs)
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1; int bm; float zm;
-                nl_walk_eval(mid, noise(mid), step, nb, cum, t0, t1, &bm, &zm);
+                eval(mid, &bm, &zm);
                 if (bm >= nb) hi = mid; else lo = mid + 1;
             }
             return lo + nb;
@@ -351,6 +360,14 @@ NL_HD int nl_walk_tail(int T, float step, int nb, int P, GetI idx, GetC cum, Get
         zl = t0(bin); curr_max_depth = t1(bin);
     }
     return s;
+}
+
+template <typename GetI, typename GetC, typename GetF0, typename GetF1, typename NoiseF, typename EmitF>
+NL_HD int nl_walk_tail(int T, float step, int nb, int P, GetI idx, GetC cum, GetF0 t0, GetF1 t1, const NlTailCtx& tc, NoiseF noise, EmitF emit) {
+    auto eval = [&](int cs, int* bin, float* z) { nl_walk_eval(cs, noise(cs), step, nb, cum, t0, t1, bin, z); };
+    int bin = 0; float zl = 0.0f;
+    if (T > 0) eval(T - 1, &bin, &zl);
+    return nl_walk_tail_from(T, bin, zl, nb, P, idx, t0, t1, tc, eval, emit);
 }
 
 // host / single-thread driver of the step-parallel form: same results and emit order as nl_sample_walk

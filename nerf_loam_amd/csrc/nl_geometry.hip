@@ -828,115 +828,236 @@ struct SampleArgs {
 // ---------------------------------------------------------------------------------------------
 #define SP_LPR 8
 #define SP_RAYS (NL_GEO_THREADS / SP_LPR)
+static_assert(NL_MAX_HITS == 20 && SP_LPR == 8, "a ray's 20 hit-list entries: three per lane, as five 16-byte LDS reads");
+
+// A ray's walk is a chain of dependent latencies, and the regime this kernel serves (a pose-refinement step: 2048 rays, 64
+// workgroups) has nothing to hide them with, so the chain is kept short:
+//   * every global load whose address does not depend on data is issued at the top (the ray's whole 20-entry row, its hit rank);
+//     the two dependent levels of the closing loop's context (first ray of the batch row -> its hit list) are issued on the way
+//     and land in LDS just before the closing loop, which then reads LDS instead of one global word per iteration;
+//   * interval lengths and their quotients len / tot are computed by the ray's eight lanes (three divisions each instead of
+//     twenty in one lane); the two sequential fp32 chains (tot, the CDF boundaries) run on registers in every lane;
+//   * the bin search of a step compares against the 20 boundaries in registers (first b with !(cdf > cum[b]), +inf beyond the
+//     usable intervals - the same bin as the linear search, which paid one LDS round trip per interval);
+//   * a step needs the evaluation of the step before it: that is the neighbouring lane's result (one shuffle), not a second
+//     evaluation.
+// Same arithmetic in the same order as nl_walk_plan / nl_walk_eval / nl_walk_step / nl_walk_tail (nl_device_math.h), bit for bit.
+struct SpRay {
+    float cumr[NL_MAX_HITS];    // CDF boundary of interval b for b < nb, +inf beyond
+    float tot, step;
+    int nb, T, P;
+    int guard;
+    // context of the closing loop (the reference's tail quirk)
+    int j_in_row, rays_in_row;
+    int rf_val[3], rf_cnt, rf_bias;   // this lane's three entries of the row-first ray's hit list (raw), its length, the list's bias
+};
+
+struct SpLds { int* i; float* t0; float* t1; float* c; float* q; int* rf; };
+
+__device__ __forceinline__ void sp_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();                               // a ray's lanes sit in one wave
+}
+
+// returns whether the ray has hits.  All eight lanes of the ray call it together.
+__device__ __forceinline__ bool sp_setup(const SampleArgs& a, int r, int j, const SpLds& m, SpRay& s)
+{
+    const bool in_range = r < a.N;
+    const int rr = in_range ? r : 0;
+    // level 0: nothing here depends on loaded data
+    const int nh = in_range ? a.hit_count[rr] : 0;
+    const int rank_local = a.hit_rank[rr];
+    int li[3]; float l0[3], l1[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int l = j + SP_LPR * t;
+        const size_t o = (size_t)rr * NL_MAX_HITS + (l < NL_MAX_HITS ? l : 0);
+        li[t] = a.hit_idx[o]; l0[t] = a.hit_t0[o]; l1[t] = a.hit_t1[o];
+    }
+    const int P = a.counters[NLC_HMAX], Rg = a.counters[NLC_R_GLOBAL], Roff = a.counters[NLC_R_OFFSET], Rloc = a.counters[NLC_R];
+    s.P = P;
+    const bool live = nh > 0;
+    float len[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int l = j + SP_LPR * t;
+        const bool v = l < nh;                                     // row tails beyond the ray's own hits are padding
+        const int i_ = v ? li[t] : -1;
+        const float t0_ = v ? l0[t] : a.max_depth, t1_ = v ? l1[t] : a.max_depth;
+        len[t] = (i_ == -1) ? 0.0f : (t1_ - t0_);
+        if (l < NL_MAX_HITS) { m.i[l] = i_; m.t0[l] = t0_; m.t1[l] = t1_; m.q[l] = len[t]; }
+    }
+    // level 1 of the closing loop's context: which ray is the first of this ray's batch row
+    int first_rank = 0;
+    nl_sampler_layout(rank_local + Roff, Rg, &s.j_in_row, &s.rays_in_row, &first_rank);
+    const int first_local = first_rank - Roff;
+    const bool is_local = first_local >= 0 && first_local < Rloc;
+    const bool want_rf = live && !a.tail_always;
+    const int first_ray = (want_rf && is_local) ? a.ray_of_rank[first_local] : rr;
+    sp_wave_sync();
+    // tot: the sequential fp32 sum over the row (entries beyond the ray's hits add +0, as they do in the reference's padded rows)
+    float L[NL_MAX_HITS]; int I[NL_MAX_HITS];
+#pragma unroll
+    for (int g = 0; g < NL_MAX_HITS / 4; ++g) {
+        const float4 v = reinterpret_cast<const float4*>(m.q)[g];
+        const int4 w = reinterpret_cast<const int4*>(m.i)[g];
+        L[4 * g] = v.x; L[4 * g + 1] = v.y; L[4 * g + 2] = v.z; L[4 * g + 3] = v.w;
+        I[4 * g] = w.x; I[4 * g + 1] = w.y; I[4 * g + 2] = w.z; I[4 * g + 3] = w.w;
+    }
+    float tot = 0.0f;
+#pragma unroll
+    for (int l = 0; l < NL_MAX_HITS; ++l) tot = tot + L[l];
+    s.tot = tot;
+    // nb (nl_walk_plan): the leading usable intervals among the first P; an invalid first interval still counts as one
+    int nb = 0; bool run = true;
+#pragma unroll
+    for (int b = 0; b < NL_MAX_HITS; ++b) { run = run && b < P && I[b] != -1; nb += run ? 1 : 0; }
+    if (I[0] == -1 && P > 0) nb = 1;
+    s.nb = nb;
+    // the quotients len / tot, three per lane; the chain c[b] = c[b-1] + q[b] again in every lane
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { const int l = j + SP_LPR * t; if (l < NL_MAX_HITS) m.c[l] = len[t] / tot; }
+    sp_wave_sync();
+    float c = 0.0f;
+    float cb[NL_MAX_HITS];
+#pragma unroll
+    for (int g = 0; g < NL_MAX_HITS / 4; ++g) {
+        const float4 v = reinterpret_cast<const float4*>(m.c)[g];
+        cb[4 * g] = v.x; cb[4 * g + 1] = v.y; cb[4 * g + 2] = v.z; cb[4 * g + 3] = v.w;
+    }
+#pragma unroll
+    for (int b = 0; b < NL_MAX_HITS; ++b) { c = (b == 0) ? cb[0] : (c + cb[b]); cb[b] = c; s.cumr[b] = b < nb ? c : __builtin_inff(); }
+    if (j == 0) {
+#pragma unroll
+        for (int g = 0; g < NL_MAX_HITS / 4; ++g) reinterpret_cast<float4*>(m.c)[g] = make_float4(cb[4 * g], cb[4 * g + 1], cb[4 * g + 2], cb[4 * g + 3]);
+    }
+    s.guard = (live && tot > 10.0f * NL_FILL_DEPTH) ? 1 : 0;
+    const float steps = tot / a.step_size;
+    s.step = (float)(1.0 / (double)steps);
+    s.T = (int)ceilf(steps);
+    // level 2 of the closing loop's context: the row-first ray's hit list (from the exchanged table if that ray lives on another rank)
+    s.rf_cnt = 0; s.rf_bias = 0; s.rf_val[0] = s.rf_val[1] = s.rf_val[2] = -1;
+    if (want_rf) {
+        const int* src = a.hit_idx + (size_t)first_ray * NL_MAX_HITS;
+        if (!is_local && a.row_first) {
+            const int* e = a.row_first + (size_t)nl_row_first_entry(first_rank, Rg) * (1 + NL_MAX_HITS);
+            src = e + 1; s.rf_cnt = e[0]; s.rf_bias = 1;
+        } else {
+            s.rf_cnt = a.hit_count[first_ray];
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { const int l = j + SP_LPR * t; s.rf_val[t] = src[l < NL_MAX_HITS ? l : 0]; }
+    }
+    sp_wave_sync();
+    return live;
+}
+
+// the walk of a ray whose set-up is in `s` / LDS; returns the ray's sample count on lane 0.  emit(sample index, voxel, depth, dist)
+template <typename NoiseF, typename EmitF>
+__device__ __forceinline__ int sp_walk(const SampleArgs& a, int j, const SpLds& m, const SpRay& s, NoiseF noise, EmitF emit)
+{
+    auto get_i = [&](int b) { return m.i[b]; };
+    auto get_0 = [&](int b) { return m.t0[b]; };
+    auto get_1 = [&](int b) { return m.t1[b]; };
+    const int nb = s.nb, T = s.T;
+    auto eval = [&](int cs, int* bin, float* z) {
+        const float cdf = ((float)cs + noise(cs)) * s.step;
+        unsigned gt = 0u;
+#pragma unroll
+        for (int q = 0; q < NL_MAX_HITS; ++q) gt |= (cdf > s.cumr[q]) ? (1u << q) : 0u;
+        const int b = __builtin_ctz(~gt);                          // first interval with !(cdf > cum): at most nb (+inf beyond)
+        *bin = b; *z = 0.0f;
+        if (b < nb) {
+            const float lo = (b > 0) ? m.c[b - 1] : 0.0f, hi = m.c[b];
+            const float u = (cdf - lo) / (hi - lo);
+            const float d0 = m.t0[b], d1 = m.t1[b];
+            *z = d0 + u * (d1 - d0);
+        }
+    };
+    int b_cur = 0; float z_cur = 0.0f;                             // this lane's latest evaluation
+    int b_seg = 0; float z_seg = 0.0f;                             // lane 7's evaluation of the previous round (lane 0's predecessor)
+    for (int base = 0; base < T; base += SP_LPR) {
+        const int cs = base + j;
+        if (cs < T) eval(cs, &b_cur, &z_cur);
+        int bp = __shfl_up(b_cur, 1, SP_LPR); float zp = __shfl_up(z_cur, 1, SP_LPR);
+        if (j == 0) { bp = b_seg; zp = z_seg; }
+        b_seg = __shfl(b_cur, SP_LPR - 1, SP_LPR); z_seg = __shfl(z_cur, SP_LPR - 1, SP_LPR);
+        if (cs < T) nl_walk_step_from(cs, bp, zp, b_cur, z_cur, nb, get_i, get_0, get_1, emit);
+    }
+    // the closing loop (lane 0), after the last step's evaluation; the row-first list goes to LDS first
+    const int last = (T - 1) & (SP_LPR - 1);
+    const int bin_e = __shfl(b_cur, last, SP_LPR); const float z_e = __shfl(z_cur, last, SP_LPR);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { const int l = j + SP_LPR * t; if (l < NL_MAX_HITS) m.rf[l] = l < s.rf_cnt ? s.rf_val[t] - s.rf_bias : -1; }
+    sp_wave_sync();
+    int n = 0;
+    if (j == 0) {
+        NlTailCtx tc;
+        tc.j_in_row = s.j_in_row; tc.rays_in_row = s.rays_in_row;
+        tc.row_first_idx = m.rf; tc.row_first_count = NL_MAX_HITS; tc.row_first_bias = 0;
+        tc.tail_always = a.tail_always != 0;
+        n = nl_walk_tail_from(T, bin_e, z_e, nb, s.P, get_i, get_0, get_1, tc, eval, emit);
+    }
+    return n;
+}
+
 template <bool EMIT>
 __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample_par(SampleArgs a)
 {
     __shared__ int s_red[8];
     __shared__ double s_dred[2];
-    __shared__ int s_i[SP_RAYS * NL_MAX_HITS];
-    __shared__ float s_0[SP_RAYS * NL_MAX_HITS], s_1[SP_RAYS * NL_MAX_HITS], s_c[SP_RAYS * NL_MAX_HITS];
-    __shared__ float s_tot[SP_RAYS];
-    __shared__ int s_nb[SP_RAYS];
+    __shared__ __attribute__((aligned(16))) int s_i[SP_RAYS * NL_MAX_HITS], s_rf[SP_RAYS * NL_MAX_HITS];
+    __shared__ __attribute__((aligned(16))) float s_0[SP_RAYS * NL_MAX_HITS], s_1[SP_RAYS * NL_MAX_HITS], s_c[SP_RAYS * NL_MAX_HITS], s_q[SP_RAYS * NL_MAX_HITS];
     if (threadIdx.x < 8) s_red[threadIdx.x] = 0;
     if (threadIdx.x < 2) s_dred[threadIdx.x] = 0.0;
     __syncthreads();
     const int rl = threadIdx.x / SP_LPR, j = threadIdx.x % SP_LPR;
+    const SpLds m = {s_i + rl * NL_MAX_HITS, s_0 + rl * NL_MAX_HITS, s_1 + rl * NL_MAX_HITS, s_c + rl * NL_MAX_HITS, s_q + rl * NL_MAX_HITS,
+                     s_rf + rl * NL_MAX_HITS};
     // persistent over batches of SP_RAYS rays: the per-block reduction and its ~10 global atomics happen once per workgroup
     // (one workgroup per 32 rays would mean 4096 x 10 atomics on the same counters for a full scan)
     int vmax = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0;
     double d1 = 0.0, d2 = 0.0;
+    const unsigned seed = a.seed_mix ? a.seed + 0x9E3779B9u * (*a.seed_mix) : a.seed;
+    const bool hash = a.use_hash_noise != 0;
     for (int batch = blockIdx.x; batch * SP_RAYS < a.N; batch += gridDim.x) {
-    const int r = batch * SP_RAYS + rl;
-    int cnt = 0, nfs = 0, nsdf = 0, inv_fs = 0, inv_sdf = 0, guard = 0;
-    double inv_d2 = 0.0;
-    const bool live = r < a.N && a.hit_count[r] > 0;
-    int* my_i = s_i + rl * NL_MAX_HITS; float* my_0 = s_0 + rl * NL_MAX_HITS; float* my_1 = s_1 + rl * NL_MAX_HITS; float* my_c = s_c + rl * NL_MAX_HITS;
-    const int P = a.counters[NLC_HMAX];
-    if (live) {
-        const int nh = a.hit_count[r];
-        for (int l = j; l < NL_MAX_HITS; l += SP_LPR) {          // row tails beyond the ray's own hits are padding
-            const bool v = l < nh;
-            my_i[l] = v ? a.hit_idx[(size_t)r * NL_MAX_HITS + l] : -1;
-            my_0[l] = v ? a.hit_t0[(size_t)r * NL_MAX_HITS + l] : a.max_depth;
-            my_1[l] = v ? a.hit_t1[(size_t)r * NL_MAX_HITS + l] : a.max_depth;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();                               // a ray's lanes sit in one wave
-    auto get_i = [&](int b) { return my_i[b]; };
-    auto get_0 = [&](int b) { return my_0[b]; };
-    auto get_1 = [&](int b) { return my_1[b]; };
-    auto get_c = [&](int b) { return my_c[b]; };
-    if (live && j == 0) {
-        float tot = 0.0f;
-        for (int l = 0; l < P; ++l) { const int i_ = my_i[l]; tot = tot + ((i_ == -1) ? 0.0f : (my_1[l] - my_0[l])); }
-        s_tot[rl] = tot;
-        s_nb[rl] = nl_walk_plan(get_i, get_0, get_1, P, tot, [&](int b, float c) { my_c[b] = c; });
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (live) {
-        const float tot = s_tot[rl];
-        const int nb = s_nb[rl];
-        if (tot > 10.0f * NL_FILL_DEPTH) guard = 1;
-        const float c = a.cos_gt[r], d = a.gt_dist[r];
-        const unsigned rid = (unsigned)(r + a.ray_id_base);
-        const unsigned seed = a.seed_mix ? a.seed + 0x9E3779B9u * (*a.seed_mix) : a.seed;
-        const bool hash = a.use_hash_noise != 0;
-        auto noise = [&](int step) -> float { return hash ? nl_noise(seed, rid, (unsigned)step) : 0.5f; };
-        const int off = EMIT ? a.samp_off[r] : 0;
-        const int cap = a.capacity;
-        auto emit = [&](int s, int vox, float depth, float dist) {
-            if (EMIT) {
-                const int p = off + s;
-                if (p < cap) { a.s_vox[p] = vox; a.s_depth[p] = depth; a.s_dist[p] = dist < 0.0f ? 0.0f : dist; a.s_ray[p] = r; }
-            } else {
-                bool f, m;
-                nl_loss_masks(depth * c, d, a.tau, a.max_depth, &f, &m);
-                nfs += f ? 1 : 0; nsdf += m ? 1 : 0;
-            }
-        };
-        if (!guard) {
-            const float steps = tot / a.step_size;
-            const float step = (float)(1.0 / (double)steps);
-            const int T = (int)ceilf(steps);
-            for (int cs = j; cs < T; cs += SP_LPR) nl_walk_step(cs, step, nb, get_i, get_c, get_0, get_1, noise, emit);
-            if (j == 0) {
-                NlTailCtx tc;
-                const int Rg = a.counters[NLC_R_GLOBAL];
-                const int rank = a.hit_rank[r] + a.counters[NLC_R_OFFSET];
-                int first_rank;
-                nl_sampler_layout(rank, Rg, &tc.j_in_row, &tc.rays_in_row, &first_rank);
-                // single-GPU: the row's first ray is local.  multi-GPU: it may live on another rank - the ranks exchange the 200 x
-                // ceil(L / 800) row-first hit lists (nl_dist_row_first + one all-reduce, dist.py), stored as idx + 1
-                const int first_local = first_rank - a.counters[NLC_R_OFFSET];
-                const bool is_local = first_local >= 0 && first_local < a.counters[NLC_R];
-                const int first_ray = is_local ? a.ray_of_rank[first_local] : r;
-                tc.row_first_idx = a.hit_idx + (size_t)first_ray * NL_MAX_HITS;
-                tc.row_first_count = a.hit_count[first_ray];
-                tc.row_first_bias = 0;
-                if (!is_local && a.row_first) {
-                    const int* e = a.row_first + (size_t)nl_row_first_entry(first_rank, Rg) * (1 + NL_MAX_HITS);
-                    tc.row_first_idx = e + 1; tc.row_first_count = e[0]; tc.row_first_bias = 1;
+        const int r = batch * SP_RAYS + rl;
+        int cnt = 0, nfs = 0, nsdf = 0, inv_fs = 0, inv_sdf = 0, guard = 0;
+        double inv_d2 = 0.0;
+        const float c = r < a.N ? a.cos_gt[r] : 0.0f, d = r < a.N ? a.gt_dist[r] : 0.0f;
+        const int off = (EMIT && r < a.N) ? a.samp_off[r] : 0;
+        SpRay s;
+        const bool live = sp_setup(a, r, j, m, s);
+        if (live) {
+            guard = s.guard;
+            const unsigned rid = (unsigned)(r + a.ray_id_base);
+            auto noise = [&](int step) -> float { return hash ? nl_noise(seed, rid, (unsigned)step) : 0.5f; };
+            const int cap = a.capacity;
+            auto emit = [&](int s_, int vox, float depth, float dist) {
+                if (EMIT) {
+                    const int p = off + s_;
+                    if (p < cap) { a.s_vox[p] = vox; a.s_depth[p] = depth; a.s_dist[p] = dist < 0.0f ? 0.0f : dist; a.s_ray[p] = r; }
+                } else {
+                    bool f, mk;
+                    nl_loss_masks(depth * c, d, a.tau, a.max_depth, &f, &mk);
+                    nfs += f ? 1 : 0; nsdf += mk ? 1 : 0;
                 }
-                tc.tail_always = a.tail_always != 0;
-                cnt = nl_walk_tail(T, step, nb, P, get_i, get_c, get_0, get_1, tc, noise, emit);
+            };
+            if (!guard) cnt = sp_walk(a, j, m, s, noise, emit);
+            if (!EMIT && j == 0) {
+                bool f, mk;
+                nl_loss_masks(NL_FILL_DEPTH * c, d, a.tau, a.max_depth, &f, &mk);
+                if (!guard) { inv_fs = f ? 1 : 0; inv_sdf = mk ? 1 : 0; inv_d2 = mk ? (double)d * (double)d : 0.0; }
             }
         }
-        if (!EMIT && j == 0) {
-            bool f, m;
-            nl_loss_masks(NL_FILL_DEPTH * c, d, a.tau, a.max_depth, &f, &m);
-            if (!guard) { inv_fs = f ? 1 : 0; inv_sdf = m ? 1 : 0; inv_d2 = m ? (double)d * (double)d : 0.0; }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();                               // the ray's LDS rows are reused by the next batch
-    if (EMIT) continue;
-    if (r < a.N && j == 0) a.samp_count[r] = cnt;
-    // per-lane running sums (a ray's mask counts are spread over its lanes; cnt and the per-ray constants sit in lane 0)
-    vmax = max(vmax, cnt);
-    v1 += nfs; v2 += nsdf; v3 += inv_fs; v4 += inv_fs * cnt; v5 += inv_sdf; v6 += inv_sdf * cnt; v7 += guard;
-    d1 += inv_d2; d2 += inv_d2 * (double)cnt;
+        sp_wave_sync();                                                // the ray's LDS rows are reused by the next batch
+        if (EMIT) continue;
+        if (r < a.N && j == 0) a.samp_count[r] = cnt;
+        // per-lane running sums (a ray's mask counts are spread over its lanes; cnt and the per-ray constants sit in lane 0)
+        vmax = max(vmax, cnt);
+        v1 += nfs; v2 += nsdf; v3 += inv_fs; v4 += inv_fs * cnt; v5 += inv_sdf; v6 += inv_sdf * cnt; v7 += guard;
+        d1 += inv_d2; d2 += inv_d2 * (double)cnt;
     }
     if (EMIT) return;
 #pragma unroll
@@ -991,101 +1112,48 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample_fused(SampleFusedArgs
     const SampleArgs& a = fa.s;
     __shared__ int s_red[8];
     __shared__ double s_dred[2];
-    __shared__ int s_i[SP_RAYS * NL_MAX_HITS];
-    __shared__ float s_0[SP_RAYS * NL_MAX_HITS], s_1[SP_RAYS * NL_MAX_HITS], s_c[SP_RAYS * NL_MAX_HITS];
-    __shared__ float s_tot[SP_RAYS];
-    __shared__ int s_nb[SP_RAYS], s_cnt[SP_RAYS], s_excl[SP_RAYS];
+    __shared__ __attribute__((aligned(16))) int s_i[SP_RAYS * NL_MAX_HITS], s_rf[SP_RAYS * NL_MAX_HITS];
+    __shared__ __attribute__((aligned(16))) float s_0[SP_RAYS * NL_MAX_HITS], s_1[SP_RAYS * NL_MAX_HITS], s_c[SP_RAYS * NL_MAX_HITS], s_q[SP_RAYS * NL_MAX_HITS];
+    __shared__ int s_cnt[SP_RAYS], s_excl[SP_RAYS];
     __shared__ int b_vox[SP_RAYS * SF_CAP];
     __shared__ float b_depth[SP_RAYS * SF_CAP], b_dist[SP_RAYS * SF_CAP];
-    __shared__ int s_base, s_ovf, s_last;
+    __shared__ int s_base, s_ovf;
     // the launch's epoch lives in device memory and is advanced by the last workgroup to finish (after every workgroup has read
     // it): nothing to pass or clear from the host, and a captured launch can be replayed
     const unsigned epoch = ((unsigned)*reinterpret_cast<volatile unsigned long long*>(fa.wg_state) + 1u) & 0x3FFFFFFFu;
     unsigned long long* const wg_words = fa.wg_state + 1;
     if (threadIdx.x < 8) s_red[threadIdx.x] = 0;
     if (threadIdx.x < 2) s_dred[threadIdx.x] = 0.0;
-    if (threadIdx.x == 0) { s_ovf = 0; s_last = 0; }
+    if (threadIdx.x == 0) s_ovf = 0;
     __syncthreads();
     const int rl = threadIdx.x / SP_LPR, j = threadIdx.x % SP_LPR;
     const int r = blockIdx.x * SP_RAYS + rl;
     int cnt = 0, nfs = 0, nsdf = 0, inv_fs = 0, inv_sdf = 0, guard = 0;
     double inv_d2 = 0.0;
-    const bool live = r < a.N && a.hit_count[r] > 0;
-    int* my_i = s_i + rl * NL_MAX_HITS; float* my_0 = s_0 + rl * NL_MAX_HITS; float* my_1 = s_1 + rl * NL_MAX_HITS; float* my_c = s_c + rl * NL_MAX_HITS;
-    const int P = a.counters[NLC_HMAX];
-    if (live) {
-        const int nh = a.hit_count[r];
-        for (int l = j; l < NL_MAX_HITS; l += SP_LPR) {          // row tails beyond the ray's own hits are padding
-            const bool v = l < nh;
-            my_i[l] = v ? a.hit_idx[(size_t)r * NL_MAX_HITS + l] : -1;
-            my_0[l] = v ? a.hit_t0[(size_t)r * NL_MAX_HITS + l] : a.max_depth;
-            my_1[l] = v ? a.hit_t1[(size_t)r * NL_MAX_HITS + l] : a.max_depth;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();                               // a ray's lanes sit in one wave
-    auto get_i = [&](int b) { return my_i[b]; };
-    auto get_0 = [&](int b) { return my_0[b]; };
-    auto get_1 = [&](int b) { return my_1[b]; };
-    auto get_c = [&](int b) { return my_c[b]; };
-    if (live && j == 0) {
-        float tot = 0.0f;
-        for (int l = 0; l < P; ++l) { const int i_ = my_i[l]; tot = tot + ((i_ == -1) ? 0.0f : (my_1[l] - my_0[l])); }
-        s_tot[rl] = tot;
-        s_nb[rl] = nl_walk_plan(get_i, get_0, get_1, P, tot, [&](int b, float c) { my_c[b] = c; });
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const float tot = live ? s_tot[rl] : 0.0f;
-    const int nb = live ? s_nb[rl] : 0;
-    if (live && tot > 10.0f * NL_FILL_DEPTH) guard = 1;
-    const float c = live ? a.cos_gt[r] : 0.0f, d = live ? a.gt_dist[r] : 0.0f;
-    const unsigned rid = (unsigned)(r + a.ray_id_base);
+    const SpLds m = {s_i + rl * NL_MAX_HITS, s_0 + rl * NL_MAX_HITS, s_1 + rl * NL_MAX_HITS, s_c + rl * NL_MAX_HITS, s_q + rl * NL_MAX_HITS,
+                     s_rf + rl * NL_MAX_HITS};
+    const float c = r < a.N ? a.cos_gt[r] : 0.0f, d = r < a.N ? a.gt_dist[r] : 0.0f;
     const unsigned seed = a.seed_mix ? a.seed + 0x9E3779B9u * (*a.seed_mix) : a.seed;
+    SpRay sr;
+    const bool live = sp_setup(a, r, j, m, sr);
+    guard = live ? sr.guard : 0;
+    const unsigned rid = (unsigned)(r + a.ray_id_base);
     const bool hash = a.use_hash_noise != 0;
     auto noise = [&](int step) -> float { return hash ? nl_noise(seed, rid, (unsigned)step) : 0.5f; };
-    // one walk of this lane's share of the ray's steps (+ the closing loop on lane 0); returns the sample count on lane 0
-    auto walk = [&](auto emit) -> int {
-        int n = 0;
-        const float steps = tot / a.step_size;
-        const float step = (float)(1.0 / (double)steps);
-        const int T = (int)ceilf(steps);
-        for (int cs = j; cs < T; cs += SP_LPR) nl_walk_step(cs, step, nb, get_i, get_c, get_0, get_1, noise, emit);
-        if (j == 0) {
-            NlTailCtx tc;
-            const int Rg = a.counters[NLC_R_GLOBAL];
-            const int rank = a.hit_rank[r] + a.counters[NLC_R_OFFSET];
-            int first_rank;
-            nl_sampler_layout(rank, Rg, &tc.j_in_row, &tc.rays_in_row, &first_rank);
-            const int first_local = first_rank - a.counters[NLC_R_OFFSET];
-            const bool is_local = first_local >= 0 && first_local < a.counters[NLC_R];
-            const int first_ray = is_local ? a.ray_of_rank[first_local] : r;
-            tc.row_first_idx = a.hit_idx + (size_t)first_ray * NL_MAX_HITS;
-            tc.row_first_count = a.hit_count[first_ray];
-            tc.row_first_bias = 0;
-            if (!is_local && a.row_first) {
-                const int* e = a.row_first + (size_t)nl_row_first_entry(first_rank, Rg) * (1 + NL_MAX_HITS);
-                tc.row_first_idx = e + 1; tc.row_first_count = e[0]; tc.row_first_bias = 1;
-            }
-            tc.tail_always = a.tail_always != 0;
-            n = nl_walk_tail(T, step, nb, P, get_i, get_c, get_0, get_1, tc, noise, emit);
-        }
-        return n;
-    };
     if (live && !guard) {
         auto emit = [&](int s_, int vox, float depth, float dist) {
-            bool f, m;
-            nl_loss_masks(depth * c, d, a.tau, a.max_depth, &f, &m);
-            nfs += f ? 1 : 0; nsdf += m ? 1 : 0;
+            bool f, mk;
+            nl_loss_masks(depth * c, d, a.tau, a.max_depth, &f, &mk);
+            nfs += f ? 1 : 0; nsdf += mk ? 1 : 0;
             if (s_ < SF_CAP) { const int q = rl * SF_CAP + s_; b_vox[q] = vox; b_depth[q] = depth; b_dist[q] = dist < 0.0f ? 0.0f : dist; }
             else s_ovf = 1;
         };
-        cnt = walk(emit);
+        cnt = sp_walk(a, j, m, sr, noise, emit);
     }
     if (live && j == 0) {
-        bool f, m;
-        nl_loss_masks(NL_FILL_DEPTH * c, d, a.tau, a.max_depth, &f, &m);
-        if (!guard) { inv_fs = f ? 1 : 0; inv_sdf = m ? 1 : 0; inv_d2 = m ? (double)d * (double)d : 0.0; }
+        bool f, mk;
+        nl_loss_masks(NL_FILL_DEPTH * c, d, a.tau, a.max_depth, &f, &mk);
+        if (!guard) { inv_fs = f ? 1 : 0; inv_sdf = mk ? 1 : 0; inv_d2 = mk ? (double)d * (double)d : 0.0; }
     }
     if (j == 0) s_cnt[rl] = cnt;
     // the loss normalisers' sums (as in the count pass)
@@ -1107,6 +1175,20 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample_fused(SampleFusedArgs
         }
     }
     __syncthreads();
+    // the workgroup's sums go out first, from a wave that is not in the look-back (nothing waits for them here: their round trips run
+    // under the look-back; the same thread draws the ticket at the end, behind its own fence)
+    if (threadIdx.x == 64) {
+        if (s_red[0] > 0) atomicMax(&a.counters[NLC_SMAX], s_red[0]);
+        if (s_red[1]) atomicAdd(&a.counters[NLC_NFS], s_red[1]);
+        if (s_red[2]) atomicAdd(&a.counters[NLC_NSDF], s_red[2]);
+        if (s_red[3]) atomicAdd(&a.counters[NLC_INV_FS_RAYS], s_red[3]);
+        if (s_red[4]) atomicAdd(&a.counters[NLC_INV_FS_CNT], s_red[4]);
+        if (s_red[5]) atomicAdd(&a.counters[NLC_INV_SDF_RAYS], s_red[5]);
+        if (s_red[6]) atomicAdd(&a.counters[NLC_INV_SDF_CNT], s_red[6]);
+        if (s_red[7]) atomicMax(&a.counters[NLC_GUARD], 1);
+        if (s_dred[0] != 0.0) atomicAdd(&a.dcounters[NLD_INV_D2], s_dred[0]);
+        if (s_dred[1] != 0.0) atomicAdd(&a.dcounters[NLD_INV_D2CNT], s_dred[1]);
+    }
     // this workgroup's sample offset: exclusive prefix over the rays inside it + look-back over the workgroups before it
     if (threadIdx.x < 64) {
         const int t = threadIdx.x;
@@ -1141,18 +1223,6 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample_fused(SampleFusedArgs
             __hip_atomic_store(&wg_words[b], tag | (SF_STATUS_PREFIX << 32) | (unsigned)(base + agg), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             s_base = base;
             if (b == (int)gridDim.x - 1) a.counters[NLC_P] = base + agg;
-            if (s_red[0] > 0) atomicMax(&a.counters[NLC_SMAX], s_red[0]);
-            if (s_red[1]) atomicAdd(&a.counters[NLC_NFS], s_red[1]);
-            if (s_red[2]) atomicAdd(&a.counters[NLC_NSDF], s_red[2]);
-            if (s_red[3]) atomicAdd(&a.counters[NLC_INV_FS_RAYS], s_red[3]);
-            if (s_red[4]) atomicAdd(&a.counters[NLC_INV_FS_CNT], s_red[4]);
-            if (s_red[5]) atomicAdd(&a.counters[NLC_INV_SDF_RAYS], s_red[5]);
-            if (s_red[6]) atomicAdd(&a.counters[NLC_INV_SDF_CNT], s_red[6]);
-            if (s_red[7]) atomicMax(&a.counters[NLC_GUARD], 1);
-            if (s_dred[0] != 0.0) atomicAdd(&a.dcounters[NLD_INV_D2], s_dred[0]);
-            if (s_dred[1] != 0.0) atomicAdd(&a.dcounters[NLD_INV_D2CNT], s_dred[1]);
-            __threadfence();
-            if (atomicAdd(&a.counters[NLC_TICKET], 1) == (int)gridDim.x - 1) s_last = 1;
         }
     }
     __syncthreads();
@@ -1170,12 +1240,18 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_sample_fused(SampleFusedArgs
             const int p = off + s_;
             if (p < cap) { a.s_vox[p] = vox; a.s_depth[p] = depth; a.s_dist[p] = dist < 0.0f ? 0.0f : dist; a.s_ray[p] = r; }
         };
-        (void)walk(emit);
+        (void)sp_walk(a, j, m, sr, noise, emit);
     }
-    if (s_last && threadIdx.x == 0) {                              // every workgroup's sums and the total are in: the loss normalisers
+    // the ticket comes last, off the path of the workgroup's own samples: whoever draws the last one finds every workgroup's sums and
+    // the total (stored before the barrier above, which drains the storing wave's memory operations) in place and computes the
+    // loss normalisers
+    if (threadIdx.x == 64) {
         __threadfence();
-        *reinterpret_cast<volatile unsigned long long*>(fa.wg_state) = (unsigned long long)epoch;   // the next launch's epoch differs
-        loss_finalize_one(a.counters, fa.ls, fa.fs_weight, fa.sdf_weight, a.tau, a.max_depth, a.capacity);
+        if (atomicAdd(&a.counters[NLC_TICKET], 1) == (int)gridDim.x - 1) {
+            __threadfence();
+            *reinterpret_cast<volatile unsigned long long*>(fa.wg_state) = (unsigned long long)epoch;   // the next launch's epoch differs
+            loss_finalize_one(a.counters, fa.ls, fa.fs_weight, fa.sdf_weight, a.tau, a.max_depth, a.capacity);
+        }
     }
 }
 
@@ -1568,9 +1644,10 @@ int nl_sample_rays(int emit, int N, const int* hit_idx, const float* hit_t0, con
     a.counters = counters; a.dcounters = (double*)(counters + NL_CNT_INTS);
     a.samp_count = samp_count; a.samp_off = samp_off; a.capacity = capacity;
     a.s_vox = s_vox; a.s_depth = s_depth; a.s_dist = s_dist; a.s_ray = s_ray;
-    // step-parallel (SP_LPR lanes per ray) in the latency-bound regime; at full-scan sizes its extra threads and redundant step
-    // evaluations cost throughput (count pass 96 us against 30 us at 131 072 rays) and the sequential kernel is used
-    if (g_sampler_mode == 1 || (g_sampler_mode == 2 && N <= 8192)) {   // (16 384 rays: count pass 16 -> 21 us, no gain)
+    // step-parallel (SP_LPR lanes per ray): the emit pass at every size (131 072 rays: 22.7 us against 29.3 us sequential, 16 384: 12.1
+    // against 15.3), the count pass in the latency-bound regime only - beyond 8192 rays its 1024 workgroups x 10 same-line atomics and
+    // the extra threads cost more than the shorter chains save (16 384 rays: 19.5 against 15.5 us, 131 072: 77 against 24)
+    if (g_sampler_mode == 1 || (g_sampler_mode == 2 && (emit || N <= 8192))) {
         const int nbk = nl_div_up(N, SP_RAYS) < 1024 ? nl_div_up(N, SP_RAYS) : 1024;
         if (emit) hipLaunchKernelGGL(k_sample_par<true>, dim3(nbk), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);
         else      hipLaunchKernelGGL(k_sample_par<false>, dim3(nbk), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);
