@@ -143,6 +143,18 @@ int nl_dist_row_first(const int* counters, const int* hit_idx, const int* hit_co
 /* global loss normalisers from the counter block (criterion.py:84-88 weights, :65 mean divisor R*S) */
 int nl_loss_finalize(int* counters, void* loss_scalars, float fs_weight, float sdf_weight, float tau, float max_depth,
                      int capacity, void* stream);
+/* Criterion.forward on caller tensors (replaces /root/reference/src/criterion.py:16-115 for a caller holding its own render_rays
+ * `outputs`: l2, no eikonal term).  sdf, z_vals [R,S] fp32 and valid_mask [R,S] bytes are the padded sample block; points [N,3] and
+ * cos [N] the frame's observations, ray_idx [R] the rows of the rays that hit (outputs["ray_mask"].nonzero(), or NULL when R == N).
+ * workspace: >= 32 bytes, cleared here.  out[8] = loss, fs_loss, sdf_loss, the two data-dependent weights (:84-88), 2 / (R S), the
+ * front and sdf-mask counts - all on the device, nothing is read back.  backward: dsdf [R,S] = grad_loss (device scalar, NULL = 1) *
+ * dloss / dsdf with the weights treated as constants (count_nonzero has no gradient), `out` from the forward call. */
+int nl_criterion_forward(int R, int S, const float* sdf, const float* z_vals, const unsigned char* valid_mask, const float* points,
+                         const float* cos, const int* ray_idx, float truncation, float max_depth, float fs_weight, float sdf_weight,
+                         void* workspace, float* out, void* stream);
+int nl_criterion_backward(int R, int S, const float* sdf, const float* z_vals, const unsigned char* valid_mask, const float* points,
+                          const float* cos, const int* ray_idx, float truncation, float max_depth, float fs_weight, float sdf_weight,
+                          const float* out, const float* grad_loss, float* dsdf, void* stream);
 /* nl_sample_rays(count) + nl_exclusive_scan_i32 + nl_loss_finalize + nl_sample_rays(emit) as ONE launch up to 8192 rays (single
  * GPU: no row_first table): every workgroup walks its rays once, parks the samples in LDS, obtains its offset by decoupled
  * look-back over the workgroups before it (state: >= 8 * (1 + ceil(N / 32)) bytes only this function touches, zero-initialised

@@ -103,6 +103,8 @@ _SIGS = {
     "nl_sample_rays": ([_I, _I] + [_P] * 8 + [_F, _F, _F, _U, _I, _I, _I] + [_P, _P, _P, _P, _P, _I] + [_P] * 5, _I),
     "nl_dist_row_first": ([_P, _P, _P, _P, _P, _I, _P], _I),
     "nl_loss_finalize": ([_P, _P, _F, _F, _F, _F, _I, _P], _I),
+    "nl_criterion_forward": ([_I, _I] + [_P] * 6 + [_F] * 4 + [_P] * 3, _I),
+    "nl_criterion_backward": ([_I, _I] + [_P] * 6 + [_F] * 4 + [_P] * 4, _I),
     "nl_scan_samples_finalize": ([_P, _P, _I, _P, _P, _F, _F, _F, _F, _I, _P, _P], _I),
     "nl_sample_rays_fused": ([_I] + [_P] * 8 + [_F, _F, _F, _U, _I, _I, _I] + [_P] * 4 + [_I] + [_P] * 5 + [_F, _F, _P, _P, _P], _I),
     "nl_ray_intersect_scan": ([_I] + [_P] * 7 + [_I, _F, _F] + [_P] * 13, _I),

@@ -75,6 +75,27 @@ def loss_finalize(counters, loss_scalars, fs_weight, sdf_weight, tau, max_depth,
                                    int(capacity), stream_ptr()), "nl_loss_finalize")
 
 
+def criterion_forward(sdf, z_vals, valid_u8, points, cos, ray_idx, truncation, max_depth, fs_weight, sdf_weight, workspace, out):
+    """Criterion.forward on caller tensors (include/nerfloam_hip.h nl_criterion_forward): out[8] on the device."""
+    for t, d, n in ((sdf, F32, "sdf"), (z_vals, F32, "z_vals"), (valid_u8, torch.uint8, "valid_mask"), (points, F32, "points"), (cos, F32, "cos"),
+                    (ray_idx, I32, "ray_idx"), (out, F32, "out")):
+        _chk(t, d, n)
+    R, S = sdf.shape
+    check(L.lib().nl_criterion_forward(int(R), int(S), ptr(sdf), ptr(z_vals), ptr(valid_u8), ptr(points), ptr(cos), ptr(ray_idx), float(truncation),
+                                       float(max_depth), float(fs_weight), float(sdf_weight), ptr(workspace), ptr(out), stream_ptr()),
+          "nl_criterion_forward")
+
+
+def criterion_backward(sdf, z_vals, valid_u8, points, cos, ray_idx, truncation, max_depth, fs_weight, sdf_weight, out, grad_loss, dsdf):
+    for t, d, n in ((sdf, F32, "sdf"), (z_vals, F32, "z_vals"), (valid_u8, torch.uint8, "valid_mask"), (points, F32, "points"), (cos, F32, "cos"),
+                    (ray_idx, I32, "ray_idx"), (out, F32, "out"), (grad_loss, F32, "grad_loss"), (dsdf, F32, "dsdf")):
+        _chk(t, d, n)
+    R, S = sdf.shape
+    check(L.lib().nl_criterion_backward(int(R), int(S), ptr(sdf), ptr(z_vals), ptr(valid_u8), ptr(points), ptr(cos), ptr(ray_idx), float(truncation),
+                                        float(max_depth), float(fs_weight), float(sdf_weight), ptr(out), ptr(grad_loss), ptr(dsdf), stream_ptr()),
+          "nl_criterion_backward")
+
+
 def gather_trilinear(loss_scalars, s_vox, s_depth, s_ray, rays_d_world, frame_id, poses12, n_frames, centres, vertex_rows, emb,
                      voxel_size, X, nblocks):
     check(L.lib().nl_gather_trilinear(ptr(loss_scalars), ptr(s_vox), ptr(s_depth), ptr(s_ray), ptr(rays_d_world), ptr(frame_id),
