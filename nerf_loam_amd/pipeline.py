@@ -218,7 +218,9 @@ class SdfEngine:
         self.cos_gt = torch.zeros(N, dtype=F32, device=d)
         self.frame_id = torch.zeros(N, dtype=I32, device=d)
         # poses
-        self.pose6 = torch.zeros(self.F_cap, 6, dtype=F32, device=d)
+        # pose6 [F_cap,6] and the per-frame optimise flags in ONE buffer: set_poses is one host-to-device copy
+        self._pose_io = torch.zeros(self.F_cap * 7, dtype=I32, device=d)
+        self.pose6 = self._pose_io[:self.F_cap * 6].view(F32).view(self.F_cap, 6)
         self.poses12 = torch.zeros(self.F_cap, 12, dtype=F32, device=d)
         # the small per-call optimiser state lives in ONE buffer, cleared by one memset per call (begin_call):
         # [g_pose f64 F x 12 | adam_state 28 i32 | pose_m F x 6 | pose_v F x 6 | pose_grad6 F x 6]
@@ -229,7 +231,7 @@ class SdfEngine:
         o += L.NL_ADAM_STATE_BYTES // 4
         self.pose_m = self._call_state[o:o + Fc * 6].view(F32).view(Fc, 6)
         self.pose_v = self._call_state[o + Fc * 6:o + 2 * Fc * 6].view(F32).view(Fc, 6)
-        self.pose_enable = torch.zeros(self.F_cap, dtype=I32, device=d)
+        self.pose_enable = self._pose_io[self.F_cap * 6:]
         self.g_pose = self._call_state[:Fc * 24].view(torch.float64).view(Fc, 12)     # fp64 accumulators (nl_trilinear_bwd)
         self.pose_grad6 = self._call_state[o + 2 * Fc * 6:o + 3 * Fc * 6].view(F32).view(Fc, 6)
         # per-ray workspace
@@ -403,20 +405,39 @@ class SdfEngine:
                        ws=torch.zeros(-(-iters * F // L.NL_SEL_MAX_FRAMES) * L.NL_SEL_MAX_FRAMES * L.NL_SEL_BATCH_WS_INTS_PER_FRAME, dtype=I32, device=d),
                        parity=0)
             self._pre = pre
-        pairs = [(it, f) for it in range(iters) for f in range(F)]
         lib, sp = L.lib(), L.stream_ptr()
         per = L.NL_SEL_BATCH_WS_INTS_PER_FRAME
-        offs = [sum(ns[:f]) for f in range(F)]
-        for c0 in range(0, len(pairs), L.NL_SEL_MAX_FRAMES):
-            chunk = pairs[c0:c0 + L.NL_SEL_MAX_FRAMES]
-            n = len(chunk)
-            I, U, PP = ctypes.c_int * n, ctypes.c_uint * n, ctypes.c_void_p * n
-            rc = lib.nl_select_rays_batch_ex(
-                n, I(*[Ms[f] for _, f in chunk]), I(*[ns[f] for _, f in chunk]), U(*[(int(seeds[it]) * 1000003 + f) & 0xFFFFFFFF for it, f in chunk]),
-                PP(*[scans[f]["dirs"].data_ptr() for _, f in chunk]), PP(*[scans[f]["points"].data_ptr() for _, f in chunk]),
-                PP(*[scans[f]["cos"].data_ptr() for _, f in chunk]), PP(*[pre["masks"][f][it].data_ptr() for it, f in chunk]),
-                I(*[it * tot + offs[f] for it, f in chunk]), I(*[f for _, f in chunk]), pre["d"].data_ptr(), pre["p"].data_ptr(), pre["c"].data_ptr(),
-                pre["f"].data_ptr(), pre["ws"].data_ptr() + 4 * c0 * per, pre["parity"], self.adam_state.data_ptr() + 12, sp)
+        key = (iters, tuple(ns), tuple(sc["dirs"].data_ptr() for sc in scans), tuple(sc["points"].data_ptr() for sc in scans),
+               tuple(sc["cos"].data_ptr() for sc in scans))
+        if pre.get("key") != key:
+            # the marshalled argument arrays of every chunk of eight (iteration, frame) pairs: built once per configuration, only the
+            # seeds change from call to call
+            pairs = [(it, f) for it in range(iters) for f in range(F)]
+            offs = [sum(ns[:f]) for f in range(F)]
+            mbase = [mk.data_ptr() for mk in pre["masks"]]
+            chunks = []
+            for c0 in range(0, len(pairs), L.NL_SEL_MAX_FRAMES):
+                chunk = pairs[c0:c0 + L.NL_SEL_MAX_FRAMES]
+                n = len(chunk)
+                I, U, PP = ctypes.c_int * n, ctypes.c_uint * n, ctypes.c_void_p * n
+                chunks.append(dict(n=n, pairs=chunk, Ms=I(*[Ms[f] for _, f in chunk]), ns=I(*[ns[f] for _, f in chunk]), seeds=U(),
+                                   dirs=PP(*[scans[f]["dirs"].data_ptr() for _, f in chunk]), points=PP(*[scans[f]["points"].data_ptr() for _, f in chunk]),
+                                   cos=PP(*[scans[f]["cos"].data_ptr() for _, f in chunk]), masks=PP(*[mbase[f] + it * Ms[f] for it, f in chunk]),
+                                   out_off=I(*[it * tot + offs[f] for it, f in chunk]), fid=I(*[f for _, f in chunk]), ws=pre["ws"].data_ptr() + 4 * c0 * per))
+            pre["chunks"], pre["key"] = chunks, key
+        # a call clears the other-parity candidate counters only of the (iteration, frame) slots it includes: slots beyond the previous
+        # call's count may hold counters of an older call at either parity - clear both before this call uses them
+        n_pairs, last = iters * F, pre.get("pairs_last", 0)
+        if n_pairs > last > 0:
+            pre["ws"].view(-1, per)[last:n_pairs, :2].zero_()
+        pre["pairs_last"] = n_pairs
+        for ch in pre["chunks"]:
+            sd = ch["seeds"]
+            for i, (it, f) in enumerate(ch["pairs"]):
+                sd[i] = (int(seeds[it]) * 1000003 + f) & 0xFFFFFFFF
+            rc = lib.nl_select_rays_batch_ex(ch["n"], ch["Ms"], ch["ns"], sd, ch["dirs"], ch["points"], ch["cos"], ch["masks"], ch["out_off"], ch["fid"],
+                                             pre["d"].data_ptr(), pre["p"].data_ptr(), pre["c"].data_ptr(), pre["f"].data_ptr(), ch["ws"], pre["parity"],
+                                             self.adam_state.data_ptr() + 12, sp)
             if rc == 4:
                 return False
             L.check(rc, "nl_select_rays_batch_ex")
@@ -436,13 +457,14 @@ class SdfEngine:
 
     def set_poses(self, pose6, optimise=None):
         """pose6 [F,6] = (t, w) like se3pose.OptimizablePose.data; optimise[f] = pose is in the optimiser."""
-        p = torch.as_tensor(np.asarray(pose6, np.float32)).reshape(-1, 6)
+        p = np.asarray(pose6, np.float32).reshape(-1, 6)
         self.F = p.shape[0]
         if self.F > self.F_cap:
             raise L.NerfLoamHipError("too many frames")
-        self.pose6[:self.F].copy_(p)
-        en = np.ones(self.F, np.int32) if optimise is None else np.asarray(optimise, np.int32)
-        self.pose_enable[:self.F].copy_(torch.as_tensor(en))
+        io = np.zeros(self.F_cap * 7, np.int32)
+        io[:self.F * 6] = p.reshape(-1).view(np.int32)
+        io[self.F_cap * 6:self.F_cap * 6 + self.F] = 1 if optimise is None else np.asarray(optimise, np.int32)
+        self._pose_io.copy_(torch.from_numpy(io))
         ops.pose_matrices(self.pose6[:self.F], self.poses12)
 
     def begin_call(self, m: MapDevice, dec: DecoderDevice = None, emb_state=True):

@@ -82,20 +82,41 @@ def _decoder_version(sdf_network):
 
 def _decoder_device(sdf_network, device):
     """device-resident parameter block + operand planes of the decoder module, kept between calls: rebuilt only when somebody
-    else wrote the module's parameters (tensor version counters) - no per-call D2H / H2D round trip"""
+    else wrote the module's parameters (tensor version counters) - no per-call D2H / H2D round trip.  A module that already lives on
+    the device has its parameters turned into VIEWS of the block: the optimiser kernels then update the module in place and a call
+    ends without the six write-back copies (an outside write - load_state_dict, an optimiser of the caller's - goes through the same
+    views, bumps the version counters and the block is rebuilt with its planes at the next call)."""
     cached = getattr(sdf_network, "_nl_device", None)
     ver = _decoder_version(sdf_network)
     if cached is not None and cached[0] == ver and cached[1].params.device == torch.device(device):
         return cached[1]
     p = sdf_network.flat_params(device)
     dec = DecoderDevice.from_flat(p)
-    sdf_network._nl_device = (ver, dec)
+    plist = sdf_network.param_list()
+    if all(q.device == dec.params.device and q.dtype == torch.float32 for q in plist):
+        with torch.no_grad():
+            off = 0
+            for q in plist:
+                n = q.numel()
+                q.data = dec.params[off:off + n].view(q.shape)
+                off += n
+    sdf_network._nl_device = (_decoder_version(sdf_network), dec)
     return dec
 
 
+def _decoder_aliased(sdf_network, dec):
+    off, base = 0, dec.params.data_ptr()
+    for q in sdf_network.param_list():
+        if q.data_ptr() != base + 4 * off:
+            return False
+        off += q.numel()
+    return True
+
+
 def _decoder_writeback(sdf_network, dec):
-    with torch.no_grad():
-        sdf_network.load_flat(dec.params)
+    if not _decoder_aliased(sdf_network, dec):               # (a module on another device / dtype: copy the block back)
+        with torch.no_grad():
+            sdf_network.load_flat(dec.params)
     sdf_network._nl_device = (_decoder_version(sdf_network), dec)
 
 
@@ -209,7 +230,8 @@ def track_frame(frame_pose, curr_frame, map_states, sdf_network, loss_criteria, 
     dec = _decoder_device(sdf_network, device)
     eng = _engine(N_rays, 1, device)
     cfg = _cfg(loss_criteria, voxel_size, step_size, max_distance)
-    init_pose = deepcopy(frame_pose)
+    # (the reference deep-copies the module, render_helpers.py:445; a module holding one 6-vector is rebuilt directly - 0.1 ms of the call)
+    init_pose = type(frame_pose)(frame_pose.data.detach().clone()) if type(frame_pose).__name__ == "OptimizablePose" else deepcopy(frame_pose)
     lr = learning_rate * 2 if curr_frame.index < 2 else learning_rate / 3
     eng.set_poses(init_pose.data.detach().cpu().numpy()[None], [1])
     eng.begin_call(m, None, emb_state=False)

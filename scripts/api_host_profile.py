@@ -87,6 +87,7 @@ def main():
         pr.disable()
         s = io.StringIO()
         pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(18)
+        pstats.Stats(pr, stream=s).sort_stats("cumtime").print_stats(45)
         print("\n".join(l[:170] for l in s.getvalue().splitlines() if l.strip())[:6000])
 
 

@@ -313,6 +313,30 @@ def test_get_scores_matches_oracle():
     assert np.abs(got.reshape(-1) - ref).max() < 1e-5
 
 
+def test_predraw_with_a_varying_iteration_count_meets_no_stale_candidate_counter():
+    """calls of 20, 5, 5 + 1 odd one, then 20 iterations on one engine (the tracker's first call runs 5x the iterations of the later ones,
+    tracking.py:42): the (iteration, frame) slots the short calls skip keep the long call's candidate counters at ITS parity - the engine
+    clears them before a later call uses them again.  Every subset of the last call against a fresh engine's draw, bitwise."""
+    from nerf_loam_amd import pipeline as P
+    rng = np.random.default_rng(11)
+    M, n = 131072, 2048
+    scans = [dict(dirs=torch.from_numpy(rng.normal(size=(M, 3)).astype(np.float32)).cuda(),
+                  points=torch.from_numpy(rng.normal(size=(M, 3)).astype(np.float32)).cuda(), cos=torch.from_numpy(rng.random(M).astype(np.float32)).cuda())]
+    eng = P.SdfEngine(max_rays=n, samples_per_ray_cap=4, max_frames=2)
+    ref = P.SdfEngine(max_rays=n, samples_per_ray_cap=4, max_frames=2)
+    for k, iters in enumerate((20, 5, 5, 20, 7, 20)):
+        seeds = [50 * k + it for it in range(iters)]
+        assert eng.predraw(scans, n, seeds)
+        torch.cuda.synchronize()
+        assert not eng.adam_state[3].item()
+        pre = eng._pre
+        for it in range(iters):
+            masks = ref.select_rays(scans, n, seeds[it], want_masks=True)
+            sl = slice(it * n, (it + 1) * n)
+            assert torch.equal(pre["d"][sl], ref.rays_d_sensor[:n]) and torch.equal(pre["c"][sl], ref.cos_gt[:n]), (k, iters, it)
+            assert torch.equal(pre["masks"][0][it], masks[0]), (k, iters, it)
+
+
 @pytest.mark.parametrize("shapes,iters", [([(131072, 2048)], 20), ([(131072, 4096)] * 4, 15), ([(90001, 2048), (131072, 2048), (65536, 1024)], 5)])
 def test_predrawn_subsets_equal_the_per_iteration_selection(shapes, iters):
     """SdfEngine.predraw (the ray subsets of ALL iterations of a call drawn up front, eight (iteration, frame) pairs per two launches)
