@@ -147,12 +147,15 @@ __device__ __forceinline__ int tb_insert(int* s_key, int key)
     unsigned h = ((unsigned)key * 2654435761u) >> 25;          // top 7 bits -> [0, 128)
 #pragma unroll 1
     for (int i = 0; i < TB_PROBES; ++i) {
-        const int prev = atomicCAS(&s_key[h], -1, key);         // lanes of this wave racing for a slot (integer CAS: cheap)
-        if (prev == -1 || prev == key) return (int)h;
+        const int prev = atomicCAS(&s_key[h], -1, key);         // lanes of this wave racing for a slot (integer CAS: cheap; a plain read
+        if (prev == -1 || prev == key) return (int)h;           // in front of it for rows already in the table measured no gain)
         h = (h + 1) & (TB_SLOTS - 1);
     }
     return -1;
 }
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs a)
 {
@@ -160,10 +163,12 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
     __shared__ int s_key_all[TB_WAVES * TB_SLOTS];
     __shared__ double s_pose[NL_MAX_FRAMES * 12];
     __shared__ int s_new[TB_WAVES * TB_SLOTS], s_new_n, s_new_base;     // rows this workgroup touches first (a.touched): one list append per workgroup
+    __shared__ unsigned char s_own_all[TB_WAVES * TB_SLOTS];            // per table slot: the lane whose claim of the slot stands in this round (flush_run)
     if (threadIdx.x == 0) s_new_n = 0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* s_val = s_val_all + wv * TB_SLOTS * NL_C;            // this wave's table
     int* s_key = s_key_all + wv * TB_SLOTS;
+    unsigned char* s_own = s_own_all + wv * TB_SLOTS;
     for (int i = threadIdx.x; i < a.n_frames * 12; i += NL_FIELD_THREADS) s_pose[i] = 0.0;
     for (int i = lane; i < TB_SLOTS; i += 64) s_key[i] = -1;
     for (int i = lane; i < TB_SLOTS * NL_C; i += 64) s_val[i] = 0.f;
@@ -186,20 +191,17 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
     // the few samples of one ray (ra: sum dx, sum depth * dx), folded at every ray change into the workgroup's fp64 accumulators
     // in LDS (ds_add_f64) and from there to memory (global_atomic_add_f64) - the result is independent of the summation order
     // to ~1e-13, i.e. reproducible run to run after the optimiser's rounding to fp32.
+    // Lanes 0..2 of a sample's group carry one component each (lane i: sum dx_i, sum depth * dx_i): the division, the running sums and
+    // the fold are one component's work per lane instead of three in lane 0 (a wave instruction costs the same with one lane or with three).
     int pf = -1, pr = -1;
-    float ra[6], rds[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 6; ++i) ra[i] = 0.f;
+    float ra0 = 0.f, ra1 = 0.f, rds[3] = {0.f, 0.f, 0.f};
     auto fold_ray = [&]() {
         if (pf < 0) return;
         double* sp = s_pose + 12 * pf;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            atomicAdd(sp + i, (double)ra[i]);
-            const double t = (double)ra[3 + i];
-            atomicAdd(sp + 3 + 3 * i, t * (double)rds[0]); atomicAdd(sp + 4 + 3 * i, t * (double)rds[1]); atomicAdd(sp + 5 + 3 * i, t * (double)rds[2]);
-            ra[i] = 0.f; ra[3 + i] = 0.f;
-        }
+        atomicAdd(sp + k, (double)ra0);
+        const double t = (double)ra1;
+        atomicAdd(sp + 3 + 3 * k, t * (double)rds[0]); atomicAdd(sp + 4 + 3 * k, t * (double)rds[1]); atomicAdd(sp + 5 + 3 * k, t * (double)rds[2]);
+        ra0 = 0.f; ra1 = 0.f;
     };
     for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const int s_end = min(P, (chunk + 1) * span);
@@ -226,10 +228,18 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
                     for (int c = 0; c < NL_C; ++c) atomicAdd(dst + c, acc[c]);
                 }
             }
+            // Lanes whose slots differ add together; two groups of the wave that finish a run on the SAME row (neighbouring rays
+            // share voxel corners) must not read-modify-write the slot at once: every pending lane claims its slot, the claim that
+            // stands adds its 16 floats, the others go again - 1-3 rounds instead of one per group (eight dependent LDS round trips
+            // of ~300 cycles on the path of every sample step).  Which claim stands is the LDS's fixed write order: run-to-run stable.
+            bool pend = slot >= 0;
 #pragma unroll 1
-            for (int gi = 0; gi < 8; ++gi) {                         // one group at a time: same-row updates of different groups stay ordered
-                if (((fm >> (8 * gi)) & 0xFFull) == 0ull) continue;
-                if (gw == gi && slot >= 0) {
+            while (__ballot(pend) != 0ull) {
+                if (pend) s_own[slot] = (unsigned char)lane;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const bool win = pend && s_own[slot] == (unsigned char)lane;
+                if (win) {
                     float4* dst = reinterpret_cast<float4*>(s_val + slot * NL_C);
                     float4 v0 = dst[0], v1 = dst[1], v2 = dst[2], v3 = dst[3];
                     v0.x += acc[0]; v0.y += acc[1]; v0.z += acc[2]; v0.w += acc[3];
@@ -238,7 +248,9 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
                     v3.x += acc[12]; v3.y += acc[13]; v3.z += acc[14]; v3.w += acc[15];
                     dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
                 }
-                __builtin_amdgcn_wave_barrier();                    // keep the groups' read-modify-writes in program order
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();                    // the slot is written before the next claim's lane reads it
+                pend = pend && !win;
             }
         };
         const int s_base = chunk * span + grp * per_group;
@@ -248,7 +260,16 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
             const bool live = s < s_end;                            // the 8 lanes of a group share s; dead groups keep calling flush_run
             if (__ballot(live) == 0ull) break;
             SampleGeom g;
-            if (live) g = sample_geom(a, s); else { g.vox = cur_vox; g.ray = 0; g.depth = 0.f; g.p[0] = g.p[1] = g.p[2] = 0.f; }
+            if (live) {
+                // the sample's local coordinates, one axis per lane (lanes 0..2 of the group; the others repeat axis 2) and one shuffle
+                // per axis, instead of all three axes - nine loads, three IEEE divisions - in every lane
+                g.vox = a.s_vox[s]; g.ray = a.s_ray[s]; g.depth = a.s_depth[s];
+                const int ax = k < 2 ? k : 2;
+                const float t_ax = a.poses[12 * (a.frame_id ? a.frame_id[g.ray] : 0) + 9 + ax];
+                const float x_ax = t_ax + a.rays_d_world[3 * g.ray + ax] * g.depth;          // ray(): o + d * depth
+                const float p_ax = (x_ax - a.centres[3 * g.vox + ax]) / a.voxel_size + 0.5f;  // nl_trilinear_p, one axis
+                g.p[0] = __shfl(p_ax, lane0); g.p[1] = __shfl(p_ax, lane0 + 1); g.p[2] = __shfl(p_ax, lane0 + 2);
+            } else { g.vox = cur_vox; g.ray = 0; g.depth = 0.f; g.p[0] = g.p[1] = g.p[2] = 0.f; }
             const bool change = live && g.vox != cur_vox;
             flush_run(change);
             if (change) {
@@ -263,10 +284,8 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
                 }
             }
             if (!live) continue;
-            float w[8]; nl_trilinear_w(g.p, w);
-            float wk = w[0];
-#pragma unroll
-            for (int i = 1; i < 8; ++i) wk = (k == i) ? w[i] : wk;
+            // this lane's corner weight (nl_trilinear_w's w[k]: (tx * ty) * tz)
+            const float wk = (((k & 4) ? g.p[0] : 1.0f - g.p[0]) * ((k & 2) ? g.p[1] : 1.0f - g.p[1])) * ((k & 1) ? g.p[2] : 1.0f - g.p[2]);
             float d[NL_C];
             {
                 const float4* di = reinterpret_cast<const float4*>(a.dX + (size_t)s * NL_C);
@@ -275,8 +294,14 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
                 d[8] = d2.x; d[9] = d2.y; d[10] = d2.z; d[11] = d2.w; d[12] = d3.x; d[13] = d3.y; d[14] = d3.z; d[15] = d3.w;
             }
             if (a.want_emb_grad) {
+                // bf16(w_k dX) as torch's embedding backward forms it: round-to-nearest-even by the hardware conversion (two values per
+                // instruction; nl_round_bf16 is the same rounding in five integer instructions per value - 80 of the loop's ~440)
 #pragma unroll
-                for (int c = 0; c < NL_C; ++c) acc[c] += nl_round_bf16(wk * d[c]);
+                for (int c = 0; c < NL_C; c += 2) {
+                    const f32x2_t pr2 = {wk * d[c], wk * d[c + 1]};
+                    const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(pr2, bf16x2_t));
+                    acc[c] += __uint_as_float(u << 16); acc[c + 1] += __uint_as_float(u & 0xFFFF0000u);
+                }
             }
             if (!a.want_pose_grad) continue;
             float t0 = 0.f, t1 = 0.f;                               // <e_k, dX>: 8 + 8 channels, then add
@@ -289,7 +314,7 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
             float dot[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) dot[i] = __shfl(dotk, lane0 + i);
-            if (k != 0) continue;
+            if (k > 2) continue;
             float dp[3]; nl_trilinear_dp(g.p, dot, dp);
             if (g.ray != pr) {
                 fold_ray();
@@ -297,12 +322,9 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
                 rds[0] = a.rays_d_sensor[3 * g.ray]; rds[1] = a.rays_d_sensor[3 * g.ray + 1]; rds[2] = a.rays_d_sensor[3 * g.ray + 2];
                 pf = a.frame_id ? a.frame_id[g.ray] : 0;
             }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const float dx = dp[i] / a.voxel_size;
-                ra[i] += dx;
-                ra[3 + i] += g.depth * dx;
-            }
+            const float dx = (k == 0 ? dp[0] : (k == 1 ? dp[1] : dp[2])) / a.voxel_size;
+            ra0 += dx;
+            ra1 += g.depth * dx;
         }
         FSTAMP(2);
         flush_run(true);
@@ -352,7 +374,7 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
         }
     }
     if (a.want_pose_grad) {
-        fold_ray();
+        if (k <= 2) fold_ray();
         __syncthreads();
         for (int i = threadIdx.x; i < a.n_frames * 12; i += NL_FIELD_THREADS)
             if (s_pose[i] != 0.0) atomicAdd(a.g_pose + i, s_pose[i]);

@@ -25,17 +25,17 @@ for blocks in (eng.field_blocks, 2 * eng.field_blocks):
         for _ in range(5): run(emb, pose, blocks)
         e1.record(); torch.cuda.synchronize()
         print(f"blocks {blocks} emb_grad {emb} pose_grad {pose}: {e0.elapsed_time(e1) / 5 * 1e3:.1f} us")
-nb = eng.field_blocks
+nb = 2 * eng.field_blocks
 dbg = torch.zeros(nb * 8, dtype=torch.int64, device="cuda")
 L.lib().nl_field_set_debug_buffer(L.ptr(dbg))
 run(1, 1, nb)
 torch.cuda.synchronize()
 L.lib().nl_field_set_debug_buffer(None)
 d = dbg.cpu().numpy().reshape(nb, 8)
-d = d[d[:, 0] > 0]
-names = ["init->barrier", "sample loop", "last run flush", "barrier", "table flush", "barrier"]
-ph = np.diff(d[:, :7], axis=1)
+d = d[(d[:, [0, 1, 2, 3, 5]] > 0).all(1)]
+names = ["init->barrier", "sample loop", "last run flush", "table flush + touched rows"]
+ph = np.diff(d[:, [0, 1, 2, 3, 5]], axis=1)
 print("workgroups", len(d))
 for n, v, mx in zip(names, ph.mean(0), ph.max(0)):
-    print(f"  {n:16s} mean {v:10.0f}  max {mx:10.0f}")
-print("  per workgroup total mean", (d[:, 6] - d[:, 0]).mean())
+    print(f"  {n:28s} mean {v:10.0f}  max {mx:10.0f}")
+print("  per workgroup total mean", (d[:, 5] - d[:, 0]).mean(), "cycles; kernel span", (d[:, 5].max() - d[:, 0].min()), "cycles")
