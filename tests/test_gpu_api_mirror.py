@@ -264,13 +264,14 @@ def test_device_resident_share_data_hand_off():
     assert torch.equal(w_pub, mapper.decoder.pts_linears[1].weight.detach()) and share.decoder is not mapper.decoder
     # the mapper keeps optimising: the published snapshot does not move until the next publication
     snap = st["voxel_vertex_emb"].clone(); ptr3 = st["voxel_vertex_emb"].data_ptr()
+    emb_clean = mapper.dynamic_embeddings.detach().clone()
     mapper.dynamic_embeddings.add_(1.0)
     assert torch.equal(share.states["voxel_vertex_emb"], snap) and share.states is st
     mapper.update_share_data(share)
     st4 = share.states
     assert share.version == 4 and st4 is not st and st4["voxel_vertex_emb"].data_ptr() != ptr3       # the other buffer
     assert torch.equal(st4["voxel_vertex_emb"], mapper.dynamic_embeddings)
-    mapper.dynamic_embeddings.sub_(1.0)
+    mapper.dynamic_embeddings.copy_(emb_clean)                                              # the optimised map again, bit for bit
     mapper.update_share_data(share)
     assert share.version == 5 and share.states["voxel_vertex_emb"].data_ptr() == ptr3              # buffers alternate
     # the tracker consumes the snapshot exactly like the reference's share_data
@@ -281,9 +282,10 @@ def test_device_resident_share_data_hand_off():
     tracker.last_frame = f1
     out = tracker.do_tracking(share, LidarFrame(2, torch.from_numpy(pts), torch.from_numpy(cos), np.eye(4)))
     err1 = float((out.pose.translation().detach() - f0.pose.translation().detach()).norm())
-    # (the snapshot went through + 1.0 - 1.0 in bf16: the map is degraded on purpose, the hand-off is under test - the numeric quality of
-    #  track_frame is tests/test_gpu_api_parity.py's; ten steps still pull the pose back, by 10 .. 25 % from run to run)
-    assert err1 < 0.95 * err0, (err0, err1)
+    # (the hand-off is under test - the numeric quality of track_frame is tests/test_gpu_api_parity.py's; the margin by which ten steps on
+    #  a map of three mapping calls pull the pose back moves from run to run)
+    print("share hand-off tracking", err0, err1)
+    assert err1 < 0.8 * err0, (err0, err1)                                                  # measured 0.57
 
 
 def test_get_scores_matches_oracle():

@@ -51,6 +51,7 @@ def test_share_data_across_two_processes():
         assert r["ptr"] != mapper.dynamic_embeddings.data_ptr()
         # the mapper keeps optimising and publishes TWICE while the tracker still works on the snapshot it leased: not overwritten
         snap_sum = r["emb_sum"]
+        emb_clean = mapper.dynamic_embeddings.detach().clone()
         with torch.no_grad():
             mapper.dynamic_embeddings.add_(0.25)
         mapper.update_share_data(share)
@@ -63,13 +64,14 @@ def test_share_data_across_two_processes():
         r3 = ask("read")
         assert r3["version"] == 5 and r3["emb_sum"] == float(mapper.dynamic_embeddings.float().abs().sum()) and r3["emb_sum"] != snap_sum
         with torch.no_grad():
-            mapper.dynamic_embeddings.sub_(0.5)
+            mapper.dynamic_embeddings.copy_(emb_clean)                        # the optimised map again, bit for bit
         mapper.update_share_data(share)
         t = ask("track")                                                      # do_tracking in the other process, on the shared snapshot
-        # (the snapshot went through + 0.25 + 0.25 - 0.5 in bf16, i.e. the map is degraded on purpose: the hand-off is under test, the
-        #  numeric quality of track_frame is tests/test_gpu_api_parity.py's; ten steps still pull the pose back - by 16 .. 25 % from run
-        #  to run, the fp32 atomics of the mapper's embedding gradients are not ordered)
-        assert t["err1"] < 0.92 * t["err0"] and 0.9 < t["hit_ratio"] <= 1.0, t
+        # (the hand-off is under test, the numeric quality of track_frame is tests/test_gpu_api_parity.py's: ten steps on a map of three
+        #  mapping calls pull the pose back by a margin that moves from run to run - the fp32 atomics of the mapper's embedding gradients
+        #  are not ordered and bf16 Adam amplifies that)
+        print("share_ipc tracking", t)
+        assert t["err1"] < 0.8 * t["err0"] and 0.9 < t["hit_ratio"] <= 1.0, t       # measured 0.59 .. 0.66
     finally:
         q_in.put("stop")
         proc.join(60)
