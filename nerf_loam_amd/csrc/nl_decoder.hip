@@ -349,6 +349,8 @@ __device__ __forceinline__ unsigned store_h1_planes(unsigned short* sP, int col,
 {
     const bool odd = (col & 1) != 0;
     unsigned* pb = reinterpret_cast<unsigned*>(sP + opaque((4 * lh + (odd ? 1 : 0)) * SM_STRIDE + (col & ~1)));   // odd lanes: the odd rows
+    // plane 2 lies beyond the 64 KB an LDS offset field reaches: its own base register instead of an address add per store
+    unsigned* pb2 = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(sP) + opaque(((4 * lh + (odd ? 1 : 0)) * SM_STRIDE + (col & ~1)) * 2 + 2 * X_PLANE_BYTES));
     unsigned m1 = 0u;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
@@ -361,7 +363,7 @@ __device__ __forceinline__ unsigned store_h1_planes(unsigned short* sP, int col,
             unsigned q0, q1, q2;
             split3_pair(lo_k, hi_k, &q0, &q1, &q2);
             unsigned* d = pb + ((32 * sub + D32_RR(r)) * SM_STRIDE) / 2;
-            d[0] = q0; d[X_PLANE_ELEMS / 2] = q1; d[X_PLANE_ELEMS] = q2;
+            d[0] = q0; d[X_PLANE_ELEMS / 2] = q1; pb2[((32 * sub + D32_RR(r)) * SM_STRIDE) / 2] = q2;
         }
     }
     return m1;
@@ -618,8 +620,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             for (int r = 0; r < 16; ++r) {
                 if (XG) {
                     const float d0 = dsb[D32_RR(r)], d1 = dsb[32 + D32_RR(r)];           // unconditional loads: no exec-mask branches
-                    g0v[r] *= ((m1 >> r) & 1u) ? d0 : 0.f;                              // select on the factor: v_cndmask, no branch
-                    g1v[r] *= ((m1 >> (16 + r)) & 1u) ? d1 : 0.f;
+                    // the ReLU bit as an all-ones / zero word (one v_bfe_i32) ANDed onto the factor: no compare, no branch
+                    g0v[r] *= __uint_as_float(__float_as_uint(d0) & (unsigned)__builtin_amdgcn_sbfe((int)m1, r, 1));
+                    g1v[r] *= __uint_as_float(__float_as_uint(d1) & (unsigned)__builtin_amdgcn_sbfe((int)m1, 16 + r, 1));
                 } else {
                     g0v[r] = hb[D32_RR(r) * LDH] > 0.f ? g0v[r] : 0.f;
                     g1v[r] = hb[(32 + D32_RR(r)) * LDH] > 0.f ? g1v[r] : 0.f;
