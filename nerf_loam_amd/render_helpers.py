@@ -40,17 +40,27 @@ RAY_SELECTION = os.environ.get("NL_RAY_SELECTION", "device")
 SAMPLER_NOISE = None
 
 _PRIVATE_GEN = None
+_PRIVATE_SEED = None
 
 
 def _draw_seed():
-    """seeds of the device-side random streams (ray subsets, sampler jitter) come from a PRIVATE generator, itself seeded once
-    from torch's global seed: reproducible under torch.manual_seed, and the global CPU stream the reference's sample_rays
-    consumes is left untouched"""
-    global _PRIVATE_GEN
-    if _PRIVATE_GEN is None:
+    """seeds of the device-side random streams (ray subsets, sampler jitter) come from a PRIVATE generator derived from torch's global
+    seed: reproducible under torch.manual_seed - a new manual_seed starts the private stream again, whatever was drawn before - and the
+    global CPU stream the reference's sample_rays consumes is left untouched"""
+    global _PRIVATE_GEN, _PRIVATE_SEED
+    if _PRIVATE_GEN is None or _PRIVATE_SEED != torch.initial_seed():
+        _PRIVATE_SEED = torch.initial_seed()
         _PRIVATE_GEN = torch.Generator()
-        _PRIVATE_GEN.manual_seed((torch.initial_seed() * 0x9E3779B1 + 0x7F4A7C15) & 0x7FFFFFFFFFFFFFFF)
+        _PRIVATE_GEN.manual_seed((_PRIVATE_SEED * 0x9E3779B1 + 0x7F4A7C15) & 0x7FFFFFFFFFFFFFFF)
     return int(torch.randint(0, 2 ** 31 - 1, (1,), generator=_PRIVATE_GEN).item())
+
+
+def reseed():
+    """start the private seed stream of _draw_seed again from torch's current global seed (a torch.manual_seed with a NEW value does
+    that by itself; re-seeding with the same value cannot be told from not seeding): for runs that must not depend on what the
+    process drew before"""
+    global _PRIVATE_GEN
+    _PRIVATE_GEN = None
 
 
 def _engine(n_rays, n_frames, device):
