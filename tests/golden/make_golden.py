@@ -371,6 +371,36 @@ def run_se3_case():
     print("se3: ok")
 
 
+def run_criterion_case():
+    """the reference's Criterion.forward (criterion.py:16-115) on tensors it did not produce itself: loss, its two parts and dloss / dsdf by
+    the reference's own autograd - what nerf_loam_amd.criterion.Criterion's caller-tensor path (nl_criterion_forward / _backward) must return"""
+    from criterion import Criterion
+    args = Namespace(criteria=dict(sdf_weight=10000.0, fs_weight=1, eiko_weight=0.1, sdf_truncation=0.30), data_specs=dict(max_depth=50.0))
+    crit = Criterion(args)
+    rng = np.random.default_rng(791)
+    out = {}
+    for tag, (N, R, S) in (("a", (400, 300, 40)), ("b", (1500, 1024, 64))):
+        pts = rng.normal(0, 8, (N, 3)).astype(np.float32)
+        pts[: N // 8] *= 20                                            # beyond max_depth: depth mask off
+        cos = rng.uniform(0.3, 1.0, N).astype(np.float32)
+        ray_mask = np.zeros(N, bool); ray_mask[rng.choice(N, R, replace=False)] = True
+        d = np.linalg.norm(pts[ray_mask], axis=1)
+        z = (d[:, None] + rng.normal(0, 0.4, (R, S))).astype(np.float32)
+        valid = rng.random((R, S)) < 0.8
+        z[~valid] = 80.0                                               # the padded slots of render_rays (voxel_helpers.py:590)
+        sdf = rng.normal(0, 0.5, (R, S)).astype(np.float32)
+        sdf_t = torch.from_numpy(sdf).requires_grad_(True)
+        outputs = dict(sdf=sdf_t, z_vals=torch.from_numpy(z), ray_mask=torch.from_numpy(ray_mask), valid_mask=torch.from_numpy(valid), sampled_xyz=None)
+        loss, ld = crit(outputs, torch.from_numpy(pts), torch.from_numpy(cos).view(-1, 1))
+        loss.backward()
+        out.update({f"{tag}_points": pts, f"{tag}_cos": cos, f"{tag}_ray_mask": np.packbits(ray_mask), f"{tag}_n": np.int32(N), f"{tag}_z_vals": z,
+                    f"{tag}_valid": np.packbits(valid, axis=-1), f"{tag}_sdf": sdf, f"{tag}_loss": np.float32(loss.item()),
+                    f"{tag}_fs_loss": np.float32(ld["fs_loss"]), f"{tag}_sdf_loss": np.float32(ld["sdf_loss"]),
+                    f"{tag}_dsdf": sdf_t.grad.numpy().astype(np.float32)})
+    np.savez_compressed(os.path.join(HERE, "criterion.npz"), **out)
+    print("criterion:", {k: float(v) for k, v in out.items() if k.endswith("loss")})
+
+
 def run_adam_case():
     """torch.optim.Adam on a bf16 and an fp32 parameter, 5 steps, sparse-ish gradients."""
     rng = np.random.default_rng(11)
@@ -394,6 +424,7 @@ def run_adam_case():
 CASES = {
     "se3": lambda: run_se3_case(),
     "adam": lambda: run_adam_case(),
+    "criterion": lambda: run_criterion_case(),
     "map_1f_1it": lambda: run_mapping_case("map_1f_1it", n_frames=1, n_rays=512, n_iter=1, seed=777),
     "map_1f_3it": lambda: run_mapping_case("map_1f_3it", n_frames=1, n_rays=512, n_iter=3, seed=778),
     "map_2f_2it_frozen": lambda: run_mapping_case("map_2f_2it_frozen", n_frames=2, n_rays=384, n_iter=2, seed=779,

@@ -95,3 +95,25 @@ def test_criterion_rejects_what_it_cannot_do():
     assert loss == 0 and ld == {"loss": 0}
     with pytest.raises(ValueError):
         crit(dict(dev_out, z_vals=dev_out["z_vals"][:, :-1]), t(pts).cuda(), t(cos).cuda())
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_criterion_on_caller_tensors_matches_the_reference_class(golden_dir, tag):
+    """tests/golden/criterion.npz: the reference's OWN Criterion.forward + autograd on these tensors (make_golden.py run_criterion_case)"""
+    import os
+    from nerf_loam_amd.criterion import Criterion
+    g = np.load(os.path.join(golden_dir, "criterion.npz"))
+    N = int(g[f"{tag}_n"])
+    ray_mask = np.unpackbits(g[f"{tag}_ray_mask"])[:N].astype(bool)
+    z = g[f"{tag}_z_vals"]; R, S = z.shape
+    valid = np.unpackbits(g[f"{tag}_valid"], axis=-1)[:, :S].astype(bool)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    sdf_t = t(g[f"{tag}_sdf"]).requires_grad_(True)
+    loss, ld = Criterion(_args())(dict(sdf=sdf_t, z_vals=t(z), ray_mask=t(ray_mask), valid_mask=t(valid), sampled_xyz=None),
+                                  t(g[f"{tag}_points"]), t(g[f"{tag}_cos"]).view(-1, 1))
+    loss.backward()
+    assert ld["loss"] == pytest.approx(float(g[f"{tag}_loss"]), rel=2e-5)
+    assert ld["fs_loss"] == pytest.approx(float(g[f"{tag}_fs_loss"]), rel=2e-5) and ld["sdf_loss"] == pytest.approx(float(g[f"{tag}_sdf_loss"]), rel=2e-5)
+    ref = g[f"{tag}_dsdf"]
+    got = sdf_t.grad.cpu().numpy()
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max() and np.array_equal(got != 0, ref != 0)

@@ -162,3 +162,21 @@ def test_tracking_two_iterations(golden_dir, case):
     np.testing.assert_allclose(outs[1]["grad_pose"][0], g["pose_grad_last"], rtol=5e-2, atol=1e-5)
     np.testing.assert_allclose(pose, g["pose_final"], rtol=0, atol=3e-4)
     assert np.array_equal(outs[-1]["hits"], g["hit_mask"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_criterion_on_caller_tensors(golden_dir, tag):
+    """oracle.sdf_loss against the reference's OWN Criterion.forward + autograd on tensors it did not produce itself
+    (make_golden.py run_criterion_case): the checker of nerf_loam_amd.criterion.Criterion's caller-tensor path is pinned to the reference class"""
+    g = load(golden_dir, "criterion")
+    N = int(g[f"{tag}_n"])
+    ray_mask = np.unpackbits(g[f"{tag}_ray_mask"])[:N].astype(bool)
+    z = g[f"{tag}_z_vals"]
+    valid = np.unpackbits(g[f"{tag}_valid"], axis=-1)[:, :z.shape[1]].astype(bool)
+    loss, dsdf, st = O.sdf_loss(z, g[f"{tag}_sdf"], valid, g[f"{tag}_points"][ray_mask], g[f"{tag}_cos"][ray_mask],
+                                O.LossCfg(truncation=0.3, sdf_weight=10000.0, fs_weight=1.0, max_depth=50.0))
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) <= 1e-6 * float(g[f"{tag}_loss"])
+    assert abs(float(st["fs_loss"]) - float(g[f"{tag}_fs_loss"])) <= 1e-6 * float(g[f"{tag}_fs_loss"])
+    assert abs(float(st["sdf_loss"]) - float(g[f"{tag}_sdf_loss"])) <= 1e-6 * float(g[f"{tag}_sdf_loss"])
+    ref = g[f"{tag}_dsdf"]
+    assert np.abs(dsdf - ref).max() <= 1e-5 * np.abs(ref).max() and np.array_equal(dsdf != 0, ref != 0)
