@@ -95,10 +95,16 @@ int nl_ray_intersect_scan(int N, const float* rays_d_sensor, const float* points
                           float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
                           int* counters, int* ray_of_rank, int* hit_rank, int* total_out, int* total_out2, int* scan_ws, void* stream);
 
+/* LidarFrame.get_rays (src/lidarFrame.py:47-52): rays_d[M,3] = points / (||points||_2 + 1e-8), rays_norm[M] (optional) = that
+ * denominator - the arithmetic of the reference's host torch ops, bit for bit (nl_device_math.h nl_unit_dir).  The selection entry
+ * points below compute the same direction in flight when their rays_d argument is NULL. */
+int nl_unit_dirs(int M, const float* points, float* out_rays_d, float* out_rays_norm /* optional */, void* stream);
+
 /* On-device ray selection (LidarFrame.sample_rays -> sampling_without_replacement, src/lidarFrame.py:55-57,
  * src/utils/sample_util.py:4-19): a uniformly random subset of n_select of the frame's M returns, kept in dataset order,
  * gathered into out_*[0..n_select) (out_frame_id, mask_out optional; mask_out[M] = the reference's boolean sample_mask).
- * Deterministic in (seed, M, n_select).  workspace >= NL_SELECT_WS_INTS(M) ints. */
+ * Deterministic in (seed, M, n_select).  workspace >= NL_SELECT_WS_INTS(M) ints.  rays_d may be NULL (also per frame in the batch
+ * forms): the directions are then computed from `points` (nl_unit_dirs' arithmetic) - a frame is resident as points + cos only. */
 #define NL_SELECT_WS_INTS(M) (264 + 2 * (M) + ((M) + 1023) / 1024 + 8)
 int nl_select_rays(int M, int n_select, unsigned seed, const float* rays_d, const float* points, const float* cos_in, int frame,
                    float* out_rays_d, float* out_points, float* out_cos, int* out_frame_id, unsigned char* mask_out,

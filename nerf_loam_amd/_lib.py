@@ -123,6 +123,7 @@ _SIGS = {
     "nl_geometry_set_intersect_prune": ([_I], _I),
     "nl_geometry_set_sampler_mode": ([_I], _I),
     "nl_dist_merge_counters": ([_P, _I, _I, _I, _P, _P], _I),
+    "nl_unit_dirs": ([_I, _P, _P, _P, _P], _I),
     "nl_select_rays": ([_I, _I, ctypes.c_uint, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P], _I),
     "nl_select_rays_batch": ([_I] + [_P] * 13 + [_I, _P, _P], _I),
     "nl_select_rays_batch_ex": ([_I] + [_P] * 14 + [_I, _P, _P], _I),

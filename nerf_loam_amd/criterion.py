@@ -81,6 +81,9 @@ class Criterion(nn.Module):
         ray_idx = torch.nonzero(outputs["ray_mask"].to(dev).reshape(-1), as_tuple=False).reshape(-1).to(torch.int32).contiguous()
         points = obs.detach().to(dev, torch.float32).reshape(-1, 3).contiguous()
         cos = pointsCos.detach().to(dev, torch.float32).reshape(-1).contiguous()
+        n_rays = outputs["ray_mask"].numel()
+        if points.shape[0] != n_rays or cos.numel() != n_rays:    # (the reference's boolean indexing `points[ray_mask]` raises on a mismatch)
+            raise ValueError(f"Criterion.forward: ray_mask has {n_rays} entries, obs {points.shape[0]} points, pointsCos {cos.numel()}")
         if sdf.dim() != 2 or z_vals.shape != sdf.shape or valid_u8.shape != sdf.shape or ray_idx.numel() != sdf.shape[0]:
             raise ValueError("Criterion.forward: sdf, z_vals, valid_mask must be [R,S] with R = ray_mask.sum()")
         if sdf.shape[0] == 0:

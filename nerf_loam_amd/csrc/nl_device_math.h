@@ -14,6 +14,7 @@
 //   nl_loss_*           src/criterion.py:59-100
 //   nl_adam_*           torch/optim/adam.py::_single_tensor_adam (torch 2.10)
 //   nl_rodrigues*       src/se3pose.py:24-32,64-83
+//   nl_unit_dir         src/lidarFrame.py:47-52
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -70,6 +71,19 @@ NL_HD uint32_t nl_select_key(uint32_t seed, uint32_t i) {
     uint32_t x = i ^ (seed * 0x9E3779B9u + 0x7F4A7C15u);
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
     return x;
+}
+
+// unit direction of a LiDAR return (src/lidarFrame.py:47-52: rays_norm = ||p||_2 + 1e-8, rays_d = p / rays_norm).  The reference
+// evaluates it with torch on the host, whose vector-norm kernel accumulates the squares with fused multiply-adds
+// (s = x x; s = fma(y, y, s); s = fma(z, z, s) - measured: 400 000 random points, 0 mismatches; the unfused and the fp64 forms differ on
+// 10-15 % of them); square root and division are IEEE.  tests/test_device_math_host.py pins this against torch, bit for bit.
+NL_HD float nl_unit_dir(float x, float y, float z, float* dx, float* dy, float* dz) {
+    float s = x * x;
+    s = fmaf(y, y, s);
+    s = fmaf(z, z, s);
+    const float n = sqrtf(s) + 1e-8f;
+    *dx = x / n; *dy = y / n; *dz = z / n;
+    return n;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -13,9 +13,12 @@
 // Four collectives per iteration, all on the stream the kernels run on: a sharded iteration is one C call (nl_iteration) with no
 // host work between its launches, and hipGraph-capturable (RCCL collectives are).
 //
-// RCCL binding: the functions are looked up in the RCCL the process has already loaded (torch ships its own librccl.so and
-// ProcessGroupNCCL hands out its ncclComm_t): no second RCCL, no second communicator.
+// RCCL binding: the functions are looked up ONLY in an RCCL the process has already loaded (torch ships its own librccl.so and
+// ProcessGroupNCCL hands out its ncclComm_t) - dlopen(NULL) / RTLD_NOLOAD on the loaded object: no second RCCL, no second communicator.
 #include <dlfcn.h>
+#include <link.h>
+#include <cstring>
+#include <string>
 #include <hip/hip_runtime.h>
 
 #include "../../include/nerfloam_hip.h"
@@ -40,11 +43,29 @@ struct Rccl {
 
 Rccl& rccl()
 {
-    static Rccl r = [] {
+    static Rccl r;
+    if (r.ok) return r;                                                          // (a failed look-up is retried: RCCL may be loaded later)
+    r = [] {
         Rccl x;
-        void* h = dlopen(nullptr, RTLD_NOW | RTLD_GLOBAL);                       // whatever RCCL the process already holds (torch's)
-        if (!h || !dlsym(h, "ncclAllReduce")) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h || !dlsym(h, "ncclAllReduce")) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        // ONLY the RCCL the process already holds (torch's): the ncclComm_t handed to nl_comm_init_rccl belongs to that build, and a second
+        // copy of the library (another soname / version found on the loader path) must never receive it.  Global scope first, then the
+        // objects loaded with RTLD_LOCAL (Python extensions), found by walking the loaded-object list and re-opened with RTLD_NOLOAD -
+        // which never loads anything.  No loaded RCCL: not ok -> nl_comm_init_rccl returns "no device" and dist.py uses backend "torch".
+        void* h = dlopen(nullptr, RTLD_NOW);
+        if (!h || !dlsym(h, "ncclAllReduce")) {
+            h = nullptr;
+            std::string found;
+            dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void* out) -> int {
+                const char* nm = info->dlpi_name;
+                if (!nm) return 0;
+                const char* base = strrchr(nm, '/');
+                base = base ? base + 1 : nm;
+                if (strncmp(base, "librccl", 7) == 0 || strncmp(base, "libnccl", 7) == 0) { *(std::string*)out = nm; return 1; }
+                return 0;
+            }, &found);
+            if (!found.empty()) h = dlopen(found.c_str(), RTLD_NOW | RTLD_NOLOAD);
+            if (h && !dlsym(h, "ncclAllReduce")) h = nullptr;
+        }
         if (!h) return x;
         x.all_gather = (allgather_fn)dlsym(h, "ncclAllGather");
         x.all_reduce = (allreduce_fn)dlsym(h, "ncclAllReduce");

@@ -66,6 +66,34 @@ __global__ void k_sel_flags(int M, unsigned seed, int n_select, const int* __res
     }
 }
 
+// one selected return -> the engine's ray buffers.  rays_d == NULL: the unit direction is computed here from the point
+// (LidarFrame.get_rays, src/lidarFrame.py:47-52 - nl_unit_dir), so a frame is resident as points + cos only and no direction array
+// is ever built, uploaded or read.
+__device__ __forceinline__ void sel_emit(const float* __restrict__ rays_d, const float* __restrict__ points, const float* __restrict__ cos_in, size_t i,
+                                         int frame, float* __restrict__ out_d, float* __restrict__ out_p, float* __restrict__ out_cos,
+                                         int* __restrict__ out_frame, size_t o)
+{
+    const float px = points[3 * i], py = points[3 * i + 1], pz = points[3 * i + 2];
+    float dx, dy, dz;
+    if (rays_d) { dx = rays_d[3 * i]; dy = rays_d[3 * i + 1]; dz = rays_d[3 * i + 2]; }
+    else nl_unit_dir(px, py, pz, &dx, &dy, &dz);
+    out_d[3 * o] = dx; out_d[3 * o + 1] = dy; out_d[3 * o + 2] = dz;
+    out_p[3 * o] = px; out_p[3 * o + 1] = py; out_p[3 * o + 2] = pz;
+    out_cos[o] = cos_in[i];
+    if (out_frame) out_frame[o] = frame;
+}
+
+// LidarFrame.get_rays for a whole scan (src/lidarFrame.py:47-52): rays_d [M,3] (and rays_norm [M], optional) from points [M,3]
+__global__ void k_unit_dirs(int M, const float* __restrict__ points, float* __restrict__ out_d, float* __restrict__ out_norm)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
+        float dx, dy, dz;
+        const float n = nl_unit_dir(points[3 * (size_t)i], points[3 * (size_t)i + 1], points[3 * (size_t)i + 2], &dx, &dy, &dz);
+        out_d[3 * (size_t)i] = dx; out_d[3 * (size_t)i + 1] = dy; out_d[3 * (size_t)i + 2] = dz;
+        if (out_norm) out_norm[i] = n;
+    }
+}
+
 __global__ void k_sel_gather(int M, const int* __restrict__ flags, const int* __restrict__ rank, const float* __restrict__ rays_d,
                              const float* __restrict__ points, const float* __restrict__ cos_in, int frame, int cap,
                              float* __restrict__ out_d, float* __restrict__ out_p, float* __restrict__ out_cos, int* __restrict__ out_frame)
@@ -74,10 +102,7 @@ __global__ void k_sel_gather(int M, const int* __restrict__ flags, const int* __
         if (!flags[i]) continue;
         const int o = rank[i];
         if (o >= cap) continue;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { out_d[3 * (size_t)o + c] = rays_d[3 * (size_t)i + c]; out_p[3 * (size_t)o + c] = points[3 * (size_t)i + c]; }
-        out_cos[o] = cos_in[i];
-        if (out_frame) out_frame[o] = frame;
+        sel_emit(rays_d, points, cos_in, (size_t)i, frame, out_d, out_p, out_cos, out_frame, (size_t)o);
     }
 }
 
@@ -235,10 +260,7 @@ __global__ __launch_bounds__(256) void k_sel_window_b(SelArgs a)
             const int o = rank + __popcll(bal & ((1ull << lane) - 1ull));
             if (o < cap) {
                 const size_t oo = (size_t)(fr.out_off + o);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { a.out_d[3 * oo + c] = fr.d[3 * (size_t)i + c]; a.out_p[3 * oo + c] = fr.p[3 * (size_t)i + c]; }
-                a.out_c[oo] = fr.c[i];
-                if (a.out_frame) a.out_frame[oo] = fr.frame;
+                sel_emit(fr.d, fr.p, fr.c, (size_t)i, fr.frame, a.out_d, a.out_p, a.out_c, a.out_frame, oo);
             }
         }
         rank += __popcll(bal);
@@ -247,11 +269,21 @@ __global__ __launch_bounds__(256) void k_sel_window_b(SelArgs a)
 
 extern "C" {
 
+int nl_unit_dirs(int M, const float* points, float* out_rays_d, float* out_rays_norm, void* stream)
+{
+    if (M < 0 || (M > 0 && (!points || !out_rays_d))) return NL_ERR_INVALID_ARG;
+    if (M == 0) return NL_OK;
+    const int blocks = nl_div_up(M, 256) < 2048 ? nl_div_up(M, 256) : 2048;
+    hipLaunchKernelGGL(k_unit_dirs, dim3(blocks), dim3(256), 0, (hipStream_t)stream, M, points, out_rays_d, out_rays_norm);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
 int nl_select_rays(int M, int n_select, unsigned seed, const float* rays_d, const float* points, const float* cos_in, int frame,
                    float* out_rays_d, float* out_points, float* out_cos, int* out_frame_id, unsigned char* mask_out,
                    int* workspace, void* stream)
 {
-    if (M <= 0 || n_select <= 0 || !rays_d || !points || !cos_in || !out_rays_d || !out_points || !out_cos || !workspace)
+    if (M <= 0 || n_select <= 0 || !points || !cos_in || !out_rays_d || !out_points || !out_cos || !workspace)
         return NL_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     int* state = workspace;                 // 8 ints
@@ -287,14 +319,14 @@ int nl_select_rays_batch_ex(int F, const int* M, const int* n_select, const unsi
                             const int* frame_ids, float* out_rays_d, float* out_points, float* out_cos, int* out_frame_id, int* workspace,
                             int parity, int* fail_word, void* stream)
 {
-    if (F <= 0 || F > SEL_MAX_FRAMES || !M || !n_select || !seed || !rays_d || !points || !cos_in || !out_off || !out_rays_d || !out_points ||
+    if (F <= 0 || F > SEL_MAX_FRAMES || !M || !n_select || !seed || !points || !cos_in || !out_off || !out_rays_d || !out_points ||
         !out_cos || !workspace || (parity != 0 && parity != 1))
         return NL_ERR_INVALID_ARG;
     SelArgs a;
     int max_blk = 1;
     for (int f = 0; f < F; ++f) {
         const int m = M[f], n = n_select[f];
-        if (m <= 0 || n <= 0 || !rays_d[f] || !points[f] || !cos_in[f]) return NL_ERR_INVALID_ARG;
+        if (m <= 0 || n <= 0 || !points[f] || !cos_in[f]) return NL_ERR_INVALID_ARG;
         if (n >= m) return NL_ERR_CAPACITY;
         const double p = (double)n / (double)m, sigma = sqrt((double)n * (1.0 - p)), W = 16.0 * sigma + 64.0;
         if (2.0 * W + 64.0 > (double)SEL_CAP) return NL_ERR_CAPACITY;
@@ -302,7 +334,7 @@ int nl_select_rays_batch_ex(int F, const int* M, const int* n_select, const unsi
         const double lo = T0 - delta, hi = T0 + delta;
         if (lo < 1.0 || hi > 4294967294.0) return NL_ERR_CAPACITY;
         SelFrame& fr = a.f[f];
-        fr.d = rays_d[f]; fr.p = points[f]; fr.c = cos_in[f]; fr.mask = mask_out ? mask_out[f] : nullptr;
+        fr.d = rays_d ? rays_d[f] : nullptr; fr.p = points[f]; fr.c = cos_in[f]; fr.mask = mask_out ? mask_out[f] : nullptr;
         fr.M = m; fr.n = n; fr.out_off = out_off[f]; fr.frame = frame_ids ? frame_ids[f] : f; fr.seed = seed[f]; fr.lo = (unsigned)lo; fr.hi = (unsigned)hi;
         int nblk = nl_div_up(m, 1024); if (nblk > SEL_MAXB) nblk = SEL_MAXB;
         fr.nblk = nblk;

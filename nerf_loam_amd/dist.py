@@ -147,6 +147,7 @@ class RayShardedExchange:
         eng = self.eng
         dev = eng.counters.device
         self._torch_comm = None
+        requested = backend
         if backend == "auto":
             backend = "rccl" if self._nccl_comm_ptr() else "torch"
         if backend == "rccl":
@@ -155,7 +156,15 @@ class RayShardedExchange:
                 raise L.NerfLoamHipError("backend 'rccl' needs a ProcessGroupNCCL with an initialised communicator "
                                          "(init_process_group('nccl', device_id=...)); use backend='torch' otherwise")
             self.comm = L.NlComm()
-            L.check(L.lib().nl_comm_init_rccl(ctypes.byref(self.comm), ctypes.c_void_p(ptr), self.world, self.rank), "nl_comm_init_rccl")
+            rc = L.lib().nl_comm_init_rccl(ctypes.byref(self.comm), ctypes.c_void_p(ptr), self.world, self.rank)
+            if rc == 3 and requested == "auto":
+                # the library binds only an RCCL that is ALREADY loaded in the process (never a second copy): none found -> the same four
+                # entry points over torch.distributed
+                backend = "torch"
+            else:
+                L.check(rc, "nl_comm_init_rccl")
+        if backend == "rccl":
+            pass
         elif backend == "torch":
             self._torch_comm = _TorchComm(self.group, self.world, self.rank)
             self.comm = self._torch_comm.struct

@@ -1,26 +1,46 @@
-"""LidarFrame: one scan's returns, unit ray directions and pose.
+"""LidarFrame: one scan as a DEVICE-RESIDENT container (points + cos uploaded once, nothing else).
 
-Mirror of /root/reference/src/lidarFrame.py (+ src/utils/sample_util.py for the per-iteration ray
-subset): same constructor and accessors, the +2000 m world offset (lidarFrame.py:18), rays_d =
-points / (||points|| + 1e-8), and `sample_rays(N)` drawing N rays without replacement by Gumbel
-top-k on the host and storing a boolean `sample_mask` (rays keep dataset order)."""
+Keeps the constructor and accessor names of /root/reference/src/lidarFrame.py:9-57 (the Mapping / Tracking call sites use them),
+but what the reference computes with host torch ops comes from HIP kernels here:
+
+  * unit directions `rays_d = points / (||points|| + 1e-8)` (lidarFrame.py:47-52): never materialised on the hot path - the ray
+    selection kernels compute the direction of a selected return in flight (nl_select.hip `sel_emit`); the `rays_d` / `rays_norm`
+    attributes are lazy views of `nl_unit_dirs`' output for callers that want the whole array (bit-identical to the host ops);
+  * the per-iteration ray subset (lidarFrame.py:55-57, sample_util.py:4-19): drawn on the device by nl_select_rays_batch
+    (render_helpers.RAY_SELECTION = "device"); `sample_rays` below is only the seeded host fallback that consumes torch's global
+    CPU generator exactly like the reference does.
+
+Any object with `.index`, `.pose.data`, `.points`, `.pointsCos` works in bundle_adjust_frames / track_frame (render_helpers.scan_of),
+the reference's own LidarFrame included; this class is what `Mapping.insert_keyframe` builds."""
 import numpy as np
 import torch
 import torch.nn as nn
 
 from .se3pose import OptimizablePose
 
-
-def sampling_without_replacement(logp, k):
-    g = -torch.log(-torch.log(torch.rand_like(logp) + 1e-7) + 1e-7)
-    return (logp + g).topk(k, dim=-1)[1]
+WORLD_OFFSET = 2000.0           # lidarFrame.py:18 (B1): added to the translation of every frame that arrives with a pose matrix
 
 
-def sample_rays(mask, num_samples):
-    B, H, W = mask.shape
-    probs = (mask / (mask.sum() + 1e-9)).reshape(B, -1)
-    idx = sampling_without_replacement(torch.log(probs + 1e-9), num_samples)
-    return (torch.zeros_like(probs).scatter_(-1, idx, 1).reshape(B, H, W) > 0)
+def scan_of(frame, device):
+    """The frame's returns resident on `device`, cached on the frame object: dict(points [M,3] f32, cos [M] f32, dirs, mask_u8 [M]).
+    `dirs` is None when the points are fp32 - the selection kernels then derive directions from the points (a1 on the device);
+    a frame that holds points in another dtype has its own `rays_d` uploaded (the reference divides in that dtype and rounds after)."""
+    dev = torch.device(device)
+    pts = frame.points
+    key = (pts.data_ptr(), pts._version, int(pts.shape[0]), dev)
+    sc = frame.__dict__.get("_nl_scan")
+    if sc is None or sc["key"] != key:
+        p = pts.detach().reshape(-1, 3)
+        dirs = None
+        if p.dtype != torch.float32:
+            own = frame.__dict__.get("rays_d")                   # (the reference's LidarFrame keeps the array it built in that dtype)
+            own = p / (torch.norm(p, 2, -1, keepdim=True) + 1e-8) if own is None else own
+            dirs = own.detach().reshape(-1, 3).to(dev, torch.float32).contiguous()
+        sc = dict(key=key, points=p.to(dev, torch.float32).contiguous(),
+                  cos=frame.pointsCos.detach().reshape(-1).to(dev, torch.float32).contiguous(), dirs=dirs,
+                  mask_u8=torch.zeros(int(pts.shape[0]), dtype=torch.uint8, device=dev))
+        frame.__dict__["_nl_scan"] = sc
+    return sc
 
 
 class LidarFrame(nn.Module):
@@ -30,16 +50,16 @@ class LidarFrame(nn.Module):
         self.num_point = len(points)
         self.points = points
         self.pointsCos = pointsCos
-        if (not new_keyframe) and (pose is not None):
-            pose = np.array(pose, dtype=np.float64, copy=True)
-            pose[:3, 3] += 2000
-            self.pose = OptimizablePose.from_matrix(torch.tensor(pose, dtype=torch.float32))
-        elif new_keyframe:
-            self.pose = pose
-        self.rays_d = self.get_rays()
+        if new_keyframe:
+            self.pose = pose                                     # a key-scan shares the pose module of the frame it was cut from
+        elif pose is not None:
+            T = np.array(pose, dtype=np.float64, copy=True)
+            T[:3, 3] += WORLD_OFFSET
+            self.pose = OptimizablePose.from_matrix(torch.tensor(T, dtype=torch.float32))
         self.rel_pose = None
         self.sample_mask = None
 
+    # ---- accessors of the reference surface
     def get_pose(self):
         return self.pose.matrix()
 
@@ -61,23 +81,43 @@ class LidarFrame(nn.Module):
     def get_rel_pose(self):
         return self.rel_pose
 
-    @torch.no_grad()
-    def get_rays(self):
-        self.rays_norm = torch.norm(self.points, 2, -1, keepdim=True) + 1e-8
-        return (self.points / self.rays_norm).unsqueeze(1).float()
+    # ---- a1 on the device
+    def device_scan(self, device="cuda"):
+        return scan_of(self, device)
 
     @torch.no_grad()
-    def device_scan(self, device):
-        """the frame's returns resident on `device` (cached): input of SdfEngine.select_rays (on-device ray selection)"""
-        sc = getattr(self, "_device_scan", None)
-        if sc is None or sc["dirs"].device != torch.device(device):
-            sc = dict(dirs=self.rays_d.reshape(-1, 3).float().contiguous().to(device),
-                      points=self.points.reshape(-1, 3).float().contiguous().to(device),
-                      cos=self.pointsCos.reshape(-1).float().contiguous().to(device),
-                      mask_u8=torch.zeros(self.num_point, dtype=torch.uint8, device=device))
-            self._device_scan = sc
-        return sc
+    def get_rays(self, device="cuda"):
+        """[M,1,3] unit directions, computed by nl_unit_dirs on the resident points (device tensor); sets `rays_norm` like the reference"""
+        from . import ops
+        sc = scan_of(self, device)
+        if "rays_d" not in sc:
+            M = sc["points"].shape[0]
+            d = torch.empty(M, 3, dtype=torch.float32, device=sc["points"].device)
+            n = torch.empty(M, dtype=torch.float32, device=sc["points"].device)
+            ops.unit_dirs(sc["points"], d, n)
+            sc["rays_d"], sc["rays_norm"] = d.view(M, 1, 3), n.view(M, 1)
+        return sc["rays_d"]
 
+    @property
+    def rays_d(self):
+        return self.get_rays()
+
+    @property
+    def rays_norm(self):
+        self.get_rays()
+        return self.__dict__["_nl_scan"]["rays_norm"]
+
+    # ---- a2, seeded host fallback (RAY_SELECTION = "host")
     @torch.no_grad()
     def sample_rays(self, N_rays, track=False):
-        self.sample_mask = sample_rays(torch.ones((self.num_point, 1))[None, ...], N_rays)[0, ...]
+        """Uniform N-subset by Gumbel top-k on torch's global CPU generator: the same draw, score arithmetic and top-k as
+        sample_util.py:4-19 applied to an all-ones mask, so a seeded run selects the rays the reference selects (tests/test_reference_surface.py).
+        Every return has the log-probability log(1/M + 1e-9); the Gumbel variate of a uniform u is -log(1e-7 - log(u + 1e-7))."""
+        M = self.num_point
+        ones = torch.ones(1, M)
+        logp = torch.log(ones / (ones.sum() + 1e-9) + 1e-9)
+        u = torch.rand_like(logp)
+        keep = (logp + -torch.log(1e-7 - torch.log(u + 1e-7))).topk(N_rays, dim=-1).indices
+        mask = torch.zeros(M, dtype=torch.bool)
+        mask[keep.reshape(-1)] = True
+        self.sample_mask = mask.view(M, 1)

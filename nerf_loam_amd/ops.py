@@ -203,6 +203,11 @@ def mfma_selftest(A32, B32, D32, A16, B16, D16):
     check(L.lib().nl_mfma_selftest(ptr(A32), ptr(B32), ptr(D32), ptr(A16), ptr(B16), ptr(D16), stream_ptr()), "nl_mfma_selftest")
 
 
+def unit_dirs(points, out_rays_d, out_rays_norm=None):
+    """LidarFrame.get_rays (lidarFrame.py:47-52) for a resident scan: points [M,3] -> rays_d [M,3] (+ rays_norm [M])"""
+    check(L.lib().nl_unit_dirs(int(points.shape[0]), ptr(points), ptr(out_rays_d), ptr(out_rays_norm), stream_ptr()), "nl_unit_dirs")
+
+
 def select_rays(M, n_select, seed, rays_d, points, cos_in, frame, out_rays_d, out_points, out_cos, out_frame_id, mask_out, workspace):
     check(L.lib().nl_select_rays(int(M), int(n_select), int(seed) & 0xFFFFFFFF, ptr(rays_d), ptr(points), ptr(cos_in), int(frame),
                                  ptr(out_rays_d), ptr(out_points), ptr(out_cos), ptr(out_frame_id), ptr(mask_out), ptr(workspace),
@@ -216,7 +221,7 @@ def select_rays_batch(Ms, ns, seeds, rays_d, points, cos_in, masks, out_off, out
     F = len(Ms)
     I, U, PP = ctypes.c_int * F, ctypes.c_uint * F, ctypes.c_void_p * F
     rc = L.lib().nl_select_rays_batch(F, I(*[int(m) for m in Ms]), I(*[int(n) for n in ns]), U(*[int(s) & 0xFFFFFFFF for s in seeds]),
-                                      PP(*[t.data_ptr() for t in rays_d]), PP(*[t.data_ptr() for t in points]),
+                                      PP(*[(t.data_ptr() if t is not None else None) for t in rays_d]), PP(*[t.data_ptr() for t in points]),
                                       PP(*[t.data_ptr() for t in cos_in]), PP(*[(t.data_ptr() if t is not None else None) for t in masks]),
                                       I(*[int(x) for x in out_off]), ptr(out_rays_d), ptr(out_points), ptr(out_cos), ptr(out_frame_id),
                                       ptr(workspace), int(parity), ptr(fail_word), stream_ptr())

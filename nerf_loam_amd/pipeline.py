@@ -302,30 +302,31 @@ class SdfEngine:
 
     def select_rays(self, scans, n_rays, seed, want_masks=False):
         """On-device ray selection (LidarFrame.sample_rays, lidarFrame.py:55-57): for every frame in `scans`
-        (dicts of DEVICE tensors dirs [M,3], points [M,3], cos [M]) a uniformly random subset of n_rays returns, dataset
+        (dicts of DEVICE tensors points [M,3], cos [M], dirs [M,3] or None = derived from the points in the kernel, lidarFrame.py:47-52)
+        a uniformly random subset of n_rays returns, dataset
         order kept, gathered straight into the engine's ray buffers - no host RNG, no top-k on the CPU, no H2D copy.
         Deterministic in (seed, M, n_rays).  Returns the boolean masks (device) when want_masks."""
         total = 0
         masks = []
         # every frame in the same two launches when the shapes allow it (n << M: the live configurations)
-        Ms = [int(sc["dirs"].shape[0]) for sc in scans]
+        Ms = [int(sc["points"].shape[0]) for sc in scans]
         ns = [min(int(n_rays), M) for M in Ms]
         if sum(ns) > self.N_cap:
             raise L.NerfLoamHipError(f"{sum(ns)} rays exceed engine capacity {self.N_cap}")
-        if len(scans) <= L.NL_SEL_MAX_FRAMES and all(sc["dirs"].is_contiguous() and sc["points"].is_contiguous() for sc in scans):
+        if len(scans) <= L.NL_SEL_MAX_FRAMES and all((sc.get("dirs") is None or sc["dirs"].is_contiguous()) and sc["points"].is_contiguous() for sc in scans):
             self._selb_frames(len(scans))
             mks = [sc.get("mask_u8") if sc.get("mask_u8") is not None else (torch.empty(M, dtype=torch.uint8, device=self.dev) if want_masks else None)
                    for sc, M in zip(scans, Ms)]
             offs = [sum(ns[:f]) for f in range(len(ns))]
             if ops.select_rays_batch(Ms, ns, [(int(seed) * 1000003 + f) & 0xFFFFFFFF for f in range(len(scans))],
-                                     [sc["dirs"] for sc in scans], [sc["points"] for sc in scans], [sc["cos"] for sc in scans], mks, offs,
+                                     [sc.get("dirs") for sc in scans], [sc["points"] for sc in scans], [sc["cos"] for sc in scans], mks, offs,
                                      self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self._selb_ws, self._selb_parity,
                                      self.adam_state[3:4]):
                 self._selb_parity ^= 1
                 self.N = sum(ns)
                 return mks if want_masks else None
         for f, sc in enumerate(scans):
-            M = int(sc["dirs"].shape[0])
+            M = int(sc["points"].shape[0])
             n = min(int(n_rays), M)
             if total + n > self.N_cap:
                 raise L.NerfLoamHipError(f"{total + n} rays exceed engine capacity {self.N_cap}")
@@ -335,7 +336,7 @@ class SdfEngine:
             mask = sc.get("mask_u8")                        # a caller-owned [M] uint8 buffer receives the boolean sample mask
             if mask is None and want_masks:
                 mask = torch.empty(M, dtype=torch.uint8, device=self.dev)
-            ops.select_rays(M, n, (int(seed) * 1000003 + f) & 0xFFFFFFFF, sc["dirs"], sc["points"], sc["cos"], f,
+            ops.select_rays(M, n, (int(seed) * 1000003 + f) & 0xFFFFFFFF, sc.get("dirs"), sc["points"], sc["cos"], f,
                             self.rays_d_sensor[total:], self.points_gt[total:], self.cos_gt[total:], self.frame_id[total:],
                             mask, self._sel_ws)
             masks.append(mask)
@@ -358,14 +359,15 @@ class SdfEngine:
         """marshal the frame list of a call ONCE (select_rays re-builds its argument arrays on every call); then reselect(seed) is
         one C call per iteration.  Returns False when the shapes need the per-frame radix path (use select_rays then)."""
         F = len(scans)
-        Ms = [int(sc["dirs"].shape[0]) for sc in scans]
+        Ms = [int(sc["points"].shape[0]) for sc in scans]
         ns = [min(int(n_rays), M) for M in Ms]
         if F > L.NL_SEL_MAX_FRAMES or sum(ns) > self.N_cap or any(sc.get("mask_u8") is None for sc in scans):
             return False
         self._selb_frames(F)
         I, U, PP = ctypes.c_int * F, ctypes.c_uint * F, ctypes.c_void_p * F
+        dptr = lambda sc: None if sc.get("dirs") is None else sc["dirs"].data_ptr()          # noqa: E731  (NULL: directions from the points)
         self._sel_prepared = dict(
-            F=F, M=I(*Ms), n=I(*ns), seed=U(*([0] * F)), d=PP(*[sc["dirs"].data_ptr() for sc in scans]),
+            F=F, M=I(*Ms), n=I(*ns), seed=U(*([0] * F)), d=PP(*[dptr(sc) for sc in scans]),
             p=PP(*[sc["points"].data_ptr() for sc in scans]), c=PP(*[sc["cos"].data_ptr() for sc in scans]),
             mk=PP(*[sc["mask_u8"].data_ptr() for sc in scans]), off=I(*[sum(ns[:f]) for f in range(F)]), total=sum(ns), keep=scans)
         return True
@@ -391,10 +393,12 @@ class SdfEngine:
         were 10 % of an iteration).  The same subsets as reselect(seed) iteration by iteration: same keys, same seeds.  use_predrawn(it)
         then points the iteration descriptor at iteration it's slice.  Returns False when the shapes need the per-frame radix path."""
         F, iters = len(scans), len(seeds)
-        Ms = [int(sc["dirs"].shape[0]) for sc in scans]
+        Ms = [int(sc["points"].shape[0]) for sc in scans]
         ns = [min(int(n_rays), M) for M in Ms]
         tot = sum(ns)
-        if tot > self.N_cap or F > L.NL_SEL_MAX_FRAMES or any(n >= M for n, M in zip(ns, Ms)) or not all(sc["dirs"].is_contiguous() for sc in scans):
+        dptr = lambda sc: None if sc.get("dirs") is None else sc["dirs"].data_ptr()          # noqa: E731  (NULL: directions from the points)
+        if tot > self.N_cap or F > L.NL_SEL_MAX_FRAMES or any(n >= M for n, M in zip(ns, Ms)) or \
+                not all(sc["points"].is_contiguous() and (sc.get("dirs") is None or sc["dirs"].is_contiguous()) for sc in scans):
             return False
         d = self.dev
         pre = getattr(self, "_pre", None)
@@ -407,7 +411,7 @@ class SdfEngine:
             self._pre = pre
         lib, sp = L.lib(), L.stream_ptr()
         per = L.NL_SEL_BATCH_WS_INTS_PER_FRAME
-        key = (iters, tuple(ns), tuple(sc["dirs"].data_ptr() for sc in scans), tuple(sc["points"].data_ptr() for sc in scans),
+        key = (iters, tuple(ns), tuple(dptr(sc) for sc in scans), tuple(sc["points"].data_ptr() for sc in scans),
                tuple(sc["cos"].data_ptr() for sc in scans))
         if pre.get("key") != key:
             # the marshalled argument arrays of every chunk of eight (iteration, frame) pairs: built once per configuration, only the
@@ -421,7 +425,7 @@ class SdfEngine:
                 n = len(chunk)
                 I, U, PP = ctypes.c_int * n, ctypes.c_uint * n, ctypes.c_void_p * n
                 chunks.append(dict(n=n, pairs=chunk, Ms=I(*[Ms[f] for _, f in chunk]), ns=I(*[ns[f] for _, f in chunk]), seeds=U(),
-                                   dirs=PP(*[scans[f]["dirs"].data_ptr() for _, f in chunk]), points=PP(*[scans[f]["points"].data_ptr() for _, f in chunk]),
+                                   dirs=PP(*[dptr(scans[f]) for _, f in chunk]), points=PP(*[scans[f]["points"].data_ptr() for _, f in chunk]),
                                    cos=PP(*[scans[f]["cos"].data_ptr() for _, f in chunk]), masks=PP(*[mbase[f] + it * Ms[f] for it, f in chunk]),
                                    out_off=I(*[it * tot + offs[f] for it, f in chunk]), fid=I(*[f for _, f in chunk]), ws=pre["ws"].data_ptr() + 4 * c0 * per))
             pre["chunks"], pre["key"] = chunks, key

@@ -21,6 +21,8 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from . import ops
+from .lidar_frame import scan_of
 from .pipeline import DecoderDevice, IterConfig, MapDevice, SdfEngine
 
 _ENGINES = OrderedDict()
@@ -86,8 +88,23 @@ def _map_device(map_states, voxel_size, device):
     return md
 
 
+def _param_list(sdf_network):
+    """the six parameter tensors of the shipped decoder configuration (W1 b1 W2 b2 W3 b3) of ANY module laid out like the reference's
+    variations/lidar.py:105-107 (`pts_linears[0..1]`, `sdf_out`): nerf_loam_amd.decoder.Decoder and the reference's own Decoder alike"""
+    if hasattr(sdf_network, "param_list"):
+        return sdf_network.param_list()
+    lin = list(getattr(sdf_network, "pts_linears", []))
+    out = getattr(sdf_network, "sdf_out", None)
+    shapes = [tuple(l.weight.shape) for l in lin] + ([tuple(out.weight.shape)] if out is not None else [])
+    if shapes != [(L.NL_W, L.NL_C), (L.NL_W, L.NL_W), (1, L.NL_W)] or getattr(sdf_network, "skips", []) not in ([], ()) or \
+            type(getattr(sdf_network, "pe", None)).__name__ not in ("NoneType", "Same"):
+        raise NotImplementedError("the MI355X decoder kernels implement the reference's shipped configuration only: depth 2, width 256, "
+                                  f"in_dim 16, skips [], embedder none (got layers {shapes})")
+    return [lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, out.weight, out.bias]
+
+
 def _decoder_version(sdf_network):
-    return tuple((p.data_ptr(), p._version) for p in sdf_network.param_list())
+    return tuple((p.data_ptr(), p._version) for p in _param_list(sdf_network))
 
 
 def _decoder_device(sdf_network, device):
@@ -100,9 +117,9 @@ def _decoder_device(sdf_network, device):
     ver = _decoder_version(sdf_network)
     if cached is not None and cached[0] == ver and cached[1].params.device == torch.device(device):
         return cached[1]
-    p = sdf_network.flat_params(device)
+    plist = _param_list(sdf_network)
+    p = torch.cat([q.detach().reshape(-1).float() for q in plist]).to(device).contiguous()
     dec = DecoderDevice.from_flat(p)
-    plist = sdf_network.param_list()
     if all(q.device == dec.params.device and q.dtype == torch.float32 for q in plist):
         with torch.no_grad():
             off = 0
@@ -116,7 +133,7 @@ def _decoder_device(sdf_network, device):
 
 def _decoder_aliased(sdf_network, dec):
     off, base = 0, dec.params.data_ptr()
-    for q in sdf_network.param_list():
+    for q in _param_list(sdf_network):
         if q.data_ptr() != base + 4 * off:
             return False
         off += q.numel()
@@ -126,7 +143,11 @@ def _decoder_aliased(sdf_network, dec):
 def _decoder_writeback(sdf_network, dec):
     if not _decoder_aliased(sdf_network, dec):               # (a module on another device / dtype: copy the block back)
         with torch.no_grad():
-            sdf_network.load_flat(dec.params)
+            off = 0
+            for q in _param_list(sdf_network):
+                n = q.numel()
+                q.copy_(dec.params[off:off + n].view_as(q))
+                off += n
     sdf_network._nl_device = (_decoder_version(sdf_network), dec)
 
 
@@ -141,38 +162,52 @@ def _fresh_noise():
     return True if SAMPLER_NOISE is None else bool(SAMPLER_NOISE[1])
 
 
-def _gather_rays(frames, N_rays, track=False):
+def _gather_rays(eng, frames, N_rays, track=False):
+    """host ray selection: every frame draws its boolean `sample_mask` the reference's way (frame.sample_rays, lidarFrame.py:55-57 - torch's
+    global CPU generator, or whatever a test patched in); the M-byte mask is all that is uploaded - points / cos are gathered from the
+    resident scan and the unit directions of the selected returns come from nl_unit_dirs (lidarFrame.py:47-52 on the device)."""
     d, p, c, f = [], [], [], []
     for i, fr in enumerate(frames):
         fr.sample_rays(N_rays, track=track) if track else fr.sample_rays(N_rays)
-        mask = fr.sample_mask.reshape(-1)
-        d.append(fr.rays_d.reshape(-1, 3)[mask]); p.append(fr.points.reshape(-1, 3)[mask]); c.append(fr.pointsCos.reshape(-1)[mask])
-        f.append(torch.full((int(mask.sum()),), i, dtype=torch.int32))
-    return torch.cat(d).float(), torch.cat(p).float(), torch.cat(c).float(), torch.cat(f)
+        sc = scan_of(fr, eng.dev)
+        idx = fr.sample_mask.reshape(-1).to(eng.dev).nonzero().squeeze(1)
+        pts = sc["points"][idx]
+        if sc["dirs"] is None:
+            dirs = torch.empty_like(pts)
+            ops.unit_dirs(pts, dirs)
+        else:
+            dirs = sc["dirs"][idx]
+        d.append(dirs); p.append(pts); c.append(sc["cos"][idx])
+        f.append(torch.full((idx.numel(),), i, dtype=torch.int32, device=eng.dev))
+    return torch.cat(d), torch.cat(p), torch.cat(c), torch.cat(f)
 
 
 def _ray_plan(eng, frames, N_rays, seeds, track=False):
-    """-> use(it): makes iteration `it` of the call run on its ray subset.  Device selection: the subsets of ALL iterations are drawn up front
-    (SdfEngine.predraw: two launches per eight (iteration, frame) pairs), an iteration then only points the descriptor at its slice; the
-    frames' boolean `sample_mask` (the reference's, lidarFrame.py:55-57) ends as a view of the last iteration's mask.  Shapes outside the
-    window method's range and host selection: one draw per iteration (_ray_drawer)."""
+    """-> (use(it), done()): use makes iteration `it` of the call run on its ray subset, done() leaves every frame's boolean `sample_mask`
+    (the reference's attribute, lidarFrame.py:55-57) = the LAST iteration's selection in a buffer the frame owns.  Frames are anything with
+    .points / .pointsCos (scan_of: resident once, directions derived in the selection kernel).  Device selection: the subsets of ALL
+    iterations are drawn up front (SdfEngine.predraw: two launches per eight (iteration, frame) pairs), an iteration then only points the
+    descriptor at its slice.  Shapes outside the window method's range and host selection: one draw per iteration (_ray_drawer)."""
     if RAY_SELECTION == "device":
-        scans = [fr.device_scan(eng.dev) for fr in frames]
+        scans = [scan_of(fr, eng.dev) for fr in frames]
         if eng.predraw(scans, N_rays, seeds):
-            for f, fr in enumerate(frames):
-                fr.sample_mask = eng._pre["masks"][f][len(seeds) - 1].view(torch.bool).view(-1, 1)
-            return eng.use_predrawn
+            def done():
+                # the predrawn masks live in an engine-wide buffer the next call overwrites: a frame keeps its own copy (M bytes, D2D)
+                for f, (fr, sc) in enumerate(zip(frames, scans)):
+                    sc["mask_u8"].copy_(eng._pre["masks"][f][len(seeds) - 1])
+                    fr.sample_mask = sc["mask_u8"].view(torch.bool).view(-1, 1)
+            return eng.use_predrawn, done
     draw = _ray_drawer(eng, frames, N_rays, track=track)
-    return lambda it: draw(seeds[it])
+    return (lambda it: draw(seeds[it])), (lambda: None)
 
 
 def _ray_drawer(eng, frames, N_rays, track=False):
     """-> draw(seed): puts the iteration's ray subset of every frame into the engine.  Device selection: the frame list is
     marshalled once per call, every draw is one C call (two launches for all frames); the frames' boolean `sample_mask`
-    attribute (the reference's, lidarFrame.py:55-57) is a view of the buffer the selection kernel writes."""
+    attribute (the reference's, lidarFrame.py:55-57) is a view of the frame-owned buffer the selection kernel writes."""
     if RAY_SELECTION != "device":
-        return lambda seed: eng.set_rays(*_gather_rays(frames, N_rays, track=track))
-    scans = [fr.device_scan(eng.dev) for fr in frames]
+        return lambda seed: eng.set_rays(*_gather_rays(eng, frames, N_rays, track=track))
+    scans = [scan_of(fr, eng.dev) for fr in frames]
     for fr, sc in zip(frames, scans):
         fr.sample_mask = sc["mask_u8"].view(torch.bool).view(-1, 1)
     if eng.prepare_selection(scans, N_rays):
@@ -214,7 +249,7 @@ def bundle_adjust_frames(keyframe_graph, embeddings, map_states, sdf_network, lo
     if profiler is not None:
         profiler.tok("mapping_add_optim")
     seed0 = _draw_seed()
-    use = _ray_plan(eng, keyframe_graph, N_rays, [seed0 + it for it in range(num_iterations)])
+    use, masks_done = _ray_plan(eng, keyframe_graph, N_rays, [seed0 + it for it in range(num_iterations)])
     # one C call per iteration (nl_iteration: ~15 launches); no host synchronisation inside the loop: an unusable iteration is
     # recognised and skipped by the optimiser kernel itself (skip_mode), fresh sampler jitter comes from the device step counter
     eng.bind(m, dec, cfg, train_decoder=update_decoder, want_emb_grad=True, want_pose_grad=any(optimise), update_emb=True,
@@ -222,6 +257,7 @@ def bundle_adjust_frames(keyframe_graph, embeddings, map_states, sdf_network, lo
     for it in range(num_iterations):
         use(it)
         eng.run_bound()
+    masks_done()
     _, _, p6 = _finish_call(eng, "Mapping")
     with torch.no_grad():
         if update_decoder:
@@ -246,12 +282,13 @@ def track_frame(frame_pose, curr_frame, map_states, sdf_network, loss_criteria, 
     eng.set_poses(init_pose.data.detach().cpu().numpy()[None], [1])
     eng.begin_call(m, None, emb_state=False)
     seed0 = _draw_seed()
-    use = _ray_plan(eng, [curr_frame], N_rays, [seed0 + it for it in range(num_iterations)], track=True)
+    use, masks_done = _ray_plan(eng, [curr_frame], N_rays, [seed0 + it for it in range(num_iterations)], track=True)
     eng.bind(m, dec, cfg, train_decoder=False, want_emb_grad=False, want_pose_grad=True, update_emb=False, update_decoder=False,
              update_pose=True, lr_pose=lr, skip_mode=2, fresh_noise=_fresh_noise())       # sticky skip = the reference's `break`
     for it in range(num_iterations):
         use(it)
         eng.run_bound()
+    masks_done()
     _, skipped, p6 = _finish_call(eng, "Tracking")
     hit_mask = None if skipped else (eng.hit_count[:eng.N] > 0)
     with torch.no_grad():

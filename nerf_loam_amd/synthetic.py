@@ -41,9 +41,17 @@ def scan_pose(tx=0.0, ty=0.0, tz=0.0, w=(0.0, 0.0, 0.0)):
 
 
 def unit_dirs(points):
-    """lidarFrame.py:47-52: rays_d = points / (||points|| + 1e-8)."""
-    nrm = np.sqrt((points.astype(np.float32) ** 2).sum(-1, keepdims=True, dtype=np.float32)) + np.float32(1e-8)
-    return (points / nrm).astype(np.float32)
+    """lidarFrame.py:47-52: rays_d = points / (||points|| + 1e-8), in the arithmetic of the reference's host torch ops: the norm kernel
+    accumulates the squares with fused multiply-adds (s = x x; s = fma(y, y, s); s = fma(z, z, s)), emulated here through fp64 (a
+    24 x 24-bit product is exact in fp64).  Host-side restatement of nl_unit_dir (csrc/nl_device_math.h) for the synthetic-data
+    generator and the oracle; pinned against torch and the device function in tests/test_device_math_host.py."""
+    p = np.asarray(points, np.float32)
+    q = p.astype(np.float64)
+    s = (p[..., 0] * p[..., 0]).astype(np.float32)
+    s = (q[..., 1] * q[..., 1] + s.astype(np.float64)).astype(np.float32)
+    s = (q[..., 2] * q[..., 2] + s.astype(np.float64)).astype(np.float32)
+    nrm = np.sqrt(s) + np.float32(1e-8)
+    return (p / nrm[..., None]).astype(np.float32)
 
 
 def voxel_coords(points, pose_R, pose_t, voxel_size):

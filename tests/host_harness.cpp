@@ -116,5 +116,9 @@ void hh_select_key(int n, uint32_t seed, uint32_t* out)
     for (int i = 0; i < n; ++i) out[i] = nl_select_key(seed, (uint32_t)i);
 }
 
+void hh_unit_dirs(int n, const float* p, float* d, float* norm)
+{
+    for (int i = 0; i < n; ++i) norm[i] = nl_unit_dir(p[3 * i], p[3 * i + 1], p[3 * i + 2], &d[3 * i], &d[3 * i + 1], &d[3 * i + 2]);
+}
 
 }  // extern "C"

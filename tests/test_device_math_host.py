@@ -314,6 +314,27 @@ def test_select_key_is_a_bijection_and_matches_the_numpy_restatement(hh):
     assert np.array_equal(out.astype(np.uint64), x)
 
 
+def test_unit_dir_is_the_reference_frames_host_arithmetic(hh):
+    """a1 (LidarFrame.get_rays, /root/reference/src/lidarFrame.py:47-52): nl_unit_dir - what nl_unit_dirs and the ray-selection kernels
+    evaluate on the device - against the reference's two torch lines run here, bit for bit: scan-like points, tiny / huge / axis-aligned
+    ones and the zero point (0 / 1e-8 = 0); and the generator-side restatement S.unit_dirs against both."""
+    import torch
+    from nerf_loam_amd import synthetic as S
+    rng = np.random.default_rng(5)
+    pts = np.concatenate([H.scene_points(64, 256, 3)[0], rng.normal(size=(200000, 3)).astype(np.float32) * 30,
+                          rng.normal(size=(2000, 3)).astype(np.float32) * 1e-12, rng.normal(size=(2000, 3)).astype(np.float32) * 1e12,
+                          np.eye(3, dtype=np.float32) * 7.5, np.zeros((1, 3), np.float32)]).astype(np.float32)
+    t = torch.from_numpy(pts)
+    ref_norm = torch.norm(t, 2, -1, keepdim=True) + 1e-8
+    ref_d = (t / ref_norm).float().numpy()
+    d, nrm = np.empty_like(pts), np.empty(len(pts), np.float32)
+    hh.hh_unit_dirs(len(pts), p(pts), p(d), p(nrm))
+    assert np.array_equal(d.view(np.uint32), ref_d.view(np.uint32))
+    assert np.array_equal(nrm.view(np.uint32), ref_norm.numpy()[:, 0].view(np.uint32))
+    assert np.array_equal(S.unit_dirs(pts).view(np.uint32), ref_d.view(np.uint32))
+    assert np.array_equal(d[-1], np.zeros(3, np.float32)) and np.all(np.abs(np.linalg.norm(d[:200000].astype(np.float64), axis=1) - 1) < 1e-6)
+
+
 def test_relu_mask_identities_behind_the_bf16_backward_gemms():
     """with dH2[i][j] = m(i,j) * dsdf_i * w3_j (m = 0/1 ReLU mask of H2),
         dH2 @ W2      == dsdf[:,None] * (m @ (w3[:,None] * W2))            (dgrad, gemm_mask_x)

@@ -50,7 +50,7 @@ def test_mapping_then_tracking_like_the_reference_loop():
 
     def rendered_loss():
         pose = f0.get_pose()
-        d = (f0.rays_d.reshape(-1, 3) @ pose[:3, :3].T).cuda()
+        d = f0.rays_d.reshape(-1, 3) @ pose[:3, :3].T.cuda()
         o = pose[:3, 3].reshape(1, 3).expand_as(d).cuda().contiguous()
         out = render_rays(o[None], d[None], mapper.map_states, mapper.decoder, mapper.step_size, 0.2, 0.3, 20, 50.0)
         z = out["z_vals"]; sdf = out["sdf"]; m = out["valid_mask"]
