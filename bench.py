@@ -83,6 +83,54 @@ def pmc_traffic(kernel):
         return None
 
 
+def pmc_traffic_in_run(kernel_prefix, timeout=240):
+    """HBM bytes per launch of the dominant kernel MEASURED IN THIS RUN: two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE - they do not fit one
+    pass, MI355X_MICROARCH.md "rocprofv3 PMC slots"; --kernel-trace + --pmc only) over a child `bench.py --pmc-child` (the same
+    workload, three iterations), counters of the full-scan launches averaged, (2 x FETCH_SIZE + WRITE_SIZE) KB with the guide's gfx950
+    FETCH_SIZE correction.  None when rocprofv3 is not on PATH, NL_BENCH_PMC=0, or a pass fails (the caller falls back to the committed
+    summary and says so)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or os.environ.get("NL_BENCH_PMC", "1") == "0":
+        return None
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="nl_pmc_", dir="/tmp")
+        try:
+            subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                            os.path.abspath(__file__), "--pmc-child"], cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, timeout=timeout,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            path = next((os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")), None)
+            got = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+                   if r["Counter_Name"] == counter and r["Kernel_Name"].replace("void ", "").startswith(kernel_prefix)]
+            top = max(got)
+            keep = [v for v in got if 2 * v >= top]                  # (the full-scan launches)
+            vals[counter] = sum(keep) / len(keep)
+        except Exception as e:                                       # noqa: BLE001
+            print(f"in-run PMC pass {counter} failed: {e!r}", file=sys.stderr)
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
+def committed_traffic_source():
+    import glob
+    import subprocess
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return "no PMC summary available"
+    rel = os.path.relpath(files[-1], ROOT)
+    try:
+        h = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", rel], capture_output=True, text=True, timeout=10).stdout.strip()
+    except Exception:                                                # noqa: BLE001
+        h = ""
+    return f"committed rocprofv3 PMC passes of this command ({rel}" + (f" @ {h}" if h else "") + "), NOT measured in this run"
+
+
 def build_workload(device, seed=777):
     from nerf_loam_amd import pipeline as P, synthetic as S
     from nerf_loam_amd.svo import Octree
@@ -107,16 +155,54 @@ def build_workload(device, seed=777):
     W3 = rng.uniform(-k2, k2, (1, 256)); b3 = rng.uniform(-k2, k2, 1)
     m = P.MapDevice(centres, structure, vertex_idx, id2row, emb_bits, 0.2, device=device)
     dec = P.DecoderDevice(W1, b1, W2, b2, W3, b3, device=device)
-    return dict(points=pts, cos=cos, dirs=S.unit_dirs(pts), pose=pose, map=m, dec=dec, n_nodes=len(centres), n_rows=E,
+    # unit directions (LidarFrame.get_rays, lidarFrame.py:47-52) by the device kernel from the resident points; the oracle-side
+    # restatement S.unit_dirs is what the CPU legs consume - parity_check holds the two against each other, bit for bit
+    from nerf_loam_amd import ops
+    pts_dev = torch.from_numpy(np.ascontiguousarray(pts)).to(device)
+    dirs_dev = torch.empty_like(pts_dev)
+    ops.unit_dirs(pts_dev, dirs_dev)
+    return dict(points=pts, cos=cos, dirs=dirs_dev.cpu().numpy(), dirs_host=S.unit_dirs(pts), pose=pose, map=m, dec=dec, n_nodes=len(centres), n_rows=E,
                 host=dict(centres=centres, structure=structure, vertex_idx=vertex_idx, id2row=id2row, emb_bits=emb_bits,
                           dec=(W1, b1, W2, b2, W3, b3)))
 
 
-def cpu_baseline(w, n_rays=32768, warm=2, reps=5, n_rays_1t=8192, reps_1t=3, seed=1):
-    """The SAME iteration on this box's host cores with the oracle port (oracle/oracle.py + nl_oracle.c: numpy / C, the GEMMs on
-    the torch-CPU BLAS threads) - kind "port": the reference checkout does not exist on the GPU box; the reference's own Python
-    path timed on CPU in the build container is recorded in BASELINE.md.  Bounded sample of the same 64x2048 scan (a strided
-    subset keeps the beam mix), full mapping iteration incl. Adam, `warm` untimed + `reps` timed, median; all cores and one."""
+REF_OFFBOX = ("the reference's own unmodified Python path (scripts/ref_cpu_baseline.py) needs its checkout, which a GPU box does not have: timed in the "
+              "build container on 8 cores it does 12.5-13.9 k rays/s (BASELINE.md section 5: 9.4 s per 131 072-ray iteration)")
+
+
+def reference_cpu_baseline(n_rays=8192, timeout=600):
+    """kind "reference": the reference's OWN bundle_adjust_frames -> render_rays -> Criterion -> backward -> Adam on this box's host cores
+    (scripts/ref_cpu_baseline.py in a child process - its harness patches torch's .cuda()), when a checkout is present
+    (NL_REFERENCE_ROOT or /root/reference) and oracle/_ref holds its octree build.  None otherwise."""
+    import subprocess
+    root = os.environ.get("NL_REFERENCE_ROOT", "/root/reference")
+    if not (os.path.isdir(os.path.join(root, "src")) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "svo_ref.so"))):
+        return None
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ref_cpu_baseline.py"), "--json", str(n_rays)], capture_output=True,
+                           text=True, timeout=timeout, env={**os.environ, "NL_REFERENCE_ROOT": root, "CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": ""})
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:                                       # noqa: BLE001 - report, fall back to the port
+        print(f"reference CPU baseline failed ({e!r}); falling back to the oracle port", file=sys.stderr)
+        return None
+    return dict(value=d["rays_per_s"], unit="rays/s", cores=d["threads"], kind="reference",
+                sample=f"{d['rays']} rays (every {max(1, 131072 // d['rays'])}th return of the same 64x2048 scan), the reference's unmodified bundle_adjust_frames "
+                       f"(render_rays + Criterion + autograd backward + torch.optim.Adam, {root}/src) on {d['threads']} torch-CPU threads of {os.cpu_count()} host "
+                       f"cores, 1 warm-up + {d['timed_iterations']} timed iterations, {d['ms_per_iter']:.0f} ms/iter; its two CUDA kernels replaced by their C "
+                       f"restatement (oracle/nl_oracle.c); {d['octree_nodes']} octree nodes, {d['embedding_rows']} embedding rows as the reference allocates them")
+
+
+def cpu_baseline(w, n_rays_probe=16384, n_rays_1t=8192, reps_1t=2, seed=1):
+    """The SAME iteration on this box's host cores.  With a reference checkout on the box: the reference's own Python path (kind
+    "reference").  Otherwise the oracle port (oracle/oracle.py + nl_oracle.c: numpy / C with closed-form gradients, the GEMMs and the
+    decoder's element-wise stages on the torch-CPU threads) - kind "port": a short probe picks the better of {all cores, 16 threads}, then ONE
+    timed mapping iteration incl. Adam over ALL 131 072 rays of the scan at that thread count (after one warm-up on the probe subset), and the
+    single-thread figure on a strided subset.  The two C stages (intersect, sampler: independent per ray) are 2 % of the port's iteration
+    (cProfile: 0.09 s of 4.8 s at 32 768 rays on 8 cores) - parallelising them would not move the number; what limits the port is numpy's
+    single-threaded element-wise passes over [P,256] arrays."""
+    ref = reference_cpu_baseline()
+    if ref is not None:
+        return ref
     from oracle import oracle as O
     h = w["host"]
     N = len(w["points"])
@@ -125,7 +211,7 @@ def cpu_baseline(w, n_rays=32768, warm=2, reps=5, n_rays_1t=8192, reps_1t=3, see
         ms = O.MapState(h["centres"], h["structure"], h["vertex_idx"], h["id2row"], h["emb_bits"].copy(), 0.2)
         dec = O.DecoderParams(*[np.asarray(a, np.float32) for a in h["dec"]])
         sel = np.arange(0, N, max(1, N // n))[:n]
-        fr = O.Frame(w["dirs"][sel], w["points"][sel], w["cos"][sel], w["pose"].copy())
+        fr = O.Frame(w["dirs_host"][sel], w["points"][sel], w["cos"][sel], w["pose"].copy())
         st = O.AdamState()
         cfg = O.IterCfg()
         ts = []
@@ -139,22 +225,21 @@ def cpu_baseline(w, n_rays=32768, warm=2, reps=5, n_rays_1t=8192, reps_1t=3, see
 
     cores = int(torch.get_num_threads())
     res = {}
-    for thr, (n, w_, r_) in ((cores, (n_rays, warm, reps)), (min(16, cores), (n_rays, 1, 3)), (1, (n_rays_1t, 1, reps_1t))):
-        if thr in res:
-            continue
-        torch.set_num_threads(thr)
-        try:
-            res[thr] = run(n, w_, r_) + (w_, r_)
-        finally:
-            torch.set_num_threads(cores)
-    best = max((t for t in res if t != 1), key=lambda t: res[t][0] / res[t][1])
-    n_b, t_b, w_b, r_b = res[best]
-    n_1, t_1 = res[1][:2]
-    every = max(1, N // n_rays)
+    try:
+        for thr in dict.fromkeys((cores, min(16, cores))):               # probe: which thread count serves the port best on this box
+            torch.set_num_threads(thr)
+            res[thr] = run(n_rays_probe, 1, 1) + (1, 1)
+        best = max(res, key=lambda t: res[t][0] / res[t][1])
+        torch.set_num_threads(best)
+        n_b, t_b = run(N, 0, 1)                                           # the whole scan, one timed iteration (the probe was its warm-up)
+        torch.set_num_threads(1)
+        n_1, t_1 = run(n_rays_1t, 1, reps_1t)
+    finally:
+        torch.set_num_threads(cores)
     return dict(value=n_b / t_b, unit="rays/s", cores=best, kind="port",
-                sample=f"{n_b} rays (every {every}th return of the same 64x2048 scan), 1 mapping iteration incl. Adam, "
-                       f"{w_b} warm-up + {r_b} timed, median {t_b * 1e3:.0f} ms/iter; numpy/C oracle port, GEMMs on {best} torch-CPU threads "
-                       f"of {os.cpu_count()} host cores (the numpy / C stages are single-threaded)",
+                sample=f"all {n_b} rays of the same 64x2048 scan, 1 mapping iteration incl. Adam, 1 timed iteration after a warm-up on {n_rays_probe} rays: "
+                       f"{t_b * 1e3:.0f} ms/iter; numpy/C oracle port, GEMMs + decoder element-wise stages on {best} torch-CPU threads of {os.cpu_count()} host cores "
+                       f"(the other numpy stages are single-threaded).  NOT the reference's own code: " + REF_OFFBOX,
                 by_threads={str(t): dict(value=res[t][0] / res[t][1], rays=res[t][0], ms_per_iter=res[t][1] * 1e3, warmup=res[t][2], timed=res[t][3])
                             for t in res},
                 single_thread=dict(value=n_1 / t_1, unit="rays/s", cores=1,
@@ -187,7 +272,7 @@ def parity_check(eng, w, cfg, train_dec, every=8):
     t0 = time.perf_counter()
     ms = O.MapState(h["centres"], h["structure"], h["vertex_idx"], h["id2row"], emb_bits, 0.2)
     dp = O.DecoderParams(dn["W1"], dn["b1"], dn["W2"], dn["b2"], dn["W3"], dn["b3"])
-    fr = O.Frame(w["dirs"], w["points"], w["cos"], pose)
+    fr = O.Frame(w["dirs_host"], w["points"], w["cos"], pose)      # the oracle's own directions (host restatement of lidarFrame.py:47-52)
     sub = np.zeros(N, bool); sub[::every] = True
     out = O.render_and_grad(ms, dp, [fr], O.IterCfg(step_size=cfg.step_size, noise_seed=cfg.noise_seed), want_emb_grad=False,
                             want_dec_grad=False, eval_rays=sub)
@@ -203,7 +288,8 @@ def parity_check(eng, w, cfg, train_dec, every=8):
     samples_equal = bool(P_ == out["n_samples"] and st["S"] == out["valid"].shape[1]
                          and np.array_equal(got["samp_count"][hr], out["valid"].sum(1))
                          and np.array_equal(got["depth"], out["z_vals"][rr, ss]) and np.array_equal(got["vox"], out["s_idx"][rr, ss]))
-    res = dict(rays=int(N), hits_equal=hits_equal, samples_equal=samples_equal, valid_samples=int(P_), subset_rays=int(sub.sum()))
+    dirs_equal = bool(np.array_equal(w["dirs"].view(np.uint32), w["dirs_host"].view(np.uint32)))      # nl_unit_dirs == lidarFrame.py:47-52 on the host
+    res = dict(rays=int(N), unit_dirs_equal=dirs_equal, hits_equal=hits_equal, samples_equal=samples_equal, valid_samples=int(P_), subset_rays=int(sub.sum()))
     if samples_equal:
         idx = got["samp_off"][out["sample_ray"]] + out["sample_slot"]            # engine sample index of the subset's samples
         ref_sdf = out["sdf"][np.searchsorted(hr, out["sample_ray"]), out["sample_slot"]]
@@ -214,10 +300,10 @@ def parity_check(eng, w, cfg, train_dec, every=8):
                    X_max_abs_err=float(np.abs(got["X"][idx] - out["feats"]).max()),
                    dsdf_max_err_rel_to_max=float(np.abs(got["dsdf"][idx] - ref_ds).max() / max(np.abs(ref_ds).max(), 1e-30)),
                    dX_rel_l2=float(np.linalg.norm(dxe - dxr) / max(np.linalg.norm(dxr), 1e-30)))
-        res["ok"] = bool(hits_equal and res["sdf_max_abs_err"] < 1e-4 and res["dsdf_max_err_rel_to_max"] < 1e-3 and res["dX_rel_l2"] < 1e-3)
+        res["ok"] = bool(dirs_equal and hits_equal and res["sdf_max_abs_err"] < 1e-4 and res["dsdf_max_err_rel_to_max"] < 1e-3 and res["dX_rel_l2"] < 1e-3)
     else:
         res["ok"] = False
-    res["bars"] = {"hits/samples": "bit-exact", "sdf_max_abs_err": 1e-4, "dsdf_max_err_rel_to_max": 1e-3, "dX_rel_l2": 1e-3}
+    res["bars"] = {"unit_dirs/hits/samples": "bit-exact", "sdf_max_abs_err": 1e-4, "dsdf_max_err_rel_to_max": 1e-3, "dX_rel_l2": 1e-3}
     res["oracle_seconds"] = round(time.perf_counter() - t0, 2)
     return res
 
@@ -514,7 +600,7 @@ def pose_refine_bench(w, device, steps=200):
     out["ms_per_step_one_c_call"] = (time.perf_counter() - t0) / steps * 1e3
     # the reference's track_frame re-draws its 2048 rays every iteration (LidarFrame.sample_rays on the CPU + H2D copy):
     # same step with the rays re-drawn on the device from the resident scan (nl_select_rays)
-    scan = dict(dirs=torch.from_numpy(np.ascontiguousarray(w["dirs"])).to(device), points=torch.from_numpy(np.ascontiguousarray(w["points"])).to(device),
+    scan = dict(dirs=None, points=torch.from_numpy(np.ascontiguousarray(w["points"])).to(device),      # dirs None: derived from the points in the selection kernel
                 cos=torch.from_numpy(np.ascontiguousarray(w["cos"])).to(device))
     def one_sel(k):
         eng.select_rays([scan], 2048, k)
@@ -540,9 +626,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle parity check")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 PMC passes behind roofline.traffic (the committed summary is quoted instead)")
     ap.add_argument("--no-api-path", action="store_true", help="skip the bundle_adjust_frames / track_frame timings")
     ap.add_argument("--no-large-map", action="store_true", help="skip the 150-scan / 1e6-row map leg")
     ap.add_argument("--frozen-decoder", action="store_true", help="mapping with update_decoder=False (after freeze_frame)")
+    ap.add_argument("--pmc-child", action="store_true", help="(internal) the child run rocprofv3 profiles for roofline.traffic: three iterations, no output")
     ap.add_argument("--rccl-world1", action="store_true", help="run the ray-sharded code path (RCCL communicator, exchanges inside nl_iteration) "
                                                                 "on ONE GPU with a world-size-1 process group: what a 1-GPU box can check of --gpus N")
     args = ap.parse_args()
@@ -610,6 +698,11 @@ def main():
             tdist.barrier()
         torch.cuda.synchronize()
 
+    if args.pmc_child:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        return
     for _ in range(args.warmup):
         step()
     barrier()
@@ -671,9 +764,14 @@ def main():
         gm, wm = _lib.lib().nl_decoder_get_gemm_mode(), _lib.lib().nl_decoder_get_wgrad2_mode()
         kname = "k_decoder" + ("<train>" if train_dec else "<frozen>")
         rf = roofline_entry(kname, "decoder", dec_ms, P_local, gm, wm, train_dec)
+        kfull = ("k_decoder<true, %s" if train_dec else "k_decoder<false, %s") % ("true" if gm >= 1 else "false")
+        # (quick runs - --no-cpu-baseline - and runs that are themselves under a profiler skip the two nested rocprofv3 passes)
+        under_profiler = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY"))
+        traffic = pmc_traffic_in_run(kfull) if not (shard or args.no_pmc or args.no_cpu_baseline or under_profiler) else None
         rf = {"bound": "mfma", **rf,
-              "traffic": pmc_traffic(("k_decoder<true, %s>" if train_dec else "k_decoder<false, %s>") % ("true" if gm >= 1 else "false")),
-              "traffic_source": "committed rocprofv3 PMC passes of this command (newest profiles/r*_pmc_summary.json), not measured in this run",
+              "traffic": traffic if traffic is not None else pmc_traffic(kfull + ">"),
+              "traffic_source": ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes over a 3-iteration child of this command), "
+                                 "(2 x FETCH_SIZE + WRITE_SIZE) KB per launch" if traffic is not None else committed_traffic_source()),
               "peak_note": ("matrix-pipe bound of the kernel's instruction mix: "
                             + (f"256-deep GEMMs as bf16 three-term splits ({ {1: 9, 3: 8, 2: 6}.get(gm, 9)} of 9 forward + 3 dgrad MFMAs per fp32 product, 2500 TF pipe), "
                                "layer-1 forward as nine bf16 products too, dX / dW1 (K=16) on the fp32 pipe (157.3 TF)" if gm >= 1 else "all GEMMs on the fp32 pipe (157.3 TF)")),

@@ -8,6 +8,8 @@ The number goes into BASELINE.md next to the oracle-port number bench.py measure
 reference checkout, so bench.py's cpu_baseline is kind "port").
 
     python scripts/ref_cpu_baseline.py [n_rays ...]      (default 8192 32768)
+    python scripts/ref_cpu_baseline.py --json N          (bench.py's cpu_baseline leg when a reference checkout exists: ONE line of JSON
+                                                          for N rays on all torch threads; NL_REFERENCE_ROOT overrides /root/reference)
 """
 import os
 import sys
@@ -26,7 +28,22 @@ G.RH.render_rays = G._orig_render
 
 
 def main():
-    sizes = [int(a) for a in sys.argv[1:]] or [8192, 32768]
+    as_json = "--json" in sys.argv
+    if as_json:
+        sys.argv.remove("--json")
+        import contextlib
+        import io
+        import json
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            res = measure([int(a) for a in sys.argv[1:]] or [8192], threads_list=(torch.get_num_threads(),))
+        print(json.dumps(res[0]))
+        return
+    measure([int(a) for a in sys.argv[1:]] or [8192, 32768])
+
+
+def measure(sizes, threads_list=None):
+    results = []
     sc = G.build_scene(64, 2048, 777)
     M = len(sc["points"])
     print(f"scan {M} returns, {sc['centres'].shape[0]} octree nodes, {sc['emb'].shape[0]} embedding rows, "
@@ -39,7 +56,7 @@ def main():
             m[sel] = True
             self.sample_mask = torch.from_numpy(m)
         G.LidarFrame.sample_rays = sample_rays
-        for threads in (torch.get_num_threads(), 1):
+        for threads in (threads_list or (torch.get_num_threads(), 1)):
             torch.set_num_threads(threads)
             fr = G.make_frame(1, sc["points"], sc["cos"], G.pose4())
             dec = G.make_decoder(777)
@@ -55,7 +72,10 @@ def main():
             run(reps)
             dt = (time.perf_counter() - t0) / reps
             print(f"reference python path, {len(sel)} rays, {threads} thread(s): {dt * 1e3:.0f} ms/iter = {len(sel) / dt:.0f} rays/s")
+            results.append(dict(rays=int(len(sel)), threads=int(threads), ms_per_iter=dt * 1e3, rays_per_s=len(sel) / dt, timed_iterations=reps,
+                                octree_nodes=int(sc["centres"].shape[0]), embedding_rows=int(sc["emb"].shape[0])))
         torch.set_num_threads(os.cpu_count())
+    return results
 
 
 if __name__ == "__main__":

@@ -80,16 +80,49 @@ def _run(P, sc, masks, emb_bits, dec_np, pose0, sparse, one_call, grow_after_cal
     return out
 
 
+def _atomics_noise_only(a, b):
+    """two runs of the SAME engine configuration can differ by the order in which waves' fp32 atomics reach an accumulator row
+    (k_trilinear_bwd: one global atomic per touched row and wave): the sum changes in its last bit, the bf16 rounding of the gradient flips
+    for one element in ~10^5, and Adam turns that into one bf16 ulp of the parameter (scripts/sparse_adam_diag.py: the first run of a
+    process against its repeats - 1 embedding element, 4 / 6 moment elements, the decoder 8e-7 downstream).  True when `a` and `b` differ
+    by no more than that."""
+    for call in (0, 1):
+        for k in ("emb", "m", "v"):
+            x, y = a[call][k].view(np.uint16), b[call][k].view(np.uint16)
+            bad = x != y
+            if bad.sum() > 1e-3 * x.size:
+                return False
+            xf, yf = O.bf16_to_f32(x[bad]), O.bf16_to_f32(y[bad])
+            if bad.any() and not (np.abs(xf - yf) <= 4 * 2.0 ** (np.floor(np.log2(np.maximum(np.abs(xf), 1e-30))) - 7) + 1e-30).all():
+                return False
+        if np.abs(a[call]["dec"] - b[call]["dec"]).max() > 1e-4 or np.abs(a[call]["pose"] - b[call]["pose"]).max() > 1e-5:
+            return False
+    return True
+
+
+def _identical(a, b):
+    return all(np.array_equal(a[call][k], b[call][k]) for call in (0, 1) for k in ("emb", "m", "v", "g", "dec", "pose"))
+
+
 @pytest.mark.parametrize("one_call", [False, True])
 @pytest.mark.parametrize("pad_rows,grow", [(0, 0), (300000, 0), (50000, 20000)])
 def test_touched_rows_adam_equals_the_dense_sweep(golden_dir, one_call, pad_rows, grow):
+    """every piece of optimiser state after two calls, touched-rows engine against dense engine: BIT-identical.  The comparison is between two
+    separate runs, so the order of the scatter's fp32 atomics must coincide as well - it does from the second run of a process on (the first
+    one loads its kernels on the way: other timing, occasionally another order); a pair that differs must differ by atomics noise only
+    (_atomics_noise_only), and one of three attempts must match bit for bit - a bookkeeping error would fail every attempt."""
     g, sc, masks, emb, dec_np, P = _scene(golden_dir, pad_rows)
     pose0 = g["poses0"][0].copy()
-    dense = _run(P, sc, masks, emb, dec_np, pose0, sparse=False, one_call=one_call, grow_after_call=grow)
-    sparse = _run(P, sc, masks, emb, dec_np, pose0, sparse=True, one_call=one_call, grow_after_call=grow)
+    for attempt in range(3):
+        dense = _run(P, sc, masks, emb, dec_np, pose0, sparse=False, one_call=one_call, grow_after_call=grow)
+        sparse = _run(P, sc, masks, emb, dec_np, pose0, sparse=True, one_call=one_call, grow_after_call=grow)
+        if _identical(dense, sparse):
+            break
+        assert _atomics_noise_only(dense, sparse), "dense and touched-rows engines differ by more than the order of fp32 atomics explains"
+    else:
+        pytest.fail("no bit-identical pair in three attempts")
+    H.record_gpu_metric(f"sparse_adam_{pad_rows}_{grow}_{int(one_call)}", attempts=attempt + 1)
     for call in (0, 1):
-        for k in ("emb", "m", "v", "g", "dec", "pose"):
-            assert np.array_equal(dense[call][k], sparse[call][k]), (call, k)
         assert not sparse[call]["g"].any()                                  # the optimiser leaves the accumulators cleared
         moved = int((sparse[call]["m"] != 0).any(1).sum())
         assert 0 < moved <= sparse[call]["touched"] < 40000                 # a few 10^4 rows of the (up to 3.5 x 10^5-row) table
