@@ -131,14 +131,14 @@ def committed_traffic_source():
     return f"committed rocprofv3 PMC passes of this command ({rel}" + (f" @ {h}" if h else "") + "), NOT measured in this run"
 
 
-def build_workload(device, seed=777):
+def build_workload(device, seed=777, voxel=0.2):
     from nerf_loam_amd import pipeline as P, synthetic as S
     from nerf_loam_amd.svo import Octree
     pts, cos = S.synthetic_scan(64, 2048, seed)
     pose = S.scan_pose()
     oc = Octree()
-    oc.init(256 * 256 * 4, 16, 0.2)
-    oc.insert(S.voxel_coords(pts, np.eye(3, dtype=np.float32), pose[:3], 0.2))
+    oc.init(256 * 256 * 4, 16, voxel)
+    oc.insert(S.voxel_coords(pts, np.eye(3, dtype=np.float32), pose[:3], voxel))
     centres, structure, vertex_idx = oc.export_device_layout()
     # embedding rows: one per vertex, like nerf_loam_amd.mapping.Mapping.get_embeddings (the reference allocates one per
     # OCCURRENCE, mapping.py:293-317: ~3x the rows, the duplicates are never read - SURVEY B7)
@@ -153,7 +153,7 @@ def build_workload(device, seed=777):
     W1 = rng.uniform(-k1, k1, (256, 16)); b1 = rng.uniform(-k1, k1, 256)
     W2 = rng.uniform(-k2, k2, (256, 256)); b2 = rng.uniform(-k2, k2, 256)
     W3 = rng.uniform(-k2, k2, (1, 256)); b3 = rng.uniform(-k2, k2, 1)
-    m = P.MapDevice(centres, structure, vertex_idx, id2row, emb_bits, 0.2, device=device)
+    m = P.MapDevice(centres, structure, vertex_idx, id2row, emb_bits, voxel, device=device)
     dec = P.DecoderDevice(W1, b1, W2, b2, W3, b3, device=device)
     # unit directions (LidarFrame.get_rays, lidarFrame.py:47-52) by the device kernel from the resident points; the oracle-side
     # restatement S.unit_dirs is what the CPU legs consume - parity_check holds the two against each other, bit for bit
@@ -161,7 +161,7 @@ def build_workload(device, seed=777):
     pts_dev = torch.from_numpy(np.ascontiguousarray(pts)).to(device)
     dirs_dev = torch.empty_like(pts_dev)
     ops.unit_dirs(pts_dev, dirs_dev)
-    return dict(points=pts, cos=cos, dirs=dirs_dev.cpu().numpy(), dirs_host=S.unit_dirs(pts), pose=pose, map=m, dec=dec, n_nodes=len(centres), n_rows=E,
+    return dict(points=pts, cos=cos, dirs=dirs_dev.cpu().numpy(), dirs_host=S.unit_dirs(pts), pose=pose, map=m, dec=dec, n_nodes=len(centres), n_rows=E, voxel=voxel,
                 host=dict(centres=centres, structure=structure, vertex_idx=vertex_idx, id2row=id2row, emb_bits=emb_bits,
                           dec=(W1, b1, W2, b2, W3, b3)))
 
@@ -270,7 +270,7 @@ def parity_check(eng, w, cfg, train_dec, every=8):
         eng.g_emb.zero_()
     eng.g_pose.zero_()
     t0 = time.perf_counter()
-    ms = O.MapState(h["centres"], h["structure"], h["vertex_idx"], h["id2row"], emb_bits, 0.2)
+    ms = O.MapState(h["centres"], h["structure"], h["vertex_idx"], h["id2row"], emb_bits, w.get("voxel", 0.2))
     dp = O.DecoderParams(dn["W1"], dn["b1"], dn["W2"], dn["b2"], dn["W3"], dn["b3"])
     fr = O.Frame(w["dirs_host"], w["points"], w["cos"], pose)      # the oracle's own directions (host restatement of lidarFrame.py:47-52)
     sub = np.zeros(N, bool); sub[::every] = True
@@ -552,6 +552,44 @@ def large_map_bench(w, device, n_scans=150, spacing=3.0, iters=20):
     return out
 
 
+# the reference's other shipped settings (configs/kitti/kitti.yaml: voxel 0.3, mapper step 0.5 x 0.3; configs/ncd/ncd.yaml: voxel 0.2, mapper
+# step 0.2 x 0.2 = 0.04 m: up to ~60 samples per ray) on the same 64 x 2048 scan
+SETTINGS = {"kitti": dict(voxel=0.3, step=0.15, lrs=(0.01, 0.005, 0.001)), "ncd": dict(voxel=0.2, step=0.04, lrs=(0.002, 0.005, 0.001))}
+
+
+def settings_bench(device, iters=6, with_parity=True):
+    """one full-scan mapping iteration under the kitti and ncd settings: ms per iteration (one C call per iteration), samples per ray, and the
+    in-run oracle check of parity_check on that configuration - so that a regression at 58 samples per ray shows in the bench line"""
+    from nerf_loam_amd import pipeline as P
+    out = {}
+    for name, sp in SETTINGS.items():
+        w = build_workload(device, voxel=sp["voxel"])
+        N = len(w["points"])
+        eng = P.SdfEngine(max_rays=N, samples_per_ray_cap=64, device=device)
+        eng.set_rays(w["dirs"], w["points"], w["cos"]); eng.set_poses(w["pose"][None], [1])
+        cfg = P.IterConfig(voxel_size=sp["voxel"], step_size=sp["step"], lr_emb=sp["lrs"][0], lr_dec=sp["lrs"][1], lr_pose=sp["lrs"][2])
+        eng.begin_call(w["map"], w["dec"])
+        eng.bind(w["map"], w["dec"], cfg, train_decoder=True)
+        for _ in range(2):
+            eng.run_bound()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(iters):
+            eng.run_bound()
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / iters
+        st = eng.stats()
+        if st["overflow"] or st["guard"] or eng.call_status()[2]:
+            raise SystemExit(f"bench invalid ({name} settings): overflow={st['overflow']} guard={st['guard']}")
+        r = dict(voxel_size_m=sp["voxel"], step_size_m=sp["step"], octree_nodes=w["n_nodes"], embedding_rows=w["n_rows"], ms_per_iter=dt * 1e3,
+                 rays_per_s=N / dt, valid_samples=int(st["P"]), samples_per_hit_ray=float(st["P"]) / max(st["R"], 1), max_samples_per_ray=int(st["S"]),
+                 max_hits_per_ray=int(st["H"]))
+        if with_parity:
+            r["parity"] = parity_check(eng, w, cfg, True, every=16)
+        out[name] = r
+        del eng, w
+        torch.cuda.empty_cache()
+    return out
+
+
 def pose_refine_bench(w, device, steps=200):
     """M2: ms per pose-refine step (track_frame iteration, render_helpers.py:452-512): 2048 rays, step 0.2*voxel,
     decoder + embeddings frozen, 6-dof pose Adam; rays resident, the launch sequence replayed as a hipGraph."""
@@ -629,6 +667,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 PMC passes behind roofline.traffic (the committed summary is quoted instead)")
     ap.add_argument("--no-api-path", action="store_true", help="skip the bundle_adjust_frames / track_frame timings")
     ap.add_argument("--no-large-map", action="store_true", help="skip the 150-scan / 1e6-row map leg")
+    ap.add_argument("--no-settings", action="store_true", help="skip the kitti / ncd settings legs")
     ap.add_argument("--frozen-decoder", action="store_true", help="mapping with update_decoder=False (after freeze_frame)")
     ap.add_argument("--pmc-child", action="store_true", help="(internal) the child run rocprofv3 profiles for roofline.traffic: three iterations, no output")
     ap.add_argument("--rccl-world1", action="store_true", help="run the ray-sharded code path (RCCL communicator, exchanges inside nl_iteration) "
@@ -813,6 +852,8 @@ def main():
                 out["large_map"] = large_map_bench(w, device)
             if not args.no_parity:
                 out["parity"] = parity_check(eng, w, cfg, train_dec)
+            if not (args.no_settings or args.no_large_map):      # (--no-large-map: the headline map only - the profiling scripts pass it)
+                out["settings"] = settings_bench(device, with_parity=not args.no_parity)
         if not args.no_cpu_baseline and not shard:
             out["cpu_baseline"] = cpu_baseline(w)
         sys.stdout.flush()

@@ -45,7 +45,7 @@ int nl_decoder_grid_hint(void);         /* persistent-kernel grid = compute unit
 
 /* grid.svo_intersect(ray_start[B,m,3], ray_dir[B,m,3], points[B,n,3], children[B,n,9], voxelsize, n_max)
  *   -> idx i32[B,m,n_max] (-1 padded), min_depth/max_depth f32[B,m,n_max] (0 where unused)
- * third_party/sparse_voxels/src/intersect.cpp:83-112, intersect_gpu.cu:193-272.  n_max <= 20. */
+ * third_party/sparse_voxels/src/intersect.cpp:83-112, intersect_gpu.cu:193-272.  Any n_max >= 1 (the reference's caller passes 20). */
 int nl_svo_intersect(const float* ray_start, const float* ray_dir, const float* points, const int* children,
                      int b, int m, int n, float voxelsize, int n_max,
                      int* idx, float* min_depth, float* max_depth, void* stream);

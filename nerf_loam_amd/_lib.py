@@ -5,7 +5,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnerfloam_hip.so")
+# NL_LIB_PATH: another build of the same library (same-box A/B builds in ab_libs/, the AddressSanitizer build of scripts/asan_build.py)
+LIB_PATH = os.environ.get("NL_LIB_PATH") or os.path.join(_HERE, "libnerfloam_hip.so")
 
 NL_MAX_HITS = 20
 NL_CNT_INTS = 16

@@ -29,6 +29,7 @@ struct LdsStack {
 // [B,m,3] rays, [B,n,3]/[B,n,9] octree per batch row, [B,m,n_max] outputs (idx -1 padded, depths
 // zero where unused like intersect.cpp:98-106).
 // ---------------------------------------------------------------------------------------------
+template <bool DIRECT>                                  // DIRECT: n_max beyond the 20 register slots - the walk records straight into the ray's output row
 __global__ __launch_bounds__(NL_GEO_THREADS) void k_svo_intersect_raw(
     int b, int n, int m, float voxelsize, int n_max,
     const float* __restrict__ ray_start, const float* __restrict__ ray_dir,
@@ -43,16 +44,20 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_svo_intersect_raw(
     const int* ch = children + (size_t)bi * n * 9;
     const float* o = ray_start + gid * 3;
     const float* d = ray_dir + gid * 3;
-    int hi[NL_MAX_HITS]; float h0[NL_MAX_HITS], h1[NL_MAX_HITS];
     LdsStack stk{&s_stack[threadIdx.x]};
-    const int nm = n_max < NL_MAX_HITS ? n_max : NL_MAX_HITS;
-    const int cnt = nl_octree_walk(pts, ch, o[0], o[1], o[2], d[0], d[1], d[2], voxelsize * 0.5f, nm, stk, hi, h0, h1);
     int* oi = idx + gid * n_max; float* o0 = min_depth + gid * n_max; float* o1 = max_depth + gid * n_max;
-    for (int l = 0; l < n_max; ++l) {
-        const bool v = l < cnt;
-        oi[l] = v ? hi[l] : -1;
-        o0[l] = v ? h0[l] : 0.0f;
-        o1[l] = v ? h1[l] : 0.0f;
+    if (DIRECT) {
+        const int cnt = nl_octree_walk(pts, ch, o[0], o[1], o[2], d[0], d[1], d[2], voxelsize * 0.5f, n_max, stk, oi, o0, o1);
+        for (int l = cnt; l < n_max; ++l) { oi[l] = -1; o0[l] = 0.0f; o1[l] = 0.0f; }
+    } else {
+        int hi[NL_MAX_HITS]; float h0[NL_MAX_HITS], h1[NL_MAX_HITS];
+        const int cnt = nl_octree_walk(pts, ch, o[0], o[1], o[2], d[0], d[1], d[2], voxelsize * 0.5f, n_max, stk, hi, h0, h1);
+        for (int l = 0; l < n_max; ++l) {
+            const bool v = l < cnt;
+            oi[l] = v ? hi[l] : -1;
+            o0[l] = v ? h0[l] : 0.0f;
+            o1[l] = v ? h1[l] : 0.0f;
+        }
     }
 }
 
@@ -1497,10 +1502,16 @@ int nl_svo_intersect(const float* ray_start, const float* ray_dir, const float* 
                      int* idx, float* min_depth, float* max_depth, void* stream)
 {
     if (!ray_start || !ray_dir || !points || !children || !idx || !min_depth || !max_depth) return NL_ERR_INVALID_ARG;
-    if (b <= 0 || m <= 0 || n <= 0 || n_max <= 0 || n_max > NL_MAX_HITS) return NL_ERR_INVALID_ARG;
+    if (b <= 0 || m <= 0 || n <= 0 || n_max <= 0) return NL_ERR_INVALID_ARG;
     const long long total = (long long)b * m;
-    hipLaunchKernelGGL(k_svo_intersect_raw, dim3(nl_div_up(total, NL_GEO_THREADS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream,
-                       b, n, m, voxelsize, n_max, ray_start, ray_dir, points, children, idx, min_depth, max_depth);
+    // any n_max, like the reference (intersect.cpp:83-112; its only caller passes 20, voxel_helpers.py:533): up to 20 the hits are kept in
+    // registers and written once, beyond the walk records into the output row
+    if (n_max <= NL_MAX_HITS)
+        hipLaunchKernelGGL(k_svo_intersect_raw<false>, dim3(nl_div_up(total, NL_GEO_THREADS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream,
+                           b, n, m, voxelsize, n_max, ray_start, ray_dir, points, children, idx, min_depth, max_depth);
+    else
+        hipLaunchKernelGGL(k_svo_intersect_raw<true>, dim3(nl_div_up(total, NL_GEO_THREADS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream,
+                           b, n, m, voxelsize, n_max, ray_start, ray_dir, points, children, idx, min_depth, max_depth);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

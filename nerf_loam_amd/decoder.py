@@ -44,11 +44,12 @@ class Decoder(nn.Module):
         if not x.is_cuda:
             raise L.NerfLoamHipError("Decoder.get_values needs a CUDA (HIP) tensor - no CPU path")
         x = x.detach().float().contiguous()
-        params = self.flat_params(x.device)
-        W2T = torch.empty(L.NL_DEC_WS_FLOATS, dtype=torch.float32, device=x.device)
-        ops.decoder_transpose_w2(params, W2T)
+        # the device parameter block + W2 operand planes, kept until somebody writes the parameters (tensor version counters): the same
+        # cache bundle_adjust_frames / track_frame use (render_helpers._decoder_device) - no re-flattening, no plane rebuild per call
+        from .render_helpers import _decoder_device
+        dec = _decoder_device(self, x.device)
         out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
-        ops.decoder_forward(x, params, W2T, x.shape[0], out, L.lib().nl_decoder_grid_hint())
+        ops.decoder_forward(x, dec.params, dec.W2T, x.shape[0], out, L.lib().nl_decoder_grid_hint())
         return out.unsqueeze(-1)
 
     def forward(self, inputs):

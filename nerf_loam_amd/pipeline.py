@@ -779,9 +779,9 @@ class SdfEngine:
         sd = (dbl[L.NLD_SDF_SQ] + st["S"] * dbl[L.NLD_INV_D2] - dbl[L.NLD_INV_D2CNT]) / n * st["w_sdf"]
         return dict(loss=cfg.fs_weight * fs + cfg.sdf_weight * sd, fs_loss=fs, sdf_loss=sd, **{k: st[k] for k in ("R", "S", "P", "H")})
 
-    def export_render(self):
-        """The dict the reference's render_rays returns (render_helpers.py:311-318), rebuilt from the
-        packed device buffers: z_vals[R,S], sdf[R,S] (ones where invalid), valid_mask[R,S], ray_mask[N]."""
+    def export_render_device(self):
+        """The dict the reference's render_rays returns (render_helpers.py:311-318), rebuilt from the packed device buffers by
+        nl_unpack_samples and LEFT ON THE DEVICE: z_vals[R,S], sdf[R,S] (ones where invalid), valid_mask[R,S] bool, ray_mask[N] bool."""
         st = self.stats()
         R, S, N = st["R"], st["S"], self.N
         if R == 0 or S == 0:
@@ -790,5 +790,12 @@ class SdfEngine:
         out_z = torch.full((R, S), 80.0, dtype=F32, device=self.dev)
         out_valid = torch.zeros(R, S, dtype=torch.uint8, device=self.dev)
         ops.unpack_samples(self.loss_scalars, self.s_ray, self.samp_off, self.hit_rank, self.sdf, self.s_depth, S, out_sdf, out_z, out_valid)
-        return dict(z_vals=out_z.cpu().numpy(), sdf=out_sdf.cpu().numpy(), valid_mask=out_valid.cpu().numpy().astype(bool),
-                    ray_mask=(self.hit_count[:N] > 0).cpu().numpy(), stats=st)
+        return dict(z_vals=out_z, sdf=out_sdf, valid_mask=out_valid.view(torch.bool), ray_mask=self.hit_count[:N] > 0, stats=st)
+
+    def export_render(self):
+        """export_render_device() as numpy arrays (tests, probes)"""
+        r = self.export_render_device()
+        if r is None:
+            return None
+        return dict(z_vals=r["z_vals"].cpu().numpy(), sdf=r["sdf"].cpu().numpy(), valid_mask=r["valid_mask"].cpu().numpy(),
+                    ray_mask=r["ray_mask"].cpu().numpy(), stats=r["stats"])

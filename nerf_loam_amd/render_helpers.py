@@ -299,30 +299,35 @@ def track_frame(frame_pose, curr_frame, map_states, sdf_network, loss_criteria, 
 @torch.no_grad()
 def render_rays(rays_o, rays_d, map_states, sdf_network, step_size, voxel_size, truncation, max_voxel_hit, max_distance,
                 chunk_size=10000, profiler=None, return_raw=False):
-    """Forward rendering of world-space rays sharing one origin per call (as every reference caller passes:
-    rays_o is the frame translation expanded over the rays)."""
+    """Forward rendering of world-space rays (render_helpers.py:190-318): any origins - every distinct origin becomes one "frame" of
+    the engine (identity rotation, that translation), so a batch of several frames' rays (bundle_adjust_frames' layout, :385-388) or
+    rays with individual origins render in one pass.  The returned tensors stay on the device."""
     emb = map_states["voxel_vertex_emb"]
     device = emb.device
-    o = rays_o.reshape(-1, 3)
-    d = rays_d.reshape(-1, 3).float()
-    if not torch.equal(o, o[:1].expand_as(o)):
-        raise L.NerfLoamHipError("render_rays: rays must share one origin (one frame) per call")
+    o = rays_o.reshape(-1, 3).to(device, torch.float32)
+    d = rays_d.reshape(-1, 3).to(device, torch.float32).contiguous()
+    if o.shape[0] != d.shape[0]:
+        o = o.expand(d.shape[0], 3)
+    if bool((o == o[:1]).all()):
+        origins, fid = o[:1], None
+    else:
+        origins, inv = torch.unique(o, dim=0, return_inverse=True)
+        fid = inv.to(torch.int32)
     m = _map_device(map_states, voxel_size, device)
     dec = _decoder_device(sdf_network, device)
-    eng = _engine(d.shape[0], 1, device)
+    eng = _engine(d.shape[0], origins.shape[0], device)
     crit = type("C", (), dict(truncation=truncation, sdf_weight=1.0, fs_weight=1.0))
     cfg = _cfg(crit, voxel_size, step_size, max_distance)
-    eng.set_poses(np.concatenate([o[0].detach().cpu().numpy(), np.zeros(3, np.float32)])[None].astype(np.float32), [0])
-    eng.set_rays(d, torch.zeros_like(d), torch.ones(d.shape[0]))
+    pose6 = torch.cat([origins, torch.zeros_like(origins)], 1).cpu().numpy()
+    eng.set_poses(pose6, [0] * origins.shape[0])
+    eng.set_rays(d, torch.zeros_like(d), torch.ones(d.shape[0], device=device), fid)
     eng.forward_only(m, dec, cfg)
-    r = eng.export_render()
+    r = eng.export_render_device()
     if r is None:
         return None
     P = r["stats"]["P"]
-    out = {"z_vals": torch.from_numpy(r["z_vals"]).to(device), "sdf": torch.from_numpy(r["sdf"]).to(device),
-           "ray_mask": torch.from_numpy(r["ray_mask"]).to(device).view(1, -1), "valid_mask": torch.from_numpy(r["valid_mask"]).to(device),
-           "sampled_xyz": m.centres[eng.s_vox[:P].long()], "_engine": eng, "_cfg": cfg}
-    return out
+    return {"z_vals": r["z_vals"], "sdf": r["sdf"], "ray_mask": r["ray_mask"].view(1, -1), "valid_mask": r["valid_mask"],
+            "sampled_xyz": m.centres[eng.s_vox[:P].long()], "_engine": eng, "_cfg": cfg}
 
 
 @torch.no_grad()

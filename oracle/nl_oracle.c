@@ -15,13 +15,14 @@
  *                              :151-171 (find_octant), :293-342 (get_centres_and_children),
  *                              include/utils.h:64-109 (Morton encode/decode)
  *
- * Pinning status:
- *   - octree: pinned against the REFERENCE ITSELF (oracle/_ref/svo_ref.so, built unmodified by
- *     oracle/build_ref.sh) in tests/test_oracle_octree.py and through tests/golden/.
- *   - intersect / sampler: the reference has no CPU path for these CUDA kernels and no tests or
- *     golden vectors of its own -> "parity unpinned" by the reference; the restatement is
- *     cross-checked by an independent brute-force numpy implementation in the tests, and the
- *     reference's Python wrappers are run ON TOP of these two functions to produce the goldens.
+ * Pinning status (DESIGN.md section 2):
+ *   - octree: pinned against the REFERENCE ITSELF (oracle/_ref/svo_ref.so, the reference's sparse_octree sources built unmodified by
+ *     oracle/build_ref.sh): tests/test_octree_host.py, bit-identical.
+ *   - intersect / sampler: pinned against the REFERENCE'S OWN CUDA KERNELS - oracle/_ref/grid_ref*.so, its third_party/sparse_voxels
+ *     sources built for gfx950 by oracle/build_grid_ref.py and run on the GPU box by tests/test_gpu_reference_grid.py: reference kernel ==
+ *     this restatement == the HIP product, bit for bit (svo_intersect incl. the 20-hit cap; inverse_cdf_sampling against the build
+ *     without FMA contraction, <= 4 ulp against the default build), also at the full 131 072-ray scan.  The reference's Python wrappers
+ *     run ON TOP of these two functions to produce tests/golden/*.npz (tests/golden/make_golden.py).
  *   - one deliberate deviation: CUDA's __fdividef(1,x) (intersect_gpu.cu:93-103) is restated as
  *     the IEEE divide 1.0f/x; CUDA -O2 also contracts a*b+c to FMA, this file does not.
  */

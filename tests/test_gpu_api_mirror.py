@@ -83,6 +83,45 @@ def test_mapping_then_tracking_like_the_reference_loop():
     assert 0.9 < float(out.hit_ratio) <= 1.0
 
 
+def test_render_rays_with_per_frame_origins_matches_the_oracle():
+    """render_rays (render_helpers.py:190-318) takes world-space rays with ANY origins - bundle_adjust_frames hands it the concatenated
+    rays of several frames (:385-388).  Two frames' rays in one call: hit mask, depths, validity bit for bit and sdf to 5e-6 against the
+    oracle's two-frame iteration; tensors come back on the device."""
+    from oracle import oracle as O
+    from nerf_loam_amd import render_helpers as RH, synthetic as S
+    from nerf_loam_amd.lidar_frame import LidarFrame
+    from nerf_loam_amd.mapping import Mapping
+    torch.manual_seed(3)
+    pts, cos = H.scene_points(64, 64, 11)
+    mapper = Mapping(make_args())
+    f0 = LidarFrame(0, torch.from_numpy(pts), torch.from_numpy(cos), np.eye(4))
+    mapper.create_voxels(f0)
+    with torch.no_grad():
+        mapper.dynamic_embeddings.copy_(torch.randn_like(mapper.dynamic_embeddings, dtype=torch.float32).mul_(0.01).to(torch.bfloat16))
+    poses = [S.scan_pose(), S.scan_pose(tx=0.4, ty=-0.25, tz=0.05)]
+    sel = [np.arange(0, len(pts), 3), np.arange(1, len(pts), 4)]
+    dirs = S.unit_dirs(pts)
+    o = torch.from_numpy(np.concatenate([np.broadcast_to(p[:3], (len(s_), 3)) for p, s_ in zip(poses, sel)]).astype(np.float32)).cuda()
+    d = torch.from_numpy(np.concatenate([dirs[s_] for s_ in sel])).cuda()
+    monkey_noise = RH.SAMPLER_NOISE
+    RH.SAMPLER_NOISE = (777, False)
+    try:
+        out = RH.render_rays(o[None], d[None], mapper.map_states, mapper.decoder, mapper.step_size, 0.2, 0.3, 20, 50.0)
+    finally:
+        RH.SAMPLER_NOISE = monkey_noise
+    assert all(out[k].is_cuda for k in ("z_vals", "sdf", "ray_mask", "valid_mask", "sampled_xyz"))
+    mp = mapper.map_states
+    ms = O.MapState(mp["voxel_center_xyz"].cpu().numpy(), mp["voxel_structure"].cpu().numpy(), mp["voxel_vertex_idx"].cpu().numpy(),
+                    mp["voxel_id2embedding_id"].cpu().numpy().astype(np.int32), mapper.dynamic_embeddings.view(torch.int16).cpu().numpy().view(np.uint16), 0.2)
+    dp = O.DecoderParams(*[p.detach().cpu().numpy() for p in mapper.decoder.param_list()])
+    frames = [O.Frame(dirs[s_], pts[s_], cos[s_], p.copy()) for p, s_ in zip(poses, sel)]
+    ref = O.render_and_grad(ms, dp, frames, O.IterCfg(step_size=mapper.step_size), want_emb_grad=False, want_dec_grad=False)
+    assert np.array_equal(out["ray_mask"].view(-1).cpu().numpy(), ref["hits"])
+    assert np.array_equal(out["valid_mask"].cpu().numpy(), ref["valid"]) and np.array_equal(out["z_vals"].cpu().numpy(), ref["z_vals"])
+    assert float(np.abs(out["sdf"].cpu().numpy() - ref["sdf"]).max()) < 5e-6
+    assert ref["hits"][:len(sel[0])].any() and ref["hits"][len(sel[0]):].any()
+
+
 def _select_key_np(seed, n):
     """numpy restatement of nl_select_key (nl_device_math.h): lowbias32(i ^ (seed * 0x9E3779B9 + 0x7F4A7C15))"""
     x = np.arange(n, dtype=np.uint64) ^ np.uint64((seed * 0x9E3779B9 + 0x7F4A7C15) & 0xFFFFFFFF)

@@ -81,7 +81,7 @@ def scene():
     return sc
 
 
-@pytest.mark.parametrize("n_max,batch", [(20, 1), (20, 4), (5, 2)])
+@pytest.mark.parametrize("n_max,batch", [(20, 1), (20, 4), (5, 2), (32, 2)])
 def test_grid_svo_intersect_bit_exact(nl, scene, n_max, batch):
     ms = scene["ms"]
     N = (len(scene["o"]) // batch) * batch

@@ -1,0 +1,172 @@
+"""GPU (-m gpu): SEQUENCE-level numeric parity - BASELINE config 1's shape ("first 5 scans, mapping-only") through the mirrored call sites
+of the reference's mapper (/root/reference/src/mapping.py:93-202,262-339): for every scan `Mapping.do_mapping` (20 iterations of
+bundle_adjust_frames on the current scan, pose in the optimiser, a fresh bf16 Adam per call, the decoder frozen from `freeze_frame` on),
+then `create_voxels` with the OPTIMISED pose (map growth: new octree nodes, new zero embedding rows appended to the persistent table),
+keyframe insertion every `keyframe_gap` metres, and at the end one post-processing round over the key-scan window (selection 'random',
+2 x N_rays per key-scan, poses and decoder frozen, :128-138).
+
+The oracle (oracle/oracle.py bundle_adjust) replays the same sequence with its OWN numeric state carried from scan to scan - embedding
+table, decoder, poses - on the same ray subsets and sampler noise; after every call the two states are compared.  The MAP STRUCTURE (octree
+tensors, id table) the oracle uses after each growth step is the product's: it is rebuilt by the oracle's own octree from the voxel lists the
+product inserted and must come out bit-identical (centres, structure, vertex ids) - so structure is pinned bit-exactly and numerics within
+the bars below, at every step of the sequence.  What bf16 Adam allows is measured, not assumed: the bars are rel_l2 = |got - ref| / |ref -
+state at the start of the sequence| (tests/test_gpu_api_parity.py explains why element-wise bars are meaningless for bf16 Adam)."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+N_SCANS, SPACING, N_RAYS, N_ITER = 5, 3.0, 1024, 20
+POSE_ULP_2000 = 2.0 ** -13
+
+
+def _args():
+    return Namespace(
+        criteria=dict(sdf_weight=10000.0, fs_weight=1, eiko_weight=0.1, sdf_truncation=0.30), data_specs=dict(max_depth=50.0, min_depth=1.5),
+        decoder_specs=dict(depth=2, width=256, in_dim=16, skips=[], embedder="none", multires=0),
+        tracker_specs=dict(N_rays=N_RAYS, learning_rate=0.005, step_size=0.2, max_voxel_hit=20, num_iterations=N_ITER),
+        mapper_specs=dict(N_rays_each=N_RAYS, use_local_coord=False, voxel_size=0.2, step_size=0.5, window_size=4, num_iterations=N_ITER,
+                          max_voxel_hit=20, final_iter=True, mesh_res=2, learning_rate_emb=0.03, learning_rate_decorder=0.005,
+                          learning_rate_pose=0.001, freeze_frame=3, keyframe_gap=5, remove_back=False, key_distance=12),
+        debug_args=dict(verbose=False, mesh_freq=100))
+
+
+def _bits(t):
+    return t.detach().view(torch.int16).cpu().numpy().view(np.uint16).copy()
+
+
+def _rel(got, ref, start):
+    return float(np.linalg.norm((got - ref).astype(np.float64).ravel()) / max(np.linalg.norm((ref - start).astype(np.float64).ravel()), 1e-30))
+
+
+def test_five_scan_mapping_sequence_matches_the_oracle(monkeypatch):
+    from nerf_loam_amd import _lib as L, render_helpers as RH
+    from nerf_loam_amd.lidar_frame import LidarFrame
+    from nerf_loam_amd.mapping import Mapping
+    L.require_gpu()
+    monkeypatch.setattr(RH, "RAY_SELECTION", "host")
+    monkeypatch.setattr(RH, "SAMPLER_NOISE", (777, False))
+    RH._ENGINES.clear()
+    torch.manual_seed(777)
+    rng = np.random.default_rng(11)
+
+    def sample_rays(self, N_rays, track=False):                       # seeded uniform subsets, recorded for the oracle's replay
+        m = np.zeros(self.num_point, bool)
+        m[rng.choice(self.num_point, N_rays, replace=False)] = True
+        self.__dict__.setdefault("_drawn", []).append(m)
+        self.sample_mask = torch.from_numpy(m[:, None].copy())
+    monkeypatch.setattr(LidarFrame, "sample_rays", sample_rays)
+
+    args = _args()
+    mapper = Mapping(args)
+    ms_cfg = args.mapper_specs
+    lrs = [ms_cfg["learning_rate_emb"], ms_cfg["learning_rate_decorder"], ms_cfg["learning_rate_pose"]]
+    cfg_o = O.IterCfg(step_size=ms_cfg["step_size"] * ms_cfg["voxel_size"])
+    inserted = []
+    real_insert = mapper.svo.insert
+    monkeypatch.setattr(mapper.svo, "insert", lambda v: (inserted.append(np.asarray(v).astype(np.int32).copy()), real_insert(v))[1])
+
+    # ---- oracle-side state carried through the sequence
+    dec_o = O.DecoderParams(*[p.detach().cpu().numpy().astype(np.float32).copy() for p in mapper.decoder.param_list()])
+    dec0 = {k: getattr(dec_o, k).copy() for k in ("W1", "b1", "W2", "b2", "W3", "b3")}
+    oc_o = O.Octree(); oc_o.init(256 * 256 * 4, 16, 0.2)
+    st = dict(emb=np.zeros((0, 16), np.uint16), ms=None, fed=0)
+    pose_o = {}
+
+    def grow_oracle_map():
+        """the oracle's octree takes the voxel lists the product inserted; its tensors must equal the product's map_states bit for bit.  New
+        vertices get zero rows at the row numbers the product's id table assigned (row numbering is the caller's choice)."""
+        for v in inserted[st["fed"]:]:
+            oc_o.insert(v)
+        st["fed"] = len(inserted)
+        voxels, children, features = oc_o.get_centres_and_children()
+        centres, structure = O.grid_features(voxels, children, 0.2)
+        mp = mapper.map_states
+        assert np.array_equal(centres, mp["voxel_center_xyz"].cpu().numpy()) and np.array_equal(structure, mp["voxel_structure"].cpu().numpy())
+        assert np.array_equal(features, mp["voxel_vertex_idx"].cpu().numpy())
+        id2row = mp["voxel_id2embedding_id"].cpu().numpy().astype(np.int32)
+        E = mapper.dynamic_embeddings.shape[0]
+        assert E >= len(st["emb"]) and not _bits(mapper.dynamic_embeddings)[len(st["emb"]):].any()      # appended rows are zero
+        st["emb"] = np.concatenate([st["emb"], np.zeros((E - len(st["emb"]), 16), np.uint16)])
+        st["ms"] = O.MapState(centres, structure, features, id2row, st["emb"], 0.2)
+        return E
+
+    def ba_oracle(targets, n_rays, update_pose, update_decoder):
+        scans = [dict(points=fr.points.numpy(), cos=fr.pointsCos.numpy(), pose=pose_o[id(fr.pose)], index=fr.index) for fr in targets]
+        masks = [np.stack(fr.__dict__["_drawn"][-N_ITER:]) for fr in targets]
+        assert all(int(m[0].sum()) == n_rays for m in masks)
+        st["ms"].emb = st["emb"]
+        outs = O.bundle_adjust(st["ms"], dec_o, scans, masks, cfg_o, N_ITER, lrs, update_pose=update_pose, update_decoder=update_decoder)
+        assert all(o is not None for o in outs)
+        st["emb"] = st["ms"].emb
+        for fr, sc in zip(targets, scans):
+            pose_o[id(fr.pose)] = sc["pose"]
+
+    report = []
+
+    def compare(tag, frames, emb_start):
+        got_e, ref_e = O.bf16_to_f32(_bits(mapper.dynamic_embeddings)), O.bf16_to_f32(st["emb"])
+        e0 = np.zeros_like(ref_e); e0[:len(emb_start)] = O.bf16_to_f32(emb_start)
+        r = dict(step=tag, rows=int(len(ref_e)), emb_rel_l2=_rel(got_e, ref_e, e0),
+                 emb_rows_moved_differ=float(((got_e != e0).any(1) != (ref_e != e0).any(1)).mean()))
+        gd = {k: p.detach().cpu().numpy().reshape(-1) for k, p in zip(("W1", "b1", "W2", "b2", "W3", "b3"), mapper.decoder.param_list())}
+        r["dec_rel_l2"] = max(_rel(gd[k], getattr(dec_o, k).reshape(-1), dec0[k].reshape(-1)) for k in gd if np.any(getattr(dec_o, k) != dec0[k])) \
+            if any(np.any(getattr(dec_o, k) != dec0[k]) for k in gd) else 0.0
+        dp = [np.abs(fr.pose.data.detach().cpu().numpy() - pose_o[id(fr.pose)]) for fr in frames]
+        r["pose_t_ulp"] = float(max(d[:3].max() for d in dp) / POSE_ULP_2000)
+        r["pose_w"] = float(max(d[3:].max() for d in dp))
+        report.append(r)
+        H.record_gpu_metric("sequence_" + tag, **{k: v for k, v in r.items() if k != "step"})
+        return r
+
+    # ---- the five scans: the reference's mapper loop (mapping.py:93-118), selection 'current'
+    frames = []
+    for i in range(N_SCANS):
+        pts, cos = H.scene_points(64, 256, 100 + i)
+        T = np.eye(4); T[0, 3] = SPACING * i
+        if i:                                                          # what a tracker hands over is a little off: the mapper's BA refines it
+            T[:3, 3] += np.array([0.02, -0.015, 0.01]) * (1 if i % 2 else -1)
+        fr = LidarFrame(i, torch.from_numpy(pts), torch.from_numpy(cos), T)
+        frames.append(fr)
+        pose_o[id(fr.pose)] = fr.pose.data.detach().numpy().astype(np.float32).copy()
+        emb_start = st["emb"].copy()
+        dec_before = mapper.decoder.pts_linears[1].weight.detach().clone()
+        if i == 0:
+            mapper.first_frame_id = fr.index
+            mapper.create_voxels(fr); grow_oracle_map()
+            mapper.insert_keyframe(fr); pose_o[id(mapper.current_keyframe.pose)] = pose_o[id(fr.pose)]
+            mapper.do_mapping(None, fr, selection_method="current")
+            ba_oracle([fr], N_RAYS, True, True)
+        else:
+            mapper.do_mapping(None, fr)
+            frozen = (fr.index - mapper.first_frame_id) >= mapper.freeze_frame
+            ba_oracle([fr], N_RAYS, True, not frozen)
+            assert torch.equal(dec_before, mapper.decoder.pts_linears[1].weight.detach()) == frozen          # freeze_frame (mapping.py:196)
+            mapper.create_voxels(fr)                                   # with the pose the BA just refined
+            E_before = len(st["emb"]); E = grow_oracle_map()
+            assert E > E_before                                        # the map grew: rows appended to the persistent table
+            if float(torch.norm(fr.pose.translation().detach().cpu() - mapper.current_keyframe.pose.translation().detach().cpu())) > mapper.keyframe_gap:
+                mapper.insert_keyframe(fr)
+        r = compare(f"scan{i}", [fr], emb_start)
+        assert r["emb_rel_l2"] <= 0.05 and r["emb_rows_moved_differ"] <= 2e-3, r
+        assert r["dec_rel_l2"] <= 0.2, r
+        assert r["pose_t_ulp"] <= 2 and r["pose_w"] <= 2e-5, r
+    assert len(mapper.keyframe_graph) == 3 and [k.index for k in mapper.keyframe_graph] == [0, 2, 4]      # 3 m apart, gap 5 m
+    assert float(np.abs(frames[1].pose.data.detach().numpy() - pose_o[id(frames[1].pose)]).max()) < 1e-3 and \
+        float(np.abs(frames[1].pose.data.detach().numpy()[:3] - (np.array([SPACING, 0, 0]) + 2000)).max()) > 1e-4   # ... and the BA moved it
+
+    # ---- one post-processing round (mapping.py:128-138): the key-scan window, 2 x N_rays each, poses and decoder frozen
+    emb_start = st["emb"].copy()
+    poses_before = [k.pose.data.detach().clone() for k in mapper.keyframe_graph]
+    mapper.do_mapping(None, tracked_frame=None, update_pose=False, update_decoder=False, selection_method="random")
+    ba_oracle(mapper.keyframe_graph, 2 * N_RAYS, False, False)
+    r = compare("post_processing", mapper.keyframe_graph, emb_start)
+    assert all(torch.equal(a, k.pose.data.detach()) for a, k in zip(poses_before, mapper.keyframe_graph))
+    assert r["emb_rel_l2"] <= 0.05 and r["emb_rows_moved_differ"] <= 2e-3, r
+    print("\n".join(str(x) for x in report))

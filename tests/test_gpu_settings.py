@@ -1,0 +1,90 @@
+"""GPU (-m gpu): the reference's OTHER shipped settings at benchmark size, and the accumulated-map regime, in the test suite.
+
+  * configs/kitti/kitti.yaml (voxel 0.3 m, mapper step 0.5 x 0.3 = 0.15 m) and configs/ncd/ncd.yaml (voxel 0.2 m, mapper step 0.2 x 0.2 =
+    0.04 m: ~21 samples per ray on average, up to ~60) on the full 64 x 2048 scan: one mapping iteration against the oracle - unit
+    directions, hit lists, sample layout and depths bit for bit on ALL 131 072 rays (the C restatement of the reference's two CUDA kernels at
+    full size), sdf / dL/dsdf / dL/dX on every 16th ray's samples (bench.parity_check: the same in-run check the bench line carries);
+  * the 150-scan map of bench.py's large_map leg (1.4 M octree nodes, 1.1 M embedding rows, rays crossing up to ~60 voxels: the in-place
+    first-20 pruning of the work-list intersect) at 2048 and at 16 384 rays: geometry bit for bit, sdf / dsdf / dX."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["kitti", "ncd"])
+def test_full_scan_under_the_kitti_and_ncd_settings(name):
+    import bench
+    from nerf_loam_amd import _lib as L, pipeline as P
+    L.require_gpu()
+    sp = bench.SETTINGS[name]
+    dev = torch.device("cuda", 0)
+    w = bench.build_workload(dev, voxel=sp["voxel"])
+    N = len(w["points"])
+    eng = P.SdfEngine(max_rays=N, samples_per_ray_cap=64, device=dev)
+    eng.set_rays(w["dirs"], w["points"], w["cos"]); eng.set_poses(w["pose"][None], [1])
+    cfg = P.IterConfig(voxel_size=sp["voxel"], step_size=sp["step"], lr_emb=sp["lrs"][0])
+    eng.begin_call(w["map"], w["dec"])
+    eng.bind(w["map"], w["dec"], cfg, train_decoder=True)
+    eng.run_bound()                                                   # one optimiser step first: the check runs on updated parameters
+    r = bench.parity_check(eng, w, cfg, True, every=16)
+    st = eng.stats()
+    assert not st["overflow"] and not st["guard"]
+    assert r["unit_dirs_equal"] and r["hits_equal"] and r["samples_equal"], r
+    assert r["sdf_max_abs_err"] < 5e-6 and r["dsdf_max_err_rel_to_max"] < 1e-4 and r["dX_rel_l2"] < 1e-4, r
+    if name == "ncd":
+        assert st["S"] >= 40 and r["valid_samples"] > 2_000_000, (st["S"], r["valid_samples"])     # the many-samples regime is really exercised
+    import helpers as H
+    H.record_gpu_metric("full_scan_" + name, sdf=r["sdf_max_abs_err"], dsdf=r["dsdf_max_err_rel_to_max"], dX=r["dX_rel_l2"], S=st["S"], P=r["valid_samples"])
+
+
+@pytest.fixture(scope="module")
+def large_map():
+    import bench
+    from nerf_loam_amd import _lib as L
+    L.require_gpu()
+    dev = torch.device("cuda", 0)
+    w = bench.build_workload(dev)
+    return bench, w, bench.build_large_map(w, dev, 150, 3.0), dev
+
+
+@pytest.mark.parametrize("n_rays", [2048, 16384])
+def test_iteration_on_the_150_scan_map_matches_the_oracle(large_map, n_rays):
+    bench, w, lm, dev = large_map
+    from nerf_loam_amd import pipeline as P
+    m, poses = lm["map"], lm["poses"]
+    assert lm["E"] > 1_000_000 and len(lm["centres"]) > 1_300_000
+    dec = P.DecoderDevice(*[np.asarray(a, np.float32) for a in w["host"]["dec"]], device=dev)
+    sel = np.sort(np.random.default_rng(5).choice(len(w["points"]), n_rays, replace=False))
+    eng = P.SdfEngine(max_rays=n_rays, samples_per_ray_cap=96, max_frames=2, device=dev)
+    eng.set_rays(w["dirs"][sel], w["points"][sel], w["cos"][sel])
+    pose = poses[len(poses) // 2]
+    eng.set_poses(pose[None], [1])
+    cfg = P.IterConfig()
+    eng.begin_call(m, dec)
+    eng.forward_backward(m, dec, cfg, train_decoder=True)
+    torch.cuda.synchronize()
+    st = eng.stats()
+    P_ = st["P"]
+    assert not st["overflow"] and st["H"] == 20                       # rays with more than 20 voxels on their way: the cap is reached
+    ms_o = O.MapState(lm["centres"], lm["structure"], lm["vertex_idx"], lm["id2row"], m.emb.cpu().numpy().view(np.uint16).copy(), 0.2)
+    dn = dec.numpy()
+    dp = O.DecoderParams(dn["W1"], dn["b1"], dn["W2"], dn["b2"], dn["W3"], dn["b3"])
+    ref = O.render_and_grad(ms_o, dp, [O.Frame(w["dirs_host"][sel], w["points"][sel], w["cos"][sel], pose.copy())], O.IterCfg(), want_emb_grad=False, want_dec_grad=False)
+    rr, ss = np.nonzero(ref["valid"])
+    hc = eng.hit_count[:n_rays].cpu().numpy()
+    H_ = ref["hit_idx"].shape[1]
+    live = np.arange(H_)[None, :] < hc[:, None]
+    assert P_ == ref["n_samples"] and np.array_equal(hc > 0, ref["hits"])
+    assert np.array_equal(np.where(live, eng.hit_idx[:n_rays, :H_].cpu().numpy(), -1), ref["hit_idx"])          # first 20 in DFS order, sorted by t_min
+    assert np.array_equal(eng.s_depth[:P_].cpu().numpy(), ref["z_vals"][rr, ss]) and np.array_equal(eng.s_vox[:P_].cpu().numpy(), ref["s_idx"][rr, ss])
+    sdf_err = float(np.abs(eng.sdf[:P_].cpu().numpy() - ref["sdf"][rr, ss]).max())
+    ds_err = float(np.abs(eng.dsdf[:P_].cpu().numpy() - ref["dsdf"][rr, ss]).max() / max(np.abs(ref["dsdf"]).max(), 1e-30))
+    dx = eng.dX[:P_].cpu().numpy()
+    dx_err = float(np.linalg.norm((dx - ref["dfeat"]).astype(np.float64)) / max(np.linalg.norm(ref["dfeat"].astype(np.float64)), 1e-30))
+    import helpers as H
+    H.record_gpu_metric(f"large_map_{n_rays}", sdf=sdf_err, dsdf=ds_err, dX=dx_err, P=P_, over20=float((hc == 20).mean()))
+    assert sdf_err < 5e-6 and ds_err < 1e-4 and dx_err < 1e-4, (sdf_err, ds_err, dx_err)
