@@ -791,10 +791,11 @@ def main():
         tl = torch.tensor([dt_local], dtype=torch.float64, device=device)
         tdist.all_reduce(tl, op=tdist.ReduceOp.MAX)
         sharded = dict(rccl_world=world, exchange_backend=ex.backend, embedding_exchange=("dense" if ex._rows_cap == "dense" else f"touched rows, capacity {ex._rows_cap}"),
-                       collectives_per_step=4, per_rank=gathered, ms_per_step_without_exchanges=float(tl.item()) / args.steps * 1e3,
+                       collectives_per_step="3 on the critical path (exchange 1, exchange 2, decoder gradient) + the [pose | embedding] all-reduce on a side stream under dW2", per_rank=gathered, ms_per_step_without_exchanges=float(tl.item()) / args.steps * 1e3,
                        exchange_ms_per_step=(dt - float(tl.item())) / args.steps * 1e3,
-                       note="one C call per iteration (nl_iteration): counter all-gather + row-first all-reduce after the intersect, counter all-gather "
-                            "after the sampler, one grouped all-reduce [decoder grad | fp64 pose partials | embedding accumulators]; "
+                       note="one C call per iteration (nl_iteration): ONE all-gather [counters | per-ray hit counts] after the intersect, counter all-gather "
+                            "after the sampler, grouped all-reduce [fp64 pose partials | embedding accumulators] on a side stream right after the scatter "
+                            "(under dW2 + slab reduction), decoder-gradient all-reduce after the join; "
                             "exchange_ms_per_step = this run minus the same iterations with the communicator removed")
     dec_ms = float(np.mean([e["decoder"][0].elapsed_time(e["decoder"][1]) for e in ev]))
     wg_ms = float(np.mean([e["wgrad2"][0].elapsed_time(e["wgrad2"][1]) for e in ev])) if train_dec else 0.0

@@ -137,15 +137,9 @@ int nl_select_rays_batch_ex(int F, const int* M, const int* n_select, const unsi
 int nl_sample_rays(int emit, int N, const int* hit_idx, const float* hit_t0, const float* hit_t1, const int* hit_count,
                    const int* hit_rank, const int* ray_of_rank, const float* cos_gt, const float* gt_dist,
                    float step_size, float tau, float max_depth, unsigned seed, int use_hash_noise, int tail_always, int ray_id_base,
-                   const unsigned* seed_mix, const int* row_first /* multi-GPU: nl_dist_row_first table, else NULL */,
+                   const unsigned* seed_mix, const int* row_first /* multi-GPU: nl_dist_x1_merge table, else NULL */,
                    int* counters, int* samp_count, const int* samp_off, int capacity,
                    int* s_vox, float* s_depth, float* s_dist, int* s_ray, void* stream);
-/* Multi-GPU ray sharding: hit lists of the batch rows' first rays owned by this rank -> table[n_entries][1 + NL_MAX_HITS] =
- * (count, idx + 1, ...), zeros for rows owned elsewhere; SUM-all-reduce the table and pass it to nl_sample_rays (the sampler's
- * closing loop reads the first ray of a ray's batch row, sample_gpu.cu:231).  n_entries >= 200 * ceil(ceil(R_global / 200) / 800). */
-int nl_dist_row_first(const int* counters, const int* hit_idx, const int* hit_count, const int* ray_of_rank, int* table, int n_entries,
-                      void* stream);
-
 /* global loss normalisers from the counter block (criterion.py:84-88 weights, :65 mean divisor R*S) */
 int nl_loss_finalize(int* counters, void* loss_scalars, float fs_weight, float sdf_weight, float tau, float max_depth,
                      int capacity, void* stream);
@@ -370,9 +364,9 @@ typedef struct NlIterDesc {
     int kernel_modes;
     /* ---- ray-sharded multi-GPU iteration (NULL comm: one GPU).  With a communicator the call issues the exchanges itself, on
      * `stream`, between the kernels (nl_exchange_* below) - a sharded iteration is still ONE C call and stays hipGraph-capturable.
-     *   xg_recv     [world][xg_stride] ints: receive side of the two counter all-gathers, xg_stride >= 24 (+ rows_words when the
-     *               touched-rows bitmaps travel with the second one); xg_send [xg_stride] ints: its send side
-     *   row_first   [row_first_entries][1 + NL_MAX_HITS] ints (nl_dist_row_first)
+     *   xg_recv     [world][xg_stride] ints: receive side of the counter all-gather after the sampler, xg_stride >= 24 (+ rows_words when
+     *               the touched-rows bitmaps travel with it); xg_send [xg_stride] ints: its send side
+     *   row_first   [row_first_entries][1 + NL_MAX_HITS] ints (nl_dist_x1_merge)
      *   rows_mode   embedding-gradient exchange: 0 = dense all-reduce of g_emb, 1 = over the rows the iteration touches
      *               (rows_bitmap / rows_prefix [rows_words], rows_total [1], rows_ws [rows_words + ceil(rows_words / 1024) + 8],
      *               rows_buf [rows_cap][16] floats; the call is flagged invalid on the device when the union exceeds rows_cap) */
@@ -383,6 +377,13 @@ typedef struct NlIterDesc {
     /* touched-rows optimiser (NlTouchedRows above): with the three pointers set the scatter (and the multi-GPU unpack) record the rows they
      * write; sparse_sweep != 0: the optimiser sweeps the list, 0: the whole table (e.g. after a dense multi-GPU gradient exchange) */
     int* touched_list; int* touched_count; unsigned* touched_flags; int sparse_sweep;
+    /* exchange 1 as one all-gather: x1_send [24 ints | x1_rays bytes] (a ray's hit count per byte), x1_recv [world] such blocks of
+     * x1_stride_bytes (a multiple of 8, >= 96 + x1_rays); x1_rays = the ranks' common ray capacity (a multiple of 8, >= every rank's N) */
+    void* x1_send; void* x1_recv; int x1_stride_bytes; int x1_rays;
+    /* overlapped gradient exchange (optional; nl_overlap_create): with the three handles set, a stages & 5 == 5 call runs the embedding
+     * scatter first and all-reduces [pose partials | embedding accumulators] on comm_stream under the dW2 kernel and the slab reduction
+     * (event fork after the scatter, join before the decoder gradient's all-reduce); NULL: the exchanges follow the backward pass on `stream` */
+    void* comm_stream; void* ev_fork; void* ev_join;
 } NlIterDesc;
 /* stages: bit 0 = intersect .. backward (with a communicator: + the exchanges of the forward pass), bit 1 = optimiser step,
  * bit 2 = the gradient exchange (only with a communicator; a whole sharded iteration = 7).  The bits exist separately so that the
@@ -407,17 +408,30 @@ typedef struct NlComm {
 } NlComm;
 /* fills *out for an existing RCCL communicator (ncclComm_t passed as void*); NL_ERR_NO_DEVICE when no RCCL is loaded / loadable */
 int nl_comm_init_rccl(NlComm* out, void* nccl_comm, int world, int rank);
-/* The three exchange points of a sharded iteration, as nl_iteration issues them; also callable between the stage calls:
- *  after_intersect: all-gather of the counter blocks -> global hit-ray count, this rank's hit-rank offset, global max hits
- *                   (nl_dist_merge_counters stage 1); then the batch rows' first-ray hit lists (nl_dist_row_first) SUM-all-reduced:
- *                   the sampler's closing loop reads the first ray of a ray's batch row (sample_gpu.cu:231), which may live elsewhere
+/* The exchange points of a sharded iteration, as nl_iteration issues them; also callable between the stage calls:
+ *  after_intersect: ONE all-gather of [counter block | a byte per ray: its hit count] -> global hit-ray count, this rank's hit-rank offset,
+ *                   global max hits, and the row-first table of the sampler's tail quirk (sample_gpu.cu:224-237 only tests whether
+ *                   curr_bin is below the hit count of the first ray of a ray's batch row): nl_dist_x1_pack / nl_dist_x1_merge
  *  after_sampling:  all-gather of [counter block | touched-rows bitmap] -> summed loss normalisers, max samples per ray
  *                   (stage 2), nl_loss_finalize on the merged block, union bitmap + its prefix sums (rows_mode 1)
- *  gradients:       ONE grouped SUM all-reduce of the decoder gradient (train_decoder), the fp64 pose partials (want_pose_grad)
- *                   and the embedding accumulators (want_emb_grad: dense, or packed touched rows) */
+ *  emb_pose:        grouped SUM all-reduce of the fp64 pose partials (want_pose_grad) and the embedding accumulators (want_emb_grad): dense,
+ *                   or the union's rows packed into rows_buf, reduced, unpacked (rows_mode 1)
+ *  decoder:         SUM all-reduce of the decoder gradient (train_decoder)
+ *  gradients:       emb_pose + decoder on one stream */
 int nl_exchange_after_intersect(const NlIterDesc* desc, void* stream);
 int nl_exchange_after_sampling(const NlIterDesc* desc, void* stream);
+int nl_exchange_emb_pose(const NlIterDesc* desc, void* stream);
+int nl_exchange_decoder(const NlIterDesc* desc, void* stream);
 int nl_exchange_gradients(const NlIterDesc* desc, void* stream);
+/* side stream (highest priority) + two timing-less events for NlIterDesc.comm_stream / ev_fork / ev_join: once per engine, off the hot path */
+int nl_overlap_create(void** comm_stream, void** ev_fork, void** ev_join);
+int nl_overlap_destroy(void* comm_stream, void* ev_fork, void* ev_join);
+/* exchange 1: send block [24-int counter block | n_rays_cap bytes: hit count of ray i, 0 beyond N] (n_rays_cap a multiple of 8), and the
+ * fold of the gathered blocks [world][stride_bytes] into counters (NLC_R_GLOBAL, NLC_R_OFFSET, global NLC_HMAX) + the row-first table
+ * [n_entries][1 + NL_MAX_HITS] = (count, 2 for bins below the count, 0 beyond) that nl_sample_rays reads; n_entries >= 200 *
+ * ceil(ceil(R_global / 200) / 800).  Shards are contiguous blocks of the global ray order (rank-major). */
+int nl_dist_x1_pack(const int* counters, const int* hit_count, int N, int n_rays_cap, int* send, void* stream);
+int nl_dist_x1_merge(const void* gathered, int stride_bytes, int world, int rank, int n_rays_cap, int* counters, int* table, int n_entries, void* stream);
 /* gathered blocks `stride` ints apart (nl_dist_merge_counters: stride = the block itself) */
 int nl_dist_merge_counters_strided(const int* gathered, int stride_ints, int world, int rank, int stage, int* counters, void* stream);
 /* union[w] = OR over ranks of gathered[r * stride_ints + offset_ints + w]; then nl_dist_rows_prefix on the union */

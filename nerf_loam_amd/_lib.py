@@ -62,6 +62,8 @@ def _iter_desc_fields():
     f += [("comm", P_), ("xg_send", P_), ("xg_recv", P_), ("xg_stride", I_), ("row_first", P_), ("row_first_entries", I_)]
     f += [("rows_mode", I_), ("rows_bitmap", P_), ("rows_prefix", P_), ("rows_total", P_), ("rows_ws", P_), ("rows_buf", P_), ("rows_cap", I_), ("rows_words", I_)]
     f += [("touched_list", P_), ("touched_count", P_), ("touched_flags", P_), ("sparse_sweep", I_)]
+    f += [("x1_send", P_), ("x1_recv", P_), ("x1_stride_bytes", I_), ("x1_rays", I_)]
+    f += [("comm_stream", P_), ("ev_fork", P_), ("ev_join", P_)]
     return f
 
 
@@ -102,7 +104,12 @@ _SIGS = {
     "nl_compact_hit_rays": ([_I, _P, _P, _P, _P], _I),
     "nl_scan_hit_rays": ([_P, _P, _P, _I, _P, _P, _P, _P], _I),
     "nl_sample_rays": ([_I, _I] + [_P] * 8 + [_F, _F, _F, _U, _I, _I, _I] + [_P, _P, _P, _P, _P, _I] + [_P] * 5, _I),
-    "nl_dist_row_first": ([_P, _P, _P, _P, _P, _I, _P], _I),
+    "nl_dist_x1_pack": ([_P, _P, _I, _I, _P, _P], _I),
+    "nl_dist_x1_merge": ([_P, _I, _I, _I, _I, _P, _P, _I, _P], _I),
+    "nl_exchange_emb_pose": ([_P, _P], _I),
+    "nl_exchange_decoder": ([_P, _P], _I),
+    "nl_overlap_create": ([_P, _P, _P], _I),
+    "nl_overlap_destroy": ([_P, _P, _P], _I),
     "nl_loss_finalize": ([_P, _P, _F, _F, _F, _F, _I, _P], _I),
     "nl_criterion_forward": ([_I, _I] + [_P] * 6 + [_F] * 4 + [_P] * 3, _I),
     "nl_criterion_backward": ([_I, _I] + [_P] * 6 + [_F] * 4 + [_P] * 4, _I),

@@ -66,8 +66,117 @@ __global__ void k_rows_move(const unsigned* __restrict__ bitmap, const int* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Exchange 1 as ONE all-gather (after the intersect).  What the sampler needs from other ranks: the global number of hit rays, this
+// rank's hit-rank offset, the global max hits - and, for the reference's tail quirk (sample_gpu.cu:224-237), the hit list of
+// the FIRST ray of every batch row of the [200, L] layout.  The closing loop only tests `pts_idx[curr_bin] == -1` on that list, i.e.
+// whether curr_bin is below the row-first ray's HIT COUNT (sorted / culled lists are packed, -1 beyond the count).  So every rank sends
+// [counter block | one byte per ray: its hit count]; with the gathered counts every rank finds the row-first rays itself (the global hit
+// rank of a ray is a prefix sum over the gathered bytes: shards are contiguous blocks of the global ray order) and fills the table the
+// sampler kernels read: row e = (count, then 2 for bins below the count, 0 beyond - the kernels compare entry - 1 with -1).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_x1_pack(const int* __restrict__ counters, const int* __restrict__ hit_count, int N, int n_rays_cap, int* __restrict__ send)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < NL_CNT_INTS + 2 * NL_CNT_DOUBLES) send[t] = counters[t];
+    if (4 * t < n_rays_cap) {
+        unsigned w = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 4 * t + j;
+            const int c = i < N ? hit_count[i] : 0;
+            w |= (unsigned)(c < 0 ? 0 : (c > 255 ? 255 : c)) << (8 * j);
+        }
+        reinterpret_cast<unsigned*>(send + NL_CNT_INTS + 2 * NL_CNT_DOUBLES)[t] = w;
+    }
+}
+
+#define X1_THREADS 1024
+__device__ __forceinline__ void x1_write_row(int* __restrict__ table, int e, int cnt)
+{
+    int* row = table + (size_t)e * (1 + NL_MAX_HITS);
+    row[0] = cnt;
+#pragma unroll
+    for (int b = 0; b < NL_MAX_HITS; ++b) row[1 + b] = b < cnt ? 2 : 0;
+}
+
+// one workgroup per rank's slice of the gathered buffer; every rank runs all of them and ends with the whole table
+__global__ __launch_bounds__(X1_THREADS) void k_x1_merge(const unsigned char* __restrict__ recv, int stride_bytes, int world, int rank, int n_rays_cap,
+                                                         int* __restrict__ counters, int* __restrict__ table, int n_entries)
+{
+    __shared__ int s_wave[X1_THREADS / 64];
+    __shared__ int s_cnt0;
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int Rg = 0, off_r = 0, off_me = 0, hmax = 0;
+    for (int q = 0; q < world; ++q) {
+        const int* blk = reinterpret_cast<const int*>(recv + (size_t)q * stride_bytes);
+        const int v = blk[NLC_R];
+        Rg += v; if (q < r) off_r += v; if (q < rank) off_me += v;
+        hmax = max(hmax, blk[NLC_HMAX]);
+    }
+    if (r == 0 && tid == 0) { counters[NLC_R_GLOBAL] = Rg; counters[NLC_R_OFFSET] = off_me; counters[NLC_HMAX] = hmax; }
+    const int L = (Rg + NL_SAMPLER_G - 1) / NL_SAMPLER_G;
+    const int nch = L > 0 ? (L + NL_SAMPLER_CHUNK - 1) / NL_SAMPLER_CHUNK : 1;
+    const int used = NL_SAMPLER_G * nch < n_entries ? NL_SAMPLER_G * nch : n_entries;
+    if (r == 0) for (int e = (L > 0 ? used : 0) + tid; e < n_entries; e += X1_THREADS) x1_write_row(table, e, 0);    // entries no row uses
+    if (tid == 0) s_cnt0 = -1;
+    if (L == 0) return;
+    const unsigned char* bytes = recv + (size_t)r * stride_bytes + (NL_CNT_INTS + 2 * NL_CNT_DOUBLES) * 4;
+    const int per = (n_rays_cap + X1_THREADS - 1) / X1_THREADS, i0 = tid * per, i1 = min(n_rays_cap, i0 + per);
+    int mine = 0;
+    for (int i = i0; i < i1; ++i) mine += bytes[i] ? 1 : 0;
+    int incl = mine;                                              // inclusive scan over the workgroup: wave shuffles, then the wave totals
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int q = 0; q < w; ++q) before += s_wave[q];
+    int q = off_r + before + incl - mine;                         // global hit rank of this thread's first hit ray
+    for (int i = i0; i < i1; ++i) {
+        const int c = bytes[i];
+        if (!c) continue;
+        if (q == 0) s_cnt0 = c;
+        const int within = q % L;
+        if (within % NL_SAMPLER_CHUNK == 0) {
+            const int e = (q / L) * nch + within / NL_SAMPLER_CHUNK;
+            if (e < n_entries) x1_write_row(table, e, c);
+        }
+        ++q;
+    }
+    __syncthreads();
+    const int cnt0 = s_cnt0;                                      // this slice holds hit-ray 0: the padding rows replicate it (voxel_helpers.py:278-284)
+    if (cnt0 >= 0)
+        for (int e = tid; e < used; e += X1_THREADS) {
+            const int first = (e / nch) * L + (e % nch) * NL_SAMPLER_CHUNK;
+            if (first >= Rg) x1_write_row(table, e, cnt0);
+        }
+}
+
 extern "C" {
 
+/* exchange 1, send side: send = [counter block (24 ints) | n_rays_cap bytes: hit count of ray i, 0 beyond N]; n_rays_cap a multiple of 8 */
+int nl_dist_x1_pack(const int* counters, const int* hit_count, int N, int n_rays_cap, int* send, void* stream)
+{
+    if (!counters || !hit_count || !send || N < 0 || n_rays_cap < N || (n_rays_cap & 7)) return NL_ERR_INVALID_ARG;
+    const int threads = n_rays_cap / 4 > NL_CNT_INTS + 2 * NL_CNT_DOUBLES ? n_rays_cap / 4 : NL_CNT_INTS + 2 * NL_CNT_DOUBLES;
+    hipLaunchKernelGGL(k_x1_pack, dim3(nl_div_up(threads, 256)), dim3(256), 0, (hipStream_t)stream, counters, hit_count, N, n_rays_cap, send);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+/* exchange 1, receive side: gathered [world][stride_bytes] -> counters (NLC_R_GLOBAL, NLC_R_OFFSET, global NLC_HMAX) + the row-first
+ * table [n_entries][1 + NL_MAX_HITS] of nl_sample_rays (n_entries >= 200 * ceil(ceil(R_global / 200) / 800)) */
+int nl_dist_x1_merge(const void* gathered, int stride_bytes, int world, int rank, int n_rays_cap, int* counters, int* table, int n_entries, void* stream)
+{
+    if (!gathered || !counters || !table || world <= 0 || rank < 0 || rank >= world || n_rays_cap <= 0 || n_entries <= 0 ||
+        stride_bytes < (NL_CNT_INTS + 2 * NL_CNT_DOUBLES) * 4 + n_rays_cap || (stride_bytes & 7))
+        return NL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_x1_merge, dim3(world), dim3(X1_THREADS), 0, (hipStream_t)stream, (const unsigned char*)gathered, stride_bytes, world, rank,
+                       n_rays_cap, counters, table, n_entries);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
 
 /* bitmap[ceil(E / 32)] (zero-filled by the caller) |= rows of the voxels hit by the N rays */
 int nl_dist_mark_rows(int N, const int* hit_idx, const int* hit_count, const int* vertex_rows, unsigned* bitmap, void* stream)

@@ -2,16 +2,18 @@
 //
 // The reference has no distributed code; north_star: "a scan's rays shard embarrassingly across the 8 GPUs of one node
 // with RCCL all-reduce of embedding and pose gradients over xGMI".  Rays are independent up to three reductions:
-//   1. after intersect : the sampler's tail quirk depends on a ray's GLOBAL hit rank and on the hit list of the first ray of its
-//                        batch row (sample_gpu.cu:231) -> all-gather of the 96-byte counter blocks, then a SUM
-//                        all-reduce of the 200 x ceil(L / 800) row-first hit lists (17 KB at the headline size; which rays
-//                        they are is known only after the first one)
+//   1. after intersect : the sampler's tail quirk depends on a ray's GLOBAL hit rank and on the hit COUNT of the first ray of its
+//                        batch row (sample_gpu.cu:224-237 tests pts_idx[curr_bin] == -1 on that ray's packed list) -> ONE
+//                        all-gather of [96-byte counter block | a byte per ray: its hit count] (16 KB per rank at the headline size);
+//                        every rank derives the row-first table from the gathered counts (nl_dist.hip k_x1_merge)
 //   2. after sampling  : criterion.py:84-88 weights and the R*S mean divisor are global -> all-gather of the counter blocks, the
 //                        touched-rows bitmaps riding along
-//   3. gradients       : ONE grouped SUM all-reduce (decoder gradient | fp64 pose partials | embedding accumulators, dense or
-//                        packed touched rows); then every rank applies the identical optimiser step to its replica.
-// Four collectives per iteration, all on the stream the kernels run on: a sharded iteration is one C call (nl_iteration) with no
-// host work between its launches, and hipGraph-capturable (RCCL collectives are).
+//   3. gradients       : a grouped SUM all-reduce of [fp64 pose partials | embedding accumulators, dense or packed touched rows] issued
+//                        right after the scatter on a SIDE stream, under the dW2 kernel and the slab reduction (event fork / join inside
+//                        nl_iteration), then the decoder gradient's all-reduce (282 KB); every rank applies the identical optimiser step.
+// Three collectives on the critical path of an iteration (exchange 1, exchange 2, the decoder gradient) + one hidden under compute; a
+// sharded iteration is one C call (nl_iteration) with no host work between its launches, and hipGraph-capturable (RCCL collectives
+// and cross-stream event dependencies are).
 //
 // RCCL binding: the functions are looked up ONLY in an RCCL the process has already loaded (torch ships its own librccl.so and
 // ProcessGroupNCCL hands out its ncclComm_t) - dlopen(NULL) / RTLD_NOLOAD on the loaded object: no second RCCL, no second communicator.
@@ -113,13 +115,15 @@ int nl_comm_init_rccl(NlComm* out, void* nccl_comm, int world, int rank)
 
 int nl_exchange_after_intersect(const NlIterDesc* d, void* stream)
 {
-    if (!d || !comm_ok(d->comm) || !d->counters || !d->xg_recv || d->xg_stride < CNT_STRIDE || !d->row_first || d->row_first_entries <= 0)
+    if (!d || !comm_ok(d->comm) || !d->counters || !d->hit_count || !d->x1_send || !d->x1_recv || d->x1_rays < d->N || (d->x1_rays & 7) ||
+        d->x1_stride_bytes < CNT_STRIDE * 4 + d->x1_rays || (d->x1_stride_bytes & 7) || !d->row_first || d->row_first_entries <= 0)
         return X_ERR_INVALID_ARG;
     const NlComm* c = d->comm;
-    X_TRY(c->all_gather(c->ctx, d->counters, d->xg_recv, CNT_STRIDE * 4, stream));
-    X_TRY(nl_dist_merge_counters(d->xg_recv, c->world, c->rank, 1, d->counters, stream));
-    X_TRY(nl_dist_row_first(d->counters, d->hit_idx, d->hit_count, d->ray_of_rank, d->row_first, d->row_first_entries, stream));
-    return c->all_reduce_sum(c->ctx, d->row_first, (long long)d->row_first_entries * (1 + NL_MAX_HITS), NL_COMM_I32, stream);
+    // ONE all-gather of [counter block | a byte per ray: its hit count]; the row-first table of the sampler's tail quirk follows from the
+    // gathered counts on every rank (nl_dist.hip k_x1_merge) - no second collective
+    X_TRY(nl_dist_x1_pack(d->counters, d->hit_count, d->N, d->x1_rays, (int*)d->x1_send, stream));
+    X_TRY(c->all_gather(c->ctx, d->x1_send, d->x1_recv, d->x1_stride_bytes, stream));
+    return nl_dist_x1_merge(d->x1_recv, d->x1_stride_bytes, c->world, c->rank, d->x1_rays, d->counters, d->row_first, d->row_first_entries, stream);
 }
 
 int nl_exchange_after_sampling(const NlIterDesc* d, void* stream)
@@ -147,13 +151,15 @@ int nl_exchange_after_sampling(const NlIterDesc* d, void* stream)
     return nl_loss_finalize(d->counters, d->loss_scalars, d->fs_weight, d->sdf_weight, d->truncation, d->max_distance, d->P_cap, stream);
 }
 
-int nl_exchange_gradients(const NlIterDesc* d, void* stream)
+// embedding accumulators (dense, or the union's rows packed) + fp64 pose partials: one grouped SUM all-reduce
+int nl_exchange_emb_pose(const NlIterDesc* d, void* stream)
 {
     if (!d || !comm_ok(d->comm)) return X_ERR_INVALID_ARG;
     const NlComm* c = d->comm;
     const bool rows = d->want_emb_grad && d->rows_mode == 1;
     int* fail = d->adam_state ? d->adam_state + 3 : nullptr;             // the latched "call invalid" word (nl_optimiser_step)
     if (d->want_emb_grad && !d->g_emb) return X_ERR_INVALID_ARG;
+    if (!d->want_emb_grad && !d->want_pose_grad) return X_OK;
     if (rows) {
         if (!d->rows_buf || d->rows_cap <= 0 || !d->rows_bitmap || !d->rows_prefix) return X_ERR_INVALID_ARG;
         // slots beyond the union are never unpacked, so the buffer needs no clearing
@@ -161,7 +167,6 @@ int nl_exchange_gradients(const NlIterDesc* d, void* stream)
     }
     X_TRY(c->group_begin(c->ctx));
     int rc = X_OK;
-    if (rc == X_OK && d->train_decoder) rc = c->all_reduce_sum(c->ctx, d->dec_grad, NL_DEC_PARAMS, NL_COMM_F32, stream);
     if (rc == X_OK && d->want_pose_grad) rc = c->all_reduce_sum(c->ctx, d->g_pose, (long long)d->F * 12, NL_COMM_F64, stream);
     if (rc == X_OK && d->want_emb_grad)
         rc = rows ? c->all_reduce_sum(c->ctx, d->rows_buf, (long long)d->rows_cap * NL_EMB_CHANNELS, NL_COMM_F32, stream)
@@ -174,6 +179,48 @@ int nl_exchange_gradients(const NlIterDesc* d, void* stream)
         X_TRY(nl_dist_rows_move_t(1, d->rows_bitmap, d->rows_prefix, d->rows_words, d->g_emb, d->rows_buf, d->rows_cap, fail,
                                   d->touched_flags ? &touched : nullptr, stream));
     }
+    return X_OK;
+}
+
+int nl_exchange_decoder(const NlIterDesc* d, void* stream)
+{
+    if (!d || !comm_ok(d->comm)) return X_ERR_INVALID_ARG;
+    if (!d->train_decoder) return X_OK;
+    const NlComm* c = d->comm;
+    return c->all_reduce_sum(c->ctx, d->dec_grad, NL_DEC_PARAMS, NL_COMM_F32, stream);
+}
+
+// the whole gradient exchange on one stream (the stage-wise hook; the first iteration of a touched-rows call, whose row exchange is sized
+// between the backward pass and this call).  nl_iteration otherwise issues the two halves itself, the first one under the dW2 kernel.
+int nl_exchange_gradients(const NlIterDesc* d, void* stream)
+{
+    X_TRY(nl_exchange_emb_pose(d, stream));
+    return nl_exchange_decoder(d, stream);
+}
+
+/* the side stream + the two events of the overlapped gradient exchange (NlIterDesc.comm_stream / ev_fork / ev_join): created once per
+ * engine by the host, never on the hot path */
+int nl_overlap_create(void** comm_stream, void** ev_fork, void** ev_join)
+{
+    if (!comm_stream || !ev_fork || !ev_join) return X_ERR_INVALID_ARG;
+    hipStream_t s = nullptr; hipEvent_t a = nullptr, b = nullptr;
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) return X_ERR_LAUNCH;
+    if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+        if (a) (void)hipEventDestroy(a);
+        (void)hipStreamDestroy(s);
+        return X_ERR_LAUNCH;
+    }
+    *comm_stream = s; *ev_fork = a; *ev_join = b;
+    return X_OK;
+}
+
+int nl_overlap_destroy(void* comm_stream, void* ev_fork, void* ev_join)
+{
+    if (ev_fork) (void)hipEventDestroy((hipEvent_t)ev_fork);
+    if (ev_join) (void)hipEventDestroy((hipEvent_t)ev_join);
+    if (comm_stream) (void)hipStreamDestroy((hipStream_t)comm_stream);
     return X_OK;
 }
 

@@ -1473,28 +1473,6 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_inverse_cdf_raw(
 // =============================================================================================
 // C ABI launchers (declared in include/nerfloam_hip.h)
 // =============================================================================================
-// row-first hit lists of this rank (nl_dist_row_first): 32 lanes per table entry
-__global__ void k_dist_row_first(const int* __restrict__ counters, const int* __restrict__ hit_idx, const int* __restrict__ hit_count,
-                                 const int* __restrict__ ray_of_rank, int* __restrict__ table, int n_entries)
-{
-    const int e = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
-    if (e >= n_entries || l > NL_MAX_HITS) return;
-    const int Rg = counters[NLC_R_GLOBAL], off = counters[NLC_R_OFFSET], R = counters[NLC_R];
-    const int L = (Rg + NL_SAMPLER_G - 1) / NL_SAMPLER_G;
-    const int nch = L > 0 ? (L + NL_SAMPLER_CHUNK - 1) / NL_SAMPLER_CHUNK : 1;
-    int v = 0;
-    if (L > 0 && e < NL_SAMPLER_G * nch) {
-        int first = (e / nch) * L + (e % nch) * NL_SAMPLER_CHUNK;
-        if (first >= Rg) first = 0;                                  // padding rows replicate hit-ray 0
-        const int loc = first - off;
-        if (loc >= 0 && loc < R) {
-            const int ray = ray_of_rank[loc], cnt = hit_count[ray];
-            v = l == 0 ? cnt : (l - 1 < cnt ? hit_idx[(size_t)ray * NL_MAX_HITS + l - 1] + 1 : 0);
-        }
-    }
-    table[(size_t)e * (1 + NL_MAX_HITS) + l] = v;
-}
-
 extern "C" {
 
 int nl_svo_intersect(const float* ray_start, const float* ray_dir, const float* points, const int* children,
@@ -1708,21 +1686,6 @@ int nl_sample_rays_fused(int N, const int* hit_idx, const float* hit_t0, const f
     fa.samp_off_out = samp_off; fa.wg_state = (unsigned long long*)state;
     fa.ls = (NlLossScalars*)loss_scalars; fa.fs_weight = fs_weight; fa.sdf_weight = sdf_weight;
     hipLaunchKernelGGL(k_sample_fused, dim3(nl_div_up(N, SP_RAYS)), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, fa);
-    NL_LAUNCH_CHECK();
-    return NL_OK;
-}
-
-/* Multi-GPU (dist.py): the sampler's closing loop consults the hit list of the FIRST ray of a ray's batch row (sample_gpu.cu:231,
- * SURVEY B5); under ray sharding that ray may live on another rank.  After exchange 1 (global hit count, rank offset) every rank
- * writes the lists of the row-first rays IT owns into table[entry][1 + NL_MAX_HITS] = (count, idx + 1, ...) and zeros elsewhere; one
- * SUM all-reduce of the table then gives every rank every list (nl_sample_rays' row_first argument).  entries >= 200 *
- * ceil(ceil(R_global / 200) / 800). */
-int nl_dist_row_first(const int* counters, const int* hit_idx, const int* hit_count, const int* ray_of_rank, int* table, int n_entries,
-                      void* stream)
-{
-    if (!counters || !hit_idx || !hit_count || !ray_of_rank || !table || n_entries <= 0) return NL_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_dist_row_first, dim3(nl_div_up(n_entries, 8)), dim3(256), 0, (hipStream_t)stream, counters, hit_idx, hit_count,
-                       ray_of_rank, table, n_entries);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

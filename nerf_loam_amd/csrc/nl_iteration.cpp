@@ -19,6 +19,7 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
     const NlTouchedRows touched_rows = {d->touched_list, d->touched_count, d->touched_flags};
     const NlTouchedRows* touched = d->touched_flags ? &touched_rows : nullptr;      // rows written by the scatter are recorded
     int rc = IT_OK;
+    bool overlapped = false;
 #define NL_TRY(call) do { rc = (call); if (rc != IT_OK) return rc; } while (0)
     if (stages & 1) {
         int* c = d->counters;
@@ -52,15 +53,34 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
                                    d->vertex_rows, d->emb, d->voxel_size, d->X, d->field_blocks, stream));
         NL_TRY(nl_decoder_fwd_bwd_m(d->loss_scalars, d->X, d->dec_params, d->dec_ws, d->s_ray, d->s_depth, d->cos_gt, d->gt_dist, d->sdf, d->dsdf,
                                     d->dX, d->partials, d->relu2_mask, d->n_slabs, d->train_decoder, c, d->kernel_modes, stream));
+        // ray-sharded with the gradient exchange in the same call: the embedding scatter goes FIRST and its all-reduce (the large message:
+        // 64 B per embedding row or per touched row, + the pose partials) leaves on the side stream while dW2 and the slab reduction run
+        // ("overlap the embedding-grad reduce with the decoder wgrad"); the decoder gradient's all-reduce follows the join.
+        // Same kernels on the same data as the serial order - the two halves touch disjoint buffers - so the results are those of the
+        // serial order bit for bit.
+        overlapped = sharded && (stages & 4) && d->comm_stream && d->ev_fork && d->ev_join;
+        if (overlapped) {
+            hipStream_t cs = (hipStream_t)d->comm_stream;
+            NL_TRY(nl_trilinear_bwd_t(d->loss_scalars, d->s_vox, d->s_depth, d->s_ray, d->rays_d_world, d->rays_d_sensor, d->frame_id, d->poses12, d->F,
+                                      d->centres, d->vertex_rows, d->emb, d->voxel_size, d->dX, d->want_emb_grad ? d->g_emb : nullptr,
+                                      d->want_pose_grad ? d->g_pose : nullptr, 2 * d->field_blocks, touched, stream));
+            if (hipEventRecord((hipEvent_t)d->ev_fork, st) != hipSuccess || hipStreamWaitEvent(cs, (hipEvent_t)d->ev_fork, 0) != hipSuccess) return IT_ERR_LAUNCH;
+            NL_TRY(nl_exchange_emb_pose(d, d->comm_stream));
+            if (hipEventRecord((hipEvent_t)d->ev_join, cs) != hipSuccess) return IT_ERR_LAUNCH;
+        }
         if (d->train_decoder) {
             NL_TRY(nl_decoder_wgrad2_m(d->loss_scalars, d->X, d->dec_params, d->dsdf, d->relu2_mask, d->partials, d->n_slabs, d->kernel_modes, stream));
             NL_TRY(nl_decoder_reduce_m(d->partials, d->n_slabs, d->dec_params, d->dec_grad, d->kernel_modes, stream));
         }
+        if (overlapped) {
+            if (hipStreamWaitEvent(st, (hipEvent_t)d->ev_join, 0) != hipSuccess) return IT_ERR_LAUNCH;
+            NL_TRY(nl_exchange_decoder(d, stream));
+        } else
         NL_TRY(nl_trilinear_bwd_t(d->loss_scalars, d->s_vox, d->s_depth, d->s_ray, d->rays_d_world, d->rays_d_sensor, d->frame_id, d->poses12, d->F,
                                   d->centres, d->vertex_rows, d->emb, d->voxel_size, d->dX, d->want_emb_grad ? d->g_emb : nullptr,
                                   d->want_pose_grad ? d->g_pose : nullptr, 2 * d->field_blocks, touched, stream));
     }
-    if ((stages & 4) && sharded) NL_TRY(nl_exchange_gradients(d, stream));
+    if ((stages & 4) && sharded && !overlapped) NL_TRY(nl_exchange_gradients(d, stream));
     if (stages & 2) {
         const bool hand_over = d->counters_copy && (stages & 1);       // only a whole iteration leaves the block to the next one
         NL_TRY(nl_optimiser_step_t(d->adam_state, d->lr_emb, d->lr_dec, d->lr_pose,

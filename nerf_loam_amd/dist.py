@@ -2,16 +2,18 @@
 
 The reference has no distributed code.  Rays are independent up to three reductions:
 
-  1. after intersect : the sampler's tail quirk depends on a ray's GLOBAL hit rank and on the hit list of the first ray of its batch
-                       row (sample_gpu.cu:231): all-gather of the 96-byte counter blocks (-> global hit-ray count, this
-                       rank's hit-rank offset, global max hits), then a SUM all-reduce of the 200 x ceil(L / 800) row-first hit lists
-                       (which rays those are is known only after the first collective).  With them the samples of a sharded run are
-                       bit-identical to the unsharded run.
+  1. after intersect : the sampler's tail quirk depends on a ray's GLOBAL hit rank and on the hit COUNT of the first ray of its batch row
+                       (sample_gpu.cu:224-237 tests `pts_idx[curr_bin] == -1` on that ray's packed hit list): ONE all-gather of
+                       [96-byte counter block | a byte per ray: its hit count] (-> global hit-ray count, this rank's hit-rank offset,
+                       global max hits, and - a prefix sum over the gathered bytes - the row-first table, computed by every rank for
+                       itself).  With it the samples of a sharded run are bit-identical to the unsharded run.
   2. after sampling  : criterion.py:84-88 weights and the R*S mean divisor are global: all-gather of the counter blocks (loss
                        normalisers SUM, max samples per ray MAX), the touched-rows bitmaps riding along.
-  3. gradients       : ONE grouped SUM all-reduce of the decoder gradient, the fp64 pose partials [F,12] and the embedding accumulators -
-                       dense ([E,16] fp32) on a small map, or only the rows the iteration touches; every rank then applies the identical
-                       optimiser step to its replica.
+  3. gradients       : a grouped SUM all-reduce of the fp64 pose partials [F,12] and the embedding accumulators - dense ([E,16] fp32) on a
+                       small map, or only the rows the iteration touches - issued right after the embedding scatter on a SIDE stream, under
+                       the dW2 kernel and the slab reduction (event fork / join inside nl_iteration); then the decoder gradient's
+                       all-reduce (282 KB).  Every rank then applies the identical optimiser step to its replica.
+  Three collectives on an iteration's critical path + one hidden under compute.
 
 Where the exchanges run.  On the GPU they are issued FROM C, on the stream the kernels run on (csrc/nl_exchange.cpp: nl_exchange_* /
 inside nl_iteration), through a four-function communicator (NlComm, include/nerfloam_hip.h):
@@ -102,12 +104,20 @@ class _TorchComm:
             self.error = e
             return 2
 
+    @staticmethod
+    def _on(stream, t):
+        """the collective is enqueued on the stream the C side names (the launch stream, or the side stream of the overlapped gradient
+        exchange): torch.distributed orders its work after torch's CURRENT stream"""
+        import contextlib
+        return torch.cuda.stream(torch.cuda.ExternalStream(int(stream))) if (stream and t.is_cuda) else contextlib.nullcontext()
+
     def _all_gather(self, ctx, send, recv, nbytes, stream):
         def run():
             s = self._view(send, nbytes)
             r = self._view(recv, nbytes * self.world)
             assert s.dtype == r.dtype
-            dist.all_gather_into_tensor(r, s, group=self.group)
+            with self._on(stream, s):
+                dist.all_gather_into_tensor(r, s, group=self.group)
         return self._guard(run)
 
     def _all_reduce(self, ctx, buf, count, dtype, stream):
@@ -115,7 +125,8 @@ class _TorchComm:
             size = {L.NL_COMM_F32: 4, L.NL_COMM_F64: 8, L.NL_COMM_I32: 4}[dtype]
             t = self._view(buf, count * size)
             assert t.dtype == {L.NL_COMM_F32: torch.float32, L.NL_COMM_F64: torch.float64, L.NL_COMM_I32: torch.int32}[dtype]
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            with self._on(stream, t):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return self._guard(run)
 
     def _group(self, ctx):
@@ -123,10 +134,14 @@ class _TorchComm:
 
 
 class RayShardedExchange:
-    def __init__(self, engine, group=None, sparse_rows="auto", backend="auto"):
+    def __init__(self, engine, group=None, sparse_rows="auto", backend="auto", overlap=True):
         """sparse_rows: "auto" (touched-rows exchange when it moves less than half of the dense table), True, False.
-        backend: "rccl" | "torch" | "auto" (rccl when the process group is ProcessGroupNCCL and exposes its communicator)."""
+        backend: "rccl" | "torch" | "auto" (rccl when the process group is ProcessGroupNCCL and exposes its communicator).
+        overlap: the [pose partials | embedding accumulators] all-reduce leaves on a side stream right after the scatter, under the dW2
+        kernel and the slab reduction (False: every exchange on the launch stream - same results bit for bit)."""
         self.group = group
+        self.overlap = bool(overlap)
+        self._overlap_handles = None
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.eng = engine
@@ -171,13 +186,33 @@ class RayShardedExchange:
         else:
             raise ValueError(backend)
         self.backend = backend
-        self._entries = row_first_entries(eng.N_cap * self.world)
+        # exchange 1: every rank sends [counter block | a byte per ray]; the all-gather needs ONE block size, so the ranks agree on the
+        # largest ray capacity among them (one host collective at set-up)
+        cap = torch.tensor([eng.N_cap], dtype=torch.int32, device=dev)
+        dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=self.group)
+        self._x1_rays = (int(cap.item()) + 7) & ~7
+        self._x1_stride = CNT_STRIDE * 4 + self._x1_rays
+        self._x1_send = torch.zeros(self._x1_stride // 4, dtype=torch.int32, device=dev)
+        self._x1_recv = torch.zeros(self.world * self._x1_stride // 4, dtype=torch.int32, device=dev)
+        self._entries = row_first_entries(self._x1_rays * self.world)
         self._row_first = torch.zeros(self._entries, 1 + L.NL_MAX_HITS, dtype=torch.int32, device=dev)
         eng.row_first = self._row_first
+        if self.overlap:
+            h = (ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p())
+            L.check(L.lib().nl_overlap_create(ctypes.byref(h[0]), ctypes.byref(h[1]), ctypes.byref(h[2])), "nl_overlap_create")
+            self._overlap_handles = h
         self._xg_stride = CNT_STRIDE
         self._xg_send = None
         self._xg_recv = self._gather
         self._fill_desc()
+
+    def __del__(self):
+        h, self._overlap_handles = getattr(self, "_overlap_handles", None), None
+        if h is not None:
+            try:
+                L.lib().nl_overlap_destroy(h[0], h[1], h[2])
+            except Exception:                # noqa: BLE001 - interpreter shutdown
+                pass
 
     def _nccl_comm_ptr(self):
         try:
@@ -196,6 +231,9 @@ class RayShardedExchange:
         d.xg_send = None if self._xg_send is None else self._xg_send.data_ptr()
         d.xg_recv, d.xg_stride = self._xg_recv.data_ptr(), self._xg_stride
         d.row_first, d.row_first_entries = self._row_first.data_ptr(), self._entries
+        d.x1_send, d.x1_recv, d.x1_stride_bytes, d.x1_rays = self._x1_send.data_ptr(), self._x1_recv.data_ptr(), self._x1_stride, self._x1_rays
+        h = self._overlap_handles
+        d.comm_stream, d.ev_fork, d.ev_join = (None, None, None) if h is None else (h[0].value, h[1].value, h[2].value)
         st = self._rows
         if st is None:
             d.rows_mode, d.rows_bitmap, d.rows_prefix, d.rows_total, d.rows_ws, d.rows_buf, d.rows_cap, d.rows_words = 0, None, None, None, None, None, 0, 0
@@ -209,7 +247,7 @@ class RayShardedExchange:
         if self._torch_comm is not None:
             tc = self._torch_comm
             tc.buffers.clear()
-            tc.register(eng.counters, self._xg_recv, self._xg_send, self._row_first, eng.g_pose, eng.g_emb, None if st is None else st.get("buf"))
+            tc.register(eng.counters, self._xg_recv, self._xg_send, self._x1_send, self._x1_recv, eng.g_pose, eng.g_emb, None if st is None else st.get("buf"))
             dec = getattr(eng, "_dec_for_exchange", None)
             if dec is not None:
                 tc.register(dec.grad)

@@ -41,13 +41,13 @@ def main():
     cfg = P.IterConfig(step_size=float(g["step_size"]), noise_seed=7)
     out = {}
 
-    def run(mode, pad_rows=0, sparse_rows="auto", iters=3):
+    def run(mode, pad_rows=0, sparse_rows="auto", iters=3, overlap=True):
         ms = sc["ms"]
         emb = ms.emb if not pad_rows else np.concatenate([ms.emb, np.zeros((pad_rows, 16), np.uint16)])
         m = P.MapDevice(ms.centres, ms.structure, ms.vertex_idx, ms.id2row, emb, ms.voxel_size)
         dec = P.DecoderDevice(dec_np.W1, dec_np.b1, dec_np.W2, dec_np.b2, dec_np.W3, dec_np.b3)
         eng = P.SdfEngine(max_rays=len(rays), samples_per_ray_cap=64, max_frames=max(2, nf))
-        ex = D.RayShardedExchange(eng, sparse_rows=sparse_rows, backend="rccl") if mode != "plain" else None
+        ex = D.RayShardedExchange(eng, sparse_rows=sparse_rows, backend="rccl", overlap=overlap) if mode != "plain" else None
         eng.set_rays(rays, pts, cos, fid)
         eng.set_poses(poses, [1] * nf)
         eng.begin_call(m, dec)
@@ -55,6 +55,15 @@ def main():
             eng.capture_iteration(m, dec, cfg, train_decoder=True)
             for _ in range(iters):
                 eng.replay()
+        elif mode == "boundgraph":                               # the ONE-C-CALL iteration (overlapped exchange: side stream, event fork / join) in a hipGraph
+            eng.bind(m, dec, cfg, train_decoder=True)
+            eng.run_bound()
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                eng.run_bound()
+            for _ in range(iters - 1):
+                gr.replay()
         elif mode == "stagewise":
             for _ in range(iters):
                 eng.forward_backward(m, dec, cfg, train_decoder=True)
@@ -67,6 +76,14 @@ def main():
         st = eng.call_status()
         res = dict(params=dec.params.cpu().numpy().copy(), emb=m.emb.cpu().numpy().copy(), pose6=eng.pose6[:nf].cpu().numpy().copy(), status=st,
                    rows_cap=None if ex is None else ex._rows_cap, backend=None if ex is None else ex.backend)
+        if mode == "boundgraph":
+            ts = []
+            for _ in range(3):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(20):
+                    gr.replay()
+                torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / 20 * 1e3)
+            res["ms_per_iter"] = float(np.median(ts))
         if mode == "onecall":                                   # what the exchanges cost per iteration on this (one-rank) communicator
             ts = []
             for _ in range(3):
@@ -80,8 +97,9 @@ def main():
     plain = run("plain")
     out["steps_plain"] = plain["status"][0]
     ok = True
-    for name, kw in (("onecall", {}), ("stagewise", {}), ("graph", {}), ("onecall_rows", dict(pad_rows=400000)), ("graph_rows", dict(pad_rows=400000)),
-                     ("onecall_dense_forced", dict(sparse_rows=False))):
+    for name, kw in (("onecall", {}), ("onecall_serial", dict(overlap=False)), ("stagewise", {}), ("graph", {}), ("boundgraph", {}),
+                     ("onecall_rows", dict(pad_rows=400000)), ("onecall_rows_serial", dict(pad_rows=400000, overlap=False)), ("graph_rows", dict(pad_rows=400000)),
+                     ("boundgraph_rows", dict(pad_rows=400000)), ("onecall_dense_forced", dict(sparse_rows=False))):
         mode = name.split("_")[0]
         r = run(mode, **{k: v for k, v in kw.items()})
         base = plain if not kw.get("pad_rows") else run("plain", pad_rows=kw["pad_rows"])

@@ -1035,7 +1035,7 @@ class _ThreadRanks:
             raise NotImplementedError(op)
 
 
-def _sharded_vs_single(nl, golden_dir, monkeypatch, world, pad_rows=0, sparse_rows="auto", one_call=False):
+def _sharded_vs_single(nl, golden_dir, monkeypatch, world, pad_rows=0, sparse_rows="auto", one_call=False, overlap=True):
     """ray-sharded iteration (the exchanges of nerf_loam_amd/dist.py, real kernels, `world` ranks as threads on one GPU) against the
     unsharded one on the same ray list"""
     import threading
@@ -1095,7 +1095,7 @@ def _sharded_vs_single(nl, golden_dir, monkeypatch, world, pad_rows=0, sparse_ro
             fake.tl.rank = r
             torch.cuda.set_device(0)
             lo, hi = D.shard_bounds(N, r, world)
-            res[r] = run(lo, hi, lambda eng: D.RayShardedExchange(eng, sparse_rows=sparse_rows))
+            res[r] = run(lo, hi, lambda eng: D.RayShardedExchange(eng, sparse_rows=sparse_rows, overlap=overlap))
         except Exception as e:                                   # noqa: BLE001
             import traceback
             errs.append(traceback.format_exc()); fake.bar.abort()
@@ -1118,6 +1118,7 @@ def _sharded_vs_single(nl, golden_dir, monkeypatch, world, pad_rows=0, sparse_ro
     for k, tol in (("gdec", 1e-5), ("gemb", 1e-5), ("gpose", 1e-6)):       # (gpose: fp32 over a ray's samples inside one lane group, then fp64)
         assert np.linalg.norm(a[k].astype(np.float64) - one[k]) <= tol * np.linalg.norm(one[k].astype(np.float64)), k
     assert np.abs(a["params"] - one["params"]).max() < 1e-5 and np.abs(a["pose6"] - one["pose6"]).max() < 1e-6
+    info["rank0"] = a
     return info
 
 
@@ -1133,6 +1134,21 @@ def test_eight_virtual_ranks_with_the_touched_rows_exchange(nl, golden_dir, monk
     """8 ranks, an embedding table 30x the rows the iteration touches: the embedding gradients travel as [capacity, 16] touched rows"""
     info = _sharded_vs_single(nl, golden_dir, monkeypatch, 8, pad_rows=400000, sparse_rows="auto", one_call=one_call)
     assert isinstance(info["rows_cap"], int) and info["rows_cap"] < 100000
+
+
+@pytest.mark.parametrize("world,pad_rows", [(2, 0), (8, 400000)])
+def test_overlapped_gradient_exchange_equals_the_serial_one(nl, golden_dir, monkeypatch, world, pad_rows):
+    """nl_iteration with the [pose | embedding] all-reduce on the side stream under dW2 + slab reduction (event fork / join) against the same
+    iteration with every exchange on the launch stream: every gradient, every parameter after the optimiser step - bit for bit (dense and
+    touched-rows exchange).  The two orders run the same kernels on the same data; only when things run differs."""
+    a = _sharded_vs_single(nl, golden_dir, monkeypatch, world, pad_rows=pad_rows, one_call=True, overlap=True)["rank0"]
+    b = _sharded_vs_single(nl, golden_dir, monkeypatch, world, pad_rows=pad_rows, one_call=True, overlap=False)["rank0"]
+    for k in ("sdf", "depth", "vox", "gdec", "params", "pose6"):
+        assert np.array_equal(a[k], b[k]), k
+    np.testing.assert_allclose(a["gpose"], b["gpose"], rtol=1e-10, atol=1e-300)     # (fp64 atomics: order-independent to ~1e-13, not bitwise)
+    # (the embedding accumulators are summed by fp32 atomics whose order is not fixed between two runs: last-bit noise, see tests/test_gpu_stress.py)
+    assert np.abs(a["gemb"].astype(np.float64) - b["gemb"]).max() <= 2e-5 * np.abs(b["gemb"]).max()
+    assert (a["emb"] != b["emb"]).mean() < 1e-3
 
 
 @pytest.mark.parametrize("mode", [0, 1])
