@@ -709,7 +709,10 @@ def main():
     N = len(w["points"])
     lo, hi = D.shard_bounds(N, rank, world)
     eng = P.SdfEngine(max_rays=hi - lo, samples_per_ray_cap=48, device=device)
-    ex = D.RayShardedExchange(eng) if shard else None         # backend "rccl": the exchanges are issued from C inside nl_iteration
+    # backend "rccl": the exchanges are issued from C inside nl_iteration; the timed iterations are hipGraph replays of that one C call
+    # (BASELINE config 5), so the [pose | embedding] all-reduce rides a side stream under dW2 + slab reduction at no cost (a graph edge)
+    use_graph = shard and os.environ.get("NL_BENCH_SHARD_GRAPH", "1") != "0"
+    ex = D.RayShardedExchange(eng, overlap=use_graph) if shard else None
     # balanced shards: the scan is beam-major and beams differ several-fold in voxels/samples per ray, so each rank takes every
     # world-th return instead of a block of whole beams (identity for one GPU; scripts/shard_probe.py, profiles/r01_k_shard_probe.txt)
     order = D.interleaved_order(N, world)
@@ -724,9 +727,11 @@ def main():
         # ray-sharded: ONE C call per iteration (nl_iteration: kernels + the four RCCL collectives on the launch stream)
         eng.bind(w["map"], w["dec"], cfg, train_decoder=train_dec, update_decoder=train_dec, ray_id_base=lo)
 
+    graph = [None]
+
     def step():
         if shard:
-            eng.run_bound()
+            graph[0].replay() if graph[0] is not None else eng.run_bound()
             return
         eng.forward_backward(w["map"], w["dec"], cfg, train_decoder=train_dec, ray_id_base=lo)
         eng.optimiser_step(w["map"], w["dec"], cfg, update_decoder=train_dec)
@@ -742,9 +747,23 @@ def main():
             step()
         torch.cuda.synchronize()
         return
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 2) if shard else args.warmup):   # (sharded: the first iteration sizes the row exchange of the call)
         step()
     barrier()
+    graph_note = None
+    if use_graph:
+        try:
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_):
+                eng.run_bound()
+            graph[0] = g_
+            step()
+            barrier()
+            graph_note = "hipGraph replay of the one-C-call iteration (kernels + RCCL collectives, side-stream fork / join as graph edges)"
+        except Exception as e:                                       # noqa: BLE001 - report, fall back to eager launches
+            graph[0] = None
+            graph_note = "eager launches (hipGraph capture failed: " + repr(e)[:160] + ")"
+            torch.cuda.synchronize()
     # per-kernel events for the roofline object (same stream as the launches)
     ev = [{n: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for n in ("decoder", "wgrad2")}
           for _ in range(args.steps)]
@@ -769,6 +788,7 @@ def main():
         import torch.distributed as tdist
         # (a) the same iterations without the communicator (every rank on its own share, no exchange): what the collectives cost;
         # (b) a short stage-wise pass with the per-kernel events for the roofline object (the hooks run the same C exchanges)
+        graph[0] = None                                           # (the remaining passes launch eagerly)
         d = eng._desc
         comm_ptr, d.comm = d.comm, None
         eng._exchange = None
@@ -790,13 +810,13 @@ def main():
         tdist.all_gather_object(gathered, dict(rank=rank, rays=int(hi - lo), valid_samples=int(P_local), hit_rays=int(st["R"])))
         tl = torch.tensor([dt_local], dtype=torch.float64, device=device)
         tdist.all_reduce(tl, op=tdist.ReduceOp.MAX)
-        sharded = dict(rccl_world=world, exchange_backend=ex.backend, embedding_exchange=("dense" if ex._rows_cap == "dense" else f"touched rows, capacity {ex._rows_cap}"),
+        sharded = dict(rccl_world=world, exchange_backend=ex.backend, launch_mode=graph_note or "eager launches", gradient_exchange_overlapped=bool(ex.overlap), embedding_exchange=("dense" if ex._rows_cap == "dense" else f"touched rows, capacity {ex._rows_cap}"),
                        collectives_per_step="3 on the critical path (exchange 1, exchange 2, decoder gradient) + the [pose | embedding] all-reduce on a side stream under dW2", per_rank=gathered, ms_per_step_without_exchanges=float(tl.item()) / args.steps * 1e3,
                        exchange_ms_per_step=(dt - float(tl.item())) / args.steps * 1e3,
                        note="one C call per iteration (nl_iteration): ONE all-gather [counters | per-ray hit counts] after the intersect, counter all-gather "
                             "after the sampler, grouped all-reduce [fp64 pose partials | embedding accumulators] on a side stream right after the scatter "
                             "(under dW2 + slab reduction), decoder-gradient all-reduce after the join; "
-                            "exchange_ms_per_step = this run minus the same iterations with the communicator removed")
+                            "exchange_ms_per_step = this run minus the same iterations with the communicator removed (those launched eagerly, one C call each)")
     dec_ms = float(np.mean([e["decoder"][0].elapsed_time(e["decoder"][1]) for e in ev]))
     wg_ms = float(np.mean([e["wgrad2"][0].elapsed_time(e["wgrad2"][1]) for e in ev])) if train_dec else 0.0
     stage_ms, stage_bytes, hbm_entries = stage_rooflines(eng, w, cfg, train_dec) if not shard else ({}, {}, [])

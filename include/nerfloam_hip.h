@@ -378,7 +378,7 @@ typedef struct NlIterDesc {
      * write; sparse_sweep != 0: the optimiser sweeps the list, 0: the whole table (e.g. after a dense multi-GPU gradient exchange) */
     int* touched_list; int* touched_count; unsigned* touched_flags; int sparse_sweep;
     /* exchange 1 as one all-gather: x1_send [24 ints | x1_rays bytes] (a ray's hit count per byte), x1_recv [world] such blocks of
-     * x1_stride_bytes (a multiple of 8, >= 96 + x1_rays); x1_rays = the ranks' common ray capacity (a multiple of 8, >= every rank's N) */
+     * x1_stride_bytes (a multiple of 16, >= 96 + x1_rays); x1_rays = the ranks' common ray capacity (a multiple of 16, >= every rank's N) */
     void* x1_send; void* x1_recv; int x1_stride_bytes; int x1_rays;
     /* overlapped gradient exchange (optional; nl_overlap_create): with the three handles set, a stages & 5 == 5 call runs the embedding
      * scatter first and all-reduces [pose partials | embedding accumulators] on comm_stream under the dW2 kernel and the slab reduction
@@ -426,12 +426,15 @@ int nl_exchange_gradients(const NlIterDesc* desc, void* stream);
 /* side stream (highest priority) + two timing-less events for NlIterDesc.comm_stream / ev_fork / ev_join: once per engine, off the hot path */
 int nl_overlap_create(void** comm_stream, void** ev_fork, void** ev_join);
 int nl_overlap_destroy(void* comm_stream, void* ev_fork, void* ev_join);
-/* exchange 1: send block [24-int counter block | n_rays_cap bytes: hit count of ray i, 0 beyond N] (n_rays_cap a multiple of 8), and the
+/* exchange 1: send block [24-int counter block | n_rays_cap bytes: hit count of ray i, 0 beyond N] (n_rays_cap a multiple of 16), and the
  * fold of the gathered blocks [world][stride_bytes] into counters (NLC_R_GLOBAL, NLC_R_OFFSET, global NLC_HMAX) + the row-first table
  * [n_entries][1 + NL_MAX_HITS] = (count, 2 for bins below the count, 0 beyond) that nl_sample_rays reads; n_entries >= 200 *
  * ceil(ceil(R_global / 200) / 800).  Shards are contiguous blocks of the global ray order (rank-major). */
 int nl_dist_x1_pack(const int* counters, const int* hit_count, int N, int n_rays_cap, int* send, void* stream);
 int nl_dist_x1_merge(const void* gathered, int stride_bytes, int world, int rank, int n_rays_cap, int* counters, int* table, int n_entries, void* stream);
+/* exchange 2, receive side: stage 2 of nl_dist_merge_counters_strided + nl_loss_finalize on the merged block in one launch */
+int nl_dist_merge_finalize(const int* gathered, int stride_ints, int world, int* counters, void* loss_scalars, float fs_weight, float sdf_weight,
+                           float tau, float max_depth, int capacity, void* stream);
 /* gathered blocks `stride` ints apart (nl_dist_merge_counters: stride = the block itself) */
 int nl_dist_merge_counters_strided(const int* gathered, int stride_ints, int world, int rank, int stage, int* counters, void* stream);
 /* union[w] = OR over ranks of gathered[r * stride_ints + offset_ints + w]; then nl_dist_rows_prefix on the union */

@@ -104,6 +104,7 @@ _SIGS = {
     "nl_compact_hit_rays": ([_I, _P, _P, _P, _P], _I),
     "nl_scan_hit_rays": ([_P, _P, _P, _I, _P, _P, _P, _P], _I),
     "nl_sample_rays": ([_I, _I] + [_P] * 8 + [_F, _F, _F, _U, _I, _I, _I] + [_P, _P, _P, _P, _P, _I] + [_P] * 5, _I),
+    "nl_dist_merge_finalize": ([_P, _I, _I, _P, _P, _F, _F, _F, _F, _I, _P], _I),
     "nl_dist_x1_pack": ([_P, _P, _I, _I, _P, _P], _I),
     "nl_dist_x1_merge": ([_P, _I, _I, _I, _I, _P, _P, _I, _P], _I),
     "nl_exchange_emb_pose": ([_P, _P], _I),

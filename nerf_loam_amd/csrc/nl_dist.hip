@@ -121,28 +121,43 @@ __global__ __launch_bounds__(X1_THREADS) void k_x1_merge(const unsigned char* __
     if (r == 0) for (int e = (L > 0 ? used : 0) + tid; e < n_entries; e += X1_THREADS) x1_write_row(table, e, 0);    // entries no row uses
     if (tid == 0) s_cnt0 = -1;
     if (L == 0) return;
-    const unsigned char* bytes = recv + (size_t)r * stride_bytes + (NL_CNT_INTS + 2 * NL_CNT_DOUBLES) * 4;
-    const int per = (n_rays_cap + X1_THREADS - 1) / X1_THREADS, i0 = tid * per, i1 = min(n_rays_cap, i0 + per);
-    int mine = 0;
-    for (int i = i0; i < i1; ++i) mine += bytes[i] ? 1 : 0;
-    int incl = mine;                                              // inclusive scan over the workgroup: wave shuffles, then the wave totals
+    // a thread's 16 rays = one 16-byte load (n_rays_cap and the block stride are multiples of 16: the send block is laid out that way)
+    const uint4* words = reinterpret_cast<const uint4*>(recv + (size_t)r * stride_bytes + (NL_CNT_INTS + 2 * NL_CNT_DOUBLES) * 4);
+    const int chunks = n_rays_cap >> 4;
+    int q_block = off_r;                                          // hit rays of this slice in front of the current pass
+    for (int c0 = 0; c0 < chunks; c0 += X1_THREADS) {
+        const int ci = c0 + tid;
+        const uint4 v = ci < chunks ? words[ci] : make_uint4(0u, 0u, 0u, 0u);
+        const unsigned wd[4] = {v.x, v.y, v.z, v.w};
+        int mine = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-    if (lane == 63) s_wave[w] = incl;
-    __syncthreads();
-    int before = 0;
-    for (int q = 0; q < w; ++q) before += s_wave[q];
-    int q = off_r + before + incl - mine;                         // global hit rank of this thread's first hit ray
-    for (int i = i0; i < i1; ++i) {
-        const int c = bytes[i];
-        if (!c) continue;
-        if (q == 0) s_cnt0 = c;
-        const int within = q % L;
-        if (within % NL_SAMPLER_CHUNK == 0) {
-            const int e = (q / L) * nch + within / NL_SAMPLER_CHUNK;
-            if (e < n_entries) x1_write_row(table, e, c);
-        }
-        ++q;
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mine += ((wd[j] >> (8 * k)) & 255u) ? 1 : 0;
+        int incl = mine;                                          // inclusive scan over the workgroup: wave shuffles, then the wave totals
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+        __syncthreads();                                          // (the previous pass has read s_wave)
+        if (lane == 63) s_wave[w] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int k = 0; k < X1_THREADS / 64; ++k) { const int u = s_wave[k]; if (k < w) before += u; total += u; }
+        int q = q_block + before + incl - mine;                   // global hit rank of this thread's first hit ray
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = (int)((wd[j] >> (8 * k)) & 255u);
+                if (!c) continue;
+                if (q == 0) s_cnt0 = c;
+                const int within = q % L;
+                if (within % NL_SAMPLER_CHUNK == 0) {
+                    const int e = (q / L) * nch + within / NL_SAMPLER_CHUNK;
+                    if (e < n_entries) x1_write_row(table, e, c);
+                }
+                ++q;
+            }
+        q_block += total;
     }
     __syncthreads();
     const int cnt0 = s_cnt0;                                      // this slice holds hit-ray 0: the padding rows replicate it (voxel_helpers.py:278-284)
@@ -155,10 +170,10 @@ __global__ __launch_bounds__(X1_THREADS) void k_x1_merge(const unsigned char* __
 
 extern "C" {
 
-/* exchange 1, send side: send = [counter block (24 ints) | n_rays_cap bytes: hit count of ray i, 0 beyond N]; n_rays_cap a multiple of 8 */
+/* exchange 1, send side: send = [counter block (24 ints) | n_rays_cap bytes: hit count of ray i, 0 beyond N]; n_rays_cap a multiple of 16 */
 int nl_dist_x1_pack(const int* counters, const int* hit_count, int N, int n_rays_cap, int* send, void* stream)
 {
-    if (!counters || !hit_count || !send || N < 0 || n_rays_cap < N || (n_rays_cap & 7)) return NL_ERR_INVALID_ARG;
+    if (!counters || !hit_count || !send || N < 0 || n_rays_cap < N || (n_rays_cap & 15)) return NL_ERR_INVALID_ARG;
     const int threads = n_rays_cap / 4 > NL_CNT_INTS + 2 * NL_CNT_DOUBLES ? n_rays_cap / 4 : NL_CNT_INTS + 2 * NL_CNT_DOUBLES;
     hipLaunchKernelGGL(k_x1_pack, dim3(nl_div_up(threads, 256)), dim3(256), 0, (hipStream_t)stream, counters, hit_count, N, n_rays_cap, send);
     NL_LAUNCH_CHECK();
@@ -170,7 +185,7 @@ int nl_dist_x1_pack(const int* counters, const int* hit_count, int N, int n_rays
 int nl_dist_x1_merge(const void* gathered, int stride_bytes, int world, int rank, int n_rays_cap, int* counters, int* table, int n_entries, void* stream)
 {
     if (!gathered || !counters || !table || world <= 0 || rank < 0 || rank >= world || n_rays_cap <= 0 || n_entries <= 0 ||
-        stride_bytes < (NL_CNT_INTS + 2 * NL_CNT_DOUBLES) * 4 + n_rays_cap || (stride_bytes & 7))
+        stride_bytes < (NL_CNT_INTS + 2 * NL_CNT_DOUBLES) * 4 + n_rays_cap || (stride_bytes & 15) || (n_rays_cap & 15))
         return NL_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_x1_merge, dim3(world), dim3(X1_THREADS), 0, (hipStream_t)stream, (const unsigned char*)gathered, stride_bytes, world, rank,
                        n_rays_cap, counters, table, n_entries);

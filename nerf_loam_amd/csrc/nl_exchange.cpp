@@ -115,8 +115,8 @@ int nl_comm_init_rccl(NlComm* out, void* nccl_comm, int world, int rank)
 
 int nl_exchange_after_intersect(const NlIterDesc* d, void* stream)
 {
-    if (!d || !comm_ok(d->comm) || !d->counters || !d->hit_count || !d->x1_send || !d->x1_recv || d->x1_rays < d->N || (d->x1_rays & 7) ||
-        d->x1_stride_bytes < CNT_STRIDE * 4 + d->x1_rays || (d->x1_stride_bytes & 7) || !d->row_first || d->row_first_entries <= 0)
+    if (!d || !comm_ok(d->comm) || !d->counters || !d->hit_count || !d->x1_send || !d->x1_recv || d->x1_rays < d->N || (d->x1_rays & 15) ||
+        d->x1_stride_bytes < CNT_STRIDE * 4 + d->x1_rays || (d->x1_stride_bytes & 15) || !d->row_first || d->row_first_entries <= 0)
         return X_ERR_INVALID_ARG;
     const NlComm* c = d->comm;
     // ONE all-gather of [counter block | a byte per ray: its hit count]; the row-first table of the sampler's tail quirk follows from the
@@ -131,12 +131,12 @@ int nl_exchange_after_sampling(const NlIterDesc* d, void* stream)
     if (!d || !comm_ok(d->comm) || !d->counters || !d->xg_recv || d->xg_stride < CNT_STRIDE || !d->loss_scalars) return X_ERR_INVALID_ARG;
     const NlComm* c = d->comm;
     const bool rows = d->want_emb_grad && d->rows_mode == 1;
+    int stride = CNT_STRIDE;
     if (!rows) {
         X_TRY(c->all_gather(c->ctx, d->counters, d->xg_recv, CNT_STRIDE * 4, stream));
-        X_TRY(nl_dist_merge_counters(d->xg_recv, c->world, c->rank, 2, d->counters, stream));
     } else {
         // send block = [counter block | bitmap of the embedding rows this rank's hit voxels reference]
-        const int stride = CNT_STRIDE + d->rows_words;
+        stride = CNT_STRIDE + d->rows_words;
         if (!d->xg_send || d->xg_stride < stride || (stride & 1) || !d->rows_bitmap || !d->rows_prefix || !d->rows_total || !d->rows_ws || d->rows_words <= 0)
             return X_ERR_INVALID_ARG;
         hipStream_t st = (hipStream_t)stream;
@@ -144,11 +144,12 @@ int nl_exchange_after_sampling(const NlIterDesc* d, void* stream)
         if (hipMemsetAsync(d->xg_send + CNT_STRIDE, 0, (size_t)d->rows_words * 4, st) != hipSuccess) return X_ERR_LAUNCH;
         X_TRY(nl_dist_mark_rows(d->N, d->hit_idx, d->hit_count, d->vertex_rows, (unsigned*)(d->xg_send + CNT_STRIDE), stream));
         X_TRY(c->all_gather(c->ctx, d->xg_send, d->xg_recv, (long long)stride * 4, stream));
-        X_TRY(nl_dist_merge_counters_strided(d->xg_recv, stride, c->world, c->rank, 2, d->counters, stream));
         X_TRY(nl_dist_rows_union_prefix(d->xg_recv, stride, CNT_STRIDE, c->world, d->rows_bitmap, d->rows_words, d->rows_prefix, d->rows_total,
                                         d->rows_ws, stream));
     }
-    return nl_loss_finalize(d->counters, d->loss_scalars, d->fs_weight, d->sdf_weight, d->truncation, d->max_distance, d->P_cap, stream);
+    // gathered counter blocks -> summed loss normalisers, max samples per ray; the loss scalars of the merged block: one launch
+    return nl_dist_merge_finalize(d->xg_recv, stride, c->world, d->counters, d->loss_scalars, d->fs_weight, d->sdf_weight, d->truncation, d->max_distance,
+                                  d->P_cap, stream);
 }
 
 // embedding accumulators (dense, or the union's rows packed) + fp64 pose partials: one grouped SUM all-reduce

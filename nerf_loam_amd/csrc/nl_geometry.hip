@@ -1402,6 +1402,30 @@ __global__ void k_loss_finalize(int* __restrict__ counters, NlLossScalars* __res
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     loss_finalize_one(counters, ls, fs_weight, sdf_weight, tau, max_depth, capacity);
 }
+// ray-sharded iteration, exchange 2: the gathered counter blocks folded into the local one (summed loss normalisers / flags, max samples per
+// ray, summed padded-slot constants - stage 2 of k_dist_merge, nl_optim.hip) and the loss scalars from the merged block, in ONE launch
+__global__ void k_dist_merge_finalize(const int* __restrict__ gathered, int STRIDE, int world, int* __restrict__ counters, NlLossScalars* __restrict__ ls,
+                                      float fs_weight, float sdf_weight, float tau, float max_depth, int capacity)
+{
+    const int t = threadIdx.x;
+    if (t >= NLC_NFS && t <= NLC_GUARD) {                        // NFS, NSDF, INV_* (4), OVERFLOW, GUARD: contiguous
+        int sum = 0;
+        for (int r = 0; r < world; ++r) sum += gathered[r * STRIDE + t];
+        counters[t] = sum;
+    } else if (t == NLC_SMAX) {
+        int m = 0;
+        for (int r = 0; r < world; ++r) m = max(m, gathered[r * STRIDE + NLC_SMAX]);
+        counters[NLC_SMAX] = m;
+    } else if (t == 32 || t == 33) {
+        const int d = t == 32 ? NLD_INV_D2 : NLD_INV_D2CNT;
+        double sum = 0.0;
+        for (int r = 0; r < world; ++r) sum += reinterpret_cast<const double*>(gathered + r * STRIDE + NL_CNT_INTS)[d];
+        reinterpret_cast<double*>(counters + NL_CNT_INTS)[d] = sum;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (t == 0) loss_finalize_one(counters, ls, fs_weight, sdf_weight, tau, max_depth, capacity);
+}
 // the sample-offset scan of the launch-bound regime with the loss normalisers behind it (thread 0 wrote counters[NLC_P] itself)
 __global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_samples_finalize(const int* __restrict__ samp_count, int* __restrict__ samp_off, int n,
                                                                            int* __restrict__ counters, NlLossScalars* __restrict__ ls,
@@ -1696,6 +1720,18 @@ int nl_loss_finalize(int* counters, void* loss_scalars, float fs_weight, float s
     if (!counters || !loss_scalars) return NL_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, counters, (NlLossScalars*)loss_scalars,
                        fs_weight, sdf_weight, tau, max_depth, capacity);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+/* exchange 2 of the ray-sharded iteration: nl_dist_merge_counters_strided(stage 2) + nl_loss_finalize in one launch */
+int nl_dist_merge_finalize(const int* gathered, int stride_ints, int world, int* counters, void* loss_scalars, float fs_weight, float sdf_weight,
+                           float tau, float max_depth, int capacity, void* stream)
+{
+    if (!gathered || !counters || !loss_scalars || world <= 0 || stride_ints < NL_CNT_INTS + 2 * NL_CNT_DOUBLES || (stride_ints & 1))
+        return NL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_dist_merge_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, gathered, stride_ints, world, counters,
+                       (NlLossScalars*)loss_scalars, fs_weight, sdf_weight, tau, max_depth, capacity);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

@@ -134,11 +134,14 @@ class _TorchComm:
 
 
 class RayShardedExchange:
-    def __init__(self, engine, group=None, sparse_rows="auto", backend="auto", overlap=True):
+    def __init__(self, engine, group=None, sparse_rows="auto", backend="auto", overlap=False):
         """sparse_rows: "auto" (touched-rows exchange when it moves less than half of the dense table), True, False.
         backend: "rccl" | "torch" | "auto" (rccl when the process group is ProcessGroupNCCL and exposes its communicator).
         overlap: the [pose partials | embedding accumulators] all-reduce leaves on a side stream right after the scatter, under the dW2
-        kernel and the slab reduction (False: every exchange on the launch stream - same results bit for bit)."""
+        kernel and the slab reduction (False: every exchange on the launch stream - same results bit for bit).  For iterations replayed as
+        a hipGraph (bench.py --gpus N): there the event fork / join is a graph edge and costs nothing (scripts/timeline_probe.py sections
+        8 / 9: 0.4543 -> 0.4505 ms on a one-rank communicator).  Issued EAGERLY, cross-stream dependencies cost this ROCm ~0.3 ms per
+        iteration (section 7: 0.79 against 0.46 ms), so eager loops keep the default."""
         self.group = group
         self.overlap = bool(overlap)
         self._overlap_handles = None
@@ -190,7 +193,7 @@ class RayShardedExchange:
         # largest ray capacity among them (one host collective at set-up)
         cap = torch.tensor([eng.N_cap], dtype=torch.int32, device=dev)
         dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=self.group)
-        self._x1_rays = (int(cap.item()) + 7) & ~7
+        self._x1_rays = (int(cap.item()) + 15) & ~15
         self._x1_stride = CNT_STRIDE * 4 + self._x1_rays
         self._x1_send = torch.zeros(self._x1_stride // 4, dtype=torch.int32, device=dev)
         self._x1_recv = torch.zeros(self.world * self._x1_stride // 4, dtype=torch.int32, device=dev)

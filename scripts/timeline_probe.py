@@ -49,7 +49,11 @@ def parse(path, out=sys.stdout):
     titles = {1: "pose-refinement step, 2048 rays, eager", 2: "pose-refinement step, 2048 rays, hipGraph replay",
               3: "rank share of an 8-GPU mapping iteration: 16 384 interleaved rays, trainable decoder, eager",
               4: "pose-refinement step, 2048 rays, one C call per iteration (nl_iteration: fused launches)",
-              5: "rank share of an 8-GPU mapping iteration, one C call per iteration"}
+              5: "rank share of an 8-GPU mapping iteration, one C call per iteration",
+              6: "rank share + the exchanges on a one-rank RCCL communicator, every collective on the launch stream (overlap=False)",
+              7: "rank share + the exchanges, [pose | embedding] all-reduce on the side stream under dW2 + slab reduction (overlap=True; gaps < 0 = concurrent)",
+              8: "section 6 (every collective on the launch stream) replayed as a hipGraph",
+              9: "section 7 (overlapped gradient exchange) replayed as a hipGraph"}
     for sid in sorted(sections):
         ks = sections[sid]
         anchors = [i for i, r in enumerate(ks) if ANCHOR in r[0]]
@@ -147,7 +151,33 @@ def run():
     e2.bind(w["map"], w["dec"], cfg2, train_decoder=True)
     e2.run_bound(); mark(6)
     print(f"section 5 host-timed: {timed(e2.run_bound, 40):.4f} ms/step", flush=True)
-    mark(7)
+    # sections 6 + 7: the same rank share with the exchanges of the ray-sharded iteration on a ONE-RANK RCCL communicator (what issuing them
+    # costs; the messages themselves go nowhere): serial and overlapped
+    try:
+        import torch.distributed as tdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+        tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+        for sec, overlap in ((6, False), (7, True)):
+            e3 = P.SdfEngine(max_rays=len(s), samples_per_ray_cap=48, device=dev)
+            ex = D.RayShardedExchange(e3, backend="rccl", overlap=overlap)
+            e3.set_rays(w["dirs"][s], w["points"][s], w["cos"][s]); e3.set_poses(w["pose"][None], [1])
+            e3.begin_call(w["map"], w["dec"])
+            e3.bind(w["map"], w["dec"], cfg2, train_decoder=True)
+            e3.run_bound(); e3.run_bound(); mark(sec + 1)
+            print(f"section {sec} host-timed: {timed(e3.run_bound, 40):.4f} ms/step  ({ex.backend}, rows: {ex._rows_cap})", flush=True)
+            # the same iteration captured in a hipGraph (what a multi-GPU run replays: the host cost of issuing ~25 launches + 5 RCCL calls
+            # per iteration is off the critical path)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                e3.run_bound()
+            gr.replay(); mark(sec + 3)
+            print(f"section {sec + 2} host-timed: {timed(gr.replay, 40):.4f} ms/step  (hipGraph replay, overlap={overlap})", flush=True)
+            del gr, ex, e3
+        mark(11)
+        tdist.destroy_process_group()
+    except Exception as e:                                          # noqa: BLE001
+        print("sharded sections failed:", repr(e)[:300]); mark(11)
 
 
 if __name__ == "__main__":
