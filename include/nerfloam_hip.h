@@ -423,7 +423,7 @@ int nl_exchange_after_sampling(const NlIterDesc* desc, void* stream);
 int nl_exchange_emb_pose(const NlIterDesc* desc, void* stream);
 int nl_exchange_decoder(const NlIterDesc* desc, void* stream);
 int nl_exchange_gradients(const NlIterDesc* desc, void* stream);
-/* side stream (highest priority) + two timing-less events for NlIterDesc.comm_stream / ev_fork / ev_join: once per engine, off the hot path */
+/* side stream + two timing-less events for NlIterDesc.comm_stream / ev_fork / ev_join: once per engine, off the hot path */
 int nl_overlap_create(void** comm_stream, void** ev_fork, void** ev_join);
 int nl_overlap_destroy(void* comm_stream, void* ev_fork, void* ev_join);
 /* exchange 1: send block [24-int counter block | n_rays_cap bytes: hit count of ray i, 0 beyond N] (n_rays_cap a multiple of 16), and the

@@ -19,6 +19,7 @@
 // ProcessGroupNCCL hands out its ncclComm_t) - dlopen(NULL) / RTLD_NOLOAD on the loaded object: no second RCCL, no second communicator.
 #include <dlfcn.h>
 #include <link.h>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <hip/hip_runtime.h>
@@ -205,8 +206,10 @@ int nl_overlap_create(void** comm_stream, void** ev_fork, void** ev_join)
 {
     if (!comm_stream || !ev_fork || !ev_join) return X_ERR_INVALID_ARG;
     hipStream_t s = nullptr; hipEvent_t a = nullptr, b = nullptr;
+    // default priority unless NL_COMM_STREAM_PRIORITY=high (measurement switch: scripts/timeline_probe.py section 7)
     int lo = 0, hi = 0;
-    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
+    const char* pr = getenv("NL_COMM_STREAM_PRIORITY");
+    if (!(pr && pr[0] == 'h') || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
     if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) return X_ERR_LAUNCH;
     if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
         if (a) (void)hipEventDestroy(a);
