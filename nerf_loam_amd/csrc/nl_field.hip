@@ -362,12 +362,12 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
                     if (tkey[t] >= 0 && !(tword[t] & bit) && !(atomicOr(a.touched.flags + (tkey[t] >> 5), bit) & bit)) s_new[atomicAdd(&s_new_n, 1)] = tkey[t];
                 }
                 __syncthreads();
-                if (s_new_n > 0) {                                  // uniform over the workgroup; after the first iterations of a call: rare
-                    if (threadIdx.x == 0) s_new_base = atomicAdd(a.touched.count, s_new_n);
+                const int n_new = s_new_n;                          // snapshot: nobody may see a later chunk's increment of the counter
+                __syncthreads();
+                if (n_new > 0) {                                    // uniform over the workgroup; after the first iterations of a call: rare
+                    if (threadIdx.x == 0) { s_new_base = atomicAdd(a.touched.count, n_new); s_new_n = 0; }
                     __syncthreads();
-                    for (int i = threadIdx.x; i < s_new_n; i += NL_FIELD_THREADS) a.touched.list[s_new_base + i] = s_new[i];
-                    __syncthreads();
-                    if (threadIdx.x == 0) s_new_n = 0;
+                    for (int i = threadIdx.x; i < n_new; i += NL_FIELD_THREADS) a.touched.list[s_new_base + i] = s_new[i];
                     __syncthreads();
                 }
             }
