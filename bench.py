@@ -712,7 +712,7 @@ def main():
     # backend "rccl": the exchanges are issued from C inside nl_iteration; the timed iterations are hipGraph replays of that one C call
     # (BASELINE config 5), so the [pose | embedding] all-reduce rides a side stream under dW2 + slab reduction at no cost (a graph edge)
     use_graph = shard and os.environ.get("NL_BENCH_SHARD_GRAPH", "1") != "0"
-    ex = D.RayShardedExchange(eng, overlap=use_graph) if shard else None
+    ex = D.RayShardedExchange(eng, overlap=True) if shard else None
     # balanced shards: the scan is beam-major and beams differ several-fold in voxels/samples per ray, so each rank takes every
     # world-th return instead of a block of whole beams (identity for one GPU; scripts/shard_probe.py, profiles/r01_k_shard_probe.txt)
     order = D.interleaved_order(N, world)

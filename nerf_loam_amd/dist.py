@@ -134,14 +134,15 @@ class _TorchComm:
 
 
 class RayShardedExchange:
-    def __init__(self, engine, group=None, sparse_rows="auto", backend="auto", overlap=False):
+    def __init__(self, engine, group=None, sparse_rows="auto", backend="auto", overlap=True):
         """sparse_rows: "auto" (touched-rows exchange when it moves less than half of the dense table), True, False.
         backend: "rccl" | "torch" | "auto" (rccl when the process group is ProcessGroupNCCL and exposes its communicator).
         overlap: the [pose partials | embedding accumulators] all-reduce leaves on a side stream right after the scatter, under the dW2
-        kernel and the slab reduction (False: every exchange on the launch stream - same results bit for bit).  For iterations replayed as
-        a hipGraph (bench.py --gpus N): there the event fork / join is a graph edge and costs nothing (scripts/timeline_probe.py sections
-        8 / 9: 0.4543 -> 0.4505 ms on a one-rank communicator).  Issued EAGERLY, cross-stream dependencies cost this ROCm ~0.3 ms per
-        iteration (section 7: 0.79 against 0.46 ms), so eager loops keep the default."""
+        kernel and the slab reduction (False: every exchange on the launch stream - same results bit for bit).  Replayed as a hipGraph
+        (bench.py --gpus N) the event fork / join is a graph edge and costs nothing; issued eagerly it costs ~8 us per iteration on a
+        one-rank communicator (scripts/timeline_probe.py sections 6-9: 0.449 -> 0.457 ms eager, 0.443 -> 0.440 ms replayed).  The side
+        stream has DEFAULT priority: a high-priority one makes every kernel of the launch stream measure 2x slower on this ROCm
+        (0.92 ms per iteration, NL_COMM_STREAM_PRIORITY=high reproduces it)."""
         self.group = group
         self.overlap = bool(overlap)
         self._overlap_handles = None
