@@ -623,8 +623,30 @@ def test_fused_scan_launches_equal_the_separate_calls(nl):
         lib.nl_geometry_set_intersect_prune(1)
 
 
+@pytest.mark.parametrize("n", [1, 1023, 4097, 16384, 20003, 32768, 32769, 100000])
+def test_exclusive_scan_at_every_regime_and_alignment(nl, n):
+    """nl_exclusive_scan_i32 / nl_scan_hit_rays: one narrow workgroup (<= 4096), the wide one-block scan (<= 32 768: 16 items per thread as
+    16-byte accesses when the arrays are 16-byte aligned, scalar otherwise), two launches beyond - against numpy, on aligned arrays and on
+    views that start one element into an allocation"""
+    ops, L = nl["ops"], nl["L"]
+    rng = np.random.default_rng(n)
+    vals = rng.integers(0, 5, n).astype(np.int32)
+    for shift in (0, 1):
+        inp = torch.zeros(n + 4, dtype=torch.int32, device="cuda"); out = torch.full((n + 4,), -7, dtype=torch.int32, device="cuda")
+        ror = torch.full((n + 4,), -1, dtype=torch.int32, device="cuda")
+        inp[shift:shift + n] = torch.from_numpy(vals).cuda()
+        tot = torch.zeros(2, dtype=torch.int32, device="cuda"); ws = torch.zeros((n + 1023) // 1024 + 8, dtype=torch.int32, device="cuda")
+        ops.exclusive_scan(inp[shift:shift + n], out[shift:shift + n], n, 0, tot[:1], ws)
+        assert np.array_equal(out[shift:shift + n].cpu().numpy(), np.cumsum(vals) - vals) and int(tot[0]) == vals.sum()
+        assert int(out[shift + n]) == -7 and (shift == 0 or int(out[0]) == -7)                 # nothing written outside the range
+        ops.scan_hit_rays(inp[shift:shift + n], out[shift:shift + n], ror[shift:shift + n], n, tot[:1], tot[1:], ws)
+        hit = vals > 0
+        assert np.array_equal(out[shift:shift + n].cpu().numpy(), np.cumsum(hit) - hit) and int(tot[0]) == int(tot[1]) == hit.sum()
+        assert np.array_equal(ror[shift:shift + int(hit.sum())].cpu().numpy(), np.nonzero(hit)[0])
+
+
 def _fused_scan_cases(P, ops, L, lib, m, origin, pose):
-    for n in (4096, 6000):
+    for n in (4096, 6000, 16384, 20001, 40000):            # one narrow pass / the wide one-block scan (<= 32 768) / the two-launch scan
         rng = np.random.default_rng(5)
         tgt = np.stack([rng.uniform(2000.0, 2009.6, n), rng.uniform(2000.0, 2008.0, n), rng.uniform(1998.5, 2002.0, n)], -1).astype(np.float32)
         d = tgt - origin; d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
@@ -665,6 +687,9 @@ def _fused_scan_cases(P, ops, L, lib, m, origin, pose):
             if k in ("hit_idx", "hit_t0", "hit_t1"):
                 x, y = np.where(live, x, 0), np.where(live, y, 0)
             assert np.array_equal(x, y), (n, k)
+        hc = res[1]["hit_count"]
+        assert np.array_equal(res[1]["hit_rank"], np.cumsum(hc > 0) - (hc > 0)) and np.array_equal(res[1]["samp_off"], np.cumsum(hc) - hc)
+        assert np.array_equal(res[1]["ray_of_rank"], np.nonzero(hc > 0)[0]) and res[1]["counters"][L.NLC_P] == hc.sum()
 
 
 @pytest.mark.parametrize("step_size,cap", [(0.1, 64), (0.01, 640)])
