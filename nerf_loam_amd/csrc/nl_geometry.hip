@@ -470,18 +470,22 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
         if (__any(prune && live && ((ovf_now == 1 && !strict) || nh_now > NL_MAX_HITS))) break;       // a ray of this wave needs service
         if (!__any(height > 0)) { finished = true; break; }        // wave-uniform: all rays of this wave are done
         ++rounds;
-        // nodes popped this round: all the lanes can take; on the ray's second attempt only as many as can push four children each
-        // (a line meets at most four of a node's eight octants): 4 k <= QCAP - height + k
+        // nodes popped this round: all the lanes can take, but never more than can push four children each (a line meets at most four of a
+        // node's eight octants: 4 k <= QCAP - height + k) - a stack that runs over costs the ray a second traversal
         int k = height < IQ_LPR ? height : IQ_LPR;
         if (strict) { const int room = (IQ_QCAP - height) / 3; k = k < room ? k : (room > 1 ? room : 1); }
+        else if (prune) { const int room = (IQ_QCAP - height) / 2; k = k < room ? k : (room > 1 ? room : 1); }   // (first attempt: three children per node on average)
+        // ... and on the first attempt a LEAF PARENT is expanded only by the lanes the hit list has room for at four hits each; the others put
+        // their node back (it keeps its place in the DFS order) - a list that runs over costs the ray a second traversal as well
+        const int hit_lanes = (IQ_HCAP - nh_now) / 3;
         const bool mine = j < k;
         int4 e = make_int4(0, 0, 0, 0);
         if (mine) e = s_q[rl * IQ_QCAP + height - 1 - j];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();                           // every lane of the group has fetched its entry
-        if (j == 0 && height > 0) s_tail(rl) = height - k;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        // pushes of this round (filled below, issued after the block): the children a lane's node expands into, or - careful mode - the
+        // leaf parent itself when its hits found no room
+        unsigned pm = 0u; int pbase = 0, ppx = 0, ppy = 0, ppz = 0, pcs = 0, pcsl = 0; unsigned phas = 0u; bool repush = false;
         if (mine) {
             const int b = e.x, px = e.y, py = e.z, pz = e.w & 0xFFFFF, csl = e.w >> 20, cs = 1 << csl;
             // leaf-parent blocks also need their node ids: both loads depend on b only, so issue them together (inside the
@@ -507,9 +511,10 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
             }
             if (cs == 1) {
                 const int ids[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
-                if (!strict) {
-                    // first attempt: one slot per hit; a list that runs over (more than IQ_HCAP - 20 new hits since the last compaction)
-                    // starts the ray again in the careful mode below
+                if (!strict && prune && !thr_on && j >= hit_lanes && keep != 0u) repush = true;   // (with a threshold few voxels pass: no deferral)
+                else if (!strict) {
+                    // first attempt: one slot per hit; a list that runs over all the same (a degenerate ray touching more than four
+                    // octants of a node) starts the ray again in the careful mode below
 #pragma unroll
                     for (int u = 7; u >= 0; --u) {
                         if (!((keep >> u) & 1u) || ids[u] < 0) continue;
@@ -550,11 +555,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
                                 s_hid[a] = ids[u]; s_ht0[a] = tn; s_ht1[a] = tf;
                                 s_hx[a] = px + (u & 1); s_hy[a] = py + ((u >> 1) & 1); s_hz[a] = pz + ((u >> 2) & 1);
                             }
-                        } else {
-                            // the list is full until the next round's compaction (>= 8 free slots then): back on the stack (this pop freed a slot)
-                            const int slot = atomicAdd(&s_tail(rl), 1);
-                            if (slot < IQ_QCAP) s_q[rl * IQ_QCAP + slot] = e; else s_ovf(rl) = 2;
-                        }
+                        } else repush = true;      // the list is full until the next round's compaction (>= 8 free slots then): back on the stack
                     }
                 }
             } else {
@@ -564,17 +565,41 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
 #pragma unroll
                 for (int u = 7; u >= 0; --u) {
                     if (!((keep >> u) & 1u)) continue;
-                    const int cx = px + ((u & 1) ? cs : 0), cy = py + ((u & 2) ? cs : 0), cz = pz + ((u & 4) ? cs : 0);
                     float tn, tf;
-                    if (slabs.hit(u, &tn, &tf)) {
-                        const int cb = hdr.x + __popc(has & ((1u << u) - 1u));
-                        const int slot = atomicAdd(&s_tail(rl), 1);
-                        if (slot < IQ_QCAP)
-                            s_q[rl * IQ_QCAP + slot] = make_int4(cb, cx, cy, cz | ((csl - 1) << 20));
-                        else s_ovf(rl) = 1;
-                    }
+                    if (slabs.hit(u, &tn, &tf)) pm |= 1u << u;
+                }
+                pbase = hdr.x; phas = has; ppx = px; ppy = py; ppz = pz; pcs = cs; pcsl = csl;
+            }
+        }
+        // The pushes keep the stack in the reference's DFS ORDER (top = next): the lane that popped the top entry (j = 0) puts its
+        // children on top of those of lane 1, and so on; inside a node the highest octant ends on top (the reference pops 7 .. 0).
+        // Slots come from a suffix sum over the ray's lanes instead of one returning LDS atomic per child (each a round trip on the
+        // traversal's latency chain, and their arrival order scrambled the stack: the first-20 pruning then explored subtrees far behind
+        // the final threshold before the near ones had tightened it - the tail of the accumulated-map regime).
+        {
+            const int c = __popc(pm) + (repush ? 1 : 0);
+            int suf = c;                                            // inclusive suffix sum over the lanes j .. LPR - 1 of this ray: DPP row shifts
+            // (a ray's lanes lie inside one 16-lane row; lane i reads lane i + off, zero beyond the row - four VALU instructions instead of
+            //  four cross-lane LDS permutes on the traversal's latency chain)
+            { const int t = __builtin_amdgcn_mov_dpp(suf, 0x101 /* row_shl:1 */, 0xF, 0xF, true); if (j + 1 < IQ_LPR) suf += t; }
+            if (IQ_LPR > 2) { const int t = __builtin_amdgcn_mov_dpp(suf, 0x102 /* row_shl:2 */, 0xF, 0xF, true); if (j + 2 < IQ_LPR) suf += t; }
+            if (IQ_LPR > 4) { const int t = __builtin_amdgcn_mov_dpp(suf, 0x104 /* row_shl:4 */, 0xF, 0xF, true); if (j + 4 < IQ_LPR) suf += t; }
+            if (IQ_LPR > 8) { const int t = __builtin_amdgcn_mov_dpp(suf, 0x108 /* row_shl:8 */, 0xF, 0xF, true); if (j + 8 < IQ_LPR) suf += t; }
+            const int total = suf;                                  // (lane 0 of the ray: the ray's total; other lanes: what lies at or below them)
+            const int base = height - k;
+            if (base + suf > IQ_QCAP) {                             // this lane's slots (or some below them) lie beyond the stack: the ray starts again
+                if (c > 0) s_ovf(rl) = repush ? 2 : 1;
+            } else {
+                int slot = rl * IQ_QCAP + base + (suf - c);
+                if (repush) s_q[slot++] = e;
+#pragma unroll 1
+                for (unsigned rest = pm; rest != 0u; rest &= rest - 1u) {        // ascending octants: at most four for a line
+                    const int u = __ffs((int)rest) - 1;
+                    const int cx = ppx + ((u & 1) ? pcs : 0), cy = ppy + ((u & 2) ? pcs : 0), cz = ppz + ((u & 4) ? pcs : 0);
+                    s_q[slot++] = make_int4(pbase + __popc(phas & ((1u << u) - 1u)), cx, cy, cz | ((pcsl - 1) << 20));
                 }
             }
+            if (j == 0 && height > 0) s_tail(rl) = base + total;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -33,6 +33,6 @@ for tag, m, pose in (("single", w["map"], w["pose"]), ("large", lm["map"], lm["p
             L.lib().nl_geometry_set_debug_buffer(L.ptr(dbg)); run(); torch.cuda.synchronize(); L.lib().nl_geometry_set_debug_buffer(None)
             d = dbg.cpu().numpy().reshape(nb, 8)
             ovf = int(eng.counters[L.NLC_ISECT_OVF].item())
-            print(f"{tag:6s} push desc N={n:7d} {a.elapsed_time(b)/10*1e3:8.1f} us | rounds mean {d[:,4].mean():6.1f} max {d[:,4].max():4d} | "
+            print(f"{tag:6s} flags {flags} N={n:7d} {a.elapsed_time(b)/10*1e3:8.1f} us | rounds mean {d[:,4].mean():6.1f} max {d[:,4].max():4d} | "
                   f"restarted {d[:,5].mean()*100:5.1f} %  compactions/ray {d[:,6].mean():5.2f} max {d[:,6].max()}  fallback rays {ovf}")
 L.lib().nl_geometry_set_intersect_prune(1)
