@@ -85,8 +85,8 @@ def pack_children_blocks(centres, structure):
         head = blk_hdr[:40].cpu().numpy()
         cs, b, pos, octs = root_side_of(structure) >> 1, 1, [0, 0, 0], []
         while cs > 1 and b < len(head) and len(octs) < 20:
-            has = (int(head[b, 1]) >> 8) & 255
-            if has == 0 or has & (has - 1):                           # no child block, or several: the chain ends here
+            has, exist = (int(head[b, 1]) >> 8) & 255, int(head[b, 1]) & 255
+            if has == 0 or has & (has - 1) or exist != has:           # no child block, several, or a child without a block of its own: the chain ends here
                 break
             u = has.bit_length() - 1
             octs.append(u)
