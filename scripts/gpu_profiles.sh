@@ -5,7 +5,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=gpurun_out; mkdir -p $OUT
-TAG=${1:-r02}
+TAG=${1:-r04}
 timeout 900 python bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o prof -- python ${GRAFT_REPO_ROOT:-/root/repo}/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity --no-api-path --no-large-map > /tmp/prof_$TAG.log 2>&1 ; echo "rocprof rc=$?" )
 cp $(find /tmp/prof_$TAG -name "*kernel_stats*.csv" | head -1) $OUT/${TAG}_kernel_stats.csv 2>/dev/null; cut -d, -f1-4 $OUT/${TAG}_kernel_stats.csv | head -14
