@@ -125,7 +125,7 @@ _SIGS = {
     "nl_decoder_fwd_bwd_m": ([_P] * 13 + [_I, _I, _P, _I, _P], _I),
     "nl_decoder_wgrad2_m": ([_P] * 6 + [_I, _I, _P], _I),
     "nl_decoder_forward_m": ([_P, _P, _P, _I, _P, _I, _I, _P], _I),
-    "nl_decoder_reduce_m": ([_P, _I, _P, _P, _I, _P], _I),
+    "nl_decoder_reduce_m": ([_P, _P, _I, _P, _P, _I, _P], _I),
     "nl_field_set_debug_buffer": ([_P], _I),
     "nl_geometry_set_debug_buffer": ([_P], _I),
     "nl_geometry_set_lanes_per_ray": ([_I], _I),
@@ -141,7 +141,7 @@ _SIGS = {
     "nl_decoder_set_wgrad2_mode": ([_I], _I),
     "nl_decoder_get_wgrad2_mode": ([], _I),
     "nl_reduce_partials": ([_P, _I, _I, _P, _P], _I),
-    "nl_decoder_reduce": ([_P, _I, _P, _P, _P], _I),
+    "nl_decoder_reduce": ([_P, _P, _I, _P, _P, _P], _I),
     "nl_decoder_transpose_w2": ([_P, _P, _P], _I),
     "nl_trilinear_bwd": ([_P] * 8 + [_I] + [_P] * 3 + [_F] + [_P] * 3 + [_I, _P], _I),
     "nl_unpack_samples": ([_P] * 6 + [_I] + [_P] * 4, _I),

@@ -581,7 +581,7 @@ class SdfEngine:
             ops.decoder_wgrad2(self.loss_scalars, self.X, dec.params, self.dsdf, self.relu2_mask, self.partials, self.n_slabs, self.kernel_modes)
             tm("wgrad2", 1)
             tm("reduce", 0)
-            ops.decoder_reduce(self.partials, self.n_slabs, dec.params, dec.grad, self.kernel_modes)
+            ops.decoder_reduce(self.loss_scalars, self.partials, self.n_slabs, dec.params, dec.grad, self.kernel_modes)
             tm("reduce", 1)
         tm("scatter", 0)
         ops.trilinear_bwd(self.loss_scalars, self.s_vox, self.s_depth, self.s_ray, self.rays_d_world, self.rays_d_sensor, self.frame_id,
