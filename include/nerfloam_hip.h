@@ -186,9 +186,7 @@ int nl_gather_points(int P, const float* xyz, const int* vox, const float* centr
  * decoder backward (autograd of render_helpers.py:422).  params = decoder block, W2T = decoder weight workspace (nl_decoder_transpose_w2).
  * Outputs sdf[P], dsdf[P], dX[P,16]; with train_decoder: per-workgroup weight-gradient slabs
  * partials[nslabs][NL_DEC_PARAMS] (all but the W2 block; nl_decoder_wgrad2 adds that; sum the slabs with
- * nl_decoder_reduce) and relu2_mask[ceil(P/64)][512] scratch (one 32-bit ReLU word per tile and thread).
- * Of the nslabs workgroups only A = ceil(T / ceil(T / nslabs)) take tiles (T = ceil(P/64): the fewest that finish in the same
- * number of tile rounds); the others write NO slab, so slabs [A, nslabs) hold stale data - nl_decoder_reduce applies the same rule. */
+ * nl_decoder_reduce) and relu2_mask[ceil(P/64)][512] scratch (one 32-bit ReLU word per tile and thread). */
 int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* params, const float* W2T,
                        const int* s_ray, const float* s_depth, const float* cos_gt, const float* gt_dist,
                        float* sdf, float* dsdf, float* dX, float* partials, unsigned* relu2_mask, int nslabs, int train_decoder,
@@ -203,16 +201,15 @@ int nl_decoder_fwd_bwd_m(const void* loss_scalars, const float* X, const float* 
                          int* counters, int kernel_modes, void* stream);
 int nl_decoder_wgrad2_m(const void* loss_scalars, const float* X, const float* params, const float* dsdf, const unsigned* relu2_mask,
                         float* partials, int nslabs, int kernel_modes, void* stream);
-int nl_decoder_reduce_m(const void* loss_scalars, const float* partials, int nslabs, const float* params, float* grad_out, int kernel_modes,
-                        void* stream);
+int nl_decoder_reduce_m(const float* partials, int nslabs, const float* params, float* grad_out, int kernel_modes, void* stream);
 int nl_decoder_forward_m(const float* X, const float* params, const float* W2T, int P, float* sdf, int nblocks, int kernel_modes,
                          void* stream);
 /* second half of the decoder weight gradient: dW2 = dH2^T H1 into partials[slab][W2 block] (train only) */
 int nl_decoder_wgrad2(const void* loss_scalars, const float* X, const float* params, const float* dsdf, const unsigned* relu2_mask,
                       float* partials, int nslabs, void* stream);
 /* sum of the per-workgroup slabs partials[nslabs][NL_DEC_PARAMS] written by nl_decoder_fwd_bwd + nl_decoder_wgrad2 into the decoder
- * gradient grad_out[NL_DEC_PARAMS]; loss_scalars = the block those launches ran on (it holds P, hence which slabs were written) */
-int nl_decoder_reduce(const void* loss_scalars, const float* partials, int nslabs, const float* params, float* grad_out, void* stream);
+ * gradient grad_out[NL_DEC_PARAMS] */
+int nl_decoder_reduce(const float* partials, int nslabs, const float* params, float* grad_out, void* stream);
 /* dW2 kernel selection: 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32), 1 = bf16 matrix cores on the exact
  * formulation dW2[j][k] = w3_j * sum_i m(i,j) * (dsdf_i * H1[i][k]) with the {0,1} mask m as A operand and the fp32
  * B operand split into three bf16 terms (exact products, fp32 accumulation; default). */
@@ -220,7 +217,6 @@ int nl_decoder_set_wgrad2_mode(int mode);
 int nl_decoder_get_wgrad2_mode(void);
 /* forward only: Decoder.get_values on a dense batch (mesh-time get_scores, render_helpers.py:96-153) */
 int nl_decoder_forward(const float* X, const float* params, const float* W2T, int P, float* sdf, int nblocks, void* stream);
-/* generic column sum out[i] = sum_b partials[b][i] over ALL nslabs rows (not for decoder slabs: see nl_decoder_reduce) */
 int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, void* stream);
 /* Decoder weight workspace W2T[NL_DEC_WS_FLOATS], rebuilt from params after every optimiser step:
  *   floats [0, 65536):        W2 transposed (fp32; forward GEMM B operand of gemm mode 0),
@@ -467,6 +463,9 @@ int nl_geometry_set_intersect_prune(int on);    /* nl_ray_intersect (tests): 0 =
 int nl_geometry_set_lanes_per_ray(int lpr);     /* nl_ray_intersect: 0 = by ray count (default), or 4 / 8 / 16 lanes per ray */
 int nl_geometry_set_debug_buffer(void* dbg);   /* [blocks][8] int64 stamps of nl_ray_intersect's work-list kernel */
 int nl_field_set_debug_buffer(void* dbg);      /* [blocks][8] int64 stamps of nl_trilinear_bwd's workgroups */
+/* nl_trilinear_bwd is a latency chain per wave: while ONE round of resident workgroups (4 per compute unit) covers the samples with at
+ * most 18 per 8-lane group, the launch's other workgroups leave at once (default on; 0 = every workgroup takes samples: A/B aid) */
+int nl_field_set_one_round(int on);
 int nl_decoder_set_debug_buffer(void* dbg);
 /* MFMA lane-map self test (debug) */
 int nl_mfma_selftest(const float* A32, const float* B32, float* D32, const float* A16, const float* B16, float* D16, void* stream);

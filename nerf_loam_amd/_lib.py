@@ -125,8 +125,9 @@ _SIGS = {
     "nl_decoder_fwd_bwd_m": ([_P] * 13 + [_I, _I, _P, _I, _P], _I),
     "nl_decoder_wgrad2_m": ([_P] * 6 + [_I, _I, _P], _I),
     "nl_decoder_forward_m": ([_P, _P, _P, _I, _P, _I, _I, _P], _I),
-    "nl_decoder_reduce_m": ([_P, _P, _I, _P, _P, _I, _P], _I),
+    "nl_decoder_reduce_m": ([_P, _I, _P, _P, _I, _P], _I),
     "nl_field_set_debug_buffer": ([_P], _I),
+    "nl_field_set_one_round": ([_I], _I),
     "nl_geometry_set_debug_buffer": ([_P], _I),
     "nl_geometry_set_lanes_per_ray": ([_I], _I),
     "nl_geometry_set_intersect_prune": ([_I], _I),
@@ -141,7 +142,7 @@ _SIGS = {
     "nl_decoder_set_wgrad2_mode": ([_I], _I),
     "nl_decoder_get_wgrad2_mode": ([], _I),
     "nl_reduce_partials": ([_P, _I, _I, _P, _P], _I),
-    "nl_decoder_reduce": ([_P, _P, _I, _P, _P, _P], _I),
+    "nl_decoder_reduce": ([_P, _I, _P, _P, _P], _I),
     "nl_decoder_transpose_w2": ([_P, _P, _P], _I),
     "nl_trilinear_bwd": ([_P] * 8 + [_I] + [_P] * 3 + [_F] + [_P] * 3 + [_I, _P], _I),
     "nl_unpack_samples": ([_P] * 6 + [_I] + [_P] * 4, _I),
@@ -208,6 +209,8 @@ def lib():
             L.nl_geometry_set_sampler_mode(int(os.environ["NL_SAMPLER_MODE"]))
         if os.environ.get("NL_LANES_PER_RAY"):              # A/B switch for measurements: lanes per ray of the work-list intersect
             L.nl_geometry_set_lanes_per_ray(int(os.environ["NL_LANES_PER_RAY"]))
+        if os.environ.get("NL_FIELD_ONE_ROUND"):            # A/B switch for measurements: the scatter's one-round rule (nl_field_set_one_round)
+            L.nl_field_set_one_round(int(os.environ["NL_FIELD_ONE_ROUND"]))
         if os.environ.get("NL_WGRAD2_MODE"):                # A/B switch for measurements (default: the library's own default)
             if L.nl_decoder_set_wgrad2_mode(int(os.environ["NL_WGRAD2_MODE"])) != 0:
                 raise NerfLoamHipError("NL_WGRAD2_MODE must be 0 or 1")

@@ -402,17 +402,6 @@ __device__ __forceinline__ float halfwave_rowsum(const f32x16& h0, const f32x16&
     return (up ? v2[1] : v2[0]) + __shfl_xor(up ? v2[0] : v2[1], 1);
 }
 
-// Workgroups of a persistent decoder launch that take tiles: the fewest that finish in the same number of tile rounds as the whole grid
-// (266 tiles on 256 workgroups = 2 rounds = 133 workgroups with 2 tiles each).  The others leave at once and WRITE NO SLAB, so the
-// slab reduction (k_reduce_partials: 282 KB per slab) reads only what was produced - at the live 2048-ray shapes half of it.
-// One rule for k_decoder, both dW2 kernels and the reduction; slabs [0, active) are the written ones.
-__device__ __forceinline__ int dec_active_workgroups(int ntiles, int grid)
-{
-    if (ntiles <= 0) return 0;
-    const int rounds = (ntiles + grid - 1) / grid;
-    return (ntiles + rounds - 1) / rounds;
-}
-
 template <bool TRAIN, bool XG, int NP = 9>               // NP: partial products of the forward GEMM (gemm_x9); XG: both 256-deep GEMMs on the bf16 matrix cores (exact-product formulations)
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 {
@@ -430,8 +419,6 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
     const NlLossScalars ls = *a.ls;
     const int P = ls.P;
     const int ntiles = (P + DEC_M - 1) / DEC_M;
-    const int nwg = dec_active_workgroups(ntiles, gridDim.x);     // tile stride; workgroups beyond it have no tile and no slab
-    if ((int)blockIdx.x >= nwg) return;
 
     const i32x4 rsW2 = make_w_rsrc(a.params + NL_OFF_W2), rsW2T = make_w_rsrc(a.W2T);
     const i32x4 rsW2X = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W2T + NL_DEC_WS_W2X_OFF), 0, 3 * W2X_PLANE_BYTES, 0x00020000);
@@ -488,11 +475,11 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
     }
     stage_x(lds + S_X);                                  // phase A of the first tile: X -> LDS buffer 0
     float cz = pz, cd = pd;
-    prefetch(blockIdx.x + nwg);
+    prefetch(blockIdx.x + gridDim.x);
     __syncthreads();
 
     int tile_no = 0;
-    for (int tile = blockIdx.x; tile < ntiles; tile += nwg, ++tile_no) {
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++tile_no) {
         const int row0 = tile * DEC_M;
         float* sX = lds + S_X + (tile_no & 1) * (DEC_M * LDX);
         DBG_STAMP(0);
@@ -721,7 +708,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         {
             stage_x(lds + S_X + ((tile_no + 1) & 1) * (DEC_M * LDX));
             cz = pz; cd = pd;
-            prefetch(tile + 2 * nwg);
+            prefetch(tile + 2 * gridDim.x);
         }
         nl_lds_barrier();
         DBG_STAMP(10);
@@ -773,8 +760,6 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2(const NlLossS
     const int col = 32 * w + l31;
     const int P = lsp->P;
     const int ntiles = (P + DEC_M - 1) / DEC_M;
-    const int nwg = dec_active_workgroups(ntiles, gridDim.x);
-    if ((int)blockIdx.x >= nwg) return;
     const float b1c = params[NL_OFF_B1 + col], w3c = params[NL_OFF_W3 + col];
     f32x16 accW2[8];
 #pragma unroll
@@ -794,12 +779,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2(const NlLossS
     };
     prefetch(blockIdx.x);
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += nwg) {
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         sX[xi * LDX + xc] = xv.x; sX[xi * LDX + xc + 1] = xv.y;
         if (tid < DEC_M) sdS[tid] = pds;
         const unsigned mw = pmk;
         __syncthreads();
-        prefetch(tile + nwg);
+        prefetch(tile + gridDim.x);
         {   // H1 -> LDS
             f32x16 c0, c1;
 #pragma unroll
@@ -891,8 +876,6 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
     const int wj = w >> 1, wk = w & 1;                   // consumer role: dW2 block of this wave
     const int P = lsp->P;
     const int ntiles = (P + DEC_M - 1) / DEC_M;
-    const int nwg = dec_active_workgroups(ntiles, gridDim.x);
-    if ((int)blockIdx.x >= nwg) return;
     const float b1c = params[NL_OFF_B1 + col];
     // layer 1 on the bf16 matrix cores, exact products like the 256-deep GEMMs: X and W1 as three bf16 terms each, nine K = 16
     // MFMAs per half tile (288 pipe cycles) instead of eight fp32 ones (512).  B fragments (W1 row of this lane's column, k = 8 lh + e)
@@ -1010,20 +993,20 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
     // split/LDS-store work of one wave runs under the other waves' matrix work.
     prefetch(blockIdx.x);
     stage_inputs(0);
-    prefetch(blockIdx.x + nwg);
+    prefetch(blockIdx.x + gridDim.x);
     __syncthreads();
     if (blockIdx.x < ntiles) produce(0, 0);
     __syncthreads();
     int par = 0;
-    for (int tile = blockIdx.x; tile < ntiles; tile += nwg, par ^= 1) {
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
         // step A: inputs of the next tile -> the other buffers; planes of this tile's second half; MFMAs of its first half
         stage_inputs(par ^ 1);
-        prefetch(tile + 2 * nwg);
+        prefetch(tile + 2 * gridDim.x);
         produce(par, 1);
         consume(par, 0);
         nl_lds_barrier();
         // step B: planes of the next tile's first half (its inputs were published by the barrier above); MFMAs of this tile's second half
-        if (tile + nwg < ntiles) produce(par ^ 1, 0);
+        if (tile + gridDim.x < ntiles) produce(par ^ 1, 0);
         consume(par, 1);
         nl_lds_barrier();
     }
@@ -1138,15 +1121,11 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
 
 // sum per-workgroup partial slabs: out[i] = sum_b partials[b][i].  HBM-bound (nslabs x n floats in): 64 columns per block,
 // 4 slab groups per column, 4 independent accumulators per thread (16 loads in flight), fixed combination order.
-// lsp != NULL: the slabs are those of a decoder launch of `nslabs` workgroups over lsp->P samples - only the first
-// dec_active_workgroups() of them were written (and are read).
-__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partials, int nslabs, int n, float* __restrict__ out,
-                                                         const NlLossScalars* __restrict__ lsp)
+__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partials, int nslabs, int n, float* __restrict__ out)
 {
     __shared__ float red[4][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + c;
-    if (lsp) nslabs = dec_active_workgroups((lsp->P + DEC_M - 1) / DEC_M, nslabs);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (i < n) {
         const float* p = partials + i;
@@ -1306,29 +1285,23 @@ int nl_decoder_forward(const float* X, const float* params, const float* W2T, in
 int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, void* stream)
 {
     if (!partials || !out || nslabs <= 0 || n <= 0) return NL_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_reduce_partials, dim3(nl_div_up(n, 64)), dim3(256), 0, (hipStream_t)stream, partials, nslabs, n, out,
-                       (const NlLossScalars*)nullptr);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nl_div_up(n, 64)), dim3(256), 0, (hipStream_t)stream, partials, nslabs, n, out);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }
 
-/* sum of the per-workgroup weight-gradient slabs of nl_decoder_fwd_bwd + nl_decoder_wgrad2 into the decoder gradient.  loss_scalars =
- * the block those two launches ran on: workgroups without a tile wrote no slab (dec_active_workgroups) and theirs are not read. */
-int nl_decoder_reduce_m(const void* loss_scalars, const float* partials, int nslabs, const float* params, float* grad_out, int kernel_modes,
-                        void* stream)
+/* sum of the per-workgroup weight-gradient slabs of nl_decoder_fwd_bwd + nl_decoder_wgrad2 into the decoder gradient */
+int nl_decoder_reduce_m(const float* partials, int nslabs, const float* params, float* grad_out, int kernel_modes, void* stream)
 {
     DecModes km;
     if (!resolve_modes(kernel_modes, &km)) return NL_ERR_INVALID_ARG;
-    if (!loss_scalars || !partials || !params || !grad_out || nslabs <= 0) return NL_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_reduce_partials, dim3(nl_div_up(NL_DEC_PARAMS, 64)), dim3(256), 0, (hipStream_t)stream, partials, nslabs,
-                       NL_DEC_PARAMS, grad_out, (const NlLossScalars*)loss_scalars);
-    NL_LAUNCH_CHECK();
-    return NL_OK;
+    if (!partials || !params || !grad_out || nslabs <= 0) return NL_ERR_INVALID_ARG;
+    return nl_reduce_partials(partials, nslabs, NL_DEC_PARAMS, grad_out, stream);
 }
 
-int nl_decoder_reduce(const void* loss_scalars, const float* partials, int nslabs, const float* params, float* grad_out, void* stream)
+int nl_decoder_reduce(const float* partials, int nslabs, const float* params, float* grad_out, void* stream)
 {
-    return nl_decoder_reduce_m(loss_scalars, partials, nslabs, params, grad_out, 0, stream);
+    return nl_decoder_reduce_m(partials, nslabs, params, grad_out, 0, stream);
 }
 
 int nl_mfma_selftest(const float* A32, const float* B32, float* D32, const float* A16, const float* B16, float* D16, void* stream)

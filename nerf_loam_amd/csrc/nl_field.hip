@@ -33,6 +33,7 @@ struct FieldArgs {
     int want_emb_grad;
     int want_pose_grad;
     long long* dbg;                 // optional [blocks][8] s_memtime stamps of thread 0 (profiling aid, k_trilinear_bwd)
+    int resident_blocks;            // k_trilinear_bwd: workgroups the device holds at once (4 per compute unit)
     NlTouchedDev touched;           // optional: rows whose accumulators receive a contribution are recorded (nl_touch_row)
 };
 #define FSTAMP(k) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -141,6 +142,11 @@ __global__ __launch_bounds__(NL_FIELD_THREADS) void k_gather_points(int P, const
 #define TB_SMALL_P 524288                               // below: the kernel is a latency chain over a group's samples, not atomics-bound:
 #define TB_MIN_SPAN_SMALL 64                            // shorter spans (2 samples per 8-lane group instead of 8; 1 measured worse).
                                                         // 2048 rays + embeddings: iteration 0.217 -> 0.184 ms; 4096 x 4: 0.371 -> 0.341
+#define TB_ONE_ROUND_SPAN 18                            // the kernel is a latency chain per wave (~4 waves per SIMD resident): as long as ONE round of
+                                                        // resident workgroups covers P with at most this many samples per 8-lane group (beyond it the
+                                                        // wave tables overflow), the workgroups of a second round leave at once.  scripts/scatter_sweep.py,
+                                                        // 1024 against 2048 workgroups: 8192 rays 26.8 / 35.9 us, 16 384 (a rank's share) 39.6 / 45.1,
+                                                        // 32 768 57.9 / 62.2, 65 536 91.7 / 94.9, the full scan (34 per group) 179 / 150
 
 __device__ __forceinline__ int tb_insert(int* s_key, int key)
 {
@@ -164,6 +170,10 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
     __shared__ double s_pose[NL_MAX_FRAMES * 12];
     __shared__ int s_new[TB_WAVES * TB_SLOTS], s_new_n, s_new_base;     // rows this workgroup touches first (a.touched): one list append per workgroup
     __shared__ unsigned char s_own_all[TB_WAVES * TB_SLOTS];            // per table slot: the lane whose claim of the slot stands in this round (flush_run)
+    const int P = a.ls->P;
+    int grid = (int)gridDim.x;
+    if (a.resident_blocks > 0 && a.resident_blocks < grid && P <= TB_ONE_ROUND_SPAN * TB_GROUPS * a.resident_blocks) grid = a.resident_blocks;
+    if ((int)blockIdx.x >= grid) return;
     if (threadIdx.x == 0) s_new_n = 0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* s_val = s_val_all + wv * TB_SLOTS * NL_C;            // this wave's table
@@ -175,14 +185,13 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
     FSTAMP(0);
     __syncthreads();
     FSTAMP(1);
-    const int P = a.ls->P;
     const int k = threadIdx.x & 7;                              // this lane's voxel corner
     const int grp = threadIdx.x >> 3;
     const int gw = lane >> 3;                                   // group index inside the wave
     const int lane0 = lane & ~7;                                // first lane of the group inside its wave
     // the P samples are split EVENLY over the workgroups (one span each, one table flush each): with fixed-size chunks
     // P = 1.05 x grid x chunk would send 5 % of the workgroups through a second chunk and double the kernel's time
-    int per_group = (P + (int)gridDim.x * TB_GROUPS - 1) / ((int)gridDim.x * TB_GROUPS);
+    int per_group = (P + grid * TB_GROUPS - 1) / (grid * TB_GROUPS);
     const int min_span = P < TB_SMALL_P ? TB_MIN_SPAN_SMALL : TB_MIN_SPAN;
     if (per_group * TB_GROUPS < min_span) per_group = min_span / TB_GROUPS;
     const int span = per_group * TB_GROUPS;
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
         atomicAdd(sp + 3 + 3 * k, t * (double)rds[0]); atomicAdd(sp + 4 + 3 * k, t * (double)rds[1]); atomicAdd(sp + 5 + 3 * k, t * (double)rds[2]);
         ra0 = 0.f; ra1 = 0.f;
     };
-    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += grid) {
         const int s_end = min(P, (chunk + 1) * span);
         int cur_vox = -1, row = -1;
         float acc[NL_C];
@@ -396,6 +405,19 @@ __global__ void k_unpack_samples(const NlLossScalars* ls, const int* s_ray, cons
 }
 
 static long long* g_field_dbg = nullptr;
+static int g_field_one_round = 1;       // k_trilinear_bwd: TB_ONE_ROUND_SPAN rule on (0: every launched workgroup takes samples; A/B aid)
+
+// workgroups of k_trilinear_bwd the current device holds at once: 4 per compute unit (its 33 KB of LDS and launch bounds)
+static int field_resident_blocks()
+{
+    static int cached = 0;
+    if (cached == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        cached = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                     ? 4 * prop.multiProcessorCount : -1;
+    }
+    return cached > 0 ? cached : 0;
+}
 
 extern "C" {
 
@@ -410,6 +432,7 @@ static int fill_args(FieldArgs& a, const void* ls, const int* s_vox, const float
     a.rays_d_sensor = rays_d_sensor; a.frame_id = frame_id; a.poses = poses; a.centres = centres; a.vertex_rows = vertex_rows;
     a.emb = (const uint16_t*)emb; a.voxel_size = voxel_size; a.n_frames = n_frames;
     a.X = nullptr; a.dX = nullptr; a.g_emb = nullptr; a.g_pose = nullptr; a.want_emb_grad = 0; a.want_pose_grad = 0;
+    a.resident_blocks = 0;
     return NL_OK;
 }
 
@@ -439,6 +462,8 @@ int nl_gather_points(int P, const float* xyz, const int* vox, const float* centr
     return NL_OK;
 }
 
+/* A/B aid: 0 = every launched workgroup of k_trilinear_bwd takes samples (the pre-round-4 behaviour), 1 = the one-round rule (default) */
+int nl_field_set_one_round(int on) { g_field_one_round = on != 0; return NL_OK; }
 /* profiling aid: device buffer [nblocks][8] int64 receiving s_memtime stamps of k_trilinear_bwd (NULL disables) */
 int nl_field_set_debug_buffer(void* dbg) { g_field_dbg = (long long*)dbg; return NL_OK; }
 
@@ -453,6 +478,7 @@ int nl_trilinear_bwd_t(const void* loss_scalars, const int* s_vox, const float* 
     if (touched && touched->flags && (!touched->list || !touched->count)) return NL_ERR_INVALID_ARG;
     a.dX = dX; a.g_emb = g_emb; a.g_pose = g_pose; a.want_emb_grad = g_emb != nullptr; a.want_pose_grad = g_pose != nullptr;
     a.dbg = g_field_dbg;
+    a.resident_blocks = g_field_one_round ? field_resident_blocks() : 0;
     if (touched && g_emb) { a.touched.list = touched->list; a.touched.count = touched->count; a.touched.flags = touched->flags; }
     hipLaunchKernelGGL(k_trilinear_bwd, dim3(nblocks), dim3(NL_FIELD_THREADS), 0, (hipStream_t)stream, a);
     NL_LAUNCH_CHECK();

@@ -70,7 +70,7 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
         }
         if (d->train_decoder) {
             NL_TRY(nl_decoder_wgrad2_m(d->loss_scalars, d->X, d->dec_params, d->dsdf, d->relu2_mask, d->partials, d->n_slabs, d->kernel_modes, stream));
-            NL_TRY(nl_decoder_reduce_m(d->loss_scalars, d->partials, d->n_slabs, d->dec_params, d->dec_grad, d->kernel_modes, stream));
+            NL_TRY(nl_decoder_reduce_m(d->partials, d->n_slabs, d->dec_params, d->dec_grad, d->kernel_modes, stream));
         }
         if (overlapped) {
             if (hipStreamWaitEvent(st, (hipEvent_t)d->ev_join, 0) != hipSuccess) return IT_ERR_LAUNCH;

@@ -131,9 +131,8 @@ def reduce_partials(partials, nslabs, n, out):
     check(L.lib().nl_reduce_partials(ptr(partials), int(nslabs), int(n), ptr(out), stream_ptr()), "nl_reduce_partials")
 
 
-def decoder_reduce(loss_scalars, partials, nslabs, params, grad_out, modes=0):
-    check(L.lib().nl_decoder_reduce_m(ptr(loss_scalars), ptr(partials), int(nslabs), ptr(params), ptr(grad_out), int(modes), stream_ptr()),
-          "nl_decoder_reduce_m")
+def decoder_reduce(partials, nslabs, params, grad_out, modes=0):
+    check(L.lib().nl_decoder_reduce_m(ptr(partials), int(nslabs), ptr(params), ptr(grad_out), int(modes), stream_ptr()), "nl_decoder_reduce_m")
 
 
 def decoder_transpose_w2(params, W2T):

@@ -15,6 +15,7 @@ Multi-GPU (dist.py): rays are sharded; nl_iteration issues the exchanges itself 
 path reaches the same C exchange functions through the `hook_*` points.
 """
 import ctypes
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -264,9 +265,10 @@ class SdfEngine:
         self.sample_state = torch.zeros(1 + max(1, (N + 31) // 32), dtype=torch.int64, device=d)   # launch counter + look-back words of the one-launch sampler
         self.loss_scalars = torch.zeros(L.NL_LOSS_SCALARS_BYTES // 4, dtype=I32, device=d)
         # decoder partial slabs (one per persistent workgroup)
-        self.n_slabs = int(L.lib().nl_decoder_grid_hint())
+        hint = int(L.lib().nl_decoder_grid_hint())
+        self.n_slabs = int(os.environ.get("NL_N_SLABS") or hint)       # (override: scripts/sequence_diag.py, the summation partition of the decoder gradient)
         self.partials = torch.zeros(self.n_slabs, L.NL_DEC_PARAMS, dtype=F32, device=d)
-        self.field_blocks = 4 * self.n_slabs
+        self.field_blocks = 4 * hint
         self.N = 0
         self.F = 1
         self.g_emb = None
@@ -581,7 +583,7 @@ class SdfEngine:
             ops.decoder_wgrad2(self.loss_scalars, self.X, dec.params, self.dsdf, self.relu2_mask, self.partials, self.n_slabs, self.kernel_modes)
             tm("wgrad2", 1)
             tm("reduce", 0)
-            ops.decoder_reduce(self.loss_scalars, self.partials, self.n_slabs, dec.params, dec.grad, self.kernel_modes)
+            ops.decoder_reduce(self.partials, self.n_slabs, dec.params, dec.grad, self.kernel_modes)
             tm("reduce", 1)
         tm("scatter", 0)
         ops.trilinear_bwd(self.loss_scalars, self.s_vox, self.s_depth, self.s_ray, self.rays_d_world, self.rays_d_sensor, self.frame_id,

@@ -857,53 +857,6 @@ def test_one_call_iteration_equals_the_stage_calls(nl, golden_dir):
     assert (outs["one_call"][2] != outs["stages"][2]).mean() < 5e-3
 
 
-@pytest.mark.parametrize("one_call", [False, True])
-def test_decoder_slabs_without_a_tile_are_neither_written_nor_read(nl, golden_dir, one_call):
-    """Of the n_slabs workgroups of the decoder launches only ceil(T / ceil(T / n_slabs)) take tiles; the rest write no slab and the
-    reduction reads none of theirs.  At every regime of tiles vs workgroups (one round with idle workgroups, two rounds, exactly full,
-    three rounds), with the slab buffer poisoned before each iteration: the decoder gradient is finite, matches the oracle, and is the
-    same sum whatever the partition (fp32 re-association only)."""
-    g = np.load(os.path.join(golden_dir, "map_1f_1it.npz"))
-    sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]))
-    sc["ms"].id2row = g["id_table"].copy()
-    masks = H.unpack_masks(g["masks"], len(sc["points"]))
-    dec_np = O.decoder_init(int(g["seed"]))
-    fr = O.select_rays(sc["points"], sc["cos"], g["poses0"][0].copy(), masks[0][0], optimize_pose=False)
-    out = O.render_and_grad(sc["ms"], dec_np, [fr], O.IterCfg(step_size=float(g["step_size"])), want_dec_grad=True)
-    m, dec, eng = make_engine(nl, sc, dec_np, len(fr.rays_d))
-    cfgP = nl["P"].IterConfig(step_size=float(g["step_size"]))
-    eng.set_rays(fr.rays_d, fr.points, fr.cos); eng.set_poses(fr.pose[None], [0])
-    T = (int(out["n_samples"]) + 63) // 64
-    full = eng.n_slabs
-    assert 4 <= T and (T + 1) // 2 + 1 <= full
-    grads = {}
-    for n_slabs in sorted({min(full, T + 5), T - 1, (T + 1) // 2, (T + 1) // 2 - 1}):
-        eng.n_slabs = n_slabs
-        eng.begin_call(m, dec)
-        if one_call:
-            eng.bind(m, dec, cfgP, train_decoder=True)
-        eng.partials.fill_(float("nan"))
-        if one_call:
-            eng.run_bound(1)
-        else:
-            eng.forward_backward(m, dec, cfgP, train_decoder=True)
-        torch.cuda.synchronize()
-        rounds = -(-T // n_slabs); active = -(-T // rounds)
-        slab = eng.partials.view(-1, nl["L"].NL_DEC_PARAMS)
-        written = ~torch.isnan(slab).any(1)
-        assert bool(written[:active].all()) and not bool(written[active:full].any()), (n_slabs, active)
-        gd = dec.grad.cpu().numpy().copy()
-        assert np.isfinite(gd).all(), n_slabs
-        grads[n_slabs] = gd
-        for n_, ref in out["grad_dec"].items():
-            got = nl_split(gd)[n_].reshape(ref.shape)
-            assert np.linalg.norm((got - ref).astype(np.float64)) <= 2e-3 * np.linalg.norm(ref.astype(np.float64)), (n_slabs, n_)
-    eng.n_slabs = full
-    base = grads.pop(min(grads))
-    for n_slabs, gd in grads.items():
-        assert np.linalg.norm((gd - base).astype(np.float64)) <= 1e-5 * np.linalg.norm(base.astype(np.float64)), n_slabs
-
-
 def test_hipgraph_replay_matches_eager(nl, golden_dir):
     """The captured launch sequence (forward+backward+Adam, device-side step counter) replayed 3x gives the same
     pose / decoder trajectory as 3 eager iterations (embedding atomics are order-nondeterministic: tolerance)."""

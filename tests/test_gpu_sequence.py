@@ -120,8 +120,9 @@ def test_five_scan_mapping_sequence_matches_the_oracle(monkeypatch):
                  rows_moved_got=int(mv_g.sum()), rows_moved_ref=int(mv_r.sum()),
                  odd_rows_max_move=float(max(np.abs(got_e - g0)[odd].max(initial=0.0), np.abs(ref_e - e0)[odd].max(initial=0.0))))
         gd = {k: p.detach().cpu().numpy().reshape(-1) for k, p in zip(("W1", "b1", "W2", "b2", "W3", "b3"), mapper.decoder.param_list())}
-        r["dec_rel_l2"] = max(_rel(gd[k], getattr(dec_o, k).reshape(-1), dec0[k].reshape(-1)) for k in gd if np.any(getattr(dec_o, k) != dec0[k])) \
-            if any(np.any(getattr(dec_o, k) != dec0[k]) for k in gd) else 0.0
+        by = {k: _rel(gd[k], getattr(dec_o, k).reshape(-1), dec0[k].reshape(-1)) for k in gd if np.any(getattr(dec_o, k) != dec0[k])}
+        r["dec_rel_l2"] = max(by.values()) if by else 0.0
+        print({k: round(v, 5) for k, v in by.items()}, flush=True)
         dp = [np.abs(fr.pose.data.detach().cpu().numpy() - pose_o[id(fr.pose)]) for fr in frames]
         r["pose_t_ulp"] = float(max(d[:3].max() for d in dp) / POSE_ULP_2000)
         r["pose_w"] = float(max(d[3:].max() for d in dp))
