@@ -17,7 +17,7 @@ timeout 300 python __graft_entry__.py smoke > $OUT/${TAG}_smoke.log 2>&1; echo "
 echo "== bench"
 timeout 600 python bench.py --steps 10 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?"; cat $OUT/${TAG}_bench.json; tail -5 $OUT/${TAG}_bench.err
 echo "== rocprof kernel stats"
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o prof -- python ${GRAFT_REPO_ROOT:-/root/repo}/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity --no-api-path > /tmp/prof_$TAG.log 2>&1 ; echo "rocprof rc=$?" )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o prof -- python ${GRAFT_REPO_ROOT:-/root/repo}/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-steady-state --no-parity --no-api-path > /tmp/prof_$TAG.log 2>&1 ; echo "rocprof rc=$?" )
 find /tmp/prof_$TAG -type f | head -10
 for f in $(find /tmp/prof_$TAG -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/${TAG}_kernel_stats.csv; head -30 $f; done
 tail -3 /tmp/prof_$TAG.log

@@ -7,7 +7,7 @@ OUT=gpurun_out; mkdir -p $OUT
 TAG=${1:-pmc}
 run() { # name, counters...
   name=$1; shift
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_${TAG}_$name -o p -- python ${GRAFT_REPO_ROOT:-/root/repo}/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-parity --no-api-path --no-large-map > /tmp/pmc_${TAG}_$name.log 2>&1; echo "$name rc=$?" )
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_${TAG}_$name -o p -- python ${GRAFT_REPO_ROOT:-/root/repo}/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-steady-state --no-parity --no-api-path --no-large-map > /tmp/pmc_${TAG}_$name.log 2>&1; echo "$name rc=$?" )
   ls /tmp/pmc_${TAG}_$name | head -5
   cp /tmp/pmc_${TAG}_$name/p_counter_collection.csv $OUT/${TAG}_${name}_counters.csv 2>/dev/null
   tail -2 /tmp/pmc_${TAG}_$name.log
