@@ -464,7 +464,7 @@ int nl_geometry_set_lanes_per_ray(int lpr);     /* nl_ray_intersect: 0 = by ray 
 int nl_geometry_set_debug_buffer(void* dbg);   /* [blocks][8] int64 stamps of nl_ray_intersect's work-list kernel */
 int nl_field_set_debug_buffer(void* dbg);      /* [blocks][8] int64 stamps of nl_trilinear_bwd's workgroups */
 /* nl_trilinear_bwd is a latency chain per wave: while ONE round of resident workgroups (4 per compute unit) covers the samples with at
- * most 18 per 8-lane group, the launch's other workgroups leave at once (default on; 0 = every workgroup takes samples: A/B aid) */
+ * most 6 per 8-lane group, the launch's other workgroups leave at once (default on; 0 = every workgroup takes samples: A/B aid) */
 int nl_field_set_one_round(int on);
 int nl_decoder_set_debug_buffer(void* dbg);
 /* MFMA lane-map self test (debug) */

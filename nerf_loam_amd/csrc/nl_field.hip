@@ -142,11 +142,13 @@ __global__ __launch_bounds__(NL_FIELD_THREADS) void k_gather_points(int P, const
 #define TB_SMALL_P 524288                               // below: the kernel is a latency chain over a group's samples, not atomics-bound:
 #define TB_MIN_SPAN_SMALL 64                            // shorter spans (2 samples per 8-lane group instead of 8; 1 measured worse).
                                                         // 2048 rays + embeddings: iteration 0.217 -> 0.184 ms; 4096 x 4: 0.371 -> 0.341
-#define TB_ONE_ROUND_SPAN 18                            // the kernel is a latency chain per wave (~4 waves per SIMD resident): as long as ONE round of
-                                                        // resident workgroups covers P with at most this many samples per 8-lane group (beyond it the
-                                                        // wave tables overflow), the workgroups of a second round leave at once.  scripts/scatter_sweep.py,
-                                                        // 1024 against 2048 workgroups: 8192 rays 26.8 / 35.9 us, 16 384 (a rank's share) 39.6 / 45.1,
-                                                        // 32 768 57.9 / 62.2, 65 536 91.7 / 94.9, the full scan (34 per group) 179 / 150
+#define TB_ONE_ROUND_SPAN 6                             // the kernel is a latency chain per wave (~4 waves per SIMD resident): as long as ONE round of
+                                                        // resident workgroups covers P with at most this many samples per 8-lane group, the workgroups of a
+                                                        // second round leave at once.  scripts/scatter_sweep.py, 1024 against 2048 workgroups, single-scan map:
+                                                        // 8192 rays 26.8 / 35.9 us, 16 384 (a rank's share) 39.6 / 45.1; 150-scan map (a ray crosses ~15 voxels
+                                                        // with ~1.5 samples each: a wave's 128-slot table overflows early): 4096 rays 125 / 145, 8192 rays 177 / 238,
+                                                        // but 16 384 rays (12 samples per group in one round) 479 / 316 - hence 6, not the 18 the single-scan map
+                                                        // alone would allow (32 768 rays there: 57.9 / 62.2, 65 536: 91.7 / 94.9, full scan 179 / 150)
 
 __device__ __forceinline__ int tb_insert(int* s_key, int key)
 {

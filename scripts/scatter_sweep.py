@@ -16,9 +16,14 @@ for n in (4096, 8192, 32768, 65536):
     shapes[f"{n} rays"] = np.sort(rs.choice(N, n, replace=False))
 BLOCKS = [int(b) for b in os.environ.get("BLOCKS", "128,256,512,768,1024,1536,2048,3072,4096").split(",")]
 m = w["map"]
+pose0 = w["pose"]
+if "--large-map" in sys.argv:                                     # the 150-scan map of bench.py large_map: a ray crosses many more voxels, ~1 sample each
+    lm = bench.build_large_map(w, dev)
+    m, pose0 = lm["map"], lm["poses"][len(lm["poses"]) // 2]
+    shapes = {k: v for k, v in shapes.items() if k != "full scan"}
 for name, sel in shapes.items():
-    eng = P.SdfEngine(max_rays=len(sel), samples_per_ray_cap=48, device=dev)
-    eng.set_rays(w["dirs"][sel], w["points"][sel], w["cos"][sel]); eng.set_poses(w["pose"][None], [1])
+    eng = P.SdfEngine(max_rays=len(sel), samples_per_ray_cap=96 if "--large-map" in sys.argv else 48, device=dev)
+    eng.set_rays(w["dirs"][sel], w["points"][sel], w["cos"][sel]); eng.set_poses(pose0[None], [1])
     cfg = P.IterConfig(); eng.begin_call(m, w["dec"])
     for _ in range(2):
         eng.forward_backward(m, w["dec"], cfg, train_decoder=True)
