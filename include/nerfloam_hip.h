@@ -466,6 +466,9 @@ int nl_field_set_debug_buffer(void* dbg);      /* [blocks][8] int64 stamps of nl
 /* nl_trilinear_bwd is a latency chain per wave: while ONE round of resident workgroups (4 per compute unit) covers the samples with at
  * most 6 per 8-lane group, the launch's other workgroups leave at once (default on; 0 = every workgroup takes samples: A/B aid) */
 int nl_field_set_one_round(int on);
+int nl_field_set_midspan_flush(int min_steps_left);   /* A/B aid: nl_trilinear_bwd writes a full wave table out mid-span when its 8-lane groups have at least this
+                                                         many sample steps left (default 2; < 0 = never: overflowing runs go to memory from their lane) */
+int nl_field_set_probes(int n);               /* A/B aid: open-addressing probes of nl_trilinear_bwd's wave tables before a run goes straight to memory */
 int nl_decoder_set_debug_buffer(void* dbg);
 /* MFMA lane-map self test (debug) */
 int nl_mfma_selftest(const float* A32, const float* B32, float* D32, const float* A16, const float* B16, float* D16, void* stream);

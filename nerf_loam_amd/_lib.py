@@ -128,6 +128,8 @@ _SIGS = {
     "nl_decoder_reduce_m": ([_P, _I, _P, _P, _I, _P], _I),
     "nl_field_set_debug_buffer": ([_P], _I),
     "nl_field_set_one_round": ([_I], _I),
+    "nl_field_set_probes": ([_I], _I),
+    "nl_field_set_midspan_flush": ([_I], _I),
     "nl_geometry_set_debug_buffer": ([_P], _I),
     "nl_geometry_set_lanes_per_ray": ([_I], _I),
     "nl_geometry_set_intersect_prune": ([_I], _I),
@@ -209,6 +211,10 @@ def lib():
             L.nl_geometry_set_sampler_mode(int(os.environ["NL_SAMPLER_MODE"]))
         if os.environ.get("NL_LANES_PER_RAY"):              # A/B switch for measurements: lanes per ray of the work-list intersect
             L.nl_geometry_set_lanes_per_ray(int(os.environ["NL_LANES_PER_RAY"]))
+        if os.environ.get("NL_FIELD_MIDSPAN_FLUSH"):        # A/B switch for measurements (nl_field_set_midspan_flush)
+            L.nl_field_set_midspan_flush(int(os.environ["NL_FIELD_MIDSPAN_FLUSH"]))
+        if os.environ.get("NL_FIELD_PROBES"):               # A/B switch for measurements (nl_field_set_probes)
+            L.nl_field_set_probes(int(os.environ["NL_FIELD_PROBES"]))
         if os.environ.get("NL_FIELD_ONE_ROUND"):            # A/B switch for measurements: the scatter's one-round rule (nl_field_set_one_round)
             L.nl_field_set_one_round(int(os.environ["NL_FIELD_ONE_ROUND"]))
         if os.environ.get("NL_WGRAD2_MODE"):                # A/B switch for measurements (default: the library's own default)

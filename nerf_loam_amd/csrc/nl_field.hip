@@ -34,6 +34,8 @@ struct FieldArgs {
     int want_pose_grad;
     long long* dbg;                 // optional [blocks][8] s_memtime stamps of thread 0 (profiling aid, k_trilinear_bwd)
     int resident_blocks;            // k_trilinear_bwd: workgroups the device holds at once (4 per compute unit)
+    int probes;                     // k_trilinear_bwd: open-addressing probes before a run goes straight to memory
+    int flush_steps_left;           // k_trilinear_bwd: a full table is written out mid-span if the groups have at least this many sample steps left
     NlTouchedDev touched;           // optional: rows whose accumulators receive a contribution are recorded (nl_touch_row)
 };
 #define FSTAMP(k) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -137,6 +139,8 @@ __global__ __launch_bounds__(NL_FIELD_THREADS) void k_gather_points(int P, const
 #define TB_WAVES (NL_FIELD_THREADS / 64)
 #define TB_SLOTS 128                                    // per wave
 #define TB_PROBES 16
+#define TB_FLUSH_MIN_STEPS_LEFT 2                       // ... and the 8-lane groups have at least this many sample steps of their span left
+#define TB_FLUSH_OCCUPANCY 96                          // a run without a slot: the wave writes its table out if at least this many of the 128 slots are taken
 #define TB_GROUPS (NL_FIELD_THREADS / 8)                 // 8-lane groups per workgroup
 #define TB_MIN_SPAN 256                                 // samples per workgroup: at least this many (aggregation), else P / grid
 #define TB_SMALL_P 524288                               // below: the kernel is a latency chain over a group's samples, not atomics-bound:
@@ -150,11 +154,11 @@ __global__ __launch_bounds__(NL_FIELD_THREADS) void k_gather_points(int P, const
                                                         // but 16 384 rays (12 samples per group in one round) 479 / 316 - hence 6, not the 18 the single-scan map
                                                         // alone would allow (32 768 rays there: 57.9 / 62.2, 65 536: 91.7 / 94.9, full scan 179 / 150)
 
-__device__ __forceinline__ int tb_insert(int* s_key, int key)
+__device__ __forceinline__ int tb_insert(int* s_key, int key, int probes)
 {
     unsigned h = ((unsigned)key * 2654435761u) >> 25;          // top 7 bits -> [0, 128)
 #pragma unroll 1
-    for (int i = 0; i < TB_PROBES; ++i) {
+    for (int i = 0; i < probes; ++i) {
         const int prev = atomicCAS(&s_key[h], -1, key);         // lanes of this wave racing for a slot (integer CAS: cheap; a plain read
         if (prev == -1 || prev == key) return (int)h;           // in front of it for rows already in the table measured no gain)
         h = (h + 1) & (TB_SLOTS - 1);
@@ -223,22 +227,8 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
         for (int c = 0; c < NL_C; ++c) acc[c] = 0.f;
 #pragma unroll
         for (int c = 0; c < NL_C / 2; ++c) eb[c] = 0u;
-        // add this lane's finished run (row, acc) into the wave's table; `flush` may differ per 8-lane group but is uniform
-        // inside a group.  All 64 lanes call it together.
-        auto flush_run = [&](bool flush) {
-            flush = flush && row >= 0 && a.want_emb_grad;
-            const unsigned long long fm = __ballot(flush);
-            if (fm == 0ull) return;
-            int slot = -1;
-            if (flush) {
-                slot = tb_insert(s_key, row);
-                if (slot < 0) {                                     // table full: straight to memory
-                    nl_touch_row(a.touched, row);
-                    float* dst = a.g_emb + (size_t)row * NL_C;
-#pragma unroll
-                    for (int c = 0; c < NL_C; ++c) atomicAdd(dst + c, acc[c]);
-                }
-            }
+        // add the finished runs (row, acc) of the lanes with a table slot (slot >= 0) into the wave's table.  All 64 lanes call it together.
+        auto add_runs = [&](int slot) {
             // Lanes whose slots differ add together; two groups of the wave that finish a run on the SAME row (neighbouring rays
             // share voxel corners) must not read-modify-write the slot at once: every pending lane claims its slot, the claim that
             // stands adds its 16 floats, the others go again - 1-3 rounds instead of one per group (eight dependent LDS round trips
@@ -264,6 +254,56 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
                 pend = pend && !win;
             }
         };
+        // add this lane's finished run (row, acc) into the wave's table; `flush` may differ per 8-lane group but is uniform
+        // inside a group.  All 64 lanes call it together.
+        auto flush_run = [&](bool flush, int steps_left) {
+            flush = flush && row >= 0 && a.want_emb_grad;
+            const unsigned long long fm = __ballot(flush);
+            if (fm == 0ull) return;
+            int slot = -1;
+            if (flush) slot = tb_insert(s_key, row, a.probes);
+            // A run that finds no slot (a wave that meets more distinct rows than its table holds: the accumulated map, where a ray crosses ~15
+            // voxels with ~1.5 samples each) used to go to memory from its own lane - 16 scalar atomics per lane, the slowest thing this kernel can
+            // do (scripts/scatter_sweep.py --probes).  Now the wave writes the table out the way the end of a span does - 16 lanes per slot, one
+            // 64-byte row per atomic instruction quarter - and the run goes into the emptied table.  Runs that did find a slot add first.
+            bool ovf = flush && slot < 0;
+            // (Not when the table is half empty - a probe sequence also fails on clustering - and not in the last steps of a span, where the table
+            //  is about to be written out anyway and the odd lane's scalar atomics are cheaper than a second pass over 128 slots: a rank's
+            //  interleaved share of the single-scan map fills its tables right at the end of its 5-sample spans, 40.9 -> 46.4 us without this test.
+            //  scripts/scatter_sweep.py [--large-map] --probes, never / always / with >= 2 steps left: that share 40.9 / 46.4 / 40.9 us; 150-scan map
+            //  8192 rays 178 / 168 / 178, 16 384 rays 318 / 295 / 318, 32 768 rays 579 / 366 / 392, 65 536 rays 1137 / 483 / 503; a criterion on the
+            //  number of lanes without a slot did not separate the two maps.)
+            if (__ballot(ovf) != 0ull && steps_left >= a.flush_steps_left &&
+                __popcll(__ballot(s_key[lane] >= 0)) + __popcll(__ballot(s_key[lane + 64] >= 0)) >= TB_FLUSH_OCCUPANCY) {
+                add_runs(slot);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int base = 0; base < TB_SLOTS; base += 4) {
+                    const int sl = base + (lane >> 4), c = lane & 15;
+                    const int key = s_key[sl];
+                    if (key >= 0) {
+                        const float v = s_val[sl * NL_C + c];
+                        if (c == 0) nl_touch_row(a.touched, key);
+                        if (v != 0.f) atomicAdd(a.g_emb + (size_t)key * NL_C + c, v);
+                        s_val[sl * NL_C + c] = 0.f;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < TB_SLOTS; i += 64) s_key[i] = -1;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                slot = ovf ? tb_insert(s_key, row, a.probes) : -1;     // at most 64 runs into 128 empty slots
+                ovf = ovf && slot < 0;                                 // (a probe sequence can still fail - with the A/B aid's 1 or 2 probes it does)
+            }
+            if (ovf) {                                              // straight to memory from this lane
+                nl_touch_row(a.touched, row);
+                float* dst = a.g_emb + (size_t)row * NL_C;
+#pragma unroll
+                for (int c = 0; c < NL_C; ++c) atomicAdd(dst + c, acc[c]);
+            }
+            add_runs(slot);
+        };
         const int s_base = chunk * span + grp * per_group;
 #pragma unroll 1
         for (int j = 0; j < per_group; ++j) {
@@ -282,7 +322,7 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
                 g.p[0] = __shfl(p_ax, lane0); g.p[1] = __shfl(p_ax, lane0 + 1); g.p[2] = __shfl(p_ax, lane0 + 2);
             } else { g.vox = cur_vox; g.ray = 0; g.depth = 0.f; g.p[0] = g.p[1] = g.p[2] = 0.f; }
             const bool change = live && g.vox != cur_vox;
-            flush_run(change);
+            flush_run(change, per_group - 1 - j);
             if (change) {
                 cur_vox = g.vox;
                 row = a.vertex_rows[8 * (size_t)g.vox + k];
@@ -338,7 +378,7 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
             ra1 += g.depth * dx;
         }
         FSTAMP(2);
-        flush_run(true);
+        flush_run(true, 0);
         FSTAMP(3);
         if (a.want_emb_grad) {
             // rows whose accumulators receive their first contribution since begin_call go onto the touched-rows list (a.touched).  Their
@@ -407,6 +447,8 @@ __global__ void k_unpack_samples(const NlLossScalars* ls, const int* s_ray, cons
 }
 
 static long long* g_field_dbg = nullptr;
+static int g_field_probes = TB_PROBES;   // (A/B aid: nl_field_set_probes)
+static int g_field_flush_steps = TB_FLUSH_MIN_STEPS_LEFT;   // (A/B aid: nl_field_set_midspan_flush; a huge value = never)
 static int g_field_one_round = 1;       // k_trilinear_bwd: TB_ONE_ROUND_SPAN rule on (0: every launched workgroup takes samples; A/B aid)
 
 // workgroups of k_trilinear_bwd the current device holds at once: 4 per compute unit (its 33 KB of LDS and launch bounds)
@@ -434,7 +476,7 @@ static int fill_args(FieldArgs& a, const void* ls, const int* s_vox, const float
     a.rays_d_sensor = rays_d_sensor; a.frame_id = frame_id; a.poses = poses; a.centres = centres; a.vertex_rows = vertex_rows;
     a.emb = (const uint16_t*)emb; a.voxel_size = voxel_size; a.n_frames = n_frames;
     a.X = nullptr; a.dX = nullptr; a.g_emb = nullptr; a.g_pose = nullptr; a.want_emb_grad = 0; a.want_pose_grad = 0;
-    a.resident_blocks = 0;
+    a.resident_blocks = 0; a.probes = g_field_probes; a.flush_steps_left = g_field_flush_steps;
     return NL_OK;
 }
 
@@ -466,6 +508,8 @@ int nl_gather_points(int P, const float* xyz, const int* vox, const float* centr
 
 /* A/B aid: 0 = every launched workgroup of k_trilinear_bwd takes samples (the pre-round-4 behaviour), 1 = the one-round rule (default) */
 int nl_field_set_one_round(int on) { g_field_one_round = on != 0; return NL_OK; }
+int nl_field_set_midspan_flush(int min_steps_left) { g_field_flush_steps = min_steps_left < 0 ? (1 << 30) : min_steps_left; return NL_OK; }
+int nl_field_set_probes(int n) { if (n < 1 || n > TB_SLOTS) return NL_ERR_INVALID_ARG; g_field_probes = n; return NL_OK; }
 /* profiling aid: device buffer [nblocks][8] int64 receiving s_memtime stamps of k_trilinear_bwd (NULL disables) */
 int nl_field_set_debug_buffer(void* dbg) { g_field_dbg = (long long*)dbg; return NL_OK; }
 

@@ -33,6 +33,39 @@ for name, sel in shapes.items():
                           eng.poses12, eng.F, m.centres, m.vertex_rows, m.emb, m.voxel_size, eng.dX, eng.g_emb, eng.g_pose, blocks,
                           eng._touched if touched else None)
     print(f"{name}: P = {Pn}, engine launches {2 * eng.field_blocks} workgroups")
+    if "--probes" in sys.argv:                                    # the product's launch under 2 .. 16 open-addressing probes per insert
+        for pr in (1, 2, 4, 8, 16):
+            L.lib().nl_field_set_probes(pr)
+            run(2 * eng.field_blocks, 1); torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10): run(2 * eng.field_blocks, 1)
+                e1.record(); torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / 10 * 1e3)
+            print(f"  probes {pr:2d}: {best:7.1f} us")
+        L.lib().nl_field_set_probes(16)
+        for fl in (-1, 0, 1, 2, 3, 4):                             # mid-span write-out of a full table: never / with >= fl sample steps left
+            L.lib().nl_field_set_midspan_flush(fl)
+            run(2 * eng.field_blocks, 1); torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10): run(2 * eng.field_blocks, 1)
+                e1.record(); torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / 10 * 1e3)
+            print(f"  mid-span flush {fl:2d}: {best:7.1f} us")
+        L.lib().nl_field_set_midspan_flush(2)
+        nb = 2 * eng.field_blocks                                  # per-phase cycle stamps of every workgroup (scripts/scatter_probe.py)
+        dbg = torch.zeros(nb * 8, dtype=torch.int64, device=dev)
+        L.lib().nl_field_set_debug_buffer(L.ptr(dbg)); run(nb, 1); torch.cuda.synchronize(); L.lib().nl_field_set_debug_buffer(None)
+        d = dbg.cpu().numpy().reshape(nb, 8); d = d[(d[:, [0, 1, 2, 3, 5]] > 0).all(1)]
+        ph = np.diff(d[:, [0, 1, 2, 3, 5]], axis=1)
+        print("  cycles per workgroup (%d active): " % len(d) + ", ".join(f"{n} {v:.0f}" for n, v in zip(("init", "sample loop", "last run flush", "table flush + touched rows"), ph.mean(0)))
+              + f"; kernel span {d[:, 5].max() - d[:, 0].min()}")
+        continue
     L.lib().nl_field_set_one_round(0)
     for blocks in BLOCKS + [-1]:
         if blocks < 0:                                            # the product's launch: 2 x field_blocks workgroups, one-round rule on

@@ -857,6 +857,38 @@ def test_one_call_iteration_equals_the_stage_calls(nl, golden_dir):
     assert (outs["one_call"][2] != outs["stages"][2]).mean() < 5e-3
 
 
+@pytest.mark.parametrize("probes", [1, 2, 3])
+def test_scatter_tables_that_overflow_are_written_out_mid_span(nl, golden_dir, probes):
+    """k_trilinear_bwd: a wave whose 128-slot table cannot take a run writes the table out (16 lanes per row) and carries on in the emptied table.
+    With 1-3 open-addressing probes per insert (A/B aid nl_field_set_probes; the product uses 16) that happens on every scene, many times per
+    wave: embedding gradient, touched rows and pose gradient must still be the oracle's, in the stage calls and after two more iterations."""
+    lib = nl["L"].lib()
+    g = np.load(os.path.join(golden_dir, "map_1f_3it.npz"))
+    sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]))
+    sc["ms"].id2row = g["id_table"].copy()
+    masks = H.unpack_masks(g["masks"], len(sc["points"]))
+    dec_np = O.decoder_init(int(g["seed"]))
+    fr = O.select_rays(sc["points"], sc["cos"], g["poses0"][0].copy(), masks[0][0], optimize_pose=True)
+    cfgO = O.IterCfg(step_size=float(g["step_size"]))
+    out = O.render_and_grad(sc["ms"], dec_np, [fr], cfgO, want_dec_grad=True)
+    cfgP = nl["P"].IterConfig(step_size=float(g["step_size"]))
+    assert lib.nl_field_set_probes(probes) == 0
+    try:
+        m, dec, eng = make_engine(nl, sc, dec_np, len(fr.rays_d))
+        load_frames(eng, [fr])
+        eng.begin_call(m, dec)
+        eng.forward_backward(m, dec, cfgP, train_decoder=True)
+        compare_iteration(eng, m, dec, out, cfgP, True)
+        touched = int(eng._touched[1].item())
+        rows = np.unique(eng._touched[0][:touched].cpu().numpy())
+        assert len(rows) == touched                                                     # every row on the list once
+        ref_rows = np.nonzero((O.bf16_to_f32(out["grad_emb"]) != 0).any(1))[0]
+        assert set(ref_rows.tolist()) <= set(rows.tolist())                             # (a row whose contributions round to zero is touched, too)
+        compare_emb_and_pose_grads(nl, eng, m, dec, out, cfgP, 1, True)
+    finally:
+        lib.nl_field_set_probes(16)
+
+
 def test_hipgraph_replay_matches_eager(nl, golden_dir):
     """The captured launch sequence (forward+backward+Adam, device-side step counter) replayed 3x gives the same
     pose / decoder trajectory as 3 eager iterations (embedding atomics are order-nondeterministic: tolerance)."""
