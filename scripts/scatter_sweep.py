@@ -63,8 +63,10 @@ for name, sel in shapes.items():
         L.lib().nl_field_set_debug_buffer(L.ptr(dbg)); run(nb, 1); torch.cuda.synchronize(); L.lib().nl_field_set_debug_buffer(None)
         d = dbg.cpu().numpy().reshape(nb, 8); d = d[(d[:, [0, 1, 2, 3, 5]] > 0).all(1)]
         ph = np.diff(d[:, [0, 1, 2, 3, 5]], axis=1)
+        tot = d[:, 5] - d[:, 0]
         print("  cycles per workgroup (%d active): " % len(d) + ", ".join(f"{n} {v:.0f}" for n, v in zip(("init", "sample loop", "last run flush", "table flush + touched rows"), ph.mean(0)))
-              + f"; kernel span {d[:, 5].max() - d[:, 0].min()}")
+              + "; whole workgroup: median %.0f, 90 %% %.0f, 99 %% %.0f, max %.0f; table flush max %.0f (the counters of different XCDs are not comparable: no kernel span)"
+              % (np.median(tot), np.percentile(tot, 90), np.percentile(tot, 99), tot.max(), ph[:, 3].max()))
         continue
     L.lib().nl_field_set_one_round(0)
     for blocks in BLOCKS + [-1]:
