@@ -146,6 +146,8 @@ __global__ __launch_bounds__(NL_FIELD_THREADS) void k_gather_points(int P, const
 #define TB_SMALL_P 524288                               // below: the kernel is a latency chain over a group's samples, not atomics-bound:
 #define TB_MIN_SPAN_SMALL 64                            // shorter spans (2 samples per 8-lane group instead of 8; 1 measured worse).
                                                         // 2048 rays + embeddings: iteration 0.217 -> 0.184 ms; 4096 x 4: 0.371 -> 0.341
+#define TB_LONG_RAY_SAMPLES 20                          // samples per hit ray from which a small launch takes ...
+#define TB_MIN_SPAN_LONG_RAYS 192                       // ... 6 samples per 8-lane group
 #define TB_ONE_ROUND_SPAN 6                             // the kernel is a latency chain per wave (~4 waves per SIMD resident): as long as ONE round of
                                                         // resident workgroups covers P with at most this many samples per 8-lane group, the workgroups of a
                                                         // second round leave at once.  scripts/scatter_sweep.py, 1024 against 2048 workgroups, single-scan map:
@@ -198,7 +200,11 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
     // the P samples are split EVENLY over the workgroups (one span each, one table flush each): with fixed-size chunks
     // P = 1.05 x grid x chunk would send 5 % of the workgroups through a second chunk and double the kernel's time
     int per_group = (P + grid * TB_GROUPS - 1) / (grid * TB_GROUPS);
-    const int min_span = P < TB_SMALL_P ? TB_MIN_SPAN_SMALL : TB_MIN_SPAN;
+    // ... unless the rays are long in samples (an accumulated map: ~23 samples per hit ray over ~15 voxels against 8 over 3-4 on a one-scan map).
+    // There the voxels around the sensor are crossed by every ray, their rows are the target of thousands of same-address atomics
+    // (profiles/experiments/README.md), and a wave that walks 16 samples merges less than one ray's worth of them: 6 samples per group
+    // (two rays per wave) - 150-scan map 2048 rays 77 -> 62 us, 4096 rays 125 -> 108; the one-scan map at 2048 rays would pay 14.5 -> 22 us for it.
+    const int min_span = P < TB_SMALL_P ? (P > TB_LONG_RAY_SAMPLES * a.ls->R ? TB_MIN_SPAN_LONG_RAYS : TB_MIN_SPAN_SMALL) : TB_MIN_SPAN;
     if (per_group * TB_GROUPS < min_span) per_group = min_span / TB_GROUPS;
     const int span = per_group * TB_GROUPS;
     const int nchunks = (P + span - 1) / span;
