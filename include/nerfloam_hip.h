@@ -94,6 +94,19 @@ int nl_ray_intersect_scan(int N, const float* rays_d_sensor, const float* points
                           const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
                           float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
                           int* counters, int* ray_of_rank, int* hit_rank, int* total_out, int* total_out2, int* scan_ws, void* stream);
+/* The same two calls with the lanes a ray's work-list gets chosen by the caller: 0 = by ray count (16 up to 16 384 rays, 8 beyond), or
+ * 4 / 8 / 16 / 32.  Same results bit for bit; what changes is the number of traversal rounds.  32 pays on an ACCUMULATED map, where a ray
+ * crosses many occupied voxels and has more than 16 nodes pending per round (150-scan map: 2048 rays 122 -> 71 us, 16 384 rays 120 -> 95),
+ * and costs on a one-scan map (16 384 rays 41 -> 65 us): the host side passes 32 for maps of >= 100 000 children blocks at <= 16 384 rays
+ * (nerf_loam_amd/pipeline.py MapDevice.isect_lanes); NlIterDesc.isect_lanes carries the same choice. */
+int nl_ray_intersect_lanes(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
+                           const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
+                           float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
+                           int* counters, int* scratch_rays, int lanes, void* stream);
+int nl_ray_intersect_scan_lanes(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
+                                const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
+                                float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
+                                int* counters, int* ray_of_rank, int* hit_rank, int* total_out, int* total_out2, int* scan_ws, int lanes, void* stream);
 
 /* LidarFrame.get_rays (src/lidarFrame.py:47-52): rays_d[M,3] = points / (||points||_2 + 1e-8), rays_norm[M] (optional) = that
  * denominator - the arithmetic of the reference's host torch ops, bit for bit (nl_device_math.h nl_unit_dir).  The selection entry
@@ -384,6 +397,7 @@ typedef struct NlIterDesc {
      * scatter first and all-reduces [pose partials | embedding accumulators] on comm_stream under the dW2 kernel and the slab reduction
      * (event fork after the scatter, join before the decoder gradient's all-reduce); NULL: the exchanges follow the backward pass on `stream` */
     void* comm_stream; void* ev_fork; void* ev_join;
+    int isect_lanes;            /* lanes per ray of the intersect's work-list: 0 = by ray count, or 4 / 8 / 16 / 32 (nl_ray_intersect_lanes) */
 } NlIterDesc;
 /* stages: bit 0 = intersect .. backward (with a communicator: + the exchanges of the forward pass), bit 1 = optimiser step,
  * bit 2 = the gradient exchange (only with a communicator; a whole sharded iteration = 7).  The bits exist separately so that the
@@ -460,7 +474,7 @@ int nl_octree_export_delta(void* h, float voxel_size, int* ids, float* centres, 
 /* profiling aid: 256 x int64 device buffer receiving per-phase shader-clock stamps of workgroup 0 (NULL = off) */
 int nl_geometry_set_sampler_mode(int mode);     /* nl_sample_rays: 0 = sequential walk per ray, 1 = step-parallel, 2 = by ray count (default); same results */
 int nl_geometry_set_intersect_prune(int on);    /* nl_ray_intersect (tests): 0 = rays with more hits than the work-list kernel's list holds go to the sequential fallback instead of being pruned to the first 20 in place; 1 = default */
-int nl_geometry_set_lanes_per_ray(int lpr);     /* nl_ray_intersect: 0 = by ray count (default), or 4 / 8 / 16 lanes per ray */
+int nl_geometry_set_lanes_per_ray(int lpr);     /* nl_ray_intersect: 0 = the caller's choice / by ray count (default), or 4 / 8 / 16 / 32 lanes per ray for every call */
 int nl_geometry_set_debug_buffer(void* dbg);   /* [blocks][8] int64 stamps of nl_ray_intersect's work-list kernel */
 int nl_field_set_debug_buffer(void* dbg);      /* [blocks][8] int64 stamps of nl_trilinear_bwd's workgroups */
 /* nl_trilinear_bwd is a latency chain per wave: while ONE round of resident workgroups (4 per compute unit) covers the samples with at

@@ -64,6 +64,7 @@ def _iter_desc_fields():
     f += [("touched_list", P_), ("touched_count", P_), ("touched_flags", P_), ("sparse_sweep", I_)]
     f += [("x1_send", P_), ("x1_recv", P_), ("x1_stride_bytes", I_), ("x1_rays", I_)]
     f += [("comm_stream", P_), ("ev_fork", P_), ("ev_join", P_)]
+    f += [("isect_lanes", I_)]
     return f
 
 
@@ -100,6 +101,7 @@ _SIGS = {
     "nl_svo_intersect": ([_P] * 4 + [_I, _I, _I, _F, _I] + [_P] * 4, _I),
     "nl_inverse_cdf_sampling": ([_P] * 6 + [_I] * 4 + [_F] + [_P] * 4, _I),
     "nl_ray_intersect": ([_I] + [_P] * 7 + [_I, _F, _F] + [_P] * 9, _I),
+    "nl_ray_intersect_lanes": ([_I] + [_P] * 7 + [_I, _F, _F] + [_P] * 8 + [_I, _P], _I),
     "nl_exclusive_scan_i32": ([_P, _P, _I, _I, _P, _P, _P], _I),
     "nl_compact_hit_rays": ([_I, _P, _P, _P, _P], _I),
     "nl_scan_hit_rays": ([_P, _P, _P, _I, _P, _P, _P, _P], _I),
@@ -117,6 +119,7 @@ _SIGS = {
     "nl_scan_samples_finalize": ([_P, _P, _I, _P, _P, _F, _F, _F, _F, _I, _P, _P], _I),
     "nl_sample_rays_fused": ([_I] + [_P] * 8 + [_F, _F, _F, _U, _I, _I, _I] + [_P] * 4 + [_I] + [_P] * 5 + [_F, _F, _P, _P, _P], _I),
     "nl_ray_intersect_scan": ([_I] + [_P] * 7 + [_I, _F, _F] + [_P] * 13, _I),
+    "nl_ray_intersect_scan_lanes": ([_I] + [_P] * 7 + [_I, _F, _F] + [_P] * 12 + [_I, _P], _I),
     "nl_gather_trilinear": ([_P] * 7 + [_I] + [_P] * 3 + [_F, _P, _I, _P], _I),
     "nl_gather_points": ([_I] + [_P] * 5 + [_F, _P, _P], _I),
     "nl_decoder_fwd_bwd": ([_P] * 13 + [_I, _I, _P, _P], _I),

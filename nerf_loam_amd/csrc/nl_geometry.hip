@@ -252,6 +252,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_dfs(DfsArgs a)
 // sequential fallback is left with rays whose stack is too small even one node at a time.
 template <int LPR> struct IqCaps { static constexpr int Q = 32, H = 28; };      // 8 / 4 lanes per ray (large ray counts): 1.2 KB of LDS per ray
 template <> struct IqCaps<16> { static constexpr int Q = 64, H = 40; };         // 16 lanes per ray (up to 16 384 rays): 2 KB per ray
+template <> struct IqCaps<32> { static constexpr int Q = 128, H = 40; };        // 32 lanes per ray (opt-in: NL_LANES_PER_RAY=32): 3 KB per ray
 
 __device__ __forceinline__ bool less_msb(unsigned a, unsigned b) { return a < b && a < (a ^ b); }
 // true if voxel 1 precedes voxel 2 in the reference's DFS order (= larger z-major Morton code)
@@ -585,6 +586,10 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_q(
             if (IQ_LPR > 2) { const int t = __builtin_amdgcn_mov_dpp(suf, 0x102 /* row_shl:2 */, 0xF, 0xF, true); if (j + 2 < IQ_LPR) suf += t; }
             if (IQ_LPR > 4) { const int t = __builtin_amdgcn_mov_dpp(suf, 0x104 /* row_shl:4 */, 0xF, 0xF, true); if (j + 4 < IQ_LPR) suf += t; }
             if (IQ_LPR > 8) { const int t = __builtin_amdgcn_mov_dpp(suf, 0x108 /* row_shl:8 */, 0xF, 0xF, true); if (j + 8 < IQ_LPR) suf += t; }
+            if (IQ_LPR > 16) {                                      // two rows per ray: the lower row adds the upper row's total (a cross-lane read)
+                const int upper = __shfl(suf, (int)(threadIdx.x & 63u & ~31u) + 16);
+                if (j < 16) suf += upper;
+            }
             const int total = suf;                                  // (lane 0 of the ray: the ray's total; other lanes: what lies at or below them)
             const int base = height - k;
             if (base + suf > IQ_QCAP) {                             // this lane's slots (or some below them) lie beyond the stack: the ray starts again
@@ -1564,13 +1569,14 @@ static int scan_launch(const int* in, int* out, int n, int flag_mode, int* ray_o
 static int intersect_launch(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
                             const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
                             float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
-                            int* counters, int* scratch_rays, int* hit_rank, int* total_out, int* total_out2, int* scan_ws, void* stream)
+                            int* counters, int* scratch_rays, int* hit_rank, int* total_out, int* total_out2, int* scan_ws, int lanes, void* stream)
 {
+    if (lanes != 0 && lanes != 4 && lanes != 8 && lanes != 16 && lanes != 32) return NL_ERR_INVALID_ARG;
     if (N <= 0 || !rays_d_sensor || !points_gt || !cos_gt || !poses || !blk_ids || !blk_hdr || root_side < 2 || !rays_d_world || !gt_dist ||
         !hit_idx || !hit_t0 || !hit_t1 || !hit_count || !counters || !scratch_rays) return NL_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const int lpr = g_isect_lpr ? g_isect_lpr : (N <= 16384 ? 16 : 8);
-    auto kq = lpr == 16 ? k_ray_intersect_q<16> : lpr == 8 ? k_ray_intersect_q<8> : k_ray_intersect_q<4>;
+    const int lpr = g_isect_lpr ? g_isect_lpr : lanes ? lanes : (N <= 16384 ? 16 : 8);      // A/B override, the caller's choice (the map's: see the header), by ray count
+    auto kq = lpr == 32 ? k_ray_intersect_q<32> : lpr == 16 ? k_ray_intersect_q<16> : lpr == 8 ? k_ray_intersect_q<8> : k_ray_intersect_q<4>;
     const int IQ_RAYS = NL_GEO_THREADS / lpr;
     hipLaunchKernelGGL(kq, dim3(nl_div_up(N, IQ_RAYS)), dim3(NL_GEO_THREADS), 0, st,
                        N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, (const int2*)blk_hdr, (const int4*)blk_ids, root_side, voxel_size, max_distance,
@@ -1595,7 +1601,16 @@ int nl_ray_intersect(int N, const float* rays_d_sensor, const float* points_gt, 
                      int* counters, int* scratch_rays, void* stream)
 {
     return intersect_launch(N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, blk_hdr, blk_ids, root_side, voxel_size, max_distance, rays_d_world,
-                            gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, scratch_rays, nullptr, nullptr, nullptr, nullptr, stream);
+                            gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, scratch_rays, nullptr, nullptr, nullptr, nullptr, 0, stream);
+}
+
+int nl_ray_intersect_lanes(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
+                           const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
+                           float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
+                           int* counters, int* scratch_rays, int lanes, void* stream)
+{
+    return intersect_launch(N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, blk_hdr, blk_ids, root_side, voxel_size, max_distance, rays_d_world,
+                            gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, scratch_rays, nullptr, nullptr, nullptr, nullptr, lanes, stream);
 }
 
 /* nl_ray_intersect + nl_scan_hit_rays (ray_of_rank == the intersect kernel's scratch list, as in the stage-wise sequence): one
@@ -1607,7 +1622,17 @@ int nl_ray_intersect_scan(int N, const float* rays_d_sensor, const float* points
 {
     if (!hit_rank || !total_out || !scan_ws) return NL_ERR_INVALID_ARG;
     return intersect_launch(N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, blk_hdr, blk_ids, root_side, voxel_size, max_distance, rays_d_world,
-                            gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, ray_of_rank, hit_rank, total_out, total_out2, scan_ws, stream);
+                            gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, ray_of_rank, hit_rank, total_out, total_out2, scan_ws, 0, stream);
+}
+
+int nl_ray_intersect_scan_lanes(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
+                                const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
+                                float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
+                                int* counters, int* ray_of_rank, int* hit_rank, int* total_out, int* total_out2, int* scan_ws, int lanes, void* stream)
+{
+    if (!hit_rank || !total_out || !scan_ws) return NL_ERR_INVALID_ARG;
+    return intersect_launch(N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, blk_hdr, blk_ids, root_side, voxel_size, max_distance, rays_d_world,
+                            gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, ray_of_rank, hit_rank, total_out, total_out2, scan_ws, lanes, stream);
 }
 
 static int scan_launch(const int* in, int* out, int n, int flag_mode, int* ray_of_rank, int* total_out, int* total_out2,
@@ -1647,7 +1672,7 @@ int nl_geometry_set_sampler_mode(int mode) { if (mode < 0 || mode > 2) return NL
 
 /* lanes per ray of the work-list intersect kernel: 0 = by ray count (default: 16 up to 16 384 rays, else 8), or 2 / 4 / 8 / 16 */
 int nl_geometry_set_intersect_prune(int on) { g_isect_prune = on ? 1 : 0; return NL_OK; }
-int nl_geometry_set_lanes_per_ray(int lpr) { if (lpr != 0 && lpr != 4 && lpr != 8 && lpr != 16) return NL_ERR_INVALID_ARG; g_isect_lpr = lpr; return NL_OK; }
+int nl_geometry_set_lanes_per_ray(int lpr) { if (lpr != 0 && lpr != 4 && lpr != 8 && lpr != 16 && lpr != 32) return NL_ERR_INVALID_ARG; g_isect_lpr = lpr; return NL_OK; }
 
 /* profiling aid: device buffer [blocks][8] int64: cycle stamps (start, after set-up, after traversal, after finalise) and the
  * round count of wave 0 of every workgroup of k_ray_intersect_q (NULL disables) */

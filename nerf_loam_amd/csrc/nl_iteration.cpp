@@ -27,9 +27,9 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
         // (counters_copy + counters_clean, set by the host after a stages == 3 call), by a memset launch otherwise
         if (!(d->counters_copy && d->counters_clean) &&
             hipMemsetAsync(c, 0, NL_CNT_INTS * 4 + NL_CNT_DOUBLES * 8, st) != hipSuccess) return IT_ERR_LAUNCH;
-        NL_TRY(nl_ray_intersect_scan(d->N, d->rays_d_sensor, d->points_gt, d->cos_gt, d->frame_id, d->poses12, d->blk_hdr, d->blk_ids, d->root_side,
-                                     d->voxel_size, d->max_distance, d->rays_d_world, d->gt_dist, d->hit_idx, d->hit_t0, d->hit_t1, d->hit_count, c,
-                                     d->ray_of_rank, d->hit_rank, c + IT_R, c + IT_R_GLOBAL, d->scan_ws, stream));
+        NL_TRY(nl_ray_intersect_scan_lanes(d->N, d->rays_d_sensor, d->points_gt, d->cos_gt, d->frame_id, d->poses12, d->blk_hdr, d->blk_ids, d->root_side,
+                                           d->voxel_size, d->max_distance, d->rays_d_world, d->gt_dist, d->hit_idx, d->hit_t0, d->hit_t1, d->hit_count, c,
+                                           d->ray_of_rank, d->hit_rank, c + IT_R, c + IT_R_GLOBAL, d->scan_ws, d->isect_lanes, stream));
         const unsigned* mix = d->fresh_noise ? (const unsigned*)d->adam_state : nullptr;
         if (sharded) {
             // exchange 1 -> global hit ranks + the batch rows' first-ray hit lists; count, scan, emit on the local rays; exchange 2 ->

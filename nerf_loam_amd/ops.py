@@ -45,10 +45,12 @@ def inverse_cdf_sampling(pts_idx, min_depth, max_depth, noise, probs, steps, fix
 
 
 def ray_intersect(N, rays_d_sensor, points_gt, cos_gt, frame_id, poses12, blk_hdr, blk_ids, root_side, voxel_size, max_distance,
-                  rays_d_world, gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, scratch_rays):
-    check(L.lib().nl_ray_intersect(int(N), ptr(rays_d_sensor), ptr(points_gt), ptr(cos_gt), ptr(frame_id), ptr(poses12), ptr(blk_hdr),
-                                   ptr(blk_ids), int(root_side), float(voxel_size), float(max_distance), ptr(rays_d_world), ptr(gt_dist),
-                                   ptr(hit_idx), ptr(hit_t0), ptr(hit_t1), ptr(hit_count), ptr(counters), ptr(scratch_rays), stream_ptr()), "nl_ray_intersect")
+                  rays_d_world, gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, scratch_rays, lanes=0):
+    """lanes: lanes per ray of the traversal's work-list, 0 = by ray count (MapDevice.isect_lanes_for picks 32 on an accumulated map)"""
+    check(L.lib().nl_ray_intersect_lanes(int(N), ptr(rays_d_sensor), ptr(points_gt), ptr(cos_gt), ptr(frame_id), ptr(poses12), ptr(blk_hdr),
+                                         ptr(blk_ids), int(root_side), float(voxel_size), float(max_distance), ptr(rays_d_world), ptr(gt_dist),
+                                         ptr(hit_idx), ptr(hit_t0), ptr(hit_t1), ptr(hit_count), ptr(counters), ptr(scratch_rays), int(lanes),
+                                         stream_ptr()), "nl_ray_intersect_lanes")
 
 
 def exclusive_scan(inp, out, n, flag_mode, total_out, workspace):

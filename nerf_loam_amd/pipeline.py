@@ -43,6 +43,9 @@ class IterConfig:
     tail_always: bool = False          # False = reference sampler tail behaviour
 
 
+ISECT_WIDE_BLOCKS = 100_000      # children blocks from which MapDevice.isect_lanes_for gives a ray 32 lanes
+
+
 def pack_children_blocks(centres, structure):
     """Children-block traversal layout of nl_ray_intersect (device tensors in, device tensors out).
     Block 0 = pseudo block with the root in slot 0; every node with a listed child owns one block; blocks are
@@ -122,6 +125,13 @@ class MapDevice:
 
     def emb_bits(self):
         return self.emb.cpu().numpy().view(np.uint16)
+
+    def isect_lanes_for(self, n_rays):
+        """lanes per ray of the intersect's work-list (nl_ray_intersect_lanes): 32 on an accumulated map - a ray crosses many occupied voxels and
+        has more than 16 nodes pending per round (150-scan map, 300 k children blocks: 2048 rays 122 -> 71 us, 16 384 rays 120 -> 95) -, 0 = by
+        ray count otherwise (a one-scan map, 17 k blocks, pays 41 -> 65 us for 32 lanes at 16 384 rays; beyond 16 384 rays 8 lanes win on both)."""
+        blk = getattr(self, "blk_hdr", None)
+        return 32 if blk is not None and blk.shape[0] >= ISECT_WIDE_BLOCKS and n_rays <= 16384 else 0
 
     @classmethod
     def from_tensors(cls, centres, structure, vertex_idx, id2row, emb_bf16, voxel_size, device="cuda", traversal=True):
@@ -549,7 +559,7 @@ class SdfEngine:
         tm("intersect", 0)
         ops.ray_intersect(N, self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self.poses12, m.blk_hdr, m.blk_ids, m.root_side,
                           m.voxel_size, cfg.max_distance, self.rays_d_world, self.gt_dist, self.hit_idx, self.hit_t0, self.hit_t1,
-                          self.hit_count, c, self.ray_of_rank)
+                          self.hit_count, c, self.ray_of_rank, m.isect_lanes_for(N))
         # hit-ray ranks + compaction + R (and R_GLOBAL: overwritten by the multi-GPU hook) in one launch (two beyond 4096 rays)
         ops.scan_hit_rays(self.hit_count, self.hit_rank, self.ray_of_rank, N, c[L.NLC_R:L.NLC_R + 1], c[L.NLC_R_GLOBAL:L.NLC_R_GLOBAL + 1],
                           self.scan_ws)
@@ -608,7 +618,7 @@ class SdfEngine:
         c.zero_()
         ops.ray_intersect(N, self.rays_d_sensor, self.points_gt, self.cos_gt, self.frame_id, self.poses12, m.blk_hdr, m.blk_ids, m.root_side,
                           m.voxel_size, cfg.max_distance, self.rays_d_world, self.gt_dist, self.hit_idx, self.hit_t0, self.hit_t1,
-                          self.hit_count, c, self.ray_of_rank)
+                          self.hit_count, c, self.ray_of_rank, m.isect_lanes_for(N))
         ops.scan_hit_rays(self.hit_count, self.hit_rank, self.ray_of_rank, N, c[L.NLC_R:L.NLC_R + 1], c[L.NLC_R_GLOBAL:L.NLC_R_GLOBAL + 1],
                           self.scan_ws)
         seed = 0 if cfg.noise_seed is None else cfg.noise_seed
@@ -677,6 +687,7 @@ class SdfEngine:
                      "adam_state", "partials", "g_emb", "emb_m", "emb_v"):
             setattr(d, name, pt(getattr(self, name)))
         d.blk_hdr, d.blk_ids, d.root_side, d.voxel_size = pt(m.blk_hdr), pt(m.blk_ids), int(m.root_side), float(m.voxel_size)
+        d.isect_lanes = m.isect_lanes_for(self.N)
         d.centres, d.vertex_rows, d.emb, d.n_emb_elems = pt(m.centres), pt(m.vertex_rows), pt(m.emb), int(m.emb.numel())
         d.dec_params, d.dec_ws, d.dec_grad, d.dec_m, d.dec_v = pt(dec.params), pt(dec.W2T), pt(dec.grad), pt(dec.m), pt(dec.v)
         d.P_cap, d.n_slabs, d.field_blocks = self.P_cap, self.n_slabs, self.field_blocks

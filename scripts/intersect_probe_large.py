@@ -27,7 +27,7 @@ for tag, m, pose in (("single", w["map"], w["pose"]), ("large", lm["map"], lm["p
             a.record()
             for _ in range(10): run()
             b.record(); torch.cuda.synchronize()
-            lpr = 16 if n <= 16384 else 8
+            lpr = int(os.environ.get("NL_LANES_PER_RAY") or 0) or (16 if n <= 16384 else 8)      # (the stamps: one row per workgroup)
             nb = (n * lpr + 255) // 256
             dbg = torch.zeros(nb * 8, dtype=torch.int64, device="cuda")
             L.lib().nl_geometry_set_debug_buffer(L.ptr(dbg)); run(); torch.cuda.synchronize(); L.lib().nl_geometry_set_debug_buffer(None)

@@ -553,7 +553,7 @@ def test_full_scan_invariants(nl):
             assert np.abs(g0).max() > 0 and np.abs(g0 - g1).max() <= 5e-5 * np.abs(g0).max(), (name, other)
 
 
-@pytest.mark.parametrize("prune,lpr", [(1, 0), (1, 8), (1, 4), (0, 0)])
+@pytest.mark.parametrize("prune,lpr", [(1, 0), (1, 8), (1, 4), (1, 32), (0, 0)])
 def test_intersect_cap_and_overflow_paths(nl, prune, lpr):
     """Dense voxel slab + grazing rays: up to ~60 voxels per ray.  Exercises the 20-hit cap (first 20 in the
     reference's DFS order, before the t_min sort): prune = 1 - the work-list kernel ranks a ray's hits in DFS order whenever its list
