@@ -94,11 +94,11 @@ int nl_ray_intersect_scan(int N, const float* rays_d_sensor, const float* points
                           const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
                           float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
                           int* counters, int* ray_of_rank, int* hit_rank, int* total_out, int* total_out2, int* scan_ws, void* stream);
-/* The same two calls with the lanes a ray's work-list gets chosen by the caller: 0 = by ray count (16 up to 16 384 rays, 8 beyond), or
- * 4 / 8 / 16 / 32.  Same results bit for bit; what changes is the number of traversal rounds.  32 pays on an ACCUMULATED map, where a ray
- * crosses many occupied voxels and has more than 16 nodes pending per round (150-scan map: 2048 rays 122 -> 71 us, 16 384 rays 120 -> 95),
- * and costs on a one-scan map (16 384 rays 41 -> 65 us): the host side passes 32 for maps of >= 100 000 children blocks at <= 16 384 rays
- * (nerf_loam_amd/pipeline.py MapDevice.isect_lanes); NlIterDesc.isect_lanes carries the same choice. */
+/* The same two calls with the lanes a ray's work-list gets chosen by the caller: 0 = by ray count (32 up to 4096 rays, 16 up to 16 384, 8
+ * beyond), or 4 / 8 / 16 / 32.  Same results bit for bit; what changes is the number of traversal rounds.  Between 4097 and 16 384 rays 32 lanes
+ * pay on an ACCUMULATED map only, where a ray crosses many occupied voxels and has more than 16 nodes pending per round (150-scan map:
+ * 16 384 rays 120 -> 95 us; a one-scan map 41 -> 65): the host side passes 32 for maps of >= 60 000 children blocks there
+ * (nerf_loam_amd/pipeline.py MapDevice.isect_lanes_for); NlIterDesc.isect_lanes carries the same choice. */
 int nl_ray_intersect_lanes(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
                            const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
                            float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,

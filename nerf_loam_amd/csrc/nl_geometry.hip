@@ -1575,7 +1575,10 @@ static int intersect_launch(int N, const float* rays_d_sensor, const float* poin
     if (N <= 0 || !rays_d_sensor || !points_gt || !cos_gt || !poses || !blk_ids || !blk_hdr || root_side < 2 || !rays_d_world || !gt_dist ||
         !hit_idx || !hit_t0 || !hit_t1 || !hit_count || !counters || !scratch_rays) return NL_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const int lpr = g_isect_lpr ? g_isect_lpr : lanes ? lanes : (N <= 16384 ? 16 : 8);      // A/B override, the caller's choice (the map's: see the header), by ray count
+    // A/B override, else the caller's choice (the map's: see the header), else by ray count: up to 4096 rays the launch leaves most of the device
+    // idle and 32 lanes cost nothing (one-scan map 2048 rays ~35 -> 30 us, 5 / 15 / 40 / 150 scans 39 -> 31, 61 -> 45, 94 -> 54, 122 -> 71); beyond, 32 lanes
+    // mean twice the workgroups and only maps whose rays have wide fronts gain (profiles/r04_n_intersect_lanes_ab.txt)
+    const int lpr = g_isect_lpr ? g_isect_lpr : lanes ? lanes : (N <= 4096 ? 32 : N <= 16384 ? 16 : 8);
     auto kq = lpr == 32 ? k_ray_intersect_q<32> : lpr == 16 ? k_ray_intersect_q<16> : lpr == 8 ? k_ray_intersect_q<8> : k_ray_intersect_q<4>;
     const int IQ_RAYS = NL_GEO_THREADS / lpr;
     hipLaunchKernelGGL(kq, dim3(nl_div_up(N, IQ_RAYS)), dim3(NL_GEO_THREADS), 0, st,

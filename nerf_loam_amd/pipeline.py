@@ -43,7 +43,7 @@ class IterConfig:
     tail_always: bool = False          # False = reference sampler tail behaviour
 
 
-ISECT_WIDE_BLOCKS = 100_000      # children blocks from which MapDevice.isect_lanes_for gives a ray 32 lanes
+ISECT_WIDE_BLOCKS = 60_000       # children blocks from which MapDevice.isect_lanes_for gives a ray 32 lanes at 4097 .. 16 384 rays
 
 
 def pack_children_blocks(centres, structure):
@@ -128,8 +128,9 @@ class MapDevice:
 
     def isect_lanes_for(self, n_rays):
         """lanes per ray of the intersect's work-list (nl_ray_intersect_lanes): 32 on an accumulated map - a ray crosses many occupied voxels and
-        has more than 16 nodes pending per round (150-scan map, 300 k children blocks: 2048 rays 122 -> 71 us, 16 384 rays 120 -> 95) -, 0 = by
-        ray count otherwise (a one-scan map, 17 k blocks, pays 41 -> 65 us for 32 lanes at 16 384 rays; beyond 16 384 rays 8 lanes win on both)."""
+        has more than 16 nodes pending per round (at 16 384 rays: 150 scans / 300 k children blocks 120 -> 95 us, 40 scans / 71 k blocks 97 -> 90;
+        15 scans / 38 k blocks 68 -> 80, a one-scan map 41 -> 65) -, 0 = by ray count otherwise (32 lanes up to 4096 rays on every map, 16 up to
+        16 384, 8 beyond)."""
         blk = getattr(self, "blk_hdr", None)
         return 32 if blk is not None and blk.shape[0] >= ISECT_WIDE_BLOCKS and n_rays <= 16384 else 0
 

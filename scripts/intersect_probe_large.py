@@ -7,13 +7,14 @@ import bench
 from nerf_loam_amd import _lib as L, pipeline as P, ops
 dev = torch.device("cuda")
 w = bench.build_workload(dev)
-lm = bench.build_large_map(w, dev)
+lm = bench.build_large_map(w, dev, n_scans=int(os.environ.get("N_SCANS", "150")))
+print("map of", os.environ.get("N_SCANS", "150"), "scans:", int(lm["map"].blk_hdr.shape[0]), "children blocks")
 N = len(w["points"])
 rng = np.random.default_rng(0)
-for tag, m, pose in (("single", w["map"], w["pose"]), ("large", lm["map"], lm["poses"][75])):
+for tag, m, pose in (("single", w["map"], w["pose"]), ("large", lm["map"], lm["poses"][len(lm["poses"]) // 2])):
     for flags in (1,):
         L.lib().nl_geometry_set_intersect_prune(flags)
-        for n in (2048, 16384, N):
+        for n in ((2048, 16384) if os.environ.get("N_SCANS") else (2048, 16384, N)):
             sel = np.arange(N) if n == N else np.sort(rng.choice(N, n, replace=False))
             eng = P.SdfEngine(max_rays=n, samples_per_ray_cap=4)
             eng.set_rays(w["dirs"][sel], w["points"][sel], w["cos"][sel]); eng.set_poses(pose[None], [1])
