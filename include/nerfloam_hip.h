@@ -205,7 +205,7 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
                        float* sdf, float* dsdf, float* dX, float* partials, unsigned* relu2_mask, int nslabs, int train_decoder,
                        int* counters, void* stream);
 /* The same four decoder entry points with the kernel selection passed per call instead of taken from the process-wide defaults
- * (nl_decoder_set_gemm_mode / nl_decoder_set_wgrad2_mode below): kernel_modes = NL_KERNEL_MODES(gemm_mode, wgrad2_mode), either
+ * (3, 1; include/nerfloam_hip_debug.h holds the A/B setters): kernel_modes = NL_KERNEL_MODES(gemm_mode, wgrad2_mode), either
  * mode -1 (or kernel_modes == 0) = the process default.  NlIterDesc.kernel_modes carries the same word for nl_iteration. */
 #define NL_KERNEL_MODES(gemm_mode, wgrad2_mode) ((((gemm_mode) + 1) & 0xFF) | ((((wgrad2_mode) + 1) & 0xFF) << 8))
 int nl_decoder_fwd_bwd_m(const void* loss_scalars, const float* X, const float* params, const float* W2T,
@@ -223,11 +223,6 @@ int nl_decoder_wgrad2(const void* loss_scalars, const float* X, const float* par
 /* sum of the per-workgroup slabs partials[nslabs][NL_DEC_PARAMS] written by nl_decoder_fwd_bwd + nl_decoder_wgrad2 into the decoder
  * gradient grad_out[NL_DEC_PARAMS] */
 int nl_decoder_reduce(const float* partials, int nslabs, const float* params, float* grad_out, void* stream);
-/* dW2 kernel selection: 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32), 1 = bf16 matrix cores on the exact
- * formulation dW2[j][k] = w3_j * sum_i m(i,j) * (dsdf_i * H1[i][k]) with the {0,1} mask m as A operand and the fp32
- * B operand split into three bf16 terms (exact products, fp32 accumulation; default). */
-int nl_decoder_set_wgrad2_mode(int mode);
-int nl_decoder_get_wgrad2_mode(void);
 /* forward only: Decoder.get_values on a dense batch (mesh-time get_scores, render_helpers.py:96-153) */
 int nl_decoder_forward(const float* X, const float* params, const float* W2T, int P, float* sdf, int nblocks, void* stream);
 int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, void* stream);
@@ -246,10 +241,10 @@ int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream);
  * 3 = eight of the nine (without lo x lo, below 2^-30 of a product = 2^-6 of one fp32 rounding; bound proven on the host in rational
  *     arithmetic, tests/test_device_math_host.py): THE DEFAULT, 8/9 of the forward matrix-pipe time.
  * 2 = six (also without lo x mid, mid x lo: below 2^-24 of a product): opt-in, never a default.
- * These two setters change the PROCESS-WIDE DEFAULT used by the entry points without a kernel_modes argument (A/B measurements,
- * NL_GEMM_MODE / NL_WGRAD2_MODE of the Python package); callers that need their own selection pass it per call (*_m, NlIterDesc). */
-int nl_decoder_set_gemm_mode(int mode);
-int nl_decoder_get_gemm_mode(void);
+ * dW2 kernel (wgrad2_mode): 0 = fp32 matrix cores, 1 = bf16 matrix cores on dW2[j][k] = w3_j * sum_i m(i,j) * (dsdf_i * H1[i][k]) with the
+ * {0,1} mask m as A operand and the fp32 B operand split into three bf16 terms (exact products, fp32 accumulation; default).
+ * The selection is a PER-CALL argument (kernel_modes of the *_m entry points, NlIterDesc.kernel_modes); the entry points without it use the
+ * library defaults (3, 1).  Changing those defaults process-wide is a test / A-B aid: include/nerfloam_hip_debug.h. */
 
 /* backward of get_features: embedding gradient (fp32 accumulation of bf16-rounded contributions, the
  * CUDA embedding_dense_backward semantics) and pose-gradient partials g_pose[F,12] = (dL/dt, dL/dR), accumulated in fp64
@@ -346,6 +341,7 @@ int nl_dist_rows_move_t(int direction, const unsigned* bitmap, const int* prefix
  * it removes is the host's per-launch cost (~15 launches x ~250 marshalled arguments per iteration from Python). */
 struct NlComm;
 typedef struct NlIterDesc {
+    int struct_size;            /* = sizeof(NlIterDesc) of the header the caller was built with: nl_iteration refuses any other value */
     /* rays of this iteration (sensor frame) and the frames' poses */
     int N, F;
     const float* rays_d_sensor; const float* points_gt; const float* cos_gt; const int* frame_id;
@@ -470,22 +466,6 @@ int nl_octree_export_device_layout(void* h, float voxel_size, float* centres, in
 /* incremental export: rows, in the layout above, of the nodes that changed since the previous call */
 long long nl_octree_delta_count(void* h);
 int nl_octree_export_delta(void* h, float voxel_size, int* ids, float* centres, int* structure, int* vertex_idx);
-
-/* profiling aid: 256 x int64 device buffer receiving per-phase shader-clock stamps of workgroup 0 (NULL = off) */
-int nl_geometry_set_sampler_mode(int mode);     /* nl_sample_rays: 0 = sequential walk per ray, 1 = step-parallel, 2 = by ray count (default); same results */
-int nl_geometry_set_intersect_prune(int on);    /* nl_ray_intersect (tests): 0 = rays with more hits than the work-list kernel's list holds go to the sequential fallback instead of being pruned to the first 20 in place; 1 = default */
-int nl_geometry_set_lanes_per_ray(int lpr);     /* nl_ray_intersect: 0 = the caller's choice / by ray count (default), or 4 / 8 / 16 / 32 lanes per ray for every call */
-int nl_geometry_set_debug_buffer(void* dbg);   /* [blocks][8] int64 stamps of nl_ray_intersect's work-list kernel */
-int nl_field_set_debug_buffer(void* dbg);      /* [blocks][8] int64 stamps of nl_trilinear_bwd's workgroups */
-/* nl_trilinear_bwd is a latency chain per wave: while ONE round of resident workgroups (4 per compute unit) covers the samples with at
- * most 6 per 8-lane group, the launch's other workgroups leave at once (default on; 0 = every workgroup takes samples: A/B aid) */
-int nl_field_set_one_round(int on);
-int nl_field_set_midspan_flush(int min_steps_left);   /* A/B aid: nl_trilinear_bwd writes a full wave table out mid-span when its 8-lane groups have at least this
-                                                         many sample steps left (default 2; < 0 = never: overflowing runs go to memory from their lane) */
-int nl_field_set_probes(int n);               /* A/B aid: open-addressing probes of nl_trilinear_bwd's wave tables before a run goes straight to memory */
-int nl_decoder_set_debug_buffer(void* dbg);
-/* MFMA lane-map self test (debug) */
-int nl_mfma_selftest(const float* A32, const float* B32, float* D32, const float* A16, const float* B16, float* D16, void* stream);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,7 @@ NL_DEC_PARAMS = 70401
 NL_DEC_WS_FLOATS = 262144        # decoder weight workspace: W2^T fp32 + 2 x 3 bf16 operand planes (include/nerfloam_hip.h)
 NL_SEL_BATCH_WS_INTS_PER_FRAME = 8 + 4 * 128 + 2 * 4096     # NL_SELECT_BATCH_WS_INTS(1)
 NL_SEL_MAX_FRAMES = 8
+NL_MAX_FRAMES = 32               # frames (poses) one field-kernel launch takes (csrc/nl_field.hip)
 NL_C = 16
 NL_W = 256
 OFF_W1, OFF_B1 = 0, 256 * 16
@@ -40,7 +41,7 @@ class NerfLoamHipError(RuntimeError):
 
 def _iter_desc_fields():
     P_, I_, F_, D_, LL_, U_ = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_longlong, ctypes.c_uint
-    f = [("N", I_), ("F", I_)]
+    f = [("struct_size", I_), ("N", I_), ("F", I_)]
     f += [(n, P_) for n in ("rays_d_sensor", "points_gt", "cos_gt", "frame_id")]
     f += [(n, P_) for n in ("pose6", "poses12", "pose_m", "pose_v", "pose_enable", "g_pose", "pose_grad6")]
     f += [("blk_hdr", P_), ("blk_ids", P_), ("root_side", I_), ("voxel_size", F_)]

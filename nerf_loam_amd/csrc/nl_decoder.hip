@@ -24,6 +24,7 @@
 //     (K = 16) and dH2 from dsdf + the 256-bit ReLU mask the first kernel saves per sample (32 B instead of a 1 KB row).
 // FLOPs per sample (algorithmic): 3 * 2 * (16*256 + 256*256 + 256) = 419,328 (279,552 with a frozen decoder).
 #include "nl_common.h"
+#include <atomic>
 
 #define DEC_M 64
 #define DEC_THREADS 512
@@ -1153,10 +1154,11 @@ __global__ void k_mfma_selftest(const float* A32, const float* B32, float* D32, 
     for (int r = 0; r < 4; ++r) D16[((lane >> 4) * 4 + r) * 16 + (lane & 15)] = e[r];
 }
 
-static long long* g_dec_dbg = nullptr;
-static int g_gemm_mode = 3;              // 0: fp32 MFMA GEMMs; bf16 MFMA on the exact-product formulations (gemm_x9 / gemm_mask_x) with
+// process-global A/B / profiling state (include/nerfloam_hip_debug.h): relaxed atomics - a setter racing a launch is not a data race
+static std::atomic<long long*> g_dec_dbg{nullptr};
+static std::atomic<int> g_gemm_mode{3};             // 0: fp32 MFMA GEMMs; bf16 MFMA on the exact-product formulations (gemm_x9 / gemm_mask_x) with
                                          // 1: all nine forward products (exact), 3: eight (without lo x lo: the default), 2: six (opt-in)
-static int g_wgrad2_mode = 1;            // 0: fp32 MFMA (k_decoder_wgrad2), 1: exact 0/1-mask x 3-term bf16 split (k_decoder_wgrad2_x)
+static std::atomic<int> g_wgrad2_mode{1};           // 0: fp32 MFMA (k_decoder_wgrad2), 1: exact 0/1-mask x 3-term bf16 split (k_decoder_wgrad2_x)
 
 extern "C" {
 
@@ -1183,8 +1185,8 @@ static bool resolve_modes(int kernel_modes, DecModes* m)
 {
     const int g = (kernel_modes & 0xFF) - 1, w = ((kernel_modes >> 8) & 0xFF) - 1;
     if (g > 3 || w > 1 || (kernel_modes >> 16) != 0) return false;
-    m->gemm = g < 0 ? g_gemm_mode : g;
-    m->wgrad2 = w < 0 ? g_wgrad2_mode : w;
+    m->gemm = g < 0 ? g_gemm_mode.load(std::memory_order_relaxed) : g;
+    m->wgrad2 = w < 0 ? g_wgrad2_mode.load(std::memory_order_relaxed) : w;
     return true;
 }
 

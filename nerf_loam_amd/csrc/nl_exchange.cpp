@@ -21,6 +21,7 @@
 #include <link.h>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <hip/hip_runtime.h>
 
@@ -47,6 +48,8 @@ struct Rccl {
 Rccl& rccl()
 {
     static Rccl r;
+    static std::mutex mu;                                                        // (two threads in nl_comm_init_rccl: one look-up at a time)
+    std::lock_guard<std::mutex> lock(mu);
     if (r.ok) return r;                                                          // (a failed look-up is retried: RCCL may be loaded later)
     r = [] {
         Rccl x;

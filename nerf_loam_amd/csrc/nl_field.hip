@@ -9,6 +9,7 @@
 //
 // Two lanes per sample, 8 channels (one 16-byte bf16 load per corner) each.
 #include "nl_common.h"
+#include <atomic>
 #include "../../include/nerfloam_hip.h"
 
 #define NL_FIELD_THREADS 256
@@ -452,10 +453,10 @@ __global__ void k_unpack_samples(const NlLossScalars* ls, const int* s_ray, cons
     }
 }
 
-static long long* g_field_dbg = nullptr;
-static int g_field_probes = TB_PROBES;   // (A/B aid: nl_field_set_probes)
-static int g_field_flush_steps = TB_FLUSH_MIN_STEPS_LEFT;   // (A/B aid: nl_field_set_midspan_flush; a huge value = never)
-static int g_field_one_round = 1;       // k_trilinear_bwd: TB_ONE_ROUND_SPAN rule on (0: every launched workgroup takes samples; A/B aid)
+static std::atomic<long long*> g_field_dbg{nullptr};   // process-global A/B / profiling state (include/nerfloam_hip_debug.h), relaxed atomics
+static std::atomic<int> g_field_probes{TB_PROBES};   // (A/B aid: nl_field_set_probes)
+static std::atomic<int> g_field_flush_steps{TB_FLUSH_MIN_STEPS_LEFT};   // (A/B aid: nl_field_set_midspan_flush; a huge value = never)
+static std::atomic<int> g_field_one_round{1};       // k_trilinear_bwd: TB_ONE_ROUND_SPAN rule on (0: every launched workgroup takes samples; A/B aid)
 
 // workgroups of k_trilinear_bwd the current device holds at once: 4 per compute unit (its 33 KB of LDS and launch bounds)
 static int field_resident_blocks()

@@ -6,6 +6,7 @@
 // Reference behaviour: third_party/sparse_voxels/src/intersect_gpu.cu:193-272,
 // src/variations/voxel_helpers.py:531-598, third_party/sparse_voxels/src/sample_gpu.cu:133-239.
 #include "nl_common.h"
+#include <atomic>
 
 #define NL_GEO_THREADS 256
 
@@ -302,9 +303,9 @@ struct ChildSlabs {
     }
 };
 
-static int g_isect_lpr = 0;
-static int g_isect_prune = 1;           // 0 (tests): no first-20 pruning - a ray with more hits than its list holds goes to the sequential fallback
-static int g_sampler_mode = 2;          // 0: one lane per ray, sequential walk (k_sample); 1: step-parallel (k_sample_par); 2: by ray count
+static std::atomic<int> g_isect_lpr{0};                // process-global A/B / test state (include/nerfloam_hip_debug.h), relaxed atomics
+static std::atomic<int> g_isect_prune{1};          // 0 (tests): no first-20 pruning - a ray with more hits than its list holds goes to the sequential fallback
+static std::atomic<int> g_sampler_mode{2};         // 0: one lane per ray, sequential walk (k_sample); 1: step-parallel (k_sample_par); 2: by ray count
 __device__ long long* g_isect_dbg = nullptr;            // optional [blocks][8] stamps of thread 0 (profiling aid, nl_geometry_set_debug_buffer)
 #define ISTAMP(k, v) do { if (g_isect_dbg && threadIdx.x == 0) g_isect_dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)(v); } while (0)
 #define SSTAMP(k) do { if (g_isect_dbg && threadIdx.x == 0) g_isect_dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -1578,12 +1579,13 @@ static int intersect_launch(int N, const float* rays_d_sensor, const float* poin
     // A/B override, else the caller's choice (the map's: see the header), else by ray count: up to 4096 rays the launch leaves most of the device
     // idle and 32 lanes cost nothing (one-scan map 2048 rays ~35 -> 30 us, 5 / 15 / 40 / 150 scans 39 -> 31, 61 -> 45, 94 -> 54, 122 -> 71); beyond, 32 lanes
     // mean twice the workgroups and only maps whose rays have wide fronts gain (profiles/r04_n_intersect_lanes_ab.txt)
-    const int lpr = g_isect_lpr ? g_isect_lpr : lanes ? lanes : (N <= 4096 ? 32 : N <= 16384 ? 16 : 8);
+    const int forced = g_isect_lpr.load(std::memory_order_relaxed);
+    const int lpr = forced ? forced : lanes ? lanes : (N <= 4096 ? 32 : N <= 16384 ? 16 : 8);
     auto kq = lpr == 32 ? k_ray_intersect_q<32> : lpr == 16 ? k_ray_intersect_q<16> : lpr == 8 ? k_ray_intersect_q<8> : k_ray_intersect_q<4>;
     const int IQ_RAYS = NL_GEO_THREADS / lpr;
     hipLaunchKernelGGL(kq, dim3(nl_div_up(N, IQ_RAYS)), dim3(NL_GEO_THREADS), 0, st,
                        N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, (const int2*)blk_hdr, (const int4*)blk_ids, root_side, voxel_size, max_distance,
-                       rays_d_world, gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, scratch_rays, g_isect_prune);
+                       rays_d_world, gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, scratch_rays, g_isect_prune.load(std::memory_order_relaxed));
     // rays whose LDS queue / hit list overflowed (none on ordinary scans): sequential DFS, device-side count
     const DfsArgs da = {N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, (const int2*)blk_hdr, (const int4*)blk_ids, root_side, voxel_size,
                         max_distance, rays_d_world, gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, (const int*)scratch_rays};
@@ -1713,7 +1715,8 @@ int nl_sample_rays(int emit, int N, const int* hit_idx, const float* hit_t0, con
     // step-parallel (SP_LPR lanes per ray): the emit pass at every size (131 072 rays: 22.7 us against 29.3 us sequential, 16 384: 12.1
     // against 15.3), the count pass in the latency-bound regime only - beyond 8192 rays its 1024 workgroups x 10 same-line atomics and
     // the extra threads cost more than the shorter chains save (16 384 rays: 19.5 against 15.5 us, 131 072: 77 against 24)
-    if (g_sampler_mode == 1 || (g_sampler_mode == 2 && (emit || N <= 8192))) {
+    const int smode = g_sampler_mode.load(std::memory_order_relaxed);
+    if (smode == 1 || (smode == 2 && (emit || N <= 8192))) {
         const int nbk = nl_div_up(N, SP_RAYS) < 1024 ? nl_div_up(N, SP_RAYS) : 1024;
         if (emit) hipLaunchKernelGGL(k_sample_par<true>, dim3(nbk), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);
         else      hipLaunchKernelGGL(k_sample_par<false>, dim3(nbk), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);

@@ -13,14 +13,26 @@ enum { IT_R = 0, IT_R_GLOBAL = 13, IT_OK = 0, IT_ERR_INVALID_ARG = 1, IT_ERR_LAU
 
 extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
 {
-    if (!d || d->N <= 0 || d->F <= 0 || !(stages & 7)) return IT_ERR_INVALID_ARG;
+    // struct_size: a caller built against another revision of the header (the descriptor has grown every round) is refused instead of
+    // having its shorter struct read past the end
+    if (!d || d->struct_size != (int)sizeof(NlIterDesc) || d->N <= 0 || d->F <= 0 || !(stages & 7)) return IT_ERR_INVALID_ARG;
     const bool sharded = d->comm != nullptr;                    // ray-sharded multi-GPU iteration: the exchanges of nl_exchange.cpp ride along
     hipStream_t st = (hipStream_t)stream;
     const NlTouchedRows touched_rows = {d->touched_list, d->touched_count, d->touched_flags};
     const NlTouchedRows* touched = d->touched_flags ? &touched_rows : nullptr;      // rows written by the scatter are recorded
     int rc = IT_OK;
-    bool overlapped = false;
-#define NL_TRY(call) do { rc = (call); if (rc != IT_OK) return rc; } while (0)
+    bool overlapped = false, forked = false;
+    // an error after the side stream was forked still JOINS it before returning: a capture in progress is not left with a dangling
+    // stream, and later work on `stream` cannot race the all-reduce that may be in flight on the accumulators
+    auto leave = [&](int code) {
+        if (forked) {
+            hipEventRecord((hipEvent_t)d->ev_join, (hipStream_t)d->comm_stream);
+            hipStreamWaitEvent(st, (hipEvent_t)d->ev_join, 0);
+            forked = false;
+        }
+        return code;
+    };
+#define NL_TRY(call) do { rc = (call); if (rc != IT_OK) return leave(rc); } while (0)
     if (stages & 1) {
         int* c = d->counters;
         // the counter block starts an iteration zeroed: by the previous iteration's last kernel when that handed it over
@@ -65,15 +77,17 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
                                       d->centres, d->vertex_rows, d->emb, d->voxel_size, d->dX, d->want_emb_grad ? d->g_emb : nullptr,
                                       d->want_pose_grad ? d->g_pose : nullptr, 2 * d->field_blocks, touched, stream));
             if (hipEventRecord((hipEvent_t)d->ev_fork, st) != hipSuccess || hipStreamWaitEvent(cs, (hipEvent_t)d->ev_fork, 0) != hipSuccess) return IT_ERR_LAUNCH;
+            forked = true;
             NL_TRY(nl_exchange_emb_pose(d, d->comm_stream));
-            if (hipEventRecord((hipEvent_t)d->ev_join, cs) != hipSuccess) return IT_ERR_LAUNCH;
+            if (hipEventRecord((hipEvent_t)d->ev_join, cs) != hipSuccess) return leave(IT_ERR_LAUNCH);
         }
         if (d->train_decoder) {
             NL_TRY(nl_decoder_wgrad2_m(d->loss_scalars, d->X, d->dec_params, d->dsdf, d->relu2_mask, d->partials, d->n_slabs, d->kernel_modes, stream));
             NL_TRY(nl_decoder_reduce_m(d->partials, d->n_slabs, d->dec_params, d->dec_grad, d->kernel_modes, stream));
         }
         if (overlapped) {
-            if (hipStreamWaitEvent(st, (hipEvent_t)d->ev_join, 0) != hipSuccess) return IT_ERR_LAUNCH;
+            if (hipStreamWaitEvent(st, (hipEvent_t)d->ev_join, 0) != hipSuccess) return leave(IT_ERR_LAUNCH);
+            forked = false;
             NL_TRY(nl_exchange_decoder(d, stream));
         } else
         NL_TRY(nl_trilinear_bwd_t(d->loss_scalars, d->s_vox, d->s_depth, d->s_ray, d->rays_d_world, d->rays_d_sensor, d->frame_id, d->poses12, d->F,

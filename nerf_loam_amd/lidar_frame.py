@@ -26,14 +26,14 @@ def scan_of(frame, device):
     `dirs` is None when the points are fp32 - the selection kernels then derive directions from the points (a1 on the device);
     a frame that holds points in another dtype has its own `rays_d` uploaded (the reference divides in that dtype and rounds after)."""
     dev = torch.device(device)
-    pts = frame.points
-    key = (pts.data_ptr(), pts._version, int(pts.shape[0]), dev)
+    pts, pc = frame.points, frame.pointsCos
+    key = (pts.data_ptr(), pts._version, int(pts.shape[0]), dev, pc.data_ptr(), pc._version)
     sc = frame.__dict__.get("_nl_scan")
     if sc is None or sc["key"] != key:
         p = pts.detach().reshape(-1, 3)
         dirs = None
         if p.dtype != torch.float32:
-            own = frame.__dict__.get("rays_d")                   # (the reference's LidarFrame keeps the array it built in that dtype)
+            own = frame.__dict__.get("rays_d", frame.__dict__.get("_nl_own_rays_d"))     # (the reference's LidarFrame keeps the array it built in that dtype)
             own = p / (torch.norm(p, 2, -1, keepdim=True) + 1e-8) if own is None else own
             dirs = own.detach().reshape(-1, 3).to(dev, torch.float32).contiguous()
         sc = dict(key=key, points=p.to(dev, torch.float32).contiguous(),
@@ -98,14 +98,36 @@ class LidarFrame(nn.Module):
             sc["rays_d"], sc["rays_norm"] = d.view(M, 1, 3), n.view(M, 1)
         return sc["rays_d"]
 
+    # `rays_d` [M,1,3] / `rays_norm` [M,1] as the reference's attributes (lidarFrame.py:47-52): on the device of `points`, so that
+    # reference-style code mixing them with `points` (mapping.py:260-262 `frame.points[frame.rays_norm.reshape(-1) <= d]`) works on host
+    # points too; computed once by nl_unit_dirs (the engine itself never reads them: device_scan / get_rays are its accessors).
+    # Assignable like plain attributes (`frame.rays_d = ...` keeps the caller's tensor).
+    def _host_side(self, name):
+        own = self.__dict__.get("_nl_own_" + name)
+        if own is not None:
+            return own
+        self.get_rays()
+        sc = self.__dict__["_nl_scan"]
+        t = sc[name]
+        if t.device != self.points.device:
+            t = sc.setdefault(name + "_on_points_device", t.to(self.points.device))
+        return t
+
     @property
     def rays_d(self):
-        return self.get_rays()
+        return self._host_side("rays_d")
+
+    @rays_d.setter
+    def rays_d(self, value):
+        self.__dict__["_nl_own_rays_d"] = value
 
     @property
     def rays_norm(self):
-        self.get_rays()
-        return self.__dict__["_nl_scan"]["rays_norm"]
+        return self._host_side("rays_norm")
+
+    @rays_norm.setter
+    def rays_norm(self, value):
+        self.__dict__["_nl_own_rays_norm"] = value
 
     # ---- a2, seeded host fallback (RAY_SELECTION = "host")
     @torch.no_grad()

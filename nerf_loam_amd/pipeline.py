@@ -43,6 +43,19 @@ class IterConfig:
     tail_always: bool = False          # False = reference sampler tail behaviour
 
 
+BYTES_PER_SAMPLE = 184         # per-sample workspace of an engine: voxel, depth, dist, ray, X[16], dX[16], sdf, dsdf, 8 ReLU words
+
+
+def samples_per_ray_bound(voxel_size, step_size, max_hits=L.NL_MAX_HITS):
+    """Most valid samples one ray can produce (reference sampler, voxel_helpers.py:572-577 + sample_gpu.cu:165-238): a ray keeps at most
+    `max_hits` voxels, a straight line stays inside a cube of side v for at most sqrt(3) v, the sampler takes
+    steps = sum(len) / step_size stratified samples (+1: the ceil) and one closing sample per hit interval.  An engine whose sample
+    workspace holds N times this many samples cannot overflow, whatever the map: maicity tracker (0.2 m / 0.04 m) 195, kitti tracker
+    (0.3 / 0.06) 195, ncd tracker (0.2 / 0.02) 368, the mappers (step = voxel / 2) 91."""
+    import math
+    return int(math.ceil(max_hits * math.sqrt(3.0) * float(voxel_size) / float(step_size))) + int(max_hits) + 1
+
+
 ISECT_WIDE_BLOCKS = 60_000       # children blocks from which MapDevice.isect_lanes_for gives a ray 32 lanes at 4097 .. 16 384 rays
 
 
@@ -220,6 +233,7 @@ class SdfEngine:
         self.kernel_modes = L.kernel_modes(gemm_mode, wgrad2_mode)
         self.dev = torch.device(device)
         self.N_cap = int(max_rays)
+        self.samples_per_ray_cap, self.samples_clipped = int(samples_per_ray_cap), False     # (samples_per_ray_bound: what no call can exceed)
         self.P_cap = int(max_rays) * int(samples_per_ray_cap)
         self.F_cap = int(max_frames)
         d = self.dev
@@ -681,6 +695,7 @@ class SdfEngine:
     def _fill_desc(self, m, dec, cfg, train_decoder=True, want_emb_grad=True, want_pose_grad=True, update_emb=True, update_decoder=True,
                    update_pose=True, lr_pose=None, skip_mode=0, fresh_noise=False, ray_id_base=0):
         d = self._desc
+        d.struct_size = ctypes.sizeof(L.NlIterDesc)
         pt = lambda t: None if t is None else t.data_ptr()          # noqa: E731
         for name in ("rays_d_sensor", "points_gt", "cos_gt", "frame_id", "pose6", "poses12", "pose_m", "pose_v", "pose_enable", "g_pose", "pose_grad6",
                      "rays_d_world", "gt_dist", "hit_idx", "hit_t0", "hit_t1", "hit_count", "hit_rank", "ray_of_rank", "samp_count", "samp_off",
@@ -718,6 +733,8 @@ class SdfEngine:
     def run_bound(self, stages=3):
         """one iteration of the bound configuration: stages bit 0 = forward + backward, bit 1 = optimiser step"""
         d = self._desc
+        if d.N != self.N:                                           # (the lane choice follows the ray count: 32 / 16 / 8 lanes per ray)
+            d.isect_lanes = self._bound[0].isect_lanes_for(self.N) if self._bound is not None else 0
         d.N, d.F = self.N, self.F
         stages = int(stages)
         ex = self._exchange

@@ -23,7 +23,7 @@ import torch
 from . import _lib as L
 from . import ops
 from .lidar_frame import scan_of
-from .pipeline import DecoderDevice, IterConfig, MapDevice, SdfEngine
+from .pipeline import BYTES_PER_SAMPLE, DecoderDevice, IterConfig, MapDevice, SdfEngine, samples_per_ray_bound
 
 _ENGINES = OrderedDict()
 MAX_CACHED_ENGINES = 4          # (device, ray capacity, frame capacity) -> SdfEngine, least recently used evicted
@@ -65,11 +65,34 @@ def reseed():
     _PRIVATE_GEN = None
 
 
-def _engine(n_rays, n_frames, device):
+SAMPLE_MEMORY_FRACTION = 0.5     # of the device memory that is free when an engine is built: the most its per-sample workspace may take
+
+
+def _samples_per_ray_cap(n_rays, voxel_size, step_size, device):
+    """-> (samples per ray the engine provides for, True when device memory clipped it).  The capacity is DERIVED from the call's
+    settings (pipeline.samples_per_ray_bound: the most samples the reference's sampler can give one ray at this voxel / step size),
+    so no legal configuration overflows it - the tracker steps of the shipped configs (tracking.py:36: 0.2 x voxel, ncd 0.1 x voxel)
+    on a map of any density included.  Only the device's memory limits it: 184 B per sample, i.e. 2048 rays x 368 samples = 139 MB."""
+    need = samples_per_ray_bound(voxel_size, step_size)
+    try:
+        free = torch.cuda.mem_get_info(device)[0]
+    except Exception:                                       # noqa: BLE001 - no memory query: trust the bound
+        return need, False
+    fit = int(free * SAMPLE_MEMORY_FRACTION / (BYTES_PER_SAMPLE * max(int(n_rays), 1)))
+    return (need, False) if fit >= need else (max(fit, 1), True)
+
+
+def _engine(n_rays, n_frames, device, voxel_size, step_size):
     key = (str(device), int(n_rays), max(2, int(n_frames)))
     eng = _ENGINES.get(key)
-    if eng is None:
-        eng = SdfEngine(max_rays=key[1], samples_per_ray_cap=96, max_frames=key[2], device=device)
+    need = samples_per_ray_bound(voxel_size, step_size)
+    if eng is None or (eng.samples_per_ray_cap < need and not eng.samples_clipped):
+        # (a cached engine built for a coarser step - the mapper's - is replaced by one that also holds the tracker's samples)
+        if eng is not None:
+            del _ENGINES[key], eng
+        cap, clipped = _samples_per_ray_cap(key[1], voxel_size, step_size, device)
+        eng = SdfEngine(max_rays=key[1], samples_per_ray_cap=cap, max_frames=key[2], device=device)
+        eng.samples_clipped = clipped
         _ENGINES[key] = eng
         while len(_ENGINES) > MAX_CACHED_ENGINES:
             _ENGINES.popitem(last=False)
@@ -223,9 +246,11 @@ def _finish_call(eng, what):
     frames' poses"""
     (steps, skipped, overflow), poses = eng.call_status_and_poses()
     if overflow:
-        raise L.NerfLoamHipError(f"the call is invalid: an iteration produced more than {eng.P_cap} valid samples "
-                                 f"({eng.P_cap // max(eng.N_cap, 1)} per ray on average are provided for: step_size too fine for "
-                                 "nerf_loam_amd.render_helpers._engine's samples_per_ray_cap), or the on-device ray selection missed its "
+        # the sample workspace holds the sampler's worst case for the call's voxel / step size (_samples_per_ray_cap), so this is reachable
+        # only when device memory clipped that capacity, or when the on-device ray selection missed its threshold window
+        raise L.NerfLoamHipError(f"the call is invalid: an iteration produced more than {eng.P_cap} valid samples ({eng.P_cap // max(eng.N_cap, 1)} "
+                                 "per ray are provided for" + (": device memory clipped the sample workspace below the sampler's worst case for this "
+                                 "step_size" if getattr(eng, "samples_clipped", False) else "") + "), or the on-device ray selection missed its "
                                  "threshold window")
     for _ in range(skipped if what == "Mapping" else min(skipped, 1)):
         print(f"Encouter a bug while {what}, currently not be fixed, " + ("Continue!!" if what == "Mapping" else "Restarting!!"))
@@ -241,7 +266,7 @@ def bundle_adjust_frames(keyframe_graph, embeddings, map_states, sdf_network, lo
     assert map_states["voxel_vertex_emb"].data_ptr() == embeddings.data_ptr(), "embeddings must be map_states['voxel_vertex_emb']"
     m = _map_device(map_states, voxel_size, device)
     dec = _decoder_device(sdf_network, device)
-    eng = _engine(N_rays * len(keyframe_graph), len(keyframe_graph), device)
+    eng = _engine(N_rays * len(keyframe_graph), len(keyframe_graph), device, voxel_size, step_size)
     cfg = _cfg(loss_criteria, voxel_size, step_size, max_distance, learning_rate)
     optimise = [int(kf.index != 0 and update_pose) for kf in keyframe_graph]
     eng.set_poses(np.stack([kf.pose.data.detach().cpu().numpy() for kf in keyframe_graph]), optimise)
@@ -274,7 +299,7 @@ def track_frame(frame_pose, curr_frame, map_states, sdf_network, loss_criteria, 
     device = emb.device
     m = _map_device(map_states, voxel_size, device)
     dec = _decoder_device(sdf_network, device)
-    eng = _engine(N_rays, 1, device)
+    eng = _engine(N_rays, 1, device, voxel_size, step_size)
     cfg = _cfg(loss_criteria, voxel_size, step_size, max_distance)
     # (the reference deep-copies the module, render_helpers.py:445; a module holding one 6-vector is rebuilt directly - 0.1 ms of the call)
     init_pose = type(frame_pose)(frame_pose.data.detach().clone()) if type(frame_pose).__name__ == "OptimizablePose" else deepcopy(frame_pose)
@@ -301,7 +326,8 @@ def render_rays(rays_o, rays_d, map_states, sdf_network, step_size, voxel_size, 
                 chunk_size=10000, profiler=None, return_raw=False):
     """Forward rendering of world-space rays (render_helpers.py:190-318): any origins - every distinct origin becomes one "frame" of
     the engine (identity rotation, that translation), so a batch of several frames' rays (bundle_adjust_frames' layout, :385-388) or
-    rays with individual origins render in one pass.  The returned tensors stay on the device."""
+    rays with individual origins render in one pass - up to NL_MAX_FRAMES = 32 distinct origins per call (the field kernels keep the
+    frames' poses in registers); more raise here, render them in groups.  The returned tensors stay on the device."""
     emb = map_states["voxel_vertex_emb"]
     device = emb.device
     o = rays_o.reshape(-1, 3).to(device, torch.float32)
@@ -313,9 +339,12 @@ def render_rays(rays_o, rays_d, map_states, sdf_network, step_size, voxel_size, 
     else:
         origins, inv = torch.unique(o, dim=0, return_inverse=True)
         fid = inv.to(torch.int32)
+        if origins.shape[0] > L.NL_MAX_FRAMES:
+            raise L.NerfLoamHipError(f"render_rays: {origins.shape[0]} distinct ray origins in one call, the field kernels take at most "
+                                     f"{L.NL_MAX_FRAMES} frames (csrc/nl_field.hip NL_MAX_FRAMES): render the rays in groups of origins")
     m = _map_device(map_states, voxel_size, device)
     dec = _decoder_device(sdf_network, device)
-    eng = _engine(d.shape[0], origins.shape[0], device)
+    eng = _engine(d.shape[0], origins.shape[0], device, voxel_size, step_size)
     crit = type("C", (), dict(truncation=truncation, sdf_weight=1.0, fs_weight=1.0))
     cfg = _cfg(crit, voxel_size, step_size, max_distance)
     pose6 = torch.cat([origins, torch.zeros_like(origins)], 1).cpu().numpy()

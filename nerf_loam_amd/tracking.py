@@ -2,7 +2,8 @@
 
 Mirror of /root/reference/src/tracking.py:98-148 (`do_tracking`): constant-velocity initialisation of
 the translation, `track_frame`, relative-pose bookkeeping, the 5x iteration count on the first
-tracked frame (B17).  The data loader, keyframe policy and process loop stay with the reference."""
+tracked frame (B17), and the hand-over of every tracked frame to the mapper's queue (`check_keyframe`, :144-153: the reference's
+`spin()` relies on `do_tracking` doing it).  The data loader and the process loop stay with the reference."""
 from copy import deepcopy
 
 import torch
@@ -49,4 +50,14 @@ class Tracking:
         self.rel_pose = torch.linalg.inv(self.last_frame.get_pose().detach()) @ current_frame.get_pose().detach()
         current_frame.set_rel_pose(self.rel_pose)
         self.last_frame = current_frame
+        self.check_keyframe(current_frame, kf_buffer)             # tracking.py:144-147: the mapper process receives every tracked frame
         return current_frame
+
+    def check_keyframe(self, check_frame, kf_buffer):
+        """tracking.py:150-154: a blocking put on the mapper's queue; a missing / closed queue is ignored like the reference ignores it"""
+        if kf_buffer is None:
+            return
+        try:
+            kf_buffer.put(check_frame, block=True)
+        except Exception:                                         # noqa: BLE001 - the reference's bare `except: pass`
+            pass

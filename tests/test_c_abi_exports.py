@@ -10,10 +10,23 @@ from nerf_loam_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "nerfloam_hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(nl_[a-z0-9_]+)\s*\(", src)))
+HEADERS = ("nerfloam_hip.h", "nerfloam_hip_debug.h")      # the product surface; test / profiling / A-B aids (process-global switches)
+
+
+def declared_symbols(headers=HEADERS):
+    out = set()
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        out |= set(re.findall(r"\b(nl_[a-z0-9_]+)\s*\(", src))
+    return sorted(out)
+
+
+def test_the_product_header_declares_no_process_global_switch():
+    """the library is thread-safe given distinct streams - every nl_*_set_* (process-global state) lives in the debug header"""
+    prod = declared_symbols(HEADERS[:1])
+    assert not [s for s in prod if "_set_" in s or "_get_" in s or "selftest" in s], prod
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == sorted(HEADERS)
 
 
 def test_header_symbols_exported_and_bound():
@@ -34,7 +47,7 @@ def test_header_is_plain_c_and_every_entry_links_from_c(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("no gcc")
     syms = declared_symbols()
-    src = ['#include "nerfloam_hip.h"', "#include <stdio.h>", "typedef void (*fn)(void);", "int main(void) {",
+    src = ['#include "nerfloam_hip.h"', '#include "nerfloam_hip_debug.h"', "#include <stdio.h>", "typedef void (*fn)(void);", "int main(void) {",
            "    fn table[] = {"] + [f"        (fn){s}," for s in syms] + ["    };",
            "    void* t = nl_octree_create(64);", "    int v[6] = {1, 2, 3, 1, 2, 4};",
            "    if (!t || nl_octree_insert(t, v, 2) != 0) return 2;",

@@ -50,7 +50,9 @@ def test_mapping_then_tracking_like_the_reference_loop():
 
     def rendered_loss():
         pose = f0.get_pose()
-        d = f0.rays_d.reshape(-1, 3) @ pose[:3, :3].T.cuda()
+        assert f0.rays_d.device == f0.points.device and f0.rays_norm.shape == (len(pts), 1)     # the reference's attributes, on the points' device
+        assert (f0.points[f0.rays_norm.reshape(-1) <= 30.0].shape[0]) > 0                        # mapping.py:260-262 style indexing
+        d = f0.get_rays().reshape(-1, 3) @ pose[:3, :3].T.cuda()
         o = pose[:3, 3].reshape(1, 3).expand_as(d).cuda().contiguous()
         out = render_rays(o[None], d[None], mapper.map_states, mapper.decoder, mapper.step_size, 0.2, 0.3, 20, 50.0)
         z = out["z_vals"]; sdf = out["sdf"]; m = out["valid_mask"]
@@ -76,7 +78,10 @@ def test_mapping_then_tracking_like_the_reference_loop():
     err0 = float((f1.pose.translation() - f0.pose.translation()).norm())
     tracker.last_frame = f1                                             # start from the perturbed pose (no motion model yet)
     f2 = LidarFrame(2, torch.from_numpy(pts), torch.from_numpy(cos), np.eye(4))
-    out = tracker.do_tracking(share, f2)
+    import queue
+    kf_buffer = queue.Queue()
+    out = tracker.do_tracking(share, f2, kf_buffer)
+    assert kf_buffer.get_nowait() is out and kf_buffer.empty()         # tracking.py:144-147: every tracked frame goes to the mapper's queue
     err1 = float((out.pose.translation() - f0.pose.translation()).norm())
     assert out.pose.data.shape == (6,) and torch.isfinite(out.pose.data).all()
     assert err1 < 0.8 * err0, (err0, err1)                              # 10 steps on freshly drawn rays pull it back towards the true pose

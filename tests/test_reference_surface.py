@@ -110,7 +110,7 @@ def _ast_methods(path, cls):
 @pytest.mark.parametrize("module,cls,methods", [
     ("mapping", "Mapping", ["__init__", "create_voxels", "get_embeddings", "update_grid_features", "do_mapping", "select_optimize_targets",
                             "insert_keyframe", "update_share_data"]),
-    ("tracking", "Tracking", ["__init__", "do_tracking"])])
+    ("tracking", "Tracking", ["__init__", "do_tracking", "check_keyframe"])])
 def test_mapping_and_tracking_call_sites_keep_their_signatures(module, cls, methods):
     """mapping.py / tracking.py cannot be imported here (open3d, a hard-coded load_library path): their signatures are read from
     the source tree with ast.  Every call that is valid for the reference must be valid here: same names and order, same defaults; ours may make a
