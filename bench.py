@@ -443,18 +443,18 @@ def shard_probe_bench(w, device, full_ms, steps=12):
     return out
 
 
-def build_large_map(w, device, n_scans=150, spacing=3.0):
+def build_large_map(w, device, n_scans=150, spacing=3.0, voxel=0.2):
     """the synthetic scan inserted at `n_scans` poses `spacing` m apart along x (host octree, nerf_loam_amd.svo), N(0, 0.01^2) embeddings"""
     from nerf_loam_amd import pipeline as P, synthetic as S
     from nerf_loam_amd.svo import Octree
     t0 = time.perf_counter()
     oc = Octree()
-    oc.init(256 * 256 * 4, 16, 0.2)
+    oc.init(256 * 256 * 4, 16, voxel)
     poses = []
     for i in range(n_scans):
         pose = S.scan_pose(tx=spacing * i)
         poses.append(pose)
-        oc.insert(S.voxel_coords(w["points"], np.eye(3, dtype=np.float32), pose[:3], 0.2))
+        oc.insert(S.voxel_coords(w["points"], np.eye(3, dtype=np.float32), pose[:3], voxel))
     centres, structure, vertex_idx = oc.export_device_layout()
     flat = np.unique(vertex_idx[vertex_idx >= 0])
     id2row = -np.ones(len(centres), np.int32)
@@ -463,8 +463,85 @@ def build_large_map(w, device, n_scans=150, spacing=3.0):
     emb = np.random.default_rng(778).normal(0, 0.01, (E, 16)).astype(np.float32)
     emb_bits = (emb.view(np.uint32) >> 16).astype(np.uint16)
     build_s = time.perf_counter() - t0
-    m = P.MapDevice(centres, structure, vertex_idx, id2row, emb_bits, 0.2, device=device)
-    return dict(centres=centres, structure=structure, vertex_idx=vertex_idx, id2row=id2row, E=E, map=m, poses=poses, build_s=build_s)
+    m = P.MapDevice(centres, structure, vertex_idx, id2row, emb_bits, voxel, device=device)
+    return dict(centres=centres, structure=structure, vertex_idx=vertex_idx, id2row=id2row, E=E, map=m, poses=poses, build_s=build_s, voxel=voxel)
+
+
+# the tracker's operating points of the shipped configs: step = tracker_specs.step_size x voxel_size (src/tracking.py:36) -
+# configs/maicity/maicity.yaml:22,29 (0.2 x 0.2), configs/kitti/kitti.yaml:22,29 (0.2 x 0.3), configs/ncd/ncd.yaml:22,29 (0.1 x 0.2)
+TRACKER_SETTINGS = {"maicity": dict(voxel=0.2, step=0.04, lr=0.005), "kitti": dict(voxel=0.3, step=0.06, lr=0.005), "ncd": dict(voxel=0.2, step=0.02, lr=0.005)}
+
+
+def tracker_step_on_map(w, lm, device, step, lr=0.005, n_rays=2048, steps=100, with_parity=True, samples_per_ray_cap=None):
+    """M2 at the reference's real operating point: the track_frame-shaped iteration (render_helpers.py:452-512: decoder and embeddings frozen,
+    pose gradient, 6-dof Adam with the tracker's lr / 3 rule) on `n_rays` returns of the scan in the middle of an ACCUMULATED map `lm`
+    (build_large_map), from a pose 3-4 cm off.  The sample workspace is sized by pipeline.samples_per_ray_bound, like the API sizes it.
+    -> ms per step (one C call per iteration), samples per hit ray, and the parity of one iteration against the oracle: hit lists, sample
+    layout and depths bit for bit, sdf, dL/dsdf, dL/dX, the 6-dof pose gradient."""
+    from nerf_loam_amd import pipeline as P
+    voxel = lm["voxel"]
+    m, poses = lm["map"], lm["poses"]
+    dec = P.DecoderDevice(*[np.asarray(a, np.float32) for a in w["host"]["dec"]], device=device)
+    sel = np.sort(np.random.default_rng(5).choice(len(w["points"]), n_rays, replace=False))
+    cap = P.samples_per_ray_bound(voxel, step) if samples_per_ray_cap is None else samples_per_ray_cap
+    eng = P.SdfEngine(max_rays=n_rays, samples_per_ray_cap=cap, max_frames=2, device=device)
+    eng.set_rays(w["dirs"][sel], w["points"][sel], w["cos"][sel])
+    pose = poses[len(poses) // 2].copy(); pose[:3] += np.array([0.03, -0.02, 0.01], np.float32)
+    eng.set_poses(pose[None], [1])
+    cfg = P.IterConfig(voxel_size=voxel, step_size=step)
+    flags = dict(train_decoder=False, want_emb_grad=False, want_pose_grad=True, update_emb=False, update_decoder=False, update_pose=True, lr_pose=lr / 3)
+    eng.begin_call(m, None, emb_state=False)
+    out = dict(voxel_size_m=voxel, step_size_m=step, rays=n_rays, samples_per_ray_capacity=cap, octree_nodes=int(len(lm["centres"])), embedding_rows=int(lm["E"]))
+    if with_parity:
+        from oracle import oracle as O
+        eng.forward_backward(m, dec, cfg, train_decoder=False, want_emb_grad=False, want_pose_grad=True)
+        eng.optimiser_step(m, dec, cfg, update_emb=False, update_decoder=False, update_pose=False)       # pose_grad6 of this iteration, no step
+        torch.cuda.synchronize()
+        st = eng.stats()
+        P_ = st["P"]
+        out.update(valid_samples=int(P_), hit_rays=int(st["R"]), max_hits=int(st["H"]), max_samples_per_ray=int(st["S"]), overflow=int(st["overflow"]),
+                   samples_per_hit_ray=float(P_) / max(st["R"], 1))
+        ms_o = O.MapState(lm["centres"], lm["structure"], lm["vertex_idx"], lm["id2row"], m.emb.cpu().numpy().view(np.uint16).copy(), voxel)
+        dn = dec.numpy()
+        dp = O.DecoderParams(dn["W1"], dn["b1"], dn["W2"], dn["b2"], dn["W3"], dn["b3"])
+        ref = O.render_and_grad(ms_o, dp, [O.Frame(w["dirs_host"][sel], w["points"][sel], w["cos"][sel], pose.copy())], O.IterCfg(step_size=step),
+                                want_emb_grad=False, want_dec_grad=False)
+        rr, ss = np.nonzero(ref["valid"])
+        hc = eng.hit_count[:n_rays].cpu().numpy()
+        H_ = ref["hit_idx"].shape[1]
+        live = np.arange(H_)[None, :] < hc[:, None]
+        geom = bool(not st["overflow"] and P_ == ref["n_samples"] and np.array_equal(hc > 0, ref["hits"])
+                    and np.array_equal(np.where(live, eng.hit_idx[:n_rays, :H_].cpu().numpy(), -1), ref["hit_idx"])
+                    and np.array_equal(eng.s_depth[:P_].cpu().numpy(), ref["z_vals"][rr, ss]) and np.array_equal(eng.s_vox[:P_].cpu().numpy(), ref["s_idx"][rr, ss]))
+        par = dict(geometry_bit_exact=geom, rays_at_the_20_hit_cap=float((hc == 20).mean()))
+        if geom:
+            g6, r6 = eng.pose_grad6[0].cpu().numpy().astype(np.float64), ref["grad_pose"][0].astype(np.float64)
+            dx = eng.dX[:P_].cpu().numpy()
+            par.update(sdf_max_abs_err=float(np.abs(eng.sdf[:P_].cpu().numpy() - ref["sdf"][rr, ss]).max()),
+                       dsdf_max_err_rel_to_max=float(np.abs(eng.dsdf[:P_].cpu().numpy() - ref["dsdf"][rr, ss]).max() / max(np.abs(ref["dsdf"]).max(), 1e-30)),
+                       dX_rel_l2=float(np.linalg.norm((dx - ref["dfeat"]).astype(np.float64)) / max(np.linalg.norm(ref["dfeat"].astype(np.float64)), 1e-30)),
+                       pose_grad_max_err_rel_to_max=float(np.abs(g6 - r6).max() / max(np.abs(r6).max(), 1e-30)))
+            par["ok"] = bool(par["sdf_max_abs_err"] < 1e-4 and par["dsdf_max_err_rel_to_max"] < 1e-3 and par["dX_rel_l2"] < 1e-3 and par["pose_grad_max_err_rel_to_max"] < 1e-3)
+        else:
+            par["ok"] = False
+        out["parity_vs_oracle"] = par
+        eng.begin_call(m, None, emb_state=False)
+        eng.set_poses(pose[None], [1])
+    if steps:
+        eng.bind(m, dec, cfg, skip_mode=2, **flags)
+        for _ in range(10):
+            eng.run_bound()
+        blocks = []
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(steps):
+                eng.run_bound()
+            torch.cuda.synchronize(); blocks.append((time.perf_counter() - t0) / steps * 1e3)
+        st = eng.stats()
+        steps_done, skipped, overflow = eng.call_status()
+        out.update(ms_per_step=float(min(blocks)), ms_per_step_blocks=blocks, steps_skipped=int(skipped), call_overflow=bool(overflow),
+                   valid_samples_last_step=int(st["P"]), pose_moved_m=float(np.abs(eng.pose6[0, :3].cpu().numpy() - pose[:3]).max()))
+    return out, eng
 
 
 def large_map_bench(w, device, n_scans=150, spacing=3.0, iters=20):
@@ -520,6 +597,15 @@ def large_map_bench(w, device, n_scans=150, spacing=3.0, iters=20):
     out["ba_4096x4_frozen_decoder"] = loop(4096, 4, False, True)[0]
     out["ba_4096x4_frozen_decoder_dense_bookkeeping"] = loop(4096, 4, False, False)[0]
     out["full_scan_131072"] = loop(0, 1, True, True, full=True)[0]
+    # the pose-refine step (M2) at the shipped tracker steps on this map (and on the same trajectory at kitti's 0.3 m voxels)
+    trk = {}
+    for name, ts in TRACKER_SETTINGS.items():
+        lm_t = lm if ts["voxel"] == 0.2 else build_large_map(w, device, n_scans, spacing, voxel=ts["voxel"])
+        trk[name] = tracker_step_on_map(w, lm_t, device, ts["step"], ts["lr"])[0]
+        if lm_t is not lm:
+            del lm_t
+            torch.cuda.empty_cache()
+    out["track_2048"] = trk
     # parity of one mapping iteration on this map against the oracle (2048 rays of the middle scan): geometry bit for bit, sdf / dsdf / dX
     from oracle import oracle as O
     eng = eng_small

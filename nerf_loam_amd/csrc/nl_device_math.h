@@ -208,7 +208,7 @@ struct NlTailCtx {
     int j_in_row;               // j   = this ray's index inside its row chunk
     const int* row_first_idx;   // hit list (stride 1) of the row's first ray in the chunk
     int row_first_count;        // number of valid entries in that list (entries beyond it read as -1)
-    int row_first_bias;         // the list stores idx + bias (1 for a list received from another rank, nl_dist_row_first)
+    int row_first_bias;         // the list stores idx + bias (1 for the table nl_dist_x1_merge derives from the gathered hit counts: 2 below the count, 0 beyond)
     bool tail_always;
 };
 
@@ -416,7 +416,7 @@ NL_HD void nl_sampler_layout(int r, int R, int* j_in_row, int* rays_in_row, int*
     *row_first_rank = first < R ? first : 0;     // padding rows replicate hit-ray 0
 }
 
-// index of a row-first hit-rank in the table of nl_dist_row_first: [batch row 200][chunk ceil(L / 800)]
+// index of a row-first hit-rank in the table of nl_dist_x1_merge: [batch row 200][chunk ceil(L / 800)]
 NL_HD int nl_row_first_entry(int first_rank, int R) {
     const int L = (R + NL_SAMPLER_G - 1) / NL_SAMPLER_G;
     const int nch = (L + NL_SAMPLER_CHUNK - 1) / NL_SAMPLER_CHUNK;

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_ray_intersect_dfs(DfsArgs a)
 // sequential fallback is left with rays whose stack is too small even one node at a time.
 template <int LPR> struct IqCaps { static constexpr int Q = 32, H = 28; };      // 8 / 4 lanes per ray (large ray counts): 1.2 KB of LDS per ray
 template <> struct IqCaps<16> { static constexpr int Q = 64, H = 40; };         // 16 lanes per ray (up to 16 384 rays): 2 KB per ray
-template <> struct IqCaps<32> { static constexpr int Q = 128, H = 40; };        // 32 lanes per ray (opt-in: NL_LANES_PER_RAY=32): 3 KB per ray
+template <> struct IqCaps<32> { static constexpr int Q = 128, H = 40; };        // 32 lanes per ray (the default up to 4096 rays, and on accumulated maps up to 16 384): 3 KB per ray
 
 __device__ __forceinline__ bool less_msb(unsigned a, unsigned b) { return a < b && a < (a ^ b); }
 // true if voxel 1 precedes voxel 2 in the reference's DFS order (= larger z-major Morton code)
@@ -847,7 +847,7 @@ struct SampleArgs {
     const float* cos_gt; const float* gt_dist;
     float step_size; float tau; float max_depth;
     unsigned seed; int use_hash_noise; int tail_always; int ray_id_base;
-    const int* row_first;       // multi-GPU: [entries][1 + NL_MAX_HITS] = (count, idx + 1 ...) of every batch row's first ray (nl_dist_row_first), or NULL
+    const int* row_first;       // multi-GPU: [entries][1 + NL_MAX_HITS] = (count, 2 for bins below the count, 0 beyond) of every batch row's first ray (nl_dist_x1_merge), or NULL
     const unsigned* seed_mix;   // optional device word (the optimiser's step counter) folded into the seed: fresh jitter per iteration
     int* counters; double* dcounters;
     int* samp_count;            // [N]  (0 for rays without hits)
@@ -1675,7 +1675,7 @@ int nl_scan_hit_rays(const int* hit_count, int* hit_rank, int* ray_of_rank, int 
  * 8192 rays, sequential beyond (default); same results */
 int nl_geometry_set_sampler_mode(int mode) { if (mode < 0 || mode > 2) return NL_ERR_INVALID_ARG; g_sampler_mode = mode; return NL_OK; }
 
-/* lanes per ray of the work-list intersect kernel: 0 = by ray count (default: 16 up to 16 384 rays, else 8), or 2 / 4 / 8 / 16 */
+/* lanes per ray of the work-list intersect kernel: 0 = the caller's choice, else by ray count (32 up to 4096 rays, 16 up to 16 384, else 8), or 4 / 8 / 16 / 32 for every call */
 int nl_geometry_set_intersect_prune(int on) { g_isect_prune = on ? 1 : 0; return NL_OK; }
 int nl_geometry_set_lanes_per_ray(int lpr) { if (lpr != 0 && lpr != 4 && lpr != 8 && lpr != 16 && lpr != 32) return NL_ERR_INVALID_ARG; g_isect_lpr = lpr; return NL_OK; }
 

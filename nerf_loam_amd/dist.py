@@ -66,7 +66,7 @@ def interleaved_order(n, world):
 
 
 def row_first_entries(n_rays_total):
-    """table size of nl_dist_row_first: 200 batch rows x ceil(L / 800) chunks, L = rays per batch row"""
+    """table size of nl_dist_x1_merge's row-first table: 200 batch rows x ceil(L / 800) chunks, L = rays per batch row"""
     return 200 * (((n_rays_total + 199) // 200 + 799) // 800)
 
 

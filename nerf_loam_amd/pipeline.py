@@ -302,7 +302,7 @@ class SdfEngine:
         # (adam_state: device step counter + hyper-parameters, a slice of _call_state above)
         self.graph = None
         # multi-GPU hooks (dist.py installs them); identity on one GPU
-        self.row_first = None    # multi-GPU: table of the batch rows' first-ray hit lists (dist.py, nl_dist_row_first)
+        self.row_first = None    # multi-GPU: table of the batch rows' first-ray hit lists (dist.py, nl_dist_x1_merge)
         self._exchange = None    # multi-GPU: dist.RayShardedExchange (its communicator rides in the descriptor: nl_iteration exchanges itself)
         self.hook_after_intersect = None
         self.hook_after_count = None

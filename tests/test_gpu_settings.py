@@ -5,7 +5,11 @@
     directions, hit lists, sample layout and depths bit for bit on ALL 131 072 rays (the C restatement of the reference's two CUDA kernels at
     full size), sdf / dL/dsdf / dL/dX on every 16th ray's samples (bench.parity_check: the same in-run check the bench line carries);
   * the 150-scan map of bench.py's large_map leg (1.4 M octree nodes, 1.1 M embedding rows, rays crossing up to ~60 voxels: the in-place
-    first-20 pruning of the work-list intersect) at 2048 and at 16 384 rays: geometry bit for bit, sdf / dsdf / dX."""
+    first-20 pruning of the work-list intersect) at 2048 and at 16 384 rays: geometry bit for bit, sdf / dsdf / dX;
+  * the TRACKER's steps of the three shipped configs (src/tracking.py:36: 0.2 x 0.2 = 0.04 m maicity, 0.2 x 0.3 = 0.06 m kitti,
+    0.1 x 0.2 = 0.02 m ncd) on that accumulated map: the track_frame-shaped iteration (frozen decoder and embeddings, pose gradient)
+    against the oracle, the sample workspace sized by pipeline.samples_per_ray_bound; a step the old fixed capacity (96 samples per
+    ray) cannot hold; track_frame itself at the ncd step."""
 import numpy as np
 import pytest
 import torch
@@ -88,3 +92,74 @@ def test_iteration_on_the_150_scan_map_matches_the_oracle(large_map, n_rays):
     import helpers as H
     H.record_gpu_metric(f"large_map_{n_rays}", sdf=sdf_err, dsdf=ds_err, dX=dx_err, P=P_, over20=float((hc == 20).mean()))
     assert sdf_err < 5e-6 and ds_err < 1e-4 and dx_err < 5e-4, (sdf_err, ds_err, dx_err)      # (measured: 4e-8, 6e-6, 4e-7 / 5e-5)
+
+
+@pytest.fixture(scope="module")
+def large_map_kitti(large_map):
+    bench, w, _, dev = large_map
+    return bench.build_large_map(w, dev, 150, 3.0, voxel=0.3)
+
+
+@pytest.mark.parametrize("name", ["maicity", "kitti", "ncd"])
+def test_tracker_step_on_the_150_scan_map_matches_the_oracle(large_map, large_map_kitti, name):
+    """the pose-refine step at the reference's real operating point - the shipped tracker steps on an accumulated map
+    (oracle, 2048 rays: 44 samples per hit ray at 0.04 m, 78 at 0.02 m, up to 220 on one ray)."""
+    bench, w, lm, dev = large_map
+    ts = bench.TRACKER_SETTINGS[name]
+    r, eng = bench.tracker_step_on_map(w, lm if ts["voxel"] == 0.2 else large_map_kitti, dev, ts["step"], ts["lr"], steps=20)
+    par = r["parity_vs_oracle"]
+    import helpers as H
+    H.record_gpu_metric("tracker_step_large_map_" + name, P=r["valid_samples"], per_ray=r["samples_per_hit_ray"], S=r["max_samples_per_ray"], cap=r["samples_per_ray_capacity"],
+                        ms=r["ms_per_step"], **{k: v for k, v in par.items() if isinstance(v, float)})
+    assert not r["overflow"] and not r["call_overflow"] and r["steps_skipped"] == 0
+    assert r["max_samples_per_ray"] <= r["samples_per_ray_capacity"]          # the derived bound holds ray by ray
+    assert par["geometry_bit_exact"], par
+    assert par["sdf_max_abs_err"] < 5e-6 and par["dsdf_max_err_rel_to_max"] < 1e-4 and par["dX_rel_l2"] < 5e-4, par
+    assert par["pose_grad_max_err_rel_to_max"] < 2e-4, par
+    assert r["max_hits"] == 20 and 0.0 < r["pose_moved_m"] < 0.2
+    if name == "ncd":
+        assert r["samples_per_hit_ray"] > 60 and r["max_samples_per_ray"] > 96, r      # beyond what the fixed capacity of rounds 1-4 (96 per ray) assumed
+
+
+def test_a_step_the_old_fixed_capacity_cannot_hold(large_map):
+    """samples_per_ray_cap was a constant (96) whose overflow raised at the end of the call.  At step 0.01 m on the accumulated map a ray averages more than
+    96 samples: an engine with the old capacity flags the overflow (and skips the step), the derived capacity holds it and matches the oracle."""
+    bench, w, lm, dev = large_map
+    from nerf_loam_amd import pipeline as P
+    old, eng_old = bench.tracker_step_on_map(w, lm, dev, 0.01, steps=2, with_parity=False, samples_per_ray_cap=96)
+    assert old["call_overflow"] and old["steps_skipped"] == 2
+    r, _ = bench.tracker_step_on_map(w, lm, dev, 0.01, steps=2)
+    assert r["samples_per_hit_ray"] > 96 and r["samples_per_ray_capacity"] == P.samples_per_ray_bound(0.2, 0.01) == 714
+    assert not r["call_overflow"] and r["steps_skipped"] == 0 and r["parity_vs_oracle"]["ok"] and r["parity_vs_oracle"]["geometry_bit_exact"], r
+
+
+def test_track_frame_at_the_ncd_step_on_the_150_scan_map(large_map):
+    """the API call itself (render_helpers.track_frame: engine from the cache, capacity derived from voxel / step): the ncd tracker's settings on the accumulated
+    map run to the end, without the overflow error the fixed capacity was one dense scene away from, and pull a perturbed pose back"""
+    bench, w, lm, dev = large_map
+    from nerf_loam_amd import render_helpers as RH
+    from nerf_loam_amd.criterion import Criterion
+    from nerf_loam_amd.decoder import Decoder
+    from nerf_loam_amd.lidar_frame import LidarFrame
+    from nerf_loam_amd.se3pose import OptimizablePose
+    from argparse import Namespace
+    m = lm["map"]
+    map_states = {"voxel_vertex_idx": torch.from_numpy(lm["vertex_idx"]), "voxel_center_xyz": torch.from_numpy(lm["centres"]),
+                  "voxel_structure": torch.from_numpy(lm["structure"]), "voxel_vertex_emb": m.emb.view(torch.bfloat16),
+                  "voxel_id2embedding_id": torch.from_numpy(lm["id2row"]).view(-1, 1)}
+    args = Namespace(criteria=dict(sdf_weight=10000.0, fs_weight=1.0, sdf_truncation=0.30, eiko_weight=0.0), data_specs=dict(max_depth=50.0))
+    dec = Decoder(depth=2, width=256, in_dim=16).to(dev)
+    with torch.no_grad():
+        for q, a in zip(RH._param_list(dec), w["host"]["dec"]):
+            q.copy_(torch.from_numpy(np.asarray(a, np.float32)).view_as(q))
+    fr = LidarFrame(5, torch.from_numpy(w["points"]), torch.from_numpy(w["cos"]))
+    pose0 = lm["poses"][len(lm["poses"]) // 2].copy(); pose0[:3] += np.array([0.03, -0.02, 0.01], np.float32)
+    fr.pose = OptimizablePose(torch.from_numpy(pose0.copy()))
+    RH._ENGINES.clear()
+    new_pose, hit_mask = RH.track_frame(fr.pose, fr, map_states, dec, Criterion(args), 0.2, 2048, 0.02, 10, 0.30, 0.005, 20, 50.0)
+    torch.cuda.synchronize()
+    (eng,) = RH._ENGINES.values()
+    assert eng.samples_per_ray_cap == 368 and not eng.samples_clipped
+    assert hit_mask is not None and int(hit_mask.sum()) > 1900
+    got = new_pose.data.detach().cpu().numpy()
+    assert np.isfinite(got).all() and 0 < np.abs(got[:3] - pose0[:3]).max() < 0.05
