@@ -51,6 +51,8 @@ def matrix_pipe_model(kernel, gemm_mode, wgrad2_mode, train):
         small = L1 * (3 if train else 2)                        # layer-1 forward, dX, (dW1)
         if gemm_mode in (1, 2, 3):                              # forward: 3x3 split (9, 8 or 6 of the nine products), dgrad: {0,1} mask x
             return alg, small - L1, {1: 9, 3: 8, 2: 6}[gemm_mode] * G + 3 * G + 9 * L1   # 3-term split; layer-1 forward: 3x3 split too
+        if gemm_mode in (4, 5):                                 # fp16 pairs: forward 3 or 4 of the four products, dgrad mask x 2 terms, layer 1 all four
+            return alg, small - L1, {4: 3, 5: 4}[gemm_mode] * G + 2 * G + 4 * L1
         return alg, small + 2 * G, 0
     if wgrad2_mode == 1:
         return FLOPS_PER_SAMPLE_WGRAD2, 0, 3 * G + 9 * L1       # H1 rebuilt as 3x3 bf16 products; mask x 3-term split

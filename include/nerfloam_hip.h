@@ -29,7 +29,7 @@ extern "C" {
 #define NL_CNT_DOUBLES 4        /* ... followed by double sums: counter block = 16*4 + 4*8 bytes */
 #define NL_LOSS_SCALARS_BYTES 48
 #define NL_DEC_PARAMS 70401     /* W1[256x16] b1[256] W2[256x256] b2[256] W3[256] b3[1] */
-#define NL_DEC_WS_FLOATS 262144    /* decoder weight workspace: W2^T fp32 + 2 x 3 bf16 operand planes */
+#define NL_DEC_WS_FLOATS 393216    /* decoder weight workspace: W2^T fp32 + 2 x 3 bf16 operand planes + 2 x 2 fp16 operand planes */
 #define NL_EMB_CHANNELS 16
 
 /* Multi-GPU ray sharding: fold the all-gathered counter blocks gathered[world][NL_CNT_INTS + 2*NL_CNT_DOUBLES] (ints) into
@@ -230,7 +230,9 @@ int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, voi
  *   floats [0, 65536):        W2 transposed (fp32; forward GEMM B operand of gemm mode 0),
  *   floats [65536, 163840):   "W2X"  = w3_j * W2[j][k] as three bf16 planes (hi + mid + lo == the fp32 value exactly) in
  *                             MFMA-fragment order: dgrad GEMM B operand on the bf16 matrix cores,
- *   floats [163840, 262144):  "W2TX" = W2[n][k], same split and order: forward GEMM B operand on the bf16 matrix cores. */
+ *   floats [163840, 262144):  "W2TX" = W2[n][k], same split and order: forward GEMM B operand on the bf16 matrix cores,
+ *   floats [262144, 327680):  "W2H"  = (w3_j * W2[j][k]) * 2^12 as two fp16 planes (hi = f16(x), lo = f16(x - hi), round to nearest), same order,
+ *   floats [327680, 393216):  "W2TH" = W2[n][k] * 2^8, likewise: the operands of gemm modes 4 / 5. */
 int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream);
 /* The two 256-deep GEMMs of nl_decoder_fwd_bwd / nl_decoder_forward: 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32);
  * 1, 2, 3 = bf16 matrix cores (v_mfma_f32_32x32x16_bf16) on exact-product formulations:

@@ -15,7 +15,7 @@ NL_CNT_BYTES = NL_CNT_INTS * 4 + NL_CNT_DOUBLES * 8
 NL_LOSS_SCALARS_BYTES = 48
 NL_ADAM_STATE_BYTES = 112
 NL_DEC_PARAMS = 70401
-NL_DEC_WS_FLOATS = 262144        # decoder weight workspace: W2^T fp32 + 2 x 3 bf16 operand planes (include/nerfloam_hip.h)
+NL_DEC_WS_FLOATS = 393216        # decoder weight workspace: W2^T fp32 + 2 x 3 bf16 + 2 x 2 fp16 operand planes (include/nerfloam_hip.h)
 NL_SEL_BATCH_WS_INTS_PER_FRAME = 8 + 4 * 128 + 2 * 4096     # NL_SELECT_BATCH_WS_INTS(1)
 NL_SEL_MAX_FRAMES = 8
 NL_MAX_FRAMES = 32               # frames (poses) one field-kernel launch takes (csrc/nl_field.hip)
@@ -210,7 +210,7 @@ def lib():
             fn.restype = res
         if os.environ.get("NL_GEMM_MODE"):
             if L.nl_decoder_set_gemm_mode(int(os.environ["NL_GEMM_MODE"])) != 0:
-                raise NerfLoamHipError("NL_GEMM_MODE must be 0 .. 3")
+                raise NerfLoamHipError("NL_GEMM_MODE must be 0 .. 5")
         if os.environ.get("NL_SAMPLER_MODE"):
             L.nl_geometry_set_sampler_mode(int(os.environ["NL_SAMPLER_MODE"]))
         if os.environ.get("NL_LANES_PER_RAY"):              # A/B switch for measurements: lanes per ray of the work-list intersect
@@ -251,8 +251,8 @@ def kernel_modes(gemm_mode=None, wgrad2_mode=None):
     default (NL_GEMM_MODE / NL_WGRAD2_MODE, nl_decoder_set_*_mode)"""
     g = -1 if gemm_mode is None else int(gemm_mode)
     w = -1 if wgrad2_mode is None else int(wgrad2_mode)
-    if not (-1 <= g <= 3 and -1 <= w <= 1):
-        raise ValueError(f"gemm_mode {gemm_mode} / wgrad2_mode {wgrad2_mode}: 0..3 / 0..1 or None")
+    if not (-1 <= g <= 5 and -1 <= w <= 1):
+        raise ValueError(f"gemm_mode {gemm_mode} / wgrad2_mode {wgrad2_mode}: 0..5 / 0..1 or None")
     return ((g + 1) & 0xFF) | (((w + 1) & 0xFF) << 8)
 
 

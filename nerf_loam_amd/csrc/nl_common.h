@@ -51,6 +51,9 @@ enum {
 #define NL_OFF_W3 (NL_OFF_B2 + NL_W)
 #define NL_OFF_B3 (NL_OFF_W3 + NL_W)
 #define NL_DEC_PARAMS 70401
+// decoder weight workspace (floats; include/nerfloam_hip.h nl_decoder_transpose_w2): W2^T fp32 | W2X, W2TX (3 bf16 planes each) | W2H, W2TH (2 fp16 planes each)
+static_assert(NL_W * NL_W + 2 * 3 * NL_W * NL_W / 2 + 2 * 2 * NL_W * NL_W / 2 == 393216, "NL_DEC_WS_FLOATS of include/nerfloam_hip.h");
+#define NL_DEC_WS_W2H_OFF16 (2 * 3 * NL_W * NL_W)          // 16-bit elements from the start of W2X to the start of W2H
 static_assert(NL_DEC_PARAMS == NL_OFF_B3 + 1, "decoder parameter block");
 
 #define NL_LAUNCH_CHECK()                                   \

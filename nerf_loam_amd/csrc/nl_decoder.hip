@@ -38,6 +38,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 // LDS carve (floats)
 #define S_H1 0
@@ -136,6 +139,31 @@ __device__ __forceinline__ void l1_w1_fragments(const float* __restrict__ params
     for (int pl = 0; pl < 3; ++pl) out[pl] = make_uint4(q[pl][0], q[pl][1], q[pl][2], q[pl][3]);
 }
 
+// ---- "f16 pair" arithmetic (gemm modes 4 / 5; nl_device_math.h nl_split2_f16): an fp32 operand, scaled by a power of two and saturated at
+// the fp16 range by the caller, as hi = f16(x), lo = f16(x - hi), both round-to-nearest-even (v_cvt_pk_f16_f32); two values per call,
+// packed like the MFMA fragments want them.  6 VALU instructions per pair against ~13 for the three-term bf16 split.
+__device__ __forceinline__ void split2_pair_f16(float a, float b, unsigned* hi, unsigned* lo)
+{
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    const f32x2v v = {a, b};
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2v r = {a - (float)h[0], b - (float)h[1]};
+    *hi = __builtin_bit_cast(unsigned, h); *lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+__device__ __forceinline__ float sat_f16(float x) { return __builtin_amdgcn_fmed3f(x, -NL_F16_MAX, NL_F16_MAX); }
+// layer 1 as f16 pairs: this lane's B fragments, W1[col][8 lh + e] * 2^8 (e = 0..7)
+__device__ __forceinline__ void l1_w1_fragments_f16(const float* __restrict__ params, int col, int lh, uint4 (&out)[2])
+{
+    const float4* wr = reinterpret_cast<const float4*>(params + NL_OFF_W1 + col * NL_C + 8 * lh);
+    const float4 wa = wr[0], wb = wr[1];
+    const float v[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+    unsigned q[2][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split2_pair_f16(sat_f16(v[2 * e] * NL_F16_SW1), sat_f16(v[2 * e + 1] * NL_F16_SW1), &q[0][e], &q[1][e]);
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) out[pl] = make_uint4(q[pl][0], q[pl][1], q[pl][2], q[pl][3]);
+}
+
 // LICM hoists every "base + constant" LDS address out of the persistent tile loop into its own VGPR (dozens of them);
 // laundering the base through an empty asm inside the loop keeps ONE base register and lets the constants fold into the
 // ds_read/ds_write offset fields.
@@ -161,9 +189,18 @@ __device__ __forceinline__ uint4 bload4(i32x4 rsrc, int voff_bytes, int soff_byt
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_bytes, soff_bytes, 0));
 }
 
+// one 32x32x16 matrix-core instruction on packed 16-bit fragments: bf16 (exact three-term splits) or fp16 (two-term pairs)
+template <bool F16>
+__device__ __forceinline__ f32x16 mma16(const uint4& a, const uint4& b, const f32x16& c)
+{
+    if constexpr (F16) return MFMA_F16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c);
+    else return MFMA_BF16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c);
+}
+
 #define MX_RING 6                                       // B fragments run MX_RING-1 k-steps (6 MFMAs = 192 pipe cycles each) ahead
 #define MX_PRE 2                                        // of which this many are issued before the barrier (register budget)
 // first MX_PRE stages of the B stream: independent of the tile, so issued BEFORE the barrier that publishes the mask
+template <int NPL>                                      // NPL: operand planes of the B matrix (3 bf16 terms, or 2 with the fp16 pairs)
 __device__ __forceinline__ void gemm_mask_x_prefetch(i32x4 rsX, int w, int lane, uint4 (&bq)[MX_RING][3])
 {
     const int voff = lane * 16;
@@ -171,10 +208,10 @@ __device__ __forceinline__ void gemm_mask_x_prefetch(i32x4 rsX, int w, int lane,
 #pragma unroll
     for (int s = 0; s < MX_PRE; ++s)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bq[s][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + kt_off + s * 1024);
+        for (int p = 0; p < NPL; ++p) bq[s][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + kt_off + s * 1024);
 }
 
-template <bool PIN>                                     // PIN: hold the software pipeline in place with scheduling barriers.  Without them
+template <bool PIN, bool F16 = false>                                   // PIN: hold the software pipeline in place with scheduling barriers.  Without them
                                                         // the scheduler sinks every prefetch to just before its use (vmcnt(0) after each
                                                         // load); with them the trainable-decoder kernel, which is at the 256-VGPR limit,
                                                         // spills ~40 registers - so it is enabled where registers allow (frozen / forward)
@@ -185,29 +222,28 @@ __device__ __forceinline__ void gemm_mask_x(i32x4 rsX, int w, int lane, const un
     const int kt_off = __builtin_amdgcn_readfirstlane(w) * 16 * 1024;     // this wave's column tile; provably wave-uniform, or every
                                                                           // load below becomes a waterfall loop over soffset
     const unsigned char* a0 = sM + opaque(l31 * (SM_STRIDE * 2) + 16 * lh);
-    constexpr int RING = MX_RING;
+    constexpr int RING = MX_RING, NPL = F16 ? 2 : 3;
     uint4 aq[2][2];
 #pragma unroll
     for (int s = MX_PRE; s < RING - 1; ++s)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bq[s][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + kt_off + s * 1024);
+        for (int p = 0; p < NPL; ++p) bq[s][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + kt_off + s * 1024);
     aq[0][0] = *reinterpret_cast<const uint4*>(a0); aq[0][1] = *reinterpret_cast<const uint4*>(a0 + 32 * SM_STRIDE * 2);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         if (s + RING - 1 < 16) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bq[(s + RING - 1) % RING][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + kt_off + (s + RING - 1) * 1024);
+            for (int p = 0; p < NPL; ++p) bq[(s + RING - 1) % RING][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + kt_off + (s + RING - 1) * 1024);
         }
         if (s + 1 < 16) {
             aq[(s + 1) & 1][0] = *reinterpret_cast<const uint4*>(a0 + 32 * (s + 1));
             aq[(s + 1) & 1][1] = *reinterpret_cast<const uint4*>(a0 + 32 * SM_STRIDE * 2 + 32 * (s + 1));
         }
         if (PIN) __builtin_amdgcn_sched_barrier(0);
-        const bf16x8 fa0 = __builtin_bit_cast(bf16x8, aq[s & 1][0]), fa1 = __builtin_bit_cast(bf16x8, aq[s & 1][1]);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const bf16x8 fb = __builtin_bit_cast(bf16x8, bq[s % RING][p]);
-            c0 = MFMA_BF16(fa0, fb, c0); c1 = MFMA_BF16(fa1, fb, c1);
+        for (int i = 0; i < NPL; ++i) {
+            const int p = F16 ? NPL - 1 - i : i;           // (fp16 pairs: the low term first)
+            c0 = mma16<F16>(aq[s & 1][0], bq[s % RING][p], c0); c1 = mma16<F16>(aq[s & 1][1], bq[s % RING][p], c1);
         }
     }
 }
@@ -215,6 +251,7 @@ __device__ __forceinline__ void gemm_mask_x(i32x4 rsX, int w, int lane, const un
 // Rolled variant for the trainable-decoder kernel (no scheduling barriers, so no spills at its 256-VGPR limit): the k-steps go
 // through a rolled loop in pairs with two register buffers, like gemm256 - a load issued in one half of the body cannot be
 // sunk below the MFMAs of that half because its consumers sit in the other half.  bq[0], bq[1] arrive preloaded.
+template <bool F16 = false>
 __device__ __forceinline__ void gemm_mask_x_rolled(i32x4 rsX, int w, int lane, const unsigned char* sM, uint4 (&bq)[MX_RING][3], f32x16& c0, f32x16& c1)
 {
     static_assert(MX_PRE == 2, "the rolled loop consumes the two pre-barrier stages as its first buffer");
@@ -222,20 +259,21 @@ __device__ __forceinline__ void gemm_mask_x_rolled(i32x4 rsX, int w, int lane, c
     const int voff = lane * 16;
     const int kt_off = __builtin_amdgcn_readfirstlane(w) * 16 * 1024;
     const unsigned char* a0 = sM + opaque(l31 * (SM_STRIDE * 2) + 16 * lh);
+    constexpr int NPL = F16 ? 2 : 3;
     uint4 bA[2][3], bB[2][3];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bA[t][p] = bq[t][p];
+        for (int p = 0; p < NPL; ++p) bA[t][p] = bq[t][p];
     auto steps2 = [&](const uint4 (&b)[2][3], const unsigned char* ap) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const bf16x8 fa0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + 32 * t));
-            const bf16x8 fa1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + 32 * SM_STRIDE * 2 + 32 * t));
+            const uint4 fa0 = *reinterpret_cast<const uint4*>(ap + 32 * t);
+            const uint4 fa1 = *reinterpret_cast<const uint4*>(ap + 32 * SM_STRIDE * 2 + 32 * t);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const bf16x8 fb = __builtin_bit_cast(bf16x8, b[t][p]);
-                c0 = MFMA_BF16(fa0, fb, c0); c1 = MFMA_BF16(fa1, fb, c1);
+            for (int i = 0; i < NPL; ++i) {
+                const int p = F16 ? NPL - 1 - i : i;       // (fp16 pairs: the low term first)
+                c0 = mma16<F16>(fa0, b[t][p], c0); c1 = mma16<F16>(fa1, b[t][p], c1);
             }
         }
     };
@@ -245,13 +283,13 @@ __device__ __forceinline__ void gemm_mask_x_rolled(i32x4 rsX, int w, int lane, c
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bB[t][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + so + (2 + t) * 1024);
+            for (int p = 0; p < NPL; ++p) bB[t][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + so + (2 + t) * 1024);
         steps2(bA, a0 + 32 * s);
         if (s + 4 < 16) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bA[t][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + so + (4 + t) * 1024);
+                for (int p = 0; p < NPL; ++p) bA[t][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + so + (4 + t) * 1024);
         }
         steps2(bB, a0 + 32 * (s + 2));
     }
@@ -266,6 +304,8 @@ __device__ __forceinline__ void gemm_mask_x_rolled(i32x4 rsX, int w, int lane, c
 #define X_PLANE_ELEMS (DEC_M * SM_STRIDE)
 #define X_PLANE_BYTES (X_PLANE_ELEMS * 2)
 #define NL_DEC_WS_W2TX_OFF (NL_DEC_WS_W2X_OFF + 3 * NL_W * NL_W / 2)       // floats
+#define NL_DEC_WS_W2H_OFF (NL_DEC_WS_W2TX_OFF + 3 * NL_W * NL_W / 2)      // fp16 pairs: dgrad planes (w3_j W2[j][k] * 2^12), two planes
+#define NL_DEC_WS_W2TH_OFF (NL_DEC_WS_W2H_OFF + 2 * NL_W * NL_W / 2)      // forward planes (W2 * 2^8)
 
 // bf16 mode, layer 1 on the bf16 matrix cores as well (exact 3 x 3 term products, nine K = 16 MFMAs per 32-row sub-tile instead of
 // eight fp32 ones): W1 as B fragments [wave][plane][lane][16 B] and the X tile as three planes [64 rows][32 B], in LDS the bf16 mode
@@ -333,6 +373,62 @@ __device__ __forceinline__ void gemm_x9(i32x4 rsX, int w, int lane, const unsign
     }
 }
 
+// ---- forward GEMM as fp16 pairs (gemm modes 4 / 5) ------------------------------------------------------------------------------
+// H1 * 2^4 and W2 * 2^8 as hi + lo (nl_split2_f16); per k-step and 32-row sub-tile the products lo x hi, hi x lo, hi x hi (NP = 3: what is
+// dropped, lo x lo, is below 2^-22 of a product - under the rounding of the 256-deep fp32 accumulation) or all four (NP = 4): 6 or 8 matrix
+// instructions per k-step against 16 of the eight-product bf16 split.  A planes: LDS, f16 [2][64 rows][264]; B planes "W2TH": fragment-major
+// like W2TX.  The accumulators come out scaled by 2^12 (the caller's epilogue folds 2^-12 into its bias add: exact).
+#define F16_RING 4                                      // B fragments 3 k-steps (6-8 MFMAs = 192-256 pipe cycles each) ahead
+__device__ __forceinline__ void gemm_f16_prefetch(i32x4 rsH, int w, int lane, uint4 (&bq)[F16_RING][2])
+{
+    const int voff = lane * 16;
+    const int nt_off = __builtin_amdgcn_readfirstlane(w) * 16 * 1024;
+#pragma unroll
+    for (int s = 0; s < F16_RING - 1; ++s)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) bq[s][p] = bload4(rsH, voff, p * W2X_PLANE_BYTES + nt_off + s * 1024);
+}
+
+template <bool PIN, int NP>
+__device__ __forceinline__ void gemm_f16(i32x4 rsH, int w, int lane, const unsigned char* sP, uint4 (&bq)[F16_RING][2], f32x16& c0, f32x16& c1)
+{
+    static_assert(NP == 3 || NP == 4, "three or four partial products");
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int voff = lane * 16;
+    const int nt_off = __builtin_amdgcn_readfirstlane(w) * 16 * 1024;     // wave-uniform scalar offset (no waterfall loops)
+    const unsigned char* a0 = sP + opaque(l31 * (SM_STRIDE * 2) + 16 * lh);
+    constexpr int RING = F16_RING;
+    // the A fragments of the NEXT k-step (hi / lo plane x two row tiles: four ds_read_b128) and the B fragments three k-steps ahead are
+    // issued between this k-step's matrix instructions, one memory instruction per instruction pair
+    uint4 aq[2][4];                                      // [k-step parity][hi rows 0-31, hi rows 32-63, lo rows 0-31, lo rows 32-63]
+    aq[0][0] = *reinterpret_cast<const uint4*>(a0); aq[0][1] = *reinterpret_cast<const uint4*>(a0 + 32 * SM_STRIDE * 2);
+    aq[0][2] = *reinterpret_cast<const uint4*>(a0 + X_PLANE_BYTES); aq[0][3] = *reinterpret_cast<const uint4*>(a0 + X_PLANE_BYTES + 32 * SM_STRIDE * 2);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        const uint4 bh = bq[s % RING][0], bl = bq[s % RING][1];
+        if (NP == 4) { c0 = mma16<true>(aq[cur][2], bl, c0); c1 = mma16<true>(aq[cur][3], bl, c1); }
+        c0 = mma16<true>(aq[cur][2], bh, c0); c1 = mma16<true>(aq[cur][3], bh, c1);
+        if (s + 1 < 16) {
+            aq[nxt][0] = *reinterpret_cast<const uint4*>(a0 + 32 * (s + 1));
+            aq[nxt][1] = *reinterpret_cast<const uint4*>(a0 + 32 * SM_STRIDE * 2 + 32 * (s + 1));
+        }
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
+        c0 = mma16<true>(aq[cur][0], bl, c0); c1 = mma16<true>(aq[cur][1], bl, c1);
+        if (s + 1 < 16) {
+            aq[nxt][2] = *reinterpret_cast<const uint4*>(a0 + X_PLANE_BYTES + 32 * (s + 1));
+            aq[nxt][3] = *reinterpret_cast<const uint4*>(a0 + X_PLANE_BYTES + 32 * SM_STRIDE * 2 + 32 * (s + 1));
+        }
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
+        c0 = mma16<true>(aq[cur][0], bh, c0); c1 = mma16<true>(aq[cur][1], bh, c1);
+        if (s + RING - 1 < 16) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bq[(s + RING - 1) % RING][p] = bload4(rsH, voff, p * W2X_PLANE_BYTES + nt_off + (s + RING - 1) * 1024);
+        }
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // value of the neighbouring lane (lane ^ 1) - the neighbouring output column of the 32x32 MFMA tile
 __device__ __forceinline__ float dpp_swap1(float v)
 {
@@ -365,6 +461,32 @@ __device__ __forceinline__ unsigned store_h1_planes(unsigned short* sP, int col,
             split3_pair(lo_k, hi_k, &q0, &q1, &q2);
             unsigned* d = pb + ((32 * sub + D32_RR(r)) * SM_STRIDE) / 2;
             d[0] = q0; d[X_PLANE_ELEMS / 2] = q1; pb2[((32 * sub + D32_RR(r)) * SM_STRIDE) / 2] = q2;
+        }
+    }
+    return m1;
+}
+
+// the same for the fp16 pairs: H1 * 2^4 = relu(acc * 2^-10 + 16 b1) (acc = the layer-1 accumulator, scaled 2^14; power-of-two scaling commutes
+// with the rounding of the add), saturated at the fp16 range by the same v_med3 that is the ReLU, as two planes hi / lo
+__device__ __forceinline__ unsigned store_h1_planes_f16(unsigned short* sP, int col, int lh, const f32x16& c0, const f32x16& c1, float b1s)
+{
+    const bool odd = (col & 1) != 0;
+    unsigned* pb = reinterpret_cast<unsigned*>(sP + opaque((4 * lh + (odd ? 1 : 0)) * SM_STRIDE + (col & ~1)));   // odd lanes: the odd rows
+    constexpr float S1 = NL_F16_SH / (NL_F16_SX * NL_F16_SW1);
+    unsigned m1 = 0u;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float ha = __builtin_amdgcn_fmed3f(fmaf(sub ? c1[r] : c0[r], S1, b1s), 0.f, NL_F16_MAX);
+            const float hb = __builtin_amdgcn_fmed3f(fmaf(sub ? c1[r + 1] : c0[r + 1], S1, b1s), 0.f, NL_F16_MAX);
+            m1 |= ((ha > 0.f) ? (1u << (16 * sub + r)) : 0u) | ((hb > 0.f) ? (1u << (16 * sub + r + 1)) : 0u);
+            const float got = dpp_swap1(odd ? ha : hb);            // even lane: the odd lane's row r; odd lane: the even lane's row r + 1
+            const float lo_k = odd ? got : ha, hi_k = odd ? hb : got;      // columns (k, k + 1) of this lane's row
+            unsigned q0, q1;
+            split2_pair_f16(lo_k, hi_k, &q0, &q1);
+            unsigned* d = pb + ((32 * sub + D32_RR(r)) * SM_STRIDE) / 2;
+            d[0] = q0; d[X_PLANE_ELEMS / 2] = q1;
         }
     }
     return m1;
@@ -403,7 +525,7 @@ __device__ __forceinline__ float halfwave_rowsum(const f32x16& h0, const f32x16&
     return (up ? v2[1] : v2[0]) + __shfl_xor(up ? v2[0] : v2[1], 1);
 }
 
-template <bool TRAIN, bool XG, int NP = 9>               // NP: partial products of the forward GEMM (gemm_x9); XG: both 256-deep GEMMs on the bf16 matrix cores (exact-product formulations)
+template <bool TRAIN, bool XG, int NP = 9>               // NP: partial products of the forward GEMM - 9 / 8 / 6: three-term bf16 splits (gemm_x9), 3 / 4: fp16 pairs (gemm_f16); XG: the 256-deep GEMMs on the 16-bit matrix cores
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[S_ALLOC];
@@ -413,6 +535,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
     float* sH1 = lds + S_H1; float* sD = XG ? lds + X_PLANE_BYTES / 4 : lds + S_D; float* sW1 = lds + S_W1;
     float* sS = lds + S_S;
 
+    constexpr bool F16 = XG && NP <= 4;                   // fp16 pairs: every 16-bit operand plane below is one of two (hi, lo) instead of one of three
+    // F16: the dgrad accumulators are 2^12 x dH1 / dsdf (the scale of the W2H planes); dH1 goes through phases H / I with that factor and
+    // it is taken out where the results leave (dX store, the dW1 / db1 slab) - powers of two: exact
+    constexpr float DHS = F16 ? 1.0f / NL_F16_SG : 1.0f;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5, l15 = lane & 15, lq = lane >> 4;
     const int col = 32 * w + l31;                 // this lane's output column in 32x32 tiles
@@ -424,6 +550,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
     const i32x4 rsW2 = make_w_rsrc(a.params + NL_OFF_W2), rsW2T = make_w_rsrc(a.W2T);
     const i32x4 rsW2X = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W2T + NL_DEC_WS_W2X_OFF), 0, 3 * W2X_PLANE_BYTES, 0x00020000);
     const i32x4 rsW2TX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W2T + NL_DEC_WS_W2TX_OFF), 0, 3 * W2X_PLANE_BYTES, 0x00020000);
+    const i32x4 rsW2H = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W2T + NL_DEC_WS_W2H_OFF), 0, 2 * W2X_PLANE_BYTES, 0x00020000);
+    const i32x4 rsW2TH = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W2T + NL_DEC_WS_W2TH_OFF), 0, 2 * W2X_PLANE_BYTES, 0x00020000);
     const float b1c = a.params[NL_OFF_B1 + col], b2c = a.params[NL_OFF_B2 + col], w3c = a.params[NL_OFF_W3 + col];
     const float b3 = a.params[NL_OFF_B3];
 
@@ -459,7 +587,13 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
     // X tile of the next phase B: fp32 (dW1 of the trainable decoder reads it in phase I) and, in the bf16 mode, three bf16 planes
     auto stage_x = [&](float* sXf) {
         if (!XG || TRAIN) { sXf[xi * LDX + xc] = xv.x; sXf[xi * LDX + xc + 1] = xv.y; }
-        if (XG) {
+        if (F16) {
+            unsigned q0, q1;
+            split2_pair_f16(sat_f16(xv.x * NL_F16_SX), sat_f16(xv.y * NL_F16_SX), &q0, &q1);
+            const int o = opaque(xi * 32 + 2 * xc);
+            *reinterpret_cast<unsigned*>(ldsb + XG_XP01_OFF + o) = q0;
+            *reinterpret_cast<unsigned*>(ldsb + XG_XP01_OFF + XG_XP_BYTES + o) = q1;
+        } else if (XG) {
             unsigned q0, q1, q2;
             split3_pair(xv.x, xv.y, &q0, &q1, &q2);
             const int o = opaque(xi * 32 + 2 * xc);
@@ -468,7 +602,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             *reinterpret_cast<unsigned*>(ldsb + XG_XP2_OFF + o) = q2;
         }
     };
-    if (XG) {   // this lane's B fragments of layer 1, parked in LDS (the kernel has no registers to spare)
+    if (F16) {  // this lane's B fragments of layer 1, parked in LDS (the kernel has no registers to spare)
+        uint4 wq[2];
+        l1_w1_fragments_f16(a.params, col, lh, wq);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<uint4*>(ldsb + XG_W1X_OFF + ((w * 3 + pl) * 64 + lane) * 16) = wq[pl];
+    } else if (XG) {
         uint4 wq[3];
         l1_w1_fragments(a.params, col, lh, wq);
 #pragma unroll
@@ -488,11 +627,26 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         // ---------------- B: H1 = relu(X W1^T + b1) ----------------
         unsigned m1 = 0u;                               // XG: this lane's 32 ReLU bits of H1
         uint4 bq9[X9_RING][3];
+        uint4 bqh[F16_RING][2];
         {
             f32x16 c0, c1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
-            if (XG) {
+            if (F16) {
+                const unsigned char* xq = ldsb + opaque(l31 * 32 + 16 * lh);
+                const unsigned char* wq = ldsb + opaque(XG_W1X_OFF + (w * 3 * 64 + lane) * 16);
+                uint4 xa0[2], xa1[2], wf[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    xa0[pl] = *reinterpret_cast<const uint4*>(xq + XG_XP01_OFF + pl * XG_XP_BYTES);
+                    xa1[pl] = *reinterpret_cast<const uint4*>(xq + XG_XP01_OFF + pl * XG_XP_BYTES + 32 * 32);
+                    wf[pl] = *reinterpret_cast<const uint4*>(wq + pl * 64 * 16);
+                }
+#pragma unroll
+                for (int pa = 1; pa >= 0; --pa)               // all four products, the smallest first (K = 16: two dozen pipe cycles)
+#pragma unroll
+                    for (int pq = 1; pq >= 0; --pq) { c0 = mma16<true>(xa0[pa], wf[pq], c0); c1 = mma16<true>(xa1[pa], wf[pq], c1); }
+            } else if (XG) {
                 const unsigned char* xq = ldsb + opaque(l31 * 32 + 16 * lh);
                 const unsigned char* wq = ldsb + opaque(XG_W1X_OFF + (w * 3 * 64 + lane) * 16);
                 bf16x8 xa0[3], xa1[3], wf[3];
@@ -516,7 +670,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
                     c0 = MFMA32(xb[2 * kk], bw, c0); c1 = MFMA32(xb[32 * LDX + 2 * kk], bw, c1);
                 }
             }
-            if (XG) {
+            if (F16) {
+                gemm_f16_prefetch(rsW2TH, w, lane, bqh);         // W2 planes of the first k-steps: in flight across the barrier
+                m1 = store_h1_planes_f16(reinterpret_cast<unsigned short*>(lds), col, lh, c0, c1, b1c * NL_F16_SH);
+            } else if (XG) {
                 gemm_x9_prefetch(rsW2TX, w, lane, bq9);          // W2 planes of the first k-steps: in flight across the barrier
                 m1 = store_h1_planes(reinterpret_cast<unsigned short*>(lds), col, lh, c0, c1, b1c);
             } else {
@@ -535,11 +692,15 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
-            if (XG) gemm_x9<true, NP>(rsW2TX, w, lane, reinterpret_cast<const unsigned char*>(lds), bq9, h0, h1);
+            if constexpr (F16) gemm_f16<true, NP>(rsW2TH, w, lane, reinterpret_cast<const unsigned char*>(lds), bqh, h0, h1);
+            else if (XG) gemm_x9<true, F16 ? 9 : NP>(rsW2TX, w, lane, reinterpret_cast<const unsigned char*>(lds), bq9, h0, h1);
             else    gemm256(rsW2T, (lh * NL_W + col) * 4, sH1 + l31 * LDH + lh, sH1 + (32 + l31) * LDH + lh, h0, h1);
             DBG_STAMP(3);
+            constexpr float S2 = 1.0f / (NL_F16_SH * NL_F16_SW2);     // fp16 pairs: the accumulators are 2^12 x H1 W2^T
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { h0[r] = fmaxf(h0[r] + b2c, 0.f); h1[r] = fmaxf(h1[r] + b2c, 0.f); }
+            for (int r = 0; r < 16; ++r) {
+                h0[r] = fmaxf(F16 ? fmaf(h0[r], S2, b2c) : h0[r] + b2c, 0.f); h1[r] = fmaxf(F16 ? fmaf(h1[r], S2, b2c) : h1[r] + b2c, 0.f);
+            }
             const float tot = halfwave_rowsum(h0, h1, w3c, l31);               // entry e = l31 of [h0 rows | h1 rows]
             sS[w * DEC_M + (l31 >> 4) * 32 + d32_row(l31 & 15, lh)] = tot;     // this wave's 32 columns of 64 distinct rows
         }
@@ -571,7 +732,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         DBG_STAMP(5);
         // ---------------- E: dH2 = ds * w3 * [H2 > 0] -> LDS ----------------
         uint4 bqm[MX_RING][3];
-        if (XG) gemm_mask_x_prefetch(rsW2X, w, lane, bqm);
+        if (F16) gemm_mask_x_prefetch<2>(rsW2H, w, lane, bqm);
+        else if (XG) gemm_mask_x_prefetch<3>(rsW2X, w, lane, bqm);
         {
             unsigned mw = 0u;                       // this lane's 32 ReLU bits: bit r = h0[r] > 0, bit 16+r = h1[r] > 0
             const float* dsb = sdS + opaque(4 * lh);
@@ -598,7 +760,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         const unsigned lb = (odd ? lo_bits >> 1 : lo_bits) >> (16 * sub + r), hb = (odd ? hi_bits >> 1 : hi_bits) >> (16 * sub + r);
-                        mb[((32 * sub + D32_RR(r)) * SM_STRIDE) / 2] = ((lb & 1u) ? 0x3F80u : 0u) | ((hb & 1u) ? 0x3F800000u : 0u);
+                        mb[((32 * sub + D32_RR(r)) * SM_STRIDE) / 2] = ((lb & 1u) ? (F16 ? 0x3C00u : 0x3F80u) : 0u) | ((hb & 1u) ? (F16 ? 0x3C000000u : 0x3F800000u) : 0u);     // 1.0 as fp16 / bf16
                     }
             }
             // one word per thread, thread-major per tile: k_decoder_wgrad2's thread (same wave/lane) reads it back
@@ -611,7 +773,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { g0v[r] = 0.f; g1v[r] = 0.f; }
-            if (XG && TRAIN) gemm_mask_x_rolled(rsW2X, w, lane, reinterpret_cast<const unsigned char*>(lds), bqm, g0v, g1v);
+            if (F16 && TRAIN) gemm_mask_x_rolled<true>(rsW2H, w, lane, reinterpret_cast<const unsigned char*>(lds), bqm, g0v, g1v);
+            else if (F16)    gemm_mask_x<true, true>(rsW2H, w, lane, reinterpret_cast<const unsigned char*>(lds), bqm, g0v, g1v);
+            else if (XG && TRAIN) gemm_mask_x_rolled(rsW2X, w, lane, reinterpret_cast<const unsigned char*>(lds), bqm, g0v, g1v);
             else if (XG)     gemm_mask_x<true>(rsW2X, w, lane, reinterpret_cast<const unsigned char*>(lds), bqm, g0v, g1v);
             else    gemm256(rsW2, (lh * NL_W + col) * 4, sD + l31 * LDH + lh, sD + (32 + l31) * LDH + lh, g0v, g1v);
             DBG_STAMP(7);
@@ -667,7 +831,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int g = row0 + 16 * w + 4 * lq + r;
-                if (g < P) a.dX[(size_t)g * NL_C + l15] = cxa[r] + cxb[r];
+                if (g < P) a.dX[(size_t)g * NL_C + l15] = F16 ? (cxa[r] + cxb[r]) * DHS : cxa[r] + cxb[r];
             }
         } else if (TRAIN) {
             const float* xr = sX + opaque(lq * LDX + l15);
@@ -732,10 +896,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    base[NL_OFF_W1 + (hb + 16 * t + 4 * lq + r) * NL_C + l15] = accW1[t][r];
+                    base[NL_OFF_W1 + (hb + 16 * t + 4 * lq + r) * NL_C + l15] = F16 ? accW1[t][r] * DHS : accW1[t][r];
         }
         aW3 += __shfl_xor(aW3, 32); aB2 += __shfl_xor(aB2, 32); aB1 += __shfl_xor(aB1, 32);
-        if (lh == 0) { base[NL_OFF_W3 + col] = aW3; base[NL_OFF_B2 + col] = aB2; base[NL_OFF_B1 + col] = aB1; }
+        if (lh == 0) { base[NL_OFF_W3 + col] = aW3; base[NL_OFF_B2 + col] = aB2; base[NL_OFF_B1 + col] = F16 ? aB1 * DHS : aB1; }
         if (tid < 64) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) aB3 += __shfl_xor(aB3, off);
@@ -1031,6 +1195,7 @@ template <bool XG, int NP = 9>
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __restrict__ X, const float* __restrict__ params,
                                                                  const float* __restrict__ W2T, int P, float* __restrict__ sdf)
 {
+    constexpr bool F16 = XG && NP <= 4;                   // fp16 pairs (gemm modes 4 / 5): two planes of every 16-bit operand
     constexpr int H1_FLOATS = XG ? 3 * X_PLANE_BYTES / 4 : DEC_M * LDH;
     constexpr int XS_FLOATS = XG ? 3 * XG_XP_BYTES / 4 : DEC_M * LDX;      // bf16 mode: the X tile as three bf16 planes [64][32 B]
     __shared__ __attribute__((aligned(16))) float lds[H1_FLOATS + XS_FLOATS + 8 * DEC_M];
@@ -1040,10 +1205,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
     const float* W1 = params + NL_OFF_W1;
     const i32x4 rsW2T = make_w_rsrc(W2T);
     const i32x4 rsW2TX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W2T + NL_DEC_WS_W2TX_OFF), 0, 3 * W2X_PLANE_BYTES, 0x00020000);
+    const i32x4 rsW2TH = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W2T + NL_DEC_WS_W2TH_OFF), 0, 2 * W2X_PLANE_BYTES, 0x00020000);
     const float b1c = params[NL_OFF_B1 + col], b2c = params[NL_OFF_B2 + col], w3c = params[NL_OFF_W3 + col], b3 = params[NL_OFF_B3];
     float w1r[NL_C / 2];
-    uint4 w1p[3];
-    if (XG) l1_w1_fragments(params, col, lh, w1p);
+    uint4 w1p[3], w1h[2];
+    if (F16) l1_w1_fragments_f16(params, col, lh, w1h);
+    else if (XG) l1_w1_fragments(params, col, lh, w1p);
     else {
 #pragma unroll
         for (int kk = 0; kk < NL_C / 2; ++kk) w1r[kk] = W1[col * NL_C + 2 * kk + lh];
@@ -1055,18 +1222,34 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
             const int e = tid * 2, i = e >> 4, c = e & 15;
             float2 v = make_float2(0.f, 0.f);
             if (row0 + i < P) v = *reinterpret_cast<const float2*>(X + (size_t)(row0 + i) * NL_C + c);
-            if (XG) {
+            if (F16) {
+                unsigned* d = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(sX) + i * 32 + 2 * c);
+                split2_pair_f16(sat_f16(v.x * NL_F16_SX), sat_f16(v.y * NL_F16_SX), &d[0], &d[XG_XP_BYTES / 4]);
+            } else if (XG) {
                 unsigned* d = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(sX) + i * 32 + 2 * c);
                 split3_pair(v.x, v.y, &d[0], &d[XG_XP_BYTES / 4], &d[2 * XG_XP_BYTES / 4]);
             } else { sX[i * LDX + c] = v.x; sX[i * LDX + c + 1] = v.y; }
         }
         __syncthreads();
         uint4 bq9[X9_RING][3];
+        uint4 bqh[F16_RING][2];
         {
             f32x16 c0, c1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
-            if (XG) {                                     // the same nine products in the same order as k_decoder's phase B
+            if (F16) {                                    // the same four products in the same order as k_decoder's phase B
+                const unsigned char* xq = reinterpret_cast<const unsigned char*>(sX) + opaque(l31 * 32 + 16 * lh);
+                uint4 xa0[2], xa1[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    xa0[pl] = *reinterpret_cast<const uint4*>(xq + pl * XG_XP_BYTES);
+                    xa1[pl] = *reinterpret_cast<const uint4*>(xq + pl * XG_XP_BYTES + 32 * 32);
+                }
+#pragma unroll
+                for (int pa = 1; pa >= 0; --pa)
+#pragma unroll
+                    for (int pq = 1; pq >= 0; --pq) { c0 = mma16<true>(xa0[pa], w1h[pq], c0); c1 = mma16<true>(xa1[pa], w1h[pq], c1); }
+            } else if (XG) {                              // the same nine products in the same order as k_decoder's phase B
                 const unsigned char* xq = reinterpret_cast<const unsigned char*>(sX) + opaque(l31 * 32 + 16 * lh);
                 bf16x8 xa0[3], xa1[3];
 #pragma unroll
@@ -1086,7 +1269,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
 #pragma unroll
                 for (int kk = 0; kk < NL_C / 2; ++kk) { c0 = MFMA32(xb[2 * kk], w1r[kk], c0); c1 = MFMA32(xb[32 * LDX + 2 * kk], w1r[kk], c1); }
             }
-            if (XG) {
+            if (F16) {
+                gemm_f16_prefetch(rsW2TH, w, lane, bqh);
+                store_h1_planes_f16(reinterpret_cast<unsigned short*>(lds), col, lh, c0, c1, b1c * NL_F16_SH);
+            } else if (XG) {
                 gemm_x9_prefetch(rsW2TX, w, lane, bq9);
                 store_h1_planes(reinterpret_cast<unsigned short*>(lds), col, lh, c0, c1, b1c);
             } else {
@@ -1102,10 +1288,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
             f32x16 h0, h1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
-            if (XG) gemm_x9<true, NP>(rsW2TX, w, lane, reinterpret_cast<const unsigned char*>(lds), bq9, h0, h1);
+            if constexpr (F16) gemm_f16<true, NP>(rsW2TH, w, lane, reinterpret_cast<const unsigned char*>(lds), bqh, h0, h1);
+            else if (XG) gemm_x9<true, F16 ? 9 : NP>(rsW2TX, w, lane, reinterpret_cast<const unsigned char*>(lds), bq9, h0, h1);
             else    gemm256(rsW2T, (lh * NL_W + col) * 4, sH1 + l31 * LDH + lh, sH1 + (32 + l31) * LDH + lh, h0, h1);
+            constexpr float S2 = 1.0f / (NL_F16_SH * NL_F16_SW2);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { h0[r] = fmaxf(h0[r] + b2c, 0.f); h1[r] = fmaxf(h1[r] + b2c, 0.f); }
+            for (int r = 0; r < 16; ++r) {
+                h0[r] = fmaxf(F16 ? fmaf(h0[r], S2, b2c) : h0[r] + b2c, 0.f); h1[r] = fmaxf(F16 ? fmaf(h1[r], S2, b2c) : h1[r] + b2c, 0.f);
+            }
             const float tot = halfwave_rowsum(h0, h1, w3c, l31);
             sS[w * DEC_M + (l31 >> 4) * 32 + d32_row(l31 & 15, lh)] = tot;
         }
@@ -1174,7 +1364,7 @@ int nl_decoder_get_wgrad2_mode(void) { return g_wgrad2_mode; }
  * three-term split of w3_j W2[j][k], fp32 accumulation in both.  1 = all nine forward products (exact); 3 = eight, without lo x lo
  * (below 2^-30 of a product: the default); 2 = six (the dropped ones are below 2^-24 of a product: opt-in).  Process-wide
  * DEFAULTS: the *_m entry points and NlIterDesc.kernel_modes take the selection per call. */
-int nl_decoder_set_gemm_mode(int mode) { if (mode < 0 || mode > 3) return NL_ERR_INVALID_ARG; g_gemm_mode = mode; return NL_OK; }
+int nl_decoder_set_gemm_mode(int mode) { if (mode < 0 || mode > 5) return NL_ERR_INVALID_ARG; g_gemm_mode = mode; return NL_OK; }
 int nl_decoder_get_gemm_mode(void) { return g_gemm_mode; }
 
 }  // extern "C"
@@ -1184,7 +1374,7 @@ struct DecModes { int gemm, wgrad2; };
 static bool resolve_modes(int kernel_modes, DecModes* m)
 {
     const int g = (kernel_modes & 0xFF) - 1, w = ((kernel_modes >> 8) & 0xFF) - 1;
-    if (g > 3 || w > 1 || (kernel_modes >> 16) != 0) return false;
+    if (g > 5 || w > 1 || (kernel_modes >> 16) != 0) return false;
     m->gemm = g < 0 ? g_gemm_mode.load(std::memory_order_relaxed) : g;
     m->wgrad2 = w < 0 ? g_wgrad2_mode.load(std::memory_order_relaxed) : w;
     return true;
@@ -1216,7 +1406,13 @@ int nl_decoder_fwd_bwd_m(const void* loss_scalars, const float* X, const float* 
     a.dcounters = (double*)(counters + NL_CNT_INTS);
     a.dbg = g_dec_dbg;
     const dim3 g(nslabs), b(DEC_THREADS);
-    if (km.gemm == 3) {
+    if (km.gemm == 4) {
+        if (train_decoder) hipLaunchKernelGGL((k_decoder<true, true, 3>), g, b, 0, (hipStream_t)stream, a);
+        else               hipLaunchKernelGGL((k_decoder<false, true, 3>), g, b, 0, (hipStream_t)stream, a);
+    } else if (km.gemm == 5) {
+        if (train_decoder) hipLaunchKernelGGL((k_decoder<true, true, 4>), g, b, 0, (hipStream_t)stream, a);
+        else               hipLaunchKernelGGL((k_decoder<false, true, 4>), g, b, 0, (hipStream_t)stream, a);
+    } else if (km.gemm == 3) {
         if (train_decoder) hipLaunchKernelGGL((k_decoder<true, true, 8>), g, b, 0, (hipStream_t)stream, a);
         else               hipLaunchKernelGGL((k_decoder<false, true, 8>), g, b, 0, (hipStream_t)stream, a);
     } else if (km.gemm == 2) {
@@ -1271,7 +1467,9 @@ int nl_decoder_forward_m(const float* X, const float* params, const float* W2T, 
     if (!resolve_modes(kernel_modes, &km)) return NL_ERR_INVALID_ARG;
     if (!X || !params || !W2T || !sdf || P < 0 || nblocks <= 0) return NL_ERR_INVALID_ARG;
     if (P == 0) return NL_OK;
-    if (km.gemm == 3) hipLaunchKernelGGL((k_decoder_fwd<true, 8>), dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
+    if (km.gemm == 4) hipLaunchKernelGGL((k_decoder_fwd<true, 3>), dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
+    else if (km.gemm == 5) hipLaunchKernelGGL((k_decoder_fwd<true, 4>), dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
+    else if (km.gemm == 3) hipLaunchKernelGGL((k_decoder_fwd<true, 8>), dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
     else if (km.gemm == 2) hipLaunchKernelGGL((k_decoder_fwd<true, 6>), dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
     else if (km.gemm == 1) hipLaunchKernelGGL(k_decoder_fwd<true>, dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
     else                  hipLaunchKernelGGL(k_decoder_fwd<false>, dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);

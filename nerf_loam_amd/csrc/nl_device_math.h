@@ -66,6 +66,54 @@ NL_HD void nl_split3_bf16(float v, uint16_t* hi, uint16_t* mid, uint16_t* lo) {
     *hi = (uint16_t)(a.u >> 16); *mid = (uint16_t)(b.u >> 16); *lo = (uint16_t)(r.u >> 16);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-term fp16 split of an fp32 value ("f16 pair": gemm modes 4 / 5 of the decoder kernels).
+//   x = v * scale (a power of two: exact), saturated at +-65504;  hi = f16(x), lo = f16(x - hi), both round-to-nearest-even.
+// x - hi is exact in fp32, |x - hi| <= 2^-11 |x|, and lo carries its next 11 bits: |x - (hi + lo)| <= 2^-23 |x| (one fp32 rounding of the
+// operand at worst, exact for most values) as long as lo is a normal fp16 number, i.e. |x| >= 2^-2; below that the error is absolute,
+// <= 2^-25 (half the fp16 subnormal spacing) - the matrix cores keep subnormal fp16 inputs (scripts/micro/f16_pair.hip).  A product of two
+// fp16 values is exact in fp32 (22 significand bits), so hi*hi' + hi*lo' + lo*hi' (+ lo*lo') accumulated in fp32 is the fp32 product of
+// the operands up to 2^-22 (2^-23 with the fourth product) - below the rounding of the 256-deep fp32 accumulation it enters.
+// The scales put the operands of the shipped decoder high in fp16's range and bound what saturates:
+//   X * 2^6 (|X| < 1023), W1 * 2^8 (|W1| < 256), H1 * 2^4 (H1 < 4094), W2 * 2^8 (|W2| < 256), w3_j W2[j][k] * 2^12 (< 16).
+// These software conversions are what the weight-plane kernels (nl_optim.hip) and the host tests use; the decoder kernels convert with
+// v_cvt_pk_f16_f32 / v_cvt_f32_f16 (same IEEE results).
+// ---------------------------------------------------------------------------------------------
+#define NL_F16_MAX 65504.0f
+#define NL_F16_SX 64.0f
+#define NL_F16_SW1 256.0f
+#define NL_F16_SH 16.0f
+#define NL_F16_SW2 256.0f
+#define NL_F16_SG 4096.0f
+NL_HD uint16_t nl_f32_to_f16(float f) {
+    union { float f; uint32_t u; } v; v.f = f;
+    const uint32_t sign = (v.u >> 16) & 0x8000u, a = v.u & 0x7FFFFFFFu;
+    if (a >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | (a > 0x7F800000u ? 0x200u : 0u));      // inf / NaN
+    if (a >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);                                         // >= 65520 rounds to inf
+    if (a < 0x33000001u) return (uint16_t)sign;                                                      // <= 2^-25 rounds to zero (the tie goes to even)
+    const int e = (int)(a >> 23) - 127;
+    const uint32_t m = (a & 0x7FFFFFu) | 0x800000u;                                                  // 24-bit significand
+    const int shift = e < -14 ? 13 + (-14 - e) : 13;                                                 // bits below the fp16 result (subnormal: more)
+    uint32_t kept = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (kept & 1u))) ++kept;
+    return (uint16_t)(sign | (e < -14 ? kept : ((uint32_t)(e + 15) << 10) + (kept - 0x400u)));       // a rounding carry moves into the exponent
+}
+NL_HD float nl_f16_to_f32(uint16_t h) {
+    const uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3FFu;
+    union { uint32_t u; float f; } v;
+    if (e == 31u) v.u = sign | 0x7F800000u | (m << 13);
+    else if (e) v.u = sign | ((e + 112u) << 23) | (m << 13);
+    else { v.f = (float)m * 5.9604644775390625e-08f; v.u |= sign; }                                  // m * 2^-24, exact
+    return v.f;
+}
+NL_HD void nl_split2_f16(float v, float scale, uint16_t* hi, uint16_t* lo) {
+    float x = v * scale;
+    x = x > NL_F16_MAX ? NL_F16_MAX : (x < -NL_F16_MAX ? -NL_F16_MAX : x);
+    const uint16_t h = nl_f32_to_f16(x);
+    *hi = h; *lo = nl_f32_to_f16(x - nl_f16_to_f32(h));
+}
+
 // ray-selection key (nl_select.hip): lowbias32 is a bijection on 32-bit integers, so keys of distinct rays never tie
 NL_HD uint32_t nl_select_key(uint32_t seed, uint32_t i) {
     uint32_t x = i ^ (seed * 0x9E3779B9u + 0x7F4A7C15u);

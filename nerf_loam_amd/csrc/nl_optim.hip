@@ -72,6 +72,8 @@ __global__ void k_transpose_w2(const float* __restrict__ params, float* __restri
 // contiguous 1 KB load:  [plane(3)][column tile t(8)][k-step s(16)][lane(64)][8 bf16],  lane = 32 h + c:
 //     W2X  (dgrad,   dH1 = dH2 W2):    element e <-> j = 16 s + 8 h + e, k = 32 t + c, value w3_j * W2[j][k]
 //     W2TX (forward, H2 = H1 W2^T):    element e <-> k = 16 s + 8 h + e, n = 32 t + c, value W2[n][k]
+// The same two matrices as fp16 pairs (gemm modes 4 / 5; nl_split2_f16): [plane(2)][t(8)][s(16)][lane(64)][8 f16], the same element order,
+//     W2H  (dgrad):   (w3_j * W2[j][k]) * 2^12,    W2TH (forward):  W2[n][k] * 2^8.
 __global__ void k_prepare_w2x(const float* __restrict__ params, uint16_t* __restrict__ W2X, uint16_t* __restrict__ W2TX)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;         // one thread per (tile, s, lane)
@@ -84,6 +86,8 @@ __global__ void k_prepare_w2x(const float* __restrict__ params, uint16_t* __rest
             const int kk = k0 + e;
             const float v = which ? params[NL_OFF_W2 + c * NL_W + kk] : params[NL_OFF_W3 + kk] * params[NL_OFF_W2 + kk * NL_W + c];
             nl_split3_bf16(v, &dst[e], &dst[e + NL_W * NL_W], &dst[e + 2 * NL_W * NL_W]);
+            uint16_t* dh = W2X + NL_DEC_WS_W2H_OFF16 + (which ? 2 * NL_W * NL_W : 0) + (size_t)t * 8 + e;      // W2H | W2TH behind the bf16 planes
+            nl_split2_f16(v, which ? NL_F16_SW2 : NL_F16_SG, &dh[0], &dh[NL_W * NL_W]);
         }
     }
 }
@@ -236,10 +240,14 @@ __global__ void __launch_bounds__(256) k_optim_step(OptimArgs a)
             {   // forward planes: value W2[n = j][kk = k]
                 uint16_t* d = a.W2TX + (size_t)((((j >> 5) * 16 + (k >> 4)) * 64) + 32 * ((k >> 3) & 1) + (j & 31)) * 8 + (k & 7);
                 nl_split3_bf16(p, &d[0], &d[NL_W * NL_W], &d[2 * NL_W * NL_W]);
+                uint16_t* dh = a.W2X + NL_DEC_WS_W2H_OFF16 + 2 * NL_W * NL_W + (d - a.W2TX);
+                nl_split2_f16(p, NL_F16_SW2, &dh[0], &dh[NL_W * NL_W]);
             }
             {   // dgrad planes: value w3_j * W2[j][k] at row index j (the reduction index), column k
                 uint16_t* d = a.W2X + (size_t)((((k >> 5) * 16 + (j >> 4)) * 64) + 32 * ((j >> 3) & 1) + (k & 31)) * 8 + (j & 7);
                 nl_split3_bf16(w3 * p, &d[0], &d[NL_W * NL_W], &d[2 * NL_W * NL_W]);
+                uint16_t* dh = a.W2X + NL_DEC_WS_W2H_OFF16 + (d - a.W2X);
+                nl_split2_f16(w3 * p, NL_F16_SG, &dh[0], &dh[NL_W * NL_W]);
             }
         } else {
             const int g = (r - NL_W) * 256 + tid;

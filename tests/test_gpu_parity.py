@@ -14,13 +14,14 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 # decoder GEMM arithmetic (include/nerfloam_hip.h nl_decoder_set_gemm_mode): 0: fp32 MFMA GEMMs, 1: bf16 matrix cores, all nine partial
-# products of the three-term splits (exact), 3: eight of them (without lo x lo: THE DEFAULT), 2: six (opt-in, not exact).  The default
-# runs on every golden; the exact / fp32 modes and the opt-in one on a subset (they are the same kernels with other template arguments).
-ITERATION_CASES = ([(c, 3) for c in ["map_1f_1it", "map_2f_2it_frozen", "map_kitti_1f_1it", "map_ncd_1f_1it"]]
-                   + [("map_1f_1it", 0), ("map_1f_1it", 1), ("map_kitti_1f_1it", 1), ("map_2f_2it_frozen", 0), ("map_1f_1it", 2)])
+# products of the three-term splits (exact), 3: eight of them (without lo x lo), 2: six; 4 / 5: fp16 pairs - two-term fp16 splits, three / four of
+# the four forward products (round 5).  Modes 3 and 4 run on every golden; the exact / fp32 modes and the others on a subset (they are the same
+# kernels with other template arguments).
+ITERATION_CASES = ([(c, md) for md in (3, 4) for c in ["map_1f_1it", "map_2f_2it_frozen", "map_kitti_1f_1it", "map_ncd_1f_1it"]]
+                   + [("map_1f_1it", 0), ("map_1f_1it", 1), ("map_kitti_1f_1it", 1), ("map_2f_2it_frozen", 0), ("map_1f_1it", 2), ("map_1f_1it", 5), ("map_ncd_1f_1it", 5)])
 # sdf bars per mode (max |sdf - oracle|; the north_star bar is 1e-4).  Measured on MI355X (round 3): 2e-8 .. 3e-8 in every mode on the
 # golden scenes (6e-7 on the full scan); against the reference goldens 0.9e-6 .. 1.8e-6 (the oracle's own distance from them)
-SDF_TOL = {0: 5e-7, 1: 5e-7, 3: 5e-7, 2: 5e-6}
+SDF_TOL = {0: 5e-7, 1: 5e-7, 3: 5e-7, 2: 5e-6, 4: 5e-7, 5: 5e-7}
 _METRICS = {}
 
 
@@ -326,11 +327,11 @@ def test_engines_carry_their_own_kernel_modes(nl, golden_dir):
         assert not np.array_equal(got[(0, 0)]["sdf"], got[(1, 1)]["sdf"]) or not np.array_equal(got[(0, 0)]["gdec"], got[(1, 1)]["gdec"])
         assert np.abs(got[(0, 0)]["sdf"] - got[(1, 1)]["sdf"]).max() < 1e-5 and np.abs(got[(3, 1)]["sdf"] - got[(1, 1)]["sdf"]).max() < 1e-5
     with pytest.raises(ValueError):
-        nl["P"].SdfEngine(max_rays=8, gemm_mode=4)
+        nl["P"].SdfEngine(max_rays=8, gemm_mode=6)
     assert lib.nl_decoder_forward_m(None, None, None, 0, None, 1, 0x0600, None) != 0       # wgrad2 mode 5: rejected
 
 
-@pytest.mark.parametrize("backward_mode", [1, 3], indirect=True)
+@pytest.mark.parametrize("backward_mode", [1, 3, 4], indirect=True)
 def test_mapping_three_steps_track_oracle(nl, golden_dir, backward_mode):
     """3 Adam iterations (embeddings bf16 + decoder + pose), same ray masks: parameters after each
     step stay within round-off of the oracle's; final state close to the reference golden."""
@@ -388,7 +389,7 @@ def test_mapping_three_steps_track_oracle(nl, golden_dir, backward_mode):
     np.testing.assert_allclose(pose[3:], g["poses_final"][0][3:], rtol=0, atol=1e-5)
 
 
-@pytest.mark.parametrize("backward_mode", [1, 3], indirect=True)
+@pytest.mark.parametrize("backward_mode", [1, 3, 4], indirect=True)
 @pytest.mark.parametrize("case", ["track_2it"] + EXTRA_TRACK_GOLDENS)
 def test_tracking_matches_oracle_and_golden(nl, golden_dir, case, backward_mode):
     g = np.load(os.path.join(golden_dir, case + ".npz"))
@@ -442,7 +443,7 @@ def full_scan_scene():
     return dict(points=pts, cos=cos, pose=pose, ms=ms)
 
 
-@pytest.mark.parametrize("backward_mode", [1, 3], indirect=True)
+@pytest.mark.parametrize("backward_mode", [1, 3, 4], indirect=True)
 def test_full_scan_matches_the_oracle(nl, backward_mode):
     """one whole mapping iteration on all 131 072 rays of the synthetic scan against the oracle run on the same inputs:
     hit lists, sample layout and depths bit for bit (C restatement of the two CUDA kernels at full size, incl. the
@@ -528,7 +529,7 @@ def test_full_scan_invariants(nl):
     lib = nl["L"].lib()
     old = lib.nl_decoder_get_wgrad2_mode(), lib.nl_decoder_get_gemm_mode()
     res = []
-    for mode in (0, 1, 3):
+    for mode in (0, 1, 3, 4, 5):
         assert lib.nl_decoder_set_wgrad2_mode(min(mode, 1)) == 0 and lib.nl_decoder_set_gemm_mode(mode) == 0
         eng.g_emb.zero_(); eng.g_pose.zero_()
         eng.forward_backward(m, dec, cfg)
@@ -539,12 +540,14 @@ def test_full_scan_invariants(nl):
         assert eng.forward_only(m, dec, cfg) == Pn
         assert np.array_equal(eng.sdf[:Pn].cpu().numpy(), res[-1][2])                      # forward-only kernel: same arithmetic
     lib.nl_decoder_set_wgrad2_mode(old[0]); lib.nl_decoder_set_gemm_mode(old[1])
-    assert np.abs(res[0][2] - res[1][2]).max() <= 2e-6 and np.abs(res[0][2] - res[2][2]).max() <= 2e-6    # sdf: |values| ~ 0.1, 256-term sums
+    for other in (1, 2, 3, 4):
+        assert np.abs(res[0][2] - res[other][2]).max() <= 2e-6, other                       # sdf: |values| ~ 0.1, 256-term sums
+    record_metric("full_scan_invariants", **{f"sdf_mode{md}_vs_fp32_mfma": np.abs(res[0][2] - res[i][2]).max() for i, md in enumerate((0, 1, 3, 4, 5)) if i})
     # dX: a hidden unit whose pre-activation is ~0 can fall on either side of the ReLU under a different summation order
     # (a handful of the 1.1 M x 256 units), so compare in norm and element-wise on all but a vanishing fraction
     dx0 = res[0][1]
     assert np.abs(dx0).max() > 0
-    for other in (1, 2):
+    for other in (1, 2, 3, 4):
         dx1 = res[other][1]
         assert np.linalg.norm(dx0 - dx1) <= 1e-3 * np.linalg.norm(dx0)                    # ~1e2 flipped units of 2.8e8
         assert (np.abs(dx0 - dx1) > 2e-5 * np.abs(dx0).max()).mean() < 1e-4
