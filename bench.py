@@ -880,6 +880,22 @@ def main():
             step()
         barrier()
         steady = (time.perf_counter() - t1) / STEADY_STEPS * 1e3
+    # the same step with the decoder's EXACT-product arithmetic (gemm mode 3: three-term bf16 splits, eight of nine products), timed right
+    # behind the sustained run (warm clock: compare with steady_state): what the default's fp16 pairs buy, and the line a caller that pins
+    # exact fp32 products gets.  Selected per call (kernel_modes) - the process default is not touched.
+    exact_leg = None
+    if not (shard or args.no_steady_state) and _lib.lib().nl_decoder_get_gemm_mode() in (4, 5):
+        km0 = eng.kernel_modes
+        eng.kernel_modes = _lib.kernel_modes(3, None)
+        for _ in range(3):
+            step()
+        barrier(); t1 = time.perf_counter()
+        for _ in range(50):
+            step()
+        barrier()
+        exact_leg = (time.perf_counter() - t1) / 50 * 1e3
+        eng.kernel_modes = km0
+        step(); barrier()
     if shard:
         import torch.distributed as tdist
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -939,7 +955,9 @@ def main():
               "traffic_source": ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes over a 3-iteration child of this command), "
                                  "(2 x FETCH_SIZE + WRITE_SIZE) KB per launch" if traffic is not None else committed_traffic_source()),
               "peak_note": ("matrix-pipe bound of the kernel's instruction mix: "
-                            + (f"256-deep GEMMs as bf16 three-term splits ({ {1: 9, 3: 8, 2: 6}.get(gm, 9)} of 9 forward + 3 dgrad MFMAs per fp32 product, 2500 TF pipe), "
+                            + (f"256-deep GEMMs as fp16 pairs ({ {4: 3, 5: 4}[gm]} of 4 forward + 2 dgrad MFMAs per fp32 product, 2500 TF pipe), layer-1 forward as four fp16 "
+                               "products, dX / dW1 (K=16) on the fp32 pipe (157.3 TF)" if gm >= 4 else
+                               f"256-deep GEMMs as bf16 three-term splits ({ {1: 9, 3: 8, 2: 6}.get(gm, 9)} of 9 forward + 3 dgrad MFMAs per fp32 product, 2500 TF pipe), "
                                "layer-1 forward as nine bf16 products too, dX / dW1 (K=16) on the fp32 pipe (157.3 TF)" if gm >= 1 else "all GEMMs on the fp32 pipe (157.3 TF)")),
               "second_kernel": (roofline_entry("k_decoder_wgrad2_x" if wm == 1 else "k_decoder_wgrad2", "wgrad2", wg_ms, P_local, gm, wm, True)
                                 if train_dec else None)}
@@ -948,10 +966,14 @@ def main():
             "value": N * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "dtype_note": ("fp32 values and fp32 accumulation throughout; the decoder's 256-deep GEMMs are evaluated on the bf16 "
-                           "matrix cores as exact-product splits (each fp32 operand = 3 bf16 terms exactly; ReLU masks are {0,1}); the "
-                           "forward GEMM forms " + {1: "all nine", 3: "eight of the nine (without lo x lo: < 2^-30 of a product)", 2: "six of the nine"}.get(gm, "?")
-                           + " partial products; NL_GEMM_MODE=1 = all nine, NL_GEMM_MODE=0 / NL_WGRAD2_MODE=0 = the plain fp32-MFMA kernels" if (gm >= 1 or wm == 1)
+            "dtype_note": ("fp32 values and fp32 accumulation throughout; the decoder's 256-deep GEMMs run on the 16-bit matrix cores on split operands: "
+                           + ("fp16 pairs - every fp32 operand (scaled by a power of two) = hi + lo, two fp16 terms that reproduce it to one fp32 rounding "
+                              "(2^-23), each hi/lo product exact in fp32; the forward GEMM forms " + {4: "three of the four partial products (without lo x lo: < 2^-22 of a product)", 5: "all four partial products"}[gm]
+                              + ", the dgrad is the {0,1} ReLU mask x two terms.  Measured against the oracle and the reference goldens this is indistinguishable from the exact-product "
+                              "mode (exact_products: NL_GEMM_MODE=3, three-term bf16 splits)" if gm >= 4 else
+                              "exact-product splits (each fp32 operand = 3 bf16 terms exactly; ReLU masks are {0,1}); the forward GEMM forms "
+                              + {1: "all nine", 3: "eight of the nine (without lo x lo: < 2^-30 of a product)", 2: "six of the nine"}.get(gm, "?") + " partial products")
+                           + "; NL_GEMM_MODE=0 / NL_WGRAD2_MODE=0 = the plain fp32-MFMA kernels" if (gm >= 1 or wm == 1)
                            else "fp32 MFMA kernels (NL_GEMM_MODE=0, NL_WGRAD2_MODE=0)"),
             "config": {"workload": "synthetic 64x2048 scan (131072 rays), 1 mapping iteration/step: intersect+sample+gather+"
                                    "decoder fwd/bwd+SDF loss+emb/decoder/pose grads+Adam; voxel 0.2 m, step 0.1 m, "
@@ -960,6 +982,11 @@ def main():
                        "valid_samples_rank0": P_local, "max_samples_per_ray": st["S"], "parallelism": f"ray-shard x{world}" + (" (interleaved returns)" if world > 1 else "")},
             "roofline": rf,
         }
+        if exact_leg is not None:
+            out["exact_products"] = {"gemm_mode": 3, "ms_per_step": exact_leg, "rays_per_s": N / exact_leg * 1e3, "steps": 50,
+                                     "note": "the same step with the 256-deep GEMMs as three-term bf16 splits (every product exact, eight of the nine forward products: the "
+                                             "default of rounds 3-4), timed right behind steady_state on the warm device - compare with steady_state.ms_per_step; selectable per call "
+                                             "(NlIterDesc.kernel_modes / SdfEngine(gemm_mode=3)) or process-wide (NL_GEMM_MODE=3)"}
         if steady is not None:
             out["steady_state"] = {"steps": STEADY_STEPS, "ms_per_step": steady, "rays_per_s": N / steady * 1e3,
                                    "note": "the same step, the next %d launches after the timed region (local time of rank 0): the device reaches its steady clock "

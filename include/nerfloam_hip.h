@@ -205,7 +205,7 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
                        float* sdf, float* dsdf, float* dX, float* partials, unsigned* relu2_mask, int nslabs, int train_decoder,
                        int* counters, void* stream);
 /* The same four decoder entry points with the kernel selection passed per call instead of taken from the process-wide defaults
- * (3, 1; include/nerfloam_hip_debug.h holds the A/B setters): kernel_modes = NL_KERNEL_MODES(gemm_mode, wgrad2_mode), either
+ * (4, 1; include/nerfloam_hip_debug.h holds the A/B setters): kernel_modes = NL_KERNEL_MODES(gemm_mode, wgrad2_mode), either
  * mode -1 (or kernel_modes == 0) = the process default.  NlIterDesc.kernel_modes carries the same word for nl_iteration. */
 #define NL_KERNEL_MODES(gemm_mode, wgrad2_mode) ((((gemm_mode) + 1) & 0xFF) | ((((wgrad2_mode) + 1) & 0xFF) << 8))
 int nl_decoder_fwd_bwd_m(const void* loss_scalars, const float* X, const float* params, const float* W2T,
@@ -234,19 +234,27 @@ int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, voi
  *   floats [262144, 327680):  "W2H"  = (w3_j * W2[j][k]) * 2^12 as two fp16 planes (hi = f16(x), lo = f16(x - hi), round to nearest), same order,
  *   floats [327680, 393216):  "W2TH" = W2[n][k] * 2^8, likewise: the operands of gemm modes 4 / 5. */
 int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream);
-/* The two 256-deep GEMMs of nl_decoder_fwd_bwd / nl_decoder_forward: 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32);
- * 1, 2, 3 = bf16 matrix cores (v_mfma_f32_32x32x16_bf16) on exact-product formulations:
- *   forward  H2 = H1 W2^T:  both operands split into three bf16 terms (v = hi + mid + lo exactly), partial products exact in fp32;
- *   dgrad    dH1[i][k] = dsdf_i * sum_j m(i,j) * (w3_j W2[j][k]),  m = the {0,1} ReLU mask as A operand, B split in three.
- * Accumulation is fp32 in every mode.
- * 1 = all nine forward products: the exact fp32 x fp32 products (results differ from mode 0 by summation order only).
- * 3 = eight of the nine (without lo x lo, below 2^-30 of a product = 2^-6 of one fp32 rounding; bound proven on the host in rational
- *     arithmetic, tests/test_device_math_host.py): THE DEFAULT, 8/9 of the forward matrix-pipe time.
- * 2 = six (also without lo x mid, mid x lo: below 2^-24 of a product): opt-in, never a default.
+/* The two 256-deep GEMMs of nl_decoder_fwd_bwd / nl_decoder_forward (gemm_mode).  Values and accumulation are fp32 in every mode; the
+ * modes differ in how the matrix cores form the fp32 x fp32 products:
+ *   0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32), 1/16 of the 16-bit rate.
+ *   1, 3, 2 = bf16 matrix cores (v_mfma_f32_32x32x16_bf16) on EXACT three-term splits (v = hi + mid + lo exactly, 8 + 8 + 8 bits):
+ *       forward  H2 = H1 W2^T:  both operands split, partial products exact in fp32;
+ *       dgrad    dH1[i][k] = dsdf_i * sum_j m(i,j) * (w3_j W2[j][k]),  m = the {0,1} ReLU mask as A operand, B split in three.
+ *     1 = all nine forward products: the exact fp32 x fp32 products (results differ from mode 0 by summation order only);
+ *     3 = eight of the nine (without lo x lo, below 2^-30 of a product; bound proven in rational arithmetic, tests/test_device_math_host.py):
+ *         the default of rounds 3-4, what a caller that wants exact products at the best speed pins;
+ *     2 = six (also without lo x mid, mid x lo: below 2^-24 of a product).
+ *   4, 5 = fp16 matrix cores (v_mfma_f32_32x32x16_f16) on TWO-term splits ("fp16 pairs", round 5): every operand, scaled by a fixed power of two,
+ *     is hi + lo with hi = f16(x), lo = f16(x - hi), round to nearest - the pair reproduces x to one fp32 rounding (2^-23; nl_split2_f16 in
+ *     csrc/nl_device_math.h), each hi/lo product is exact in fp32.  Forward: 4 = hi hi' + hi lo' + lo hi' (THE DEFAULT: what is dropped is below
+ *     2^-22 of a product, under the rounding of the 256-deep fp32 accumulation), 5 = all four; dgrad: the {0,1} mask x two terms; layer 1: all four.
+ *     6 + 4 matrix instructions per k-step against 16 + 6 of mode 3.  Measured against the oracle and the reference-generated goldens the modes 1, 3,
+ *     4, 5 are indistinguishable (sdf 3e-8, the same gradient bars).  Operands saturate instead of overflowing fp16:
+ *     |X| < 1023, |W1| < 256, H1 < 4094, |W2| < 256, |w3_j W2[j][k]| < 16 - far outside what the decoder of an SDF map holds.
  * dW2 kernel (wgrad2_mode): 0 = fp32 matrix cores, 1 = bf16 matrix cores on dW2[j][k] = w3_j * sum_i m(i,j) * (dsdf_i * H1[i][k]) with the
  * {0,1} mask m as A operand and the fp32 B operand split into three bf16 terms (exact products, fp32 accumulation; default).
  * The selection is a PER-CALL argument (kernel_modes of the *_m entry points, NlIterDesc.kernel_modes); the entry points without it use the
- * library defaults (3, 1).  Changing those defaults process-wide is a test / A-B aid: include/nerfloam_hip_debug.h. */
+ * library defaults (4, 1).  Changing those defaults process-wide is a test / A-B aid: include/nerfloam_hip_debug.h. */
 
 /* backward of get_features: embedding gradient (fp32 accumulation of bf16-rounded contributions, the
  * CUDA embedding_dense_backward semantics) and pose-gradient partials g_pose[F,12] = (dL/dt, dL/dR), accumulated in fp64

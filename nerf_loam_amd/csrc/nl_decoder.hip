@@ -1346,8 +1346,9 @@ __global__ void k_mfma_selftest(const float* A32, const float* B32, float* D32, 
 
 // process-global A/B / profiling state (include/nerfloam_hip_debug.h): relaxed atomics - a setter racing a launch is not a data race
 static std::atomic<long long*> g_dec_dbg{nullptr};
-static std::atomic<int> g_gemm_mode{3};             // 0: fp32 MFMA GEMMs; bf16 MFMA on the exact-product formulations (gemm_x9 / gemm_mask_x) with
-                                         // 1: all nine forward products (exact), 3: eight (without lo x lo: the default), 2: six (opt-in)
+static std::atomic<int> g_gemm_mode{4};             // 0: fp32 MFMA GEMMs; bf16 MFMA on the exact-product formulations (gemm_x9 / gemm_mask_x) with
+                                         // 1: all nine forward products (exact), 3: eight (without lo x lo), 2: six; fp16 pairs (gemm_f16) with
+                                         // 4: three of the four forward products (THE DEFAULT), 5: all four
 static std::atomic<int> g_wgrad2_mode{1};           // 0: fp32 MFMA (k_decoder_wgrad2), 1: exact 0/1-mask x 3-term bf16 split (k_decoder_wgrad2_x)
 
 extern "C" {

@@ -111,6 +111,16 @@ void hh_split3_bf16(int n, const float* v, uint16_t* hi, uint16_t* mid, uint16_t
     for (int i = 0; i < n; ++i) nl_split3_bf16(v[i], &hi[i], &mid[i], &lo[i]);
 }
 
+void hh_f16_convert(int n, const float* v, uint16_t* h, float* back)
+{
+    for (int i = 0; i < n; ++i) { h[i] = nl_f32_to_f16(v[i]); back[i] = nl_f16_to_f32(h[i]); }
+}
+
+void hh_split2_f16(int n, const float* v, float scale, uint16_t* hi, uint16_t* lo)
+{
+    for (int i = 0; i < n; ++i) nl_split2_f16(v[i], scale, &hi[i], &lo[i]);
+}
+
 void hh_select_key(int n, uint32_t seed, uint32_t* out)
 {
     for (int i = 0; i < n; ++i) out[i] = nl_select_key(seed, (uint32_t)i);

@@ -425,3 +425,52 @@ def test_eight_product_forward_drops_less_than_2_to_the_minus_30_of_a_product(hh
     assert (dropped <= bound).all()
     fp32_acc = np.abs(np.cumsum((X * W).astype(np.float32), axis=1, dtype=np.float32)[:, -1].astype(np.float64) - (X.astype(np.float64) * W.astype(np.float64)).sum(1))
     assert np.median(dropped) < 0.05 * max(np.median(fp32_acc), 1e-30)                    # far inside the accumulation's own round-off
+
+
+def test_fp16_pair_split(hh):
+    """The arithmetic behind gemm modes 4 / 5 (nl_device_math.h nl_split2_f16): (i) the software fp32 -> fp16 conversion
+    the weight-plane kernels use is IEEE round-to-nearest-even incl. subnormals (== numpy, what v_cvt_pk_f16_f32 does in the decoder kernels);
+    (ii) hi + lo reproduces the scaled operand to 2^-23 relative (or 2^-25 absolute where lo is subnormal), saturating at +-65504;
+    (iii) every fp16 x fp16 product is exact in fp32; (iv) hi hi' + hi lo' + lo hi' differs from the exact product of the operands by less than
+    2^-21 of it - in exact rational arithmetic - i.e. below the rounding noise of the 256-deep fp32 accumulation the products enter."""
+    from fractions import Fraction
+    rng = np.random.default_rng(2)
+    v = np.concatenate([
+        rng.normal(size=200000).astype(np.float32), (rng.normal(size=50000) * 1e-4).astype(np.float32), (rng.normal(size=50000) * 3e4).astype(np.float32),
+        rng.integers(0, 2 ** 32, 200000, dtype=np.uint64).astype(np.uint32).view(np.float32),
+        np.array([0.0, -0.0, 1.0, -1.0, 65504.0, 65519.99, 65520.0, 1e9, -1e9, 2.0 ** -24, 2.0 ** -25, 2.0 ** -25 * 1.0001, 2.0 ** -14, 6.1e-5, 0.1, 1 / 3, np.inf, -np.inf], np.float32)])
+    v = v[~np.isnan(v)]
+    n = len(v)
+    h, back = np.empty(n, np.uint16), np.empty(n, np.float32)
+    hh.hh_f16_convert(n, p(v), p(h), p(back))
+    with np.errstate(over="ignore"):
+        ref = v.astype(np.float16)
+    assert np.array_equal(h, ref.view(np.uint16))                                   # (i) bit for bit, subnormals and the overflow boundary included
+    assert np.array_equal(back.view(np.uint32), ref.astype(np.float32).view(np.uint32))
+    # (ii) the split of operands in the ranges the decoder sees, at the kernels' scales
+    for scale, x in ((16.0, np.abs(rng.normal(0, 1.0, 100000)).astype(np.float32)), (256.0, rng.uniform(-0.07, 0.07, 100000).astype(np.float32)),
+                     (64.0, rng.normal(0, 0.02, 100000).astype(np.float32)), (4096.0, (rng.uniform(-0.06, 0.06, 100000) * rng.uniform(-0.06, 0.06, 100000)).astype(np.float32))):
+        hi, lo = np.empty(len(x), np.uint16), np.empty(len(x), np.uint16)
+        hh.hh_split2_f16(len(x), p(x), ctypes.c_float(scale), p(hi), p(lo))
+        H_, L_ = hi.view(np.float16).astype(np.float64), lo.view(np.float16).astype(np.float64)
+        xs = x.astype(np.float64) * scale
+        assert (np.abs(H_ + L_ - xs) <= np.maximum(np.abs(xs) * 2.0 ** -23, 2.0 ** -25)).all()
+        assert (np.abs(L_) <= np.abs(xs) * 2.0 ** -11 + 2.0 ** -25).all()
+        # (iii) products of two fp16 values carry at most 22 significand bits
+        a, b = H_[:50000], L_[50000:]
+        assert np.array_equal((a * b).astype(np.float32).astype(np.float64), a * b)
+    big = np.array([1e6, -1e6, 70000.0], np.float32)                                # saturation instead of inf
+    hi, lo = np.empty(3, np.uint16), np.empty(3, np.uint16)
+    hh.hh_split2_f16(3, p(big), ctypes.c_float(1.0), p(hi), p(lo))
+    assert np.array_equal(hi.view(np.float16).astype(np.float32), [65504.0, -65504.0, 65504.0]) and not lo.any()
+    # (iv) three of the four partial products, exact arithmetic
+    x = np.abs(rng.normal(0, 1.0, 400)).astype(np.float32) + np.float32(0.02)
+    w = rng.uniform(-0.07, 0.07, 400).astype(np.float32); w[np.abs(w) < 1e-3] = np.float32(0.01)
+    xh, xl, wh, wl = (np.empty(400, np.uint16) for _ in range(4))
+    hh.hh_split2_f16(400, p(x), ctypes.c_float(16.0), p(xh), p(xl)); hh.hh_split2_f16(400, p(w), ctypes.c_float(256.0), p(wh), p(wl))
+    F = lambda bits: [Fraction(float(t)) for t in bits.view(np.float16).astype(np.float64)]     # noqa: E731
+    for X, Wv, a, b, c, d in zip(x, w, F(xh), F(xl), F(wh), F(wl)):
+        exact = Fraction(float(X)) * 16 * Fraction(float(Wv)) * 256
+        three = a * c + a * d + b * c
+        assert abs(exact - three) * 2 ** 21 < abs(exact)
+        assert abs(exact - (three + b * d)) * 2 ** 22 < abs(exact)                 # all four: only the operands' own last-bit rounding is left

@@ -308,7 +308,7 @@ def test_engines_carry_their_own_kernel_modes(nl, golden_dir):
 
     for one_call in (False, True):
         got = {}
-        for gemm, wg in ((0, 0), (1, 1), (3, 1), (0, 0), (1, 1)):              # alternating selections, process default untouched
+        for gemm, wg in ((0, 0), (1, 1), (3, 1), (4, 1), (0, 0), (1, 1), (4, 1)):              # alternating selections, process default untouched
             r = run(one_call, gemm, wg)
             assert (lib.nl_decoder_get_gemm_mode(), lib.nl_decoder_get_wgrad2_mode()) == default
             if (gemm, wg) in got:
@@ -316,7 +316,7 @@ def test_engines_carry_their_own_kernel_modes(nl, golden_dir):
                     assert np.array_equal(got[(gemm, wg)][k], r[k]), (one_call, gemm, k)
             got[(gemm, wg)] = r
         try:
-            for gemm, wg in ((0, 0), (1, 1), (3, 1)):                           # the same selection as the process default: same bits
+            for gemm, wg in ((0, 0), (1, 1), (3, 1), (4, 1)):                           # the same selection as the process default: same bits
                 assert lib.nl_decoder_set_gemm_mode(gemm) == 0 and lib.nl_decoder_set_wgrad2_mode(wg) == 0
                 r = run(one_call)
                 for k in ("sdf", "dX", "gdec"):
@@ -326,6 +326,7 @@ def test_engines_carry_their_own_kernel_modes(nl, golden_dir):
         # the selections are different kernels (not a silently ignored argument) that agree to rounding
         assert not np.array_equal(got[(0, 0)]["sdf"], got[(1, 1)]["sdf"]) or not np.array_equal(got[(0, 0)]["gdec"], got[(1, 1)]["gdec"])
         assert np.abs(got[(0, 0)]["sdf"] - got[(1, 1)]["sdf"]).max() < 1e-5 and np.abs(got[(3, 1)]["sdf"] - got[(1, 1)]["sdf"]).max() < 1e-5
+        assert not np.array_equal(got[(4, 1)]["sdf"], got[(3, 1)]["sdf"]) and np.abs(got[(4, 1)]["sdf"] - got[(1, 1)]["sdf"]).max() < 1e-5
     with pytest.raises(ValueError):
         nl["P"].SdfEngine(max_rays=8, gemm_mode=6)
     assert lib.nl_decoder_forward_m(None, None, None, 0, None, 1, 0x0600, None) != 0       # wgrad2 mode 5: rejected
