@@ -54,6 +54,8 @@ def matrix_pipe_model(kernel, gemm_mode, wgrad2_mode, train):
         if gemm_mode in (4, 5):                                 # fp16 pairs: forward 3 or 4 of the four products, dgrad mask x 2 terms, layer 1 all four
             return alg, small - L1, {4: 3, 5: 4}[gemm_mode] * G + 2 * G + 4 * L1
         return alg, small + 2 * G, 0
+    if wgrad2_mode == 2:
+        return FLOPS_PER_SAMPLE_WGRAD2, 0, 2 * G + 4 * L1       # H1 rebuilt as 2x2 fp16 products; mask x fp16 pair
     if wgrad2_mode == 1:
         return FLOPS_PER_SAMPLE_WGRAD2, 0, 3 * G + 9 * L1       # H1 rebuilt as 3x3 bf16 products; mask x 3-term split
     return FLOPS_PER_SAMPLE_WGRAD2, L1 + G, 0
@@ -301,7 +303,10 @@ def parity_check(eng, w, cfg, train_dec, every=8):
                    sdf_max_abs_err=float(np.abs(got["sdf"][idx] - ref_sdf).max()), sdf_mean_abs_err=float(np.abs(got["sdf"][idx] - ref_sdf).mean()),
                    X_max_abs_err=float(np.abs(got["X"][idx] - out["feats"]).max()),
                    dsdf_max_err_rel_to_max=float(np.abs(got["dsdf"][idx] - ref_ds).max() / max(np.abs(ref_ds).max(), 1e-30)),
-                   dX_rel_l2=float(np.linalg.norm(dxe - dxr) / max(np.linalg.norm(dxr), 1e-30)))
+                   dX_rel_l2=float(np.linalg.norm(dxe - dxr) / max(np.linalg.norm(dxr), 1e-30)),
+                   # samples whose dX row is off by more than 1e-3 of the largest entry: ReLU flips (a hidden unit whose pre-activation is ~1e-8 lands on
+                   # either side of zero under another summation order), counted so that the norm bar is not mistaken for an element-wise one
+                   dX_samples_off=float((np.abs(dxe - dxr).max(1) > 1e-3 * max(np.abs(dxr).max(), 1e-30)).mean()))
         res["ok"] = bool(dirs_equal and hits_equal and res["sdf_max_abs_err"] < 1e-4 and res["dsdf_max_err_rel_to_max"] < 1e-3 and res["dX_rel_l2"] < 1e-3)
     else:
         res["ok"] = False
@@ -886,7 +891,7 @@ def main():
     exact_leg = None
     if not (shard or args.no_steady_state) and _lib.lib().nl_decoder_get_gemm_mode() in (4, 5):
         km0 = eng.kernel_modes
-        eng.kernel_modes = _lib.kernel_modes(3, None)
+        eng.kernel_modes = _lib.kernel_modes(3, 1)
         for _ in range(3):
             step()
         barrier(); t1 = time.perf_counter()
@@ -959,7 +964,7 @@ def main():
                                "products, dX / dW1 (K=16) on the fp32 pipe (157.3 TF)" if gm >= 4 else
                                f"256-deep GEMMs as bf16 three-term splits ({ {1: 9, 3: 8, 2: 6}.get(gm, 9)} of 9 forward + 3 dgrad MFMAs per fp32 product, 2500 TF pipe), "
                                "layer-1 forward as nine bf16 products too, dX / dW1 (K=16) on the fp32 pipe (157.3 TF)" if gm >= 1 else "all GEMMs on the fp32 pipe (157.3 TF)")),
-              "second_kernel": (roofline_entry("k_decoder_wgrad2_x" if wm == 1 else "k_decoder_wgrad2", "wgrad2", wg_ms, P_local, gm, wm, True)
+              "second_kernel": (roofline_entry({1: "k_decoder_wgrad2_x<bf16 x3>", 2: "k_decoder_wgrad2_x<fp16 pair>"}.get(wm, "k_decoder_wgrad2"), "wgrad2", wg_ms, P_local, gm, wm, True)
                                 if train_dec else None)}
         out = {
             "metric": "LiDAR rays/sec per SDF iter (64x2048 scan)",

@@ -223,7 +223,7 @@ def lib():
             L.nl_field_set_one_round(int(os.environ["NL_FIELD_ONE_ROUND"]))
         if os.environ.get("NL_WGRAD2_MODE"):                # A/B switch for measurements (default: the library's own default)
             if L.nl_decoder_set_wgrad2_mode(int(os.environ["NL_WGRAD2_MODE"])) != 0:
-                raise NerfLoamHipError("NL_WGRAD2_MODE must be 0 or 1")
+                raise NerfLoamHipError("NL_WGRAD2_MODE must be 0, 1 or 2")
         _lib = L
     return _lib
 
@@ -251,8 +251,8 @@ def kernel_modes(gemm_mode=None, wgrad2_mode=None):
     default (NL_GEMM_MODE / NL_WGRAD2_MODE, nl_decoder_set_*_mode)"""
     g = -1 if gemm_mode is None else int(gemm_mode)
     w = -1 if wgrad2_mode is None else int(wgrad2_mode)
-    if not (-1 <= g <= 5 and -1 <= w <= 1):
-        raise ValueError(f"gemm_mode {gemm_mode} / wgrad2_mode {wgrad2_mode}: 0..5 / 0..1 or None")
+    if not (-1 <= g <= 5 and -1 <= w <= 2):
+        raise ValueError(f"gemm_mode {gemm_mode} / wgrad2_mode {wgrad2_mode}: 0..5 / 0..2 or None")
     return ((g + 1) & 0xFF) | (((w + 1) & 0xFF) << 8)
 
 

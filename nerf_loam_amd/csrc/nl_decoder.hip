@@ -557,28 +557,37 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 
     // persistent weight-gradient accumulators (dW2 lives in k_decoder_wgrad2)
     f32x4 accW1[4];
-    float aW3 = 0.f, aB2 = 0.f, aB1 = 0.f, aB3 = 0.f;
+    float aW3 = 0.f, aB2 = 0.f, aB1 = 0.f, aB3 = 0.f, dsMax = 0.f;
     double lossFs = 0.0, lossSdf = 0.0;
     if (TRAIN) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) accW1[t][r] = 0.f;
     }
-    // software prefetch of the next tile's inputs: the X slice (2 floats per thread) and the loss inputs of row `lane`
-    // (every wave keeps its own copy: the loss gradient is recomputed per wave, which removes a workgroup barrier)
+    // software prefetch of the next tiles' inputs: the X slice (2 floats per thread) and the loss inputs of row `lane`
+    // (every wave keeps its own copy: the loss gradient is recomputed per wave, which removes a workgroup barrier).  The loss inputs are a
+    // two-level chain - sample -> its ray -> the ray's cos / range - and a load that waits for its address stalls the wave for a memory
+    // latency at the end of every tile (round 5: two such waits per tile in front of the tile's last barrier).  So the chain is spread over
+    // two tiles: a tile issues the RAY id of the tile three ahead and, with the id fetched a tile ago, the depth / cos / range loads of the
+    // tile two ahead; the product depth * cos is formed where the values are consumed, a whole tile after their loads were issued.
     const int xe = tid * 2, xi = xe >> 4, xc = xe & 15;
     float2 xv = make_float2(0.f, 0.f);
-    float pz = 0.f, pd = 0.f;
-    auto prefetch = [&](int tile) {
+    float pdep = 0.f, pcos = 0.f, pd = 0.f;
+    int pray = -1;
+    auto ray_of = [&](int tile) {
         const int row0 = tile * DEC_M;
-        xv = make_float2(0.f, 0.f); pz = 0.f; pd = 0.f;
+        return (tile < ntiles && row0 + lane < P) ? a.s_ray[row0 + lane] : -1;
+    };
+    auto prefetch_ray = [&](int tile) { pray = ray_of(tile); };
+    auto prefetch = [&](int tile) {                       // `pray` holds the ray id of this tile's row (prefetch_ray, a tile earlier)
+        const int row0 = tile * DEC_M;
+        xv = make_float2(0.f, 0.f); pdep = 0.f; pcos = 0.f; pd = 0.f;
         if (tile < ntiles) {
             if (row0 + xi < P) xv = *reinterpret_cast<const float2*>(a.X + (size_t)(row0 + xi) * NL_C + xc);
-            if (row0 + lane < P) {
-                const int ray = a.s_ray[row0 + lane];
-                pz = a.s_depth[row0 + lane] * a.cos_gt[ray]; pd = a.gt_dist[ray];
-            }
+            if (pray >= 0) { pdep = a.s_depth[row0 + lane]; pcos = a.cos_gt[pray]; pd = a.gt_dist[pray]; }
         }
     };
+    const int pray_second = ray_of(blockIdx.x + gridDim.x);       // (the first two tiles' ray ids leave together: one latency, not two)
+    prefetch_ray(blockIdx.x);
     prefetch(blockIdx.x);
     // (W1 -> LDS under the first tile's input loads: the loss inputs are a two-level dependent chain; at the live shapes a workgroup
     //  sees two tiles in all and the kernel's start is on the critical path of the step)
@@ -614,8 +623,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint4*>(ldsb + XG_W1X_OFF + ((w * 3 + pl) * 64 + lane) * 16) = wq[pl];
     }
     stage_x(lds + S_X);                                  // phase A of the first tile: X -> LDS buffer 0
-    float cz = pz, cd = pd;
+    float cz = pdep * pcos, cd = pd;
+    pray = pray_second;
     prefetch(blockIdx.x + gridDim.x);
+    prefetch_ray(blockIdx.x + 2 * gridDim.x);
     __syncthreads();
 
     int tile_no = 0;
@@ -726,7 +737,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
                 }
             }
             sdS[lane] = ds;
-            if (TRAIN && w == 0) aB3 += ds;
+            if (TRAIN && w == 0) { aB3 += ds; dsMax = fmaxf(dsMax, fabsf(ds)); }
             __builtin_amdgcn_wave_barrier();                    // same-wave LDS write -> read: in order, keep the compiler from reordering
         }
         DBG_STAMP(5);
@@ -872,8 +883,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         // ---------------- A (next tile): X -> the other LDS buffer; issue the loads of the tile after it ----------------
         {
             stage_x(lds + S_X + ((tile_no + 1) & 1) * (DEC_M * LDX));
-            cz = pz; cd = pd;
+            cz = pdep * pcos; cd = pd;
             prefetch(tile + 2 * gridDim.x);
+            prefetch_ray(tile + 3 * gridDim.x);
         }
         nl_lds_barrier();
         DBG_STAMP(10);
@@ -902,8 +914,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         if (lh == 0) { base[NL_OFF_W3 + col] = aW3; base[NL_OFF_B2 + col] = aB2; base[NL_OFF_B1 + col] = F16 ? aB1 * DHS : aB1; }
         if (tid < 64) {
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) aB3 += __shfl_xor(aB3, off);
-            if (tid == 0) base[NL_OFF_B3] = aB3;
+            for (int off = 32; off > 0; off >>= 1) { aB3 += __shfl_xor(aB3, off); dsMax = fmaxf(dsMax, __shfl_xor(dsMax, off)); }
+            if (tid == 0) {
+                base[NL_OFF_B3] = aB3;
+                // max |dL/dsdf| of the launch (non-negative floats order like their bit patterns): the scale of the fp16-pair dW2 kernel
+                if (dsMax > 0.f) atomicMax(const_cast<unsigned*>(&a.ls->ds_max_bits), __float_as_uint(dsMax));
+            }
         }
     }
 }
@@ -1026,6 +1042,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2(const NlLossS
 #define WX_TOTAL (WX_OFF_DS + 2 * DEC_M * 4)
 
 
+template <bool F16>                                     // F16 (wgrad2 mode 2): the fp32 operand as an fp16 PAIR instead of three bf16 terms - see below
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLossScalars* __restrict__ lsp, const float* __restrict__ X,
                                                                       const float* __restrict__ params, const float* __restrict__ dsdf,
                                                                       const unsigned* __restrict__ relu2_mask, float* __restrict__ partials)
@@ -1045,14 +1062,30 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
     // layer 1 on the bf16 matrix cores, exact products like the 256-deep GEMMs: X and W1 as three bf16 terms each, nine K = 16
     // MFMAs per half tile (288 pipe cycles) instead of eight fp32 ones (512).  B fragments (W1 row of this lane's column, k = 8 lh + e)
     // stay in registers for the whole kernel.
+    // F16: the operands as fp16 pairs, like k_decoder<.., 3 / 4>: H1 * 2^4 from the same four layer-1 products in the same order (the H1 the
+    // forward pass saw, bit for bit), and v = (dsdf_i * sigma / 16) * (16 H1[i][k]) split in two.  sigma is a power of two that puts the
+    // launch's largest |dsdf| in [8, 16) (NlLossScalars.ds_max_bits, raised by k_decoder): with H1 < 4094 no v leaves fp16's range, the
+    // samples that carry the gradient sit high in it, and what the low term of a small contribution loses is absolute - 2^-25 against
+    // summands of order one.  mask x 2 planes: 64 matrix instructions per tile and wave against 96.
+    constexpr int NPL = F16 ? 2 : 3;
     uint4 w1p[3];
-    l1_w1_fragments(params, col, lh, w1p);
-    if (tid < 256) {                                     // byte -> 8 bf16 (1.0 where the bit is set)
+    if (F16) { uint4 w1h[2]; l1_w1_fragments_f16(params, col, lh, w1h); w1p[0] = w1h[0]; w1p[1] = w1h[1]; }
+    else l1_w1_fragments(params, col, lh, w1p);
+    float ds_scale = 1.0f, out_scale = 1.0f;
+    if (F16) {
+        const float dsmax = __uint_as_float(lsp->ds_max_bits);
+        int e = 0;
+        if (dsmax > 0.f) { (void)frexpf(dsmax, &e); e = e < -100 ? -100 : e; }      // dsmax = m 2^e, m in [0.5, 1)
+        ds_scale = ldexpf(1.0f, 4 - e) * (1.0f / NL_F16_SH);     // dsdf * ds_scale * (16 H1) = v * sigma, sigma = 2^(4 - e)
+        out_scale = ldexpf(1.0f, e - 4);
+    }
+    if (tid < 256) {                                     // byte -> 8 bf16 / fp16 (1.0 where the bit is set)
+        constexpr unsigned ONE = F16 ? 0x3C00u : 0x3F80u;
         uint4 e;
-        e.x = ((tid & 1) ? 0x3F80u : 0u) | ((tid & 2) ? 0x3F800000u : 0u);
-        e.y = ((tid & 4) ? 0x3F80u : 0u) | ((tid & 8) ? 0x3F800000u : 0u);
-        e.z = ((tid & 16) ? 0x3F80u : 0u) | ((tid & 32) ? 0x3F800000u : 0u);
-        e.w = ((tid & 64) ? 0x3F80u : 0u) | ((tid & 128) ? 0x3F800000u : 0u);
+        e.x = ((tid & 1) ? ONE : 0u) | ((tid & 2) ? ONE << 16 : 0u);
+        e.y = ((tid & 4) ? ONE : 0u) | ((tid & 8) ? ONE << 16 : 0u);
+        e.z = ((tid & 16) ? ONE : 0u) | ((tid & 32) ? ONE << 16 : 0u);
+        e.w = ((tid & 64) ? ONE : 0u) | ((tid & 128) ? ONE << 16 : 0u);
         sLut[tid] = e;
     }
     f32x16 acc[2][4];
@@ -1077,8 +1110,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
     // inputs of a tile -> LDS buffers of parity `pb` (X tile, dsdf and mask words are double-buffered by tile parity)
     auto stage_inputs = [&](int pb) {
         unsigned* sx = reinterpret_cast<unsigned*>(sXp + pb * (3 * WXX_PLANE) + xi * WXX_STRIDE + 2 * xc);
-        split3_pair(xv.x, xv.y, &sx[0], &sx[WXX_PLANE / 4], &sx[2 * WXX_PLANE / 4]);
-        if (tid < DEC_M) sdS[pb * DEC_M + tid] = pds;
+        if (F16) split2_pair_f16(sat_f16(xv.x * NL_F16_SX), sat_f16(xv.y * NL_F16_SX), &sx[0], &sx[WXX_PLANE / 4]);
+        else split3_pair(xv.x, xv.y, &sx[0], &sx[WXX_PLANE / 4], &sx[2 * WXX_PLANE / 4]);
+        if (tid < DEC_M) sdS[pb * DEC_M + tid] = F16 ? pds * ds_scale : pds;
         sMask[pb * DEC_THREADS + tid] = pmk;
     };
     // producer of one 32-sample half tile: v = dsdf_i * relu(X W1^T + b1)[i][col], split into 3 bf16 planes, k-slot order
@@ -1089,31 +1123,40 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
 #pragma unroll
         for (int r = 0; r < 16; ++r) c0[r] = 0.f;
         {
-            bf16x8 xa[3];
+            uint4 xa[3];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) xa[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sx + pl * WXX_PLANE));
+            for (int pl = 0; pl < NPL; ++pl) xa[pl] = *reinterpret_cast<const uint4*>(sx + pl * WXX_PLANE);
 #pragma unroll
-            for (int pa = 2; pa >= 0; --pa)                  // smallest terms first
+            for (int pa = NPL - 1; pa >= 0; --pa)            // smallest terms first
 #pragma unroll
-                for (int pq = 2; pq >= 0; --pq) c0 = MFMA_BF16(xa[pa], __builtin_bit_cast(bf16x8, w1p[pq]), c0);
+                for (int pq = NPL - 1; pq >= 0; --pq) c0 = mma16<F16>(xa[pa], w1p[pq], c0);
         }
         unsigned hi[8], mid[8], lo[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const float h0 = fmaxf(c0[2 * q] + b1c, 0.f), h1 = fmaxf(c0[2 * q + 1] + b1c, 0.f);
-            const float v0 = h0 * ds[D32_RR(2 * q)], v1 = h1 * ds[D32_RR(2 * q + 1)];
-            hi[q] = pack_hi16(v0, v1);
-            const float r0 = v0 - trunc_bf16(v0), r1 = v1 - trunc_bf16(v1);
-            mid[q] = pack_hi16(r0, r1);
-            const float s0 = r0 - trunc_bf16(r0), s1 = r1 - trunc_bf16(r1);
-            lo[q] = pack_hi16(s0, s1);
+            if (F16) {
+                constexpr float S1 = NL_F16_SH / (NL_F16_SX * NL_F16_SW1);
+                const float h0 = __builtin_amdgcn_fmed3f(fmaf(c0[2 * q], S1, b1c * NL_F16_SH), 0.f, NL_F16_MAX);
+                const float h1 = __builtin_amdgcn_fmed3f(fmaf(c0[2 * q + 1], S1, b1c * NL_F16_SH), 0.f, NL_F16_MAX);
+                split2_pair_f16(h0 * ds[D32_RR(2 * q)], h1 * ds[D32_RR(2 * q + 1)], &hi[q], &lo[q]);
+            } else {
+                const float h0 = fmaxf(c0[2 * q] + b1c, 0.f), h1 = fmaxf(c0[2 * q + 1] + b1c, 0.f);
+                const float v0 = h0 * ds[D32_RR(2 * q)], v1 = h1 * ds[D32_RR(2 * q + 1)];
+                hi[q] = pack_hi16(v0, v1);
+                const float r0 = v0 - trunc_bf16(v0), r1 = v1 - trunc_bf16(v1);
+                mid[q] = pack_hi16(r0, r1);
+                const float s0 = r0 - trunc_bf16(r0), s1 = r1 - trunc_bf16(r1);
+                lo[q] = pack_hi16(s0, s1);
+            }
         }
         unsigned char* dst = sB + opaque(col * WX_STRIDE + 32 * lh + 64 * sub);
         uint4* d0 = reinterpret_cast<uint4*>(dst);
         d0[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]); d0[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
-        uint4* d1 = reinterpret_cast<uint4*>(dst + WX_PLANE);
-        d1[0] = make_uint4(mid[0], mid[1], mid[2], mid[3]); d1[1] = make_uint4(mid[4], mid[5], mid[6], mid[7]);
-        uint4* d2 = reinterpret_cast<uint4*>(dst + 2 * WX_PLANE);
+        if (!F16) {
+            uint4* d1 = reinterpret_cast<uint4*>(dst + WX_PLANE);
+            d1[0] = make_uint4(mid[0], mid[1], mid[2], mid[3]); d1[1] = make_uint4(mid[4], mid[5], mid[6], mid[7]);
+        }
+        uint4* d2 = reinterpret_cast<uint4*>(dst + (NPL - 1) * WX_PLANE);
         d2[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]); d2[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
     };
     // consumer of one half tile: 2 k-steps of 16 slots x 3 planes x 4 column tiles, each B fragment feeding both row tiles.
@@ -1126,20 +1169,21 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
         const unsigned char* bsrc = sB + opaque((128 * wk + l31) * WX_STRIDE + 16 * lh + 64 * sub);
         uint4 bfr[2][4];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) bfr[0][kt] = *reinterpret_cast<const uint4*>(bsrc + 32 * kt * WX_STRIDE);
-        bf16x8 af[2];
+        for (int kt = 0; kt < 4; ++kt) bfr[0][kt] = *reinterpret_cast<const uint4*>(bsrc + (F16 ? WX_PLANE : 0) + 32 * kt * WX_STRIDE);
+        // (plane order of a k-step: hi, mid, lo with the bf16 terms; lo, hi with the fp16 pair)
+        uint4 af[2];
 #pragma unroll
-        for (int gq = 0; gq < 6; ++gq) {
-            const int s2 = gq / 3, p3 = gq % 3;          // k-step inside the half tile: producer lane half s2
+        for (int gq = 0; gq < 2 * NPL; ++gq) {
+            const int s2 = gq / NPL, p3 = gq % NPL;      // k-step inside the half tile: producer lane half s2
             if (p3 == 0) {
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt) {
                     const unsigned byte = (mwd[jt][s2] >> (16 * sub + 8 * lh)) & 0xFFu;
-                    af[jt] = __builtin_bit_cast(bf16x8, sLut[byte]);
+                    af[jt] = sLut[byte];
                 }
             }
-            if (gq + 1 < 6) {
-                const int sn = (gq + 1) / 3, pn = (gq + 1) % 3;
+            if (gq + 1 < 2 * NPL) {
+                const int sn = (gq + 1) / NPL, pn = F16 ? 1 - (gq + 1) % NPL : (gq + 1) % NPL;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
                     bfr[(gq + 1) & 1][kt] = *reinterpret_cast<const uint4*>(bsrc + pn * WX_PLANE + 32 * kt * WX_STRIDE + 32 * sn);
@@ -1147,8 +1191,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const bf16x8 bf = __builtin_bit_cast(bf16x8, bfr[gq & 1][kt]);
-                acc[0][kt] = MFMA_BF16(af[0], bf, acc[0][kt]); acc[1][kt] = MFMA_BF16(af[1], bf, acc[1][kt]);
+                acc[0][kt] = mma16<F16>(af[0], bfr[gq & 1][kt], acc[0][kt]); acc[1][kt] = mma16<F16>(af[1], bfr[gq & 1][kt], acc[1][kt]);
             }
         }
     };
@@ -1181,7 +1224,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_wgrad2_x(const NlLos
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = 64 * wj + 32 * jt + d32_row(r, lh);
-            const float w3j = params[NL_OFF_W3 + j];
+            const float w3j = F16 ? params[NL_OFF_W3 + j] * out_scale : params[NL_OFF_W3 + j];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) base[NL_OFF_W2 + j * NL_W + 128 * wk + 32 * kt + l31] = w3j * acc[jt][kt][r];
         }
@@ -1358,7 +1401,7 @@ int nl_decoder_set_debug_buffer(void* dbg) { g_dec_dbg = (long long*)dbg; return
 
 /* dW2 kernel: 0 = fp32 matrix cores, 1 = bf16 matrix cores on the exact {0,1}-mask x 3-term-split formulation (default).
  * Same arithmetic class (exact products, fp32 accumulation); selectable for A/B measurements and cross-checks. */
-int nl_decoder_set_wgrad2_mode(int mode) { if (mode < 0 || mode > 1) return NL_ERR_INVALID_ARG; g_wgrad2_mode = mode; return NL_OK; }
+int nl_decoder_set_wgrad2_mode(int mode) { if (mode < 0 || mode > 2) return NL_ERR_INVALID_ARG; g_wgrad2_mode = mode; return NL_OK; }
 int nl_decoder_get_wgrad2_mode(void) { return g_wgrad2_mode; }
 /* the two 256-deep GEMMs of the fused decoder kernels (forward H1 W2^T, dgrad dH2 W2): 0 = fp32 matrix cores; 1, 2, 3 = bf16
  * matrix cores on exact-product formulations: forward = both operands split into three bf16 terms, dgrad = {0,1} ReLU mask x
@@ -1375,7 +1418,7 @@ struct DecModes { int gemm, wgrad2; };
 static bool resolve_modes(int kernel_modes, DecModes* m)
 {
     const int g = (kernel_modes & 0xFF) - 1, w = ((kernel_modes >> 8) & 0xFF) - 1;
-    if (g > 5 || w > 1 || (kernel_modes >> 16) != 0) return false;
+    if (g > 5 || w > 2 || (kernel_modes >> 16) != 0) return false;
     m->gemm = g < 0 ? g_gemm_mode.load(std::memory_order_relaxed) : g;
     m->wgrad2 = w < 0 ? g_wgrad2_mode.load(std::memory_order_relaxed) : w;
     return true;
@@ -1446,8 +1489,11 @@ int nl_decoder_wgrad2_m(const void* loss_scalars, const float* X, const float* p
     DecModes km;
     if (!resolve_modes(kernel_modes, &km)) return NL_ERR_INVALID_ARG;
     if (!loss_scalars || !X || !params || !dsdf || !relu2_mask || !partials || nslabs <= 0) return NL_ERR_INVALID_ARG;
-    if (km.wgrad2 == 1)
-        hipLaunchKernelGGL(k_decoder_wgrad2_x, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,
+    if (km.wgrad2 == 2)
+        hipLaunchKernelGGL(k_decoder_wgrad2_x<true>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,
+                           params, dsdf, relu2_mask, partials);
+    else if (km.wgrad2 == 1)
+        hipLaunchKernelGGL(k_decoder_wgrad2_x<false>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,
                            params, dsdf, relu2_mask, partials);
     else
         hipLaunchKernelGGL(k_decoder_wgrad2, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,

@@ -514,7 +514,8 @@ struct NlLossScalars {          // filled once per iteration from the global cou
     float inv_n;                // 1 / (R * S_max)
     float fs_weight, sdf_weight, tau, max_depth;
     int   R, S_max, P;          // hit rays, max samples per ray, valid samples
-    int   pad;
+    unsigned ds_max_bits;       // bit pattern of max |dL/dsdf| over the iteration's samples: zeroed by the finalize, raised by the decoder kernel (train),
+                                // read by the fp16-pair dW2 kernel to place dsdf_i * H1[i][k] in fp16's range
 };
 NL_HD void nl_loss_masks(float z, float d, float tau, float max_depth, bool* front, bool* sdfm) {
     const bool f = z < (d - tau);

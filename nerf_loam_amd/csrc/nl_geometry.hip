@@ -1423,7 +1423,7 @@ __device__ __forceinline__ void loss_finalize_one(int* __restrict__ counters, Nl
     o.two_over_n = 2.0f / n;
     o.inv_n = 1.0f / n;
     o.fs_weight = fs_weight; o.sdf_weight = sdf_weight; o.tau = tau; o.max_depth = max_depth;
-    o.R = R; o.S_max = S; o.P = counters[NLC_P]; o.pad = 0;
+    o.R = R; o.S_max = S; o.P = counters[NLC_P]; o.ds_max_bits = 0u;
     if (counters[NLC_P] > capacity) { counters[NLC_OVERFLOW] = 1; o.P = capacity; }
     *ls = o;
 }

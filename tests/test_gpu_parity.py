@@ -21,6 +21,7 @@ ITERATION_CASES = ([(c, md) for md in (3, 4) for c in ["map_1f_1it", "map_2f_2it
                    + [("map_1f_1it", 0), ("map_1f_1it", 1), ("map_kitti_1f_1it", 1), ("map_2f_2it_frozen", 0), ("map_1f_1it", 2), ("map_1f_1it", 5), ("map_ncd_1f_1it", 5)])
 # sdf bars per mode (max |sdf - oracle|; the north_star bar is 1e-4).  Measured on MI355X (round 3): 2e-8 .. 3e-8 in every mode on the
 # golden scenes (6e-7 on the full scan); against the reference goldens 0.9e-6 .. 1.8e-6 (the oracle's own distance from them)
+WGRAD2_OF = {0: 0, 1: 1, 2: 1, 3: 1, 4: 2, 5: 2}
 SDF_TOL = {0: 5e-7, 1: 5e-7, 3: 5e-7, 2: 5e-6, 4: 5e-7, 5: 5e-7}
 _METRICS = {}
 
@@ -221,7 +222,8 @@ def backward_mode(nl, request):
     GEMM (prepared in round 1 without GPU time left: its cases run only with NL_TEST_GEMM_MODE2=1 until it has been verified)"""
     lib = nl["L"].lib()
     old = lib.nl_decoder_get_wgrad2_mode(), lib.nl_decoder_get_gemm_mode()
-    assert lib.nl_decoder_set_wgrad2_mode(min(request.param, 1)) == 0 and lib.nl_decoder_set_gemm_mode(request.param) == 0
+    # (dW2 kernel: fp32 with gemm mode 0, the three-term bf16 split with the bf16 modes, the fp16 pair with the fp16-pair modes)
+    assert lib.nl_decoder_set_wgrad2_mode(WGRAD2_OF[request.param]) == 0 and lib.nl_decoder_set_gemm_mode(request.param) == 0
     yield request.param
     lib.nl_decoder_set_wgrad2_mode(old[0]); lib.nl_decoder_set_gemm_mode(old[1])
 
@@ -308,7 +310,7 @@ def test_engines_carry_their_own_kernel_modes(nl, golden_dir):
 
     for one_call in (False, True):
         got = {}
-        for gemm, wg in ((0, 0), (1, 1), (3, 1), (4, 1), (0, 0), (1, 1), (4, 1)):              # alternating selections, process default untouched
+        for gemm, wg in ((0, 0), (1, 1), (3, 1), (4, 2), (0, 0), (1, 1), (4, 2), (4, 1)):              # alternating selections, process default untouched
             r = run(one_call, gemm, wg)
             assert (lib.nl_decoder_get_gemm_mode(), lib.nl_decoder_get_wgrad2_mode()) == default
             if (gemm, wg) in got:
@@ -316,7 +318,7 @@ def test_engines_carry_their_own_kernel_modes(nl, golden_dir):
                     assert np.array_equal(got[(gemm, wg)][k], r[k]), (one_call, gemm, k)
             got[(gemm, wg)] = r
         try:
-            for gemm, wg in ((0, 0), (1, 1), (3, 1), (4, 1)):                           # the same selection as the process default: same bits
+            for gemm, wg in ((0, 0), (1, 1), (3, 1), (4, 2)):                           # the same selection as the process default: same bits
                 assert lib.nl_decoder_set_gemm_mode(gemm) == 0 and lib.nl_decoder_set_wgrad2_mode(wg) == 0
                 r = run(one_call)
                 for k in ("sdf", "dX", "gdec"):
@@ -326,7 +328,10 @@ def test_engines_carry_their_own_kernel_modes(nl, golden_dir):
         # the selections are different kernels (not a silently ignored argument) that agree to rounding
         assert not np.array_equal(got[(0, 0)]["sdf"], got[(1, 1)]["sdf"]) or not np.array_equal(got[(0, 0)]["gdec"], got[(1, 1)]["gdec"])
         assert np.abs(got[(0, 0)]["sdf"] - got[(1, 1)]["sdf"]).max() < 1e-5 and np.abs(got[(3, 1)]["sdf"] - got[(1, 1)]["sdf"]).max() < 1e-5
-        assert not np.array_equal(got[(4, 1)]["sdf"], got[(3, 1)]["sdf"]) and np.abs(got[(4, 1)]["sdf"] - got[(1, 1)]["sdf"]).max() < 1e-5
+        assert not np.array_equal(got[(4, 2)]["sdf"], got[(3, 1)]["sdf"]) and np.abs(got[(4, 2)]["sdf"] - got[(1, 1)]["sdf"]).max() < 1e-5
+        assert np.array_equal(got[(4, 2)]["sdf"], got[(4, 1)]["sdf"]) and not np.array_equal(got[(4, 2)]["gdec"], got[(4, 1)]["gdec"])     # the dW2 kernel alone differs
+        w2 = slice(nl["L"].OFF_W2, nl["L"].OFF_B2)
+        assert np.abs(got[(4, 2)]["gdec"][w2] - got[(4, 1)]["gdec"][w2]).max() <= 2e-5 * np.abs(got[(4, 1)]["gdec"][w2]).max()
     with pytest.raises(ValueError):
         nl["P"].SdfEngine(max_rays=8, gemm_mode=6)
     assert lib.nl_decoder_forward_m(None, None, None, 0, None, 1, 0x0600, None) != 0       # wgrad2 mode 5: rejected
@@ -531,7 +536,7 @@ def test_full_scan_invariants(nl):
     old = lib.nl_decoder_get_wgrad2_mode(), lib.nl_decoder_get_gemm_mode()
     res = []
     for mode in (0, 1, 3, 4, 5):
-        assert lib.nl_decoder_set_wgrad2_mode(min(mode, 1)) == 0 and lib.nl_decoder_set_gemm_mode(mode) == 0
+        assert lib.nl_decoder_set_wgrad2_mode(WGRAD2_OF[mode]) == 0 and lib.nl_decoder_set_gemm_mode(mode) == 0
         eng.g_emb.zero_(); eng.g_pose.zero_()
         eng.forward_backward(m, dec, cfg)
         res.append((P.DecoderDevice.split(dec.grad.cpu().numpy()), eng.dX[:Pn].cpu().numpy().astype(np.float64), eng.sdf[:Pn].cpu().numpy()))
