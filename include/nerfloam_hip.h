@@ -205,7 +205,7 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
                        float* sdf, float* dsdf, float* dX, float* partials, unsigned* relu2_mask, int nslabs, int train_decoder,
                        int* counters, void* stream);
 /* The same four decoder entry points with the kernel selection passed per call instead of taken from the process-wide defaults
- * (4, 1; include/nerfloam_hip_debug.h holds the A/B setters): kernel_modes = NL_KERNEL_MODES(gemm_mode, wgrad2_mode), either
+ * (4, 2; include/nerfloam_hip_debug.h holds the A/B setters): kernel_modes = NL_KERNEL_MODES(gemm_mode, wgrad2_mode), either
  * mode -1 (or kernel_modes == 0) = the process default.  NlIterDesc.kernel_modes carries the same word for nl_iteration. */
 #define NL_KERNEL_MODES(gemm_mode, wgrad2_mode) ((((gemm_mode) + 1) & 0xFF) | ((((wgrad2_mode) + 1) & 0xFF) << 8))
 int nl_decoder_fwd_bwd_m(const void* loss_scalars, const float* X, const float* params, const float* W2T,
@@ -251,10 +251,12 @@ int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream);
  *     6 + 4 matrix instructions per k-step against 16 + 6 of mode 3.  Measured against the oracle and the reference-generated goldens the modes 1, 3,
  *     4, 5 are indistinguishable (sdf 3e-8, the same gradient bars).  Operands saturate instead of overflowing fp16:
  *     |X| < 1023, |W1| < 256, H1 < 4094, |W2| < 256, |w3_j W2[j][k]| < 16 - far outside what the decoder of an SDF map holds.
- * dW2 kernel (wgrad2_mode): 0 = fp32 matrix cores, 1 = bf16 matrix cores on dW2[j][k] = w3_j * sum_i m(i,j) * (dsdf_i * H1[i][k]) with the
- * {0,1} mask m as A operand and the fp32 B operand split into three bf16 terms (exact products, fp32 accumulation; default).
+ * dW2 kernel (wgrad2_mode): 0 = fp32 matrix cores; 1, 2 = 16-bit matrix cores on dW2[j][k] = w3_j * sum_i m(i,j) * (dsdf_i * H1[i][k]) with the
+ * {0,1} mask m as A operand and the fp32 B operand v split: 1 = into three bf16 terms (exact products, fp32 accumulation), 2 = into an fp16
+ * pair of v * sigma, sigma the power of two that puts the launch's largest |dsdf| in [8, 16) (nl_decoder_fwd_bwd leaves that maximum in the
+ * loss-scalar block; THE DEFAULT: 64 matrix instructions per 64-sample tile and wave against 96).
  * The selection is a PER-CALL argument (kernel_modes of the *_m entry points, NlIterDesc.kernel_modes); the entry points without it use the
- * library defaults (4, 1).  Changing those defaults process-wide is a test / A-B aid: include/nerfloam_hip_debug.h. */
+ * library defaults (4, 2).  Changing those defaults process-wide is a test / A-B aid: include/nerfloam_hip_debug.h. */
 
 /* backward of get_features: embedding gradient (fp32 accumulation of bf16-rounded contributions, the
  * CUDA embedding_dense_backward semantics) and pose-gradient partials g_pose[F,12] = (dL/dt, dL/dR), accumulated in fp64

@@ -1392,7 +1392,7 @@ static std::atomic<long long*> g_dec_dbg{nullptr};
 static std::atomic<int> g_gemm_mode{4};             // 0: fp32 MFMA GEMMs; bf16 MFMA on the exact-product formulations (gemm_x9 / gemm_mask_x) with
                                          // 1: all nine forward products (exact), 3: eight (without lo x lo), 2: six; fp16 pairs (gemm_f16) with
                                          // 4: three of the four forward products (THE DEFAULT), 5: all four
-static std::atomic<int> g_wgrad2_mode{1};           // 0: fp32 MFMA (k_decoder_wgrad2), 1: exact 0/1-mask x 3-term bf16 split (k_decoder_wgrad2_x)
+static std::atomic<int> g_wgrad2_mode{2};           // 0: fp32 MFMA (k_decoder_wgrad2), 1: exact 0/1-mask x 3-term bf16 split, 2: 0/1-mask x fp16 pair (k_decoder_wgrad2_x; the default)
 
 extern "C" {
 
