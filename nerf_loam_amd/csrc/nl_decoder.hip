@@ -41,6 +41,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define MFMA16_F16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
 // LDS carve (floats)
 #define S_H1 0
@@ -436,6 +437,19 @@ __device__ __forceinline__ float dpp_swap1(float v)
 }
 __device__ __forceinline__ unsigned dpp_swap1u(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
 
+// maximum of a non-negative value over the wave: four DPP steps inside the 16-lane rows, then the four rows through scalar registers
+// (no LDS round trips: __shfl_xor is a ds_bpermute, ~100 cycles each on a latency chain)
+__device__ __forceinline__ float wave_max_nonneg(float v)
+{
+    int x = __float_as_int(v);                           // non-negative floats order like their bit patterns
+    x = max(x, __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true));        // quad_perm [1,0,3,2]
+    x = max(x, __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true));        // quad_perm [2,3,0,1]
+    x = max(x, __builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true));       // row_half_mirror
+    x = max(x, __builtin_amdgcn_mov_dpp(x, 0x140, 0xF, 0xF, true));       // row_mirror
+    const int m = max(max(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 16)), max(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)));
+    return __int_as_float(m);
+}
+
 // H1 = relu(pre + b1) for this lane's column / 32 rows -> three bf16 planes in LDS (A operand of gemm_x9); returns the
 // lane's 32 ReLU bits (bit r: row d32_row(r, lh), bit 16 + r: row 32 + d32_row(r, lh)) for the dgrad epilogue.
 // Two neighbouring lanes hold neighbouring columns (k, k + 1) of the same rows, and a row of a plane is k-contiguous: the even lane
@@ -539,6 +553,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
     // F16: the dgrad accumulators are 2^12 x dH1 / dsdf (the scale of the W2H planes); dH1 goes through phases H / I with that factor and
     // it is taken out where the results leave (dX store, the dW1 / db1 slab) - powers of two: exact
     constexpr float DHS = F16 ? 1.0f / NL_F16_SG : 1.0f;
+    // F16, phases H / I (round 5): Q[i][k] = [H1 > 0] * (dgrad accumulator) = 2^10 dH1[i][k] / dsdf_i goes on as an fp16 pair -
+    //   dX[i][c]  = dsdf_i 2^-18 * sum_k Q[i][k] (2^8 W1[k][c])               (Q planes in LDS, 16x16x32 matrix instructions, waves 0-3)
+    //   dW1[k][c] += 2^-14 / sigma_t * sum_i Q[i][k] U[i][c],  U = sigma_t dsdf_i * 2^4 X[i][c]   (A fragments = the lane's own accumulator registers, no LDS)
+    //   db1[k]    += 2^-10 / sigma_t * sum_i Q[i][k] U[i][16], U[i][16] = sigma_t dsdf_i          (a 17th column of the same matrix instruction)
+    // sigma_t = the power of two that puts the TILE's largest |dsdf| in [8, 16).  U lives behind the (single-buffered) fp32 X tile.
+    constexpr int U_CHUNK = 17 * 16, U_PLANE = 8 * U_CHUNK;               // bytes: 8 (k-step, lane half) chunks of 17 fragments per plane
+    constexpr int U_OFF = S_X * 4 + DEC_M * LDX * 4;
+    static_assert(2 * U_PLANE <= DEC_M * LDX * 4, "the U planes fit the second X buffer");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5, l15 = lane & 15, lq = lane >> 4;
     const int col = 32 * w + l31;                 // this lane's output column in 32x32 tiles
@@ -557,11 +579,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 
     // persistent weight-gradient accumulators (dW2 lives in k_decoder_wgrad2)
     f32x4 accW1[4];
+    f32x16 accW1h;                                        // F16: this wave's 32 rows of dW1 (lanes 0-15: the channel) and of db1 (lane 16), 2^-14 / 2^-10 taken out per tile
     float aW3 = 0.f, aB2 = 0.f, aB1 = 0.f, aB3 = 0.f, dsMax = 0.f;
     double lossFs = 0.0, lossSdf = 0.0;
     if (TRAIN) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) accW1[t][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW1h[r] = 0.f;
     }
     // software prefetch of the next tiles' inputs: the X slice (2 floats per thread) and the loss inputs of row `lane`
     // (every wave keeps its own copy: the loss gradient is recomputed per wave, which removes a workgroup barrier).  The loss inputs are a
@@ -591,11 +616,25 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
     prefetch(blockIdx.x);
     // (W1 -> LDS under the first tile's input loads: the loss inputs are a two-level dependent chain; at the live shapes a workgroup
     //  sees two tiles in all and the kernel's start is on the critical path of the step)
-    for (int i = tid; i < NL_W * NL_C; i += DEC_THREADS) sW1[i] = a.params[NL_OFF_W1 + i];
     unsigned char* const ldsb = reinterpret_cast<unsigned char*>(lds);
+    if (F16) {
+        // dX's B operand: W1 * 2^8 as fp16-pair fragments of the 16x16x32 matrix instruction, [k-step s(8)][plane(2)][lane(64)][16 B]:
+        // lane (c = lane & 15, q = lane >> 4) holds k = 32 s + 8 q + e (e = 0..7) of channel c
+        const int s_ = tid >> 6, c_ = lane & 15, q_ = lane >> 4;
+        unsigned qh[4], ql[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k_ = 32 * s_ + 8 * q_ + 2 * e;
+            split2_pair_f16(sat_f16(a.params[NL_OFF_W1 + k_ * NL_C + c_] * NL_F16_SW1), sat_f16(a.params[NL_OFF_W1 + (k_ + 1) * NL_C + c_] * NL_F16_SW1), &qh[e], &ql[e]);
+        }
+        uint4* dstw = reinterpret_cast<uint4*>(ldsb + S_W1 * 4 + (s_ * 2 * 64 + lane) * 16);
+        dstw[0] = make_uint4(qh[0], qh[1], qh[2], qh[3]); dstw[64] = make_uint4(ql[0], ql[1], ql[2], ql[3]);
+    } else {
+        for (int i = tid; i < NL_W * NL_C; i += DEC_THREADS) sW1[i] = a.params[NL_OFF_W1 + i];
+    }
     // X tile of the next phase B: fp32 (dW1 of the trainable decoder reads it in phase I) and, in the bf16 mode, three bf16 planes
     auto stage_x = [&](float* sXf) {
-        if (!XG || TRAIN) { sXf[xi * LDX + xc] = xv.x; sXf[xi * LDX + xc + 1] = xv.y; }
+        if (!XG || TRAIN) { sXf[xi * LDX + xc] = xv.x; sXf[xi * LDX + xc + 1] = xv.y; }      // (train: dW1 needs the fp32 values)
         if (F16) {
             unsigned q0, q1;
             split2_pair_f16(sat_f16(xv.x * NL_F16_SX), sat_f16(xv.y * NL_F16_SX), &q0, &q1);
@@ -632,7 +671,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
     int tile_no = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++tile_no) {
         const int row0 = tile * DEC_M;
-        float* sX = lds + S_X + (tile_no & 1) * (DEC_M * LDX);
+        float* sX = lds + S_X + (F16 ? 0 : (tile_no & 1) * (DEC_M * LDX));      // (F16: one fp32 X buffer - it is read in phase E only - the U planes behind it)
         DBG_STAMP(0);
         DBG_STAMP(1);
         // ---------------- B: H1 = relu(X W1^T + b1) ----------------
@@ -741,6 +780,31 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             __builtin_amdgcn_wave_barrier();                    // same-wave LDS write -> read: in order, keep the compiler from reordering
         }
         DBG_STAMP(5);
+        float inv_sigma = 1.0f;                          // F16 train: 1 / sigma_t of this tile
+        if (F16 && TRAIN) {
+            const float mx = wave_max_nonneg(fabsf(sdS[lane]));
+            int e = 0;
+            if (mx > 0.f) { (void)frexpf(mx, &e); e = e < -100 ? -100 : e; }        // mx = m 2^e, m in [0.5, 1): sigma_t = 2^(4 - e)
+            const float sigma = ldexpf(1.0f, 4 - e);
+            inv_sigma = ldexpf(1.0f, e - 4);
+            if (tid < 2 * 8 * 17) {
+                // half a B fragment of dW1's matrix instructions per thread: (k-step t, lane half hh, column c) = 8 sample rows of U, in the order the
+                // A fragments - accumulator registers 8 (t & 1) .. + 7 of sub-tile t >> 1 - hold their rows; thread parity = which four of the eight
+                const int f = tid >> 1, half = tid & 1, t = f / 34, hh = (f / 17) & 1, c = f % 17;
+                const float* xr = sX + opaque(c < NL_C ? c : 0);
+                const int row = 16 * (t & 1) + 4 * hh + 32 * (t >> 1) + 8 * half;       // rows of elements 4 half .. 4 half + 3: consecutive
+                float d[4], u[4];
+#pragma unroll
+                for (int z = 0; z < 4; ++z) { d[z] = sdS[row + z] * sigma; u[z] = xr[(row + z) * LDX]; }
+#pragma unroll
+                for (int z = 0; z < 4; ++z) u[z] = c < NL_C ? sat_f16(d[z] * 16.0f * u[z]) : d[z];
+                unsigned uh[2], ul[2];
+                split2_pair_f16(u[0], u[1], &uh[0], &ul[0]); split2_pair_f16(u[2], u[3], &uh[1], &ul[1]);
+                unsigned char* ud = ldsb + opaque(U_OFF + (t * 2 + hh) * U_CHUNK + c * 16 + 8 * half);
+                *reinterpret_cast<uint2*>(ud) = make_uint2(uh[0], uh[1]);
+                *reinterpret_cast<uint2*>(ud + U_PLANE) = make_uint2(ul[0], ul[1]);
+            }
+        }
         // ---------------- E: dH2 = ds * w3 * [H2 > 0] -> LDS ----------------
         uint4 bqm[MX_RING][3];
         if (F16) gemm_mask_x_prefetch<2>(rsW2H, w, lane, bqm);
@@ -790,6 +854,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             else if (XG)     gemm_mask_x<true>(rsW2X, w, lane, reinterpret_cast<const unsigned char*>(lds), bqm, g0v, g1v);
             else    gemm256(rsW2, (lh * NL_W + col) * 4, sD + l31 * LDH + lh, sD + (32 + l31) * LDH + lh, g0v, g1v);
             DBG_STAMP(7);
+            if constexpr (!F16) {
             const float* dsb = sdS + opaque(4 * lh);
             const float* hb = sH1 + opaque(4 * lh * LDH + col);
 #pragma unroll
@@ -805,9 +870,76 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
                 }
                 if (TRAIN) aB1 += g0v[r] + g1v[r];
             }
+            }
         }
         if (!XG) nl_lds_barrier();                       // fp32 path: dH1 overwrites the dH2 tile other waves may still be reading
         DBG_STAMP(8);
+        if constexpr (F16) {
+            // ---------------- H (fp16 pairs): Q = [H1 > 0] * accumulator, saturated, as an fp16 pair.  A lane's packed (row, row + 1) words of its
+            // own column ARE dW1's A fragments; exchanged with the neighbouring column's (one DPP move + one byte permute per word) they are the
+            // (k, k + 1) words of one row of the Q planes, dX's A operand ----------------
+            // (train) dW1 / db1 right here, k-step by k-step: the three matrix instructions of a k-step are issued as soon as its eight registers are
+            // converted - they run in the matrix pipe under the conversion of the next k-step, and no fragment outlives its k-step (the U planes were
+            // published by the barrier in front of phase F)
+            f32x16 tw;
+            if (TRAIN) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tw[r] = 0.f;
+            }
+            {
+                const bool odd = (col & 1) != 0;
+                const unsigned sel = odd ? 0x03020706u : 0x05040100u;       // odd: (neighbour.hi16, own.hi16) = row r + 1; even: (own.lo16, neighbour.lo16) = row r
+                unsigned* pq = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(lds) + opaque(X_PLANE_ELEMS + (4 * lh + (odd ? 1 : 0)) * SM_STRIDE + (col & ~1)));
+                const unsigned char* ub = ldsb + opaque(U_OFF + lh * U_CHUNK + (l31 < 17 ? l31 : 16) * 16);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int sub = t >> 1;
+                    uint4 qh, ql, bh, bl;
+                    if (TRAIN) { bh = *reinterpret_cast<const uint4*>(ub + 2 * t * U_CHUNK); bl = *reinterpret_cast<const uint4*>(ub + 2 * t * U_CHUNK + U_PLANE); }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 8 * (t & 1) + 2 * e;
+                        // saturate (one v_med3), then the ReLU bit as an all-ones / zero word ANDed on (v_bfe_i32 + v_and): no compare, no branch
+                        const float qa = __uint_as_float(__float_as_uint(sat_f16(sub ? g1v[r] : g0v[r])) & (unsigned)__builtin_amdgcn_sbfe((int)m1, 16 * sub + r, 1));
+                        const float qb = __uint_as_float(__float_as_uint(sat_f16(sub ? g1v[r + 1] : g0v[r + 1])) & (unsigned)__builtin_amdgcn_sbfe((int)m1, 16 * sub + r + 1, 1));
+                        unsigned ph, pl;
+                        split2_pair_f16(qa, qb, &ph, &pl);
+                        (&qh.x)[e] = ph; (&ql.x)[e] = pl;
+                        unsigned* d = pq + ((32 * sub + D32_RR(r)) * SM_STRIDE) / 2;
+                        d[0] = __builtin_amdgcn_perm(dpp_swap1u(ph), ph, sel);
+                        d[X_PLANE_ELEMS / 2] = __builtin_amdgcn_perm(dpp_swap1u(pl), pl, sel);
+                    }
+                    if (TRAIN) { tw = mma16<true>(ql, bh, tw); tw = mma16<true>(qh, bl, tw); tw = mma16<true>(qh, bh, tw); }
+                }
+            }
+            if (TRAIN) {
+                const float sc = inv_sigma * (l31 == 16 ? 1.0f / NL_F16_SG : 1.0f / (NL_F16_SG * 16.0f));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accW1h[r] = fmaf(tw[r], sc, accW1h[r]);
+            }
+            nl_lds_barrier();
+            DBG_STAMP(9);
+            // ---------------- I (fp16 pairs): waves 0-3: dX of 16 rows each ----------------
+            if (w < 4) {
+                f32x4 cx = {0.f, 0.f, 0.f, 0.f};
+                const unsigned char* ap = ldsb + opaque(X_PLANE_BYTES + (16 * w + l15) * (SM_STRIDE * 2) + 16 * lq);
+                const unsigned char* bp = ldsb + opaque(S_W1 * 4 + lane * 16);
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) {
+                    const f16x8 ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ap + 64 * s8));
+                    const f16x8 al = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ap + X_PLANE_BYTES + 64 * s8));
+                    const f16x8 bh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(bp + s8 * 2048));
+                    const f16x8 bl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(bp + s8 * 2048 + 1024));
+                    cx = MFMA16_F16(al, bh, cx); cx = MFMA16_F16(ah, bl, cx); cx = MFMA16_F16(ah, bh, cx);
+                }
+                const float* dsr = sdS + opaque(16 * w + 4 * lq);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int g = row0 + 16 * w + 4 * lq + r;
+                    if (g < P) a.dX[(size_t)g * NL_C + l15] = cx[r] * (dsr[r] * (1.0f / (NL_F16_SG * NL_F16_SW1)));
+                }
+            }
+        } else {
         // ---------------- H: dH1 -> LDS ----------------
         {
             float* db = sD + opaque(4 * lh * LDH + col);
@@ -842,7 +974,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int g = row0 + 16 * w + 4 * lq + r;
-                if (g < P) a.dX[(size_t)g * NL_C + l15] = F16 ? (cxa[r] + cxb[r]) * DHS : cxa[r] + cxb[r];
+                if (g < P) a.dX[(size_t)g * NL_C + l15] = cxa[r] + cxb[r];
             }
         } else if (TRAIN) {
             const float* xr = sX + opaque(lq * LDX + l15);
@@ -880,9 +1012,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
                     for (int t = 0; t < 4; ++t) accW1[t] = MFMA16(dB[u][t], xB[u], accW1[t]);
             }
         }
+        }
         // ---------------- A (next tile): X -> the other LDS buffer; issue the loads of the tile after it ----------------
         {
-            stage_x(lds + S_X + ((tile_no + 1) & 1) * (DEC_M * LDX));
+            stage_x(lds + S_X + (F16 ? 0 : ((tile_no + 1) & 1) * (DEC_M * LDX)));
             cz = pdep * pcos; cd = pd;
             prefetch(tile + 2 * gridDim.x);
             prefetch_ray(tile + 3 * gridDim.x);
@@ -902,16 +1035,24 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
     // ---------------- flush weight-gradient partials ----------------
     if (TRAIN) {
         float* base = a.partials + (size_t)blockIdx.x * NL_DEC_PARAMS;
-        if (w >= 4) {
+        if constexpr (F16) {
+            // lane c < 16: dW1[32 w + row][c]; lane 16: db1[32 w + row]  (row of accumulator register r: D32_RR(r) + 4 lh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = 32 * w + D32_RR(r) + 4 * lh;
+                if (l31 < NL_C) base[NL_OFF_W1 + k * NL_C + l31] = accW1h[r];
+                else if (l31 == NL_C) base[NL_OFF_B1 + k] = accW1h[r];
+            }
+        } else if (w >= 4) {
             const int hb = 64 * (w - 4);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    base[NL_OFF_W1 + (hb + 16 * t + 4 * lq + r) * NL_C + l15] = F16 ? accW1[t][r] * DHS : accW1[t][r];
+                    base[NL_OFF_W1 + (hb + 16 * t + 4 * lq + r) * NL_C + l15] = accW1[t][r];
         }
         aW3 += __shfl_xor(aW3, 32); aB2 += __shfl_xor(aB2, 32); aB1 += __shfl_xor(aB1, 32);
-        if (lh == 0) { base[NL_OFF_W3 + col] = aW3; base[NL_OFF_B2 + col] = aB2; base[NL_OFF_B1 + col] = F16 ? aB1 * DHS : aB1; }
+        if (lh == 0) { base[NL_OFF_W3 + col] = aW3; base[NL_OFF_B2 + col] = aB2; if (!F16) base[NL_OFF_B1 + col] = aB1; }
         if (tid < 64) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { aB3 += __shfl_xor(aB3, off); dsMax = fmaxf(dsMax, __shfl_xor(dsMax, off)); }

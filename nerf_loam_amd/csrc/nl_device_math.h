@@ -84,7 +84,7 @@ NL_HD void nl_split3_bf16(float v, uint16_t* hi, uint16_t* mid, uint16_t* lo) {
 #define NL_F16_SW1 256.0f
 #define NL_F16_SH 16.0f
 #define NL_F16_SW2 256.0f
-#define NL_F16_SG 4096.0f
+#define NL_F16_SG 1024.0f
 NL_HD uint16_t nl_f32_to_f16(float f) {
     union { float f; uint32_t u; } v; v.f = f;
     const uint32_t sign = (v.u >> 16) & 0x8000u, a = v.u & 0x7FFFFFFFu;
