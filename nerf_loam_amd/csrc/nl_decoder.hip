@@ -507,36 +507,50 @@ __device__ __forceinline__ unsigned store_h1_planes_f16(unsigned short* sP, int 
 }
 
 // For each of the 32 rows a half-wave holds (16 of h0 ++ 16 of h1), the sum over its 32 lanes of
-// h[row] * w3c, by recursive halving: 31 shuffles instead of 160; lane l31 ends up with the total of
+// h[row] * w3c, by recursive halving: 31 exchanges instead of 160; lane l31 ends up with the total of
 // list entry e = l31.  Register-lean: level 1 consumes h0/h1 directly (16 live values), then 8, 4, 2, 1.
+// No LDS round trips (round 5; the ds_bpermute of __shfl_xor put five LDS latencies on the kernel's critical path): the 16-lane rows of a
+// half-wave exchange through v_permlane16_swap (one instruction swaps what the two rows send each other - no selects at that level),
+// the levels inside a row through DPP operands of the add itself: row_mirror (l <-> 15 - l: bit 3 flips), row_half_mirror (l <-> 7 - l inside
+// each 8: bit 2 flips), quad_perm (xor 2, xor 1).  Any pairing that flips the level's lane bit halves correctly; which lanes a partial sum
+// has visited differs from the xor butterfly, the set it covers at the end - all 32 - does not.
+__device__ __forceinline__ float dpp_add(float keep, float send, int ctrl_tag)
+{
+    // keep + (the partner lane's `send`), the partner chosen by a DPP control; separate calls per control: the control is an immediate
+    switch (ctrl_tag) {
+    case 0: return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x140, 0xF, 0xF, true));   // row_mirror
+    case 1: return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    case 2: return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    default: return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    }
+}
 __device__ __forceinline__ float halfwave_rowsum(const f32x16& h0, const f32x16& h1, float w3c, int l31)
 {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     float v16[16], v8[8], v4[4], v2[2];
-    {
-        const bool up = (l31 & 16) != 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float a0 = h0[i] * w3c, a1 = h1[i] * w3c;
-            v16[i] = (up ? a1 : a0) + __shfl_xor(up ? a0 : a1, 16);
-        }
+    for (int i = 0; i < 16; ++i) {
+        // lanes 0-15 keep the h0 entry and get the partner row's, lanes 16-31 the h1 entry: after the swap both operands sit in the lane that sums them
+        const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(h0[i] * w3c), __float_as_uint(h1[i] * w3c), false, false);
+        v16[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
     {
         const bool up = (l31 & 8) != 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v8[i] = (up ? v16[i + 8] : v16[i]) + __shfl_xor(up ? v16[i] : v16[i + 8], 8);
+        for (int i = 0; i < 8; ++i) v8[i] = dpp_add(up ? v16[i + 8] : v16[i], up ? v16[i] : v16[i + 8], 0);
     }
     {
         const bool up = (l31 & 4) != 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v4[i] = (up ? v8[i + 4] : v8[i]) + __shfl_xor(up ? v8[i] : v8[i + 4], 4);
+        for (int i = 0; i < 4; ++i) v4[i] = dpp_add(up ? v8[i + 4] : v8[i], up ? v8[i] : v8[i + 4], 1);
     }
     {
         const bool up = (l31 & 2) != 0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) v2[i] = (up ? v4[i + 2] : v4[i]) + __shfl_xor(up ? v4[i] : v4[i + 2], 2);
+        for (int i = 0; i < 2; ++i) v2[i] = dpp_add(up ? v4[i + 2] : v4[i], up ? v4[i] : v4[i + 2], 2);
     }
     const bool up = (l31 & 1) != 0;
-    return (up ? v2[1] : v2[0]) + __shfl_xor(up ? v2[0] : v2[1], 1);
+    return dpp_add(up ? v2[1] : v2[0], up ? v2[0] : v2[1], 3);
 }
 
 template <bool TRAIN, bool XG, int NP = 9>               // NP: partial products of the forward GEMM - 9 / 8 / 6: three-term bf16 splits (gemm_x9), 3 / 4: fp16 pairs (gemm_f16); XG: the 256-deep GEMMs on the 16-bit matrix cores
@@ -921,17 +935,29 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             DBG_STAMP(9);
             // ---------------- I (fp16 pairs): waves 0-3: dX of 16 rows each ----------------
             if (w < 4) {
-                f32x4 cx = {0.f, 0.f, 0.f, 0.f};
+                // two accumulator chains (k-step parity), the fragments of the next k-step in flight under this one's three instructions: a plain
+                // unrolled loop has every ds_read sunk to just before its first use, i.e. one LDS latency per k-step on a dependent chain
+                f32x4 cxa = {0.f, 0.f, 0.f, 0.f}, cxb = {0.f, 0.f, 0.f, 0.f};
                 const unsigned char* ap = ldsb + opaque(X_PLANE_BYTES + (16 * w + l15) * (SM_STRIDE * 2) + 16 * lq);
                 const unsigned char* bp = ldsb + opaque(S_W1 * 4 + lane * 16);
+                uint4 fa[2][2], fb[2][2];                 // [k-step parity][hi, lo]
+                auto fetch = [&](int s8, int buf) {
+                    fa[buf][0] = *reinterpret_cast<const uint4*>(ap + 64 * s8); fa[buf][1] = *reinterpret_cast<const uint4*>(ap + X_PLANE_BYTES + 64 * s8);
+                    fb[buf][0] = *reinterpret_cast<const uint4*>(bp + s8 * 2048); fb[buf][1] = *reinterpret_cast<const uint4*>(bp + s8 * 2048 + 1024);
+                };
+                fetch(0, 0);
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
-                    const f16x8 ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ap + 64 * s8));
-                    const f16x8 al = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ap + X_PLANE_BYTES + 64 * s8));
-                    const f16x8 bh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(bp + s8 * 2048));
-                    const f16x8 bl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(bp + s8 * 2048 + 1024));
-                    cx = MFMA16_F16(al, bh, cx); cx = MFMA16_F16(ah, bl, cx); cx = MFMA16_F16(ah, bh, cx);
+                    const int cur = s8 & 1;
+                    if (s8 + 1 < 8) fetch(s8 + 1, cur ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const f16x8 ah = __builtin_bit_cast(f16x8, fa[cur][0]), al = __builtin_bit_cast(f16x8, fa[cur][1]);
+                    const f16x8 bh = __builtin_bit_cast(f16x8, fb[cur][0]), bl = __builtin_bit_cast(f16x8, fb[cur][1]);
+                    if (cur) { cxb = MFMA16_F16(al, bh, cxb); cxb = MFMA16_F16(ah, bl, cxb); cxb = MFMA16_F16(ah, bh, cxb); }
+                    else     { cxa = MFMA16_F16(al, bh, cxa); cxa = MFMA16_F16(ah, bl, cxa); cxa = MFMA16_F16(ah, bh, cxa); }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                const f32x4 cx = cxa + cxb;
                 const float* dsr = sdS + opaque(16 * w + 4 * lq);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
