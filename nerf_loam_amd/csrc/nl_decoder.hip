@@ -212,7 +212,7 @@ __device__ __forceinline__ void gemm_mask_x_prefetch(i32x4 rsX, int w, int lane,
         for (int p = 0; p < NPL; ++p) bq[s][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + kt_off + s * 1024);
 }
 
-template <bool PIN, bool F16 = false>                                   // PIN: hold the software pipeline in place with scheduling barriers.  Without them
+template <bool PIN, bool F16 = false, int RING = MX_RING>   // RING <= MX_RING: B fragments RING - 1 k-steps ahead.  PIN: hold the software pipeline in place with scheduling barriers.  Without them
                                                         // the scheduler sinks every prefetch to just before its use (vmcnt(0) after each
                                                         // load); with them the trainable-decoder kernel, which is at the 256-VGPR limit,
                                                         // spills ~40 registers - so it is enabled where registers allow (frozen / forward)
@@ -223,7 +223,8 @@ __device__ __forceinline__ void gemm_mask_x(i32x4 rsX, int w, int lane, const un
     const int kt_off = __builtin_amdgcn_readfirstlane(w) * 16 * 1024;     // this wave's column tile; provably wave-uniform, or every
                                                                           // load below becomes a waterfall loop over soffset
     const unsigned char* a0 = sM + opaque(l31 * (SM_STRIDE * 2) + 16 * lh);
-    constexpr int RING = MX_RING, NPL = F16 ? 2 : 3;
+    static_assert(RING <= MX_RING && RING - 1 >= MX_PRE, "ring depth");
+    constexpr int NPL = F16 ? 2 : 3;
     uint4 aq[2][2];
 #pragma unroll
     for (int s = MX_PRE; s < RING - 1; ++s)
