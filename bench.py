@@ -196,6 +196,20 @@ def reference_cpu_baseline(n_rays=8192, timeout=600):
                        f"restatement (oracle/nl_oracle.c); {d['octree_nodes']} octree nodes, {d['embedding_rows']} embedding rows as the reference allocates them")
 
 
+def reference_recorded():
+    """The reference's OWN CPU path, as last timed where its checkout exists (the build container: profiles/r05_reference_cpu_baseline.json, written by
+    scripts/ref_cpu_baseline.py --json 131072 with its provenance).  A GPU box has no /root/reference, so the bench line there carries this RECORD
+    next to the same-box port: one glance gives reference-path rays/s, its core count, and the port on the same thread count."""
+    try:
+        r = json.load(open(os.path.join(ROOT, "profiles", "r05_reference_cpu_baseline.json")))
+    except Exception:                                            # noqa: BLE001
+        return None
+    return dict(value=r["rays_per_s"], unit="rays/s", cores=r["threads"], kind="reference", measured_in_this_run=False, ms_per_iter=r["ms_per_iter"], rays=r["rays"],
+                torch=r["torch"], where=r["where"], reference=r["reference"], command=r["command"],
+                note="the reference's unmodified bundle_adjust_frames on the CPU, all 131 072 rays of the same synthetic scan, timed in the build container (the only place its "
+                     "checkout exists); compare with by_threads['%d'] of the port measured in this run" % r["threads"])
+
+
 def cpu_baseline(w, n_rays_probe=16384, n_rays_1t=8192, reps_1t=2, seed=1):
     """The SAME iteration on this box's host cores.  With a reference checkout on the box: the reference's own Python path (kind
     "reference").  Otherwise the oracle port (oracle/oracle.py + nl_oracle.c: numpy / C with closed-form gradients, the GEMMs and the
@@ -230,7 +244,8 @@ def cpu_baseline(w, n_rays_probe=16384, n_rays_1t=8192, reps_1t=2, seed=1):
     cores = int(torch.get_num_threads())
     res = {}
     try:
-        for thr in dict.fromkeys((cores, min(16, cores))):               # probe: which thread count serves the port best on this box
+        # (8 threads: the thread count of the recorded reference-path figure - the two are then comparable on equal cores)
+        for thr in dict.fromkeys((cores, min(16, cores), min(8, cores))):       # probe: which thread count serves the port best on this box
             torch.set_num_threads(thr)
             res[thr] = run(n_rays_probe, 1, 1) + (1, 1)
         best = max(res, key=lambda t: res[t][0] / res[t][1])
@@ -240,10 +255,13 @@ def cpu_baseline(w, n_rays_probe=16384, n_rays_1t=8192, reps_1t=2, seed=1):
         n_1, t_1 = run(n_rays_1t, 1, reps_1t)
     finally:
         torch.set_num_threads(cores)
-    return dict(value=n_b / t_b, unit="rays/s", cores=best, kind="port",
-                sample=f"all {n_b} rays of the same 64x2048 scan, 1 mapping iteration incl. Adam, 1 timed iteration after a warm-up on {n_rays_probe} rays: "
-                       f"{t_b * 1e3:.0f} ms/iter; numpy/C oracle port, GEMMs + decoder element-wise stages on {best} torch-CPU threads of {os.cpu_count()} host cores "
-                       f"(the other numpy stages are single-threaded).  NOT the reference's own code: " + REF_OFFBOX,
+    rec = reference_recorded()
+    sample = (f"all {n_b} rays of the same 64x2048 scan, 1 mapping iteration incl. Adam, 1 timed iteration after a warm-up on {n_rays_probe} rays: "
+              f"{t_b * 1e3:.0f} ms/iter; numpy/C oracle port, GEMMs + decoder element-wise stages on {best} torch-CPU threads of {os.cpu_count()} host cores "
+              f"(the other numpy stages are single-threaded).  NOT the reference's own code: ")
+    sample += (f"reference_recorded carries the reference path's figure ({rec['value']:.0f} rays/s on {rec['cores']} threads in the build container) with its provenance"
+               if rec else REF_OFFBOX)
+    return dict(value=n_b / t_b, unit="rays/s", cores=best, kind="port", reference_recorded=rec, sample=sample,
                 by_threads={str(t): dict(value=res[t][0] / res[t][1], rays=res[t][0], ms_per_iter=res[t][1] * 1e3, warmup=res[t][2], timed=res[t][3])
                             for t in res},
                 single_thread=dict(value=n_1 / t_1, unit="rays/s", cores=1,
