@@ -51,8 +51,9 @@ def matrix_pipe_model(kernel, gemm_mode, wgrad2_mode, train):
         small = L1 * (3 if train else 2)                        # layer-1 forward, dX, (dW1)
         if gemm_mode in (1, 2, 3):                              # forward: 3x3 split (9, 8 or 6 of the nine products), dgrad: {0,1} mask x
             return alg, small - L1, {1: 9, 3: 8, 2: 6}[gemm_mode] * G + 3 * G + 9 * L1   # 3-term split; layer-1 forward: 3x3 split too
-        if gemm_mode in (4, 5):                                 # fp16 pairs: forward 3 or 4 of the four products, dgrad mask x 2 terms, layer 1 all four
-            return alg, small - L1, {4: 3, 5: 4}[gemm_mode] * G + 2 * G + 4 * L1
+        if gemm_mode in (4, 5):                                 # fp16 pairs: forward 3 or 4 of the four products, dgrad mask x 2 terms, layer 1 all four,
+            # dX three products (16x16x32), dW1 / db1 three products on 32x32x16 with 17 of 32 output columns used (2 x 3 x L1 executed): nothing on the fp32 pipe
+            return alg, 0, {4: 3, 5: 4}[gemm_mode] * G + 2 * G + 4 * L1 + 3 * L1 + (6 * L1 if train else 0)
         return alg, small + 2 * G, 0
     if wgrad2_mode == 2:
         return FLOPS_PER_SAMPLE_WGRAD2, 0, 2 * G + 4 * L1       # H1 rebuilt as 2x2 fp16 products; mask x fp16 pair
@@ -979,7 +980,7 @@ def main():
                                  "(2 x FETCH_SIZE + WRITE_SIZE) KB per launch" if traffic is not None else committed_traffic_source()),
               "peak_note": ("matrix-pipe bound of the kernel's instruction mix: "
                             + (f"256-deep GEMMs as fp16 pairs ({ {4: 3, 5: 4}[gm]} of 4 forward + 2 dgrad MFMAs per fp32 product, 2500 TF pipe), layer-1 forward as four fp16 "
-                               "products, dX / dW1 (K=16) on the fp32 pipe (157.3 TF)" if gm >= 4 else
+                               "products, dX / dW1 / db1 as three fp16-pair products each (dW1 on 32x32x16 with 17 of 32 output columns used); nothing left on the fp32 pipe" if gm >= 4 else
                                f"256-deep GEMMs as bf16 three-term splits ({ {1: 9, 3: 8, 2: 6}.get(gm, 9)} of 9 forward + 3 dgrad MFMAs per fp32 product, 2500 TF pipe), "
                                "layer-1 forward as nine bf16 products too, dX / dW1 (K=16) on the fp32 pipe (157.3 TF)" if gm >= 1 else "all GEMMs on the fp32 pipe (157.3 TF)")),
               "second_kernel": (roofline_entry({1: "k_decoder_wgrad2_x<bf16 x3>", 2: "k_decoder_wgrad2_x<fp16 pair>"}.get(wm, "k_decoder_wgrad2"), "wgrad2", wg_ms, P_local, gm, wm, True)

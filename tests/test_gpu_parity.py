@@ -310,7 +310,7 @@ def test_engines_carry_their_own_kernel_modes(nl, golden_dir):
 
     for one_call in (False, True):
         got = {}
-        for gemm, wg in ((0, 0), (1, 1), (3, 1), (4, 2), (0, 0), (1, 1), (4, 2), (4, 1)):              # alternating selections, process default untouched
+        for gemm, wg in ((0, 0), (1, 1), (3, 1), (4, 2), (0, 0), (1, 1), (4, 2), (4, 1), (3, 2)):              # alternating selections, process default untouched
             r = run(one_call, gemm, wg)
             assert (lib.nl_decoder_get_gemm_mode(), lib.nl_decoder_get_wgrad2_mode()) == default
             if (gemm, wg) in got:
@@ -332,6 +332,11 @@ def test_engines_carry_their_own_kernel_modes(nl, golden_dir):
         assert np.array_equal(got[(4, 2)]["sdf"], got[(4, 1)]["sdf"]) and not np.array_equal(got[(4, 2)]["gdec"], got[(4, 1)]["gdec"])     # the dW2 kernel alone differs
         w2 = slice(nl["L"].OFF_W2, nl["L"].OFF_B2)
         assert np.abs(got[(4, 2)]["gdec"][w2] - got[(4, 1)]["gdec"][w2]).max() <= 2e-5 * np.abs(got[(4, 1)]["gdec"][w2]).max()
+        # the mixed selection (exact-product forward, fp16-pair dW2: the dW2 kernel rebuilds H1 in ITS arithmetic) agrees just as well
+        assert np.array_equal(got[(3, 2)]["sdf"], got[(3, 1)]["sdf"])
+        assert np.abs(got[(3, 2)]["gdec"][w2] - got[(3, 1)]["gdec"][w2]).max() <= 2e-5 * np.abs(got[(3, 1)]["gdec"][w2]).max()
+        record_metric(f"kernel_modes/one_call{int(one_call)}", dW2_f16pair_vs_exact_rel_max=np.abs(got[(3, 2)]["gdec"][w2] - got[(3, 1)]["gdec"][w2]).max() / np.abs(got[(3, 1)]["gdec"][w2]).max(),
+                      dW2_mode4_f16pair_vs_bf16_rel_max=np.abs(got[(4, 2)]["gdec"][w2] - got[(4, 1)]["gdec"][w2]).max() / np.abs(got[(4, 1)]["gdec"][w2]).max())
     with pytest.raises(ValueError):
         nl["P"].SdfEngine(max_rays=8, gemm_mode=6)
     assert lib.nl_decoder_forward_m(None, None, None, 0, None, 1, 0x0600, None) != 0       # wgrad2 mode 5: rejected

@@ -62,12 +62,12 @@ def test_five_scan_mapping_sequence_matches_the_oracle(monkeypatch, gemm_mode, e
     RH._ENGINES.clear()
     lib = L.lib()
     monkeypatch.setattr(RH, "_ENGINES", type(RH._ENGINES)())          # engines built under this test's mode do not outlive it
-    old_mode = lib.nl_decoder_get_gemm_mode()
-    assert lib.nl_decoder_set_gemm_mode(gemm_mode) == 0
+    old_mode = lib.nl_decoder_get_gemm_mode(), lib.nl_decoder_get_wgrad2_mode()
+    assert lib.nl_decoder_set_gemm_mode(gemm_mode) == 0 and lib.nl_decoder_set_wgrad2_mode(1 if gemm_mode == 3 else 2) == 0       # exact products in both kernels / fp16 pairs in both
     try:
         _five_scans(monkeypatch, gemm_mode, emb_bar)
     finally:
-        lib.nl_decoder_set_gemm_mode(old_mode)
+        lib.nl_decoder_set_gemm_mode(old_mode[0]); lib.nl_decoder_set_wgrad2_mode(old_mode[1])
 
 
 def _five_scans(monkeypatch, gemm_mode, emb_bar):
