@@ -1244,3 +1244,44 @@ def test_sampler_kernels_agree_bit_for_bit(nl, golden_dir, mode):
         compare_iteration(eng, m, dec, out, cfgP, True)
     finally:
         lib.nl_geometry_set_sampler_mode(2)
+
+
+@pytest.mark.parametrize("scale", [8.0, 2000.0])
+def test_fp16_pairs_on_large_weights(nl, golden_dir, scale):
+    """The fp16-pair arithmetic (gemm mode 4, dW2 mode 2) works on power-of-two scaled operands that SATURATE at fp16's range instead of overflowing
+    (include/nerfloam_hip.h: |X| < 1023, |W1| < 256, H1 < 4094, |W2| < 256, |w3_j W2[j][k]| < 64).  scale 8: a decoder whose weights are 8x the initial
+    ones and embeddings 20x (activations of order 10-100, the dgrad sums 2^10 x 4: the upper part of the ranges) still agrees with the exact-product mode like
+    any two summation orders do.  scale 2000: far outside the ranges - operands saturate, the numbers mean nothing, but nothing becomes inf / NaN by itself
+    (a NaN in dX would spread into every embedding row and the pose)."""
+    lib = nl["L"].lib()
+    g = np.load(os.path.join(golden_dir, "map_1f_1it.npz"))
+    sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]))
+    sc["ms"].id2row = g["id_table"].copy()
+    masks = H.unpack_masks(g["masks"], len(sc["points"]))
+    d0 = O.decoder_init(int(g["seed"]))
+    big = O.DecoderParams(d0.W1 * np.float32(scale), d0.b1 * np.float32(scale), d0.W2 * np.float32(scale), d0.b2 * np.float32(scale), d0.W3 * np.float32(scale), d0.b3)
+    emb = O.bf16_bits(O.bf16_to_f32(sc["ms"].emb) * np.float32(20.0))
+    sc["ms"].emb = emb
+    frames = [O.select_rays(sc["points"], sc["cos"], g["poses0"][0].copy(), masks[0][0], optimize_pose=True)]
+    cfgP = nl["P"].IterConfig(step_size=float(g["step_size"]))
+    res = {}
+    for gemm, wg in ((1, 1), (4, 2)):
+        m, dec, _ = make_engine(nl, sc, big, len(frames[0].rays_d))
+        eng = nl["P"].SdfEngine(max_rays=len(frames[0].rays_d), samples_per_ray_cap=64, max_frames=2, gemm_mode=gemm, wgrad2_mode=wg)
+        load_frames(eng, frames)
+        eng.begin_call(m, dec)
+        eng.forward_backward(m, dec, cfgP, train_decoder=True)
+        eng.optimiser_step(m, dec, cfgP, update_decoder=False, update_emb=False, update_pose=False)      # pose_grad6 only
+        torch.cuda.synchronize()
+        Pn = eng.stats()["P"]
+        res[gemm] = dict(sdf=eng.sdf[:Pn].cpu().numpy().astype(np.float64), dX=eng.dX[:Pn].cpu().numpy().astype(np.float64), gdec=dec.grad.cpu().numpy().astype(np.float64),
+                         gemb=eng.g_emb.cpu().numpy().astype(np.float64), g6=eng.pose_grad6[0].cpu().numpy().astype(np.float64))
+    a, b = res[1], res[4]
+    assert all(np.isfinite(v).all() for v in b.values()), {k: bool(np.isfinite(v).all()) for k, v in b.items()}
+    if scale > 100:
+        return                                               # (saturated operands: finite is all that is promised)
+    rel = lambda x, y: float(np.linalg.norm(x - y) / max(np.linalg.norm(y), 1e-300))      # noqa: E731
+    m_ = dict(sdf_max_rel=float(np.abs(b["sdf"] - a["sdf"]).max() / np.abs(a["sdf"]).max()), dX=rel(b["dX"], a["dX"]), gdec=rel(b["gdec"], a["gdec"]), gemb=rel(b["gemb"], a["gemb"]),
+              g6=float(np.abs(b["g6"] - a["g6"]).max() / np.abs(a["g6"]).max()), sdf_abs_max=float(np.abs(a["sdf"]).max()))
+    record_metric("fp16_pairs_large_weights", **m_)
+    assert m_["sdf_max_rel"] < 2e-6 and m_["dX"] < 2e-3 and m_["gdec"] < 1e-4 and m_["gemb"] < 5e-3 and m_["g6"] < 1e-3, m_      # (dX / embedding / pose gradients: ReLU flips of single samples)
