@@ -274,8 +274,13 @@ int nl_trilinear_bwd(const void* loss_scalars, const int* s_vox, const float* s_
  * words, zero-filled at allocation), list: the rows whose bit is set (capacity E), count: [1].  The scatter kernel records a row the first
  * time it adds to its accumulators (nl_trilinear_bwd_t; the multi-GPU unpack: nl_dist_rows_move_t), the optimiser sweeps the list
  * (nl_optimiser_step_t), nl_touched_rows_reset clears the listed rows' accumulators / moments / flags and empties the list at the start of
- * the next call (a fresh Adam per call, render_helpers.py:353) - no E-sized memset.  NULL = the dense behaviour everywhere. */
-typedef struct NlTouchedRows { int* list; int* count; unsigned* flags; } NlTouchedRows;
+ * the next call (a fresh Adam per call, render_helpers.py:353) - no E-sized memset.  NULL = the dense behaviour everywhere.
+ * copies / copy_stride (round 5): REPLICATED accumulators.  On an accumulated map the voxels around the sensor are crossed by every ray of a scan, a
+ * few dozen rows receive thousands of same-address atomics per iteration, and those queue at the memory side (scripts/micro/atomic_rows.hip: 30 % of
+ * 384 k row atomics on 48 rows: 76 us against 23 us spread out; with 16 copies 29 us).  With copies > 1 the accumulator array holds `copies` arrays
+ * copy_stride floats apart (g_emb + c * copy_stride), a wave of the scatter adds into copy (its index mod copies), and the optimiser's sweep over the
+ * touched rows - the only reader - sums a row's copies in copy order before the one bf16 rounding, and clears them.  copies <= 1: one array. */
+typedef struct NlTouchedRows { int* list; int* count; unsigned* flags; int copies; long long copy_stride; } NlTouchedRows;
 int nl_trilinear_bwd_t(const void* loss_scalars, const int* s_vox, const float* s_depth, const int* s_ray,
                        const float* rays_d_world, const float* rays_d_sensor, const int* frame_id, const float* poses, int n_frames,
                        const float* centres, const int* vertex_rows, const void* emb_bf16, float voxel_size,
@@ -398,6 +403,7 @@ typedef struct NlIterDesc {
     /* touched-rows optimiser (NlTouchedRows above): with the three pointers set the scatter (and the multi-GPU unpack) record the rows they
      * write; sparse_sweep != 0: the optimiser sweeps the list, 0: the whole table (e.g. after a dense multi-GPU gradient exchange) */
     int* touched_list; int* touched_count; unsigned* touched_flags; int sparse_sweep;
+    int touched_copies; long long touched_copy_stride;      /* replicated accumulators (NlTouchedRows.copies / copy_stride); 0 / 1 = one array */
     /* exchange 1 as one all-gather: x1_send [24 ints | x1_rays bytes] (a ray's hit count per byte), x1_recv [world] such blocks of
      * x1_stride_bytes (a multiple of 16, >= 96 + x1_rays); x1_rays = the ranks' common ray capacity (a multiple of 16, >= every rank's N) */
     void* x1_send; void* x1_recv; int x1_stride_bytes; int x1_rays;

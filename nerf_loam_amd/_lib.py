@@ -63,6 +63,7 @@ def _iter_desc_fields():
     f += [("comm", P_), ("xg_send", P_), ("xg_recv", P_), ("xg_stride", I_), ("row_first", P_), ("row_first_entries", I_)]
     f += [("rows_mode", I_), ("rows_bitmap", P_), ("rows_prefix", P_), ("rows_total", P_), ("rows_ws", P_), ("rows_buf", P_), ("rows_cap", I_), ("rows_words", I_)]
     f += [("touched_list", P_), ("touched_count", P_), ("touched_flags", P_), ("sparse_sweep", I_)]
+    f += [("touched_copies", I_), ("touched_copy_stride", LL_)]
     f += [("x1_send", P_), ("x1_recv", P_), ("x1_stride_bytes", I_), ("x1_rays", I_)]
     f += [("comm_stream", P_), ("ev_fork", P_), ("ev_join", P_)]
     f += [("isect_lanes", I_)]
@@ -76,7 +77,7 @@ class NlIterDesc(ctypes.Structure):
 
 class NlTouchedRows(ctypes.Structure):
     """rows of the embedding table touched since the optimiser of a call was created (include/nerfloam_hip.h)"""
-    _fields_ = [("list", ctypes.c_void_p), ("count", ctypes.c_void_p), ("flags", ctypes.c_void_p)]
+    _fields_ = [("list", ctypes.c_void_p), ("count", ctypes.c_void_p), ("flags", ctypes.c_void_p), ("copies", ctypes.c_int), ("copy_stride", ctypes.c_longlong)]
 
 
 # communicator of the ray-sharded iteration (NlComm, include/nerfloam_hip.h)

@@ -69,7 +69,7 @@ static inline int nl_div_up(long long a, long long b) { return (int)((a + b - 1)
 // the rows whose bit is set.  Whoever first adds to a row's gradient accumulators appends the row - the optimiser then sweeps the
 // list instead of the whole table (a row that was never touched has zero gradient and zero moments: Adam leaves it alone, so
 // skipping it is bit-identical to the dense sweep the reference's torch.optim.Adam performs).
-struct NlTouchedDev { int* list; int* count; unsigned* flags; };
+struct NlTouchedDev { int* list; int* count; unsigned* flags; int copies; long long copy_stride; };
 __device__ __forceinline__ void nl_touch_row(const NlTouchedDev& t, int row)
 {
     if (!t.flags) return;

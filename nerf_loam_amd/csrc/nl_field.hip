@@ -186,6 +186,8 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
     if (threadIdx.x == 0) s_new_n = 0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* s_val = s_val_all + wv * TB_SLOTS * NL_C;            // this wave's table
+    // this wave's copy of the accumulators (NlTouchedRows.copies: same-address atomics on the near-sensor rows of an accumulated map spread over the copies)
+    float* const gacc = a.g_emb ? a.g_emb + (size_t)((blockIdx.x * TB_WAVES + wv) % (unsigned)a.touched.copies) * (size_t)a.touched.copy_stride : nullptr;
     int* s_key = s_key_all + wv * TB_SLOTS;
     unsigned char* s_own = s_own_all + wv * TB_SLOTS;
     for (int i = threadIdx.x; i < a.n_frames * 12; i += NL_FIELD_THREADS) s_pose[i] = 0.0;
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
                     if (key >= 0) {
                         const float v = s_val[sl * NL_C + c];
                         if (c == 0) nl_touch_row(a.touched, key);
-                        if (v != 0.f) atomicAdd(a.g_emb + (size_t)key * NL_C + c, v);
+                        if (v != 0.f) atomicAdd(gacc + (size_t)key * NL_C + c, v);
                         s_val[sl * NL_C + c] = 0.f;
                     }
                 }
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
             }
             if (ovf) {                                              // straight to memory from this lane
                 nl_touch_row(a.touched, row);
-                float* dst = a.g_emb + (size_t)row * NL_C;
+                float* dst = gacc + (size_t)row * NL_C;
 #pragma unroll
                 for (int c = 0; c < NL_C; ++c) atomicAdd(dst + c, acc[c]);
             }
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(NL_FIELD_THREADS, 4) void k_trilinear_bwd(FieldArgs
                 const int key = s_key[slot];
                 if (key >= 0) {
                     const float v = s_val[slot * NL_C + c];
-                    if (v != 0.f) atomicAdd(a.g_emb + (size_t)key * NL_C + c, v);
+                    if (v != 0.f) atomicAdd(gacc + (size_t)key * NL_C + c, v);
                     s_val[slot * NL_C + c] = 0.f;
                 }
             }
@@ -476,7 +478,7 @@ static int fill_args(FieldArgs& a, const void* ls, const int* s_vox, const float
                      const float* rays_d_world, const float* rays_d_sensor, const int* frame_id, const float* poses, int n_frames,
                      const float* centres, const int* vertex_rows, const void* emb, float voxel_size)
 {
-    a.dbg = nullptr; a.touched.list = nullptr; a.touched.count = nullptr; a.touched.flags = nullptr;
+    a.dbg = nullptr; a.touched.list = nullptr; a.touched.count = nullptr; a.touched.flags = nullptr; a.touched.copies = 1; a.touched.copy_stride = 0;
     if (!ls || !s_vox || !s_depth || !s_ray || !rays_d_world || !poses || !centres || !vertex_rows || !emb) return NL_ERR_INVALID_ARG;
     if (n_frames <= 0 || n_frames > NL_MAX_FRAMES) return NL_ERR_INVALID_ARG;
     a.ls = (const NlLossScalars*)ls; a.s_vox = s_vox; a.s_depth = s_depth; a.s_ray = s_ray; a.rays_d_world = rays_d_world;
@@ -532,7 +534,13 @@ int nl_trilinear_bwd_t(const void* loss_scalars, const int* s_vox, const float* 
     a.dX = dX; a.g_emb = g_emb; a.g_pose = g_pose; a.want_emb_grad = g_emb != nullptr; a.want_pose_grad = g_pose != nullptr;
     a.dbg = g_field_dbg;
     a.resident_blocks = g_field_one_round ? field_resident_blocks() : 0;
-    if (touched && g_emb) { a.touched.list = touched->list; a.touched.count = touched->count; a.touched.flags = touched->flags; }
+    if (touched && g_emb) {
+        a.touched.list = touched->list; a.touched.count = touched->count; a.touched.flags = touched->flags;
+        if (touched->copies > 1) {
+            if (!touched->flags || touched->copy_stride <= 0) return NL_ERR_INVALID_ARG;     // copies are folded by the sweep over the touched rows only
+            a.touched.copies = touched->copies; a.touched.copy_stride = touched->copy_stride;
+        }
+    }
     hipLaunchKernelGGL(k_trilinear_bwd, dim3(nblocks), dim3(NL_FIELD_THREADS), 0, (hipStream_t)stream, a);
     NL_LAUNCH_CHECK();
     return NL_OK;

@@ -148,6 +148,7 @@ struct OptimArgs {
     int* snap_src; int* snap_dst;        // optional: the counter block is copied to snap_dst and CLEARED by the launch's last step, so that the
                                          // next iteration needs no memset launch (nl_iteration); the host reads the copy
     const int* touched_list; const int* touched_count;     // optional: the embedding group sweeps these rows instead of the whole table
+    int emb_copies; long long emb_copy_stride;             // replicated accumulators (NlTouchedRows.copies): summed - and cleared - by the sweep over the touched rows
 };
 
 // "The iteration was unusable" decided ON THE DEVICE, so that the host loop needs no per-iteration read-back.  The reference skips
@@ -187,7 +188,7 @@ __global__ void __launch_bounds__(256) k_optim_step(OptimArgs a)
         if (role == 0 && a.touched_list) {
             const long long n = (long long)*a.touched_count * NL_C;
             for (long long e = (long long)b * 256 + tid; e < n; e += (long long)a.nb_emb * 256)
-                a.g_emb[(long long)a.touched_list[e >> 4] * NL_C + (e & 15)] = 0.0f;
+                for (int c = 0; c < a.emb_copies; ++c) a.g_emb[c * a.emb_copy_stride + (long long)a.touched_list[e >> 4] * NL_C + (e & 15)] = 0.0f;
         } else if (role == 0) {
             for (long long i = (long long)b * 256 + tid; i < a.n_emb; i += (long long)a.nb_emb * 256)
                 if (a.g_emb[i] != 0.0f) a.g_emb[i] = 0.0f;
@@ -207,7 +208,11 @@ __global__ void __launch_bounds__(256) k_optim_step(OptimArgs a)
         const long long n = (long long)*a.touched_count * NL_C;
         for (long long e = (long long)b * 256 + tid; e < n; e += (long long)a.nb_emb * 256) {
             const long long i = (long long)a.touched_list[e >> 4] * NL_C + (e & 15);
-            const float ga = a.g_emb[i];
+            float ga = a.g_emb[i];
+            for (int c = 1; c < a.emb_copies; ++c) {             // the waves' accumulator copies, in copy order: fp32 sums, ONE bf16 rounding below
+                const float gc = a.g_emb[c * a.emb_copy_stride + i];
+                if (gc != 0.0f) { ga += gc; a.g_emb[c * a.emb_copy_stride + i] = 0.0f; }
+            }
             const uint16_t pm = a.emb_m[i], pv = a.emb_v[i];
             if (ga == 0.0f && pm == 0 && pv == 0) continue;
             a.g_emb[i] = 0.0f;
@@ -418,6 +423,9 @@ int nl_optimiser_step_t(int* state, double lr_emb, double lr_dec, double lr_pose
     a.emb = (uint16_t*)emb; a.g_emb = g_emb; a.emb_m = (uint16_t*)emb_m; a.emb_v = (uint16_t*)emb_v; a.n_emb = emb ? n_emb : 0;
     a.nb_emb = emb ? (int)((n_emb + 255) / 256 < 4096 ? (n_emb + 255) / 256 : 4096) : 0;
     a.touched_list = (emb && touched) ? touched->list : nullptr; a.touched_count = (emb && touched) ? touched->count : nullptr;
+    a.emb_copies = (a.touched_list && touched->copies > 1) ? touched->copies : 1;
+    a.emb_copy_stride = a.emb_copies > 1 ? touched->copy_stride : 0;
+    if (a.emb_copies > 1 && a.emb_copy_stride <= 0) return NL_ERR_INVALID_ARG;
     if (a.touched_list && a.nb_emb > 1024) a.nb_emb = 1024;        // the row count is on the device: a fixed grid strides over it
     a.params = dec_params; a.grad = dec_grad; a.dm = dec_m; a.dv = dec_v; a.W2T = dec_ws;
     a.W2X = dec_ws ? reinterpret_cast<uint16_t*>(dec_ws + NL_W * NL_W) : nullptr;
@@ -451,13 +459,14 @@ int nl_optimiser_step_ex(int* state, double lr_emb, double lr_dec, double lr_pos
 // cleared (the reference constructs a fresh torch.optim.Adam per call, render_helpers.py:353), then the list is emptied - cost
 // proportional to the touched rows, not to the table
 __global__ void k_touched_reset(const int* __restrict__ list, const int* __restrict__ count, unsigned* __restrict__ flags,
-                                float* __restrict__ g_emb, uint16_t* __restrict__ emb_m, uint16_t* __restrict__ emb_v)
+                                float* __restrict__ g_emb, uint16_t* __restrict__ emb_m, uint16_t* __restrict__ emb_v, int copies, long long copy_stride)
 {
     const long long n = (long long)*count * NL_C;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
         const int row = list[e >> 4];
         const long long i = (long long)row * NL_C + (e & 15);
         g_emb[i] = 0.0f; emb_m[i] = 0; emb_v[i] = 0;
+        for (int c = 1; c < copies; ++c) g_emb[c * copy_stride + i] = 0.0f;
         if ((e & 15) == 0) flags[row >> 5] = 0u;                     // every bit of a word belongs to a listed row: all writers store 0
     }
 }
@@ -466,8 +475,9 @@ __global__ void k_touched_count_clear(int* count) { *count = 0; }
 int nl_touched_rows_reset(const NlTouchedRows* touched, float* g_emb, void* emb_m, void* emb_v, void* stream)
 {
     if (!touched || !touched->list || !touched->count || !touched->flags || !g_emb || !emb_m || !emb_v) return NL_ERR_INVALID_ARG;
+    if (touched->copies > 1 && touched->copy_stride <= 0) return NL_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_touched_reset, dim3(1024), dim3(256), 0, (hipStream_t)stream, touched->list, touched->count, touched->flags, g_emb,
-                       (uint16_t*)emb_m, (uint16_t*)emb_v);
+                       (uint16_t*)emb_m, (uint16_t*)emb_v, touched->copies > 1 ? touched->copies : 1, touched->copy_stride);
     hipLaunchKernelGGL(k_touched_count_clear, dim3(1), dim3(1), 0, (hipStream_t)stream, touched->count);
     NL_LAUNCH_CHECK();
     return NL_OK;

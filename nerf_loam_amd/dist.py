@@ -143,6 +143,8 @@ class RayShardedExchange:
         one-rank communicator (scripts/timeline_probe.py sections 6-9: 0.449 -> 0.457 ms eager, 0.443 -> 0.440 ms replayed).  The side
         stream has DEFAULT priority: a high-priority one makes every kernel of the launch stream measure 2x slower on this ROCm
         (0.92 ms per iteration, NL_COMM_STREAM_PRIORITY=high reproduces it)."""
+        if getattr(engine, "_emb_copies_wanted", 1) != 1:
+            raise L.NerfLoamHipError("a ray-sharded engine exchanges ONE embedding-gradient array: build it with emb_grad_copies=1 (the default)")
         self.group = group
         self.overlap = bool(overlap)
         self._overlap_handles = None

@@ -142,10 +142,12 @@ def decoder_transpose_w2(params, W2T):
 
 
 def touched_rows(t):
-    """(list, count, flags) tensors -> NlTouchedRows pointer argument, None -> NULL (dense optimiser sweep)"""
+    """(list, count, flags[, copies, copy_stride]) -> NlTouchedRows pointer argument, None -> NULL (dense optimiser sweep).  copies / copy_stride: the
+    replicated accumulators of include/nerfloam_hip.h (copy c of the gradient accumulators starts copy_stride floats behind copy c - 1)"""
     if t is None:
         return None
-    return ctypes.byref(L.NlTouchedRows(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr()))
+    copies, stride = (int(t[3]), int(t[4])) if len(t) > 3 else (1, 0)
+    return ctypes.byref(L.NlTouchedRows(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), copies, stride))
 
 
 def trilinear_bwd(loss_scalars, s_vox, s_depth, s_ray, rays_d_world, rays_d_sensor, frame_id, poses12, n_frames, centres, vertex_rows,

@@ -43,6 +43,7 @@ class IterConfig:
     tail_always: bool = False          # False = reference sampler tail behaviour
 
 
+EMB_COPIES_BYTES = 4 << 30      # most memory the replicated embedding-gradient accumulators of an engine may take (SdfEngine(emb_grad_copies=))
 BYTES_PER_SAMPLE = 184         # per-sample workspace of an engine: voxel, depth, dist, ray, X[16], dX[16], sdf, dsdf, 8 ReLU words
 
 
@@ -221,7 +222,7 @@ class DecoderDevice:
 
 
 class SdfEngine:
-    def __init__(self, max_rays, samples_per_ray_cap=48, max_frames=8, device="cuda", gemm_mode=None, wgrad2_mode=None, sparse_adam=True):
+    def __init__(self, max_rays, samples_per_ray_cap=48, max_frames=8, device="cuda", gemm_mode=None, wgrad2_mode=None, sparse_adam=True, emb_grad_copies=1):
         """gemm_mode / wgrad2_mode: the decoder kernel selection of THIS engine (include/nerfloam_hip.h: 0 fp32 matrix cores,
         1 exact-product bf16 splits, ...); None = the process default (NL_GEMM_MODE / NL_WGRAD2_MODE).  Carried per call
         (NL_KERNEL_MODES), so engines with different selections coexist in one process."""
@@ -229,6 +230,10 @@ class SdfEngine:
         # sparse_adam: the embedding optimiser sweeps the rows touched since begin_call (bit-identical to the reference's dense sweep,
         # include/nerfloam_hip.h NlTouchedRows) and begin_call clears only those - False = dense sweep + E-sized memset per call
         self.sparse_adam = bool(sparse_adam)
+        # emb_grad_copies > 1: replicated gradient accumulators (NlTouchedRows.copies) - the scatter's waves add into different copies, the optimiser's
+        # sweep over the touched rows sums them: what same-address atomics on the near-sensor rows of an accumulated map cost is divided by the copies
+        # (150-scan map, 16 copies: DESIGN.md 4.7).  Only with the touched-rows optimiser, and not on a ray-sharded engine (the exchange reads one array).
+        self.emb_grad_copies = self._emb_copies_wanted = max(1, int(emb_grad_copies)) if self.sparse_adam else 1
         self._touched, self._emb_cap, self._emb_dirty_dense = None, 0, False
         self.kernel_modes = L.kernel_modes(gemm_mode, wgrad2_mode)
         self.dev = torch.device(device)
@@ -513,9 +518,14 @@ class SdfEngine:
             # gradient accumulators + moments for `cap` rows, zero-filled ONCE: a growing map (rows are appended every frame) stays
             # inside the allocation, and only rows a call touches are ever dirtied (and cleaned again through the touched-rows list)
             cap = self._emb_cap = max(E, int(1.25 * E) + 4096) if self.sparse_adam else E
-            self._emb_state = torch.zeros(2 * cap * L.NL_C, dtype=F32, device=self.dev)     # [g_emb f32 | emb_m bf16 | emb_v bf16]
+            # (copies: the requested number, halved until the accumulators fit EMB_COPIES_BYTES - 64 B per row and copy: 1.4 GB for 16 copies of the 150-scan map)
+            K = self._emb_copies_wanted
+            while K > 1 and K * cap * L.NL_C * 4 > EMB_COPIES_BYTES:
+                K //= 2
+            self.emb_grad_copies = K
+            self._emb_state = torch.zeros((K + 1) * cap * L.NL_C, dtype=F32, device=self.dev)     # [g_emb f32 x K copies | emb_m bf16 | emb_v bf16]
             self._touched = ((torch.empty(cap, dtype=I32, device=self.dev), torch.zeros(1, dtype=I32, device=self.dev),
-                              torch.zeros((cap + 31) // 32, dtype=I32, device=self.dev)) if self.sparse_adam else None)
+                              torch.zeros((cap + 31) // 32, dtype=I32, device=self.dev), K, cap * L.NL_C) if self.sparse_adam else None)
             self._emb_dirty_dense = False
             self._emb_views(E)
         else:
@@ -530,18 +540,26 @@ class SdfEngine:
                 # a fresh Adam (render_helpers.py:353): accumulators / moments / flags of the rows the PREVIOUS call touched - cost
                 # proportional to those rows, not to the table
                 ops.touched_rows_reset(self._touched, self._emb_state[:self._emb_cap * L.NL_C], self._emb_mv[:self._emb_cap * L.NL_C],
-                                       self._emb_mv[self._emb_cap * L.NL_C:])
+                                       self._emb_mv[self._emb_cap * L.NL_C:])           # (every accumulator copy of the listed rows)
             if E != self.g_emb.shape[0]:
                 self._emb_views(E)
         if dec is not None:
             dec.reset_state()
 
     def _emb_views(self, E):
-        cap = self._emb_cap
-        self.g_emb = self._emb_state[:cap * L.NL_C].view(cap, L.NL_C)[:E]
-        self._emb_mv = self._emb_state[cap * L.NL_C:].view(torch.int16)
+        cap, K = self._emb_cap, self.emb_grad_copies
+        self.g_emb = self._emb_state[:cap * L.NL_C].view(cap, L.NL_C)[:E]            # copy 0 (the only one with emb_grad_copies == 1): g_emb_total() sums the copies
+        self._emb_mv = self._emb_state[K * cap * L.NL_C:].view(torch.int16)
         self.emb_m = self._emb_mv[:cap * L.NL_C].view(cap, L.NL_C)[:E]
         self.emb_v = self._emb_mv[cap * L.NL_C:].view(cap, L.NL_C)[:E]
+
+    def g_emb_total(self):
+        """the embedding-gradient accumulators as ONE [E,16] fp32 tensor: the sum of the copies (emb_grad_copies > 1: what the optimiser's sweep forms row by row;
+        tests and probes that look at the gradient before the optimiser step)"""
+        if self.emb_grad_copies == 1:
+            return self.g_emb
+        cap, K, E = self._emb_cap, self.emb_grad_copies, self.g_emb.shape[0]
+        return self._emb_state[:K * cap * L.NL_C].view(K, cap, L.NL_C)[:, :E].sum(0)
 
     def touched_rows(self):
         """(list, count, flags) for the optimiser's sparse sweep, or None when this call sweeps the table densely: sparse_adam off, or a
@@ -728,6 +746,7 @@ class SdfEngine:
     def _desc_touched(self):
         d, t = self._desc, self._touched
         d.touched_list, d.touched_count, d.touched_flags = (None, None, None) if t is None else (t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr())
+        d.touched_copies, d.touched_copy_stride = (1, 0) if t is None else (int(t[3]), int(t[4]))
         d.sparse_sweep = int(self.touched_rows() is not None)
 
     def run_bound(self, stages=3):

@@ -65,6 +65,10 @@ def reseed():
     _PRIVATE_GEN = None
 
 
+# Replicated embedding-gradient accumulators of the API's engines (SdfEngine(emb_grad_copies=), include/nerfloam_hip.h NlTouchedRows.copies): on a map accumulated
+# over a trajectory the rows around the sensor take a contribution from every ray of a scan, and their same-address atomics are what the scatter waits for
+# (150-scan map: DESIGN.md 4.7); 1 = a single accumulator array.
+EMB_GRAD_COPIES = int(os.environ.get("NL_EMB_GRAD_COPIES", "16"))
 SAMPLE_MEMORY_FRACTION = 0.5     # of the device memory that is free when an engine is built: the most its per-sample workspace may take
 
 
@@ -91,7 +95,7 @@ def _engine(n_rays, n_frames, device, voxel_size, step_size):
         if eng is not None:
             del _ENGINES[key], eng
         cap, clipped = _samples_per_ray_cap(key[1], voxel_size, step_size, device)
-        eng = SdfEngine(max_rays=key[1], samples_per_ray_cap=cap, max_frames=key[2], device=device)
+        eng = SdfEngine(max_rays=key[1], samples_per_ray_cap=cap, max_frames=key[2], device=device, emb_grad_copies=EMB_GRAD_COPIES)
         eng.samples_clipped = clipped
         _ENGINES[key] = eng
         while len(_ENGINES) > MAX_CACHED_ENGINES:

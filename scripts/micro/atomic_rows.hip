@@ -26,6 +26,20 @@ __global__ __launch_bounds__(256) void k_rows(float* acc, unsigned distinct, uns
     }
 }
 
+// round 5: SAME-ROW contention and what replicated accumulators buy.  Of every quarter's rows a fraction `hot_pct` goes to one of `n_hot` hot rows (the
+// near-sensor voxels every ray of a scan crosses), the rest to distinct rows; with `replicas` copies of the accumulator a wave adds into copy (wave id % replicas).
+__global__ __launch_bounds__(256) void k_hot(float* acc, unsigned distinct, unsigned n_hot, unsigned hot_pct, unsigned replicas, size_t rep_stride, int per_quarter, unsigned seed)
+{
+    const unsigned q = (blockIdx.x * 256u + threadIdx.x) >> 4, c = threadIdx.x & 15;
+    const unsigned wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    float* base = acc + (size_t)(wave % replicas) * rep_stride;
+    for (int i = 0; i < per_quarter; ++i) {
+        const unsigned h = hash32(q * 977u + (unsigned)i * 7919u + seed);
+        const unsigned row = (h % 100u) < hot_pct ? (hash32(h) % n_hot) : n_hot + (hash32(h ^ 0x9E3779B9u) % distinct);
+        atomicAdd(base + (size_t)row * 16 + c, 1.0f);
+    }
+}
+
 int main()
 {
     const size_t max_rows = (size_t)1 << 24;                              // 16.8 M rows = 1 GB
@@ -60,6 +74,21 @@ int main()
                 }
                 printf("%-7s %-78s %5d workgroups: %8.1f us for %7.0f k rows = %6.2f G rows/s\n", mode == 0 ? "atomic" : "store", cs.name, blocks, best * 1e3, rows / 1e3,
                        rows / (best * 1e-3) / 1e9);
+            }
+    // hot rows: 750 workgroups x 16 quarters x 32 rows = 384 k row atomics (a 2048-ray step on the 150-scan map), 30 k cold rows
+    for (unsigned hot_pct : {0u, 10u, 30u})
+        for (unsigned n_hot : {48u, 512u})
+            for (unsigned replicas : {1u, 2u, 4u, 8u, 16u, 64u}) {
+                if (hot_pct == 0 && (replicas > 1 || n_hot > 48)) continue;
+                float best = 1e30f;
+                for (int rep = 0; rep < 4; ++rep) {
+                    hipEventRecord(e0);
+                    hipLaunchKernelGGL(k_hot, dim3(750), dim3(256), 0, 0, acc, 30000u, n_hot, hot_pct, replicas, (size_t)40000 * 16, 32, 17u + rep);
+                    hipEventRecord(e1); hipEventSynchronize(e1);
+                    float ms; hipEventElapsedTime(&ms, e0, e1);
+                    if (rep > 0 && ms < best) best = ms;
+                }
+                printf("hot     %2u %% of the rows on %3u hot rows, %2u accumulator copies: %8.1f us for 384 k row atomics\n", hot_pct, n_hot, replicas, best * 1e3);
             }
     hipFree(acc);
     return 0;

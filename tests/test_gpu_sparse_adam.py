@@ -144,3 +144,60 @@ def test_begin_call_cost_does_not_depend_on_the_table_size(golden_dir):
     # what the dense bookkeeping costs at this size (measured: begin_call 0.037 -> 0.054 ms - a 320 MB memset on top of the call's four
     # small launches -, optimiser step 0.012 -> 0.056 ms; both grow linearly with the table: x 5 at a KITTI-scale 1e7 rows)
     assert bd > bl + 0.004 and od > 3 * ol, times
+
+
+@pytest.mark.parametrize("one_call", [False, True])
+def test_replicated_accumulators_equal_a_single_array(golden_dir, one_call):
+    """SdfEngine(emb_grad_copies=K) (NlTouchedRows.copies, round 5): the scatter's waves add into K accumulator arrays, the optimiser's sweep over the touched
+    rows sums a row's copies in copy order and clears them.  Two engines in lock step - K = 8 and K = 1 -, both running their own backward pass: (i) the K arrays
+    add up to the single array's sums to fp32 round-off (the order of the atomics differs, nothing else), the same rows are touched; (ii) fed the SEQUENTIAL
+    fp32 sum of the K arrays as its accumulators, the single-array optimiser ends bit for bit where the K-copy optimiser ends - parameters, moments, and all
+    K arrays left cleared; (iii) the next call's reset clears every copy.  On a table much larger than what the rays touch."""
+    g, sc, masks, emb, dec_np, P = _scene(golden_dir, 100000)
+    pose0 = g["poses0"][0].copy()
+    ms = sc["ms"]
+    n_rays = int(masks[0].sum())
+    K = 8
+    eng = {k: P.SdfEngine(max_rays=n_rays, samples_per_ray_cap=64, max_frames=2, emb_grad_copies=c) for k, c in (("copies", K), ("single", 1))}
+    dec = {k: P.DecoderDevice(dec_np.W1, dec_np.b1, dec_np.W2, dec_np.b2, dec_np.W3, dec_np.b3) for k in eng}
+    cfg = P.IterConfig(step_size=0.1)
+    emb_t = {k: torch.from_numpy(emb.view(np.int16).copy()).cuda() for k in eng}
+    for call in range(2):
+        m = {k: P.MapDevice(ms.centres, ms.structure, ms.vertex_idx, ms.id2row, emb_t[k].cpu().numpy().view(np.uint16), ms.voxel_size) for k in eng}
+        for k in eng:
+            eng[k].set_poses(pose0[None], [1])
+            eng[k].begin_call(m[k], dec[k])
+            if one_call:
+                eng[k].bind(m[k], dec[k], cfg, train_decoder=True, skip_mode=1)
+        ec, es = eng["copies"], eng["single"]
+        assert ec.emb_grad_copies == K and es.emb_grad_copies == 1
+        cap, E = ec._emb_cap, ec.g_emb.shape[0]
+        copies = ec._emb_state[:K * cap * 16].view(K, cap, 16)
+        assert not copies.any()                                             # (iii) begin_call left every copy cleared
+        for it in ([0, 1, 2] if call == 0 else [2, 0]):
+            fr = O.select_rays(sc["points"], sc["cos"], pose0, masks[it])
+            for k in eng:
+                eng[k].set_rays(fr.rays_d, fr.points, fr.cos)
+                eng[k].run_bound(1) if one_call else eng[k].forward_backward(m[k], dec[k], cfg, train_decoder=True)
+            torch.cuda.synchronize()
+            used = int((copies[:, :E] != 0).any(2).any(1).sum())
+            assert used == K                                               # the waves really spread over the copies
+            tot, ref = ec.g_emb_total().cpu().numpy().astype(np.float64), es.g_emb.cpu().numpy().astype(np.float64)
+            assert np.abs(tot - ref).max() <= 2e-5 * np.abs(ref).max()      # (i)
+            n = {k: int(eng[k]._touched[1].item()) for k in eng}
+            rows = {k: np.sort(eng[k]._touched[0][:n[k]].cpu().numpy()) for k in eng}
+            assert np.array_equal(rows["copies"], rows["single"])
+            seq = copies[0, :E].clone()                                    # (ii) the sum the sweep forms: copy 0, then + copy 1, + copy 2, ... in fp32
+            for c in range(1, K):
+                seq = seq + copies[c, :E]
+            es.g_emb.copy_(seq); es.g_pose.copy_(ec.g_pose); dec["single"].grad.copy_(dec["copies"].grad); es.counters.copy_(ec.counters)
+            for k in eng:
+                eng[k].run_bound(2) if one_call else eng[k].optimiser_step(m[k], dec[k], cfg, skip_mode=1)
+            torch.cuda.synchronize()
+            assert not copies.any() and not es.g_emb.any()                  # every copy cleared by the sweep
+            for a_, b_ in ((m["copies"].emb, m["single"].emb), (ec.emb_m, es.emb_m), (ec.emb_v, es.emb_v), (dec["copies"].params, dec["single"].params), (ec.pose6, es.pose6)):
+                assert torch.equal(a_, b_), (call, it)
+        for k in eng:
+            emb_t[k] = m[k].emb.clone()
+    import helpers
+    helpers.record_gpu_metric("replicated_accumulators", copies=K, rows_touched=n["copies"])
