@@ -589,15 +589,16 @@ def large_map_bench(w, device, n_scans=150, spacing=3.0, iters=20):
     out = {"scans": n_scans, "spacing_m": spacing, "octree_nodes": int(len(centres)), "embedding_rows": int(E), "root_side_voxels": int(m.root_side),
            "host_build_s": round(build_s, 2), "single_scan_map_rows": w["n_rows"]}
 
-    def loop(n_rays, n_frames, train, sparse, full=False, copies=16):
+    def loop(n_rays, n_frames, train, sparse, full=False, copies=1):
         rs = np.random.default_rng(5)
         if full:
             sel, fid = np.arange(len(pts)), np.zeros(len(pts), np.int32)
         else:
             sel = np.concatenate([np.sort(rs.choice(len(pts), n_rays, replace=False)) for _ in range(n_frames)])
             fid = np.repeat(np.arange(n_frames, dtype=np.int32), n_rays)
-        # (emb_grad_copies: replicated gradient accumulators, what nerf_loam_amd.render_helpers gives its engines - the near-sensor rows of an accumulated map
-        #  take a contribution from every ray, and their same-address atomics are what the scatter waits for; the *_single_accumulator legs run without)
+        # (emb_grad_copies > 1: replicated gradient accumulators - the near-sensor rows of an accumulated map take a contribution from every ray and their
+        #  same-address atomics queue; measured in the *_16_accumulator_copies legs: the scatter gains less than the optimiser's fold over the copies costs, so the
+        #  default stays ONE array)
         eng = P.SdfEngine(max_rays=len(sel), samples_per_ray_cap=48 if full else 96, max_frames=max(2, n_frames), device=device, sparse_adam=sparse,
                           emb_grad_copies=copies if sparse else 1)
         eng.set_rays(dirs[sel], pts[sel], cos[sel], fid)
@@ -626,13 +627,12 @@ def large_map_bench(w, device, n_scans=150, spacing=3.0, iters=20):
         return r, eng
 
     out["mapping_2048x1"], eng_small = loop(2048, 1, True, True)
-    out["mapping_2048x1_single_accumulator"] = loop(2048, 1, True, True, copies=1)[0]
+    out["mapping_2048x1_16_accumulator_copies"] = loop(2048, 1, True, True, copies=16)[0]
     out["mapping_2048x1_dense_bookkeeping"] = loop(2048, 1, True, False)[0]
     out["ba_4096x4_frozen_decoder"] = loop(4096, 4, False, True)[0]
-    out["ba_4096x4_frozen_decoder_single_accumulator"] = loop(4096, 4, False, True, copies=1)[0]
+    out["ba_4096x4_frozen_decoder_16_accumulator_copies"] = loop(4096, 4, False, True, copies=16)[0]
     out["ba_4096x4_frozen_decoder_dense_bookkeeping"] = loop(4096, 4, False, False)[0]
     out["full_scan_131072"] = loop(0, 1, True, True, full=True)[0]
-    out["full_scan_131072_single_accumulator"] = loop(0, 1, True, True, full=True, copies=1)[0]
     # the pose-refine step (M2) at the shipped tracker steps on this map (and on the same trajectory at kitti's 0.3 m voxels)
     trk = {}
     for name, ts in TRACKER_SETTINGS.items():

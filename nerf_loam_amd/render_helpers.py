@@ -65,10 +65,10 @@ def reseed():
     _PRIVATE_GEN = None
 
 
-# Replicated embedding-gradient accumulators of the API's engines (SdfEngine(emb_grad_copies=), include/nerfloam_hip.h NlTouchedRows.copies): on a map accumulated
-# over a trajectory the rows around the sensor take a contribution from every ray of a scan, and their same-address atomics are what the scatter waits for
-# (150-scan map: DESIGN.md 4.7); 1 = a single accumulator array.
-EMB_GRAD_COPIES = int(os.environ.get("NL_EMB_GRAD_COPIES", "16"))
+# Replicated embedding-gradient accumulators of the API's engines (SdfEngine(emb_grad_copies=), include/nerfloam_hip.h NlTouchedRows.copies).  Default 1 = a single
+# array: on the 150-scan map 16 copies take 45 us off the scatter of a 4096 x 4 bundle adjustment (the near-sensor rows' same-address atomics) but the optimiser's
+# fold over the copies costs 64 us (bench.py large_map.*_16_accumulator_copies, profiles/experiments/README.md round 5).
+EMB_GRAD_COPIES = int(os.environ.get("NL_EMB_GRAD_COPIES", "1"))
 SAMPLE_MEMORY_FRACTION = 0.5     # of the device memory that is free when an engine is built: the most its per-sample workspace may take
 
 

@@ -87,7 +87,7 @@ def _run_pair(P, sc, masks, emb_bits, dec_np, pose0, one_call, grow_after_call=0
             assert (steps, skipped, overflow) == ((3, 0, False) if call == 0 else (3, 1, False)), k
             emb_t[k] = m[k].emb.clone()
         out[call] = state("sparse", m["sparse"])
-        lst, cnt, flags = eng["sparse"]._touched
+        lst, cnt, flags = eng["sparse"]._touched[:3]
         n = int(cnt.item())
         rows = np.sort(lst[:n].cpu().numpy())
         assert len(np.unique(rows)) == n                                    # every row listed once
