@@ -70,8 +70,9 @@ struct DecArgs {
     long long* dbg;             // optional [16 tiles][16] s_memtime stamps of workgroup 0 / thread 0 (profiling aid)
 };
 
+// (STAMPS: a template argument of k_decoder - the production instantiations carry no stamp code: eleven branches and their scalar registers per tile)
 #define DBG_STAMP(slot)                                                                          \
-    do { if (a.dbg && blockIdx.x == 0 && tid == 0 && tile_no < 16) a.dbg[tile_no * 16 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+    do { if constexpr (STAMPS) { if (a.dbg && blockIdx.x == 0 && tid == 0 && tile_no < 16) a.dbg[tile_no * 16 + (slot)] = (long long)__builtin_readcyclecounter(); } } while (0)
 
 // row of accumulator register r in a 32x32 MFMA result for this lane
 __device__ __forceinline__ int d32_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
@@ -142,14 +143,19 @@ __device__ __forceinline__ void l1_w1_fragments(const float* __restrict__ params
 
 // ---- "f16 pair" arithmetic (gemm modes 4 / 5; nl_device_math.h nl_split2_f16): an fp32 operand, scaled by a power of two and saturated at
 // the fp16 range by the caller, as hi = f16(x), lo = f16(x - hi), both round-to-nearest-even (v_cvt_pk_f16_f32); two values per call,
-// packed like the MFMA fragments want them.  6 VALU instructions per pair against ~13 for the three-term bf16 split.
+// packed like the MFMA fragments want them.  4 VALU instructions per pair against ~13 for the three-term bf16 split.
 __device__ __forceinline__ void split2_pair_f16(float a, float b, unsigned* hi, unsigned* lo)
 {
     typedef float f32x2v __attribute__((ext_vector_type(2)));
     const f32x2v v = {a, b};
-    const f16x2 h = __builtin_convertvector(v, f16x2);
-    const f32x2v r = {a - (float)h[0], b - (float)h[1]};
-    *hi = __builtin_bit_cast(unsigned, h); *lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+    // residuals a - (float)h.lo16, b - (float)h.hi16: v_fma_mix_f32 reads the fp16 half as an operand (fma(h, -1, a): the exact difference, one
+    // instruction instead of a conversion and a subtraction; the compiler does not select it by itself)
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(b));
+    const f32x2v r = {r0, r1};
+    *hi = h; *lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
 __device__ __forceinline__ float sat_f16(float x) { return __builtin_amdgcn_fmed3f(x, -NL_F16_MAX, NL_F16_MAX); }
 // layer 1 as f16 pairs: this lane's B fragments, W1[col][8 lh + e] * 2^8 (e = 0..7)
@@ -554,7 +560,8 @@ __device__ __forceinline__ float halfwave_rowsum(const f32x16& h0, const f32x16&
     return dpp_add(up ? v2[1] : v2[0], up ? v2[0] : v2[1], 3);
 }
 
-template <bool TRAIN, bool XG, int NP = 9>               // NP: partial products of the forward GEMM - 9 / 8 / 6: three-term bf16 splits (gemm_x9), 3 / 4: fp16 pairs (gemm_f16); XG: the 256-deep GEMMs on the 16-bit matrix cores
+template <bool TRAIN, bool XG, int NP = 9, bool STAMPS = false>     // NP: partial products of the forward GEMM - 9 / 8 / 6: three-term bf16 splits (gemm_x9), 3 / 4: fp16 pairs (gemm_f16); XG: the 256-deep GEMMs on the 16-bit
+                                                         // matrix cores; STAMPS: per-phase cycle stamps of workgroup 0 (scripts/phase_probe.py: nl_decoder_set_debug_buffer)
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[S_ALLOC];
@@ -832,9 +839,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             for (int r = 0; r < 16; ++r) {
                 const float ds0 = dsb[D32_RR(r)], ds1 = dsb[32 + D32_RR(r)];
                 const bool on0 = h0[r] > 0.f, on1 = h1[r] > 0.f;
-                const float g0 = on0 ? ds0 * w3c : 0.f, g1 = on1 ? ds1 * w3c : 0.f;
-                if (!XG) { db[D32_RR(r) * LDH] = g0; db[(32 + D32_RR(r)) * LDH] = g1; }
-                if (TRAIN) { aW3 = fmaf(ds0, h0[r], aW3); aW3 = fmaf(ds1, h1[r], aW3); aB2 += g0; aB2 += g1; }
+                if (!XG) { db[D32_RR(r) * LDH] = on0 ? ds0 * w3c : 0.f; db[(32 + D32_RR(r)) * LDH] = on1 ? ds1 * w3c : 0.f; }
+                // db2[col] = w3[col] * sum_i [H2 > 0] dsdf_i: the factor is applied once, at the flush (one select + one add per value here)
+                if (TRAIN) { aW3 = fmaf(ds0, h0[r], aW3); aW3 = fmaf(ds1, h1[r], aW3); aB2 += on0 ? ds0 : 0.f; aB2 += on1 ? ds1 : 0.f; }
                 if (XG || TRAIN) mw |= (on0 ? (1u << r) : 0u) | (on1 ? (1u << (16 + r)) : 0u);
             }
             if (XG) {
@@ -947,6 +954,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
                     fb[buf][0] = *reinterpret_cast<const uint4*>(bp + s8 * 2048); fb[buf][1] = *reinterpret_cast<const uint4*>(bp + s8 * 2048 + 1024);
                 };
                 fetch(0, 0);
+                const float4 dsv = *reinterpret_cast<const float4*>(sdS + opaque(16 * w + 4 * lq));      // dsdf of this lane's four rows: one read, under the loop
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
                     const int cur = s8 & 1;
@@ -959,11 +967,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const f32x4 cx = cxa + cxb;
-                const float* dsr = sdS + opaque(16 * w + 4 * lq);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int g = row0 + 16 * w + 4 * lq + r;
-                    if (g < P) a.dX[(size_t)g * NL_C + l15] = cx[r] * (dsr[r] * (1.0f / (NL_F16_SG * NL_F16_SW1)));
+                    if (g < P) a.dX[(size_t)g * NL_C + l15] = cx[r] * ((&dsv.x)[r] * (1.0f / (NL_F16_SG * NL_F16_SW1)));
                 }
             }
         } else {
@@ -1079,7 +1086,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
                     base[NL_OFF_W1 + (hb + 16 * t + 4 * lq + r) * NL_C + l15] = accW1[t][r];
         }
         aW3 += __shfl_xor(aW3, 32); aB2 += __shfl_xor(aB2, 32); aB1 += __shfl_xor(aB1, 32);
-        if (lh == 0) { base[NL_OFF_W3 + col] = aW3; base[NL_OFF_B2 + col] = aB2; if (!F16) base[NL_OFF_B1 + col] = aB1; }
+        if (lh == 0) { base[NL_OFF_W3 + col] = aW3; base[NL_OFF_B2 + col] = aB2 * w3c; if (!F16) base[NL_OFF_B1 + col] = aB1; }
         if (tid < 64) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { aB3 += __shfl_xor(aB3, off); dsMax = fmaxf(dsMax, __shfl_xor(dsMax, off)); }
@@ -1618,7 +1625,15 @@ int nl_decoder_fwd_bwd_m(const void* loss_scalars, const float* X, const float* 
     a.dcounters = (double*)(counters + NL_CNT_INTS);
     a.dbg = g_dec_dbg;
     const dim3 g(nslabs), b(DEC_THREADS);
-    if (km.gemm == 4) {
+    if (a.dbg && (km.gemm == 4 || km.gemm == 3)) {           // phase probe: the stamped instantiations of the default and of the exact-product arithmetic
+        if (km.gemm == 4) {
+            if (train_decoder) hipLaunchKernelGGL((k_decoder<true, true, 3, true>), g, b, 0, (hipStream_t)stream, a);
+            else               hipLaunchKernelGGL((k_decoder<false, true, 3, true>), g, b, 0, (hipStream_t)stream, a);
+        } else {
+            if (train_decoder) hipLaunchKernelGGL((k_decoder<true, true, 8, true>), g, b, 0, (hipStream_t)stream, a);
+            else               hipLaunchKernelGGL((k_decoder<false, true, 8, true>), g, b, 0, (hipStream_t)stream, a);
+        }
+    } else if (km.gemm == 4) {
         if (train_decoder) hipLaunchKernelGGL((k_decoder<true, true, 3>), g, b, 0, (hipStream_t)stream, a);
         else               hipLaunchKernelGGL((k_decoder<false, true, 3>), g, b, 0, (hipStream_t)stream, a);
     } else if (km.gemm == 5) {
