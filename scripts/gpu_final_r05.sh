@@ -1,0 +1,16 @@
+#!/usr/bin/env bash
+# round-5 end-of-round call: the whole -m gpu suite, smoke, the DEFAULT bench line, rocprofv3 kernel stats of the bench, PMC passes, decoder phase stamps
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp
+OUT=gpurun_out; mkdir -p $OUT
+TAG=${1:-r05_z}
+t0=$(date +%s)
+timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=6 > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$? ($(( $(date +%s) - t0 )) s)"; tail -12 $OUT/${TAG}_pytest_gpu.log | cut -c1-300
+timeout 300 python __graft_entry__.py smoke > $OUT/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/${TAG}_smoke.log
+timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?"; tail -2 $OUT/${TAG}_bench.err
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o prof -- python ${GRAFT_REPO_ROOT:-/root/repo}/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-steady-state --no-parity --no-api-path --no-large-map > /tmp/prof_$TAG.log 2>&1 ; echo "rocprof rc=$?" )
+cp $(find /tmp/prof_$TAG -name "*kernel_stats*.csv" | head -1) $OUT/${TAG}_kernel_stats.csv 2>/dev/null; cut -d, -f1-4 $OUT/${TAG}_kernel_stats.csv | head -16
+bash scripts/gpu_pmc.sh ${TAG}pmc > $OUT/${TAG}_pmc.log 2>&1; tail -30 $OUT/${TAG}_pmc.log | cut -c1-260
+timeout 300 python scripts/phase_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_phases.txt; cat $OUT/${TAG}_phases.txt
+timeout 300 python scripts/large_map_legs.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_large_map_legs.txt

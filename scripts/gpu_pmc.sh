@@ -13,6 +13,8 @@ run() { # name, counters...
   tail -2 /tmp/pmc_${TAG}_$name.log
 }
 run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE
+# (round 5: the default decoder arithmetic issues fp16 matrix instructions - their own counter, in its own pass so that an unknown counter name cannot take the others down)
+run mfma16 SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 python - <<'PY'

@@ -36,6 +36,10 @@ def big(values, ref=None):
 
 def main(prefix, out):
     mf, fe, wr = load(prefix + "_mfma_counters.csv"), load(prefix + "_fetch_counters.csv"), load(prefix + "_write_counters.csv")
+    try:
+        m16 = load(prefix + "_mfma16_counters.csv")               # (round 5: SQ_INSTS_VALU_MFMA_MOPS_F16, its own pass)
+    except OSError:
+        m16 = {}
     res = {}
     for k in sorted(mf):
         if not k.startswith("k_"):
@@ -51,6 +55,7 @@ def main(prefix, out):
                   "mfma_busy_frac": (busy / (1024.0 * xcd)) if busy is not None and xcd else None,
                   "mfma_mops_f32": sel(mf[k].get("SQ_INSTS_VALU_MFMA_MOPS_F32", [])),
                   "mfma_mops_bf16": sel(mf[k].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", [])),
+                  "mfma_mops_f16": big(m16.get(k, {}).get("SQ_INSTS_VALU_MFMA_MOPS_F16", [])) if m16 else None,
                   "fetch_kb": f, "write_kb": w_,
                   "hbm_bytes_per_launch": (2 * f + w_) * 1024.0 if f is not None and w_ is not None else None}
     json.dump(res, open(out, "w"), indent=1)
