@@ -14,3 +14,13 @@ cp $(find /tmp/prof_$TAG -name "*kernel_stats*.csv" | head -1) $OUT/${TAG}_kerne
 bash scripts/gpu_pmc.sh ${TAG}pmc > $OUT/${TAG}_pmc.log 2>&1; tail -30 $OUT/${TAG}_pmc.log | cut -c1-260
 timeout 300 python scripts/phase_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_phases.txt; cat $OUT/${TAG}_phases.txt
 timeout 300 python scripts/large_map_legs.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_large_map_legs.txt
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$TAG -o tl -- python ${GRAFT_REPO_ROOT:-/root/repo}/scripts/timeline_probe.py run > ${GRAFT_REPO_ROOT:-/root/repo}/$OUT/${TAG}_timeline_run.log 2>&1; echo "timeline rc=$?" )
+python scripts/timeline_probe.py parse $(find /tmp/tl_$TAG -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_timeline.txt 2>&1; grep -v amdgpu.ids $OUT/${TAG}_timeline_run.log | tail -14 | cut -c1-220
+timeout 600 python bench.py --rccl-world1 --no-cpu-baseline --no-api-path --no-large-map --no-settings --no-pmc > $OUT/${TAG}_bench_rccl_world1.json 2> $OUT/${TAG}_bench_rccl_world1.err; echo "rccl-world1 bench rc=$?"; python - <<PY
+import json
+try:
+    d = json.loads(open("$OUT/${TAG}_bench_rccl_world1.json").read().strip().splitlines()[-1])
+    print("rccl-world1: ms/step %.4f" % d["ms_per_step"], {k: v for k, v in d.get("sharded", {}).items() if k in ("launch_mode", "ms_per_step_without_exchanges", "exchange_ms_per_step", "embedding_exchange")})
+except Exception as e:
+    print("rccl-world1 parse failed", e)
+PY
