@@ -45,7 +45,7 @@ FLOPS_PER_SAMPLE_WGRAD2 = G                                    # dW2: 131 072
 
 
 def matrix_pipe_model(kernel, gemm_mode, wgrad2_mode, train):
-    """(algorithmic flops, executed fp32-MFMA flops, executed bf16-MFMA flops) per sample of `kernel`."""
+    """(algorithmic flops, executed fp32-MFMA flops, executed 16-bit (bf16 or fp16: same rate) MFMA flops) per sample of `kernel`."""
     if kernel == "decoder":
         alg = FLOPS_PER_SAMPLE_DECODER if train else FLOPS_PER_SAMPLE_DECODER_FROZEN
         small = L1 * (3 if train else 2)                        # layer-1 forward, dX, (dW1)
@@ -68,7 +68,7 @@ def roofline_entry(name, kernel, ms, P_local, gemm_mode, wgrad2_mode, train):
     ach = P_local * alg / (ms * 1e-3) / 1e12
     peak = alg / t_bound / 1e12
     return {"kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "avg_launch_ms": ms,
-            "flops_per_launch": P_local * alg, "mfma_flops_executed_per_launch": {"f32": P_local * f32, "bf16": P_local * b16},
+            "flops_per_launch": P_local * alg, "mfma_flops_executed_per_launch": {"f32": P_local * f32, "16bit": P_local * b16},
             "matrix_pipe_bound_ms": P_local * t_bound * 1e3}
 
 
