@@ -107,6 +107,15 @@ int nl_ray_intersect_scan_lanes(int N, const float* rays_d_sensor, const float* 
                                 const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
                                 float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
                                 int* counters, int* ray_of_rank, int* hit_rank, int* total_out, int* total_out2, int* scan_ws, int lanes, void* stream);
+/* nl_ray_intersect_scan_lanes + nl_dist_x1_pack: the ray-sharded iteration's first stage with the send block of its first exchange
+ * (x1_send = [counter block | x1_rays bytes: the hit count of ray i, 0 beyond N]; x1_rays >= N, a multiple of 16; total_out must be
+ * counters + 0, the block's hit-ray slot).  Between 4097 and 32 768 rays - a rank's share of a scan - the scan's own launch packs the block
+ * (its workgroups hold the hit counts anyway, its last one the total): one ~5 us launch fewer on the rank's critical path. */
+int nl_ray_intersect_scan_x1(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
+                             const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
+                             float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
+                             int* counters, int* ray_of_rank, int* hit_rank, int* total_out, int* total_out2, int* scan_ws, int lanes,
+                             int* x1_send, int x1_rays, void* stream);
 
 /* LidarFrame.get_rays (src/lidarFrame.py:47-52): rays_d[M,3] = points / (||points||_2 + 1e-8), rays_norm[M] (optional) = that
  * denominator - the arithmetic of the reference's host torch ops, bit for bit (nl_device_math.h nl_unit_dir).  The selection entry
@@ -445,8 +454,10 @@ int nl_comm_init_rccl(NlComm* out, void* nccl_comm, int world, int rank);
  *  emb_pose:        grouped SUM all-reduce of the fp64 pose partials (want_pose_grad) and the embedding accumulators (want_emb_grad): dense,
  *                   or the union's rows packed into rows_buf, reduced, unpacked (rows_mode 1)
  *  decoder:         SUM all-reduce of the decoder gradient (train_decoder)
- *  gradients:       emb_pose + decoder on one stream */
+ *  gradients:       emb_pose + decoder on one stream
+ *  after_intersect_packed: after_intersect without its pack launch, for a send block nl_ray_intersect_scan_x1 already filled */
 int nl_exchange_after_intersect(const NlIterDesc* desc, void* stream);
+int nl_exchange_after_intersect_packed(const NlIterDesc* desc, void* stream);
 int nl_exchange_after_sampling(const NlIterDesc* desc, void* stream);
 int nl_exchange_emb_pose(const NlIterDesc* desc, void* stream);
 int nl_exchange_decoder(const NlIterDesc* desc, void* stream);

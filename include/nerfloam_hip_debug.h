@@ -20,6 +20,7 @@ int nl_decoder_get_wgrad2_mode(void);
 
 int nl_geometry_set_sampler_mode(int mode);     /* nl_sample_rays: 0 = sequential walk per ray, 1 = step-parallel, 2 = by ray count (default); same results */
 int nl_geometry_set_intersect_prune(int on);    /* nl_ray_intersect (tests): 0 = rays with more hits than the work-list kernel's list holds go to the sequential fallback instead of being pruned to the first 20 in place; 1 = default */
+int nl_geometry_set_scan_single(int on);        /* prefix scans of 4097 .. 32 768 items: 1 = one launch (k_scan_single, default), 0 = the two launches of larger scans (equality tests, A/B) */
 int nl_geometry_set_lanes_per_ray(int lpr);     /* nl_ray_intersect: 0 = the caller's choice / by ray count (default), or 4 / 8 / 16 / 32 lanes per ray for every call */
 int nl_geometry_set_debug_buffer(void* dbg);   /* [blocks][8] int64 stamps of nl_ray_intersect's work-list kernel */
 int nl_field_set_debug_buffer(void* dbg);      /* [blocks][8] int64 stamps of nl_trilinear_bwd's workgroups */

@@ -122,6 +122,7 @@ _SIGS = {
     "nl_sample_rays_fused": ([_I] + [_P] * 8 + [_F, _F, _F, _U, _I, _I, _I] + [_P] * 4 + [_I] + [_P] * 5 + [_F, _F, _P, _P, _P], _I),
     "nl_ray_intersect_scan": ([_I] + [_P] * 7 + [_I, _F, _F] + [_P] * 13, _I),
     "nl_ray_intersect_scan_lanes": ([_I] + [_P] * 7 + [_I, _F, _F] + [_P] * 12 + [_I, _P], _I),
+    "nl_ray_intersect_scan_x1": ([_I] + [_P] * 7 + [_I, _F, _F] + [_P] * 12 + [_I, _P, _I, _P], _I),
     "nl_gather_trilinear": ([_P] * 7 + [_I] + [_P] * 3 + [_F, _P, _I, _P], _I),
     "nl_gather_points": ([_I] + [_P] * 5 + [_F, _P, _P], _I),
     "nl_decoder_fwd_bwd": ([_P] * 13 + [_I, _I, _P, _P], _I),
@@ -138,6 +139,7 @@ _SIGS = {
     "nl_geometry_set_debug_buffer": ([_P], _I),
     "nl_geometry_set_lanes_per_ray": ([_I], _I),
     "nl_geometry_set_intersect_prune": ([_I], _I),
+    "nl_geometry_set_scan_single": ([_I], _I),
     "nl_geometry_set_sampler_mode": ([_I], _I),
     "nl_dist_merge_counters": ([_P, _I, _I, _I, _P, _P], _I),
     "nl_unit_dirs": ([_I, _P, _P, _P, _P], _I),
@@ -168,6 +170,7 @@ _SIGS = {
     "nl_dist_rows_move_t": ([_I, _P, _P, _I, _P, _P, _I, _P, _P, _P], _I),
     "nl_comm_init_rccl": ([_P, _P, _I, _I], _I),
     "nl_exchange_after_intersect": ([_P, _P], _I),
+    "nl_exchange_after_intersect_packed": ([_P, _P], _I),
     "nl_exchange_after_sampling": ([_P, _P], _I),
     "nl_exchange_gradients": ([_P, _P], _I),
     "nl_dist_merge_counters_strided": ([_P, _I, _I, _I, _I, _P, _P], _I),
@@ -214,6 +217,8 @@ def lib():
                 raise NerfLoamHipError("NL_GEMM_MODE must be 0 .. 5")
         if os.environ.get("NL_SAMPLER_MODE"):
             L.nl_geometry_set_sampler_mode(int(os.environ["NL_SAMPLER_MODE"]))
+        if os.environ.get("NL_SCAN_SINGLE"):                # A/B switch: 0 = mid-size prefix scans as two launches
+            L.nl_geometry_set_scan_single(int(os.environ["NL_SCAN_SINGLE"]))
         if os.environ.get("NL_LANES_PER_RAY"):              # A/B switch for measurements: lanes per ray of the work-list intersect
             L.nl_geometry_set_lanes_per_ray(int(os.environ["NL_LANES_PER_RAY"]))
         if os.environ.get("NL_FIELD_MIDSPAN_FLUSH"):        # A/B switch for measurements (nl_field_set_midspan_flush)

@@ -142,20 +142,23 @@ __global__ __launch_bounds__(X1_THREADS) void k_x1_merge(const unsigned char* __
         __syncthreads();
         int before = 0, total = 0;
         for (int k = 0; k < X1_THREADS / 64; ++k) { const int u = s_wave[k]; if (k < w) before += u; total += u; }
-        int q = q_block + before + incl - mine;                   // global hit rank of this thread's first hit ray
+        const int q = q_block + before + incl - mine;             // global hit rank of this thread's first hit ray
+        // (batch row, position in the row) of that ray: ONE division per thread and pass, then counted up (sixteen `q / L`, `q % L` pairs by a
+        // run-time divisor were most of this kernel's 10 us on a rank's share)
+        int qrow = q / L, within = q - qrow * L;
+        bool first = q == 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int c = (int)((wd[j] >> (8 * k)) & 255u);
                 if (!c) continue;
-                if (q == 0) s_cnt0 = c;
-                const int within = q % L;
+                if (first) { s_cnt0 = c; first = false; }
                 if (within % NL_SAMPLER_CHUNK == 0) {
-                    const int e = (q / L) * nch + within / NL_SAMPLER_CHUNK;
+                    const int e = qrow * nch + within / NL_SAMPLER_CHUNK;
                     if (e < n_entries) x1_write_row(table, e, c);
                 }
-                ++q;
+                if (++within == L) { within = 0; ++qrow; }
             }
         q_block += total;
     }

@@ -117,7 +117,7 @@ int nl_comm_init_rccl(NlComm* out, void* nccl_comm, int world, int rank)
     return X_OK;
 }
 
-int nl_exchange_after_intersect(const NlIterDesc* d, void* stream)
+static int after_intersect(const NlIterDesc* d, void* stream, bool pack)
 {
     if (!d || !comm_ok(d->comm) || !d->counters || !d->hit_count || !d->x1_send || !d->x1_recv || d->x1_rays < d->N || (d->x1_rays & 15) ||
         d->x1_stride_bytes < CNT_STRIDE * 4 + d->x1_rays || (d->x1_stride_bytes & 15) || !d->row_first || d->row_first_entries <= 0)
@@ -125,10 +125,13 @@ int nl_exchange_after_intersect(const NlIterDesc* d, void* stream)
     const NlComm* c = d->comm;
     // ONE all-gather of [counter block | a byte per ray: its hit count]; the row-first table of the sampler's tail quirk follows from the
     // gathered counts on every rank (nl_dist.hip k_x1_merge) - no second collective
-    X_TRY(nl_dist_x1_pack(d->counters, d->hit_count, d->N, d->x1_rays, (int*)d->x1_send, stream));
+    if (pack) X_TRY(nl_dist_x1_pack(d->counters, d->hit_count, d->N, d->x1_rays, (int*)d->x1_send, stream));
     X_TRY(c->all_gather(c->ctx, d->x1_send, d->x1_recv, d->x1_stride_bytes, stream));
     return nl_dist_x1_merge(d->x1_recv, d->x1_stride_bytes, c->world, c->rank, d->x1_rays, d->counters, d->row_first, d->row_first_entries, stream);
 }
+int nl_exchange_after_intersect(const NlIterDesc* d, void* stream) { return after_intersect(d, stream, true); }
+// (the send block was filled by nl_ray_intersect_scan_x1: nl_iteration's sequence)
+int nl_exchange_after_intersect_packed(const NlIterDesc* d, void* stream) { return after_intersect(d, stream, false); }
 
 int nl_exchange_after_sampling(const NlIterDesc* d, void* stream)
 {

@@ -824,6 +824,87 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_hits_fused(DfsArgs a, i
     scan_one_block(a.hit_count, hit_rank, a.N, 1, ray_of_rank, total_out, total_out2);
 }
 
+// Mid-size inputs (NL_SCAN_ONE_BLOCK_MAX < n <= NL_SCAN_SINGLE_MAX: a rank's share of a scan, 4096-ray x 4-frame bundle adjustment) as ONE
+// launch of up to 8 workgroups of 1024 threads: a workgroup first sums the (flagged) items of all workgroups in front of it itself - at most
+// 7 x 16 KB out of L2, seven 16-byte loads per thread - then scans its own 4096.  The two-launch version pays a second ~4.9 us launch for
+// the same result; the redundant reads cost ~1 us.  The launch's LAST workgroup knows the grand total and can do what a launch of its own
+// did before: the loss normalisers (nl_scan_samples_finalize) or the send block of exchange 1 (nl_dist_x1_pack: one byte per ray = its hit
+// count, clamped to 255, + the counter block), whose bytes every workgroup packs from the items it holds anyway.
+#define NL_SCAN1_THREADS 1024
+#define NL_SCAN1_BLOCK (NL_SCAN1_THREADS * NL_SCAN_ITEMS)
+#define NL_SCAN_SINGLE_MAX 32768
+__device__ __forceinline__ void loss_finalize_one(int* __restrict__ counters, NlLossScalars* __restrict__ ls,
+                                                  float fs_weight, float sdf_weight, float tau, float max_depth, int capacity);
+struct ScanTail {
+    int* counters; NlLossScalars* ls; float fs_weight, sdf_weight, tau, max_depth; int capacity; int finalize;   // finalize: loss_finalize_one by the last workgroup
+    int* pack_send; int pack_cap;                                                                               // pack_send: [counter block | pack_cap bytes]
+};
+__global__ __launch_bounds__(NL_SCAN1_THREADS) void k_scan_single(const int* __restrict__ in, int* __restrict__ out, int n, int flag_mode,
+                                                                   int* __restrict__ ray_of_rank, int* total_out, int* total_out2,      // (may point into t.counters)
+                                                                   ScanTail t)
+{
+    __shared__ int s_wave[NL_SCAN1_THREADS / 64], s_part[NL_SCAN1_THREADS / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int base = b * NL_SCAN1_BLOCK + tid * NL_SCAN_ITEMS;
+    int raw[NL_SCAN_ITEMS];
+    if (base + NL_SCAN_ITEMS <= n) {
+        const int4 q = *reinterpret_cast<const int4*>(in + base);
+        raw[0] = q.x; raw[1] = q.y; raw[2] = q.z; raw[3] = q.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < NL_SCAN_ITEMS; ++i) raw[i] = base + i < n ? in[base + i] : 0;
+    }
+    int part = 0;                                                   // items of the workgroups in front (all of them whole: b * 4096 < n)
+    for (int j = tid * NL_SCAN_ITEMS; j < b * NL_SCAN1_BLOCK; j += NL_SCAN1_BLOCK) {
+        const int4 q = *reinterpret_cast<const int4*>(in + j);
+        part += flag_mode ? (q.x > 0) + (q.y > 0) + (q.z > 0) + (q.w > 0) : q.x + q.y + q.z + q.w;
+    }
+    int v[NL_SCAN_ITEMS], sum = 0;
+#pragma unroll
+    for (int i = 0; i < NL_SCAN_ITEMS; ++i) { v[i] = flag_mode ? (raw[i] > 0 ? 1 : 0) : raw[i]; sum += v[i]; }
+    int inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(inc, off); if (lane >= off) inc += u; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 63) s_wave[wid] = inc;
+    if (lane == 0) s_part[wid] = part;
+    __syncthreads();
+    int before = 0, tot = 0, add = 0;
+#pragma unroll
+    for (int w = 0; w < NL_SCAN1_THREADS / 64; ++w) { const int u = s_wave[w]; if (w < wid) before += u; tot += u; add += s_part[w]; }
+    int ex = add + before + inc - sum;
+#pragma unroll
+    for (int i = 0; i < NL_SCAN_ITEMS; ++i) {
+        if (base + i < n) {
+            out[base + i] = ex;
+            if (ray_of_rank && v[i] > 0) ray_of_rank[ex] = base + i;
+        }
+        ex += v[i];
+    }
+    unsigned* const send_bytes = t.pack_send ? reinterpret_cast<unsigned*>(t.pack_send + NL_CNT_INTS + 2 * NL_CNT_DOUBLES) : nullptr;
+    if (send_bytes && base < t.pack_cap) {                          // (pack_cap is a multiple of 16: a thread's four bytes are inside or outside together)
+        unsigned w = 0u;
+#pragma unroll
+        for (int i = 0; i < NL_SCAN_ITEMS; ++i) w |= (unsigned)(raw[i] < 0 ? 0 : (raw[i] > 255 ? 255 : raw[i])) << (8 * i);
+        send_bytes[base >> 2] = w;
+    }
+    if (b != (int)gridDim.x - 1) return;
+    if (send_bytes)                                                 // rays of the send block beyond this launch's items (another rank's shard is longer)
+        for (int j = (int)gridDim.x * NL_SCAN1_BLOCK + tid * NL_SCAN_ITEMS; j < t.pack_cap; j += NL_SCAN1_BLOCK) send_bytes[j >> 2] = 0u;
+    if (tid == 0) {
+        const int total = add + tot;
+        *total_out = total;
+        if (total_out2) *total_out2 = total;
+        if (t.finalize) loss_finalize_one(t.counters, t.ls, t.fs_weight, t.sdf_weight, t.tau, t.max_depth, t.capacity);
+    }
+    if (t.pack_send) {
+        __threadfence_block();
+        __syncthreads();                                            // the totals are in the counter block
+        if (tid < NL_CNT_INTS + 2 * NL_CNT_DOUBLES) t.pack_send[tid] = reinterpret_cast<volatile const int*>(t.counters)[tid];
+    }
+}
+
 // ray_of_rank[rank] = ray  for rays with hit_count > 0   (the reference's boolean-mask compaction
 // of hit rays, render_helpers.py:219-227)
 __global__ void k_compact_hit_rays(int N, const int* __restrict__ hit_count, const int* __restrict__ hit_rank,
@@ -1565,12 +1646,16 @@ int nl_inverse_cdf_sampling(const int* pts_idx, const float* min_depth, const fl
 }
 
 static int scan_launch(const int* in, int* out, int n, int flag_mode, int* ray_of_rank, int* total_out, int* total_out2, int* workspace,
-                       void* stream);
+                       void* stream, const ScanTail* tail = nullptr, bool* tail_done = nullptr);
+
+// (nl_dist.hip; the product header is not included by the kernel files)
+int nl_dist_x1_pack(const int* counters, const int* hit_count, int N, int n_rays_cap, int* send, void* stream);
 
 static int intersect_launch(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
                             const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
                             float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
-                            int* counters, int* scratch_rays, int* hit_rank, int* total_out, int* total_out2, int* scan_ws, int lanes, void* stream)
+                            int* counters, int* scratch_rays, int* hit_rank, int* total_out, int* total_out2, int* scan_ws, int lanes, void* stream,
+                            int* x1_send = nullptr, int x1_rays = 0)
 {
     if (lanes != 0 && lanes != 4 && lanes != 8 && lanes != 16 && lanes != 32) return NL_ERR_INVALID_ARG;
     if (N <= 0 || !rays_d_sensor || !points_gt || !cos_gt || !poses || !blk_ids || !blk_hdr || root_side < 2 || !rays_d_world || !gt_dist ||
@@ -1592,12 +1677,19 @@ static int intersect_launch(int N, const float* rays_d_sensor, const float* poin
     if (hit_rank && N <= NL_SCAN_ONE_BLOCK_MAX) {        // launch-bound regime: fallback + hit-ray scan in one launch
         hipLaunchKernelGGL(k_scan_hits_fused, dim3(1), dim3(NL_GEO_THREADS), 0, st, da, hit_rank, scratch_rays, total_out, total_out2);
         NL_LAUNCH_CHECK();
-        return NL_OK;
+        return x1_send ? nl_dist_x1_pack(counters, hit_count, N, x1_rays, x1_send, stream) : NL_OK;
     }
     hipLaunchKernelGGL(k_ray_intersect_dfs, dim3(32), dim3(NL_GEO_THREADS), 0, st, da);
     NL_LAUNCH_CHECK();
-    if (hit_rank) return scan_launch(hit_count, hit_rank, N, 1, scratch_rays, total_out, total_out2, scan_ws, stream);
-    return NL_OK;
+    if (!hit_rank) return NL_OK;
+    // ray-sharded iteration: the send block of exchange 1 (a byte per ray + the counter block) is packed by the scan's own launch where that is
+    // the single-launch kernel (a rank's share of a scan), by nl_dist_x1_pack behind it otherwise
+    ScanTail tail = {};
+    tail.counters = counters; tail.pack_send = x1_send; tail.pack_cap = x1_rays;
+    bool packed = false;
+    const int rc = scan_launch(hit_count, hit_rank, N, 1, scratch_rays, total_out, total_out2, scan_ws, stream, x1_send ? &tail : nullptr, &packed);
+    if (rc != NL_OK || !x1_send || packed) return rc;
+    return nl_dist_x1_pack(counters, hit_count, N, x1_rays, x1_send, stream);
 }
 
 int nl_ray_intersect(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
@@ -1640,12 +1732,37 @@ int nl_ray_intersect_scan_lanes(int N, const float* rays_d_sensor, const float* 
                             gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, ray_of_rank, hit_rank, total_out, total_out2, scan_ws, lanes, stream);
 }
 
+/* nl_ray_intersect_scan_lanes + nl_dist_x1_pack (the send block of the ray-sharded iteration's first exchange: x1_send = [counter block |
+ * x1_rays bytes], x1_rays >= N a multiple of 16): between 4097 and 32 768 rays the scan's launch packs the block itself */
+int nl_ray_intersect_scan_x1(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
+                             const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
+                             float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,
+                             int* counters, int* ray_of_rank, int* hit_rank, int* total_out, int* total_out2, int* scan_ws, int lanes,
+                             int* x1_send, int x1_rays, void* stream)
+{
+    if (!hit_rank || !total_out || !scan_ws || !x1_send || x1_rays < N || (x1_rays & 15)) return NL_ERR_INVALID_ARG;
+    if (total_out != counters + NLC_R) return NL_ERR_INVALID_ARG;      // the packed counter block must already hold the hit-ray total
+    return intersect_launch(N, rays_d_sensor, points_gt, cos_gt, frame_id, poses, blk_hdr, blk_ids, root_side, voxel_size, max_distance, rays_d_world,
+                            gt_dist, hit_idx, hit_t0, hit_t1, hit_count, counters, ray_of_rank, hit_rank, total_out, total_out2, scan_ws, lanes, stream,
+                            x1_send, x1_rays);
+}
+
+static std::atomic<int> g_scan_single{1};           // 0: mid-size scans as two launches (the pre-round-5 path; A/B and equality tests)
+
+// `tail`: work a launch of its own would do behind the scan (ScanTail); *tail_done says whether this scan did it (only the single-launch
+// kernel can: the caller issues the separate launch otherwise)
 static int scan_launch(const int* in, int* out, int n, int flag_mode, int* ray_of_rank, int* total_out, int* total_out2,
-                       int* workspace, void* stream)
+                       int* workspace, void* stream, const ScanTail* tail, bool* tail_done)
 {
     hipStream_t s = (hipStream_t)stream;
+    if (tail_done) *tail_done = false;
     if (n <= NL_SCAN_ONE_BLOCK_MAX) {
         hipLaunchKernelGGL(k_scan_one_block, dim3(1), dim3(NL_GEO_THREADS), 0, s, in, out, n, flag_mode, ray_of_rank, total_out, total_out2);
+    } else if (n <= NL_SCAN_SINGLE_MAX && g_scan_single.load(std::memory_order_relaxed) && !((uintptr_t)in & 15)) {
+        ScanTail t = {};
+        if (tail) { t = *tail; if (tail_done) *tail_done = true; }
+        hipLaunchKernelGGL(k_scan_single, dim3(nl_div_up(n, NL_SCAN1_BLOCK)), dim3(NL_SCAN1_THREADS), 0, s, in, out, n, flag_mode, ray_of_rank, total_out,
+                           total_out2, t);
     } else {
         const int nb = nl_div_up(n, NL_SCAN_BLOCK);
         hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(NL_GEO_THREADS), 0, s, in, out, workspace, n, flag_mode);
@@ -1677,6 +1794,8 @@ int nl_geometry_set_sampler_mode(int mode) { if (mode < 0 || mode > 2) return NL
 
 /* lanes per ray of the work-list intersect kernel: 0 = the caller's choice, else by ray count (32 up to 4096 rays, 16 up to 16 384, else 8), or 4 / 8 / 16 / 32 for every call */
 int nl_geometry_set_intersect_prune(int on) { g_isect_prune = on ? 1 : 0; return NL_OK; }
+/* A/B / test aid: 0 = scans of 4097 .. 32 768 items as two launches (k_scan_blocks + k_scan_finish, the pre-round-5 path), 1 = one launch (default) */
+int nl_geometry_set_scan_single(int on) { g_scan_single = on ? 1 : 0; return NL_OK; }
 int nl_geometry_set_lanes_per_ray(int lpr) { if (lpr != 0 && lpr != 4 && lpr != 8 && lpr != 16 && lpr != 32) return NL_ERR_INVALID_ARG; g_isect_lpr = lpr; return NL_OK; }
 
 /* profiling aid: device buffer [blocks][8] int64: cycle stamps (start, after set-up, after traversal, after finalise) and the
@@ -1804,8 +1923,12 @@ int nl_scan_samples_finalize(const int* samp_count, int* samp_off, int N, int* c
         NL_LAUNCH_CHECK();
         return NL_OK;
     }
-    const int rc = scan_launch(samp_count, samp_off, N, 0, nullptr, counters + NLC_P, nullptr, workspace, stream);
-    if (rc != NL_OK) return rc;
+    ScanTail tail = {};
+    tail.counters = counters; tail.ls = (NlLossScalars*)loss_scalars; tail.fs_weight = fs_weight; tail.sdf_weight = sdf_weight; tail.tau = tau;
+    tail.max_depth = max_depth; tail.capacity = capacity; tail.finalize = 1;
+    bool finalized = false;                              // (up to NL_SCAN_SINGLE_MAX rays the scan's last workgroup writes the loss scalars)
+    const int rc = scan_launch(samp_count, samp_off, N, 0, nullptr, counters + NLC_P, nullptr, workspace, stream, &tail, &finalized);
+    if (rc != NL_OK || finalized) return rc;
     return nl_loss_finalize(counters, loss_scalars, fs_weight, sdf_weight, tau, max_depth, capacity, stream);
 }
 

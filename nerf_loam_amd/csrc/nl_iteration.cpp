@@ -26,8 +26,8 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
     // stream, and later work on `stream` cannot race the all-reduce that may be in flight on the accumulators
     auto leave = [&](int code) {
         if (forked) {
-            hipEventRecord((hipEvent_t)d->ev_join, (hipStream_t)d->comm_stream);
-            hipStreamWaitEvent(st, (hipEvent_t)d->ev_join, 0);
+            (void)hipEventRecord((hipEvent_t)d->ev_join, (hipStream_t)d->comm_stream);
+            (void)hipStreamWaitEvent(st, (hipEvent_t)d->ev_join, 0);
             forked = false;
         }
         return code;
@@ -39,6 +39,13 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
         // (counters_copy + counters_clean, set by the host after a stages == 3 call), by a memset launch otherwise
         if (!(d->counters_copy && d->counters_clean) &&
             hipMemsetAsync(c, 0, NL_CNT_INTS * 4 + NL_CNT_DOUBLES * 8, st) != hipSuccess) return IT_ERR_LAUNCH;
+        const bool x1_fused = sharded && d->x1_send && d->x1_rays >= d->N && !(d->x1_rays & 15);     // (a bad block is reported by the exchange below)
+        if (x1_fused)
+            NL_TRY(nl_ray_intersect_scan_x1(d->N, d->rays_d_sensor, d->points_gt, d->cos_gt, d->frame_id, d->poses12, d->blk_hdr, d->blk_ids, d->root_side,
+                                            d->voxel_size, d->max_distance, d->rays_d_world, d->gt_dist, d->hit_idx, d->hit_t0, d->hit_t1, d->hit_count, c,
+                                            d->ray_of_rank, d->hit_rank, c + IT_R, c + IT_R_GLOBAL, d->scan_ws, d->isect_lanes, (int*)d->x1_send, d->x1_rays,
+                                            stream));
+        else
         NL_TRY(nl_ray_intersect_scan_lanes(d->N, d->rays_d_sensor, d->points_gt, d->cos_gt, d->frame_id, d->poses12, d->blk_hdr, d->blk_ids, d->root_side,
                                            d->voxel_size, d->max_distance, d->rays_d_world, d->gt_dist, d->hit_idx, d->hit_t0, d->hit_t1, d->hit_count, c,
                                            d->ray_of_rank, d->hit_rank, c + IT_R, c + IT_R_GLOBAL, d->scan_ws, d->isect_lanes, stream));
@@ -46,7 +53,7 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
         if (sharded) {
             // exchange 1 -> global hit ranks + the batch rows' first-ray hit lists; count, scan, emit on the local rays; exchange 2 ->
             // global loss normalisers (+ the union of the touched embedding rows)
-            NL_TRY(nl_exchange_after_intersect(d, stream));
+            NL_TRY(x1_fused ? nl_exchange_after_intersect_packed(d, stream) : nl_exchange_after_intersect(d, stream));
             for (int emit = 0; emit < 2; ++emit) {
                 NL_TRY(nl_sample_rays(emit, d->N, d->hit_idx, d->hit_t0, d->hit_t1, d->hit_count, d->hit_rank, d->ray_of_rank, d->cos_gt, d->gt_dist,
                                       d->step_size, d->truncation, d->max_distance, d->noise_seed, d->use_hash_noise, d->tail_always, d->ray_id_base,
