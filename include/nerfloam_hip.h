@@ -99,6 +99,9 @@ int nl_ray_intersect_scan(int N, const float* rays_d_sensor, const float* points
  * pay on an ACCUMULATED map only, where a ray crosses many occupied voxels and has more than 16 nodes pending per round (150-scan map:
  * 16 384 rays 120 -> 95 us; a one-scan map 41 -> 65): the host side passes 32 for maps of >= 60 000 children blocks there
  * (nerf_loam_amd/pipeline.py MapDevice.isect_lanes_for); NlIterDesc.isect_lanes carries the same choice. */
+/* the lanes-per-ray choice itself (csrc/nl_common.h: the launch-shape table): 32 up to 4096 rays; up to 16 384 rays 32 on a map of >= 60 000
+ * children blocks, else 16; 8 beyond.  n_children_blocks 0 = unknown (the rule by ray count alone). */
+int nl_isect_lanes_for(int n_rays, int n_children_blocks);
 int nl_ray_intersect_lanes(int N, const float* rays_d_sensor, const float* points_gt, const float* cos_gt, const int* frame_id,
                            const float* poses, const void* blk_hdr, const void* blk_ids, int root_side, float voxel_size, float max_distance,
                            float* rays_d_world, float* gt_dist, int* hit_idx, float* hit_t0, float* hit_t1, int* hit_count,

@@ -122,6 +122,7 @@ _SIGS = {
     "nl_sample_rays_fused": ([_I] + [_P] * 8 + [_F, _F, _F, _U, _I, _I, _I] + [_P] * 4 + [_I] + [_P] * 5 + [_F, _F, _P, _P, _P], _I),
     "nl_ray_intersect_scan": ([_I] + [_P] * 7 + [_I, _F, _F] + [_P] * 13, _I),
     "nl_ray_intersect_scan_lanes": ([_I] + [_P] * 7 + [_I, _F, _F] + [_P] * 12 + [_I, _P], _I),
+    "nl_isect_lanes_for": ([_I, _I], _I),
     "nl_ray_intersect_scan_x1": ([_I] + [_P] * 7 + [_I, _F, _F] + [_P] * 12 + [_I, _P, _I, _P], _I),
     "nl_gather_trilinear": ([_P] * 7 + [_I] + [_P] * 3 + [_F, _P, _I, _P], _I),
     "nl_gather_points": ([_I] + [_P] * 5 + [_F, _P, _P], _I),

@@ -12,6 +12,18 @@
 #define NL_ERR_NO_DEVICE 3
 #define NL_ERR_CAPACITY 4
 
+// ---------------------------------------------------------------------------------------------
+// Launch shapes by ray count: THE table.  Every entry is a measured crossover (the profile that fixed it in brackets); the code that
+// selects a launch shape (nl_geometry.hip intersect_launch / scan_launch / nl_sample_rays*, nl_iteration.cpp, pipeline.py through
+// nl_isect_lanes_for) reads these names and nothing else.
+// ---------------------------------------------------------------------------------------------
+#define NL_RAYS_ONE_WORKGROUP_SCAN 4096     // <=: hit-ray scan (+ the DFS fallback) and sample-offset scan (+ the loss scalars) by ONE workgroup (r01_m timeline)
+#define NL_RAYS_SINGLE_LAUNCH_SCAN 32768    // <=: those scans as one launch of <= 8 workgroups that sum what is in front of them; beyond: two launches (r05_s)
+#define NL_RAYS_FUSED_SAMPLER      8192     // <=: count pass + scan + normalisers + emit pass as ONE launch, step-parallel count pass (r01_l, r03_e)
+#define NL_RAYS_ISECT_32_LANES     4096     // <=: 32 lanes per ray in the work-list intersect on every map (r04_n)
+#define NL_RAYS_ISECT_16_LANES     16384    // <=: 16 lanes per ray - 32 on a map of >= NL_BLOCKS_WIDE_MAP children blocks -, 8 beyond (r01_k, r04_n)
+#define NL_BLOCKS_WIDE_MAP         60000    // children blocks from which a ray's front is wider than 16 nodes per round (40 scans / 71 k blocks gain, 15 / 38 k lose)
+
 // device counter block: int32[NL_CNT_INTS] followed (8-byte aligned) by double[NL_CNT_DOUBLES]
 enum {
     NLC_R = 0,          // number of rays with >=1 hit

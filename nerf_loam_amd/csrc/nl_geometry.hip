@@ -775,7 +775,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_finish(const int* __res
 // Whole scan in ONE launch for small inputs (tracking: 2048 rays): one block walks the input in chunks of 1024 with a carry,
 // ~1 us per chunk behind a ~4.8 us launch; the two-launch version costs 2 x 4.8 us at any of these sizes, so it wins from
 // 5 chunks on (16 384 rays: 20.8 us in one block, profiles/r01_m_timeline_latency_bound_steps.txt).
-#define NL_SCAN_ONE_BLOCK_MAX 4096
+#define NL_SCAN_ONE_BLOCK_MAX NL_RAYS_ONE_WORKGROUP_SCAN
 __device__ __forceinline__ int scan_one_block(const int* __restrict__ in, int* __restrict__ out, int n, int flag_mode,
                                               int* __restrict__ ray_of_rank, int* __restrict__ total_out, int* __restrict__ total_out2)
 {
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(NL_GEO_THREADS) void k_scan_hits_fused(DfsArgs a, i
 // count, clamped to 255, + the counter block), whose bytes every workgroup packs from the items it holds anyway.
 #define NL_SCAN1_THREADS 1024
 #define NL_SCAN1_BLOCK (NL_SCAN1_THREADS * NL_SCAN_ITEMS)
-#define NL_SCAN_SINGLE_MAX 32768
+#define NL_SCAN_SINGLE_MAX NL_RAYS_SINGLE_LAUNCH_SCAN
 __device__ __forceinline__ void loss_finalize_one(int* __restrict__ counters, NlLossScalars* __restrict__ ls,
                                                   float fs_weight, float sdf_weight, float tau, float max_depth, int capacity);
 struct ScanTail {
@@ -1648,6 +1648,14 @@ int nl_inverse_cdf_sampling(const int* pts_idx, const float* min_depth, const fl
 static int scan_launch(const int* in, int* out, int n, int flag_mode, int* ray_of_rank, int* total_out, int* total_out2, int* workspace,
                        void* stream, const ScanTail* tail = nullptr, bool* tail_done = nullptr);
 
+/* lanes per ray of the work-list intersect by ray count and map size (nl_common.h: the launch-shape table); n_children_blocks 0 = unknown */
+int nl_isect_lanes_for(int n_rays, int n_children_blocks)
+{
+    if (n_rays <= NL_RAYS_ISECT_32_LANES) return 32;
+    if (n_rays <= NL_RAYS_ISECT_16_LANES) return n_children_blocks >= NL_BLOCKS_WIDE_MAP ? 32 : 16;
+    return 8;
+}
+
 // (nl_dist.hip; the product header is not included by the kernel files)
 int nl_dist_x1_pack(const int* counters, const int* hit_count, int N, int n_rays_cap, int* send, void* stream);
 
@@ -1665,7 +1673,7 @@ static int intersect_launch(int N, const float* rays_d_sensor, const float* poin
     // idle and 32 lanes cost nothing (one-scan map 2048 rays ~35 -> 30 us, 5 / 15 / 40 / 150 scans 39 -> 31, 61 -> 45, 94 -> 54, 122 -> 71); beyond, 32 lanes
     // mean twice the workgroups and only maps whose rays have wide fronts gain (profiles/r04_n_intersect_lanes_ab.txt)
     const int forced = g_isect_lpr.load(std::memory_order_relaxed);
-    const int lpr = forced ? forced : lanes ? lanes : (N <= 4096 ? 32 : N <= 16384 ? 16 : 8);
+    const int lpr = forced ? forced : lanes ? lanes : nl_isect_lanes_for(N, 0);
     auto kq = lpr == 32 ? k_ray_intersect_q<32> : lpr == 16 ? k_ray_intersect_q<16> : lpr == 8 ? k_ray_intersect_q<8> : k_ray_intersect_q<4>;
     const int IQ_RAYS = NL_GEO_THREADS / lpr;
     hipLaunchKernelGGL(kq, dim3(nl_div_up(N, IQ_RAYS)), dim3(NL_GEO_THREADS), 0, st,
@@ -1835,7 +1843,7 @@ int nl_sample_rays(int emit, int N, const int* hit_idx, const float* hit_t0, con
     // against 15.3), the count pass in the latency-bound regime only - beyond 8192 rays its 1024 workgroups x 10 same-line atomics and
     // the extra threads cost more than the shorter chains save (16 384 rays: 19.5 against 15.5 us, 131 072: 77 against 24)
     const int smode = g_sampler_mode.load(std::memory_order_relaxed);
-    if (smode == 1 || (smode == 2 && (emit || N <= 8192))) {
+    if (smode == 1 || (smode == 2 && (emit || N <= NL_RAYS_FUSED_SAMPLER))) {
         const int nbk = nl_div_up(N, SP_RAYS) < 1024 ? nl_div_up(N, SP_RAYS) : 1024;
         if (emit) hipLaunchKernelGGL(k_sample_par<true>, dim3(nbk), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);
         else      hipLaunchKernelGGL(k_sample_par<false>, dim3(nbk), dim3(NL_GEO_THREADS), 0, (hipStream_t)stream, a);
@@ -1862,7 +1870,7 @@ int nl_sample_rays_fused(int N, const int* hit_idx, const float* hit_t0, const f
 {
     if (N <= 0 || !hit_idx || !hit_t0 || !hit_t1 || !hit_count || !hit_rank || !ray_of_rank || !cos_gt || !gt_dist || !counters || !samp_count ||
         !samp_off || !s_vox || !s_depth || !s_dist || !s_ray || !loss_scalars || !scan_ws) return NL_ERR_INVALID_ARG;
-    if (N > 8192 || !state) {                             // (16 384 rays measured: +0.03 ms against the four launches of the sequential sampler)
+    if (N > NL_RAYS_FUSED_SAMPLER || !state) {                             // (16 384 rays measured: +0.03 ms against the four launches of the sequential sampler)
         int rc = nl_sample_rays(0, N, hit_idx, hit_t0, hit_t1, hit_count, hit_rank, ray_of_rank, cos_gt, gt_dist, step_size, tau, max_depth, seed,
                                 use_hash_noise, tail_always, ray_id_base, seed_mix, nullptr, counters, samp_count, nullptr, capacity, nullptr, nullptr,
                                 nullptr, nullptr, stream);

@@ -57,7 +57,6 @@ def samples_per_ray_bound(voxel_size, step_size, max_hits=L.NL_MAX_HITS):
     return int(math.ceil(max_hits * math.sqrt(3.0) * float(voxel_size) / float(step_size))) + int(max_hits) + 1
 
 
-ISECT_WIDE_BLOCKS = 60_000       # children blocks from which MapDevice.isect_lanes_for gives a ray 32 lanes at 4097 .. 16 384 rays
 
 
 def pack_children_blocks(centres, structure):
@@ -146,7 +145,7 @@ class MapDevice:
         15 scans / 38 k blocks 68 -> 80, a one-scan map 41 -> 65) -, 0 = by ray count otherwise (32 lanes up to 4096 rays on every map, 16 up to
         16 384, 8 beyond)."""
         blk = getattr(self, "blk_hdr", None)
-        return 32 if blk is not None and blk.shape[0] >= ISECT_WIDE_BLOCKS and n_rays <= 16384 else 0
+        return int(L.lib().nl_isect_lanes_for(int(n_rays), int(blk.shape[0]) if blk is not None else 0))     # (the one table: csrc/nl_common.h)
 
     @classmethod
     def from_tensors(cls, centres, structure, vertex_idx, id2row, emb_bf16, voxel_size, device="cuda", traversal=True):

@@ -102,6 +102,24 @@ def test_header_constants_match_binding():
     assert int(consts["NL_LOSS_SCALARS_BYTES"]) == _lib.NL_LOSS_SCALARS_BYTES
 
 
+def test_launch_shape_table_is_one_table():
+    """the ray-count thresholds that pick a launch shape live in csrc/nl_common.h only; the lanes-per-ray rule the host side follows is the
+    library's (a pure host function: no device needed), and no source file repeats a threshold as a literal in a comparison"""
+    lib = _lib.lib()
+    table = dict(re.findall(r"#define\s+(NL_(?:RAYS|BLOCKS)_[A-Z0-9_]+)\s+(\d+)", open(os.path.join(ROOT, "nerf_loam_amd", "csrc", "nl_common.h")).read()))
+    assert set(table) == {"NL_RAYS_ONE_WORKGROUP_SCAN", "NL_RAYS_SINGLE_LAUNCH_SCAN", "NL_RAYS_FUSED_SAMPLER", "NL_RAYS_ISECT_32_LANES",
+                          "NL_RAYS_ISECT_16_LANES", "NL_BLOCKS_WIDE_MAP"}
+    r32, r16, wide = int(table["NL_RAYS_ISECT_32_LANES"]), int(table["NL_RAYS_ISECT_16_LANES"]), int(table["NL_BLOCKS_WIDE_MAP"])
+    for n, blocks, want in [(1, 0, 32), (r32, 0, 32), (r32 + 1, 0, 16), (r32 + 1, wide, 32), (r16, wide - 1, 16), (r16, wide, 32), (r16 + 1, wide, 8),
+                            (131072, 10 * wide, 8)]:
+        assert lib.nl_isect_lanes_for(n, blocks) == want, (n, blocks)
+    for f in ("nl_geometry.hip", "nl_iteration.cpp"):
+        src = open(os.path.join(ROOT, "nerf_loam_amd", "csrc", f)).read()
+        code = re.sub(r"//[^\n]*|/\*.*?\*/", "", src, flags=re.S)
+        assert not re.search(r"\bN\s*(<=|>|<|>=)\s*(4096|8192|16384|32768)\b", code), f
+    assert "60_000" not in open(os.path.join(ROOT, "nerf_loam_amd", "pipeline.py")).read()
+
+
 def test_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
