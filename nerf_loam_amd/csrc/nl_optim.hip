@@ -169,11 +169,13 @@ __device__ __forceinline__ void optim_note_skip(const int* __restrict__ counters
     state[2] = state[2] + 1;
     if (counters[NLC_OVERFLOW] != 0) state[3] = 1;
 }
-// end of an iteration: hand the counter block to the host-visible copy and leave it zeroed for the next iteration (one thread)
-__device__ __forceinline__ void counters_hand_over(int* __restrict__ src, int* __restrict__ dst)
+// end of an iteration: hand the counter block to the host-visible copy and leave it zeroed for the next iteration.  Called by the first
+// NL_CNT_BYTES / 4 threads of a workgroup AFTER a barrier behind the last read of the block: one word each (one thread walking the 24 words
+// put ~2.5 us of dependent round trips at the end of every launch-bound iteration)
+__device__ __forceinline__ void counters_hand_over(int* src, int* __restrict__ dst, int tid)
 {
-    if (!src || !dst) return;
-    for (int i = 0; i < NL_CNT_BYTES / 4; ++i) { dst[i] = src[i]; src[i] = 0; }
+    if (!src || !dst || tid >= NL_CNT_BYTES / 4) return;
+    dst[tid] = src[tid]; src[tid] = 0;
 }
 #define OPT_DEC_REST (NL_DEC_PARAMS - NL_W * NL_W - NL_W)            // W1, b1, b2, b3 (w3 rides with the W2 rows)
 #define OPT_DEC_BLOCKS (NL_W + (OPT_DEC_REST + 255) / 256)
@@ -196,7 +198,12 @@ __global__ void __launch_bounds__(256) k_optim_step(OptimArgs a)
             const int f = (b - a.nb_emb - a.nb_dec) * 256 + tid;
             if (f < a.F) for (int i = 0; i < 12; ++i) a.g_pose[12 * f + i] = 0.0;
         }
-        if (gridDim.x == 1) { __syncthreads(); if (tid == 0) { optim_note_skip(a.counters, a.state); counters_hand_over(a.snap_src, a.snap_dst); } }
+        if (gridDim.x == 1) {
+            __syncthreads();
+            if (tid == 0) optim_note_skip(a.counters, a.state);
+            __syncthreads();                                           // (optim_note_skip reads the overflow word)
+            counters_hand_over(a.snap_src, a.snap_dst, tid);
+        }
         return;
     }
     if (tid == 0) s_h = nl_adam_hyper(role == 0 ? a.lr_emb : (role == 1 ? a.lr_dec : a.lr_pose), step, 0.9, 0.999, 1e-8);
@@ -270,20 +277,23 @@ __global__ void __launch_bounds__(256) k_optim_step(OptimArgs a)
         const int f = (b - a.nb_emb - a.nb_dec) * 256 + tid;
         if (f < a.F) pose_step_one(f, a.pose6, a.g_pose, a.pm, a.pv, a.enable, a.grad6_out, a.poses12, h, a.apply_pose);
     }
-    if (gridDim.x == 1 && tid == 0) {                                // (every thread read the state / counter words before the barrier above)
-        a.state[0] = step;
-        counters_hand_over(a.snap_src, a.snap_dst);
+    if (gridDim.x == 1) {                                            // (every thread read the state / counter words before the barrier above)
+        if (tid == 0) a.state[0] = step;
+        counters_hand_over(a.snap_src, a.snap_dst, tid);
     }
 }
 
 // advance the step counter after a multi-workgroup k_optim_step (a last-workgroup ticket costs more than this launch: thousands
 // of same-address device-scope atomics, profiles/r01_m_optimiser_step.txt)
-__global__ void k_adam_advance(int* __restrict__ state, const int* __restrict__ counters, int skip_mode, int* __restrict__ snap_src,
+__global__ void k_adam_advance(int* __restrict__ state, const int* counters, int skip_mode, int* snap_src,      // (snap_src IS the counter block)
                                int* __restrict__ snap_dst)
 {
-    if (optim_skip(counters, state, skip_mode)) optim_note_skip(counters, state);
-    else state[0] = state[0] + 1;
-    counters_hand_over(snap_src, snap_dst);
+    if (threadIdx.x == 0) {
+        if (optim_skip(counters, state, skip_mode)) optim_note_skip(counters, state);
+        else state[0] = state[0] + 1;
+    }
+    __syncthreads();
+    counters_hand_over(snap_src, snap_dst, threadIdx.x);
 }
 
 // Multi-GPU (nerf_loam_amd/dist.py): every rank all-gathers its whole counter block (one small collective) and this kernel
@@ -438,7 +448,7 @@ int nl_optimiser_step_t(int* state, double lr_emb, double lr_dec, double lr_pose
     const int nb_pose = pose6 ? nl_div_up(F, 256) : 0;
     const int nb = a.nb_emb + a.nb_dec + nb_pose;
     hipLaunchKernelGGL(k_optim_step, dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
-    if (nb > 1) hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, state, counters, skip_mode, a.snap_src, a.snap_dst);
+    if (nb > 1) hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(64), 0, (hipStream_t)stream, state, counters, skip_mode, a.snap_src, a.snap_dst);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }
