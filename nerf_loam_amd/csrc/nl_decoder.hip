@@ -259,23 +259,31 @@ __device__ __forceinline__ void gemm_mask_x(i32x4 rsX, int w, int lane, const un
 // Rolled variant for the trainable-decoder kernel (no scheduling barriers, so no spills at its 256-VGPR limit): the k-steps go
 // through a rolled loop in pairs with two register buffers, like gemm256 - a load issued in one half of the body cannot be
 // sunk below the MFMAs of that half because its consumers sit in the other half.  bq[0], bq[1] arrive preloaded.
-template <bool F16 = false>
+template <bool F16 = false, int HS = 2>                 // HS: k-steps per register buffer - the B fragments of a buffer are requested HS k-steps (HS x 256 cycles with the SIMD's
+                                                        // other wave) before their first use.  2 at the register limit of the bf16 kernels; 4 in the fp16-pair kernel since its ReLU bits
+                                                        // left the scalar file (243 -> 199 registers): an L2 hit takes ~800 cycles, two k-steps did not cover it (phase F 4.9 k cycles
+                                                        // against 2.8 k in the frozen kernel's pinned loop)
 __device__ __forceinline__ void gemm_mask_x_rolled(i32x4 rsX, int w, int lane, const unsigned char* sM, uint4 (&bq)[MX_RING][3], f32x16& c0, f32x16& c1)
 {
-    static_assert(MX_PRE == 2, "the rolled loop consumes the two pre-barrier stages as its first buffer");
+    static_assert(MX_PRE == 2, "the rolled loop consumes the two pre-barrier stages first");
+    static_assert(HS == 2 || HS == 4, "16 k-steps in two buffers of HS");
     const int l31 = lane & 31, lh = lane >> 5;
     const int voff = lane * 16;
     const int kt_off = __builtin_amdgcn_readfirstlane(w) * 16 * 1024;
     const unsigned char* a0 = sM + opaque(l31 * (SM_STRIDE * 2) + 16 * lh);
     constexpr int NPL = F16 ? 2 : 3;
-    uint4 bA[2][3], bB[2][3];
+    uint4 bA[HS][3], bB[HS][3];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int p = 0; p < NPL; ++p) bA[t][p] = bq[t][p];
-    auto steps2 = [&](const uint4 (&b)[2][3], const unsigned char* ap) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+    for (int t = 2; t < HS; ++t)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) bA[t][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + kt_off + t * 1024);
+    auto steps = [&](const uint4 (&b)[HS][3], const unsigned char* ap) {
+#pragma unroll
+        for (int t = 0; t < HS; ++t) {
             const uint4 fa0 = *reinterpret_cast<const uint4*>(ap + 32 * t);
             const uint4 fa1 = *reinterpret_cast<const uint4*>(ap + 32 * SM_STRIDE * 2 + 32 * t);
 #pragma unroll
@@ -286,20 +294,20 @@ __device__ __forceinline__ void gemm_mask_x_rolled(i32x4 rsX, int w, int lane, c
         }
     };
 #pragma unroll 1
-    for (int s = 0; s < 16; s += 4) {
+    for (int s = 0; s < 16; s += 2 * HS) {
         const int so = kt_off + s * 1024;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < HS; ++t)
 #pragma unroll
-            for (int p = 0; p < NPL; ++p) bB[t][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + so + (2 + t) * 1024);
-        steps2(bA, a0 + 32 * s);
-        if (s + 4 < 16) {
+            for (int p = 0; p < NPL; ++p) bB[t][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + so + (HS + t) * 1024);
+        steps(bA, a0 + 32 * s);
+        if (s + 2 * HS < 16) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < HS; ++t)
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) bA[t][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + so + (4 + t) * 1024);
+                for (int p = 0; p < NPL; ++p) bA[t][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + so + (2 * HS + t) * 1024);
         }
-        steps2(bB, a0 + 32 * (s + 2));
+        steps(bB, a0 + 32 * (s + HS));
     }
 }
 
@@ -444,6 +452,18 @@ __device__ __forceinline__ float dpp_swap1(float v)
 }
 __device__ __forceinline__ unsigned dpp_swap1u(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
 
+// [v > 0] as the integer 0 / 1 in ONE instruction: the bit pattern clamped to [0, 1] as a signed integer (positive floats are positive
+// integers, +0 is 0, everything with the sign bit is negative).  Written as an instruction because the compiler turns min(max(x, 0), 1) back into
+// compare + select: a v_cmp puts the result in a scalar register PAIR, and the thirty-two ReLU bits of a lane became 64 live scalar registers
+// (53 of them spilled to vector lanes: ~130 v_readlane / v_writelane per wave and tile) or thirty-two vector registers kept alive for a deferred
+// compare (round 5: the H1 values from phase B to phase F).
+__device__ __forceinline__ unsigned pos_bit(float v)
+{
+    unsigned b;
+    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(b) : "v"(v));
+    return b;
+}
+
 // maximum of a non-negative value over the wave: four DPP steps inside the 16-lane rows, then the four rows through scalar registers
 // (no LDS round trips: __shfl_xor is a ds_bpermute, ~100 cycles each on a latency chain)
 __device__ __forceinline__ float wave_max_nonneg(float v)
@@ -501,7 +521,7 @@ __device__ __forceinline__ unsigned store_h1_planes_f16(unsigned short* sP, int 
         for (int r = 0; r < 16; r += 2) {
             const float ha = __builtin_amdgcn_fmed3f(fmaf(sub ? c1[r] : c0[r], S1, b1s), 0.f, NL_F16_MAX);
             const float hb = __builtin_amdgcn_fmed3f(fmaf(sub ? c1[r + 1] : c0[r + 1], S1, b1s), 0.f, NL_F16_MAX);
-            m1 |= ((ha > 0.f) ? (1u << (16 * sub + r)) : 0u) | ((hb > 0.f) ? (1u << (16 * sub + r + 1)) : 0u);
+            m1 |= (pos_bit(ha) << (16 * sub + r)) | (pos_bit(hb) << (16 * sub + r + 1));
             const float got = dpp_swap1(odd ? ha : hb);            // even lane: the odd lane's row r; odd lane: the even lane's row r + 1
             const float lo_k = odd ? got : ha, hi_k = odd ? hb : got;      // columns (k, k + 1) of this lane's row
             unsigned q0, q1;
@@ -838,11 +858,15 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float ds0 = dsb[D32_RR(r)], ds1 = dsb[32 + D32_RR(r)];
-                const bool on0 = h0[r] > 0.f, on1 = h1[r] > 0.f;
-                if (!XG) { db[D32_RR(r) * LDH] = on0 ? ds0 * w3c : 0.f; db[(32 + D32_RR(r)) * LDH] = on1 ? ds1 * w3c : 0.f; }
-                // db2[col] = w3[col] * sum_i [H2 > 0] dsdf_i: the factor is applied once, at the flush (one select + one add per value here)
-                if (TRAIN) { aW3 = fmaf(ds0, h0[r], aW3); aW3 = fmaf(ds1, h1[r], aW3); aB2 += on0 ? ds0 : 0.f; aB2 += on1 ? ds1 : 0.f; }
-                if (XG || TRAIN) mw |= (on0 ? (1u << r) : 0u) | (on1 ? (1u << (16 + r)) : 0u);
+                if constexpr (!XG) {
+                    const bool on0 = h0[r] > 0.f, on1 = h1[r] > 0.f;
+                    db[D32_RR(r) * LDH] = on0 ? ds0 * w3c : 0.f; db[(32 + D32_RR(r)) * LDH] = on1 ? ds1 * w3c : 0.f;
+                }
+                // the ReLU bits as integers 0 / 1 (pos_bit: no compare, no scalar lane masks)
+                const unsigned on0 = pos_bit(h0[r]), on1 = pos_bit(h1[r]);
+                // db2[col] = w3[col] * sum_i [H2 > 0] dsdf_i: the factor is applied once, at the flush; ds * 1 + acc and ds * 0 + acc are the adds they replace, bit for bit
+                if (TRAIN) { aW3 = fmaf(ds0, h0[r], aW3); aW3 = fmaf(ds1, h1[r], aW3); aB2 = fmaf(ds0, (float)on0, aB2); aB2 = fmaf(ds1, (float)on1, aB2); }
+                if (XG || TRAIN) mw |= (on0 << r) | (on1 << (16 + r));
             }
             if (XG) {
                 // the 0/1 mask itself, as bf16, is the dgrad A operand.  Neighbouring lanes = neighbouring columns of the same rows: with
@@ -870,8 +894,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { g0v[r] = 0.f; g1v[r] = 0.f; }
-            if (F16 && TRAIN) gemm_mask_x_rolled<true>(rsW2H, w, lane, reinterpret_cast<const unsigned char*>(lds), bqm, g0v, g1v);
-            else if (F16)    gemm_mask_x<true, true>(rsW2H, w, lane, reinterpret_cast<const unsigned char*>(lds), bqm, g0v, g1v);
+            if (F16 && TRAIN) gemm_mask_x_rolled<true, 4>(rsW2H, w, lane, reinterpret_cast<const unsigned char*>(lds), bqm, g0v, g1v);
+            else if (F16)    gemm_mask_x<true, true>(rsW2H, w, lane, reinterpret_cast<const unsigned char*>(lds), bqm, g0v, g1v);     // (pinned: the trainable kernel has the registers since its ReLU bits left the scalar file, 243 -> 199)
             else if (XG && TRAIN) gemm_mask_x_rolled(rsW2X, w, lane, reinterpret_cast<const unsigned char*>(lds), bqm, g0v, g1v);
             else if (XG)     gemm_mask_x<true>(rsW2X, w, lane, reinterpret_cast<const unsigned char*>(lds), bqm, g0v, g1v);
             else    gemm256(rsW2, (lh * NL_W + col) * 4, sD + l31 * LDH + lh, sD + (32 + l31) * LDH + lh, g0v, g1v);
