@@ -23,6 +23,8 @@ flops / 157.3 TF + executed bf16-MFMA flops / 2500 TF).  `frac` = achieved / pea
 launch during which the matrix pipes would be busy if nothing else limited the kernel.
 """
 import argparse
+import contextlib
+import gc
 import json
 import os
 import sys
@@ -30,6 +32,20 @@ import time
 
 import numpy as np
 import torch
+
+
+@contextlib.contextmanager
+def no_gc():
+    """host-timed regions run with the cyclic garbage collector off (what `timeit` does): a generation-2 pass over the ~10^6 objects torch's import
+    leaves behind takes tens of milliseconds - one such pause inside the 20 timed steps doubled a whole run's ms_per_step (profiles/r05_v_*)"""
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -801,6 +817,9 @@ def main():
     ap.add_argument("--rccl-world1", action="store_true", help="run the ray-sharded code path (RCCL communicator, exchanges inside nl_iteration) "
                                                                 "on ONE GPU with a world-size-1 process group: what a 1-GPU box can check of --gpus N")
     args = ap.parse_args()
+    # the cyclic garbage collector stays off for the whole run (every leg below is host-timed; no_gc() collects at the start of the main ones): its
+    # generation-2 passes showed up as one ~60 ms pause per few hundred steps in every run's per-block timings, and once inside the 20 timed steps
+    gc.disable()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -851,18 +870,15 @@ def main():
     train_dec = not args.frozen_decoder
     eng.begin_call(w["map"], w["dec"])
 
-    if shard:
-        # ray-sharded: ONE C call per iteration (nl_iteration: kernels + the four RCCL collectives on the launch stream)
-        eng.bind(w["map"], w["dec"], cfg, train_decoder=train_dec, update_decoder=train_dec, ray_id_base=lo)
+    # ONE C call per iteration (nl_iteration; ray-sharded: kernels + the four RCCL collectives on the launch stream).  The host enqueues a whole
+    # step in ~50 us - the 20 timed steps are in the queue 1-2 ms after the clock starts, and nothing that happens to the launching thread
+    # afterwards (a ~40 ms pause of it once doubled a run's ms_per_step when every stage was a Python call: profiles/r05_v_*) can starve the device
+    eng.bind(w["map"], w["dec"], cfg, train_decoder=train_dec, update_decoder=train_dec, ray_id_base=lo)
 
     graph = [None]
 
     def step():
-        if shard:
-            graph[0].replay() if graph[0] is not None else eng.run_bound()
-            return
-        eng.forward_backward(w["map"], w["dec"], cfg, train_decoder=train_dec, ray_id_base=lo)
-        eng.optimiser_step(w["map"], w["dec"], cfg, update_decoder=train_dec)
+        graph[0].replay() if graph[0] is not None else eng.run_bound()
 
     def barrier():
         if shard:
@@ -892,32 +908,40 @@ def main():
             graph[0] = None
             graph_note = "eager launches (hipGraph capture failed: " + repr(e)[:160] + ")"
             torch.cuda.synchronize()
-    # per-kernel events for the roofline object (same stream as the launches)
-    ev = [{n: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for n in ("decoder", "wgrad2")}
-          for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        eng.timers = ev[k]
-        step()
+    # per-kernel events for the roofline object: recorded by nl_iteration itself on the launch stream, in front of the decoder kernel, between it
+    # and the dW2 kernel and behind dW2 (NlIterDesc.ev_decoder_begin / ev_decoder_end / ev_wgrad2_end; an event is recorded once here so that its handle exists)
+    ev = []
+    for _ in range(args.steps):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        for e in (e0, e1, e2):
+            e.record()
+        ev.append({"decoder": (e0, e1), "wgrad2": (e1, e2)})
     barrier()
-    dt = time.perf_counter() - t0
+    with no_gc():
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            eng.timers = None if shard else ev[k]          # (sharded: the scatter runs between the two decoder kernels - a stage-wise pass below times them)
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
     eng.timers = None
     # informational: the same step sustained.  The device needs ~25 ms of load to reach its steady clock (scripts/ramp_probe.py), so a 20-step
     # timed region after a few warm-up steps still sits partly on the ramp; `value` stays what the contract defines (the K steps above)
     steady = None
     if not args.no_steady_state:
-        t1 = time.perf_counter()
-        for _ in range(STEADY_STEPS):
-            step()
-        barrier()
-        steady = (time.perf_counter() - t1) / STEADY_STEPS * 1e3
+        with no_gc():
+            t1 = time.perf_counter()
+            for _ in range(STEADY_STEPS):
+                step()
+            barrier()
+            steady = (time.perf_counter() - t1) / STEADY_STEPS * 1e3
     # the same step with the decoder's EXACT-product arithmetic (gemm mode 3: three-term bf16 splits, eight of nine products), timed right
     # behind the sustained run (warm clock: compare with steady_state): what the default's fp16 pairs buy, and the line a caller that pins
     # exact fp32 products gets.  Selected per call (kernel_modes) - the process default is not touched.
     exact_leg = None
     if not (shard or args.no_steady_state) and _lib.lib().nl_decoder_get_gemm_mode() in (4, 5):
         km0 = eng.kernel_modes
-        eng.kernel_modes = _lib.kernel_modes(3, 1)
+        eng.kernel_modes = eng._desc.kernel_modes = _lib.kernel_modes(3, 1)
         for _ in range(3):
             step()
         barrier(); t1 = time.perf_counter()
@@ -925,7 +949,7 @@ def main():
             step()
         barrier()
         exact_leg = (time.perf_counter() - t1) / 50 * 1e3
-        eng.kernel_modes = km0
+        eng.kernel_modes = eng._desc.kernel_modes = km0
         step(); barrier()
     if shard:
         import torch.distributed as tdist
@@ -1010,7 +1034,9 @@ def main():
                                    "decoder fwd/bwd+SDF loss+emb/decoder/pose grads+Adam; voxel 0.2 m, step 0.1 m, "
                                    + ("decoder trainable" if train_dec else "decoder frozen"),
                        "rays": N, "octree_nodes": w["n_nodes"], "embedding_rows": w["n_rows"], "hit_rays": st["R"],
-                       "valid_samples_rank0": P_local, "max_samples_per_ray": st["S"], "parallelism": f"ray-shard x{world}" + (" (interleaved returns)" if world > 1 else "")},
+                       "valid_samples_rank0": P_local, "max_samples_per_ray": st["S"], "parallelism": f"ray-shard x{world}" + (" (interleaved returns)" if world > 1 else ""),
+                       "launch": graph_note or "one C call per step (nl_iteration: the launch sequence SdfEngine.bind / run_bound, Mapping and Tracking use); the decoder kernels' "
+                                               "events are recorded by that call itself"},
             "roofline": rf,
         }
         if exact_leg is not None:

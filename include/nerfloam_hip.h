@@ -424,6 +424,10 @@ typedef struct NlIterDesc {
      * (event fork after the scatter, join before the decoder gradient's all-reduce); NULL: the exchanges follow the backward pass on `stream` */
     void* comm_stream; void* ev_fork; void* ev_join;
     int isect_lanes;            /* lanes per ray of the intersect's work-list: 0 = by ray count, or 4 / 8 / 16 / 32 (nl_ray_intersect_lanes) */
+    /* optional hipEvent_t handles (NULL = none) recorded on `stream` in front of the decoder kernel, between it and the dW2 kernel and behind the
+     * dW2 kernel: per-kernel durations of an iteration issued as ONE call (bench.py's timed region: the host enqueues a whole step in ~50 us
+     * and cannot starve the device); the events are the caller's, created with timing enabled */
+    void* ev_decoder_begin; void* ev_decoder_end; void* ev_wgrad2_end;
 } NlIterDesc;
 /* stages: bit 0 = intersect .. backward (with a communicator: + the exchanges of the forward pass), bit 1 = optimiser step,
  * bit 2 = the gradient exchange (only with a communicator; a whole sharded iteration = 7).  The bits exist separately so that the

@@ -67,6 +67,7 @@ def _iter_desc_fields():
     f += [("x1_send", P_), ("x1_recv", P_), ("x1_stride_bytes", I_), ("x1_rays", I_)]
     f += [("comm_stream", P_), ("ev_fork", P_), ("ev_join", P_)]
     f += [("isect_lanes", I_)]
+    f += [("ev_decoder_begin", P_), ("ev_decoder_end", P_), ("ev_wgrad2_end", P_)]
     return f
 
 

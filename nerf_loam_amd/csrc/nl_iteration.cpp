@@ -70,8 +70,10 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
                                     d->sdf_weight, d->sample_state, d->scan_ws, stream));
         NL_TRY(nl_gather_trilinear(d->loss_scalars, d->s_vox, d->s_depth, d->s_ray, d->rays_d_world, d->frame_id, d->poses12, d->F, d->centres,
                                    d->vertex_rows, d->emb, d->voxel_size, d->X, d->field_blocks, stream));
+        if (d->ev_decoder_begin && hipEventRecord((hipEvent_t)d->ev_decoder_begin, st) != hipSuccess) return leave(IT_ERR_LAUNCH);
         NL_TRY(nl_decoder_fwd_bwd_m(d->loss_scalars, d->X, d->dec_params, d->dec_ws, d->s_ray, d->s_depth, d->cos_gt, d->gt_dist, d->sdf, d->dsdf,
                                     d->dX, d->partials, d->relu2_mask, d->n_slabs, d->train_decoder, c, d->kernel_modes, stream));
+        if (d->ev_decoder_end && hipEventRecord((hipEvent_t)d->ev_decoder_end, st) != hipSuccess) return leave(IT_ERR_LAUNCH);
         // ray-sharded with the gradient exchange in the same call: the embedding scatter goes FIRST and its all-reduce (the large message:
         // 64 B per embedding row or per touched row, + the pose partials) leaves on the side stream while dW2 and the slab reduction run
         // ("overlap the embedding-grad reduce with the decoder wgrad"); the decoder gradient's all-reduce follows the join.
@@ -89,7 +91,10 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
             if (hipEventRecord((hipEvent_t)d->ev_join, cs) != hipSuccess) return leave(IT_ERR_LAUNCH);
         }
         if (d->train_decoder) {
+            // (timing events: the caller records ev_decoder_end .. ev_wgrad2_end around the dW2 kernel only where nothing else runs between them -
+            //  the overlapped sharded order puts the scatter there, and bench.py times that order without them)
             NL_TRY(nl_decoder_wgrad2_m(d->loss_scalars, d->X, d->dec_params, d->dsdf, d->relu2_mask, d->partials, d->n_slabs, d->kernel_modes, stream));
+            if (d->ev_wgrad2_end && hipEventRecord((hipEvent_t)d->ev_wgrad2_end, st) != hipSuccess) return leave(IT_ERR_LAUNCH);
             NL_TRY(nl_decoder_reduce_m(d->partials, d->n_slabs, d->dec_params, d->dec_grad, d->kernel_modes, stream));
         }
         if (overlapped) {

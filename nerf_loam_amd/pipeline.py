@@ -755,6 +755,16 @@ class SdfEngine:
             d.isect_lanes = self._bound[0].isect_lanes_for(self.N) if self._bound is not None else 0
         d.N, d.F = self.N, self.F
         stages = int(stages)
+        # bench / probes: self.timers = {"decoder": (e0, e1), "wgrad2": (e1, e2)} - torch.cuda.Event objects that have been recorded once (their
+        # handles exist): nl_iteration records them around the decoder kernel and behind dW2 (NlIterDesc.ev_decoder_begin ...)
+        t = self.timers
+        if t is not None and "decoder" in t:
+            d.ev_decoder_begin, d.ev_decoder_end = t["decoder"][0].cuda_event, t["decoder"][1].cuda_event
+            d.ev_wgrad2_end = t["wgrad2"][1].cuda_event if "wgrad2" in t else None
+            self._desc_timed = True
+        elif getattr(self, "_desc_timed", False):
+            d.ev_decoder_begin = d.ev_decoder_end = d.ev_wgrad2_end = None
+            self._desc_timed = False
         ex = self._exchange
         if ex is None:
             L.check(L.lib().nl_iteration(ctypes.byref(d), stages, L.stream_ptr()), "nl_iteration")
