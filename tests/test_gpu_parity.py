@@ -639,9 +639,9 @@ def test_fused_scan_launches_equal_the_separate_calls(nl):
 
 @pytest.mark.parametrize("n", [1, 1023, 4097, 16384, 20003, 32768, 32769, 100000])
 def test_exclusive_scan_at_every_regime_and_alignment(nl, n):
-    """nl_exclusive_scan_i32 / nl_scan_hit_rays: one narrow workgroup (<= 4096), the wide one-block scan (<= 32 768: 16 items per thread as
-    16-byte accesses when the arrays are 16-byte aligned, scalar otherwise), two launches beyond - against numpy, on aligned arrays and on
-    views that start one element into an allocation"""
+    """nl_exclusive_scan_i32 / nl_scan_hit_rays: one workgroup (<= 4096), one launch of <= 8 workgroups (<= 32 768, 16-byte accesses: only when
+    the input is 16-byte aligned - the two launches otherwise), two launches beyond - against numpy, on aligned arrays and on views that start
+    one element into an allocation"""
     ops, L = nl["ops"], nl["L"]
     rng = np.random.default_rng(n)
     vals = rng.integers(0, 5, n).astype(np.int32)

@@ -156,3 +156,37 @@ def test_virtual_ranks_with_the_send_block_packed_by_the_scan(nl, monkeypatch, s
         np.testing.assert_allclose(x["gpose"], y["gpose"], rtol=1e-9, atol=1e-12)
         for k in ("hit_rank", "ray_of_rank", "samp_off", "ls", "depth", "vox", "sdf", "gdec"):
             assert np.array_equal(x[k], y[k]), k
+
+
+def test_iteration_records_the_callers_timing_events(nl):
+    """NlIterDesc.ev_decoder_begin / ev_decoder_end / ev_wgrad2_end: nl_iteration records the caller's events around the decoder kernel and
+    behind dW2 (bench.py's timed region: one C call per step) - the intervals are those kernels' (positive, far below the call), the results do
+    not depend on the events, and a later call without timers records nothing"""
+    P = nl["P"]
+    sc, fr = _share_scene()
+    N = len(fr.rays_d)
+    m, dec, eng = make_engine(nl, sc, O.decoder_init(5), N, 1)
+    eng.set_rays(fr.rays_d, fr.points, fr.cos, np.zeros(N, np.int32)); eng.set_poses(fr.pose[None], [1])
+    cfg = P.IterConfig(step_size=0.1, noise_seed=11)
+    eng.begin_call(m, dec)
+    eng.bind(m, dec, cfg, train_decoder=True)
+    eng.run_bound(1)
+    torch.cuda.synchronize()
+    sdf0, g0 = eng.sdf[:eng.stats()["P"]].clone(), dec.grad.clone()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    for x in e:
+        x.record()                                              # (creates the handle)
+    torch.cuda.synchronize()
+    eng.timers = {"decoder": (e[0], e[1]), "wgrad2": (e[1], e[2])}
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record(); eng.run_bound(1); t1.record()
+    torch.cuda.synchronize()
+    whole, d_ms, w_ms = t0.elapsed_time(t1), e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
+    assert 0.005 < d_ms < whole and 0.003 < w_ms < whole and d_ms + w_ms < whole, (whole, d_ms, w_ms)
+    assert torch.equal(eng.sdf[:eng.stats()["P"]], sdf0) and torch.equal(dec.grad, g0)
+    eng.timers = None
+    eng.run_bound(1)
+    torch.cuda.synchronize()
+    d = eng._desc
+    assert not d.ev_decoder_begin and not d.ev_decoder_end and not d.ev_wgrad2_end
+    assert e[0].elapsed_time(e[1]) == d_ms                       # (not recorded again)
