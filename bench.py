@@ -30,14 +30,48 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+
+def host_cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), else the visible core count"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p > 0:
+            return q / p
+    except (OSError, ValueError):
+        pass
+    return float(os.cpu_count() or 1)
+
+
+# The host thread pools (numpy's OpenBLAS, torch's OpenMP) are capped BELOW the container's CPU quota before the libraries start.  On the GPU
+# boxes of this pool 256 cores are visible and the quota is 16: OpenBLAS starts 64 threads, they spin after every call, the cgroup runs out of
+# quota and the kernel throttles the WHOLE process for up to ~80 ms of a 100 ms period - the launching thread included.  That was the ~60 ms
+# pause in one 100-step block of every tracker leg (an oracle parity check runs just before them) and the one 3.57 ms default run
+# (scripts/sync_probe.py, profiles/r05_sync_probe.txt: 8-17 of 40 blocks late with the default pools, none with <= 16 threads).
+HOST_CPU_QUOTA = host_cpu_quota()
+HOST_POOL_THREADS = max(1, min(16, int(HOST_CPU_QUOTA) - 2))
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, str(HOST_POOL_THREADS))
+
+import numpy as np                                             # noqa: E402
+import torch                                                   # noqa: E402
+
+try:                                                           # (a caller imported numpy first: its pool already exists - limit it now)
+    import threadpoolctl                                       # noqa: E402
+    threadpoolctl.threadpool_limits(limits=int(os.environ["OPENBLAS_NUM_THREADS"]), user_api="blas")
+except Exception:                                              # noqa: BLE001 - no threadpoolctl: the environment variables above did it for a fresh process
+    pass
+torch.set_num_threads(int(os.environ["OMP_NUM_THREADS"]))
 
 
 @contextlib.contextmanager
 def no_gc():
-    """host-timed regions run with the cyclic garbage collector off (what `timeit` does): a generation-2 pass over the ~10^6 objects torch's import
-    leaves behind takes tens of milliseconds - one such pause inside the 20 timed steps doubled a whole run's ms_per_step (profiles/r05_v_*)"""
+    """host-timed regions run with the cyclic garbage collector off (what `timeit` does)"""
     was = gc.isenabled()
     gc.collect()
     gc.disable()
@@ -259,10 +293,11 @@ def cpu_baseline(w, n_rays_probe=16384, n_rays_1t=8192, reps_1t=2, seed=1):
         return len(sel), float(np.median(ts))
 
     cores = int(torch.get_num_threads())
+    quota = max(1, int(HOST_CPU_QUOTA))                                      # (threads beyond the container's CPU quota only get the process throttled)
     res = {}
     try:
         # (8 threads: the thread count of the recorded reference-path figure - the two are then comparable on equal cores)
-        for thr in dict.fromkeys((cores, min(16, cores), min(8, cores))):       # probe: which thread count serves the port best on this box
+        for thr in dict.fromkeys((quota, min(16, quota), min(8, quota))):       # probe: which thread count serves the port best on this box
             torch.set_num_threads(thr)
             res[thr] = run(n_rays_probe, 1, 1) + (1, 1)
         best = max(res, key=lambda t: res[t][0] / res[t][1])
@@ -274,11 +309,11 @@ def cpu_baseline(w, n_rays_probe=16384, n_rays_1t=8192, reps_1t=2, seed=1):
         torch.set_num_threads(cores)
     rec = reference_recorded()
     sample = (f"all {n_b} rays of the same 64x2048 scan, 1 mapping iteration incl. Adam, 1 timed iteration after a warm-up on {n_rays_probe} rays: "
-              f"{t_b * 1e3:.0f} ms/iter; numpy/C oracle port, GEMMs + decoder element-wise stages on {best} torch-CPU threads of {os.cpu_count()} host cores "
+              f"{t_b * 1e3:.0f} ms/iter; numpy/C oracle port, GEMMs + decoder element-wise stages on {best} torch-CPU threads ({os.cpu_count()} host cores visible, container CPU quota {HOST_CPU_QUOTA:g}) "
               f"(the other numpy stages are single-threaded).  NOT the reference's own code: ")
     sample += (f"reference_recorded carries the reference path's figure ({rec['value']:.0f} rays/s on {rec['cores']} threads in the build container) with its provenance"
                if rec else REF_OFFBOX)
-    return dict(value=n_b / t_b, unit="rays/s", cores=best, kind="port", reference_recorded=rec, sample=sample,
+    return dict(value=n_b / t_b, unit="rays/s", cores=best, kind="port", host_cpu_quota=HOST_CPU_QUOTA, reference_recorded=rec, sample=sample,
                 by_threads={str(t): dict(value=res[t][0] / res[t][1], rays=res[t][0], ms_per_iter=res[t][1] * 1e3, warmup=res[t][2], timed=res[t][3])
                             for t in res},
                 single_thread=dict(value=n_1 / t_1, unit="rays/s", cores=1,

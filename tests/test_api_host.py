@@ -40,3 +40,25 @@ def test_private_seed_stream_follows_torch_manual_seed():
     assert [RH._draw_seed() for _ in range(4)] == b
     RH.reseed()                                                                # ... hence the explicit call
     assert [RH._draw_seed() for _ in range(4)] == a
+
+
+def test_host_thread_pools_can_be_capped_below_the_cpu_quota():
+    """nerf_loam_amd.hostenv: the container's CPU quota is readable, and the BLAS / torch pools follow cap_host_thread_pools (a process whose
+    pools exceed the quota gets its launching thread throttled: profiles/r05_sync_probe.txt)"""
+    import numpy as np
+    import torch
+    from nerf_loam_amd import hostenv as H
+    q = H.host_cpu_quota()
+    assert q > 0
+    before = torch.get_num_threads()
+    try:
+        n = H.cap_host_thread_pools(2)
+        assert n == 2 and torch.get_num_threads() == 2
+        (np.ones((64, 64), np.float32) @ np.ones((64, 64), np.float32)).sum()      # (a BLAS pool exists now)
+        H.cap_host_thread_pools(2)
+        import threadpoolctl
+        assert all(i["num_threads"] <= 2 for i in threadpoolctl.threadpool_info() if i.get("user_api") == "blas")
+        assert H.pools_exceed_quota() is None or q < 2
+        assert H.cap_host_thread_pools() == max(1, min(16, int(q) - 2))
+    finally:
+        torch.set_num_threads(before)
