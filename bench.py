@@ -54,7 +54,7 @@ def host_cpu_quota():
 # pause in one 100-step block of every tracker leg (an oracle parity check runs just before them) and the one 3.57 ms default run
 # (scripts/sync_probe.py, profiles/r05_sync_probe.txt: 8-17 of 40 blocks late with the default pools, none with <= 16 threads).
 HOST_CPU_QUOTA = host_cpu_quota()
-HOST_POOL_THREADS = max(1, min(16, int(HOST_CPU_QUOTA) - 2))
+HOST_POOL_THREADS = max(1, min(16, (int(HOST_CPU_QUOTA) - 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))     # (the ranks of a node share the quota)
 for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ.setdefault(_v, str(HOST_POOL_THREADS))
 
