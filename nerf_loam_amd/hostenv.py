@@ -53,3 +53,22 @@ def pools_exceed_quota():
     import torch
     tt = int(torch.get_num_threads())
     return (blas, tt, quota) if max(blas, tt) > quota else None
+
+
+_warned = False
+
+
+def warn_once_if_pools_exceed_quota():
+    """Mapping / Tracking call this when they are constructed: one warning per process if a host thread pool is larger than the CPU quota"""
+    global _warned
+    if _warned:
+        return
+    _warned = True
+    try:
+        over = pools_exceed_quota()
+    except Exception:                                              # noqa: BLE001 - a diagnostic must not break construction
+        return
+    if over:
+        import warnings
+        warnings.warn(f"nerf_loam_amd: host thread pools (BLAS {over[0]}, torch {over[1]} threads) exceed the container's CPU quota ({over[2]:g}): multi-threaded host work "
+                      "between iterations can get the launching thread throttled for tens of ms - see nerf_loam_amd.hostenv.cap_host_thread_pools", RuntimeWarning, stacklevel=3)

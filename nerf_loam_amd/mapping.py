@@ -18,6 +18,7 @@ import random
 import numpy as np
 import torch
 
+from . import hostenv
 from .criterion import Criterion
 from .decoder import Decoder
 from .lidar_frame import LidarFrame
@@ -33,6 +34,7 @@ def _get(d, name, default):
 class Mapping:
     def __init__(self, args, logger=None, device="cuda"):
         self.args, self.logger, self.device = args, logger, torch.device(device)
+        hostenv.warn_once_if_pools_exceed_quota()
         self.decoder = Decoder(**args.decoder_specs).to(self.device)
         self.loss_criteria = Criterion(args)
         self.keyframe_graph = []

@@ -8,6 +8,7 @@ from copy import deepcopy
 
 import torch
 
+from . import hostenv
 from .criterion import Criterion
 from .render_helpers import track_frame
 from .se3pose import OptimizablePose
@@ -16,6 +17,7 @@ from .se3pose import OptimizablePose
 class Tracking:
     def __init__(self, args, data_stream=None, logger=None):
         self.args = args
+        hostenv.warn_once_if_pools_exceed_quota()
         ts = args.tracker_specs
         self.loss_criteria = Criterion(args)
         self.voxel_size = args.mapper_specs["voxel_size"]
