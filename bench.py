@@ -55,8 +55,9 @@ def host_cpu_quota():
 # (scripts/sync_probe.py, profiles/r05_sync_probe.txt: 8-17 of 40 blocks late with the default pools, none with <= 16 threads).
 HOST_CPU_QUOTA = host_cpu_quota()
 HOST_POOL_THREADS = max(1, min(16, (int(HOST_CPU_QUOTA) - 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))     # (the ranks of a node share the quota)
-for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
-    os.environ.setdefault(_v, str(HOST_POOL_THREADS))
+_POOL_VARS_SET_HERE = [_v for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS") if _v not in os.environ]
+for _v in _POOL_VARS_SET_HERE:
+    os.environ[_v] = str(HOST_POOL_THREADS)
 
 import numpy as np                                             # noqa: E402
 import torch                                                   # noqa: E402
@@ -870,7 +871,8 @@ def main():
         s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd))
+        env = {k: v for k, v in os.environ.items() if k not in _POOL_VARS_SET_HERE}      # (every rank sizes its own pools: the ranks share the node's quota)
+        raise SystemExit(subprocess.call(cmd, env=env))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} processes (or none: bench.py starts them itself)")
     from nerf_loam_amd import _lib, pipeline as P, dist as D
