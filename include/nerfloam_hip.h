@@ -29,7 +29,7 @@ extern "C" {
 #define NL_CNT_DOUBLES 4        /* ... followed by double sums: counter block = 16*4 + 4*8 bytes */
 #define NL_LOSS_SCALARS_BYTES 48
 #define NL_DEC_PARAMS 70401     /* W1[256x16] b1[256] W2[256x256] b2[256] W3[256] b3[1] */
-#define NL_DEC_WS_FLOATS 393216    /* decoder weight workspace: W2^T fp32 + 2 x 3 bf16 operand planes + 2 x 2 fp16 operand planes */
+#define NL_DEC_WS_FLOATS 401408    /* decoder weight workspace: W2^T fp32 + 2 x 3 bf16 operand planes + 2 x 2 fp16 operand planes of W2 + 2 x 2 fp16 operand planes of W1 (nl_dec_ws_floats() returns it) */
 #define NL_EMB_CHANNELS 16
 
 /* Multi-GPU ray sharding: fold the all-gathered counter blocks gathered[world][NL_CNT_INTS + 2*NL_CNT_DOUBLES] (ints) into
@@ -38,7 +38,7 @@ extern "C" {
 int nl_dist_merge_counters(const int* gathered, int world, int rank, int stage, int* counters, void* stream);
 int nl_version(void);
 int nl_device_count(void);              /* number of HIP devices visible (0 => product cannot run) */
-int nl_decoder_grid_hint(void);         /* persistent-kernel grid = compute units of the current device */
+int nl_decoder_grid_hint(void);         /* slabs to provide in `partials` = upper bound of the persistent decoder grids: 2 per compute unit of the current device */
 
 /* ---- (b1) drop-in operators of the reference's `grid` pybind module ----------------------------
  * third_party/sparse_voxels/src/binding.cpp:10-21, include/intersect.h:14-15, include/sample.h:12-14 */
@@ -220,6 +220,15 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
  * (4, 2; include/nerfloam_hip_debug.h holds the A/B setters): kernel_modes = NL_KERNEL_MODES(gemm_mode, wgrad2_mode), either
  * mode -1 (or kernel_modes == 0) = the process default.  NlIterDesc.kernel_modes carries the same word for nl_iteration. */
 #define NL_KERNEL_MODES(gemm_mode, wgrad2_mode) ((((gemm_mode) + 1) & 0xFF) | ((((wgrad2_mode) + 1) & 0xFF) << 8))
+/* OR-ed into kernel_modes: the workgroup layout of the fused decoder kernel under the fp16-pair arithmetic (gemm modes 4 / 5; round 6):
+ *   0 = by slab count: two independent 4-wave workgroups per compute unit (k_decoder2: one workgroup's VALU phases run under the other's
+ *       matrix phases) when `nslabs` >= 2 per compute unit - what nl_decoder_grid_hint() returns -, else layout 1;
+ *   1 = one 8-wave workgroup per compute unit (k_decoder, rounds 1-5);  2 = two 4-wave workgroups per compute unit whatever nslabs is.
+ * sdf, dsdf and the saved ReLU words are bit-identical between the layouts; dX and the weight gradients differ by summation order.
+ * `nslabs` is the number of slabs `partials` holds AND the upper bound of every persistent grid: the 512-thread kernels (layout 1, dW2,
+ * forward-only) launch min(nslabs, compute units) workgroups, layout 2 launches nslabs; nl_decoder_reduce_m sums each column over the slabs
+ * its producer wrote (the same rule, from the same two arguments - pass all three calls of an iteration the same nslabs and kernel_modes). */
+#define NL_KERNEL_LAYOUT(layout) (((layout) & 3) << 16)
 int nl_decoder_fwd_bwd_m(const void* loss_scalars, const float* X, const float* params, const float* W2T,
                          const int* s_ray, const float* s_depth, const float* cos_gt, const float* gt_dist,
                          float* sdf, float* dsdf, float* dX, float* partials, unsigned* relu2_mask, int nslabs, int train_decoder,
@@ -244,8 +253,16 @@ int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, voi
  *                             MFMA-fragment order: dgrad GEMM B operand on the bf16 matrix cores,
  *   floats [163840, 262144):  "W2TX" = W2[n][k], same split and order: forward GEMM B operand on the bf16 matrix cores,
  *   floats [262144, 327680):  "W2H"  = (w3_j * W2[j][k]) * 2^12 as two fp16 planes (hi = f16(x), lo = f16(x - hi), round to nearest), same order,
- *   floats [327680, 393216):  "W2TH" = W2[n][k] * 2^8, likewise: the operands of gemm modes 4 / 5. */
+ *   floats [327680, 393216):  "W2TH" = W2[n][k] * 2^8, likewise: the operands of gemm modes 4 / 5,
+ *   floats [393216, 397312):  "W1F"  = W1[k][c] * 2^8 as two fp16 planes in the order of layer 1's B fragments,
+ *   floats [397312, 401408):  "W1X"  = the same values in the order of dX's B fragments (csrc/nl_common.h NL_W1F_INDEX / NL_W1X_INDEX; round 6:
+ *                             the two-workgroups-per-CU decoder kernel has neither registers nor LDS to keep W1's operand forms resident).
+ * The workspace grew in rounds 5 and 6: a caller compiled against an older header would hand over a shorter buffer, so it checks
+ * nl_dec_ws_floats() == NL_DEC_WS_FLOATS (and nl_abi_version() == NL_ABI_VERSION) once at start-up - the Python loader does. */
 int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream);
+int nl_dec_ws_floats(void);             /* NL_DEC_WS_FLOATS of the library that is loaded */
+#define NL_ABI_VERSION 6                /* bumped whenever a struct, a workspace size or an argument's meaning changes */
+int nl_abi_version(void);               /* NL_ABI_VERSION of the library that is loaded */
 /* The two 256-deep GEMMs of nl_decoder_fwd_bwd / nl_decoder_forward (gemm_mode).  Values and accumulation are fp32 in every mode; the
  * modes differ in how the matrix cores form the fp32 x fp32 products:
  *   0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32), 1/16 of the 16-bit rate.
@@ -292,7 +309,10 @@ int nl_trilinear_bwd(const void* loss_scalars, const int* s_vox, const float* s_
  * 384 k row atomics on 48 rows: 76 us against 23 us spread out; with 16 copies 29 us).  With copies > 1 the accumulator array holds `copies` arrays
  * copy_stride floats apart (g_emb + c * copy_stride), a wave of the scatter adds into copy (its index mod copies), and the optimiser's sweep over the
  * touched rows - the only reader - sums a row's copies in copy order before the one bf16 rounding, and clears them.  copies <= 1: one array. */
-typedef struct NlTouchedRows { int* list; int* count; unsigned* flags; int copies; long long copy_stride; } NlTouchedRows;
+/* struct_size = sizeof(NlTouchedRows) of the header the caller was built with: the struct grew in round 5 (copies, copy_stride), and a caller with the
+ * shorter one would have its stack read as a copy count - every entry point that takes the struct refuses any other size (NL_ERR_INVALID_ARG).
+ * C: NlTouchedRows t = {sizeof t, list, count, flags, copies, copy_stride}. */
+typedef struct NlTouchedRows { int struct_size; int* list; int* count; unsigned* flags; int copies; long long copy_stride; } NlTouchedRows;
 int nl_trilinear_bwd_t(const void* loss_scalars, const int* s_vox, const float* s_depth, const int* s_ray,
                        const float* rays_d_world, const float* rays_d_sensor, const int* frame_id, const float* poses, int n_frames,
                        const float* centres, const int* vertex_rows, const void* emb_bf16, float voxel_size,

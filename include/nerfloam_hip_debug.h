@@ -17,6 +17,8 @@ int nl_decoder_set_gemm_mode(int mode);
 int nl_decoder_get_gemm_mode(void);
 int nl_decoder_set_wgrad2_mode(int mode);
 int nl_decoder_get_wgrad2_mode(void);
+int nl_decoder_set_layout(int layout);          /* process default of NL_KERNEL_LAYOUT: 0 = by slab count (default), 1 = one 8-wave workgroup per CU, 2 = two 4-wave workgroups */
+int nl_decoder_get_layout(void);
 
 int nl_geometry_set_sampler_mode(int mode);     /* nl_sample_rays: 0 = sequential walk per ray, 1 = step-parallel, 2 = by ray count (default); same results */
 int nl_geometry_set_intersect_prune(int on);    /* nl_ray_intersect (tests): 0 = rays with more hits than the work-list kernel's list holds go to the sequential fallback instead of being pruned to the first 20 in place; 1 = default */
@@ -30,7 +32,8 @@ int nl_field_set_one_round(int on);
 int nl_field_set_midspan_flush(int min_steps_left);   /* A/B aid: nl_trilinear_bwd writes a full wave table out mid-span when its 8-lane groups have at least this
                                                          many sample steps left (default 2; < 0 = never: overflowing runs go to memory from their lane) */
 int nl_field_set_probes(int n);               /* A/B aid: open-addressing probes of nl_trilinear_bwd's wave tables before a run goes straight to memory */
-/* profiling aid: 256 x int64 device buffer receiving per-phase shader-clock stamps of the decoder kernel's workgroup 0 (NULL = off) */
+/* profiling aid: (256 + 8 x nslabs) x int64 device buffer receiving per-phase shader-clock stamps of the decoder kernel's workgroup 0 in its first 256 words and, under
+ * layout 2, one 8-word record per workgroup behind them (start / end wall clock and shader cycles, HW_ID, XCC_ID, tiles) (NULL = off) */
 int nl_decoder_set_debug_buffer(void* dbg);
 /* MFMA lane-map self test (debug) */
 int nl_mfma_selftest(const float* A32, const float* B32, float* D32, const float* A16, const float* B16, float* D16, void* stream);

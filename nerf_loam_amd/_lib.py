@@ -15,7 +15,8 @@ NL_CNT_BYTES = NL_CNT_INTS * 4 + NL_CNT_DOUBLES * 8
 NL_LOSS_SCALARS_BYTES = 48
 NL_ADAM_STATE_BYTES = 112
 NL_DEC_PARAMS = 70401
-NL_DEC_WS_FLOATS = 393216        # decoder weight workspace: W2^T fp32 + 2 x 3 bf16 + 2 x 2 fp16 operand planes (include/nerfloam_hip.h)
+NL_ABI_VERSION = 6
+NL_DEC_WS_FLOATS = 401408        # decoder weight workspace: W2^T fp32 + 2 x 3 bf16 + 2 x 2 fp16 operand planes of W2 + 2 x 2 fp16 planes of W1 (include/nerfloam_hip.h; checked against nl_dec_ws_floats() at load)
 NL_SEL_BATCH_WS_INTS_PER_FRAME = 8 + 4 * 128 + 2 * 4096     # NL_SELECT_BATCH_WS_INTS(1)
 NL_SEL_MAX_FRAMES = 8
 NL_MAX_FRAMES = 32               # frames (poses) one field-kernel launch takes (csrc/nl_field.hip)
@@ -78,7 +79,7 @@ class NlIterDesc(ctypes.Structure):
 
 class NlTouchedRows(ctypes.Structure):
     """rows of the embedding table touched since the optimiser of a call was created (include/nerfloam_hip.h)"""
-    _fields_ = [("list", ctypes.c_void_p), ("count", ctypes.c_void_p), ("flags", ctypes.c_void_p), ("copies", ctypes.c_int), ("copy_stride", ctypes.c_longlong)]
+    _fields_ = [("struct_size", ctypes.c_int), ("list", ctypes.c_void_p), ("count", ctypes.c_void_p), ("flags", ctypes.c_void_p), ("copies", ctypes.c_int), ("copy_stride", ctypes.c_longlong)]
 
 
 # communicator of the ray-sharded iteration (NlComm, include/nerfloam_hip.h)
@@ -152,6 +153,10 @@ _SIGS = {
     "nl_decoder_get_gemm_mode": ([], _I),
     "nl_decoder_set_wgrad2_mode": ([_I], _I),
     "nl_decoder_get_wgrad2_mode": ([], _I),
+    "nl_decoder_set_layout": ([_I], _I),
+    "nl_decoder_get_layout": ([], _I),
+    "nl_dec_ws_floats": ([], _I),
+    "nl_abi_version": ([], _I),
     "nl_reduce_partials": ([_P, _I, _I, _P, _P], _I),
     "nl_decoder_reduce": ([_P, _I, _P, _P, _P], _I),
     "nl_decoder_transpose_w2": ([_P, _P, _P], _I),
@@ -214,6 +219,14 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = res
+        # the caller-allocated workspaces and the descriptor structs of this binding are sized from constants compiled in HERE: a library
+        # of another revision would overrun them - refuse it at load
+        if L.nl_abi_version() != NL_ABI_VERSION or L.nl_dec_ws_floats() != NL_DEC_WS_FLOATS:
+            raise NerfLoamHipError(f"{LIB_PATH}: ABI version {L.nl_abi_version()} / decoder workspace {L.nl_dec_ws_floats()} floats, this binding "
+                                   f"expects {NL_ABI_VERSION} / {NL_DEC_WS_FLOATS} - rebuild with `python -m nerf_loam_amd.build --force`")
+        if os.environ.get("NL_DEC_LAYOUT"):                 # A/B switch: 1 = one 8-wave decoder workgroup per CU (rounds 1-5), 2 = two 4-wave workgroups
+            if L.nl_decoder_set_layout(int(os.environ["NL_DEC_LAYOUT"])) != 0:
+                raise NerfLoamHipError("NL_DEC_LAYOUT must be 0, 1 or 2")
         if os.environ.get("NL_GEMM_MODE"):
             if L.nl_decoder_set_gemm_mode(int(os.environ["NL_GEMM_MODE"])) != 0:
                 raise NerfLoamHipError("NL_GEMM_MODE must be 0 .. 5")
@@ -254,14 +267,15 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def kernel_modes(gemm_mode=None, wgrad2_mode=None):
-    """NL_KERNEL_MODES of include/nerfloam_hip.h: the decoder kernel selection of one call / one NlIterDesc; None = the process
-    default (NL_GEMM_MODE / NL_WGRAD2_MODE, nl_decoder_set_*_mode)"""
+def kernel_modes(gemm_mode=None, wgrad2_mode=None, dec_layout=None):
+    """NL_KERNEL_MODES | NL_KERNEL_LAYOUT of include/nerfloam_hip.h: the decoder kernel selection of one call / one NlIterDesc; None = the
+    process default (NL_GEMM_MODE / NL_WGRAD2_MODE / NL_DEC_LAYOUT, nl_decoder_set_*)"""
     g = -1 if gemm_mode is None else int(gemm_mode)
     w = -1 if wgrad2_mode is None else int(wgrad2_mode)
-    if not (-1 <= g <= 5 and -1 <= w <= 2):
-        raise ValueError(f"gemm_mode {gemm_mode} / wgrad2_mode {wgrad2_mode}: 0..5 / 0..2 or None")
-    return ((g + 1) & 0xFF) | (((w + 1) & 0xFF) << 8)
+    l = 0 if dec_layout is None else int(dec_layout)
+    if not (-1 <= g <= 5 and -1 <= w <= 2 and 0 <= l <= 2):
+        raise ValueError(f"gemm_mode {gemm_mode} / wgrad2_mode {wgrad2_mode} / dec_layout {dec_layout}: 0..5 / 0..2 / 1..2 or None")
+    return ((g + 1) & 0xFF) | (((w + 1) & 0xFF) << 8) | (l << 16)
 
 
 def stream_ptr():

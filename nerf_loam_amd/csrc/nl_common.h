@@ -64,7 +64,16 @@ enum {
 #define NL_OFF_B3 (NL_OFF_W3 + NL_W)
 #define NL_DEC_PARAMS 70401
 // decoder weight workspace (floats; include/nerfloam_hip.h nl_decoder_transpose_w2): W2^T fp32 | W2X, W2TX (3 bf16 planes each) | W2H, W2TH (2 fp16 planes each)
-static_assert(NL_W * NL_W + 2 * 3 * NL_W * NL_W / 2 + 2 * 2 * NL_W * NL_W / 2 == 393216, "NL_DEC_WS_FLOATS of include/nerfloam_hip.h");
+//   | W1F, W1X (2 fp16 planes each: W1 * 2^8 in its two operand forms, round 6)
+#define NL_DEC_WS_W1F_OFF (NL_W * NL_W + 2 * 3 * NL_W * NL_W / 2 + 2 * 2 * NL_W * NL_W / 2)      // floats
+#define NL_DEC_WS_W1X_OFF (NL_DEC_WS_W1F_OFF + 2 * NL_W * NL_C / 2)
+#define NL_DEC_WS_TOTAL (NL_DEC_WS_W1X_OFF + 2 * NL_W * NL_C / 2)
+static_assert(NL_DEC_WS_W1F_OFF == 393216 && NL_DEC_WS_TOTAL == 401408, "NL_DEC_WS_FLOATS of include/nerfloam_hip.h");
+// element (k = hidden unit, c = channel, plane) of the two forms, in 16-bit elements from the start of the form:
+//   W1F [column tile k >> 5][plane][lane = 32 (c >> 3) + (k & 31)][c & 7]   - layer 1's B fragments (32x32x16: lane n holds 8 consecutive c)
+//   W1X [k-step k >> 5][plane][lane = 16 ((k >> 3) & 3) + c][k & 7]        - dX's B fragments (16x16x32: lane (c, q) holds k = 32 s + 8 q + e)
+#define NL_W1F_INDEX(k, c, plane) (((((k) >> 5) * 2 + (plane)) * 64 + 32 * ((c) >> 3) + ((k) & 31)) * 8 + ((c) & 7))
+#define NL_W1X_INDEX(k, c, plane) (((((k) >> 5) * 2 + (plane)) * 64 + 16 * (((k) >> 3) & 3) + (c)) * 8 + ((k) & 7))
 #define NL_DEC_WS_W2H_OFF16 (2 * 3 * NL_W * NL_W)          // 16-bit elements from the start of W2X to the start of W2H
 static_assert(NL_DEC_PARAMS == NL_OFF_B3 + 1, "decoder parameter block");
 

@@ -175,6 +175,7 @@ __device__ __forceinline__ void l1_w1_fragments_f16(const float* __restrict__ pa
 // laundering the base through an empty asm inside the loop keeps ONE base register and lets the constants fold into the
 // ds_read/ds_write offset fields.
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ float launder_f(float x) { asm volatile("" : "+v"(x)); return x; }
 #define D32_RR(r) (((r) & 3) + 8 * ((r) >> 2))          // row of accumulator register r within a half-wave (+ 4*lh)
 
 // ---- dgrad on the bf16 matrix cores, exactly -------------------------------------------------------------------------
@@ -322,6 +323,7 @@ __device__ __forceinline__ void gemm_mask_x_rolled(i32x4 rsX, int w, int lane, c
 #define NL_DEC_WS_W2TX_OFF (NL_DEC_WS_W2X_OFF + 3 * NL_W * NL_W / 2)       // floats
 #define NL_DEC_WS_W2H_OFF (NL_DEC_WS_W2TX_OFF + 3 * NL_W * NL_W / 2)      // fp16 pairs: dgrad planes (w3_j W2[j][k] * 2^12), two planes
 #define NL_DEC_WS_W2TH_OFF (NL_DEC_WS_W2H_OFF + 2 * NL_W * NL_W / 2)      // forward planes (W2 * 2^8)
+static_assert(NL_DEC_WS_W2TH_OFF + 2 * NL_W * NL_W / 2 == NL_DEC_WS_W1F_OFF, "W1F / W1X (nl_common.h) follow the W2 planes");
 
 // bf16 mode, layer 1 on the bf16 matrix cores as well (exact 3 x 3 term products, nine K = 16 MFMAs per 32-row sub-tile instead of
 // eight fp32 ones): W1 as B fragments [wave][plane][lane][16 B] and the X tile as three planes [64 rows][32 B], in LDS the bf16 mode
@@ -1123,6 +1125,581 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
     }
 }
 
+// =============================================================================================================================
+// k_decoder2 (round 6): the fp16-pair decoder as TWO INDEPENDENT 4-wave workgroups per CU.
+//
+// Why: k_decoder runs 8 waves (2 per SIMD) through five barrier-separated phases per tile, so the two waves of a SIMD are always in the
+// SAME phase - its ~1 300 VALU instructions per wave and tile (operand splits, ReLU bits, row sums) never run under the other wave's
+// matrix instructions, and the matrix pipe is busy 47 % of the time (profiles/r05_z_decoder_phase_cycles.txt: 23.9 k cycles per tile,
+// 11.9 k of them matrix-pipe time).  Two workgroups that share no barrier drift apart: while one is in a VALU phase the other is in a
+// GEMM.  Same arithmetic per element as k_decoder<.., true, 3 / 4> (sdf, dsdf and the ReLU masks are bit-identical; dX and the weight
+// gradients differ by summation order only).
+//
+// What had to change to fit two workgroups into one CU's 160 KB of LDS (79 360 B each):
+//   * a wave owns TWO 32-column tiles (ct = 2 w, 2 w + 1): the GEMMs run on four accumulators per wave and share every A fragment
+//     between the two column tiles (half the LDS reads per matrix instruction); the per-element code runs per column tile with the
+//     lane map of k_decoder, so the saved ReLU words have k_decoder's layout (k_decoder_wgrad2* read them unchanged);
+//   * two 33 KB plane regions instead of three: H1 hi / lo in phase C; the 0/1 mask tile (P0) in phases E / F; Q = [H1 > 0] x dgrad
+//     accumulator goes to P1 in HALF tiles (32 rows: hi in rows 0-31, lo in rows 32-63 of the region), and only into the wave's OWN 64
+//     columns: dX[i][c] = sum_k Q[i][k] W1[k][c] is split over k by wave - a wave multiplies its own 64 columns of Q (written and read
+//     back by the same wave: no workgroup barrier between F, H and I) into a partial [64][16] tile, the four partial tiles are summed in a
+//     fixed order after the tile's last barrier;
+//   * W1's two operand forms (layer-1 B fragments, dX B fragments: 16 registers each) stay in registers; U aliases the fp16 X planes.
+// Barriers per tile: 5, as before - but a barrier now stalls 4 waves while the CU's other 4 keep issuing.
+// =============================================================================================================================
+#define D2_THREADS 256
+#define D2_P1 X_PLANE_BYTES
+#define D2_XF (2 * X_PLANE_BYTES)                       // fp32 X tile [64][17] (train: U = sigma dsdf 16 X)
+#define D2_XU (D2_XF + DEC_M * LDX * 4)                 // fp16 X planes [2][64][32 B] (phase B)  /  U planes (phases D - H)
+#define D2_U_CHUNK (17 * 16)
+#define D2_U_PLANE (8 * D2_U_CHUNK)
+#define D2_SS (D2_XU + 2 * D2_U_PLANE)                  // [8 column tiles][64] partial row sums
+#define D2_SDS (D2_SS + 8 * DEC_M * 4)                  // [4 waves][64] dL/dsdf, one copy per wave
+#define D2_TOTAL (D2_SDS + 4 * DEC_M * 4)
+static_assert(2 * XG_XP_BYTES <= 2 * D2_U_PLANE, "the fp16 X planes fit the U region");
+static_assert(2 * D2_TOTAL <= 163840 && D2_TOTAL % 1280 == 0, "two workgroups per CU (LDS is granted in 1280-byte units)");
+
+#define F2_RING 3                                       // forward: B fragments 3 k-steps (12-16 matrix instructions each) ahead
+__device__ __forceinline__ void gemm_f16_2ct_prefetch(i32x4 rsH, int w, int lane, uint4 (&bq)[F2_RING][2][2])
+{
+    const int voff = lane * 16;
+    const int nt_off = __builtin_amdgcn_readfirstlane(w) * 2 * 16 * 1024;
+#pragma unroll
+    for (int s = 0; s < F2_RING - 1; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bq[s][j][p] = bload4(rsH, voff, p * W2X_PLANE_BYTES + nt_off + j * 16 * 1024 + s * 1024);
+}
+
+// H2pre of this wave's two column tiles x two row tiles: every accumulator sees k_decoder's sequence (lo x lo with NP = 4, lo x hi, hi x lo, hi x hi per
+// k-step); the four accumulators interleave, the A fragments (four ds_read_b128 per k-step) serve both column tiles
+template <int NP>
+__device__ __forceinline__ void gemm_f16_2ct(i32x4 rsH, int w, int lane, const unsigned char* sP, uint4 (&bq)[F2_RING][2][2], f32x16 (&c)[2][2])
+{
+    static_assert(NP == 3 || NP == 4, "three or four partial products");
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int voff = lane * 16;
+    const int nt_off = __builtin_amdgcn_readfirstlane(w) * 2 * 16 * 1024;
+    const unsigned char* a0 = sP + opaque(l31 * (SM_STRIDE * 2) + 16 * lh);
+    constexpr int RING = F2_RING;
+    // A fragments single-buffered (16 registers, not 32 - the kernel sits at the register limit): the lo pair of the next k-step is requested once this
+    // k-step's lo products are issued (its registers are free from there on), the hi pair after the last product; the next k-step opens with the
+    // lo products, so the hi pair has four matrix instructions to arrive
+    uint4 ahi[2], alo[2];
+    ahi[0] = *reinterpret_cast<const uint4*>(a0); ahi[1] = *reinterpret_cast<const uint4*>(a0 + 32 * SM_STRIDE * 2);
+    alo[0] = *reinterpret_cast<const uint4*>(a0 + X_PLANE_BYTES); alo[1] = *reinterpret_cast<const uint4*>(a0 + X_PLANE_BYTES + 32 * SM_STRIDE * 2);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        if (NP == 4) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { c[j][0] = mma16<true>(alo[0], bq[s % RING][j][1], c[j][0]); c[j][1] = mma16<true>(alo[1], bq[s % RING][j][1], c[j][1]); }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { c[j][0] = mma16<true>(alo[0], bq[s % RING][j][0], c[j][0]); c[j][1] = mma16<true>(alo[1], bq[s % RING][j][0], c[j][1]); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < 16) {
+            alo[0] = *reinterpret_cast<const uint4*>(a0 + X_PLANE_BYTES + 32 * (s + 1));
+            alo[1] = *reinterpret_cast<const uint4*>(a0 + X_PLANE_BYTES + 32 * SM_STRIDE * 2 + 32 * (s + 1));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { c[j][0] = mma16<true>(ahi[0], bq[s % RING][j][1], c[j][0]); c[j][1] = mma16<true>(ahi[1], bq[s % RING][j][1], c[j][1]); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { c[j][0] = mma16<true>(ahi[0], bq[s % RING][j][0], c[j][0]); c[j][1] = mma16<true>(ahi[1], bq[s % RING][j][0], c[j][1]); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < 16) {
+            ahi[0] = *reinterpret_cast<const uint4*>(a0 + 32 * (s + 1));
+            ahi[1] = *reinterpret_cast<const uint4*>(a0 + 32 * SM_STRIDE * 2 + 32 * (s + 1));
+        }
+        if (s + RING - 1 < 16) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    bq[(s + RING - 1) % RING][j][p] = bload4(rsH, voff, p * W2X_PLANE_BYTES + nt_off + j * 16 * 1024 + (s + RING - 1) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+#define M2_RING 3                                       // dgrad: B fragments 3 k-steps (8 matrix instructions each) ahead
+#define M2_PRE 2                                        // of which this many are requested before the barrier that publishes the mask tile
+__device__ __forceinline__ void gemm_mask_2ct_prefetch(i32x4 rsX, int w, int lane, uint4 (&bq)[M2_RING][2][2])
+{
+    const int voff = lane * 16;
+    const int kt_off = __builtin_amdgcn_readfirstlane(w) * 2 * 16 * 1024;
+#pragma unroll
+    for (int s = 0; s < M2_PRE; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bq[s][j][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + kt_off + j * 16 * 1024 + s * 1024);
+}
+
+// dgrad accumulators (2^10 dH1 / dsdf before the ReLU of H1) of the wave's two column tiles: 0/1 mask x (lo, hi) planes of w3_j W2[j][k], the low term first
+__device__ __forceinline__ void gemm_mask_2ct(i32x4 rsX, int w, int lane, const unsigned char* sM, uint4 (&bq)[M2_RING][2][2], f32x16 (&g)[2][2])
+{
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int voff = lane * 16;
+    const int kt_off = __builtin_amdgcn_readfirstlane(w) * 2 * 16 * 1024;
+    const unsigned char* a0 = sM + opaque(l31 * (SM_STRIDE * 2) + 16 * lh);
+    constexpr int RING = M2_RING;
+    static_assert(RING - 1 >= M2_PRE, "ring depth");
+    uint4 aq[2][2];
+#pragma unroll
+    for (int s = M2_PRE; s < RING - 1; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bq[s][j][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + kt_off + j * 16 * 1024 + s * 1024);
+    aq[0][0] = *reinterpret_cast<const uint4*>(a0); aq[0][1] = *reinterpret_cast<const uint4*>(a0 + 32 * SM_STRIDE * 2);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        if (s + RING - 1 < 16) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    bq[(s + RING - 1) % RING][j][p] = bload4(rsX, voff, p * W2X_PLANE_BYTES + kt_off + j * 16 * 1024 + (s + RING - 1) * 1024);
+        }
+        if (s + 1 < 16) {
+            aq[(s + 1) & 1][0] = *reinterpret_cast<const uint4*>(a0 + 32 * (s + 1));
+            aq[(s + 1) & 1][1] = *reinterpret_cast<const uint4*>(a0 + 32 * SM_STRIDE * 2 + 32 * (s + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 1; p >= 0; --p)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { g[j][0] = mma16<true>(aq[s & 1][0], bq[s % RING][j][p], g[j][0]); g[j][1] = mma16<true>(aq[s & 1][1], bq[s % RING][j][p], g[j][1]); }
+    }
+}
+
+// lane ids of a phase, re-derived from a LAUNDERED thread id: every LDS address of the kernel is a function of the lane id, i.e. loop-invariant, and the
+// compiler keeps each of the ~20 distinct ones in a register for the whole persistent loop (or spills and reloads it - a scratch reload queues behind the
+// weight stream's loads in flight) where two or three integer instructions per phase recompute it
+#define D2_IDS()                                                                                                            \
+    const int tid = opaque((int)threadIdx.x), lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5,               \
+              l15 = lane & 15, lq = lane >> 4, xi = tid >> 2, xc = (tid & 3) * 4;                                           \
+    float* const sdS = reinterpret_cast<float*>(ldsb + D2_SDS) + DEC_M * w;      /* this WAVE's copy of the tile's dL/dsdf */ \
+    (void)lane; (void)w; (void)l31; (void)lh; (void)l15; (void)lq; (void)xi; (void)xc; (void)sdS
+
+// wave priority by phase (A/B aid, -DD2_PRIO=n): n > 0 raises a wave's priority to n while it is in a conversion / epilogue phase and drops it to 0 inside the GEMM loops
+#ifndef D2_PRIO
+#define D2_PRIO 4
+#endif
+// n = 4: the CU's two workgroups (blocks b and b + gridDim.x / 2 start together on one CU) take turns, tile by tile, at being the one the arbiter prefers when both
+// want the same pipe: with equal priorities the OLDER workgroup always wins and finishes its 33 tiles ~20 % earlier - the kernel then ends with half-empty CUs
+#define D2_PRIO_VALU() do { if (D2_PRIO == 4) { if (prio_alt) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); } else if (D2_PRIO) __builtin_amdgcn_s_setprio(D2_PRIO); } while (0)
+#define D2_PRIO_MFMA() do { if (D2_PRIO == 4) { if (prio_alt) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } else if (D2_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
+
+template <bool TRAIN, int NP, bool STAMPS = false>
+__global__ __launch_bounds__(D2_THREADS, 2) void k_decoder2(DecArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char ldsb[D2_TOTAL];
+    float* const sXf = reinterpret_cast<float*>(ldsb + D2_XF);
+    float* const sS = reinterpret_cast<float*>(ldsb + D2_SS);
+    const NlLossScalars ls = *a.ls;
+    const int P = ls.P;
+    const int ntiles = (P + DEC_M - 1) / DEC_M;
+    // STAMPS: one record per workgroup behind the 256 phase stamps - [wall clock (100 MHz) at start, at end, shader cycles at start, at end, HW_ID, XCC_ID, tiles, -]:
+    // which CU a workgroup ran on and with whom, and the clock the kernel held (scripts/decoder_layout_probe.py)
+    long long wg_t0 = 0, wg_c0 = 0;
+    if constexpr (STAMPS) { if (a.dbg && threadIdx.x == 0) { wg_t0 = (long long)wall_clock64(); wg_c0 = (long long)__builtin_readcyclecounter(); } }
+
+    const i32x4 rsW2H = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W2T + NL_DEC_WS_W2H_OFF), 0, 2 * W2X_PLANE_BYTES, 0x00020000);
+    const i32x4 rsW2TH = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W2T + NL_DEC_WS_W2TH_OFF), 0, 2 * W2X_PLANE_BYTES, 0x00020000);
+    // W1 * 2^8 as fp16 pairs in its two operand forms comes from the weight workspace (planes W1F / W1X, rebuilt with the W2 planes after every
+    // optimiser step: nl_optim.hip) - 32 registers per lane would not fit next to four accumulators, and there is no LDS left:
+    //   w1f[j][plane]: layer 1's B fragments of column tile 2 w + j, fetched at the end of a tile for the next one (in flight across the barrier)
+    //   w1x[ks][plane]: dX's B fragments of this wave's 64 columns (k-steps 2 w, 2 w + 1 of W1X), fetched behind the dgrad loop
+    const i32x4 rsW1F = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W2T + NL_DEC_WS_W1F_OFF), 0, 2 * NL_W * NL_C * 2, 0x00020000);
+    const i32x4 rsW1X = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W2T + NL_DEC_WS_W1X_OFF), 0, 2 * NL_W * NL_C * 2, 0x00020000);
+    const i32x4 rsPar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.params), 0, NL_DEC_PARAMS * 4, 0x00020000);
+    const float b3 = a.params[NL_OFF_B3];
+    uint4 w1f[2][2];
+    auto fetch_w1f = [&](int lane_, int w_) {
+        const int so = __builtin_amdgcn_readfirstlane(w_) * 2 * 2 * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) w1f[j][pl] = bload4(rsW1F, lane_ * 16, so + (j * 2 + pl) * 1024);
+    };
+
+    f32x16 accW1h[2];                                     // this wave's 2 x 32 rows of dW1 (lanes 0-15: the channel) and of db1 (lane 16)
+    float aW3[2] = {0.f, 0.f}, aB2[2] = {0.f, 0.f}, aB3 = 0.f, dsMax = 0.f;
+    double lossFs = 0.0, lossSdf = 0.0;
+    if (TRAIN) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accW1h[j][r] = 0.f;
+    }
+    // next tile's inputs (the loss inputs are a two-level chain - sample -> its ray -> the ray's cos / range - spread over two tiles); a thread stages four values of X
+    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float pdep = 0.f, pcos = 0.f, pd = 0.f;
+    int pray = -1;
+    auto ray_of = [&](int tile, int lane_) {
+        const int row0 = tile * DEC_M;
+        return (tile < ntiles && row0 + lane_ < P) ? a.s_ray[row0 + lane_] : -1;
+    };
+    auto prefetch = [&](int tile, int lane_, int xi_, int xc_) {      // `pray` holds the ray id of this tile's row (fetched a tile earlier)
+        const int row0 = tile * DEC_M;
+        xv = make_float4(0.f, 0.f, 0.f, 0.f); pdep = 0.f; pcos = 0.f; pd = 0.f;
+        if (tile < ntiles) {
+            if (row0 + xi_ < P) xv = *reinterpret_cast<const float4*>(a.X + (size_t)(row0 + xi_) * NL_C + xc_);
+            if (pray >= 0) { pdep = a.s_depth[row0 + lane_]; pcos = a.cos_gt[pray]; pd = a.gt_dist[pray]; }
+        }
+    };
+    auto stage_x = [&](int xi_, int xc_) {
+        if (TRAIN) { float* d = sXf + opaque(xi_ * LDX + xc_); d[0] = xv.x; d[1] = xv.y; d[2] = xv.z; d[3] = xv.w; }
+        unsigned h0, l0, h1, l1;
+        split2_pair_f16(sat_f16(xv.x * NL_F16_SX), sat_f16(xv.y * NL_F16_SX), &h0, &l0);
+        split2_pair_f16(sat_f16(xv.z * NL_F16_SX), sat_f16(xv.w * NL_F16_SX), &h1, &l1);
+        unsigned char* d = ldsb + opaque(D2_XU + xi_ * 32 + 2 * xc_);
+        *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(d + XG_XP_BYTES) = make_uint2(l0, l1);
+    };
+    // the first tile's inputs; from then on a tile requests the NEXT tile's inputs at the start of its phase F (two GEMM / conversion phases = several us in
+    // front of their use at the tile's end) and the ray ids of the tile after that one: the prefetch registers are dead from the tile's start to phase F,
+    // i.e. during the forward GEMM, where the kernel is at the register limit
+    int pray_next;
+    float cz, cd;
+    {
+        D2_IDS();
+        pray_next = ray_of(blockIdx.x + gridDim.x, lane);
+        pray = ray_of(blockIdx.x, lane);
+        prefetch(blockIdx.x, lane, xi, xc);
+        fetch_w1f(lane, w);
+        stage_x(xi, xc);
+        cz = pdep * pcos; cd = pd;
+    }
+    __syncthreads();
+
+    bool prio_alt = blockIdx.x >= gridDim.x / 2;
+    D2_PRIO_VALU();
+    int tile_no = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++tile_no) {
+        const int row0 = tile * DEC_M;
+        prio_alt = ((tile_no + (blockIdx.x >= gridDim.x / 2 ? 1 : 0)) & 1) != 0;
+        const int tid = threadIdx.x;                    // (the stamps' `tid == 0`; the phases below re-derive their lane ids)
+        DBG_STAMP(0);
+        DBG_STAMP(1);
+        // ---------------- B: H1 = relu(X W1^T + b1) of both column tiles -> the hi / lo planes (P0, P1) ----------------
+        unsigned m1[2];
+        uint4 bqh[F2_RING][2][2];
+        {
+            D2_IDS();
+            const unsigned char* xq = ldsb + opaque(D2_XU + l31 * 32 + 16 * lh);
+            uint4 xa0[2], xa1[2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                xa0[pl] = *reinterpret_cast<const uint4*>(xq + pl * XG_XP_BYTES);
+                xa1[pl] = *reinterpret_cast<const uint4*>(xq + pl * XG_XP_BYTES + 32 * 32);
+            }
+            float b1s[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b1s[j] = bload(rsPar, (32 * (2 * w + j) + l31) * 4, NL_OFF_B1 * 4) * NL_F16_SH;
+            gemm_f16_2ct_prefetch(rsW2TH, w, lane, bqh);       // W2 planes of the first k-steps: in flight across the barrier
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 c0, c1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+#pragma unroll
+                for (int pa = 1; pa >= 0; --pa)
+#pragma unroll
+                    for (int pq = 1; pq >= 0; --pq) { c0 = mma16<true>(xa0[pa], w1f[j][pq], c0); c1 = mma16<true>(xa1[pa], w1f[j][pq], c1); }
+                m1[j] = store_h1_planes_f16(reinterpret_cast<unsigned short*>(ldsb), 32 * (2 * w + j) + l31, lh, c0, c1, b1s[j]);
+            }
+        }
+        nl_lds_barrier();
+        DBG_STAMP(2);
+        // ---------------- C: H2 = relu(H1 W2^T + b2), partial row sums of H2 w3 ----------------
+        f32x16 h[2][2];
+        {
+            D2_IDS();
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { h[j][0][r] = 0.f; h[j][1][r] = 0.f; }
+            float b2c[2], w3c[2];                          // (requested here, used behind the loop)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                b2c[j] = bload(rsPar, (32 * (2 * w + j) + l31) * 4, NL_OFF_B2 * 4); w3c[j] = bload(rsPar, (32 * (2 * w + j) + l31) * 4, NL_OFF_W3 * 4);
+            }
+            D2_PRIO_MFMA();
+            gemm_f16_2ct<NP>(rsW2TH, w, lane, ldsb, bqh, h);
+            D2_PRIO_VALU();
+            DBG_STAMP(3);
+            constexpr float S2 = 1.0f / (NL_F16_SH * NL_F16_SW2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { h[j][0][r] = fmaxf(fmaf(h[j][0][r], S2, b2c[j]), 0.f); h[j][1][r] = fmaxf(fmaf(h[j][1][r], S2, b2c[j]), 0.f); }
+                const float tot = halfwave_rowsum(h[j][0], h[j][1], w3c[j], l31);
+                sS[opaque((2 * w + j) * DEC_M + (l31 >> 4) * 32 + d32_row(l31 & 15, lh))] = tot;
+            }
+        }
+        nl_lds_barrier();
+        DBG_STAMP(4);
+        // ---------------- D: sdf, loss gradient: every wave computes all 64 rows (lane = row) for itself; wave 0 owns the outputs ----------------
+        float inv_sigma = 1.0f;
+        uint4 bqm[M2_RING][2][2];
+        {
+            D2_IDS();
+            {
+                const int g = row0 + lane;
+                float ds = 0.f;
+                if (g < P) {
+                    float s = sS[lane];                             // fixed summation order over the 8 column tiles (k_decoder's)
+#pragma unroll
+                    for (int ww = 1; ww < 8; ++ww) s += sS[ww * DEC_M + lane];
+                    s += b3;
+                    bool f, m;
+                    nl_loss_masks(cz, cd, ls.tau, ls.max_depth, &f, &m);
+                    float q1, q2;
+                    ds = nl_loss_grad(s, cz, cd, f, m, ls, &q1, &q2);
+                    if (w == 0) {
+                        a.sdf[g] = s; a.dsdf[g] = ds;
+                        lossFs += (double)q1; lossSdf += (double)q2;
+                    }
+                }
+                sdS[lane] = ds;
+                if (TRAIN && w == 0) { aB3 += ds; dsMax = fmaxf(dsMax, fabsf(ds)); }
+                __builtin_amdgcn_wave_barrier();
+            }
+            DBG_STAMP(5);
+            if (TRAIN) {
+                const float mx = wave_max_nonneg(fabsf(sdS[lane]));
+                int e = 0;
+                if (mx > 0.f) { (void)frexpf(mx, &e); e = e < -100 ? -100 : e; }
+                const float sigma = ldexpf(1.0f, 4 - e);
+                inv_sigma = ldexpf(1.0f, e - 4);
+                for (int f2 = tid; f2 < 2 * 8 * 17; f2 += D2_THREADS) {       // U planes: k_decoder's layout, 272 half fragments over 256 threads
+                    const int f = f2 >> 1, half = f2 & 1, t = f / 34, hh = (f / 17) & 1, c = f % 17;
+                    const float* xr = sXf + opaque(c < NL_C ? c : 0);
+                    const int row = 16 * (t & 1) + 4 * hh + 32 * (t >> 1) + 8 * half;
+                    float d[4], u[4];
+#pragma unroll
+                    for (int z = 0; z < 4; ++z) { d[z] = sdS[row + z] * sigma; u[z] = xr[(row + z) * LDX]; }
+#pragma unroll
+                    for (int z = 0; z < 4; ++z) u[z] = c < NL_C ? sat_f16(d[z] * 16.0f * u[z]) : d[z];
+                    unsigned uh[2], ul[2];
+                    split2_pair_f16(u[0], u[1], &uh[0], &ul[0]); split2_pair_f16(u[2], u[3], &uh[1], &ul[1]);
+                    unsigned char* ud = ldsb + opaque(D2_XU + (t * 2 + hh) * D2_U_CHUNK + c * 16 + 8 * half);
+                    *reinterpret_cast<uint2*>(ud) = make_uint2(uh[0], uh[1]);
+                    *reinterpret_cast<uint2*>(ud + D2_U_PLANE) = make_uint2(ul[0], ul[1]);
+                }
+            }
+            DBG_STAMP(11);
+            // ---------------- E: the 0/1 mask tile of H2 -> P0; db2 / dW3 sums; the saved ReLU words ----------------
+            gemm_mask_2ct_prefetch(rsW2H, w, lane, bqm);
+            DBG_STAMP(12);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = 32 * (2 * w + j) + l31;
+                unsigned mw = 0u;
+                const float* dsb = sdS + opaque(4 * lh);
+                // dW3 / db2 sums of the tile in four independent chains per column tile (rows of the two sub-tiles, even / odd register): one chain per sum is a
+                // 64-deep dependent sequence of FMAs (~8 cycles each with nothing to issue in between); the four partial sums are folded in a fixed order
+                float pW[4] = {0.f, 0.f, 0.f, 0.f}, pB[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float ds0 = dsb[D32_RR(r)], ds1 = dsb[32 + D32_RR(r)];
+                    // (laundered: the ReLU bits are pure functions of H2, and the compiler otherwise forms all 64 of them in phase C's epilogue and carries them -
+                    //  one register each - next to the 64 values of H2 across phase D)
+                    const float hv0 = launder_f(h[j][0][r]), hv1 = launder_f(h[j][1][r]);
+                    const unsigned on0 = pos_bit(hv0), on1 = pos_bit(hv1);
+                    if (TRAIN) {
+                        pW[r & 1] = fmaf(ds0, hv0, pW[r & 1]); pW[2 + (r & 1)] = fmaf(ds1, hv1, pW[2 + (r & 1)]);
+                        pB[r & 1] = fmaf(ds0, (float)on0, pB[r & 1]); pB[2 + (r & 1)] = fmaf(ds1, (float)on1, pB[2 + (r & 1)]);     // (ds * 1 + acc / ds * 0 + acc: the adds they replace, bit for bit)
+                    }
+                    mw |= (on0 << r) | (on1 << (16 + r));
+                }
+                // (the sums are used at the loop's back edge only: without a use HERE the machine sinker moves the chains - and with them the lifetime of all 64
+                //  values of H2, 64 ReLU bits and 64 dsdf reads - to the end of the tile: ~290 spilled registers)
+                if (TRAIN) { aW3[j] = launder_f(aW3[j] + ((pW[0] + pW[1]) + (pW[2] + pW[3]))); aB2[j] = launder_f(aB2[j] + ((pB[0] + pB[1]) + (pB[2] + pB[3]))); }
+                if (j == 0) { DBG_STAMP(13); } else { DBG_STAMP(14); }
+                const bool odd = (col & 1) != 0;
+                const unsigned nb = dpp_swap1u(mw);
+                const unsigned lo_bits = odd ? nb : mw, hi_bits = odd ? mw : nb;
+                unsigned* mb = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(ldsb) + opaque((4 * lh + (odd ? 1 : 0)) * SM_STRIDE + (col & ~1)));
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const unsigned lb = (odd ? lo_bits >> 1 : lo_bits) >> (16 * sub + r), hb = (odd ? hi_bits >> 1 : hi_bits) >> (16 * sub + r);
+                        mb[((32 * sub + D32_RR(r)) * SM_STRIDE) / 2] = ((lb & 1u) ? 0x3C00u : 0u) | ((hb & 1u) ? 0x3C000000u : 0u);
+                    }
+                if (TRAIN) a.relu2_mask[(size_t)tile * DEC_THREADS + (2 * w + j) * 64 + lane] = mw;     // k_decoder's (tile, thread) layout
+            }
+        }
+        nl_lds_barrier();
+        DBG_STAMP(6);
+        // ---------------- F: dgrad accumulators of both column tiles (registers) ----------------
+        f32x16 g[2][2];
+        uint4 w1x[2][2];
+        {
+            D2_IDS();
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { g[j][0][r] = 0.f; g[j][1][r] = 0.f; }
+            pray = pray_next;
+            prefetch(tile + gridDim.x, lane, xi, xc);
+            pray_next = ray_of(tile + 2 * gridDim.x, lane);
+            D2_PRIO_MFMA();
+            gemm_mask_2ct(rsW2H, w, lane, ldsb, bqm, g);
+            D2_PRIO_VALU();
+            DBG_STAMP(7);
+            const int so = __builtin_amdgcn_readfirstlane(w) * 2 * 2 * 1024;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) w1x[ks][pl] = bload4(rsW1X, lane * 16, so + (ks * 2 + pl) * 1024);
+        }
+        DBG_STAMP(8);
+        // ---------------- H / I: Q = [H1 > 0] x accumulator as an fp16 pair; dW1 / db1 from the lane's own registers (k_decoder's phase H); the wave's
+        //                  own 64 columns of Q through its private slice of P1, half a tile at a time, into its partial dX ----------------
+        {
+            D2_IDS();
+            f32x4 cx[2][2];                                // [sub][16-row tile] partial dX of rows 32 sub + 16 mt + 4 lq + r, channel l15
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) cx[sub][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const unsigned char* ub = ldsb + opaque(D2_XU + lh * D2_U_CHUNK + (l31 < 17 ? l31 : 16) * 16);
+            const unsigned char* qa = ldsb + opaque(D2_P1 + l15 * (SM_STRIDE * 2) + 128 * w + 16 * lq);
+            const float sc = inv_sigma * (l31 == 16 ? 1.0f / NL_F16_SG : 1.0f / (NL_F16_SG * 16.0f));
+            // column tile j = k-step j of the wave's 64 columns; a half tile (sub) of its Q goes through columns [32 sub, 32 sub + 32) of the wave's slice
+            // (hi: rows 0-31, lo: rows 32-63), so the two half tiles of a column tile never wait for each other's reads
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = 32 * (2 * w + j) + l31;
+                const bool odd = (col & 1) != 0;
+                const unsigned sel = odd ? 0x03020706u : 0x05040100u;
+                f32x16 tw;
+                if (TRAIN) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tw[r] = 0.f;
+                }
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+                    unsigned* pq = reinterpret_cast<unsigned*>(ldsb + opaque(D2_P1 + ((4 * lh + (odd ? 1 : 0)) * SM_STRIDE + 64 * w + 32 * sub + (l31 & ~1)) * 2));
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        const int t = 2 * sub + t2;
+                        uint4 qh, ql, bh, bl;
+                        if (TRAIN) { bh = *reinterpret_cast<const uint4*>(ub + 2 * t * D2_U_CHUNK); bl = *reinterpret_cast<const uint4*>(ub + 2 * t * D2_U_CHUNK + D2_U_PLANE); }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 8 * t2 + 2 * e;
+                            const float va = __uint_as_float(__float_as_uint(sat_f16(g[j][sub][r])) & (unsigned)__builtin_amdgcn_sbfe((int)m1[j], 16 * sub + r, 1));
+                            const float vb = __uint_as_float(__float_as_uint(sat_f16(g[j][sub][r + 1])) & (unsigned)__builtin_amdgcn_sbfe((int)m1[j], 16 * sub + r + 1, 1));
+                            unsigned ph, pl;
+                            split2_pair_f16(va, vb, &ph, &pl);
+                            (&qh.x)[e] = ph; (&ql.x)[e] = pl;
+                            unsigned* d = pq + (D32_RR(r) * SM_STRIDE) / 2;           // hi: rows 0-31 of the region; lo: rows 32-63
+                            d[0] = __builtin_amdgcn_perm(dpp_swap1u(ph), ph, sel);
+                            d[(32 * SM_STRIDE) / 2] = __builtin_amdgcn_perm(dpp_swap1u(pl), pl, sel);
+                        }
+                        if (TRAIN) { tw = mma16<true>(ql, bh, tw); tw = mma16<true>(qh, bl, tw); tw = mma16<true>(qh, bh, tw); }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");       // same wave: LDS is in order - this keeps the compiler from moving the reads up
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+                    const f16x8 wh = __builtin_bit_cast(f16x8, w1x[j][0]), wl = __builtin_bit_cast(f16x8, w1x[j][1]);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const f16x8 ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(qa + 16 * mt * (SM_STRIDE * 2) + 64 * sub));
+                        const f16x8 al = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(qa + (32 + 16 * mt) * (SM_STRIDE * 2) + 64 * sub));
+                        cx[sub][mt] = MFMA16_F16(al, wh, cx[sub][mt]); cx[sub][mt] = MFMA16_F16(ah, wl, cx[sub][mt]); cx[sub][mt] = MFMA16_F16(ah, wh, cx[sub][mt]);
+                    }
+                }
+                if (TRAIN) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accW1h[j][r] = launder_f(fmaf(tw[r], sc, accW1h[j][r]));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+            // the wave's partial dX tile -> its slice of P1 (the Q values there have been consumed by this wave's own reads)
+            float* px = reinterpret_cast<float*>(ldsb + opaque(D2_P1 + (4 * lq) * (SM_STRIDE * 2) + 128 * w + 4 * l15));
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) px[((32 * sub + 16 * mt + r) * (SM_STRIDE * 2)) / 4] = cx[sub][mt][r];
+        }
+        DBG_STAMP(9);
+        nl_lds_barrier();
+        // ---------------- dX = dsdf_i 2^-18 x (the four partial tiles, waves 0..3 in order); X of the next tile -> LDS ----------------
+        {
+            D2_IDS();
+            const unsigned char* pr = ldsb + opaque(D2_P1 + xi * (SM_STRIDE * 2) + 4 * xc);
+            float4 s = *reinterpret_cast<const float4*>(pr);
+#pragma unroll
+            for (int ww = 1; ww < 4; ++ww) {
+                const float4 v = *reinterpret_cast<const float4*>(pr + 128 * ww);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            const float dsc = sdS[xi] * (1.0f / (NL_F16_SG * NL_F16_SW1));
+            if (row0 + xi < P) *reinterpret_cast<float4*>(a.dX + (size_t)(row0 + xi) * NL_C + xc) = make_float4(s.x * dsc, s.y * dsc, s.z * dsc, s.w * dsc);
+            stage_x(xi, xc);
+            cz = pdep * pcos; cd = pd;
+            fetch_w1f(lane, w);
+        }
+        nl_lds_barrier();
+        DBG_STAMP(10);
+    }
+
+    if constexpr (STAMPS) {
+        if (a.dbg && threadIdx.x == 0) {
+            long long* rec = a.dbg + 256 + 8 * (long long)blockIdx.x;
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            rec[0] = wg_t0; rec[1] = (long long)wall_clock64(); rec[2] = wg_c0; rec[3] = (long long)__builtin_readcyclecounter();
+            rec[4] = hw; rec[5] = xcc; rec[6] = tile_no; rec[7] = 0;
+        }
+    }
+    D2_IDS();
+    // ---------------- loss sums ----------------
+    if (tid < 64) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { lossFs += __shfl_xor(lossFs, off); lossSdf += __shfl_xor(lossSdf, off); }
+        if (tid == 0 && (lossFs != 0.0 || lossSdf != 0.0)) {
+            atomicAdd(&a.dcounters[NLD_FS_SQ], lossFs); atomicAdd(&a.dcounters[NLD_SDF_SQ], lossSdf);
+        }
+    }
+    // ---------------- flush weight-gradient partials (slab blockIdx.x: W1, b1, b2, W3, b3 - dW2 is k_decoder_wgrad2*'s) ----------------
+    if (TRAIN) {
+        float* base = a.partials + (size_t)blockIdx.x * NL_DEC_PARAMS;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = 32 * (2 * w + j) + D32_RR(r) + 4 * lh;
+                if (l31 < NL_C) base[NL_OFF_W1 + k * NL_C + l31] = accW1h[j][r];
+                else if (l31 == NL_C) base[NL_OFF_B1 + k] = accW1h[j][r];
+            }
+            aW3[j] += __shfl_xor(aW3[j], 32); aB2[j] += __shfl_xor(aB2[j], 32);
+            if (lh == 0) { const int col = 32 * (2 * w + j) + l31; base[NL_OFF_W3 + col] = aW3[j]; base[NL_OFF_B2 + col] = aB2[j] * a.params[NL_OFF_W3 + col]; }
+        }
+        if (tid < 64) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { aB3 += __shfl_xor(aB3, off); dsMax = fmaxf(dsMax, __shfl_xor(dsMax, off)); }
+            if (tid == 0) {
+                base[NL_OFF_B3] = aB3;
+                if (dsMax > 0.f) atomicMax(const_cast<unsigned*>(&a.ls->ds_max_bits), __float_as_uint(dsMax));
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // dW2 = dH2^T H1 over all samples (K = samples).  Persistent; per 64-sample tile: H1 = relu(X W1^T+b1)
 // -> LDS, dH2[i][j] = mask(i,j) ? dsdf_i * w3_j : 0 -> LDS, then 256 MFMAs per wave into the 8
@@ -1554,11 +2131,16 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
 
 // sum per-workgroup partial slabs: out[i] = sum_b partials[b][i].  HBM-bound (nslabs x n floats in): 64 columns per block,
 // 4 slab groups per column, 4 independent accumulators per thread (16 loads in flight), fixed combination order.
-__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partials, int nslabs, int n, float* __restrict__ out)
+// Columns [lo2, hi2) are summed over the first nslabs2 slabs only (the dW2 region when the fused decoder kernel ran on more - smaller -
+// workgroups than the dW2 kernel: decoder_slab_plan below); a workgroup's 64 columns lie on one side of a region bound or take the
+// branch per lane.
+__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partials, int nslabs_all, int n, float* __restrict__ out,
+                                                         int lo2, int hi2, int nslabs2)
 {
     __shared__ float red[4][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + c;
+    const int nslabs = (i >= lo2 && i < hi2) ? nslabs2 : nslabs_all;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (i < n) {
         const float* p = partials + i;
@@ -1591,6 +2173,8 @@ static std::atomic<long long*> g_dec_dbg{nullptr};
 static std::atomic<int> g_gemm_mode{4};             // 0: fp32 MFMA GEMMs; bf16 MFMA on the exact-product formulations (gemm_x9 / gemm_mask_x) with
                                          // 1: all nine forward products (exact), 3: eight (without lo x lo), 2: six; fp16 pairs (gemm_f16) with
                                          // 4: three of the four forward products (THE DEFAULT), 5: all four
+static std::atomic<int> g_dec_layout{0};            // fp16-pair fused decoder kernel: 0 = by slab count (two 4-wave workgroups per CU - k_decoder2 - when the caller provides
+                                         // >= 2 slabs per CU, nl_decoder_grid_hint), 1 = one 8-wave workgroup per CU (k_decoder), 2 = k_decoder2 whatever the slab count
 static std::atomic<int> g_wgrad2_mode{2};           // 0: fp32 MFMA (k_decoder_wgrad2), 1: exact 0/1-mask x 3-term bf16 split, 2: 0/1-mask x fp16 pair (k_decoder_wgrad2_x; the default)
 
 extern "C" {
@@ -1609,28 +2193,59 @@ int nl_decoder_get_wgrad2_mode(void) { return g_wgrad2_mode; }
  * DEFAULTS: the *_m entry points and NlIterDesc.kernel_modes take the selection per call. */
 int nl_decoder_set_gemm_mode(int mode) { if (mode < 0 || mode > 5) return NL_ERR_INVALID_ARG; g_gemm_mode = mode; return NL_OK; }
 int nl_decoder_get_gemm_mode(void) { return g_gemm_mode; }
+/* workgroup layout of the fp16-pair fused decoder kernel (gemm modes 4 / 5): 0 = by slab count, 1 = one 8-wave workgroup per CU, 2 = two 4-wave workgroups per CU */
+int nl_decoder_set_layout(int layout) { if (layout < 0 || layout > 2) return NL_ERR_INVALID_ARG; g_dec_layout = layout; return NL_OK; }
+int nl_decoder_get_layout(void) { return g_dec_layout; }
 
 }  // extern "C"
 
-struct DecModes { int gemm, wgrad2; };
-// kernel_modes = NL_KERNEL_MODES(gemm_mode, wgrad2_mode) of include/nerfloam_hip.h; a zero field = the process default
+struct DecModes { int gemm, wgrad2, layout; };
+// kernel_modes = NL_KERNEL_MODES(gemm_mode, wgrad2_mode) | NL_KERNEL_LAYOUT(layout) of include/nerfloam_hip.h; a zero field = the process default
 static bool resolve_modes(int kernel_modes, DecModes* m)
 {
-    const int g = (kernel_modes & 0xFF) - 1, w = ((kernel_modes >> 8) & 0xFF) - 1;
-    if (g > 5 || w > 2 || (kernel_modes >> 16) != 0) return false;
+    const int g = (kernel_modes & 0xFF) - 1, w = ((kernel_modes >> 8) & 0xFF) - 1, l = (kernel_modes >> 16) & 3;
+    if (g > 5 || w > 2 || l > 2 || (kernel_modes >> 18) != 0) return false;
     m->gemm = g < 0 ? g_gemm_mode.load(std::memory_order_relaxed) : g;
     m->wgrad2 = w < 0 ? g_wgrad2_mode.load(std::memory_order_relaxed) : w;
+    m->layout = l == 0 ? g_dec_layout.load(std::memory_order_relaxed) : l;
     return true;
+}
+
+// compute units of the current device (cached per device id: hipGetDeviceProperties costs ~100 us)
+static int cu_count()
+{
+    static std::atomic<int> cached[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    const int slot = dev & 15;
+    int n = cached[slot].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    hipDeviceProp_t prop;
+    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cached[slot].store(n, std::memory_order_relaxed);
+    return n;
+}
+
+// Who writes which slab (`nslabs` = the slabs the caller's `partials` holds, also the upper bound of every persistent grid):
+//   * the 512-thread persistent kernels (k_decoder, k_decoder_wgrad2*, k_decoder_fwd) fit one workgroup per CU: grid = min(nslabs, CUs);
+//   * k_decoder2 (256 threads, two workgroups per CU) takes all nslabs; it is chosen for the fp16-pair arithmetic when the caller
+//     provides at least two slabs per CU (nl_decoder_grid_hint's count) or asks for it (layout 2).
+// nl_decoder_fwd_bwd_m, nl_decoder_wgrad2_m and nl_decoder_reduce_m derive the same plan from the same two arguments.
+struct SlabPlan { bool split; int grid_fused, grid512; };
+static SlabPlan decoder_slab_plan(const DecModes& km, int nslabs)
+{
+    const int cus = cu_count();
+    SlabPlan p;
+    p.grid512 = nslabs < cus ? nslabs : cus;
+    p.split = (km.gemm == 4 || km.gemm == 5) && km.layout != 1 && (km.layout == 2 || nslabs >= 2 * cus);
+    p.grid_fused = p.split ? nslabs : p.grid512;
+    return p;
 }
 
 extern "C" {
 
-int nl_decoder_grid_hint(void)
-{
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-}
+/* slabs to provide in `partials` (and the grid of the fused decoder kernel): two per compute unit of the current device */
+int nl_decoder_grid_hint(void) { return 2 * cu_count(); }
 
 int nl_decoder_fwd_bwd_m(const void* loss_scalars, const float* X, const float* params, const float* W2T,
                          const int* s_ray, const float* s_depth, const float* cos_gt, const float* gt_dist,
@@ -1648,7 +2263,23 @@ int nl_decoder_fwd_bwd_m(const void* loss_scalars, const float* X, const float* 
     a.relu2_mask = relu2_mask;
     a.dcounters = (double*)(counters + NL_CNT_INTS);
     a.dbg = g_dec_dbg;
-    const dim3 g(nslabs), b(DEC_THREADS);
+    const SlabPlan plan = decoder_slab_plan(km, nslabs);
+    if (plan.split) {
+        const dim3 g2(plan.grid_fused), b2(D2_THREADS);
+        if (a.dbg) {
+            if (train_decoder) hipLaunchKernelGGL((k_decoder2<true, 3, true>), g2, b2, 0, (hipStream_t)stream, a);
+            else               hipLaunchKernelGGL((k_decoder2<false, 3, true>), g2, b2, 0, (hipStream_t)stream, a);
+        } else if (km.gemm == 4) {
+            if (train_decoder) hipLaunchKernelGGL((k_decoder2<true, 3>), g2, b2, 0, (hipStream_t)stream, a);
+            else               hipLaunchKernelGGL((k_decoder2<false, 3>), g2, b2, 0, (hipStream_t)stream, a);
+        } else {
+            if (train_decoder) hipLaunchKernelGGL((k_decoder2<true, 4>), g2, b2, 0, (hipStream_t)stream, a);
+            else               hipLaunchKernelGGL((k_decoder2<false, 4>), g2, b2, 0, (hipStream_t)stream, a);
+        }
+        NL_LAUNCH_CHECK();
+        return NL_OK;
+    }
+    const dim3 g(plan.grid512), b(DEC_THREADS);
     if (a.dbg && (km.gemm == 4 || km.gemm == 3)) {           // phase probe: the stamped instantiations of the default and of the exact-product arithmetic
         if (km.gemm == 4) {
             if (train_decoder) hipLaunchKernelGGL((k_decoder<true, true, 3, true>), g, b, 0, (hipStream_t)stream, a);
@@ -1696,6 +2327,7 @@ int nl_decoder_wgrad2_m(const void* loss_scalars, const float* X, const float* p
     DecModes km;
     if (!resolve_modes(kernel_modes, &km)) return NL_ERR_INVALID_ARG;
     if (!loss_scalars || !X || !params || !dsdf || !relu2_mask || !partials || nslabs <= 0) return NL_ERR_INVALID_ARG;
+    nslabs = decoder_slab_plan(km, nslabs).grid512;
     if (km.wgrad2 == 2)
         hipLaunchKernelGGL(k_decoder_wgrad2_x<true>, dim3(nslabs), dim3(DEC_THREADS), 0, (hipStream_t)stream, (const NlLossScalars*)loss_scalars, X,
                            params, dsdf, relu2_mask, partials);
@@ -1721,6 +2353,7 @@ int nl_decoder_forward_m(const float* X, const float* params, const float* W2T, 
     if (!resolve_modes(kernel_modes, &km)) return NL_ERR_INVALID_ARG;
     if (!X || !params || !W2T || !sdf || P < 0 || nblocks <= 0) return NL_ERR_INVALID_ARG;
     if (P == 0) return NL_OK;
+    nblocks = decoder_slab_plan(km, nblocks).grid512;
     if (km.gemm == 4) hipLaunchKernelGGL((k_decoder_fwd<true, 3>), dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
     else if (km.gemm == 5) hipLaunchKernelGGL((k_decoder_fwd<true, 4>), dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
     else if (km.gemm == 3) hipLaunchKernelGGL((k_decoder_fwd<true, 8>), dim3(nblocks), dim3(DEC_THREADS), 0, (hipStream_t)stream, X, params, W2T, P, sdf);
@@ -1739,7 +2372,7 @@ int nl_decoder_forward(const float* X, const float* params, const float* W2T, in
 int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, void* stream)
 {
     if (!partials || !out || nslabs <= 0 || n <= 0) return NL_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_reduce_partials, dim3(nl_div_up(n, 64)), dim3(256), 0, (hipStream_t)stream, partials, nslabs, n, out);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nl_div_up(n, 64)), dim3(256), 0, (hipStream_t)stream, partials, nslabs, n, out, 0, 0, 0);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }
@@ -1750,7 +2383,11 @@ int nl_decoder_reduce_m(const float* partials, int nslabs, const float* params, 
     DecModes km;
     if (!resolve_modes(kernel_modes, &km)) return NL_ERR_INVALID_ARG;
     if (!partials || !params || !grad_out || nslabs <= 0) return NL_ERR_INVALID_ARG;
-    return nl_reduce_partials(partials, nslabs, NL_DEC_PARAMS, grad_out, stream);
+    const SlabPlan plan = decoder_slab_plan(km, nslabs);       // dW2's columns come from the dW2 kernel's slabs, the rest from the fused kernel's
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nl_div_up(NL_DEC_PARAMS, 64)), dim3(256), 0, (hipStream_t)stream, partials, plan.grid_fused, NL_DEC_PARAMS,
+                       grad_out, NL_OFF_W2, NL_OFF_B2, plan.grid512);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
 }
 
 int nl_decoder_reduce(const float* partials, int nslabs, const float* params, float* grad_out, void* stream)

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(X1_THREADS) void k_x1_merge(const unsigned char* __
         const int q = q_block + before + incl - mine;             // global hit rank of this thread's first hit ray
         // (batch row, position in the row) of that ray: ONE division per thread and pass, then counted up (sixteen `q / L`, `q % L` pairs by a
         // run-time divisor were most of this kernel's 10 us on a rank's share)
-        int qrow = q / L, within = q - qrow * L;
+        const int Ls = L > 0 ? L : 1;                             // (no hit ray on any rank: L == 0, nothing below is used - but no division by zero either)
+        int qrow = q / Ls, within = q - qrow * Ls;
         bool first = q == 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -232,6 +233,7 @@ int nl_dist_rows_move_t(int direction, const unsigned* bitmap, const int* prefix
                         int* fail_word, const NlTouchedRows* touched, void* stream)
 {
     if (!bitmap || !prefix || n_words <= 0 || !g_emb || !buf || capacity <= 0) return NL_ERR_INVALID_ARG;
+    if (touched && touched->struct_size != (int)sizeof(NlTouchedRows)) return NL_ERR_INVALID_ARG;
     NlTouchedDev t = {nullptr, nullptr, nullptr};
     if (touched && touched->flags && touched->list && touched->count) { t.list = touched->list; t.count = touched->count; t.flags = touched->flags; }
     const int nb = nl_div_up((long long)n_words * 32 * 16, 256);

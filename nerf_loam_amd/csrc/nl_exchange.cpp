@@ -183,7 +183,7 @@ int nl_exchange_emb_pose(const NlIterDesc* d, void* stream)
     if (rc != X_OK) return rc;
     if (rc_end != X_OK) return rc_end;
     if (rows) {
-        const NlTouchedRows touched = {d->touched_list, d->touched_count, d->touched_flags};
+        const NlTouchedRows touched = {(int)sizeof(NlTouchedRows), d->touched_list, d->touched_count, d->touched_flags, 1, 0};
         X_TRY(nl_dist_rows_move_t(1, d->rows_bitmap, d->rows_prefix, d->rows_words, d->g_emb, d->rows_buf, d->rows_cap, fail,
                                   d->touched_flags ? &touched : nullptr, stream));
     }

@@ -530,7 +530,7 @@ int nl_trilinear_bwd_t(const void* loss_scalars, const int* s_vox, const float* 
     FieldArgs a;
     int rc = fill_args(a, loss_scalars, s_vox, s_depth, s_ray, rays_d_world, rays_d_sensor, frame_id, poses, n_frames, centres, vertex_rows, emb, voxel_size);
     if (rc != NL_OK || !dX || nblocks <= 0 || (g_pose && !rays_d_sensor)) return NL_ERR_INVALID_ARG;
-    if (touched && touched->flags && (!touched->list || !touched->count)) return NL_ERR_INVALID_ARG;
+    if (touched && (touched->struct_size != (int)sizeof(NlTouchedRows) || (touched->flags && (!touched->list || !touched->count)))) return NL_ERR_INVALID_ARG;
     a.dX = dX; a.g_emb = g_emb; a.g_pose = g_pose; a.want_emb_grad = g_emb != nullptr; a.want_pose_grad = g_pose != nullptr;
     a.dbg = g_field_dbg;
     a.resident_blocks = g_field_one_round ? field_resident_blocks() : 0;

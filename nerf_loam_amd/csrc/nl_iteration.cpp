@@ -18,7 +18,7 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
     if (!d || d->struct_size != (int)sizeof(NlIterDesc) || d->N <= 0 || d->F <= 0 || !(stages & 7)) return IT_ERR_INVALID_ARG;
     const bool sharded = d->comm != nullptr;                    // ray-sharded multi-GPU iteration: the exchanges of nl_exchange.cpp ride along
     hipStream_t st = (hipStream_t)stream;
-    const NlTouchedRows touched_rows = {d->touched_list, d->touched_count, d->touched_flags, d->touched_copies, d->touched_copy_stride};
+    const NlTouchedRows touched_rows = {(int)sizeof(NlTouchedRows), d->touched_list, d->touched_count, d->touched_flags, d->touched_copies, d->touched_copy_stride};
     const NlTouchedRows* touched = d->touched_flags ? &touched_rows : nullptr;      // rows written by the scatter are recorded
     int rc = IT_OK;
     bool overlapped = false, forked = false;

@@ -74,6 +74,16 @@ __global__ void k_transpose_w2(const float* __restrict__ params, float* __restri
 //     W2TX (forward, H2 = H1 W2^T):    element e <-> k = 16 s + 8 h + e, n = 32 t + c, value W2[n][k]
 // The same two matrices as fp16 pairs (gemm modes 4 / 5; nl_split2_f16): [plane(2)][t(8)][s(16)][lane(64)][8 f16], the same element order,
 //     W2H  (dgrad):   (w3_j * W2[j][k]) * 2^12,    W2TH (forward):  W2[n][k] * 2^8.
+// W1[k][c] * 2^8 as an fp16 pair into the two operand forms k_decoder2 reads (nl_common.h: W1F, W1X); ws16 = the weight workspace as 16-bit elements
+__device__ __forceinline__ void nl_store_w1_planes(uint16_t* ws16, int k, int c, float v)
+{
+    uint16_t hi, lo;
+    nl_split2_f16(v, NL_F16_SW1, &hi, &lo);
+    uint16_t* f = ws16 + 2 * NL_DEC_WS_W1F_OFF, *x = ws16 + 2 * NL_DEC_WS_W1X_OFF;
+    f[NL_W1F_INDEX(k, c, 0)] = hi; f[NL_W1F_INDEX(k, c, 1)] = lo;
+    x[NL_W1X_INDEX(k, c, 0)] = hi; x[NL_W1X_INDEX(k, c, 1)] = lo;
+}
+
 __global__ void k_prepare_w2x(const float* __restrict__ params, uint16_t* __restrict__ W2X, uint16_t* __restrict__ W2TX)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;         // one thread per (tile, s, lane)
@@ -90,6 +100,7 @@ __global__ void k_prepare_w2x(const float* __restrict__ params, uint16_t* __rest
             nl_split2_f16(v, which ? NL_F16_SW2 : NL_F16_SG, &dh[0], &dh[NL_W * NL_W]);
         }
     }
+    if (t < NL_W * NL_C) nl_store_w1_planes(reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(W2X) - NL_W * NL_W), t >> 4, t & 15, params[NL_OFF_W1 + t]);
 }
 
 // poses12[f] = [R(w) row-major | t]   from pose6[f] = [t, w]     (se3pose.py:18-35)
@@ -271,6 +282,7 @@ __global__ void __launch_bounds__(256) k_optim_step(OptimArgs a)
                 float p = a.params[i], m = a.dm[i], v = a.dv[i];
                 nl_adam_f32(&p, a.grad[i], &m, &v, h);
                 a.params[i] = p; a.dm[i] = m; a.dv[i] = v;
+                if (i < NL_OFF_B1) nl_store_w1_planes(reinterpret_cast<uint16_t*>(a.W2T), i >> 4, i & 15, p);       // W1's operand planes (k_decoder2)
             }
         }
     } else {
@@ -385,6 +397,9 @@ int nl_adam_f32(float* p, const float* g, float* m, float* v, int n, const int* 
     return NL_OK;
 }
 
+int nl_dec_ws_floats(void) { return NL_DEC_WS_TOTAL; }
+int nl_abi_version(void) { return NL_ABI_VERSION; }
+
 int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream)
 {
     if (!params || !W2T) return NL_ERR_INVALID_ARG;
@@ -423,7 +438,7 @@ int nl_optimiser_step_t(int* state, double lr_emb, double lr_dec, double lr_pose
                         const NlTouchedRows* touched, void* stream)
 {
     if (!state || skip_mode < 0 || skip_mode > 2 || (skip_mode && !counters)) return NL_ERR_INVALID_ARG;
-    if (touched && touched->list && !touched->count) return NL_ERR_INVALID_ARG;
+    if (touched && (touched->struct_size != (int)sizeof(NlTouchedRows) || (touched->list && !touched->count))) return NL_ERR_INVALID_ARG;
     if (emb && (!g_emb || !emb_m || !emb_v || n_emb <= 0)) return NL_ERR_INVALID_ARG;
     if (dec_params && (!dec_grad || !dec_m || !dec_v || !dec_ws)) return NL_ERR_INVALID_ARG;
     if (pose6 && (!g_pose || !pose_m || !pose_v || !poses12 || F <= 0)) return NL_ERR_INVALID_ARG;
@@ -484,7 +499,7 @@ __global__ void k_touched_count_clear(int* count) { *count = 0; }
 
 int nl_touched_rows_reset(const NlTouchedRows* touched, float* g_emb, void* emb_m, void* emb_v, void* stream)
 {
-    if (!touched || !touched->list || !touched->count || !touched->flags || !g_emb || !emb_m || !emb_v) return NL_ERR_INVALID_ARG;
+    if (!touched || touched->struct_size != (int)sizeof(NlTouchedRows) || !touched->list || !touched->count || !touched->flags || !g_emb || !emb_m || !emb_v) return NL_ERR_INVALID_ARG;
     if (touched->copies > 1 && touched->copy_stride <= 0) return NL_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_touched_reset, dim3(1024), dim3(256), 0, (hipStream_t)stream, touched->list, touched->count, touched->flags, g_emb,
                        (uint16_t*)emb_m, (uint16_t*)emb_v, touched->copies > 1 ? touched->copies : 1, touched->copy_stride);

@@ -147,7 +147,7 @@ def touched_rows(t):
     if t is None:
         return None
     copies, stride = (int(t[3]), int(t[4])) if len(t) > 3 else (1, 0)
-    return ctypes.byref(L.NlTouchedRows(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), copies, stride))
+    return ctypes.byref(L.NlTouchedRows(ctypes.sizeof(L.NlTouchedRows), t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), copies, stride))
 
 
 def trilinear_bwd(loss_scalars, s_vox, s_depth, s_ray, rays_d_world, rays_d_sensor, frame_id, poses12, n_frames, centres, vertex_rows,

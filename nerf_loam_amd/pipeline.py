@@ -221,10 +221,12 @@ class DecoderDevice:
 
 
 class SdfEngine:
-    def __init__(self, max_rays, samples_per_ray_cap=48, max_frames=8, device="cuda", gemm_mode=None, wgrad2_mode=None, sparse_adam=True, emb_grad_copies=1):
+    def __init__(self, max_rays, samples_per_ray_cap=48, max_frames=8, device="cuda", gemm_mode=None, wgrad2_mode=None, sparse_adam=True, emb_grad_copies=1,
+                 dec_layout=None):
         """gemm_mode / wgrad2_mode: the decoder kernel selection of THIS engine (include/nerfloam_hip.h: 0 fp32 matrix cores,
         1 exact-product bf16 splits, ...); None = the process default (NL_GEMM_MODE / NL_WGRAD2_MODE).  Carried per call
-        (NL_KERNEL_MODES), so engines with different selections coexist in one process."""
+        (NL_KERNEL_MODES), so engines with different selections coexist in one process.  dec_layout (NL_KERNEL_LAYOUT): 1 = one 8-wave
+        decoder workgroup per CU, 2 = two independent 4-wave workgroups, None = the library's rule (2 when the slabs allow)."""
         L.require_gpu()
         # sparse_adam: the embedding optimiser sweeps the rows touched since begin_call (bit-identical to the reference's dense sweep,
         # include/nerfloam_hip.h NlTouchedRows) and begin_call clears only those - False = dense sweep + E-sized memset per call
@@ -234,7 +236,7 @@ class SdfEngine:
         # (150-scan map, 16 copies: DESIGN.md 4.7).  Only with the touched-rows optimiser, and not on a ray-sharded engine (the exchange reads one array).
         self.emb_grad_copies = self._emb_copies_wanted = max(1, int(emb_grad_copies)) if self.sparse_adam else 1
         self._touched, self._emb_cap, self._emb_dirty_dense = None, 0, False
-        self.kernel_modes = L.kernel_modes(gemm_mode, wgrad2_mode)
+        self.kernel_modes = L.kernel_modes(gemm_mode, wgrad2_mode, dec_layout)
         self.dev = torch.device(device)
         self.N_cap = int(max_rays)
         self.samples_per_ray_cap, self.samples_clipped = int(samples_per_ray_cap), False     # (samples_per_ray_bound: what no call can exceed)
@@ -800,7 +802,9 @@ class SdfEngine:
         with torch.cuda.stream(side):                       # warm-up outside capture (allocator, lazy module load)
             self.forward_backward(m, dec, cfg, **fb)
             if self.g_emb is not None:
-                self.g_emb.zero_()
+                # EVERY accumulator copy (emb_grad_copies > 1: g_emb is copy 0 only; the warm-up's waves added into all of them, and the rows they touched
+                # stay listed - the first replay's sweep would otherwise add the stale copies 1..K-1 to its gradient)
+                self._emb_state[:self.emb_grad_copies * self._emb_cap * L.NL_C].zero_()
             self.g_pose.zero_()
         torch.cuda.current_stream(self.dev).wait_stream(side)
         g = torch.cuda.CUDAGraph()

@@ -12,7 +12,7 @@ sel = np.sort(rng.choice(len(w["points"]), 2048, replace=False))
 eng = P.SdfEngine(max_rays=2048, samples_per_ray_cap=96)
 eng.set_rays(w["dirs"][sel], w["points"][sel], w["cos"][sel]); eng.set_poses(w["pose"][None], [1])
 cfg = P.IterConfig(step_size=0.04); eng.begin_call(w["map"], None)
-dbg = torch.zeros(256, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(256 + 8 * 1024, dtype=torch.int64, device="cuda")     # (+ k_decoder2's per-workgroup records)
 for _ in range(3):
     eng.forward_backward(w["map"], w["dec"], cfg, train_decoder=False, want_emb_grad=False, want_pose_grad=True)
 L.lib().nl_decoder_set_debug_buffer(L.ptr(dbg))
