@@ -29,7 +29,7 @@ extern "C" {
 #define NL_CNT_DOUBLES 4        /* ... followed by double sums: counter block = 16*4 + 4*8 bytes */
 #define NL_LOSS_SCALARS_BYTES 48
 #define NL_DEC_PARAMS 70401     /* W1[256x16] b1[256] W2[256x256] b2[256] W3[256] b3[1] */
-#define NL_DEC_WS_FLOATS 401408    /* decoder weight workspace: W2^T fp32 + 2 x 3 bf16 operand planes + 2 x 2 fp16 operand planes of W2 + 2 x 2 fp16 operand planes of W1 (nl_dec_ws_floats() returns it) */
+#define NL_DEC_WS_FLOATS 401424    /* decoder weight workspace: W2^T fp32 + 2 x 3 bf16 operand planes + 2 x 2 fp16 operand planes of W2 + 2 x 2 fp16 operand planes of W1 (nl_dec_ws_floats() returns it) */
 #define NL_EMB_CHANNELS 16
 
 /* Multi-GPU ray sharding: fold the all-gathered counter blocks gathered[world][NL_CNT_INTS + 2*NL_CNT_DOUBLES] (ints) into
@@ -229,6 +229,9 @@ int nl_decoder_fwd_bwd(const void* loss_scalars, const float* X, const float* pa
  * forward-only) launch min(nslabs, compute units) workgroups, layout 2 launches nslabs; nl_decoder_reduce_m sums each column over the slabs
  * its producer wrote (the same rule, from the same two arguments - pass all three calls of an iteration the same nslabs and kernel_modes). */
 #define NL_KERNEL_LAYOUT(layout) (((layout) & 3) << 16)
+/* the layout nl_iteration (and the Python stage-wise path) put into a kernel_modes word whose layout field is 0: 1 for iterations of up to 16 384 rays (there the
+ * iteration is a latency chain and the 8-wave workgroup finishes its one or two tiles sooner; also: those shapes keep round 5's bits), 0 = by slab count beyond */
+int nl_decoder_layout_for(int n_rays);
 int nl_decoder_fwd_bwd_m(const void* loss_scalars, const float* X, const float* params, const float* W2T,
                          const int* s_ray, const float* s_depth, const float* cos_gt, const float* gt_dist,
                          float* sdf, float* dsdf, float* dX, float* partials, unsigned* relu2_mask, int nslabs, int train_decoder,
@@ -256,11 +259,26 @@ int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, voi
  *   floats [327680, 393216):  "W2TH" = W2[n][k] * 2^8, likewise: the operands of gemm modes 4 / 5,
  *   floats [393216, 397312):  "W1F"  = W1[k][c] * 2^8 as two fp16 planes in the order of layer 1's B fragments,
  *   floats [397312, 401408):  "W1X"  = the same values in the order of dX's B fragments (csrc/nl_common.h NL_W1F_INDEX / NL_W1X_INDEX; round 6:
- *                             the two-workgroups-per-CU decoder kernel has neither registers nor LDS to keep W1's operand forms resident).
+ *                             the two-workgroups-per-CU decoder kernel has neither registers nor LDS to keep W1's operand forms resident),
+ *   words  [401408, 401424):  the RANGE BLOCK (round 6).  The fp16-pair arithmetic clips an operand that leaves its scaled fp16 range (|X| >= 1023.5 - 255.9 with a
+ *                             trainable decoder -, |W1|, |W2| >= 255.9, H1 >= 4094, |w3_j W2[j][k]| >= 63.97, a dgrad sum >= 63.97) instead of overflowing, which a caller
+ *                             must be able to notice: word 4 = STATUS, sticky NL_SAT_* bits raised by the decoder kernels at their end (X and the weight planes exactly;
+ *                             H1 and the dgrad sums through the bounds max|X| * max_k ||W1[k]||_1 + max|b1| and 256 * max|w3_j W2[j][k]| - a set bit there means "may
+ *                             have clipped"), words 0-3 the weight statistics those bounds use (maintained with the planes).  nl_optimiser_step* latches STATUS into
+ *                             bit 1 of the call status (adam_state[3]; bit 0 = sample overflow); nl_decoder_range_status reads / clears it.  Zero cost inside the
+ *                             kernels' tile loops beyond a running max |X|.  A flagged call is re-run under gemm mode 3 (exact products, unbounded range).
  * The workspace grew in rounds 5 and 6: a caller compiled against an older header would hand over a shorter buffer, so it checks
  * nl_dec_ws_floats() == NL_DEC_WS_FLOATS (and nl_abi_version() == NL_ABI_VERSION) once at start-up - the Python loader does. */
 int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream);
 int nl_dec_ws_floats(void);             /* NL_DEC_WS_FLOATS of the library that is loaded */
+#ifndef NL_SAT_X
+#define NL_SAT_X 1u         /* an input X left the fp16-pair range, or is NaN / Inf */
+#define NL_SAT_H1 2u        /* bound: the first hidden layer may have clipped */
+#define NL_SAT_Q 4u         /* bound: the dgrad sums may have clipped */
+#define NL_SAT_PLANES 8u    /* a weight operand plane clipped */
+#endif
+/* the range block's sticky status word -> *status_out (host pointer; synchronises `stream`); clear != 0 zeroes it afterwards */
+int nl_decoder_range_status(float* W2T, unsigned* status_out, int clear, void* stream);
 #define NL_ABI_VERSION 6                /* bumped whenever a struct, a workspace size or an argument's meaning changes */
 int nl_abi_version(void);               /* NL_ABI_VERSION of the library that is loaded */
 /* The two 256-deep GEMMs of nl_decoder_fwd_bwd / nl_decoder_forward (gemm_mode).  Values and accumulation are fp32 in every mode; the

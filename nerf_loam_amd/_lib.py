@@ -16,7 +16,9 @@ NL_LOSS_SCALARS_BYTES = 48
 NL_ADAM_STATE_BYTES = 112
 NL_DEC_PARAMS = 70401
 NL_ABI_VERSION = 6
-NL_DEC_WS_FLOATS = 401408        # decoder weight workspace: W2^T fp32 + 2 x 3 bf16 + 2 x 2 fp16 operand planes of W2 + 2 x 2 fp16 planes of W1 (include/nerfloam_hip.h; checked against nl_dec_ws_floats() at load)
+NL_DEC_WS_RANGE_STATUS = 401408 + 4    # float index of the range block's sticky status word in the decoder weight workspace (csrc/nl_common.h NLR_STATUS)
+NL_SAT_X, NL_SAT_H1, NL_SAT_Q, NL_SAT_PLANES = 1, 2, 4, 8
+NL_DEC_WS_FLOATS = 401424        # decoder weight workspace: W2^T fp32 + 2 x 3 bf16 + 2 x 2 fp16 operand planes of W2 + 2 x 2 fp16 planes of W1 (include/nerfloam_hip.h; checked against nl_dec_ws_floats() at load)
 NL_SEL_BATCH_WS_INTS_PER_FRAME = 8 + 4 * 128 + 2 * 4096     # NL_SELECT_BATCH_WS_INTS(1)
 NL_SEL_MAX_FRAMES = 8
 NL_MAX_FRAMES = 32               # frames (poses) one field-kernel launch takes (csrc/nl_field.hip)
@@ -155,7 +157,9 @@ _SIGS = {
     "nl_decoder_get_wgrad2_mode": ([], _I),
     "nl_decoder_set_layout": ([_I], _I),
     "nl_decoder_get_layout": ([], _I),
+    "nl_decoder_layout_for": ([_I], _I),
     "nl_dec_ws_floats": ([], _I),
+    "nl_decoder_range_status": ([_P, _P, _I, _P], _I),
     "nl_abi_version": ([], _I),
     "nl_reduce_partials": ([_P, _I, _I, _P, _P], _I),
     "nl_decoder_reduce": ([_P, _I, _P, _P, _P], _I),

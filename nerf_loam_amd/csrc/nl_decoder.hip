@@ -479,6 +479,31 @@ __device__ __forceinline__ float wave_max_nonneg(float v)
     return __int_as_float(m);
 }
 
+// Range watch of the fp16-pair arithmetic on a workgroup's FIRST tile (nl_common.h NL_SAT_H1 / NL_SAT_Q): ~100 instructions once per workgroup instead of
+// one or two per element in every tile.  h1_clips: H1 * 2^4 = relu(acc * S1 + b1s) reaches 65504 for a layer-1 accumulator of this lane; q_clips: a dgrad
+// accumulator of a row whose H1 is positive (the others are discarded) reaches +-65504.  Negated comparisons: a NaN counts.
+__device__ __forceinline__ bool h1_clips(const f32x16& c0, const f32x16& c1, float b1s)
+{
+    constexpr float S1 = NL_F16_SH / (NL_F16_SX * NL_F16_SW1);
+    float m = c0[0];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = fmaxf(fmaxf(c0[r], c1[r]), m);
+    bool nan = false;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nan |= (c0[r] != c0[r]) | (c1[r] != c1[r]);
+    return nan || !(fmaf(m, S1, b1s) < NL_F16_MAX);
+}
+__device__ __forceinline__ bool q_clips(const f32x16& g0, const f32x16& g1, unsigned m1)
+{
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        bad |= ((m1 >> r) & 1u) && !(fabsf(g0[r]) < NL_F16_MAX);
+        bad |= ((m1 >> (16 + r)) & 1u) && !(fabsf(g1[r]) < NL_F16_MAX);
+    }
+    return bad;
+}
+
 // H1 = relu(pre + b1) for this lane's column / 32 rows -> three bf16 planes in LDS (A operand of gemm_x9); returns the
 // lane's 32 ReLU bits (bit r: row d32_row(r, lh), bit 16 + r: row 32 + d32_row(r, lh)) for the dgrad epilogue.
 // Two neighbouring lanes hold neighbouring columns (k, k + 1) of the same rows, and a row of a plane is k-contiguous: the even lane
@@ -677,8 +702,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         for (int i = tid; i < NL_W * NL_C; i += DEC_THREADS) sW1[i] = a.params[NL_OFF_W1 + i];
     }
     // X tile of the next phase B: fp32 (dW1 of the trainable decoder reads it in phase I) and, in the bf16 mode, three bf16 planes
+    unsigned xw = 0u;                                   // F16: range watch (nl_common.h nl_range_check)
     auto stage_x = [&](float* sXf) {
         if (!XG || TRAIN) { sXf[xi * LDX + xc] = xv.x; sXf[xi * LDX + xc + 1] = xv.y; }      // (train: dW1 needs the fp32 values)
+        if (F16) xw = nl_xw_update(xw, xv.x, xv.y);
         if (F16) {
             unsigned q0, q1;
             split2_pair_f16(sat_f16(xv.x * NL_F16_SX), sat_f16(xv.y * NL_F16_SX), &q0, &q1);
@@ -766,6 +793,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             }
             if (F16) {
                 gemm_f16_prefetch(rsW2TH, w, lane, bqh);         // W2 planes of the first k-steps: in flight across the barrier
+                if (tile_no == 0 && h1_clips(c0, c1, b1c * NL_F16_SH)) xw = nl_xw_mark(xw, NL_SAT_H1);
                 m1 = store_h1_planes_f16(reinterpret_cast<unsigned short*>(lds), col, lh, c0, c1, b1c * NL_F16_SH);
             } else if (XG) {
                 gemm_x9_prefetch(rsW2TX, w, lane, bq9);          // W2 planes of the first k-steps: in flight across the barrier
@@ -902,6 +930,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
             else if (XG)     gemm_mask_x<true>(rsW2X, w, lane, reinterpret_cast<const unsigned char*>(lds), bqm, g0v, g1v);
             else    gemm256(rsW2, (lh * NL_W + col) * 4, sD + l31 * LDH + lh, sD + (32 + l31) * LDH + lh, g0v, g1v);
             DBG_STAMP(7);
+            if constexpr (F16) { if (tile_no == 0 && q_clips(g0v, g1v, m1)) xw = nl_xw_mark(xw, NL_SAT_Q); }
             if constexpr (!F16) {
             const float* dsb = sdS + opaque(4 * lh);
             const float* hb = sH1 + opaque(4 * lh * LDH + col);
@@ -1084,6 +1113,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
         DBG_STAMP(10);
     }
 
+    if constexpr (F16) nl_range_check(a.W2T, xw, TRAIN);       // did an operand of the fp16-pair arithmetic leave its range?  (sticky status word of the weight workspace)
     // ---------------- loss sums ----------------
     if (tid < 64) {
 #pragma unroll
@@ -1351,7 +1381,9 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_decoder2(DecArgs a)
             if (pray >= 0) { pdep = a.s_depth[row0 + lane_]; pcos = a.cos_gt[pray]; pd = a.gt_dist[pray]; }
         }
     };
+    unsigned xw = 0u;                                     // range watch (nl_common.h nl_range_check)
     auto stage_x = [&](int xi_, int xc_) {
+        xw = nl_xw_update(nl_xw_update(xw, xv.x, xv.y), xv.z, xv.w);
         if (TRAIN) { float* d = sXf + opaque(xi_ * LDX + xc_); d[0] = xv.x; d[1] = xv.y; d[2] = xv.z; d[3] = xv.w; }
         unsigned h0, l0, h1, l1;
         split2_pair_f16(sat_f16(xv.x * NL_F16_SX), sat_f16(xv.y * NL_F16_SX), &h0, &l0);
@@ -1410,6 +1442,7 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_decoder2(DecArgs a)
                 for (int pa = 1; pa >= 0; --pa)
 #pragma unroll
                     for (int pq = 1; pq >= 0; --pq) { c0 = mma16<true>(xa0[pa], w1f[j][pq], c0); c1 = mma16<true>(xa1[pa], w1f[j][pq], c1); }
+                if (tile_no == 0 && h1_clips(c0, c1, b1s[j])) xw = nl_xw_mark(xw, NL_SAT_H1);
                 m1[j] = store_h1_planes_f16(reinterpret_cast<unsigned short*>(ldsb), 32 * (2 * w + j) + l31, lh, c0, c1, b1s[j]);
             }
         }
@@ -1459,7 +1492,11 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_decoder2(DecArgs a)
                     bool f, m;
                     nl_loss_masks(cz, cd, ls.tau, ls.max_depth, &f, &m);
                     float q1, q2;
-                    ds = nl_loss_grad(s, cz, cd, f, m, ls, &q1, &q2);
+                    // (the loss gradient's uniform factors are products of launch constants: hoisted out of the tile loop they are two more vector registers
+                    //  held - here: spilled - for the whole kernel; laundering the first factors recomputes the two products per tile, same order, same bits)
+                    NlLossScalars lsd = ls;
+                    lsd.fs_weight = launder_f(ls.fs_weight); lsd.sdf_weight = launder_f(ls.sdf_weight);
+                    ds = nl_loss_grad(s, cz, cd, f, m, lsd, &q1, &q2);
                     if (w == 0) {
                         a.sdf[g] = s; a.dsdf[g] = ds;
                         lossFs += (double)q1; lossSdf += (double)q2;
@@ -1553,6 +1590,7 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_decoder2(DecArgs a)
             gemm_mask_2ct(rsW2H, w, lane, ldsb, bqm, g);
             D2_PRIO_VALU();
             DBG_STAMP(7);
+            if (tile_no == 0 && (q_clips(g[0][0], g[0][1], m1[0]) || q_clips(g[1][0], g[1][1], m1[1]))) xw = nl_xw_mark(xw, NL_SAT_Q);
             const int so = __builtin_amdgcn_readfirstlane(w) * 2 * 2 * 1024;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -1667,6 +1705,7 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_decoder2(DecArgs a)
         }
     }
     D2_IDS();
+    nl_range_check(a.W2T, xw, TRAIN);                     // did an operand of the fp16-pair arithmetic leave its range?  (sticky status word of the weight workspace)
     // ---------------- loss sums ----------------
     if (tid < 64) {
 #pragma unroll
@@ -2035,12 +2074,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
         for (int kk = 0; kk < NL_C / 2; ++kk) w1r[kk] = W1[col * NL_C + 2 * kk + lh];
     }
     const int ntiles = (P + DEC_M - 1) / DEC_M;
+    unsigned xw = 0u;                                     // F16: range watch (nl_common.h nl_range_check)
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * DEC_M;
         {
             const int e = tid * 2, i = e >> 4, c = e & 15;
             float2 v = make_float2(0.f, 0.f);
             if (row0 + i < P) v = *reinterpret_cast<const float2*>(X + (size_t)(row0 + i) * NL_C + c);
+            if (F16) xw = nl_xw_update(xw, v.x, v.y);
             if (F16) {
                 unsigned* d = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(sX) + i * 32 + 2 * c);
                 split2_pair_f16(sat_f16(v.x * NL_F16_SX), sat_f16(v.y * NL_F16_SX), &d[0], &d[XG_XP_BYTES / 4]);
@@ -2090,6 +2131,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
             }
             if (F16) {
                 gemm_f16_prefetch(rsW2TH, w, lane, bqh);
+                if (tile == (int)blockIdx.x && h1_clips(c0, c1, b1c * NL_F16_SH)) xw = nl_xw_mark(xw, NL_SAT_H1);
                 store_h1_planes_f16(reinterpret_cast<unsigned short*>(lds), col, lh, c0, c1, b1c * NL_F16_SH);
             } else if (XG) {
                 gemm_x9_prefetch(rsW2TX, w, lane, bq9);
@@ -2127,6 +2169,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder_fwd(const float* __r
         }
         // (sS is rewritten only after two more barriers; sX / sH1 after one)
     }
+    if constexpr (F16) nl_range_check(W2T, xw, false);
 }
 
 // sum per-workgroup partial slabs: out[i] = sum_b partials[b][i].  HBM-bound (nslabs x n floats in): 64 columns per block,
@@ -2196,6 +2239,9 @@ int nl_decoder_get_gemm_mode(void) { return g_gemm_mode; }
 /* workgroup layout of the fp16-pair fused decoder kernel (gemm modes 4 / 5): 0 = by slab count, 1 = one 8-wave workgroup per CU, 2 = two 4-wave workgroups per CU */
 int nl_decoder_set_layout(int layout) { if (layout < 0 || layout > 2) return NL_ERR_INVALID_ARG; g_dec_layout = layout; return NL_OK; }
 int nl_decoder_get_layout(void) { return g_dec_layout; }
+/* NL_KERNEL_LAYOUT of an iteration over n_rays rays when neither the caller nor the process default chose one (csrc/nl_common.h: the launch-shape table):
+ * 1 up to NL_RAYS_DECODER_SPLIT rays - there the iteration is a latency chain and the 8-wave workgroup finishes a tile sooner -, else 0 (by slab count) */
+int nl_decoder_layout_for(int n_rays) { return g_dec_layout.load(std::memory_order_relaxed) == 0 && n_rays <= NL_RAYS_DECODER_SPLIT ? 1 : 0; }
 
 }  // extern "C"
 

@@ -20,6 +20,8 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
     hipStream_t st = (hipStream_t)stream;
     const NlTouchedRows touched_rows = {(int)sizeof(NlTouchedRows), d->touched_list, d->touched_count, d->touched_flags, d->touched_copies, d->touched_copy_stride};
     const NlTouchedRows* touched = d->touched_flags ? &touched_rows : nullptr;      // rows written by the scatter are recorded
+    // decoder workgroup layout by ray count where the descriptor leaves it open (csrc/nl_common.h NL_RAYS_DECODER_SPLIT)
+    const int kernel_modes = (d->kernel_modes & NL_KERNEL_LAYOUT(3)) ? d->kernel_modes : (d->kernel_modes | NL_KERNEL_LAYOUT(nl_decoder_layout_for(d->N)));
     int rc = IT_OK;
     bool overlapped = false, forked = false;
     // an error after the side stream was forked still JOINS it before returning: a capture in progress is not left with a dangling
@@ -72,7 +74,7 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
                                    d->vertex_rows, d->emb, d->voxel_size, d->X, d->field_blocks, stream));
         if (d->ev_decoder_begin && hipEventRecord((hipEvent_t)d->ev_decoder_begin, st) != hipSuccess) return leave(IT_ERR_LAUNCH);
         NL_TRY(nl_decoder_fwd_bwd_m(d->loss_scalars, d->X, d->dec_params, d->dec_ws, d->s_ray, d->s_depth, d->cos_gt, d->gt_dist, d->sdf, d->dsdf,
-                                    d->dX, d->partials, d->relu2_mask, d->n_slabs, d->train_decoder, c, d->kernel_modes, stream));
+                                    d->dX, d->partials, d->relu2_mask, d->n_slabs, d->train_decoder, c, kernel_modes, stream));
         if (d->ev_decoder_end && hipEventRecord((hipEvent_t)d->ev_decoder_end, st) != hipSuccess) return leave(IT_ERR_LAUNCH);
         // ray-sharded with the gradient exchange in the same call: the embedding scatter goes FIRST and its all-reduce (the large message:
         // 64 B per embedding row or per touched row, + the pose partials) leaves on the side stream while dW2 and the slab reduction run
@@ -93,9 +95,9 @@ extern "C" int nl_iteration(const NlIterDesc* d, int stages, void* stream)
         if (d->train_decoder) {
             // (timing events: the caller records ev_decoder_end .. ev_wgrad2_end around the dW2 kernel only where nothing else runs between them -
             //  the overlapped sharded order puts the scatter there, and bench.py times that order without them)
-            NL_TRY(nl_decoder_wgrad2_m(d->loss_scalars, d->X, d->dec_params, d->dsdf, d->relu2_mask, d->partials, d->n_slabs, d->kernel_modes, stream));
+            NL_TRY(nl_decoder_wgrad2_m(d->loss_scalars, d->X, d->dec_params, d->dsdf, d->relu2_mask, d->partials, d->n_slabs, kernel_modes, stream));
             if (d->ev_wgrad2_end && hipEventRecord((hipEvent_t)d->ev_wgrad2_end, st) != hipSuccess) return leave(IT_ERR_LAUNCH);
-            NL_TRY(nl_decoder_reduce_m(d->partials, d->n_slabs, d->dec_params, d->dec_grad, d->kernel_modes, stream));
+            NL_TRY(nl_decoder_reduce_m(d->partials, d->n_slabs, d->dec_params, d->dec_grad, kernel_modes, stream));
         }
         if (overlapped) {
             if (hipStreamWaitEvent(st, (hipEvent_t)d->ev_join, 0) != hipSuccess) return leave(IT_ERR_LAUNCH);

@@ -61,6 +61,8 @@ __global__ void k_transpose_w2(const float* __restrict__ params, float* __restri
     __shared__ float t[32][33];
     const float* W2 = params + NL_OFF_W2;
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    // a rebuild from scratch: the clipped-plane flag starts again (k_prepare_w2x, the next launch, raises it); the sticky status word stays
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.y == 0 && threadIdx.x == 0) reinterpret_cast<unsigned*>(W2T + NL_DEC_WS_RANGE_OFF)[NLR_PLANE_SAT] = 0u;
     for (int r = threadIdx.y; r < 32; r += blockDim.y) t[r][threadIdx.x] = W2[(by + r) * NL_W + bx + threadIdx.x];
     __syncthreads();
     for (int r = threadIdx.y; r < 32; r += blockDim.y) W2T[(bx + r) * NL_W + by + threadIdx.x] = t[threadIdx.x][r];
@@ -90,17 +92,25 @@ __global__ void k_prepare_w2x(const float* __restrict__ params, uint16_t* __rest
     if (t >= 8 * 16 * 64) return;
     const int lane = t & 63, s = (t >> 6) & 15, tl = t >> 10;
     const int c = 32 * tl + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
+    unsigned* range = reinterpret_cast<unsigned*>(reinterpret_cast<float*>(W2X) - NL_W * NL_W + NL_DEC_WS_RANGE_OFF);
+    bool clipped = false;
     for (int which = 0; which < 2; ++which) {
         uint16_t* dst = (which ? W2TX : W2X) + (size_t)t * 8;
         for (int e = 0; e < 8; ++e) {
             const int kk = k0 + e;
             const float v = which ? params[NL_OFF_W2 + c * NL_W + kk] : params[NL_OFF_W3 + kk] * params[NL_OFF_W2 + kk * NL_W + c];
+            clipped |= !(fabsf(v) * (which ? NL_F16_SW2 : NL_F16_SG) <= NL_F16_MAX);
             nl_split3_bf16(v, &dst[e], &dst[e + NL_W * NL_W], &dst[e + 2 * NL_W * NL_W]);
             uint16_t* dh = W2X + NL_DEC_WS_W2H_OFF16 + (which ? 2 * NL_W * NL_W : 0) + (size_t)t * 8 + e;      // W2H | W2TH behind the bf16 planes
             nl_split2_f16(v, which ? NL_F16_SW2 : NL_F16_SG, &dh[0], &dh[NL_W * NL_W]);
         }
     }
-    if (t < NL_W * NL_C) nl_store_w1_planes(reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(W2X) - NL_W * NL_W), t >> 4, t & 15, params[NL_OFF_W1 + t]);
+    if (t < NL_W * NL_C) {
+        const float w = params[NL_OFF_W1 + t];
+        nl_store_w1_planes(reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(W2X) - NL_W * NL_W), t >> 4, t & 15, w);
+        clipped |= !(fabsf(w) * NL_F16_SW1 <= NL_F16_MAX);
+    }
+    if (clipped) atomicOr(range + NLR_PLANE_SAT, NL_SAT_PLANES);         // (negated comparisons: a NaN weight counts)
 }
 
 // poses12[f] = [R(w) row-major | t]   from pose6[f] = [t, w]     (se3pose.py:18-35)
@@ -178,7 +188,14 @@ __device__ __forceinline__ bool optim_skip(const int* __restrict__ counters, con
 __device__ __forceinline__ void optim_note_skip(const int* __restrict__ counters, int* __restrict__ state)
 {
     state[2] = state[2] + 1;
-    if (counters[NLC_OVERFLOW] != 0) state[3] = 1;
+    if (counters[NLC_OVERFLOW] != 0) state[3] = state[3] | 1;
+}
+// state[3] bit 1 latches the decoder's range status (nl_common.h NL_SAT_*: an operand of the fp16-pair arithmetic left - or may have left - its range during
+// this call): the host reads it with the call's one status read-back and raises, like a sample overflow.  The status word itself stays set until the next
+// begin_call clears it (forward-only callers read it directly).
+__device__ __forceinline__ void optim_latch_range(const float* __restrict__ ws, int* __restrict__ state)
+{
+    if (ws && reinterpret_cast<const volatile unsigned*>(ws + NL_DEC_WS_RANGE_OFF)[NLR_STATUS]) state[3] = state[3] | 2;
 }
 // end of an iteration: hand the counter block to the host-visible copy and leave it zeroed for the next iteration.  Called by the first
 // NL_CNT_BYTES / 4 threads of a workgroup AFTER a barrier behind the last read of the block: one word each (one thread walking the 24 words
@@ -211,7 +228,7 @@ __global__ void __launch_bounds__(256) k_optim_step(OptimArgs a)
         }
         if (gridDim.x == 1) {
             __syncthreads();
-            if (tid == 0) optim_note_skip(a.counters, a.state);
+            if (tid == 0) { optim_note_skip(a.counters, a.state); optim_latch_range(a.W2T, a.state); }
             __syncthreads();                                           // (optim_note_skip reads the overflow word)
             counters_hand_over(a.snap_src, a.snap_dst, tid);
         }
@@ -272,6 +289,9 @@ __global__ void __launch_bounds__(256) k_optim_step(OptimArgs a)
                 uint16_t* dh = a.W2X + NL_DEC_WS_W2H_OFF16 + (d - a.W2X);
                 nl_split2_f16(w3 * p, NL_F16_SG, &dh[0], &dh[NL_W * NL_W]);
             }
+            // range block (nl_common.h): a plane that clips raises the flag (one atomic when it happens - never, on a decoder inside the arithmetic's range)
+            if (!(fabsf(p) * NL_F16_SW2 <= NL_F16_MAX) || !(fabsf(w3 * p) * NL_F16_SG <= NL_F16_MAX))
+                atomicOr(reinterpret_cast<unsigned*>(a.W2T + NL_DEC_WS_RANGE_OFF) + NLR_PLANE_SAT, NL_SAT_PLANES);
         } else {
             const int g = (r - NL_W) * 256 + tid;
             int i = -1;
@@ -284,13 +304,15 @@ __global__ void __launch_bounds__(256) k_optim_step(OptimArgs a)
                 a.params[i] = p; a.dm[i] = m; a.dv[i] = v;
                 if (i < NL_OFF_B1) nl_store_w1_planes(reinterpret_cast<uint16_t*>(a.W2T), i >> 4, i & 15, p);       // W1's operand planes (k_decoder2)
             }
+            if (i >= 0 && i < NL_OFF_B1 && !(fabsf(a.params[i]) * NL_F16_SW1 <= NL_F16_MAX))       // W1's planes clip
+                atomicOr(reinterpret_cast<unsigned*>(a.W2T + NL_DEC_WS_RANGE_OFF) + NLR_PLANE_SAT, NL_SAT_PLANES);
         }
     } else {
         const int f = (b - a.nb_emb - a.nb_dec) * 256 + tid;
         if (f < a.F) pose_step_one(f, a.pose6, a.g_pose, a.pm, a.pv, a.enable, a.grad6_out, a.poses12, h, a.apply_pose);
     }
     if (gridDim.x == 1) {                                            // (every thread read the state / counter words before the barrier above)
-        if (tid == 0) a.state[0] = step;
+        if (tid == 0) { a.state[0] = step; optim_latch_range(a.W2T, a.state); }
         counters_hand_over(a.snap_src, a.snap_dst, tid);
     }
 }
@@ -298,11 +320,12 @@ __global__ void __launch_bounds__(256) k_optim_step(OptimArgs a)
 // advance the step counter after a multi-workgroup k_optim_step (a last-workgroup ticket costs more than this launch: thousands
 // of same-address device-scope atomics, profiles/r01_m_optimiser_step.txt)
 __global__ void k_adam_advance(int* __restrict__ state, const int* counters, int skip_mode, int* snap_src,      // (snap_src IS the counter block)
-                               int* __restrict__ snap_dst)
+                               int* __restrict__ snap_dst, const float* __restrict__ dec_ws)
 {
     if (threadIdx.x == 0) {
         if (optim_skip(counters, state, skip_mode)) optim_note_skip(counters, state);
         else state[0] = state[0] + 1;
+        optim_latch_range(dec_ws, state);
     }
     __syncthreads();
     counters_hand_over(snap_src, snap_dst, threadIdx.x);
@@ -398,6 +421,15 @@ int nl_adam_f32(float* p, const float* g, float* m, float* v, int n, const int* 
 }
 
 int nl_dec_ws_floats(void) { return NL_DEC_WS_TOTAL; }
+int nl_decoder_range_status(float* W2T, unsigned* status_out, int clear, void* stream)
+{
+    if (!W2T || !status_out) return NL_ERR_INVALID_ARG;
+    unsigned* word = reinterpret_cast<unsigned*>(W2T + NL_DEC_WS_RANGE_OFF) + NLR_STATUS;
+    if (hipMemcpyAsync(status_out, word, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return NL_ERR_LAUNCH;
+    if (clear && hipMemsetAsync(word, 0, 4, (hipStream_t)stream) != hipSuccess) return NL_ERR_LAUNCH;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return NL_ERR_LAUNCH;
+    return NL_OK;
+}
 int nl_abi_version(void) { return NL_ABI_VERSION; }
 
 int nl_decoder_transpose_w2(const float* params, float* W2T, void* stream)
@@ -463,7 +495,7 @@ int nl_optimiser_step_t(int* state, double lr_emb, double lr_dec, double lr_pose
     const int nb_pose = pose6 ? nl_div_up(F, 256) : 0;
     const int nb = a.nb_emb + a.nb_dec + nb_pose;
     hipLaunchKernelGGL(k_optim_step, dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
-    if (nb > 1) hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(64), 0, (hipStream_t)stream, state, counters, skip_mode, a.snap_src, a.snap_dst);
+    if (nb > 1) hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(64), 0, (hipStream_t)stream, state, counters, skip_mode, a.snap_src, a.snap_dst, (const float*)dec_ws);
     NL_LAUNCH_CHECK();
     return NL_OK;
 }

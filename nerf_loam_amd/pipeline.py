@@ -182,7 +182,7 @@ class DecoderDevice:
         flat = np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in (W1, b1, W2, b2, W3, b3)])
         assert flat.size == L.NL_DEC_PARAMS
         self.params = torch.as_tensor(flat).to(device)
-        self.W2T = torch.empty(L.NL_DEC_WS_FLOATS, dtype=F32, device=device)
+        self.W2T = torch.zeros(L.NL_DEC_WS_FLOATS, dtype=F32, device=device)       # (zeros: the range block's sticky status word starts clear)
         self.m = torch.zeros_like(self.params)
         self.v = torch.zeros_like(self.params)
         self.grad = torch.zeros_like(self.params)
@@ -194,7 +194,7 @@ class DecoderDevice:
         self = cls.__new__(cls)
         assert flat.numel() == L.NL_DEC_PARAMS and flat.is_cuda
         self.params = flat.detach().to(F32).contiguous().clone()
-        self.W2T = torch.empty(L.NL_DEC_WS_FLOATS, dtype=F32, device=flat.device)
+        self.W2T = torch.zeros(L.NL_DEC_WS_FLOATS, dtype=F32, device=flat.device)
         self.m = torch.zeros_like(self.params)
         self.v = torch.zeros_like(self.params)
         self.grad = torch.zeros_like(self.params)
@@ -207,6 +207,15 @@ class DecoderDevice:
     def reset_state(self):
         self.m.zero_()
         self.v.zero_()
+        self.W2T[L.NL_DEC_WS_RANGE_STATUS:L.NL_DEC_WS_RANGE_STATUS + 1].zero_()       # a new call starts with a clear range status
+
+    def range_status(self, clear=False):
+        """NL_SAT_* bits (include/nerfloam_hip.h) raised since the last clear by the decoder kernels under the fp16-pair arithmetic: an operand left - or, for the
+        two bound-based bits, may have left - the range its scaled fp16 pair holds, and was clipped.  Synchronises; optimisation calls get the same information
+        with their one status read-back (SdfEngine.call_status: .saturated)."""
+        out = ctypes.c_uint(0)
+        L.check(L.lib().nl_decoder_range_status(L.ptr(self.W2T), ctypes.byref(out), int(clear), ops.stream_ptr()), "nl_decoder_range_status")
+        return int(out.value)
 
     def numpy(self):
         f = self.params.cpu().numpy()
@@ -236,6 +245,7 @@ class SdfEngine:
         # (150-scan map, 16 copies: DESIGN.md 4.7).  Only with the touched-rows optimiser, and not on a ray-sharded engine (the exchange reads one array).
         self.emb_grad_copies = self._emb_copies_wanted = max(1, int(emb_grad_copies)) if self.sparse_adam else 1
         self._touched, self._emb_cap, self._emb_dirty_dense = None, 0, False
+        self.saturated = False                              # set by call_status*: the call's decoder kernels flagged an operand outside the fp16-pair range
         self.kernel_modes = L.kernel_modes(gemm_mode, wgrad2_mode, dec_layout)
         self.dev = torch.device(device)
         self.N_cap = int(max_rays)
@@ -618,16 +628,19 @@ class SdfEngine:
                              self.F, m.centres, m.vertex_rows, m.emb, m.voxel_size, self.X, self.field_blocks)
         tm("gather", 1)
         tm("decoder", 0)
+        modes = self.kernel_modes                            # decoder workgroup layout by ray count where the engine leaves it open (what nl_iteration does)
+        if not (modes >> 16) & 3:
+            modes |= int(L.lib().nl_decoder_layout_for(N)) << 16
         ops.decoder_fwd_bwd(self.loss_scalars, self.X, dec.params, dec.W2T, self.s_ray, self.s_depth, self.cos_gt, self.gt_dist,
                             self.sdf, self.dsdf, self.dX, self.partials, self.relu2_mask, self.n_slabs, int(train_decoder), c,
-                            self.kernel_modes)
+                            modes)
         tm("decoder", 1)
         if train_decoder:
             tm("wgrad2", 0)
-            ops.decoder_wgrad2(self.loss_scalars, self.X, dec.params, self.dsdf, self.relu2_mask, self.partials, self.n_slabs, self.kernel_modes)
+            ops.decoder_wgrad2(self.loss_scalars, self.X, dec.params, self.dsdf, self.relu2_mask, self.partials, self.n_slabs, modes)
             tm("wgrad2", 1)
             tm("reduce", 0)
-            ops.decoder_reduce(self.partials, self.n_slabs, dec.params, dec.grad, self.kernel_modes)
+            ops.decoder_reduce(self.partials, self.n_slabs, dec.params, dec.grad, modes)
             tm("reduce", 1)
         tm("scatter", 0)
         ops.trilinear_bwd(self.loss_scalars, self.s_vox, self.s_depth, self.s_ray, self.rays_d_world, self.rays_d_sensor, self.frame_id,
@@ -676,7 +689,7 @@ class SdfEngine:
         self._mark("optim", 0)
         ops.optimiser_step(self.adam_state, cfg.lr_emb, cfg.lr_dec, cfg.lr_pose if lr_pose is None else lr_pose,
                            (m.emb, self.g_emb, self.emb_m, self.emb_v) if update_emb else None,
-                           (dec.params, dec.grad, dec.m, dec.v, dec.W2T) if update_decoder else None,
+                           (dec.params, dec.grad, dec.m, dec.v, dec.W2T) if update_decoder else (None, None, None, None, dec.W2T),   # (the workspace always: range status)
                            (self.pose6[:self.F], self.g_pose, self.pose_m, self.pose_v, self.pose_enable, self.pose_grad6, self.poses12,
                             update_pose), self.counters if skip_mode else None, skip_mode, self.touched_rows() if update_emb else None)
         self._mark("optim", 1)
@@ -685,14 +698,16 @@ class SdfEngine:
         """(steps taken, steps skipped as unusable, overflow seen) since begin_call - ONE small read-back per call instead of one
         per iteration"""
         st = self.adam_state[:4].cpu().numpy()
-        return int(st[0]), int(st[2]), bool(st[3])
+        self.saturated = bool(st[3] & 2)                    # the decoder's range status, latched by the optimiser (DecoderDevice.range_status)
+        return int(st[0]), int(st[2]), bool(st[3] & 1)
 
     def call_status_and_poses(self):
         """call_status() + the frames' current pose6, in ONE device-to-host copy"""
         o = self.F_cap * 24
         both = torch.cat([self._call_state[o:o + 4], self.pose6[:self.F].reshape(-1).view(I32)]).cpu()
         st = both[:4].numpy()
-        return (int(st[0]), int(st[2]), bool(st[3])), both[4:].view(F32).view(self.F, 6)
+        self.saturated = bool(st[3] & 2)
+        return (int(st[0]), int(st[2]), bool(st[3] & 1)), both[4:].view(F32).view(self.F, 6)
 
     # ------------------------------------------------------------------ one C call per iteration
     def bind(self, m: MapDevice, dec: DecoderDevice, cfg: IterConfig, train_decoder=True, want_emb_grad=True, want_pose_grad=True,

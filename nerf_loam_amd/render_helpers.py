@@ -256,6 +256,12 @@ def _finish_call(eng, what):
                                  "per ray are provided for" + (": device memory clipped the sample workspace below the sampler's worst case for this "
                                  "step_size" if getattr(eng, "samples_clipped", False) else "") + "), or the on-device ray selection missed its "
                                  "threshold window")
+    if eng.saturated and os.environ.get("NL_ON_SATURATION", "raise") != "ignore":
+        # the reference's decoder is unbounded fp32 (lidar.py:109-123); the default arithmetic here clips - and a clipped operand trains on a wrong gradient
+        raise L.NerfLoamHipError("the call is invalid: an operand of the decoder left the range of the fp16-pair arithmetic (|X| < 1023 - 256 with a trainable decoder -, "
+                                 "|W1|, |W2| < 256, H1 < 4094, |w3_j W2[j][k]| < 64, dgrad sums < 64; DecoderDevice.range_status() names which, two of the four as "
+                                 "conservative bounds) and was clipped.  Run this map with the exact-product arithmetic: SdfEngine(gemm_mode=3) / NL_GEMM_MODE=3 "
+                                 "(NL_ON_SATURATION=ignore keeps the clipped results)")
     for _ in range(skipped if what == "Mapping" else min(skipped, 1)):
         print(f"Encouter a bug while {what}, currently not be fixed, " + ("Continue!!" if what == "Mapping" else "Restarting!!"))
     return steps, skipped, poses

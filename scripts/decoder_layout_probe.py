@@ -22,7 +22,7 @@ def ev_time(fn, n=30, warm=5):
 
 
 for n_rays in sizes:
-    sel = slice(None) if n_rays >= len(w["points"]) else torch.randperm(len(w["points"]), device=dev, generator=torch.Generator(device=dev).manual_seed(1))[:n_rays].sort().values
+    sel = slice(None) if n_rays >= len(w["points"]) else np.sort(np.random.default_rng(1).choice(len(w["points"]), n_rays, replace=False))
     for train in (True, False):
         for layout in (1, 2, 1, 2):
             eng = P.SdfEngine(max_rays=n_rays if n_rays < len(w["points"]) else len(w["points"]), samples_per_ray_cap=48, dec_layout=layout)

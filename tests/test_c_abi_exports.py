@@ -108,7 +108,9 @@ def test_launch_shape_table_is_one_table():
     lib = _lib.lib()
     table = dict(re.findall(r"#define\s+(NL_(?:RAYS|BLOCKS)_[A-Z0-9_]+)\s+(\d+)", open(os.path.join(ROOT, "nerf_loam_amd", "csrc", "nl_common.h")).read()))
     assert set(table) == {"NL_RAYS_ONE_WORKGROUP_SCAN", "NL_RAYS_SINGLE_LAUNCH_SCAN", "NL_RAYS_FUSED_SAMPLER", "NL_RAYS_ISECT_32_LANES",
-                          "NL_RAYS_ISECT_16_LANES", "NL_BLOCKS_WIDE_MAP"}
+                          "NL_RAYS_ISECT_16_LANES", "NL_BLOCKS_WIDE_MAP", "NL_RAYS_DECODER_SPLIT"}
+    split = int(table["NL_RAYS_DECODER_SPLIT"])
+    assert lib.nl_decoder_get_layout() == 0 and [lib.nl_decoder_layout_for(n) for n in (1, 2048, split, split + 1, 131072)] == [1, 1, 1, 0, 0]
     r32, r16, wide = int(table["NL_RAYS_ISECT_32_LANES"]), int(table["NL_RAYS_ISECT_16_LANES"]), int(table["NL_BLOCKS_WIDE_MAP"])
     for n, blocks, want in [(1, 0, 32), (r32, 0, 32), (r32 + 1, 0, 16), (r32 + 1, wide, 32), (r16, wide - 1, 16), (r16, wide, 32), (r16 + 1, wide, 8),
                             (131072, 10 * wide, 8)]:

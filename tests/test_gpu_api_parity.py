@@ -320,3 +320,40 @@ def test_track_frame_learning_rate_rule(api, golden_dir, monkeypatch):
     # Adam's first steps have size lr: the two rules differ by a factor 6
     s1, s7 = np.abs(got[1] - g["pose0"]).max(), np.abs(got[7] - g["pose0"]).max()
     assert 4.0 < s1 / s7 < 8.0, (s1, s7)
+
+
+def test_api_calls_raise_when_the_fp16_pair_arithmetic_clips(api, golden_dir, monkeypatch):
+    """The reference's decoder is unbounded fp32 (lidar.py:109-123); the default arithmetic here clips operands beyond its scaled fp16 ranges.  Round 6: a call
+    during which that happened is INVALID and says so - like a sample overflow -, NL_ON_SATURATION=ignore keeps the old silent behaviour, and the exact-product
+    arithmetic (gemm mode 3) runs the same call without complaint."""
+    from nerf_loam_amd import _lib as L
+    from nerf_loam_amd.criterion import Criterion
+    g = np.load(os.path.join(golden_dir, "map_2f_2it_frozen.npz"))
+    sc = _scene(g)
+    masks = H.unpack_masks(g["masks"], len(sc["points"]))
+    nf, n_iter, n_rays, step = masks.shape[0], int(g["n_iter"]), int(g["n_rays"]), float(g["step_size"])
+    lrs = [float(x) for x in g["lrs"]]
+    lib = L.lib()
+
+    def call(scale):
+        map_states = _map_states(sc)
+        dec, _ = _decoder_module(int(g["seed"]))
+        with torch.no_grad():
+            dec.pts_linears[1].weight.mul_(scale)                       # |W2| ~ 0.06 * scale
+        frames = _frames(sc, [i + 1 for i in range(nf)], g["poses0"], masks, monkeypatch)
+        api.bundle_adjust_frames(frames, map_states["voxel_vertex_emb"], map_states, dec, Criterion(ARGS), _voxel(g), step, n_rays, n_iter, 0.30, 20, 50.0,
+                                 learning_rate=lrs, update_pose=True, update_decoder=False)
+        torch.cuda.synchronize()
+
+    call(1.0)                                                           # inside the ranges: nothing to report
+    with pytest.raises(L.NerfLoamHipError, match="fp16-pair"):
+        call(5000.0)                                                    # |W2| > 256: the weight planes clip
+    monkeypatch.setenv("NL_ON_SATURATION", "ignore")
+    call(5000.0)
+    monkeypatch.delenv("NL_ON_SATURATION")
+    old = lib.nl_decoder_get_gemm_mode(), lib.nl_decoder_get_wgrad2_mode()
+    try:
+        assert lib.nl_decoder_set_gemm_mode(3) == 0 and lib.nl_decoder_set_wgrad2_mode(1) == 0
+        call(5000.0)                                                    # exact products: no range, no report
+    finally:
+        lib.nl_decoder_set_gemm_mode(old[0]); lib.nl_decoder_set_wgrad2_mode(old[1])

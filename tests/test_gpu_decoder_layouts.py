@@ -139,3 +139,63 @@ def test_w1_operand_planes_follow_the_optimiser(nl, golden_dir):
         assert np.abs(res[1][0][it] - res[2][0][it]).max() < 2e-5, it
     moved = np.abs(res[1][1] - np.concatenate([dec_np.W1.ravel(), dec_np.b1, dec_np.W2.ravel(), dec_np.b2, dec_np.W3.ravel(), dec_np.b3])).max()
     assert moved > 1e-4 and np.abs(res[1][1] - res[2][1]).max() < 0.05 * moved
+
+
+@pytest.mark.parametrize("layout", [1, 2])
+@pytest.mark.parametrize("one_call", [False, True])
+def test_clipped_operands_are_reported(nl, golden_dir, layout, one_call):
+    """The fp16-pair arithmetic clips what leaves its range (the reference's decoder is unbounded fp32, lidar.py:109-123); round 6 makes that loud:
+    NL_SAT_* bits in the weight workspace's sticky status word, latched into the call status by the optimiser.  Each way out of the range, under both
+    kernel layouts, on the stage-wise and on the one-call path; a clean call reports nothing and begin_call clears the word."""
+    L, P = nl["L"], nl["P"]
+    sc, dec_np, frames, step = _scene(golden_dir, "map_1f_1it")
+    fr = frames[0]
+    n = len(fr.rays_d)
+    cases = {
+        "clean": (dict(), 1.0, 0),
+        # (the golden scene: |emb| <= 0.048, |W1| <= 0.25, |W2|, |w3| <= 0.0625)
+        "X": (dict(), 2.0e5, L.NL_SAT_X),                                    # |X| ~ 2000 > 1023
+        "X_train_only": (dict(), 12000.0, L.NL_SAT_X),                       # |X| up to 574: inside X * 2^6, outside U = sigma dsdf 16 X (trainable decoder only)
+        "NaN": (dict(nan=True), 1.0, L.NL_SAT_X),
+        "planes": (dict(W2=5000.0), 1.0, L.NL_SAT_PLANES),                   # |W2| up to 312 > 256
+        "H1": (dict(W1=200.0), 2000.0, L.NL_SAT_H1),                         # |W1| <= 50, |X| <= 96: planes and X inside, H1 (std ~2300 per element) beyond 4094
+        "Q": (dict(W2=100.0, W3=100.0), 1.0, L.NL_SAT_Q),                    # |w3 W2| <= 39 < 64, |W2| <= 6.2: planes inside, the masked 256-deep sums (std ~150) beyond 64
+    }
+    for name, (wscale, escale, want) in cases.items():
+        ms = sc["ms"]
+        emb = O.bf16_to_f32(ms.emb) * np.float32(escale)
+        if wscale.get("nan"):
+            emb = emb.copy(); emb[ms.id2row[ms.id2row >= 0][:50]] = np.nan
+        m = P.MapDevice(ms.centres, ms.structure, ms.vertex_idx, ms.id2row, O.bf16_bits(emb), ms.voxel_size)
+        dec = P.DecoderDevice(dec_np.W1 * np.float32(wscale.get("W1", 1.0)), dec_np.b1, dec_np.W2 * np.float32(wscale.get("W2", 1.0)), dec_np.b2,
+                              dec_np.W3 * np.float32(wscale.get("W3", 1.0)), dec_np.b3)
+        eng = P.SdfEngine(max_rays=n, samples_per_ray_cap=64, max_frames=2, gemm_mode=4, wgrad2_mode=2, dec_layout=layout)
+        eng.set_rays(fr.rays_d, fr.points, fr.cos); eng.set_poses(fr.pose[None], [1])
+        cfg = P.IterConfig(step_size=step)
+        for train in ((True, False) if name in ("clean", "X_train_only") else (True,)):
+            eng.begin_call(m, dec)
+            assert dec.range_status() == 0
+            if one_call:
+                eng.bind(m, dec, cfg, train_decoder=train, update_decoder=False, update_emb=False, update_pose=False)
+                eng.run_bound()
+            else:
+                eng.forward_backward(m, dec, cfg, train_decoder=train)
+                eng.optimiser_step(m, dec, cfg, update_decoder=False, update_emb=False, update_pose=False)
+            eng.call_status()
+            st = dec.range_status()
+            expect = want if (train or name != "X_train_only") else 0
+            if expect == 0:
+                assert st == 0 and not eng.saturated, (name, train, st)
+            else:
+                assert st & expect and eng.saturated, (name, train, st)
+                if name != "planes":
+                    assert not st & L.NL_SAT_PLANES, (name, st)
+    # the forward-only kernel (render_rays / get_scores) reports through the same word
+    ms = sc["ms"]
+    m = P.MapDevice(ms.centres, ms.structure, ms.vertex_idx, ms.id2row, O.bf16_bits(O.bf16_to_f32(ms.emb) * np.float32(2.0e5)), ms.voxel_size)      # |X| ~ 2000
+    dec = P.DecoderDevice(dec_np.W1, dec_np.b1, dec_np.W2, dec_np.b2, dec_np.W3, dec_np.b3)
+    eng = P.SdfEngine(max_rays=n, samples_per_ray_cap=64, max_frames=2, gemm_mode=4, dec_layout=layout)
+    eng.set_rays(fr.rays_d, fr.points, fr.cos); eng.set_poses(fr.pose[None], [1])
+    eng.begin_call(m, dec, emb_state=False)
+    eng.forward_only(m, dec, P.IterConfig(step_size=step))
+    assert dec.range_status(clear=True) & L.NL_SAT_X and dec.range_status() == 0
