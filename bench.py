@@ -15,12 +15,16 @@ Extra objects: "roofline" for the dominant kernel (fused decoder fwd+bwd on the 
 live with HIP events on the launch stream; "cpu_baseline": the oracle port timed on a bounded ray
 sample on this box's host cores (a reported baseline, not the target).
 
-Roofline accounting: `achieved` = ALGORITHMIC fp32 flops per launch / launch time.
-The decoder's two 256-deep GEMMs and dW2 run on the bf16 matrix cores as exact-product splits (3 or 9
-bf16 MFMAs per fp32 product, fp32 accumulation), the K = 16 layers on the fp32 matrix cores, so
-`peak` is the matrix-pipe bound for THAT instruction mix: algorithmic flops / (executed fp32-MFMA
-flops / 157.3 TF + executed bf16-MFMA flops / 2500 TF).  `frac` = achieved / peak = the fraction of the
-launch during which the matrix pipes would be busy if nothing else limited the kernel.
+Roofline accounting (DESIGN.md section 4.0 - three numbers, one definition each):
+  * `achieved` = ALGORITHMIC fp32 flops per launch (288 256 per valid sample with a trainable decoder: what the reference's three fp32 GEMMs + autograd
+    need) / the kernel's launch time by HIP events on the launch stream;
+  * `peak` = the matrix-pipe bound of the kernel's OWN instruction mix: every contraction runs on the 16-bit matrix cores (2500 TF dense) on split
+    operands - by default fp16 PAIRS (gemm mode 4: 3 forward + 2 dgrad matrix instructions per fp32 product of the 256-deep GEMMs, 4 + 3 + 6 of the
+    K = 16 ones = 761 856 EXECUTED flops per sample), under `exact_products` three-term bf16 splits (8 + 3) -, so
+    peak = algorithmic flops / (executed 16-bit flops / 2500 TF + executed fp32-MFMA flops / 157.3 TF);
+  * `frac` = achieved / peak = matrix-pipe bound time / launch time: the fraction of the launch during which the matrix pipes would be busy if nothing
+    else limited the kernel (the SQ MFMA-busy counter of profiles/r*_pmc_summary.json agrees in kind).  `frac_of_dense_16bit_peak` prices the
+    algorithmic flops against the plain 2500 TF figure.
 """
 import argparse
 import contextlib
@@ -1036,9 +1040,16 @@ def main():
     stage_ms, stage_bytes, hbm_entries = stage_rooflines(eng, w, cfg, train_dec) if not shard else ({}, {}, [])
     if rank == 0:
         gm, wm = _lib.lib().nl_decoder_get_gemm_mode(), _lib.lib().nl_decoder_get_wgrad2_mode()
-        kname = "k_decoder" + ("<train>" if train_dec else "<frozen>")
+        # which fused decoder kernel ran (include/nerfloam_hip.h NL_KERNEL_LAYOUT): two 4-wave workgroups per CU (k_decoder2) for the fp16-pair arithmetic above
+        # 16 384 rays when the engine holds two slabs per CU, else one 8-wave workgroup (k_decoder)
+        lay = ((eng.kernel_modes >> 16) & 3) or _lib.lib().nl_decoder_layout_for(int(eng.N)) or _lib.lib().nl_decoder_get_layout()
+        split = gm in (4, 5) and lay != 1 and (lay == 2 or eng.n_slabs >= _lib.lib().nl_decoder_grid_hint())
+        kname = ("k_decoder2" if split else "k_decoder") + ("<train>" if train_dec else "<frozen>")
         rf = roofline_entry(kname, "decoder", dec_ms, P_local, gm, wm, train_dec)
-        kfull = ("k_decoder<true, %s" if train_dec else "k_decoder<false, %s") % ("true" if gm >= 1 else "false")
+        rf["workgroups"] = "two independent 4-wave workgroups per CU (k_decoder2)" if split else "one 8-wave workgroup per CU (k_decoder)"
+        rf["frac_of_dense_16bit_peak"] = rf["achieved"] / PEAK_BF16_MFMA_TFLOPS
+        kfull = (("k_decoder2<true, %d" if train_dec else "k_decoder2<false, %d") % {4: 3, 5: 4}.get(gm, 3) if split else
+                 ("k_decoder<true, %s" if train_dec else "k_decoder<false, %s") % ("true" if gm >= 1 else "false"))
         # (quick runs - --no-cpu-baseline - and runs that are themselves under a profiler skip the two nested rocprofv3 passes)
         under_profiler = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY"))
         traffic = pmc_traffic_in_run(kfull) if not (shard or args.no_pmc or args.no_cpu_baseline or under_profiler) else None

@@ -1185,11 +1185,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decoder(DecArgs a)
 #define D2_U_PLANE (8 * D2_U_CHUNK)
 #define D2_SS (D2_XU + 2 * D2_U_PLANE)                  // [8 column tiles][64] partial row sums
 #define D2_SDS (D2_SS + 8 * DEC_M * 4)                  // [4 waves][64] dL/dsdf, one copy per wave
-#define D2_TOTAL (D2_SDS + 4 * DEC_M * 4)
+#define D2_LOSS (D2_SDS + 4 * DEC_M * 4)                // [64 lanes of wave 0][2] fp64 loss sums (in LDS: four registers less across the tile loop)
+#define D2_TOTAL (D2_LOSS + DEC_M * 16)
 static_assert(2 * XG_XP_BYTES <= 2 * D2_U_PLANE, "the fp16 X planes fit the U region");
-static_assert(2 * D2_TOTAL <= 163840 && D2_TOTAL % 1280 == 0, "two workgroups per CU (LDS is granted in 1280-byte units)");
+static_assert(2 * D2_TOTAL <= 163840, "two workgroups per CU");
 
+#ifndef F2_RING
 #define F2_RING 3                                       // forward: B fragments 3 k-steps (12-16 matrix instructions each) ahead
+#endif
 __device__ __forceinline__ void gemm_f16_2ct_prefetch(i32x4 rsH, int w, int lane, uint4 (&bq)[F2_RING][2][2])
 {
     const int voff = lane * 16;
@@ -1253,7 +1256,9 @@ __device__ __forceinline__ void gemm_f16_2ct(i32x4 rsH, int w, int lane, const u
     }
 }
 
+#ifndef M2_RING
 #define M2_RING 3                                       // dgrad: B fragments 3 k-steps (8 matrix instructions each) ahead
+#endif
 #define M2_PRE 2                                        // of which this many are requested before the barrier that publishes the mask tile
 __device__ __forceinline__ void gemm_mask_2ct_prefetch(i32x4 rsX, int w, int lane, uint4 (&bq)[M2_RING][2][2])
 {
@@ -1268,7 +1273,8 @@ __device__ __forceinline__ void gemm_mask_2ct_prefetch(i32x4 rsX, int w, int lan
 }
 
 // dgrad accumulators (2^10 dH1 / dsdf before the ReLU of H1) of the wave's two column tiles: 0/1 mask x (lo, hi) planes of w3_j W2[j][k], the low term first
-__device__ __forceinline__ void gemm_mask_2ct(i32x4 rsX, int w, int lane, const unsigned char* sM, uint4 (&bq)[M2_RING][2][2], f32x16 (&g)[2][2])
+template <typename Late>                               // late(): issued two k-steps before the loop ends, when a ring stage's registers have become free (k_decoder2: dX's W1 fragments)
+__device__ __forceinline__ void gemm_mask_2ct(i32x4 rsX, int w, int lane, const unsigned char* sM, uint4 (&bq)[M2_RING][2][2], f32x16 (&g)[2][2], Late late)
 {
     const int l31 = lane & 31, lh = lane >> 5;
     const int voff = lane * 16;
@@ -1297,6 +1303,7 @@ __device__ __forceinline__ void gemm_mask_2ct(i32x4 rsX, int w, int lane, const 
             aq[(s + 1) & 1][0] = *reinterpret_cast<const uint4*>(a0 + 32 * (s + 1));
             aq[(s + 1) & 1][1] = *reinterpret_cast<const uint4*>(a0 + 32 * SM_STRIDE * 2 + 32 * (s + 1));
         }
+        if (s == 14) late();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 1; p >= 0; --p)
@@ -1358,7 +1365,8 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_decoder2(DecArgs a)
 
     f32x16 accW1h[2];                                     // this wave's 2 x 32 rows of dW1 (lanes 0-15: the channel) and of db1 (lane 16)
     float aW3[2] = {0.f, 0.f}, aB2[2] = {0.f, 0.f}, aB3 = 0.f, dsMax = 0.f;
-    double lossFs = 0.0, lossSdf = 0.0;
+    double* const sLoss = reinterpret_cast<double*>(ldsb + D2_LOSS);
+    if (threadIdx.x < 2 * DEC_M) sLoss[threadIdx.x] = 0.0;
     if (TRAIN) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -1409,6 +1417,9 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_decoder2(DecArgs a)
     __syncthreads();
 
     bool prio_alt = blockIdx.x >= gridDim.x / 2;
+#ifdef D2_STAGGER                                       // A/B aid: the CU's second workgroup starts D2_STAGGER cycles late (half a tile: anti-phase from the start)
+    if (blockIdx.x >= gridDim.x / 2) { const long long t0 = __builtin_readcyclecounter(); while (__builtin_readcyclecounter() - t0 < D2_STAGGER) __builtin_amdgcn_s_sleep(8); }
+#endif
     D2_PRIO_VALU();
     int tile_no = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++tile_no) {
@@ -1499,7 +1510,7 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_decoder2(DecArgs a)
                     ds = nl_loss_grad(s, cz, cd, f, m, lsd, &q1, &q2);
                     if (w == 0) {
                         a.sdf[g] = s; a.dsdf[g] = ds;
-                        lossFs += (double)q1; lossSdf += (double)q2;
+                        sLoss[2 * lane] += (double)q1; sLoss[2 * lane + 1] += (double)q2;       // (this lane's own slots: plain read-modify-write)
                     }
                 }
                 sdS[lane] = ds;
@@ -1513,20 +1524,30 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_decoder2(DecArgs a)
                 if (mx > 0.f) { (void)frexpf(mx, &e); e = e < -100 ? -100 : e; }
                 const float sigma = ldexpf(1.0f, 4 - e);
                 inv_sigma = ldexpf(1.0f, e - 4);
-                for (int f2 = tid; f2 < 2 * 8 * 17; f2 += D2_THREADS) {       // U planes: k_decoder's layout, 272 half fragments over 256 threads
-                    const int f = f2 >> 1, half = f2 & 1, t = f / 34, hh = (f / 17) & 1, c = f % 17;
-                    const float* xr = sXf + opaque(c < NL_C ? c : 0);
+                // U planes (k_decoder's layout: [plane][(k-step t, lane half hh) chunk of 17 fragments][column c][8 rows], a thread = half a fragment = 4 rows): the 256
+                // half fragments of the 16 channels are one per thread - no loop -, and the 17th column (sigma dsdf itself: db1) is written row by row by the wave's
+                // lanes, which hold one dsdf each (wave w: rows 16 w .. 16 w + 15)
+                {
+                    const int c = tid & 15, f = tid >> 4, half = f & 1, hh = (f >> 1) & 1, t = f >> 2;      // f = (t, hh, half): 16 values
                     const int row = 16 * (t & 1) + 4 * hh + 32 * (t >> 1) + 8 * half;
-                    float d[4], u[4];
-#pragma unroll
-                    for (int z = 0; z < 4; ++z) { d[z] = sdS[row + z] * sigma; u[z] = xr[(row + z) * LDX]; }
-#pragma unroll
-                    for (int z = 0; z < 4; ++z) u[z] = c < NL_C ? sat_f16(d[z] * 16.0f * u[z]) : d[z];
+                    const float4 dv = *reinterpret_cast<const float4*>(sdS + opaque(row));
+                    const float* xr = sXf + opaque(row * LDX + c);
+                    float u[4];
+                    u[0] = sat_f16(dv.x * sigma * 16.0f * xr[0]); u[1] = sat_f16(dv.y * sigma * 16.0f * xr[LDX]);
+                    u[2] = sat_f16(dv.z * sigma * 16.0f * xr[2 * LDX]); u[3] = sat_f16(dv.w * sigma * 16.0f * xr[3 * LDX]);
                     unsigned uh[2], ul[2];
                     split2_pair_f16(u[0], u[1], &uh[0], &ul[0]); split2_pair_f16(u[2], u[3], &uh[1], &ul[1]);
                     unsigned char* ud = ldsb + opaque(D2_XU + (t * 2 + hh) * D2_U_CHUNK + c * 16 + 8 * half);
                     *reinterpret_cast<uint2*>(ud) = make_uint2(uh[0], uh[1]);
                     *reinterpret_cast<uint2*>(ud + D2_U_PLANE) = make_uint2(ul[0], ul[1]);
+                }
+                if ((lane >> 4) == w) {                      // lanes 16 w .. 16 w + 15 of wave w: row = lane
+                    // row = 16 (t & 1) + 4 hh + 32 (t >> 1) + 8 half + z  <=>  t = 2 (row >> 5) + ((row >> 4) & 1), half = (row >> 3) & 1, hh = (row >> 2) & 1, z = row & 3
+                    const int row = lane, t = 2 * (row >> 5) + ((row >> 4) & 1), half = (row >> 3) & 1, hh = (row >> 2) & 1, z = row & 3;
+                    const float d = sdS[row] * sigma;
+                    const _Float16 dh = (_Float16)d, dl = (_Float16)(d - (float)dh);
+                    _Float16* ud = reinterpret_cast<_Float16*>(ldsb + opaque(D2_XU + (t * 2 + hh) * D2_U_CHUNK + NL_C * 16 + 8 * half + 2 * z));
+                    ud[0] = dh; ud[D2_U_PLANE / 2] = dl;
                 }
             }
             DBG_STAMP(11);
@@ -1587,15 +1608,18 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_decoder2(DecArgs a)
             prefetch(tile + gridDim.x, lane, xi, xc);
             pray_next = ray_of(tile + 2 * gridDim.x, lane);
             D2_PRIO_MFMA();
-            gemm_mask_2ct(rsW2H, w, lane, ldsb, bqm, g);
+            // (dX's W1 fragments are requested two k-steps before the dgrad loop ends - behind the loop their L2 latency, ~900 cycles, was exposed on every tile; in
+            //  front of it they are 16 more registers through the loop, which spills)
+            gemm_mask_2ct(rsW2H, w, lane, ldsb, bqm, g, [&]() {
+                const int so = __builtin_amdgcn_readfirstlane(w) * 2 * 2 * 1024;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) w1x[ks][pl] = bload4(rsW1X, lane * 16, so + (ks * 2 + pl) * 1024);
+            });
             D2_PRIO_VALU();
             DBG_STAMP(7);
             if (tile_no == 0 && (q_clips(g[0][0], g[0][1], m1[0]) || q_clips(g[1][0], g[1][1], m1[1]))) xw = nl_xw_mark(xw, NL_SAT_Q);
-            const int so = __builtin_amdgcn_readfirstlane(w) * 2 * 2 * 1024;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) w1x[ks][pl] = bload4(rsW1X, lane * 16, so + (ks * 2 + pl) * 1024);
         }
         DBG_STAMP(8);
         // ---------------- H / I: Q = [H1 > 0] x accumulator as an fp16 pair; dW1 / db1 from the lane's own registers (k_decoder's phase H); the wave's
@@ -1708,6 +1732,7 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_decoder2(DecArgs a)
     nl_range_check(a.W2T, xw, TRAIN);                     // did an operand of the fp16-pair arithmetic leave its range?  (sticky status word of the weight workspace)
     // ---------------- loss sums ----------------
     if (tid < 64) {
+        double lossFs = sLoss[2 * lane], lossSdf = sLoss[2 * lane + 1];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { lossFs += __shfl_xor(lossFs, off); lossSdf += __shfl_xor(lossSdf, off); }
         if (tid == 0 && (lossFs != 0.0 || lossSdf != 0.0)) {

@@ -46,8 +46,9 @@ for n_rays in sizes:
             print(f"rays {n_rays:7d} samples {Pn:8d} train {int(train)} layout {layout}: kernel {t_k:.4f} ms   iteration {t_it:.4f} ms", flush=True)
             del eng
 
-# phase stamps of workgroup 0 under layout 2 (layout 1: scripts/phase_probe.py)
+# phase stamps of workgroup 0 under layout 2 (layout 1: scripts/phase_probe.py); NL_N_SLABS=<CUs> runs ONE 4-wave workgroup per CU (what a workgroup does with the CU to itself)
 eng = P.SdfEngine(max_rays=len(w["points"]), samples_per_ray_cap=48, dec_layout=2)
+print("slabs / workgroups of the stamped launch:", eng.n_slabs)
 eng.set_rays(w["dirs"], w["points"], w["cos"]); eng.set_poses(w["pose"][None], [1])
 cfg = P.IterConfig(); eng.begin_call(w["map"], w["dec"])
 dbg = torch.zeros(256 + 8 * 1024, dtype=torch.int64, device="cuda")     # 256 phase stamps + one record per workgroup (k_decoder2<.., STAMPS>)
