@@ -818,6 +818,28 @@ def pose_refine_bench(w, device, steps=200):
         eng.run_bound()
     torch.cuda.synchronize()
     out["ms_per_step_one_c_call"] = (time.perf_counter() - t0) / steps * 1e3
+    # the same one-C-call iteration (7 fused launches) as a hipGraph, one iteration and a whole 25-iteration track_frame loop per graph launch.
+    # (ms_per_step_graph above replays the STAGE-WISE sequence - 12 launches, profiles/r05_z_timeline_latency_bound_steps.txt sections 2 / 4 - which is why it
+    #  loses to the one-C-call path: the graph holds five more ~4.7 us kernels, not a slower launch mechanism)
+    try:
+        for name, iters in (("ms_per_step_graph_one_c_call", 1), ("ms_per_step_graph_25_iterations", 25)):
+            torch.cuda.synchronize()
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_):
+                for _ in range(iters):
+                    eng.run_bound()
+            for _ in range(3):
+                g_.replay()
+            torch.cuda.synchronize()
+            n_rep = max(1, steps // iters)
+            t0 = time.perf_counter()
+            for _ in range(n_rep):
+                g_.replay()
+            torch.cuda.synchronize()
+            out[name] = (time.perf_counter() - t0) / (n_rep * iters) * 1e3
+            del g_
+    except Exception as e:                                       # noqa: BLE001 - report, do not fail the bench
+        out["graph_one_c_call_error"] = repr(e)[:200]
     # the reference's track_frame re-draws its 2048 rays every iteration (LidarFrame.sample_rays on the CPU + H2D copy):
     # same step with the rays re-drawn on the device from the resident scan (nl_select_rays)
     scan = dict(dirs=None, points=torch.from_numpy(np.ascontiguousarray(w["points"])).to(device),      # dirs None: derived from the points in the selection kernel
@@ -837,6 +859,43 @@ def pose_refine_bench(w, device, steps=200):
     st = eng.stats()
     out.update(rays=2048, valid_samples=st["P"], step_size_m=0.04)
     return out
+
+
+def get_scores_bench(w, device, res=8, reps=5):
+    """f3: the mesher's dense SDF grid - render_helpers.get_scores, reference render_helpers.py:96-153 - over the SURFACE voxels of the bench map:
+    res^3 points per voxel, gather (points generated in the kernel) + forward-only decoder on the matrix cores.  voxels / s, points / s and the forward kernel's
+    matrix-pipe fraction (139 776 algorithmic flops per point; executed under the fp16-pair arithmetic: 3 products of the 256-deep GEMM + 4 of layer 1)."""
+    from nerf_loam_amd import render_helpers as RH, _lib
+    from nerf_loam_amd.decoder import Decoder
+    h = w["host"]
+    surf = np.nonzero(h["vertex_idx"][:, 0] >= 0)[0]
+    dec = Decoder().to(device)
+    dec.load_flat(torch.from_numpy(np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in h["dec"]])).to(device))
+    emb = torch.from_numpy((h["emb_bits"].astype(np.uint32) << 16).view(np.float32)).to(torch.bfloat16).to(device)
+    states = {"voxel_vertex_idx": torch.from_numpy(h["vertex_idx"][surf]), "voxel_center_xyz": torch.from_numpy(h["centres"][surf]),
+              "voxel_structure": torch.from_numpy(h["structure"][surf]), "voxel_vertex_emb": emb, "voxel_id2embedding_id": torch.from_numpy(h["id2row"])}
+    RH.get_scores(dec, states, w["voxel"], bits=res, device_out=True)          # warm-up: resident map tensors, decoder block, allocator
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g = RH.get_scores(dec, states, w["voxel"], bits=res, device_out=True)
+    torch.cuda.synchronize()
+    dt_dev = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    g_host = RH.get_scores(dec, states, w["voxel"], bits=res)
+    dt_host = time.perf_counter() - t0
+    n_pts = len(surf) * res ** 3
+    gm = _lib.lib().nl_decoder_get_gemm_mode()
+    fwd_alg = FLOPS_PER_SAMPLE_DECODER_FROZEN / 2                           # forward only: 2 (16 x 256 + 256 x 256 + 256)
+    ex16 = {4: 3, 5: 4}.get(gm, 8) * G + (4 if gm >= 4 else 9) * L1
+    bound_s = n_pts * ex16 / (PEAK_BF16_MFMA_TFLOPS * 1e12)
+    return {"voxels": int(len(surf)), "res": res, "points": int(n_pts), "ms_per_call_device_resident_grid": dt_dev * 1e3, "ms_per_call_grid_on_host": dt_host * 1e3,
+            "voxels_per_s": len(surf) / dt_dev, "points_per_s": n_pts / dt_dev, "algorithmic_tflops": n_pts * fwd_alg / dt_dev / 1e12,
+            "matrix_pipe_bound_ms": bound_s * 1e3, "matrix_pipe_frac_of_the_call": bound_s / dt_dev,
+            "hbm_bytes_algorithmic": int(n_pts * (64 * 2 + 4) + len(surf) * (12 + 32)), "sdf_range": [float(g_host.min()), float(g_host.max())],
+            "note": "whole call: map tensors -> device (cached per map), per chunk of <= 16.8 M points one nl_gather_grid + one nl_decoder_forward launch, one device-to-host copy "
+                    "of the grid (ms_per_call_grid_on_host; the reference copies every 10 000 voxels and synchronises on each); tests/test_gpu_api_mirror.py holds the call "
+                    "against the reference's own get_scores output (tests/golden/scores_res4.npz) at 5e-6"}
 
 
 def main():
@@ -1111,6 +1170,8 @@ def main():
             if not args.no_api_path:                               # for a while after use and slow the launching thread down
                 out["shard_probe"] = shard_probe_bench(w, device, dt / args.steps * 1e3)   # (same kernels at other sizes: kept out of the
                 out["api_path"] = api_path_bench(w, device)                                #  profiled command's per-kernel averages)
+            if not args.no_api_path:
+                out["get_scores"] = get_scores_bench(w, device)
             if not args.no_large_map:
                 out["large_map"] = large_map_bench(w, device)
             if not args.no_parity:

@@ -207,6 +207,12 @@ int nl_gather_trilinear(const void* loss_scalars, const int* s_vox, const float*
 int nl_gather_points(int P, const float* xyz, const int* vox, const float* centres, const int* vertex_rows, const void* emb_bf16,
                      float voxel_size, float* X, void* stream);
 
+/* get_scores' points generated on the device (render_helpers.py:103-121): the res^3 grid points lin[ix], lin[iy], lin[iz] (x voxel_size, + centre) of the
+ * voxels [vox0, vox0 + n_vox), row-major in (voxel, ix, iy, iz) like the reference's reshape, -> X[n_vox * res^3, 16].  lin[res] = torch.linspace(-0.5, 0.5, res)
+ * (device pointer; the caller's own values, so the points are the reference's bit for bit). */
+int nl_gather_grid(int n_vox, int vox0, int res, const float* lin, const float* centres, const int* vertex_rows, const void* emb_bf16, float voxel_size,
+                   float* X, void* stream);
+
 /* Decoder forward (src/variations/lidar.py:109-131) + Criterion gradient (src/criterion.py:59-100) +
  * decoder backward (autograd of render_helpers.py:422).  params = decoder block, W2T = decoder weight workspace (nl_decoder_transpose_w2).
  * Outputs sdf[P], dsdf[P], dX[P,16]; with train_decoder: per-workgroup weight-gradient slabs
@@ -255,7 +261,7 @@ int nl_reduce_partials(const float* partials, int nslabs, int n, float* out, voi
  *   floats [65536, 163840):   "W2X"  = w3_j * W2[j][k] as three bf16 planes (hi + mid + lo == the fp32 value exactly) in
  *                             MFMA-fragment order: dgrad GEMM B operand on the bf16 matrix cores,
  *   floats [163840, 262144):  "W2TX" = W2[n][k], same split and order: forward GEMM B operand on the bf16 matrix cores,
- *   floats [262144, 327680):  "W2H"  = (w3_j * W2[j][k]) * 2^12 as two fp16 planes (hi = f16(x), lo = f16(x - hi), round to nearest), same order,
+ *   floats [262144, 327680):  "W2H"  = (w3_j * W2[j][k]) * 2^10 as two fp16 planes (hi = f16(x), lo = f16(x - hi), round to nearest), same order,
  *   floats [327680, 393216):  "W2TH" = W2[n][k] * 2^8, likewise: the operands of gemm modes 4 / 5,
  *   floats [393216, 397312):  "W1F"  = W1[k][c] * 2^8 as two fp16 planes in the order of layer 1's B fragments,
  *   floats [397312, 401408):  "W1X"  = the same values in the order of dX's B fragments (csrc/nl_common.h NL_W1F_INDEX / NL_W1X_INDEX; round 6:
@@ -297,7 +303,8 @@ int nl_abi_version(void);               /* NL_ABI_VERSION of the library that is
  *     2^-22 of a product, under the rounding of the 256-deep fp32 accumulation), 5 = all four; dgrad: the {0,1} mask x two terms; layer 1: all four.
  *     6 + 4 matrix instructions per k-step against 16 + 6 of mode 3.  Measured against the oracle and the reference-generated goldens the modes 1, 3,
  *     4, 5 are indistinguishable (sdf 3e-8, the same gradient bars).  Operands saturate instead of overflowing fp16:
- *     |X| < 1023, |W1| < 256, H1 < 4094, |W2| < 256, |w3_j W2[j][k]| < 16 - far outside what the decoder of an SDF map holds.
+ *     |X| < 1023 (256 with a trainable decoder), |W1| < 256, H1 < 4094, |W2| < 256, |w3_j W2[j][k]| < 64, dgrad sums < 64 - far outside what the decoder of an
+ *     SDF map holds, and REPORTED when it happens (the range block of the weight workspace, nl_decoder_transpose_w2 below).
  * dW2 kernel (wgrad2_mode): 0 = fp32 matrix cores; 1, 2 = 16-bit matrix cores on dW2[j][k] = w3_j * sum_i m(i,j) * (dsdf_i * H1[i][k]) with the
  * {0,1} mask m as A operand and the fp32 B operand v split: 1 = into three bf16 terms (exact products, fp32 accumulation), 2 = into an fp16
  * pair of v * sigma, sigma the power of two that puts the launch's largest |dsdf| in [8, 16) (nl_decoder_fwd_bwd leaves that maximum in the

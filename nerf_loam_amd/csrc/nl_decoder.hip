@@ -321,7 +321,7 @@ __device__ __forceinline__ void gemm_mask_x_rolled(i32x4 rsX, int w, int lane, c
 #define X_PLANE_ELEMS (DEC_M * SM_STRIDE)
 #define X_PLANE_BYTES (X_PLANE_ELEMS * 2)
 #define NL_DEC_WS_W2TX_OFF (NL_DEC_WS_W2X_OFF + 3 * NL_W * NL_W / 2)       // floats
-#define NL_DEC_WS_W2H_OFF (NL_DEC_WS_W2TX_OFF + 3 * NL_W * NL_W / 2)      // fp16 pairs: dgrad planes (w3_j W2[j][k] * 2^12), two planes
+#define NL_DEC_WS_W2H_OFF (NL_DEC_WS_W2TX_OFF + 3 * NL_W * NL_W / 2)      // fp16 pairs: dgrad planes (w3_j W2[j][k] * 2^10 = NL_F16_SG), two planes
 #define NL_DEC_WS_W2TH_OFF (NL_DEC_WS_W2H_OFF + 2 * NL_W * NL_W / 2)      // forward planes (W2 * 2^8)
 static_assert(NL_DEC_WS_W2TH_OFF + 2 * NL_W * NL_W / 2 == NL_DEC_WS_W1F_OFF, "W1F / W1X (nl_common.h) follow the W2 planes");
 

@@ -75,7 +75,11 @@ NL_HD void nl_split3_bf16(float v, uint16_t* hi, uint16_t* mid, uint16_t* lo) {
 // fp16 values is exact in fp32 (22 significand bits), so hi*hi' + hi*lo' + lo*hi' (+ lo*lo') accumulated in fp32 is the fp32 product of
 // the operands up to 2^-22 (2^-23 with the fourth product) - below the rounding of the 256-deep fp32 accumulation it enters.
 // The scales put the operands of the shipped decoder high in fp16's range and bound what saturates:
-//   X * 2^6 (|X| < 1023), W1 * 2^8 (|W1| < 256), H1 * 2^4 (H1 < 4094), W2 * 2^8 (|W2| < 256), w3_j W2[j][k] * 2^12 (< 16).
+//   X * 2^6 (|X| < 1023.5; with a trainable decoder |X| < 255.9: the dW1 operand U = sigma dsdf 2^4 X with sigma dsdf in [8, 16)), W1 * 2^8 (|W1| < 255.9),
+//   H1 * 2^4 (H1 < 4094), W2 * 2^8 (|W2| < 255.9), w3_j W2[j][k] * 2^10 = NL_F16_SG (|w3 W2| < 63.97; the dgrad accumulators, sums of up to 256 of them, < 63.97 too).
+// A value beyond its range is CLIPPED (v_med3, which also turns a NaN into a finite value where the reference's fp32 decoder would propagate it) - and reported:
+// the decoder kernels raise NL_SAT_* bits in the weight workspace's status word (nl_common.h nl_range_check, round 6), the optimiser latches them into the call
+// status, the API raises.  Gemm mode 3 (exact three-term bf16 splits, no scaling, no range) is the fallback.
 // These software conversions are what the weight-plane kernels (nl_optim.hip) and the host tests use; the decoder kernels convert with
 // v_cvt_pk_f16_f32 / v_cvt_f32_f16 (same IEEE results).
 // ---------------------------------------------------------------------------------------------

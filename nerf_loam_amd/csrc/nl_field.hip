@@ -122,6 +122,41 @@ __global__ __launch_bounds__(NL_FIELD_THREADS) void k_gather_points(int P, const
     }
 }
 
+// get_scores (render_helpers.py:96-153) without the point tensor: the res^3 grid points of voxels [vox0, vox0 + n_vox) are generated here - point
+// (ix, iy, iz) of voxel v is lin[i] * voxel_size + centre_v per axis, the reference's two fp32 operations (`sampled_xyz *= voxel_size`, `+ points`), with
+// lin = torch.linspace(-0.5, 0.5, res) handed over by the caller (torch's own values) - and go through k_gather_points' arithmetic.  Saves the 12 + 4 bytes per
+// point of the xyz / voxel-id tensors (and the torch kernels that built them): a point costs its 64-byte X row and nothing else.
+__global__ __launch_bounds__(NL_FIELD_THREADS) void k_gather_grid(long long P, int vox0, int res, const float* __restrict__ lin,
+                                                                  const float* __restrict__ centres, const int* __restrict__ vertex_rows,
+                                                                  const uint16_t* __restrict__ emb, float voxel_size, float* __restrict__ X)
+{
+    const int half = threadIdx.x & 1;
+    const int r3 = res * res * res;
+    for (long long s = ((long long)blockIdx.x * NL_FIELD_THREADS + threadIdx.x) >> 1; s < P; s += ((long long)gridDim.x * NL_FIELD_THREADS) >> 1) {
+        const int v = vox0 + (int)(s / r3), q = (int)(s % r3);
+        const int ix = q / (res * res), iy = (q / res) % res, iz = q % res;
+        float x[3], c[3], p[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) c[i] = centres[3 * (size_t)v + i];
+        const float ox = lin[ix] * voxel_size, oy = lin[iy] * voxel_size, oz = lin[iz] * voxel_size;
+        x[0] = ox + c[0]; x[1] = oy + c[1]; x[2] = oz + c[2];
+        nl_trilinear_p(x, c, voxel_size, p);
+        float w[8]; nl_trilinear_w(p, w);
+        const int4 r0 = *reinterpret_cast<const int4*>(vertex_rows + 8 * (size_t)v);
+        const int4 r1 = *reinterpret_cast<const int4*>(vertex_rows + 8 * (size_t)v + 4);
+        const int rows[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float e[8]; load_emb8(emb, rows[k], half, e);
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) f[ch] = f[ch] + w[k] * e[ch];
+        }
+        float4* o = reinterpret_cast<float4*>(X + (size_t)s * NL_C + 8 * half);
+        o[0] = make_float4(f[0], f[1], f[2], f[3]); o[1] = make_float4(f[4], f[5], f[6], f[7]);
+    }
+}
+
 // backward: dE[row_k] += bf16(w_k * dX)   (fp32 accumulation of bf16-rounded contributions, then one
 // bf16 rounding in the optimiser = torch's CUDA embedding_dense_backward semantics), and
 // dL/dx = (1/vs) * d/dp sum_k w_k <e_k, dX>  ->  dt += dx, dR += depth * dx (x) d_sensor.
@@ -510,6 +545,19 @@ int nl_gather_points(int P, const float* xyz, const int* vox, const float* centr
     if (P == 0) return NL_OK;
     const int nb = nl_div_up((long long)P * 2, NL_FIELD_THREADS);
     hipLaunchKernelGGL(k_gather_points, dim3(nb < 4096 ? nb : 4096), dim3(NL_FIELD_THREADS), 0, (hipStream_t)stream, P, xyz, vox, centres,
+                       vertex_rows, (const uint16_t*)emb, voxel_size, X);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+}
+
+int nl_gather_grid(int n_vox, int vox0, int res, const float* lin, const float* centres, const int* vertex_rows, const void* emb, float voxel_size,
+                   float* X, void* stream)
+{
+    if (n_vox < 0 || vox0 < 0 || res < 2 || res > 64 || !lin || !centres || !vertex_rows || !emb || !X) return NL_ERR_INVALID_ARG;
+    if (n_vox == 0) return NL_OK;
+    const long long P = (long long)n_vox * res * res * res;
+    const long long nb = (P * 2 + NL_FIELD_THREADS - 1) / NL_FIELD_THREADS;
+    hipLaunchKernelGGL(k_gather_grid, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(NL_FIELD_THREADS), 0, (hipStream_t)stream, P, vox0, res, lin, centres,
                        vertex_rows, (const uint16_t*)emb, voxel_size, X);
     NL_LAUNCH_CHECK();
     return NL_OK;

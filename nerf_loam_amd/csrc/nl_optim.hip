@@ -75,7 +75,7 @@ __global__ void k_transpose_w2(const float* __restrict__ params, float* __restri
 //     W2X  (dgrad,   dH1 = dH2 W2):    element e <-> j = 16 s + 8 h + e, k = 32 t + c, value w3_j * W2[j][k]
 //     W2TX (forward, H2 = H1 W2^T):    element e <-> k = 16 s + 8 h + e, n = 32 t + c, value W2[n][k]
 // The same two matrices as fp16 pairs (gemm modes 4 / 5; nl_split2_f16): [plane(2)][t(8)][s(16)][lane(64)][8 f16], the same element order,
-//     W2H  (dgrad):   (w3_j * W2[j][k]) * 2^12,    W2TH (forward):  W2[n][k] * 2^8.
+//     W2H  (dgrad):   (w3_j * W2[j][k]) * 2^10 (NL_F16_SG),    W2TH (forward):  W2[n][k] * 2^8 (NL_F16_SW2).
 // W1[k][c] * 2^8 as an fp16 pair into the two operand forms k_decoder2 reads (nl_common.h: W1F, W1X); ws16 = the weight workspace as 16-bit elements
 __device__ __forceinline__ void nl_store_w1_planes(uint16_t* ws16, int k, int c, float v)
 {

@@ -110,7 +110,10 @@ class LidarFrame(nn.Module):
         sc = self.__dict__["_nl_scan"]
         t = sc[name]
         if t.device != self.points.device:
-            t = sc.setdefault(name + "_on_points_device", t.to(self.points.device))
+            k = name + "_on_points_device"
+            if k not in sc:                                  # (dict.setdefault evaluates its default - a device-to-host copy and a sync - on EVERY access)
+                sc[k] = t.to(self.points.device)
+            t = sc[k]
         return t
 
     @property
@@ -120,6 +123,7 @@ class LidarFrame(nn.Module):
     @rays_d.setter
     def rays_d(self, value):
         self.__dict__["_nl_own_rays_d"] = value
+        self.__dict__.pop("_nl_scan", None)                  # (a non-fp32 frame's resident `dirs` are built from this tensor: rebuild the scan)
 
     @property
     def rays_norm(self):

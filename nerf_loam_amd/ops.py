@@ -110,6 +110,12 @@ def gather_points(xyz, vox, centres, vertex_rows, emb, voxel_size, X):
                                    stream_ptr()), "nl_gather_points")
 
 
+def gather_grid(n_vox, vox0, res, lin, centres, vertex_rows, emb, voxel_size, X):
+    """get_scores' res^3 points per voxel, generated on the device (include/nerfloam_hip.h nl_gather_grid) -> X[n_vox * res^3, 16]"""
+    check(L.lib().nl_gather_grid(int(n_vox), int(vox0), int(res), ptr(lin), ptr(centres), ptr(vertex_rows), ptr(emb), float(voxel_size), ptr(X),
+                                 stream_ptr()), "nl_gather_grid")
+
+
 def decoder_fwd_bwd(loss_scalars, X, params, W2T, s_ray, s_depth, cos_gt, gt_dist, sdf, dsdf, dX, partials, relu2_mask, nslabs,
                     train_decoder, counters, modes=0):
     """modes: _lib.kernel_modes(gemm_mode, wgrad2_mode) - the kernel selection of this call (0: the process defaults); the

@@ -369,30 +369,37 @@ def render_rays(rays_o, rays_d, map_states, sdf_network, step_size, voxel_size, 
             "sampled_xyz": m.centres[eng.s_vox[:P].long()], "_engine": eng, "_cfg": cfg}
 
 
+SCORES_CHUNK_POINTS = 1 << 24          # points per gather + decoder launch pair of get_scores (16.8 M points = 1 GB of X rows; the reference's chunk is 10 000 voxels)
+
+
 @torch.no_grad()
-def get_scores(sdf_network, map_states, voxel_size, bits=8):
+def get_scores(sdf_network, map_states, voxel_size, bits=8, device_out=False):
     """Dense SDF grid of every voxel passed in map_states (mesh extraction, reference render_helpers.py:96-153):
     res^3 points on linspace(-0.5, 0.5, res)^3 * voxel_size around each voxel centre -> [n_voxels, res, res, res, 1]
-    on the host, like the reference returns.  One gather + one MFMA forward launch per 10 000-voxel chunk."""
+    on the host, like the reference returns (device_out=True: left on the device).  The points are generated inside the gather
+    kernel (nl_gather_grid) from torch's own linspace values - no xyz / voxel-id tensors -, a chunk is up to 16.8 M points = one gather +
+    one matrix-core forward launch, the grid stays on the device and leaves in ONE copy (the reference: a .cpu() per 10 000 voxels)."""
     from . import ops
     emb = map_states["voxel_vertex_emb"]
     device = emb.device
     m = MapDevice.from_tensors(map_states["voxel_center_xyz"], map_states["voxel_structure"], map_states["voxel_vertex_idx"],
                                map_states["voxel_id2embedding_id"], emb, voxel_size, device, traversal=False)
     dec = _decoder_device(sdf_network, device)
-    res = bits
-    lin = torch.linspace(-0.5, 0.5, res)
-    xx, yy, zz = torch.meshgrid(lin, lin, lin, indexing="ij")
-    offs = (torch.stack([xx, yy, zz], dim=-1).float().to(device) * voxel_size).reshape(1, -1, 3)
+    res = int(bits)
+    lin = torch.linspace(-0.5, 0.5, res).to(device)
     n = m.centres.shape[0]
-    out = []
-    for i in range(0, n, 10000):
-        c = m.centres[i:i + 10000]
-        xyz = (offs + c.unsqueeze(1)).reshape(-1, 3).contiguous()
-        vox = torch.arange(i, i + c.shape[0], device=device, dtype=torch.int32)[:, None].expand(-1, res ** 3).reshape(-1).contiguous()
-        X = torch.empty(xyz.shape[0], L.NL_C, dtype=torch.float32, device=device)
-        ops.gather_points(xyz, vox, m.centres, m.vertex_rows, m.emb, voxel_size, X)
-        sdf = torch.empty(xyz.shape[0], dtype=torch.float32, device=device)
-        ops.decoder_forward(X, dec.params, dec.W2T, xyz.shape[0], sdf, L.lib().nl_decoder_grid_hint())
-        out.append(sdf.reshape(-1, res ** 3, 1).cpu())
-    return torch.cat(out, 0).view(-1, res, res, res, 1)
+    r3 = res ** 3
+    sdf = torch.empty(n * r3, dtype=torch.float32, device=device)
+    chunk = max(1, SCORES_CHUNK_POINTS // r3)
+    X = torch.empty(min(n, chunk) * r3, L.NL_C, dtype=torch.float32, device=device)
+    hint = L.lib().nl_decoder_grid_hint()
+    dec.W2T[L.NL_DEC_WS_RANGE_STATUS:L.NL_DEC_WS_RANGE_STATUS + 1].zero_()            # (the range status of THIS call)
+    for i in range(0, n, chunk):
+        k = min(chunk, n - i)
+        ops.gather_grid(k, i, res, lin, m.centres, m.vertex_rows, m.emb, voxel_size, X)
+        ops.decoder_forward(X, dec.params, dec.W2T, k * r3, sdf[i * r3:], hint)
+    if dec.range_status() and os.environ.get("NL_ON_SATURATION", "raise") != "ignore":
+        raise L.NerfLoamHipError("get_scores: an operand of the decoder left the range of the fp16-pair arithmetic and was clipped (DecoderDevice.range_status()); "
+                                 "use NL_GEMM_MODE=3")
+    out = sdf.view(-1, res, res, res, 1)
+    return out if device_out else out.cpu()

@@ -421,7 +421,24 @@ def run_adam_case():
     print("adam: ok")
 
 
+def run_scores_case(name="scores_res4", n_beams=64, n_azimuth=16, seed=21, n_vox=300, res=4):
+    """the reference's own get_scores (render_helpers.py:96-153: dense res^3 SDF grid per voxel, the mesher's input) on the first n_vox SURFACE voxels
+    of a synthetic sector map - the fixture of tests/test_gpu_api_mirror.py::test_get_scores_matches_the_reference"""
+    sc = build_scene(n_beams, n_azimuth, seed)
+    surf = np.nonzero(sc["features"][:, 0].numpy() >= 0)[0][:n_vox]
+    dec = make_decoder(seed)
+    map_states = {"voxel_vertex_idx": sc["features"][surf], "voxel_center_xyz": sc["centres"][surf], "voxel_structure": sc["structure"][surf],
+                  "voxel_vertex_emb": sc["emb"], "voxel_id2embedding_id": sc["id_table"]}
+    grid_ = RH.get_scores(dec, map_states, VOXEL, bits=res)
+    assert grid_.shape == (len(surf), res, res, res, 1)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, seed=seed, n_beams=n_beams, n_azimuth=n_azimuth, res=res, voxel_size=VOXEL, surf=surf.astype(np.int32),
+                        centres=sc["centres"][surf].numpy(), sdf=grid_.numpy().astype(np.float32), id_table=sc["id_table"].numpy()[:, 0])
+    print(f"{name}: {len(surf)} voxels x {res}^3 points, sdf in [{float(grid_.min()):.4f}, {float(grid_.max()):.4f}] -> {os.path.getsize(path)/1e3:.0f} kB")
+
+
 CASES = {
+    "scores_res4": lambda: run_scores_case(),
     "se3": lambda: run_se3_case(),
     "adam": lambda: run_adam_case(),
     "criterion": lambda: run_criterion_case(),

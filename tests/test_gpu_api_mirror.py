@@ -2,6 +2,7 @@
 track_frame / render_rays / Decoder / Criterion / svo.Octree) on the HIP path: a short
 mapping-then-tracking run on a synthetic sector scan behaves like the reference's loop does -
 loss goes down, embeddings/decoder/pose are mutated in place, a perturbed pose is pulled back."""
+import os
 from argparse import Namespace
 
 import numpy as np
@@ -365,6 +366,38 @@ def test_get_scores_matches_oracle():
     feats, _ = O.trilinear_forward(xyz, vox, ms.centres, ms.vertex_rows(), ms.emb, 0.2)
     ref, _ = O.decoder_forward(feats, d0)
     assert np.abs(got.reshape(-1) - ref).max() < 1e-5
+
+
+def test_get_scores_matches_the_reference(monkeypatch):
+    """the same call against the REFERENCE's own get_scores (tests/golden/scores_res4.npz: render_helpers.py:96-153 imported and run by
+    tests/golden/make_golden.py): grid points generated on the device (nl_gather_grid) from torch's linspace, one gather + one forward launch per chunk -
+    also with a chunk of 7 voxels (43 launch pairs) and through the torch tensors of a whole map at res 8"""
+    from nerf_loam_amd.decoder import Decoder
+    from nerf_loam_amd import render_helpers as RH
+    from oracle import oracle as O
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scores_res4.npz"))
+    sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]))
+    ms = sc["ms"]
+    ms.id2row = g["id_table"].copy()
+    surf, res = g["surf"], int(g["res"])
+    assert np.array_equal(ms.centres[surf], g["centres"])                         # the same map, the same voxels
+    d0 = O.decoder_init(int(g["seed"]))
+    dec = Decoder().cuda()
+    dec.load_flat(torch.from_numpy(np.concatenate([a.reshape(-1) for a in (d0.W1, d0.b1, d0.W2, d0.b2, d0.W3, d0.b3)])).cuda())
+    emb = torch.from_numpy(H.init_embeddings(len(ms.emb), int(g["seed"]))).to(torch.bfloat16).cuda()
+    states = {"voxel_vertex_idx": torch.from_numpy(ms.vertex_idx[surf]), "voxel_center_xyz": torch.from_numpy(ms.centres[surf]),
+              "voxel_structure": torch.from_numpy(ms.structure[surf]), "voxel_vertex_emb": emb, "voxel_id2embedding_id": torch.from_numpy(ms.id2row)}
+    got = RH.get_scores(dec, states, float(g["voxel_size"]), bits=res).numpy()
+    assert got.shape == g["sdf"].shape
+    err = float(np.abs(got - g["sdf"]).max())
+    assert err < 5e-6, err                                                          # (the bar of every reference-golden sdf comparison)
+    monkeypatch.setattr(RH, "SCORES_CHUNK_POINTS", 7 * res ** 3)
+    assert np.array_equal(RH.get_scores(dec, states, float(g["voxel_size"]), bits=res).numpy(), got)
+    monkeypatch.undo()
+    dev = RH.get_scores(dec, states, float(g["voxel_size"]), bits=8, device_out=True)
+    assert dev.is_cuda and dev.shape == (len(surf), 8, 8, 8, 1) and torch.isfinite(dev).all()
+    # the corner points of the res-8 grid are the corner points of the res-4 grid (linspace end points)
+    assert np.abs(dev[:, ::7, ::7, ::7, 0].cpu().numpy() - got[:, ::3, ::3, ::3, 0]).max() < 1e-6
 
 
 def test_predraw_with_a_varying_iteration_count_meets_no_stale_candidate_counter():

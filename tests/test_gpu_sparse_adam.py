@@ -201,3 +201,38 @@ def test_replicated_accumulators_equal_a_single_array(golden_dir, one_call):
             emb_t[k] = m[k].emb.clone()
     import helpers
     helpers.record_gpu_metric("replicated_accumulators", copies=K, rows_touched=n["copies"])
+
+
+def test_captured_iteration_with_replicated_accumulators_replays_like_one_copy(golden_dir):
+    """capture_iteration's warm-up left gradients in accumulator copies 1..K-1 (it cleared copy 0 only), and the first replay's sweep over the
+    touched rows added them.  A captured + replayed iteration with emb_grad_copies = 16 against the same engine flow with one copy: the same embeddings
+    after three replays (bf16 rounding of differently associated fp32 sums apart)."""
+    import helpers as H
+    from oracle import oracle as O
+    from nerf_loam_amd import pipeline as P
+    g = np.load(os.path.join(golden_dir, "map_1f_3it.npz"))
+    sc = H.build_oracle_scene(int(g["n_beams"]), int(g["n_azimuth"]), int(g["seed"]))
+    sc["ms"].id2row = g["id_table"].copy()
+    masks = H.unpack_masks(g["masks"], len(sc["points"]))
+    dec_np = O.decoder_init(int(g["seed"]))
+    fr = O.select_rays(sc["points"], sc["cos"], g["poses0"][0].copy(), masks[0][0], optimize_pose=True)
+    res = {}
+    for copies in (1, 16):
+        ms = sc["ms"]
+        m = P.MapDevice(ms.centres, ms.structure, ms.vertex_idx, ms.id2row, ms.emb.copy(), ms.voxel_size)
+        dec = P.DecoderDevice(dec_np.W1, dec_np.b1, dec_np.W2, dec_np.b2, dec_np.W3, dec_np.b3)
+        eng = P.SdfEngine(max_rays=len(fr.rays_d), samples_per_ray_cap=64, max_frames=2, emb_grad_copies=copies)
+        eng.set_rays(fr.rays_d, fr.points, fr.cos); eng.set_poses(fr.pose[None], [1])
+        cfg = P.IterConfig(step_size=float(g["step_size"]))
+        eng.begin_call(m, dec)
+        assert eng.emb_grad_copies == copies
+        eng.capture_iteration(m, dec, cfg, train_decoder=False, update_decoder=False, update_pose=False)
+        for _ in range(3):
+            eng.replay()
+        torch.cuda.synchronize()
+        assert float(eng._emb_state[:eng.emb_grad_copies * eng._emb_cap * 16].abs().max()) == 0.0        # every copy swept clean
+        res[copies] = (m.emb_bits().copy(), int(eng.adam_state[0].item()))
+    assert res[1][1] == res[16][1] == 3
+    a, b = O.bf16_to_f32(res[1][0]), O.bf16_to_f32(res[16][0])
+    moved = np.abs(a - O.bf16_to_f32(sc["ms"].emb)).max()
+    assert moved > 0.01 and (res[1][0] != res[16][0]).mean() < 2e-3 and np.abs(a - b).max() <= 0.25 * moved
