@@ -1554,17 +1554,29 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_decoder2(DecArgs a)
             // ---------------- E: the 0/1 mask tile of H2 -> P0; db2 / dW3 sums; the saved ReLU words ----------------
             gemm_mask_2ct_prefetch(rsW2H, w, lane, bqm);
             DBG_STAMP(12);
+            // the 32 dsdf values of this lane's rows (rows D32_RR(r) + 4 lh of both sub-tiles: eight runs of four consecutive floats), read ONCE for both column
+            // tiles as eight ds_read_b128 - sixteen ds_read2_b32 per column tile issued next to their use put an LDS latency in front of every row pair
+            float dsv[2][16];
+            if (TRAIN) {
+                const float4* dq = reinterpret_cast<const float4*>(sdS + opaque(4 * lh));
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = dq[8 * sub + 2 * q];               // floats 32 sub + 8 q .. + 3 (+ 4 lh)
+                        dsv[sub][4 * q] = v.x; dsv[sub][4 * q + 1] = v.y; dsv[sub][4 * q + 2] = v.z; dsv[sub][4 * q + 3] = v.w;
+                    }
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int col = 32 * (2 * w + j) + l31;
                 unsigned mw = 0u;
-                const float* dsb = sdS + opaque(4 * lh);
                 // dW3 / db2 sums of the tile in four independent chains per column tile (rows of the two sub-tiles, even / odd register): one chain per sum is a
                 // 64-deep dependent sequence of FMAs (~8 cycles each with nothing to issue in between); the four partial sums are folded in a fixed order
                 float pW[4] = {0.f, 0.f, 0.f, 0.f}, pB[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float ds0 = dsb[D32_RR(r)], ds1 = dsb[32 + D32_RR(r)];
+                    const float ds0 = dsv[0][r], ds1 = dsv[1][r];
                     // (laundered: the ReLU bits are pure functions of H2, and the compiler otherwise forms all 64 of them in phase C's epilogue and carries them -
                     //  one register each - next to the 64 values of H2 across phase D)
                     const float hv0 = launder_f(h[j][0][r]), hv1 = launder_f(h[j][1][r]);
