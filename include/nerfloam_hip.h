@@ -213,6 +213,20 @@ int nl_gather_points(int P, const float* xyz, const int* vox, const float* centr
 int nl_gather_grid(int n_vox, int vox0, int res, const float* lin, const float* centres, const int* vertex_rows, const void* emb_bf16, float voxel_size,
                    float* X, void* stream);
 
+/* Marching cubes over get_scores' per-voxel grids, replacing MeshExtractor.marching_cubes (src/utils/mesh_util.py:145-169: skimage.measure.marching_cubes
+ * on the CPU, one voxel at a time).  sdf[n_vox][res][res][res] (device, the layout get_scores returns), 2 <= res <= 16.
+ *   nl_mc_count: n_verts[v] / n_tris[v] = vertices (lattice edges whose end values change sign) and triangles of voxel v; both 0 for a voxel the reference
+ *                skips (min > 0 or max < 0, :158-159).
+ *   nl_mc_emit:  vert_off / tri_off = exclusive scans of those counts (nl_exclusive_scan_i32); verts[total][3] = ((lattice position / (res - 1)) - 0.5) *
+ *                voxel_size + centres[v] (:162-164; centres row stride `centre_stride` floats), faces[total][3] = indices into verts, voxel after voxel like
+ *                the reference's concatenation.  Vertices are shared inside a voxel (one per crossed lattice edge, in (axis, ix, iy, iz) order), faces come
+ *                cell by cell from the 256-case table csrc/nl_mc_table.h with normals towards the positive values.
+ * The vertex SET is that of any linear-interpolation marching cubes; the triangulation of a cell is derived from the cube's geometry
+ * (scripts/gen_mc_table.py), NOT taken from scikit-image (absent here): vertex / face order and the choice on ambiguous faces are this library's own. */
+int nl_mc_count(const float* sdf, int n_vox, int res, int* n_verts, int* n_tris, void* stream);
+int nl_mc_emit(const float* sdf, const float* centres, int centre_stride, int n_vox, int res, float voxel_size, const int* vert_off, const int* tri_off,
+               float* verts, int* faces, void* stream);
+
 /* Decoder forward (src/variations/lidar.py:109-131) + Criterion gradient (src/criterion.py:59-100) +
  * decoder backward (autograd of render_helpers.py:422).  params = decoder block, W2T = decoder weight workspace (nl_decoder_transpose_w2).
  * Outputs sdf[P], dsdf[P], dX[P,16]; with train_decoder: per-workgroup weight-gradient slabs

@@ -131,6 +131,8 @@ _SIGS = {
     "nl_gather_trilinear": ([_P] * 7 + [_I] + [_P] * 3 + [_F, _P, _I, _P], _I),
     "nl_gather_points": ([_I] + [_P] * 5 + [_F, _P, _P], _I),
     "nl_gather_grid": ([_I, _I, _I, _P, _P, _P, _P, _F, _P, _P], _I),
+    "nl_mc_count": ([_P, _I, _I, _P, _P, _P], _I),
+    "nl_mc_emit": ([_P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P], _I),
     "nl_decoder_fwd_bwd": ([_P] * 13 + [_I, _I, _P, _P], _I),
     "nl_decoder_wgrad2": ([_P] * 6 + [_I, _P], _I),
     "nl_decoder_forward": ([_P, _P, _P, _I, _P, _I, _P], _I),

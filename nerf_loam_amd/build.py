@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libnerfloam_hip.so")
-SOURCES = ["nl_geometry.hip", "nl_decoder.hip", "nl_field.hip", "nl_optim.hip", "nl_select.hip", "nl_dist.hip", "nl_criterion.hip", "nl_octree.cpp", "nl_iteration.cpp", "nl_exchange.cpp"]
+SOURCES = ["nl_geometry.hip", "nl_decoder.hip", "nl_field.hip", "nl_optim.hip", "nl_select.hip", "nl_dist.hip", "nl_criterion.hip", "nl_mesh.hip", "nl_octree.cpp", "nl_iteration.cpp", "nl_exchange.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-Wno-unused-result"]
 

@@ -3,7 +3,7 @@
 Mirror of /root/reference/src/mapping.py for what SURVEY.md 8 puts in scope: `create_voxels`
 (:283-291), `get_embeddings` (:293-317), `update_grid_features` (:319-339), `do_mapping` ->
 `bundle_adjust_frames` (:172-202), `select_optimize_targets` (:205-225), `insert_keyframe` (:262-281).
-The process loop (spin), meshing, logging and the share-data plumbing stay with the reference.
+`extract_mesh` (:354-378, round 6).  The process loop (spin), logging and the share-data plumbing stay with the reference.
 
 MI355X-first differences (same results per vertex id):
   * the sparse octree is the native host octree (svo.Octree, flat arrays, per-instance counter);
@@ -144,6 +144,24 @@ class Mapping:
         }
         self.map_states["_device"] = MapDevice.from_tensors(nb["centres"][:n], nb["structure"][:n], nb["vertex_idx"][:n], nb["id2row"][:n],
                                                             self.dynamic_embeddings, self.voxel_size, self.device)
+
+    # ------------------------------------------------------------------ mesh extraction (cold path)
+    @torch.no_grad()
+    def extract_mesh(self, res=8, clean_mesh=False):
+        """reference mapping.py:354-378: the surface voxels (nodes whose eight vertex ids are all set), their dense SDF grids and the per-voxel marching
+        cubes - grid and extraction on the device (mesh_util.MeshExtractor); mesh vertices carry the reference's offset of -2000"""
+        from .mesh_util import MeshExtractor
+        if getattr(self, "mesher", None) is None:
+            self.mesher = MeshExtractor(self.args)
+        self.decoder.eval()
+        ms = self.map_states
+        surface = ~ms["voxel_vertex_idx"].eq(-1).any(-1)
+        # mapping.py:361: centres = (voxels[:, :3] + voxels[:, -1:] / 2) * voxel_size - what update_grid_features keeps in voxel_center_xyz
+        states = {"voxel_vertex_idx": ms["voxel_vertex_idx"][surface].contiguous(), "voxel_center_xyz": ms["voxel_center_xyz"][surface].contiguous(),
+                  "voxel_structure": ms["voxel_structure"][surface].contiguous(), "voxel_vertex_emb": self.dynamic_embeddings,
+                  "voxel_id2embedding_id": ms["voxel_id2embedding_id"]}
+        return self.mesher.create_mesh(self.decoder, states, self.voxel_size, states["voxel_center_xyz"], frame_poses=None, depth_maps=None,
+                                       clean_mseh=clean_mesh, require_color=False, offset=-2000, res=res)
 
     # ------------------------------------------------------------------ optimisation call site
     def do_mapping(self, share_data=None, tracked_frame=None, update_pose=True, update_decoder=True, selection_method="current"):

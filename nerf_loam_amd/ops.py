@@ -116,6 +116,30 @@ def gather_grid(n_vox, vox0, res, lin, centres, vertex_rows, emb, voxel_size, X)
                                  stream_ptr()), "nl_gather_grid")
 
 
+def marching_cubes(sdf, centres, voxel_size):
+    """MeshExtractor.marching_cubes on the device (include/nerfloam_hip.h nl_mc_count / nl_mc_emit): sdf [n, res, res, res] fp32, centres [n, >= 3] fp32
+    -> (verts [N, 3] fp32, faces [M, 3] int32) device tensors, voxel after voxel.  One host read-back (the two totals) sizes the outputs."""
+    _chk(sdf, F32, "sdf"); _chk(centres, F32, "centres")
+    n, res = int(sdf.shape[0]), int(sdf.shape[1])
+    if sdf.dim() != 4 or sdf.shape[2] != res or sdf.shape[3] != res or centres.dim() != 2 or centres.shape[0] != n or centres.shape[1] < 3:
+        raise L.NerfLoamHipError(f"marching_cubes: sdf {tuple(sdf.shape)} must be [n, res, res, res] and centres {tuple(centres.shape)} [n, >= 3]")
+    dev = sdf.device
+    counts = torch.zeros(2, n + 1, dtype=I32, device=dev)                 # [0]: vertices, [1]: triangles; the last column receives the totals
+    offs = torch.empty(2, max(n, 1), dtype=I32, device=dev)
+    ws = torch.empty(max(1, (n + 1023) // 1024) + 8, dtype=I32, device=dev)
+    if n > 0:
+        check(L.lib().nl_mc_count(ptr(sdf), n, res, ptr(counts[0]), ptr(counts[1]), stream_ptr()), "nl_mc_count")
+        for r in range(2):
+            exclusive_scan(counts[r], offs[r], n, 0, counts[r, n:], ws)
+    nv, nt = (int(x) for x in counts[:, n].tolist())
+    verts = torch.empty(nv, 3, dtype=F32, device=dev)
+    faces = torch.empty(nt, 3, dtype=I32, device=dev)
+    if nv > 0:
+        check(L.lib().nl_mc_emit(ptr(sdf), ptr(centres), int(centres.stride(0)), n, res, float(voxel_size), ptr(offs[0]), ptr(offs[1]), ptr(verts), ptr(faces),
+                                 stream_ptr()), "nl_mc_emit")
+    return verts, faces
+
+
 def decoder_fwd_bwd(loss_scalars, X, params, W2T, s_ray, s_depth, cos_gt, gt_dist, sdf, dsdf, dX, partials, relu2_mask, nslabs,
                     train_decoder, counters, modes=0):
     """modes: _lib.kernel_modes(gemm_mode, wgrad2_mode) - the kernel selection of this call (0: the process defaults); the
