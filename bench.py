@@ -885,6 +885,24 @@ def get_scores_bench(w, device, res=8, reps=5):
     g_host = RH.get_scores(dec, states, w["voxel"], bits=res)
     dt_host = time.perf_counter() - t0
     n_pts = len(surf) * res ** 3
+    # marching cubes on the grid (csrc/nl_mesh.hip; reference mesh_util.py:145-169: skimage on the CPU per voxel).  A random-init decoder's field does not change
+    # sign inside the voxels, so the zero level is moved to the grid's median - the extraction's work depends on how many voxels the surface crosses, not on where
+    from nerf_loam_amd import ops
+    gs = (g.view(-1, res, res, res) - g.median()).contiguous()
+    cdev = states["voxel_center_xyz"].to(device)
+    mv, mf = ops.marching_cubes(gs, cdev, w["voxel"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        mv, mf = ops.marching_cubes(gs, cdev, w["voxel"])
+    torch.cuda.synchronize()
+    dt_mc = (time.perf_counter() - t0) / reps
+    mc_bytes = 2 * n_pts * 4 + len(surf) * (12 + 4 * 4) + mv.numel() * 4 + mf.numel() * 4        # the grid read by both passes, counts / offsets, the mesh written once
+    mc = {"ms_per_call": dt_mc * 1e3, "vertices": int(mv.shape[0]), "triangles": int(mf.shape[0]), "voxels_per_s": len(surf) / dt_mc, "triangles_per_s": mf.shape[0] / dt_mc,
+          "roofline": {"bound": "hbm", "achieved": mc_bytes / dt_mc / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mc_bytes / dt_mc / 1e9 / HBM_PEAK_GBS,
+                       "algorithmic_bytes": int(mc_bytes)},
+          "note": "count pass + two prefix scans + one read-back of the totals + emit pass (host-timed whole call, mesh left on the device); zero level at the grid's median; "
+                  "tests/test_gpu_mesh.py: bit-exact against oracle/mc_oracle.py (triangulation unpinned to scikit-image, which is absent here - see the oracle's header)"}
     gm = _lib.lib().nl_decoder_get_gemm_mode()
     fwd_alg = FLOPS_PER_SAMPLE_DECODER_FROZEN / 2                           # forward only: 2 (16 x 256 + 256 x 256 + 256)
     ex16 = {4: 3, 5: 4}.get(gm, 8) * G + (4 if gm >= 4 else 9) * L1
@@ -892,7 +910,7 @@ def get_scores_bench(w, device, res=8, reps=5):
     return {"voxels": int(len(surf)), "res": res, "points": int(n_pts), "ms_per_call_device_resident_grid": dt_dev * 1e3, "ms_per_call_grid_on_host": dt_host * 1e3,
             "voxels_per_s": len(surf) / dt_dev, "points_per_s": n_pts / dt_dev, "algorithmic_tflops": n_pts * fwd_alg / dt_dev / 1e12,
             "matrix_pipe_bound_ms": bound_s * 1e3, "matrix_pipe_frac_of_the_call": bound_s / dt_dev,
-            "hbm_bytes_algorithmic": int(n_pts * (64 * 2 + 4) + len(surf) * (12 + 32)), "sdf_range": [float(g_host.min()), float(g_host.max())],
+            "hbm_bytes_algorithmic": int(n_pts * (64 * 2 + 4) + len(surf) * (12 + 32)), "sdf_range": [float(g_host.min()), float(g_host.max())], "marching_cubes": mc,
             "note": "whole call: map tensors -> device (cached per map), per chunk of <= 16.8 M points one nl_gather_grid + one nl_decoder_forward launch, one device-to-host copy "
                     "of the grid (ms_per_call_grid_on_host; the reference copies every 10 000 voxels and synchronises on each); tests/test_gpu_api_mirror.py holds the call "
                     "against the reference's own get_scores output (tests/golden/scores_res4.npz) at 5e-6"}
