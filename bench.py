@@ -1009,6 +1009,17 @@ def main():
             step()
         torch.cuda.synchronize()
         return
+    # per-kernel events for the roofline object: recorded by nl_iteration itself on the launch stream, in front of the decoder kernel, between it
+    # and the dW2 kernel and behind dW2 (NlIterDesc.ev_decoder_begin / ev_decoder_end / ev_wgrad2_end; an event is recorded once here so that its handle exists).
+    # Created BEFORE the warm-up steps: nothing but the barrier stands between the W warm-up steps and the K timed ones (creating 3 K events there left the
+    # device idle for a few ms in front of the timed region)
+    ev = []
+    for _ in range(args.steps):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        for e in (e0, e1, e2):
+            e.record()
+        ev.append({"decoder": (e0, e1), "wgrad2": (e1, e2)})
+    barrier()
     for _ in range(max(args.warmup, 2) if shard else args.warmup):   # (sharded: the first iteration sizes the row exchange of the call)
         step()
     barrier()
@@ -1026,15 +1037,6 @@ def main():
             graph[0] = None
             graph_note = "eager launches (hipGraph capture failed: " + repr(e)[:160] + ")"
             torch.cuda.synchronize()
-    # per-kernel events for the roofline object: recorded by nl_iteration itself on the launch stream, in front of the decoder kernel, between it
-    # and the dW2 kernel and behind dW2 (NlIterDesc.ev_decoder_begin / ev_decoder_end / ev_wgrad2_end; an event is recorded once here so that its handle exists)
-    ev = []
-    for _ in range(args.steps):
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        for e in (e0, e1, e2):
-            e.record()
-        ev.append({"decoder": (e0, e1), "wgrad2": (e1, e2)})
-    barrier()
     with no_gc():
         t0 = time.perf_counter()
         for k in range(args.steps):
