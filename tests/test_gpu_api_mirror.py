@@ -71,6 +71,19 @@ def test_mapping_then_tracking_like_the_reference_loop():
     assert not torch.equal(w_before, mapper.decoder.pts_linears[1].weight.detach())
     assert share.decoder is mapper.decoder and share.states["voxel_vertex_emb"] is mapper.dynamic_embeddings
 
+    # mesh extraction (reference mapping.py:354-378 -> mesh_util.py:80-169): dense SDF grids of the surface voxels + marching cubes, both on the device
+    mesh = mapper.extract_mesh(res=8, clean_mesh=False)
+    mv, mt = np.asarray(mesh.vertices), np.asarray(mesh.triangles)
+    assert len(mt) > 1000 and mt.min() == 0 and mt.max() == len(mv) - 1 and mv.dtype == np.float32
+    mv = mv + np.float32(2000)                                          # (create_mesh shifts the vertices by the reference's offset of -2000)
+    from scipy.spatial import cKDTree
+    centres = mapper.map_states["voxel_center_xyz"][~mapper.map_states["voxel_vertex_idx"].eq(-1).any(-1)].cpu().numpy()
+    dc, _ = cKDTree(centres).query(mv)
+    assert dc.max() <= 0.5 * 0.2 * np.sqrt(3) + 1e-4                    # every vertex lies in a surface voxel
+    dp, _ = cKDTree(pts).query(mv - np.float32(2000))                  # (the map lives at the frames' +2000 m offset, lidarFrame.py:18: the mesh's offset undoes it)
+    assert np.median(dp) < 0.15, float(np.median(dp))                   # and the zero level the map has learnt runs along the scanned surface
+    mapper.decoder.train()
+
     # tracking: perturb the pose of a second frame looking at the same scene, refine it
     tracker = Tracking(args)
     tracker.last_frame = f0
