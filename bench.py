@@ -1126,6 +1126,8 @@ def main():
         kname = ("k_decoder2" if split else "k_decoder") + ("<train>" if train_dec else "<frozen>")
         rf = roofline_entry(kname, "decoder", dec_ms, P_local, gm, wm, train_dec)
         rf["workgroups"] = "two independent 4-wave workgroups per CU (k_decoder2)" if split else "one 8-wave workgroup per CU (k_decoder)"
+        rf["clock_note"] = ("`peak` prices the matrix pipes at the part's 2.4 GHz; under this kernel the chip sits at its power cap and holds ~1.9-2.0 GHz (rocm-smi: 1330 W of 1400 W, "
+                            "profiles/r06_power_probe.txt), where the pipes are busy 57.5 % of the SIMD cycles (profiles/r06_y_pmc_summary.json)")
         rf["frac_of_dense_16bit_peak"] = rf["achieved"] / PEAK_BF16_MFMA_TFLOPS
         kfull = (("k_decoder2<true, %d" if train_dec else "k_decoder2<false, %d") % {4: 3, 5: 4}.get(gm, 3) if split else
                  ("k_decoder<true, %s" if train_dec else "k_decoder<false, %s") % ("true" if gm >= 1 else "false"))
