@@ -861,6 +861,60 @@ def pose_refine_bench(w, device, steps=200):
     return out
 
 
+def frame_loop_bench(device, n_frames=6):
+    """What a FRAME costs through the mirrored call sites (reference src/mapping.py:112-170, src/tracking.py:92-147) at the maicity settings: a full
+    64 x 2048 scan per frame (the synthetic scene seen from a standing sensor, fresh range noise per frame); per frame `Tracking.do_tracking` (20 iterations x 2048 rays, pose only), `Mapping.create_voxels`
+    (host octree insert + incremental export + device update) and `Mapping.do_mapping` (20 iterations x 2048 rays: embeddings + decoder + pose).  Medians over the
+    frames after the first two (the first tracked frame runs 5 x the iterations, the first insert builds the whole tree)."""
+    import queue
+    from argparse import Namespace
+    from nerf_loam_amd import synthetic as S
+    from nerf_loam_amd.lidar_frame import LidarFrame
+    from nerf_loam_amd.mapping import Mapping
+    from nerf_loam_amd.tracking import Tracking
+    args = Namespace(criteria=dict(sdf_weight=10000.0, fs_weight=1, eiko_weight=0.1, sdf_truncation=0.30), data_specs=dict(max_depth=50.0, min_depth=1.5),
+                     decoder_specs=dict(depth=2, width=256, in_dim=16, skips=[], embedder="none", multires=0),
+                     tracker_specs=dict(N_rays=2048, learning_rate=0.005, step_size=0.2, max_voxel_hit=20, num_iterations=20),
+                     mapper_specs=dict(N_rays_each=2048, use_local_coord=False, voxel_size=0.2, step_size=0.5, window_size=4, num_iterations=20, max_voxel_hit=20,
+                                       final_iter=True, mesh_res=8, learning_rate_emb=0.03, learning_rate_decorder=0.005, learning_rate_pose=0.001, freeze_frame=20,
+                                       keyframe_gap=8, remove_back=False, key_distance=12),
+                     debug_args=dict(verbose=False, mesh_freq=100))
+    torch.manual_seed(777)
+    mapper, tracker = Mapping(args), Tracking(args)
+    share = Namespace(decoder=None, states=None)
+    kf = queue.Queue()
+    t_track, t_vox, t_map, nodes = [], [], [], []
+
+    def clock(fn):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize()
+        return r, (time.perf_counter() - t0) * 1e3
+
+    last = None
+    for i in range(n_frames):
+        pts, cos = S.synthetic_scan(seed=777 + i, range_noise=0.01)
+        fr = LidarFrame(i, torch.from_numpy(pts), torch.from_numpy(cos), np.eye(4))
+        if i == 0:
+            _, tv = clock(lambda: mapper.create_voxels(fr))
+            _, tm = clock(lambda: mapper.do_mapping(share, fr, selection_method="current"))
+            tracker.last_frame = fr
+        else:
+            _, tt = clock(lambda: tracker.do_tracking(share, fr, kf))
+            _, tv = clock(lambda: mapper.create_voxels(fr))
+            _, tm = clock(lambda: mapper.do_mapping(share, fr, selection_method="current"))
+            t_track.append(tt)
+        t_vox.append(tv); t_map.append(tm); nodes.append(int(mapper.svo.count_nodes()))
+        last = fr
+    med = lambda a: float(np.median(a[2:])) if len(a) > 2 else float(np.median(a))
+    frame_ms = med(t_track) + med(t_vox) + med(t_map)
+    err = float(np.abs(last.pose.data.detach().cpu().numpy()[:3] - 2000.0).max())
+    return {"frames": n_frames, "points_per_frame": 131072, "ms_per_frame": frame_ms, "frames_per_s": 1e3 / frame_ms,
+            "track_ms": med(t_track), "create_voxels_ms": med(t_vox), "mapping_ms": med(t_map), "first_frame_create_voxels_ms": t_vox[0], "octree_nodes": nodes,
+            "tracked_translation_error_m": err,
+            "note": "mirrored Mapping / Tracking call sites at the maicity settings (20 + 20 iterations x 2048 rays per frame), a standing sensor with fresh 1 cm range noise per scan (the tracked pose should stay put: tracked_translation_error_m); create_voxels = host C++ octree insert "
+                    "of all 131 072 returns + incremental export + device-side growth of the map tensors (no re-upload of the tree or the embedding table); the reference's process loop, "
+                    "logging and queues are not part of this number"}
+
+
 def get_scores_bench(w, device, res=8, reps=5):
     """f3: the mesher's dense SDF grid - render_helpers.get_scores, reference render_helpers.py:96-153 - over the SURFACE voxels of the bench map:
     res^3 points per voxel, gather (points generated in the kernel) + forward-only decoder on the matrix cores.  voxels / s, points / s and the forward kernel's
@@ -1194,6 +1248,10 @@ def main():
                 out["api_path"] = api_path_bench(w, device)                                #  profiled command's per-kernel averages)
             if not args.no_api_path:
                 out["get_scores"] = get_scores_bench(w, device)
+                try:
+                    out["frame_loop"] = frame_loop_bench(device)
+                except Exception as e:                                   # noqa: BLE001 - informational leg: report, do not fail the bench
+                    out["frame_loop"] = {"error": repr(e)[:300]}
             if not args.no_large_map:
                 out["large_map"] = large_map_bench(w, device)
             if not args.no_parity:
