@@ -561,6 +561,11 @@ int nl_octree_export_device_layout(void* h, float voxel_size, float* centres, in
 /* incremental export: rows, in the layout above, of the nodes that changed since the previous call */
 long long nl_octree_delta_count(void* h);
 int nl_octree_export_delta(void* h, float voxel_size, int* ids, float* centres, int* structure, int* vertex_idx);
+/* the children-block traversal layout nl_ray_intersect* walks (blk_ids [B][8] int, blk_hdr [B][2] int: csrc/nl_geometry.hip), packed straight from the tree:
+ * breadth-first block numbering, FEATURE leaves hidden like in the export's children column, the single-child chain under the root in the pseudo block's
+ * spare slots - equal, word for word, to what the Python host layer derives from the exported rows (pipeline.pack_children_blocks), without its ~200 launches
+ * per map update.  Returns the number of blocks B; -(B) if capacity < B; with NULL buffers: B (count only). */
+long long nl_octree_pack_blocks(void* h, int* blk_ids, int* blk_hdr, long long capacity);
 
 #ifdef __cplusplus
 }

@@ -205,6 +205,7 @@ _SIGS = {
     "nl_octree_export_device_layout": ([_P, _F, _P, _P, _P], _I),
     "nl_octree_delta_count": ([_P], _LL),
     "nl_octree_export_delta": ([_P, _F, _P, _P, _P, _P], _I),
+    "nl_octree_pack_blocks": ([_P, _P, _P, _LL], _LL),
     "nl_mfma_selftest": ([_P] * 7, _I),
     "nl_decoder_set_debug_buffer": ([_P], _I),
 }

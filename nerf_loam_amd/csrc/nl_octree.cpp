@@ -380,4 +380,77 @@ int nl_octree_export_delta(void* h, float voxel_size, int* ids, float* centres, 
     return 0;
 }
 
+// Children-block traversal layout of nl_ray_intersect straight from the tree (what nerf_loam_amd/pipeline.py pack_children_blocks derives from the
+// exported `structure` rows with ~200 torch launches per map update): block 0 = pseudo block with the root in slot 0, every node with a LISTED child
+// (present and not a FEATURE leaf: the children column of the export) owns one block, blocks are numbered breadth-first so that the children blocks of
+// a block are consecutive in octant order.  blk_ids[B][8] = child node ids (-1 = none), blk_hdr[B][2] = (first child block or -1, exist mask |
+// owns-a-block mask << 8); the pseudo block's slots 1..7 carry the single-child chain under the root (length, octants packed 3 bits each in two
+// words, the block the work-list starts with, its lattice position).  Returns the number of blocks, or -(blocks needed) if `capacity` is too small
+// (nothing written beyond capacity), 0 on a bad handle.  blk_ids / blk_hdr == NULL: count only.
+long long nl_octree_pack_blocks(void* h, int* blk_ids, int* blk_hdr, long long capacity)
+{
+    if (!h) return 0;
+    const Octree& t = *(Octree*)h;
+    auto listed = [&](int c) { return c >= 0 && t.nodes[c].type != T_FEATURE; };
+    auto interior = [&](int k) { const Node& nd = t.nodes[k]; for (int i = 0; i < 8; ++i) if (listed(nd.child[i])) return true; return false; };
+    const bool has_root = interior(0);
+    const bool write = blk_ids && blk_hdr;
+    std::vector<int> frontier, next;
+    if (has_root) frontier.push_back(0);
+    long long next_index = 1;
+    if (write && capacity >= 1) {
+        for (int i = 0; i < 8; ++i) blk_ids[i] = -1;
+        blk_ids[0] = 0;
+        blk_hdr[0] = has_root ? 1 : -1; blk_hdr[1] = has_root ? 0x101 : 1;
+    }
+    while (!frontier.empty()) {
+        const long long F = (long long)frontier.size();
+        long long running = next_index + F;                              // the blocks of this level come first, then their children's
+        next.clear();
+        for (long long q = 0; q < F; ++q) {
+            const Node& nd = t.nodes[frontier[(size_t)q]];
+            const long long b = next_index + q;
+            int exist = 0, owns = 0, cnt = 0, ids[8];
+            for (int i = 0; i < 8; ++i) {
+                const int c = nd.child[i];
+                ids[i] = -1;
+                if (listed(c)) {
+                    exist |= 1 << i; ids[i] = c;
+                    if (interior(c)) { owns |= 1 << i; ++cnt; next.push_back(c); }
+                }
+            }
+            if (write && b < capacity) {
+                for (int i = 0; i < 8; ++i) blk_ids[8 * b + i] = ids[i];
+                blk_hdr[2 * b] = cnt > 0 ? (int)running : -1;
+                blk_hdr[2 * b + 1] = exist | (owns << 8);
+            }
+            running += cnt;
+        }
+        next_index += F;
+        frontier.swap(next);
+    }
+    const long long B = next_index;
+    if (write && B > capacity) return -B;
+    if (write && has_root) {
+        unsigned cs = t.nodes[0].side >> 1;
+        long long b = 1;
+        int pos[3] = {0, 0, 0}, n_oct = 0;
+        unsigned long long packed = 0;
+        while (cs > 1 && b < B && b < 40 && n_oct < 20) {
+            const int has = (blk_hdr[2 * b + 1] >> 8) & 255, exist = blk_hdr[2 * b + 1] & 255;
+            if (has == 0 || (has & (has - 1)) || exist != has) break;   // no child block, several, or a child without a block of its own
+            const int u = 31 - __builtin_clz((unsigned)has);
+            packed |= (unsigned long long)u << (3 * n_oct);
+            ++n_oct;
+            if (u & 1) pos[0] += (int)cs;
+            if (u & 2) pos[1] += (int)cs;
+            if (u & 4) pos[2] += (int)cs;
+            b = blk_hdr[2 * b]; cs >>= 1;
+        }
+        blk_ids[1] = n_oct; blk_ids[2] = (int)(packed & 0x3FFFFFFFULL); blk_ids[3] = (int)(packed >> 30); blk_ids[4] = (int)b;
+        blk_ids[5] = pos[0]; blk_ids[6] = pos[1]; blk_ids[7] = pos[2];
+    }
+    return B;
+}
+
 }  // extern "C"

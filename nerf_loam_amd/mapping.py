@@ -143,7 +143,7 @@ class Mapping:
             "voxel_id2embedding_id": nb["id2row"][:n],
         }
         self.map_states["_device"] = MapDevice.from_tensors(nb["centres"][:n], nb["structure"][:n], nb["vertex_idx"][:n], nb["id2row"][:n],
-                                                            self.dynamic_embeddings, self.voxel_size, self.device)
+                                                            self.dynamic_embeddings, self.voxel_size, self.device, blocks=self.svo.pack_blocks())
 
     # ------------------------------------------------------------------ mesh extraction (cold path)
     @torch.no_grad()

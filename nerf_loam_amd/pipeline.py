@@ -148,7 +148,7 @@ class MapDevice:
         return int(L.lib().nl_isect_lanes_for(int(n_rays), int(blk.shape[0]) if blk is not None else 0))     # (the one table: csrc/nl_common.h)
 
     @classmethod
-    def from_tensors(cls, centres, structure, vertex_idx, id2row, emb_bf16, voxel_size, device="cuda", traversal=True):
+    def from_tensors(cls, centres, structure, vertex_idx, id2row, emb_bf16, voxel_size, device="cuda", traversal=True, blocks=None):
         """Build from the reference's `map_states` tensors.  `emb_bf16` is the caller's bfloat16 CUDA parameter:
         it is ALIASED (viewed as int16 bit patterns), so the kernels update it in place like the reference's
         optimiser does.  `id2row` is the node-id -> embedding-row table (any [>=n] or [>=n,1] int tensor)."""
@@ -169,7 +169,11 @@ class MapDevice:
             raise L.NerfLoamHipError("voxel_vertex_emb must be a CUDA bfloat16 tensor")
         self.emb = emb_bf16.detach().view(torch.int16)
         if traversal:                                      # per-voxel subsets (mesh-time queries) carry no usable tree
-            self.blk_ids, self.blk_hdr = pack_children_blocks(self.centres, self.structure)
+            if blocks is not None:                         # packed by the octree itself (svo.Octree.pack_blocks: one C call instead of ~200 launches)
+                self.blk_ids = torch.as_tensor(blocks[0]).to(dev, torch.int32).contiguous()
+                self.blk_hdr = torch.as_tensor(blocks[1]).to(dev, torch.int32).contiguous()
+            else:
+                self.blk_ids, self.blk_hdr = pack_children_blocks(self.centres, self.structure)
             self.root_side = int(self.structure[0, 8])
         self.n_nodes, self.n_rows = n, self.emb.shape[0]
         return self

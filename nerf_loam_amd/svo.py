@@ -165,6 +165,17 @@ class Octree:
                 raise RuntimeError("nl_octree_export_delta failed")
         return ids, c, s, f
 
+    def pack_blocks(self):
+        """the children-block traversal layout of the ray-intersect kernels, packed by the octree itself (nl_octree_pack_blocks): blk_ids i32[B,8],
+        blk_hdr i32[B,2] - what pipeline.pack_children_blocks derives from the exported structure rows"""
+        self._need()
+        P = ctypes.c_void_p
+        B = int(L.lib().nl_octree_pack_blocks(self._h, None, None, 0))
+        ids = np.empty((B, 8), np.int32); hdr = np.empty((B, 2), np.int32)
+        if int(L.lib().nl_octree_pack_blocks(self._h, ids.ctypes.data_as(P), hdr.ctypes.data_as(P), B)) != B:
+            raise RuntimeError("nl_octree_pack_blocks failed")
+        return ids, hdr
+
     # pickle protocol of bindings.cpp:23-31: (size, feat_dim, voxel_size, all_pts), rebuilt by replay
     def __getstate__(self):
         return (self.size_, self.feat_dim_, self.voxel_size_, self.all_pts)

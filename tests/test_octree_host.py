@@ -283,3 +283,43 @@ def test_children_block_layout_describes_the_tree_and_reproduces_the_oracle_hits
         assert n == len(hits)
         assert [h[0] for h in hits] == oi[q, :n].tolist()
         assert np.array_equal(np.array([h[1] for h in hits], np.float32), o0[q, :n]) and np.array_equal(np.array([h[2] for h in hits], np.float32), o1[q, :n])
+
+
+def test_blocks_packed_by_the_octree_equal_the_host_layer_packing():
+    """nl_octree_pack_blocks (C++, straight from the tree) == pipeline.pack_children_blocks on the exported structure rows, word for word: an empty tree, one
+    voxel, a tree that branches at the root, a scan, and a map grown over six batches (FEATURE -> SURFACE upgrades, parents gaining children)"""
+    from nerf_loam_amd.pipeline import pack_children_blocks
+
+    def check(oc):
+        c, s, f = oc.export_device_layout()
+        want_ids, want_hdr = pack_children_blocks(torch.from_numpy(c), torch.from_numpy(s))
+        ids, hdr = oc.pack_blocks()
+        assert ids.dtype == np.int32 and hdr.dtype == np.int32
+        assert np.array_equal(ids, want_ids.numpy()), "blk_ids differ"
+        assert np.array_equal(hdr, want_hdr.numpy()), "blk_hdr differ"
+        return len(ids)
+
+    oc = Octree(); oc.init(256 * 256 * 4, 16, 0.2)
+    assert check(oc) == 1                                           # the pseudo block alone
+    oc.insert(torch.tensor([[10000, 10001, 10002]], dtype=torch.int32))
+    assert check(oc) > 10                                           # a single-child chain down to the voxel's parents
+    oc.insert(torch.tensor([[3, 200000, 7], [250000, 5, 9]], dtype=torch.int32))      # far corners of the lattice: the root branches, no chain
+    check(oc)
+    sc = H.build_oracle_scene(32, 24, 5)
+    oc2 = Octree(); oc2.init(256 * 256 * 4, 16, 0.2)
+    oc2.insert(torch.from_numpy(S.voxel_coords(sc["points"], np.eye(3, dtype=np.float32), S.scan_pose()[:3], 0.2)))
+    check(oc2)
+    rng = np.random.default_rng(5)
+    oc3 = Octree(); oc3.init(256 * 256 * 4, 16, 0.2)
+    base = np.array([10000, 10000, 10000])
+    for batch in range(6):
+        pts = base + rng.integers(-12, 12, size=(300, 3)) + np.array([batch * 5, 0, 0])
+        if batch == 3:
+            pts = np.concatenate([pts, prev + 1])
+        prev = pts
+        oc3.insert(torch.from_numpy(pts.astype(np.int32)))
+        check(oc3)
+    # a small grid (non power-of-two sizes take the root descent every time; 64 is the smallest the reference's tests use)
+    oc4 = Octree(); oc4.init(64, 16, 0.2)
+    oc4.insert(torch.from_numpy(rng.integers(0, 62, size=(200, 3)).astype(np.int32)))
+    check(oc4)
