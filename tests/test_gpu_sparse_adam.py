@@ -143,7 +143,9 @@ def test_begin_call_cost_does_not_depend_on_the_table_size(golden_dir):
     assert bl <= 1.3 * bs + 0.010 and ol <= 1.3 * os_ + 0.010, times
     # what the dense bookkeeping costs at this size (measured: begin_call 0.037 -> 0.054 ms - a 320 MB memset on top of the call's four
     # small launches -, optimiser step 0.012 -> 0.056 ms; both grow linearly with the table: x 5 at a KITTI-scale 1e7 rows)
-    assert bd > bl + 0.004 and od > 3 * ol, times
+    # (the optimiser sweep is the robust half of that statement: 5 x on a quiet box.  The begin_call difference - a 320 MB memset that mostly overlaps the call's
+    #  other launches - is 4-17 us by box and is recorded above, not asserted: a 4 us bar failed two runs in six on shared boxes)
+    assert od > 3 * ol, times
 
 
 @pytest.mark.parametrize("one_call", [False, True])
